@@ -1,0 +1,187 @@
+/*
+ * sgam_hip.h — C ABI of libsgam_hip.so, the MI355X (gfx950) backend of SGAM's per-step
+ * generative-sensing hot path.
+ *
+ * Conventions (SURVEY.md §8b "lower boundary"):
+ *   - extern "C", plain device pointers + sizes, no torch / C++ types;
+ *   - the CALLER owns every buffer (the Python side allocates them with torch);
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
+ *     null stream), never synchronises, never allocates device memory;
+ *   - return 0 on success, a negative SGAM_E* code on a bad argument, or a positive
+ *     hipError_t if the launch itself failed;
+ *   - activations inside the VQGAN are NHWC ("pixel-major") fp32: [B][H][W][C];
+ *     the NCHW <-> NHWC hops at the module boundary are sgam_nchw_to_nhwc / _nhwc_to_nchw.
+ *
+ * Each entry point cites the reference op (file:line under /root/reference) it replaces.
+ */
+#ifndef SGAM_HIP_H
+#define SGAM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGAM_OK 0
+#define SGAM_EINVAL (-1)   /* bad shape / unsupported size */
+#define SGAM_EALIGN (-2)   /* pointer or stride not aligned as required */
+#define SGAM_EWORKSPACE (-3)
+
+/* ABI version of this header; bumped on any signature change. */
+int sgam_abi_version(void);
+/* Human-readable build string ("gfx950 ..."). */
+const char *sgam_build_info(void);
+
+/* ------------------------------------------------------------------------------------------
+ * K1/K2/K3/K6 — convolution as implicit GEMM on the matrix cores (fp32-in/fp32-acc MFMA).
+ * Replaces torch.nn.Conv2d in ResnetBlock/Upsample/Downsample/AttnBlock/VQModel:
+ *   sgam/generative_sensing_module/modules/diffusionmodules/model.py:43-53 (nearest x2 + 3x3),
+ *   :63-75 (pad (0,1,0,1) + 3x3 stride 2), :88-116 (3x3 / 1x1 nin_shortcut), :146-165 (1x1 q,k,v,proj)
+ *   sgam/generative_sensing_module/model.py:54,62,63 (1x1 conv_in, quant_conv, post_quant_conv).
+ *
+ *   out[m][n] = bias[n] + residual[m][n] + sum_{ky,kx,c} X[b][iy][ix][c] * Wp[n][(ky*KW+kx)*Cin + c]
+ *   with m = (b*Ho + oy)*Wo + ox, iy = oy*stride + ky - pad_t, ix = ox*stride + kx - pad_l,
+ *   zero outside the (logical) input; when `upsample2x` != 0 the logical input is the nearest-
+ *   neighbour 2x enlargement of the physical [Hi][Wi] map (X[b][iy>>1][ix>>1]).
+ *
+ *   x        [B][Hi][Wi] pixels, `lda` floats apart, first Cin floats used (Cin % 32 == 0)
+ *   w_packed [N] rows, `ldb` floats apart, K = KH*KW*Cin contiguous (see sgam_pack_conv_weight)
+ *   bias     [N] or NULL;  residual [M] rows `ldr` apart or NULL
+ *   out      [M] rows `ldc` apart; only columns n < n_valid are written
+ *   workspace: sgam_conv2d_workspace_bytes(...) bytes (split-K partial sums), may be NULL if 0.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct sgam_conv_desc {
+    int32_t B, Hi, Wi, Cin;       /* physical input */
+    int32_t Ho, Wo, N;            /* output spatial size and channel count */
+    int32_t KH, KW, stride;
+    int32_t pad_t, pad_l;         /* top/left zero padding (bottom/right implied by Ho/Wo) */
+    int32_t upsample2x;           /* 1: fuse F.interpolate(scale 2, nearest) in front of the conv */
+    int32_t lda, ldb, ldc, ldr;   /* row strides in floats of x, w_packed, out, residual */
+    int32_t n_valid;              /* columns actually stored (<= N) */
+    int32_t bias_per_row;         /* 0: bias[n]; 1: bias[m] (used for the transposed V projection) */
+} sgam_conv_desc;
+
+int64_t sgam_conv2d_workspace_bytes(const sgam_conv_desc *d);
+int sgam_conv2d_nhwc_f32(const sgam_conv_desc *d, const float *x, const float *w_packed,
+                         const float *bias, const float *residual, float *out, void *workspace,
+                         int64_t workspace_bytes, void *stream);
+
+/* [Cout][Cin][KH][KW] (torch Conv2d.weight) -> [Cout_pad][KH*KW][Cin_pad], zero padded. */
+int sgam_pack_conv_weight(const float *w_oihw, float *w_packed, int32_t Cout, int32_t Cin, int32_t KH,
+                          int32_t KW, int32_t Cout_pad, int32_t Cin_pad, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K4 — GroupNorm(32 groups, eps, affine) with optional fused swish, NHWC.
+ * Replaces Normalize + nonlinearity: diffusionmodules/model.py:29-35, used at :119-127, :170,
+ * :429-430, :536-537.  Biased variance, fp32 data, fp64 cross-thread accumulation.
+ *   x,y [B][HW][C]; gamma,beta [C]; C % 128 == 0 (4 channels per lane, groups never straddle a lane)
+ *   workspace: sgam_groupnorm_workspace_bytes(B, HW, C).
+ * ------------------------------------------------------------------------------------------ */
+int64_t sgam_groupnorm_workspace_bytes(int32_t B, int32_t HW, int32_t C);
+int sgam_groupnorm_nhwc_f32(const float *x, const float *gamma, const float *beta, float *y, int32_t B,
+                            int32_t HW, int32_t C, int32_t groups, float eps, int32_t fuse_swish,
+                            void *workspace, int64_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K5 — row softmax of the attention scores, in place: s[r][:] = softmax(scale * s[r][:]).
+ * Replaces `w_ * c**-0.5` + softmax(dim=2): diffusionmodules/model.py:181-182.
+ * ------------------------------------------------------------------------------------------ */
+int sgam_softmax_rows_f32(float *s, int32_t rows, int32_t cols, int32_t ld, float scale, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K7/K8 — nearest-codeword quantiser.  Replaces VectorQuantizer2.forward
+ * (modules/vqvae/quantize.py:285-307): d = (|z|^2 + |e|^2) - 2 z.e (that expression order, fp32),
+ * arg-min with first-index-of-ties, embedding gather, straight-through value z + (e - z).
+ *   z        [T][D] tokens (NHWC latent), D % 32 == 0
+ *   codebook [n_e][D], n_e % 64 == 0;  e_sq [n_e] = sgam_row_sumsq(codebook)
+ *   dots     [T][n_e] scratch (z . e^T), caller-allocated
+ *   idx_out  [T] int64;  zq_out [T][D] (may be NULL);  dist_out [T][n_e] optional (NULL to skip)
+ *   workspace: sgam_vq_workspace_bytes(T, D, n_e) bytes (split-K partials for small T), may be 0
+ * ------------------------------------------------------------------------------------------ */
+int sgam_row_sumsq_f32(const float *x, float *out, int32_t rows, int32_t cols, void *stream);
+int64_t sgam_vq_workspace_bytes(int32_t T, int32_t D, int32_t n_e);
+int sgam_vq_nearest_f32(const float *z, const float *codebook, const float *e_sq, float *dots,
+                        int64_t *idx_out, float *zq_out, float *dist_out, int32_t T, int32_t D,
+                        int32_t n_e, int32_t straight_through, void *workspace, int64_t workspace_bytes,
+                        void *stream);
+/* pure gather (quantize.py:368, get_codebook_entry :321-335): out[t][:] = codebook[idx[t]][:] */
+int sgam_vq_gather_f32(const float *codebook, const int64_t *idx, float *out, int32_t T, int32_t D,
+                       int32_t n_e, void *stream);
+/* k smallest distances per token (ascending, ties -> lower index first), for the top-k infill
+ * sampler (quantize.py:352-354).  vals [T][k], inds [T][k] int64; k <= 64. */
+int sgam_vq_topk_f32(const float *dist, float *vals, int64_t *inds, int32_t T, int32_t n_e, int32_t k,
+                     void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Layout hops at the nn.Module boundary.
+ * ------------------------------------------------------------------------------------------ */
+int sgam_nchw_to_nhwc_f32(const float *x, float *y, int32_t B, int32_t C, int32_t HW, int32_t ldy,
+                          void *stream); /* y[b][p][c] (row stride ldy >= C; columns >= C untouched) */
+int sgam_nhwc_to_nchw_f32(const float *x, float *y, int32_t B, int32_t C, int32_t HW, int32_t ldx,
+                          void *stream);
+/* VQModel.encode head (model.py:107-113): cat(x, mask) -> 1x1 conv 5->4 -> NHWC with the pixel
+ * stride padded to `ldy` floats (channels 4..ldy-1 zeroed) so the 3x3 conv_in runs on the MFMA path.
+ *   x [B][4][HW] NCHW fp32, mask [B][HW] uint8 (0/1) or NULL (all zero), w [4][5], bias [4]. */
+int sgam_encode_head_f32(const float *x, const uint8_t *mask, const float *w, const float *bias,
+                         float *y, int32_t B, int32_t HW, int32_t ldy, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K9/K10/K12 — forward splat + 3x3 median hole fill + extrapolation mask (+ inverse-depth
+ * normalisation).  Replaces render_projection_from_srcs_fast (sgam/point_rendering/warp.py:193-286,
+ * pixel2cam :28-40, median_blur :306-347) and the depth normalisation of VQModel.get_x
+ * (sgam/generative_sensing_module/model.py:210-229).
+ *
+ * Deterministic "largest linear point index wins" scatter (point p = pixel*N + src), the
+ * semantics of the reference's sequential parallel=False loop (warp.py:246-249).
+ *   src_feats   (B,N) images of 3 channels: element (b,n,c,pix) at
+ *               src_feats[((b*N+n)*HW)*3... ] via strides: feat_cs (channel stride), feat_ps (pixel stride)
+ *               - (B,N,3,H,W) tensors: feat_cs = HW, feat_ps = 1;  (B,N,H,W,3): feat_cs = 1, feat_ps = 3
+ *   src_depths  [B][N][HW];  tgt_K [B][9];  src_Kinv [B*N][9] (inverse source intrinsics);
+ *   T [B*N][16] source->target rigid transforms (row-major 4x4)
+ *   winner      [B][HW] int32 scratch
+ *   depth_range NULL at inference (mask = merge_depth <= 0, warp.py:285) or 2 floats (host pointer)
+ *   dataset_norm 0: none, 1: google_earth, 2: clevr-infinite (model.py:210-229)
+ * Outputs (any may be NULL): merge_depths [B][HW], merge_feats [B][3][HW], extrap [B][HW] uint8,
+ *   x_out [B][4][HW] = cat(merge_feats, normalised inverse depth with holes = -2),
+ *   proj_feats [B][3][HW], proj_depth [B][HW] (pre-fill planes), inb_mask [B][HW][N] uint8,
+ *   pix_xy [B][HW][N][2] int32 (target pixel of every point, valid where inb_mask).
+ * ------------------------------------------------------------------------------------------ */
+int sgam_forward_splat_f32(const float *src_feats, int64_t feat_cs, int64_t feat_ps,
+                           const float *src_depths, const float *tgt_K, const float *src_Kinv,
+                           const float *T, int32_t B, int32_t N, int32_t H, int32_t W,
+                           const float *depth_range, int32_t dataset_norm, int32_t *winner,
+                           float *merge_depths, float *merge_feats, uint8_t *extrap, float *x_out,
+                           float *proj_feats, float *proj_depth, uint8_t *inb_mask, int32_t *pix_xy,
+                           void *stream);
+
+/* K12 standalone (VQModel.get_x, model.py:196-199 + 210-229, when the warped view is supplied by the
+ * caller): compute_mask=1: extrap = depth <= 0, out = normalised inverse depth with holes = -2;
+ * compute_mask=0: out = 2*norm(depth)-1 only (the ground-truth branch x_scaled_inverse_depth). */
+int sgam_depth_normalise_f32(const float *depth, int32_t compute_mask, uint8_t *extrap, float *out,
+                             int32_t dataset_norm, int64_t n, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K11 — target-depth-driven inverse warp with best-source selection.  Replaces
+ * InfiniteSceneGeneration.inverse_warping (sgam/inference_pipeline.py:662-743).
+ *   src_imgs [B][N][3][HW], src_depths [B][N][HW], tgt_depth [B][HW], src_K [B*N][9],
+ *   tgt_Kinv [B][9], T_tgt2src [B*N][16];  warped [B][3][HW];  zbuf [B][HW] optional.
+ * ------------------------------------------------------------------------------------------ */
+int sgam_inverse_warp_f32(const float *src_imgs, const float *src_depths, const float *tgt_depth,
+                          const float *src_K, const float *tgt_Kinv, const float *T_tgt2src, int32_t B,
+                          int32_t N, int32_t H, int32_t W, float *warped, float *zbuf, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Frame feedback codec (inference_pipeline.py:898-911 then :534-537): decoder output (B,4,HW)
+ * in [-1,1] -> RGB quantised to uint8 by truncation and re-expanded with the host-built 256-entry
+ * table lut[u] = float32(u / 127.5 - 1.0), metric depth from the normalised inverse depth.
+ *   rgb_u8 [B][HW][3] (HWC, optional), rgb_f [B][HW][3] (HWC fp32, what prepare_batch_data reloads),
+ *   depth [B][HW].
+ * ------------------------------------------------------------------------------------------ */
+int sgam_frame_feedback_f32(const float *dec, const float *lut256, int32_t dataset_norm, uint8_t *rgb_u8,
+                            float *rgb_f, float *depth, int32_t B, int32_t HW, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGAM_HIP_H */

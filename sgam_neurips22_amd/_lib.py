@@ -1,0 +1,80 @@
+"""ctypes binding of libsgam_hip.so (include/sgam_hip.h).  There is NO fallback: if the library is
+missing or a call fails, the product path raises — results never come from a CPU/torch substitute."""
+import ctypes
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libsgam_hip.so")
+
+c_i32, c_i64, c_f32, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+
+class ConvDesc(ctypes.Structure):
+    """mirror of struct sgam_conv_desc"""
+    _fields_ = [(n, c_i32) for n in (
+        "B", "Hi", "Wi", "Cin", "Ho", "Wo", "N", "KH", "KW", "stride", "pad_t", "pad_l", "upsample2x",
+        "lda", "ldb", "ldc", "ldr", "n_valid", "bias_per_row")]
+
+
+# name -> (restype, argtypes); must list every symbol include/sgam_hip.h declares
+PROTOTYPES = {
+    "sgam_abi_version": (c_i32, []),
+    "sgam_build_info": (ctypes.c_char_p, []),
+    "sgam_conv2d_workspace_bytes": (c_i64, [ctypes.POINTER(ConvDesc)]),
+    "sgam_conv2d_nhwc_f32": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "sgam_pack_conv_weight": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "sgam_groupnorm_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
+    "sgam_groupnorm_nhwc_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp,
+                                        c_i64, c_vp]),
+    "sgam_softmax_rows_f32": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_f32, c_vp]),
+    "sgam_row_sumsq_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "sgam_vq_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
+    "sgam_vq_nearest_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp,
+                                    c_i64, c_vp]),
+    "sgam_vq_gather_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "sgam_vq_topk_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "sgam_nchw_to_nhwc_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "sgam_nhwc_to_nchw_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "sgam_encode_head_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "sgam_forward_splat_f32": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,
+                                       ctypes.POINTER(c_f32), c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                       c_vp, c_vp, c_vp]),
+    "sgam_depth_normalise_f32": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_i32, c_i64, c_vp]),
+    "sgam_inverse_warp_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp,
+                                      c_vp]),
+    "sgam_frame_feedback_f32": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
+}
+
+_ERRORS = {-1: "SGAM_EINVAL (bad shape / unsupported size)", -2: "SGAM_EALIGN (pointer/stride alignment)",
+           -3: "SGAM_EWORKSPACE (workspace missing or too small)"}
+
+
+class SgamHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libsgam_hip.so; raise loudly if it has not been built (python -m sgam_neurips22_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SgamHipError(
+            f"{LIB_PATH} is missing: the HIP backend has not been built. Run "
+            "`python -m sgam_neurips22_amd.build` (needs hipcc). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = _ERRORS.get(rc, f"hipError_t {rc}" if rc > 0 else f"error {rc}")
+        raise SgamHipError(f"{what} failed: {msg}")

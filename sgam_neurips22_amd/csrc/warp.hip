@@ -1,0 +1,355 @@
+// warp.hip — the two conditioning warps of SGAM as exact-semantics gather/scatter kernels.
+//
+//   forward splat : render_projection_from_srcs_fast, sgam/point_rendering/warp.py:193-286
+//   inverse warp  : InfiniteSceneGeneration.inverse_warping, sgam/inference_pipeline.py:662-743
+//
+// These are HBM / latency-bound integer-and-compare kernels (no MFMA): ~(16N+17) bytes per target
+// pixel.  Every float expression is written with explicit round-to-nearest intrinsics in the order the
+// reference's torch-CPU path evaluates it (3-term dot products are fma chains a0*b0 -> fma(a1,b1) ->
+// fma(a2,b2), as oneMKL's sgemm does for 3x3 @ 3xHW; see oracle/warp_oracle.c) so pixel indices,
+// depths and masks are bit-identical to the reference, and this file is built with -ffp-contract=off.
+//
+// The reference's index_put_ scatter is racy (last writer wins); its deterministic meaning is "the
+// LARGEST linear point index p = pixel*N + src wins" (the sequential parallel=False loop).  Here:
+//   pass 1  splat_winner_kernel : one lane per source point -> atomicMax(winner[target pixel], p)
+//           (integer max is order-independent => deterministic by construction)
+//   pass 2  splat_resolve_kernel: 16x16 target tile + 1-pixel halo staged in LDS: each halo cell
+//           re-derives (r,g,b,z) of its winning point; then per pixel 4 exact 3x3 medians
+//           (19-exchange network), the per-channel `== 0` hole merge, the extrapolation mask and the
+//           inverse-depth normalisation of VQModel.get_x (model.py:210-229), fused.
+#include "sgam_common.h"
+
+namespace {
+
+__device__ __forceinline__ float dot3_fma(const float *a, float b0, float b1, float b2) {
+    float acc = __fmul_rn(a[0], b0);
+    acc = __fmaf_rn(a[1], b1, acc);
+    acc = __fmaf_rn(a[2], b2, acc);
+    return acc;
+}
+__device__ __forceinline__ float dot3_plain(const float *a, float b0, float b1, float b2) {
+    return __fadd_rn(__fadd_rn(__fmul_rn(a[0], b0), __fmul_rn(a[1], b1)), __fmul_rn(a[2], b2));
+}
+
+struct Cam {
+    float Kinv[9], T[12], Kt[9];
+};
+
+__device__ __forceinline__ void load_cam(Cam &c, const float *Kinv, const float *T, const float *Kt) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) c.Kinv[i] = Kinv[i];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) c.T[i] = T[i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) c.Kt[i] = Kt[i];
+}
+
+// pixel2cam (warp.py:28-40) then bmm(R, .) + t (warp.py:215): target-camera-frame point.
+__device__ __forceinline__ void to_target_cam(const Cam &c, float j, float i, float depth, float &X, float &Y,
+                                              float &Z) {
+    const float cx = __fmul_rn(dot3_fma(c.Kinv + 0, j, i, 1.0f), depth);
+    const float cy = __fmul_rn(dot3_fma(c.Kinv + 3, j, i, 1.0f), depth);
+    const float cz = __fmul_rn(dot3_fma(c.Kinv + 6, j, i, 1.0f), depth);
+    X = __fadd_rn(dot3_fma(c.T + 0, cx, cy, cz), c.T[3]);
+    Y = __fadd_rn(dot3_fma(c.T + 4, cx, cy, cz), c.T[7]);
+    Z = __fadd_rn(dot3_fma(c.T + 8, cx, cy, cz), c.T[11]);
+}
+
+// (pix2d + 0.5).long() with the bounds mask of warp.py:225-232.  Truncation toward zero; NaN and
+// out-of-range values (INT64_MIN on the reference's x86 path) are out of bounds.
+__device__ __forceinline__ bool project_pixel(const Cam &c, float X, float Y, float Z, int H, int W, int &px, int &py) {
+    const float u = dot3_fma(c.Kt + 0, X, Y, Z);
+    const float v = dot3_fma(c.Kt + 3, X, Y, Z);
+    const float w = dot3_fma(c.Kt + 6, X, Y, Z);
+    const float fx = __fadd_rn(__fdiv_rn(u, w), 0.5f);
+    const float fy = __fadd_rn(__fdiv_rn(v, w), 0.5f);
+    const bool inb = (fx > -1.0f) && (fx < (float)W) && (fy > -1.0f) && (fy < (float)H);
+    if (!inb) return false;
+    px = (int)fx;
+    py = (int)fy;
+    return px >= 0 && px < W && py >= 0 && py < H;
+}
+
+__global__ __launch_bounds__(256) void splat_winner_kernel(const float *__restrict__ src_depths,
+                                                           const float *__restrict__ tgt_K,
+                                                           const float *__restrict__ src_Kinv, const float *__restrict__ T,
+                                                           int N, int H, int W, int *__restrict__ winner,
+                                                           uint8_t *__restrict__ inb_mask, int *__restrict__ pix_xy) {
+    const int b = blockIdx.y;
+    const int HW = H * W;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;  // q = s*HW + pix: consecutive lanes -> consecutive pixels
+    if (q >= HW * N) return;
+    const int s = q / HW;
+    const int pix = q - s * HW;
+    const int bn = b * N + s;
+    Cam c;
+    load_cam(c, src_Kinv + 9 * bn, T + 16 * bn, tgt_K + 9 * b);
+    const int i = pix / W, j = pix - i * W;
+    float X, Y, Z;
+    to_target_cam(c, (float)j, (float)i, src_depths[(int64_t)bn * HW + pix], X, Y, Z);
+    int px = 0, py = 0;
+    const bool inb = project_pixel(c, X, Y, Z, H, W, px, py);
+    const int p = pix * N + s;  // the reference's linear point index (warp.py:217-218)
+    if (inb) atomicMax(&winner[(int64_t)b * HW + py * W + px], p);
+    if (inb_mask) inb_mask[(int64_t)b * HW * N + p] = inb ? 1 : 0;
+    if (pix_xy) {
+        pix_xy[((int64_t)b * HW * N + p) * 2 + 0] = px;
+        pix_xy[((int64_t)b * HW * N + p) * 2 + 1] = py;
+    }
+}
+
+#define SGAM_S2(a, b)        \
+    {                        \
+        if ((a) > (b)) {     \
+            const float t_ = (a); \
+            (a) = (b);       \
+            (b) = t_;        \
+        }                    \
+    }
+// exact lower median of 9 (torch.median -> sorted[4]); NaN propagates.  19-exchange network.
+__device__ __forceinline__ float median9(float *p) {
+    bool nan = false;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) nan |= (p[i] != p[i]);
+    SGAM_S2(p[1], p[2]); SGAM_S2(p[4], p[5]); SGAM_S2(p[7], p[8]);
+    SGAM_S2(p[0], p[1]); SGAM_S2(p[3], p[4]); SGAM_S2(p[6], p[7]);
+    SGAM_S2(p[1], p[2]); SGAM_S2(p[4], p[5]); SGAM_S2(p[7], p[8]);
+    SGAM_S2(p[0], p[3]); SGAM_S2(p[5], p[8]); SGAM_S2(p[4], p[7]);
+    SGAM_S2(p[3], p[6]); SGAM_S2(p[1], p[4]); SGAM_S2(p[2], p[5]);
+    SGAM_S2(p[4], p[7]); SGAM_S2(p[4], p[2]); SGAM_S2(p[6], p[4]);
+    SGAM_S2(p[4], p[2]);
+    return nan ? NAN : p[4];
+}
+
+constexpr int TS = 16;        // target tile edge
+constexpr int TH = TS + 2;    // with halo
+
+__device__ __forceinline__ float normalise_depth(float md, bool hole, int dataset_norm) {
+    float wd;
+    if (dataset_norm == 1) {  // google_earth, model.py:215-219
+        wd = __fdiv_rn(1.0f, __fadd_rn(md, 10.0f));
+        wd = __fdiv_rn(__fsub_rn(wd, (float)(1.0 / 14.765625)), (float)(1.0 / 10.099975586 - 1.0 / 14.765625));
+    } else {  // clevr-infinite, model.py:225-229
+        const float lo = (float)1e-7;
+        const float cl = (md != md) ? md : fmaxf(md, lo);
+        wd = __fdiv_rn(1.0f, cl);
+        wd = __fdiv_rn(__fsub_rn(wd, (float)(1.0 / 16)), (float)(1.0 / 7 - 1.0 / 16));
+    }
+    wd = __fsub_rn(__fmul_rn(2.0f, wd), 1.0f);
+    // warped_depth * ~mask + ones * (-2) * mask
+    const float m = hole ? 1.0f : 0.0f, nm = hole ? 0.0f : 1.0f;
+    return __fadd_rn(__fmul_rn(wd, nm), __fmul_rn(-2.0f, m));
+}
+
+__global__ __launch_bounds__(TS *TS) void splat_resolve_kernel(
+    const float *__restrict__ src_feats, int64_t feat_cs, int64_t feat_ps, const float *__restrict__ src_depths,
+    const float *__restrict__ src_Kinv, const float *__restrict__ T, const int *__restrict__ winner, int N, int H, int W,
+    float r0, float r1, int use_range, int dataset_norm, float *__restrict__ merge_depths,
+    float *__restrict__ merge_feats, uint8_t *__restrict__ extrap, float *__restrict__ x_out,
+    float *__restrict__ proj_feats, float *__restrict__ proj_depth) {
+    __shared__ float tile[4][TH][TH + 1];
+    const int b = blockIdx.z;
+    const int HW = H * W;
+    const int ty0 = blockIdx.y * TS, tx0 = blockIdx.x * TS;
+    for (int h = threadIdx.x; h < TH * TH; h += TS * TS) {
+        const int hy = h / TH, hx = h - hy * TH;
+        const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+        float f0 = 0.f, f1 = 0.f, f2 = 0.f, z = 0.f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            const int wv = winner[(int64_t)b * HW + gy * W + gx];
+            if (wv >= 0) {
+                const int pix = wv / N, s = wv - pix * N;
+                const int bn = b * N + s;
+                const float *fp = src_feats + (int64_t)bn * 3 * HW + (int64_t)pix * feat_ps;
+                f0 = fp[0];
+                f1 = fp[feat_cs];
+                f2 = fp[2 * feat_cs];
+                Cam c;
+                load_cam(c, src_Kinv + 9 * bn, T + 16 * bn, src_Kinv);  // Kt unused here
+                const int i = pix / W, j = pix - i * W;
+                float X, Y;
+                to_target_cam(c, (float)j, (float)i, src_depths[(int64_t)bn * HW + pix], X, Y, z);
+            }
+        }
+        tile[0][hy][hx] = f0;
+        tile[1][hy][hx] = f1;
+        tile[2][hy][hx] = f2;
+        tile[3][hy][hx] = z;
+    }
+    __syncthreads();
+    const int ly = threadIdx.x / TS, lx = threadIdx.x - ly * TS;
+    const int gy = ty0 + ly, gx = tx0 + lx;
+    if (gy >= H || gx >= W) return;
+    const int o = gy * W + gx;
+    float merged[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float v[9];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) v[dy * 3 + dx] = tile[c][ly + dy][lx + dx];
+        const float centre = v[4];
+        const float med = median9(v);
+        // mask * median + (~mask) * plane, in fp32 like warp.py:277-278 (NaN/Inf propagate the same way)
+        const float mk = (centre == 0.0f) ? 1.0f : 0.0f, nmk = (centre == 0.0f) ? 0.0f : 1.0f;
+        merged[c] = __fadd_rn(__fmul_rn(mk, med), __fmul_rn(nmk, centre));
+        if (c < 3) {
+            if (proj_feats) proj_feats[((int64_t)b * 3 + c) * HW + o] = centre;
+        } else if (proj_depth) {
+            proj_depth[(int64_t)b * HW + o] = centre;
+        }
+    }
+    const float md = merged[3];
+    bool hole;
+    if (use_range) {  // training branch, warp.py:280-283
+        const float le = (md <= r1) ? 1.0f : 0.0f, ge = (md >= r0) ? 1.0f : 0.0f;
+        hole = __fsub_rn(1.0f, __fmul_rn(le, ge)) != 0.0f;
+        if (md >= r1) merged[0] = merged[1] = merged[2] = 0.0f;
+    } else {
+        hole = md <= 0.0f;  // warp.py:285
+    }
+    if (merge_depths) merge_depths[(int64_t)b * HW + o] = md;
+    if (extrap) extrap[(int64_t)b * HW + o] = hole ? 1 : 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if (merge_feats) merge_feats[((int64_t)b * 3 + c) * HW + o] = merged[c];
+        if (x_out) x_out[((int64_t)b * 4 + c) * HW + o] = merged[c];
+    }
+    if (x_out) x_out[((int64_t)b * 4 + 3) * HW + o] = normalise_depth(md, hole, dataset_norm);
+}
+
+// ------------------------------------------------------------------------------------------------
+// inverse_warping: one lane per target pixel, sources visited in order with a running z-buffer on
+// |z_reprojected - src_depth(at the TARGET pixel, sic)| (inference_pipeline.py:719-737).
+// grid_sample(nearest, zeros, align_corners=False) as torch's vectorised CPU kernel evaluates it:
+// ix = (x+1)*(W/2) - 0.5, round-half-even.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void inverse_warp_kernel(const float *__restrict__ src_imgs,
+                                                           const float *__restrict__ src_depths,
+                                                           const float *__restrict__ tgt_depth,
+                                                           const float *__restrict__ src_K,
+                                                           const float *__restrict__ tgt_Kinv, const float *__restrict__ T,
+                                                           int N, int H, int W, float *__restrict__ warped,
+                                                           float *__restrict__ zbuf_out) {
+    const int b = blockIdx.y;
+    const int HW = H * W;
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= HW) return;
+    const int i = pix / W, j = pix - i * W;
+    const float *Ki = tgt_Kinv + 9 * b;
+    const float td = tgt_depth[(int64_t)b * HW + pix];
+    const float cx = __fmul_rn(dot3_fma(Ki + 0, (float)j, (float)i, 1.0f), td);
+    const float cy = __fmul_rn(dot3_fma(Ki + 3, (float)j, (float)i, 1.0f), td);
+    const float cz = __fmul_rn(dot3_fma(Ki + 6, (float)j, (float)i, 1.0f), td);
+    float res0 = 0.f, res1 = 0.f, res2 = 0.f, zbuf = 99999.0f;
+    for (int s = 0; s < N; ++s) {
+        const int bn = b * N + s;
+        const float *K = src_K + 9 * bn, *Tm = T + 16 * bn;
+        // proj = K @ T[:3]: 3x3 @ 3x4 goes through torch's small-gemm path (plain mul/add, no fma)
+        float P[12];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) P[r * 4 + c] = dot3_plain(K + 3 * r, Tm[c], Tm[4 + c], Tm[8 + c]);
+        const float r0[3] = {P[0], P[1], P[2]}, r1[3] = {P[4], P[5], P[6]}, r2[3] = {P[8], P[9], P[10]};
+        const float X = __fadd_rn(dot3_fma(r0, cx, cy, cz), P[3]);
+        const float Y = __fadd_rn(dot3_fma(r1, cx, cy, cz), P[7]);
+        const float Z = __fadd_rn(dot3_fma(r2, cx, cy, cz), P[11]);
+        const float xn = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, __fdiv_rn(X, Z)), (float)(W - 1)), 1.0f);
+        const float yn = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, __fdiv_rn(Y, Z)), (float)(H - 1)), 1.0f);
+        const float ix = __fsub_rn(__fmul_rn(__fadd_rn(xn, 1.0f), __fdiv_rn((float)W, 2.0f)), 0.5f);
+        const float iy = __fsub_rn(__fmul_rn(__fadd_rn(yn, 1.0f), __fdiv_rn((float)H, 2.0f)), 0.5f);
+        const float rx = rintf(ix), ry = rintf(iy);
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        if (rx >= 0.0f && rx <= (float)(W - 1) && ry >= 0.0f && ry <= (float)(H - 1)) {
+            const int64_t o = (int64_t)bn * 3 * HW + (int)ry * W + (int)rx;
+            s0 = __fadd_rn(src_imgs[o], 2.0f);
+            s1 = __fadd_rn(src_imgs[o + HW], 2.0f);
+            s2 = __fadd_rn(src_imgs[o + 2 * (int64_t)HW], 2.0f);
+        }
+        const float diff = fabsf(__fsub_rn(Z, src_depths[(int64_t)bn * HW + pix]));
+        const float sum = __fadd_rn(__fadd_rn(s0, s1), s2);
+        const bool mk = (diff < zbuf) && (Z >= 0.0f) && (sum > 0.0f);
+        const float fm = mk ? 1.0f : 0.0f, fn = mk ? 0.0f : 1.0f;
+        zbuf = __fadd_rn(__fmul_rn(fm, diff), __fmul_rn(fn, zbuf));
+        res0 = __fadd_rn(__fmul_rn(__fsub_rn(s0, 2.0f), fm), __fmul_rn(fn, res0));
+        res1 = __fadd_rn(__fmul_rn(__fsub_rn(s1, 2.0f), fm), __fmul_rn(fn, res1));
+        res2 = __fadd_rn(__fmul_rn(__fsub_rn(s2, 2.0f), fm), __fmul_rn(fn, res2));
+    }
+    warped[((int64_t)b * 3 + 0) * HW + pix] = res0;
+    warped[((int64_t)b * 3 + 1) * HW + pix] = res1;
+    warped[((int64_t)b * 3 + 2) * HW + pix] = res2;
+    if (zbuf_out) zbuf_out[(int64_t)b * HW + pix] = zbuf;
+}
+
+// standalone K12: model.py:196-199 + 210-229 when the warp comes from elsewhere (use_rgbd_integration)
+__global__ __launch_bounds__(256) void depth_normalise_kernel(const float *__restrict__ depth, int compute_mask,
+                                                              uint8_t *__restrict__ extrap, float *__restrict__ out,
+                                                              int dataset_norm, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float d = depth[i];
+    const bool hole = compute_mask ? (d <= 0.0f) : false;
+    if (extrap && compute_mask) extrap[i] = hole ? 1 : 0;
+    if (compute_mask) {
+        out[i] = normalise_depth(d, hole, dataset_norm);
+    } else {
+        // the GT branch (x_scaled_inverse_depth): no clip for clevr (model.py:221), no hole merge
+        float wd;
+        if (dataset_norm == 1) {
+            wd = __fdiv_rn(1.0f, __fadd_rn(d, 10.0f));
+            wd = __fdiv_rn(__fsub_rn(wd, (float)(1.0 / 14.765625)), (float)(1.0 / 10.099975586 - 1.0 / 14.765625));
+        } else {
+            wd = __fdiv_rn(1.0f, d);
+            wd = __fdiv_rn(__fsub_rn(wd, (float)(1.0 / 16)), (float)(1.0 / 7 - 1.0 / 16));
+        }
+        out[i] = __fsub_rn(__fmul_rn(2.0f, wd), 1.0f);
+    }
+}
+
+}  // namespace
+
+extern "C" int sgam_depth_normalise_f32(const float *depth, int32_t compute_mask, uint8_t *extrap, float *out,
+                                        int32_t dataset_norm, int64_t n, void *stream) {
+    if (!depth || !out || n <= 0 || (dataset_norm != 1 && dataset_norm != 2)) return SGAM_EINVAL;
+    hipLaunchKernelGGL(depth_normalise_kernel, dim3(sgam_cdiv(n, 256)), dim3(256), 0, sgam_stream(stream), depth,
+                       compute_mask, extrap, out, dataset_norm, n);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+extern "C" int sgam_forward_splat_f32(const float *src_feats, int64_t feat_cs, int64_t feat_ps, const float *src_depths,
+                                      const float *tgt_K, const float *src_Kinv, const float *T, int32_t B, int32_t N,
+                                      int32_t H, int32_t W, const float *depth_range, int32_t dataset_norm,
+                                      int32_t *winner, float *merge_depths, float *merge_feats, uint8_t *extrap,
+                                      float *x_out, float *proj_feats, float *proj_depth, uint8_t *inb_mask,
+                                      int32_t *pix_xy, void *stream) {
+    if (!src_feats || !src_depths || !tgt_K || !src_Kinv || !T || !winner) return SGAM_EINVAL;
+    if (B <= 0 || N <= 0 || H <= 0 || W <= 0 || (int64_t)H * W * N >= (1ll << 31)) return SGAM_EINVAL;
+    if (x_out && dataset_norm != 1 && dataset_norm != 2) return SGAM_EINVAL;
+    hipStream_t s = sgam_stream(stream);
+    const int HW = H * W;
+    hipError_t e = hipMemsetAsync(winner, 0xFF, (size_t)B * HW * sizeof(int32_t), s);  // -1 = empty
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(splat_winner_kernel, dim3(sgam_cdiv((int64_t)HW * N, 256), B), dim3(256), 0, s, src_depths, tgt_K,
+                       src_Kinv, T, N, H, W, winner, inb_mask, pix_xy);
+    SGAM_LAUNCH_CHECK();
+    const float r0 = depth_range ? depth_range[0] : 0.f, r1 = depth_range ? depth_range[1] : 0.f;
+    hipLaunchKernelGGL(splat_resolve_kernel, dim3(sgam_cdiv(W, TS), sgam_cdiv(H, TS), B), dim3(TS * TS), 0, s, src_feats,
+                       feat_cs, feat_ps, src_depths, src_Kinv, T, winner, N, H, W, r0, r1, depth_range ? 1 : 0,
+                       dataset_norm, merge_depths, merge_feats, extrap, x_out, proj_feats, proj_depth);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+extern "C" int sgam_inverse_warp_f32(const float *src_imgs, const float *src_depths, const float *tgt_depth,
+                                     const float *src_K, const float *tgt_Kinv, const float *T_tgt2src, int32_t B,
+                                     int32_t N, int32_t H, int32_t W, float *warped, float *zbuf, void *stream) {
+    if (!src_imgs || !src_depths || !tgt_depth || !src_K || !tgt_Kinv || !T_tgt2src || !warped) return SGAM_EINVAL;
+    if (B <= 0 || N <= 0 || H <= 1 || W <= 1) return SGAM_EINVAL;
+    hipLaunchKernelGGL(inverse_warp_kernel, dim3(sgam_cdiv((int64_t)H * W, 256), B), dim3(256), 0, sgam_stream(stream),
+                       src_imgs, src_depths, tgt_depth, src_K, tgt_Kinv, T_tgt2src, N, H, W, warped, zbuf);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}

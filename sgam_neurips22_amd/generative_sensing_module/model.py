@@ -1,0 +1,167 @@
+"""VQModel — the conditional VQGAN of SGAM on the MI355X HIP backend.
+
+Drop-in for ``sgam.generative_sensing_module.model.VQModel`` (reference model.py:18-269) on the
+inference path: same constructor signature, attribute names, ``state_dict`` keys (345 hot-path tensors;
+``loss.*`` / ``perceptual_loss.*`` keys of a checkpoint are tolerated with strict=False), same
+``encode`` / ``decode`` / ``forward`` / ``get_x`` signatures and return structures.  It is a plain
+``nn.Module`` (no Lightning at inference): ``global_step`` = 0, ``device`` property provided.
+
+Everything between the NCHW boundary tensors runs in libsgam_hip.so, NHWC fp32, without leaving the GPU.
+The training half of the reference class (training_step / optimisers / online k-means, model.py:271-472)
+is out of scope.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..point_rendering.warp import splat_to_model_input
+from .modules.diffusionmodules.model import Conv2d, Decoder, Encoder
+from .modules.vqvae.quantize import VectorQuantizer2 as VectorQuantizer
+
+
+class VQModel(nn.Module):
+    global_step = 0
+    global_rank = 0
+
+    def __init__(self, ddconfig, data_config, lossconfig, n_embed, embed_dim, phase=None, ckpt_path=None,
+                 ignore_keys=['loss.discriminator'], image_key="image", colorize_nlabels=None, logdir=None,
+                 use_extrapolation_mask=True, vq_step_threshold=0, monitor=None, remap=None, sane_index_shape=False,
+                 online_kmeans_config=None, batch_size=None, depth_range=None):
+        super().__init__()
+        online_kmeans_config = online_kmeans_config or {}
+        self.phase = phase
+        self.online_kmeans_config = online_kmeans_config
+        self.data_config = data_config
+        self.logdir = logdir
+        self.depth_range = depth_range
+        self.n_embed = n_embed
+        self.do_online_kmeans_clustering = online_kmeans_config.get('do_online_kmeans_clustering', False)
+        self.use_extrapolation_mask = use_extrapolation_mask
+        self.vq_step_threshold = vq_step_threshold
+        self.image_key = image_key
+        self.use_rgbd_integration = False
+        if self.use_extrapolation_mask:
+            self.conv_in = Conv2d(5, 4, kernel_size=1)
+        self.encoder = Encoder(**ddconfig)
+        self.decoder = Decoder(**ddconfig)
+        # lossconfig (LPIPS + PatchGAN) is a training-only component: accepted, not instantiated.
+        self.lossconfig = lossconfig
+        self.quantize = VectorQuantizer(n_embed, embed_dim, beta=0.25, remap=remap, sane_index_shape=sane_index_shape,
+                                        kmean_init_codebook_path=online_kmeans_config.get('kmean_init_codebook_path'))
+        self.quant_conv = Conv2d(ddconfig["z_channels"], embed_dim, 1)
+        self.post_quant_conv = Conv2d(embed_dim, ddconfig["z_channels"], 1)
+        if ckpt_path is not None:
+            self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys)
+        if monitor is not None:
+            self.monitor = monitor
+
+    # ---- Lightning-free conveniences the callers rely on ----
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def use_vq(self):
+        return self.global_step >= self.vq_step_threshold
+
+    def init_from_ckpt(self, path, ignore_keys=['loss'], only_keep_keys=[]):
+        sd = torch.load(path, map_location="cpu")["state_dict"]
+        for k in list(sd.keys()):
+            if any(k.startswith(ik) for ik in ignore_keys):
+                del sd[k]
+        for k in list(sd.keys()):
+            if any(ik not in k for ik in only_keep_keys):
+                del sd[k]
+        self.load_state_dict(sd, strict=False)
+        print(f"Restored from {path}")
+
+    # ---- NHWC core ----
+    def _encode_nhwc(self, x, extrapolation_mask):
+        """x (B,4,H,W) NCHW + mask -> pre-quant latent (B,h,w,D) NHWC."""
+        if self.use_extrapolation_mask:
+            h = ops.encode_head(x, extrapolation_mask, self.conv_in.weight, self.conv_in.bias, ld=32)
+        else:
+            h = ops.nchw_to_nhwc(x, c_pad=32)
+        return self.quant_conv.forward_nhwc(self.encoder.forward_nhwc(h))
+
+    def _decode_nhwc(self, quant_nhwc):
+        return self.decoder.forward_nhwc(self.post_quant_conv.forward_nhwc(quant_nhwc))
+
+    # ---- reference API ----
+    def encode(self, x, topk=None, encoding_indices=None, extrapolation_mask=None, use_old=False, sample_number=1):
+        pre = self._encode_nhwc(x, extrapolation_mask)
+        if not self.use_vq():
+            return ops.nhwc_to_nchw(pre)
+        if topk is None:
+            if encoding_indices is None:
+                zq, idx, _ = self.quantize.quantize_nhwc(pre)
+            else:
+                B, h, w, D = pre.shape
+                idx = encoding_indices.reshape(B, h, w)
+                zq = ops.vq_gather(self.quantize._codebook()[0], idx).view(B, h, w, D)
+            return ops.nhwc_to_nchw(zq), None, (None, None, idx), ops.nhwc_to_nchw(pre)
+        zqs, idx = self.quantize.sample_nhwc(pre, topk, sample_number, extrapolation_mask)
+        quants = torch.stack([ops.nhwc_to_nchw(zqs[:, i]) for i in range(zqs.shape[1])], 1)
+        return quants, None, (None, None, idx), ops.nhwc_to_nchw(pre)
+
+    def decode(self, quant):
+        return ops.nhwc_to_nchw(self._decode_nhwc(ops.nchw_to_nhwc(quant)))
+
+    def forward(self, input, topk=None, extrapolation_mask=None, sample_number=1, get_codebook_count=False,
+                get_pre_quantized_feature=False, get_quantized_feature=False):
+        pre = self._encode_nhwc(input, extrapolation_mask)
+        if not self.use_vq():
+            dec = ops.nhwc_to_nchw(self._decode_nhwc(pre))
+            return dec, torch.tensor(0).to(dec.device), ops.nhwc_to_nchw(pre)
+        want_q = get_quantized_feature
+        if topk is None:
+            zq, idx, _ = self.quantize.quantize_nhwc(pre)
+            decs = ops.nhwc_to_nchw(self._decode_nhwc(zq))
+            quants = ops.nhwc_to_nchw(zq) if want_q else None
+        else:
+            zqs, idx = self.quantize.sample_nhwc(pre, topk, sample_number, extrapolation_mask)
+            decs = [ops.nhwc_to_nchw(self._decode_nhwc(zqs[:, i]))[None] for i in range(sample_number)]
+            quants = torch.stack([ops.nhwc_to_nchw(zqs[:, i]) for i in range(sample_number)], 1) if want_q else None
+        res = [decs, None]
+        if get_codebook_count:
+            res.append(idx)
+        if get_pre_quantized_feature:
+            res.append(ops.nhwc_to_nchw(pre))
+        if get_quantized_feature:
+            res.append(quants)
+        return res
+
+    def get_input(self, key, batch):
+        x = batch[key]
+        if len(x.shape) == 3:
+            x = x[..., None]
+        if len(x.shape) == 4:
+            x = x.permute(0, 3, 1, 2).to(memory_format=torch.contiguous_format)
+        elif len(x.shape) == 5:
+            x = x.permute(0, 1, 4, 2, 3).to(memory_format=torch.contiguous_format)
+        return x
+
+    def get_x(self, batch, dataset, return_extrapolation_mask=False, no_depth_range=False, parallel=True):
+        """Reference model.py:179-269.  Warp (or take the supplied warp), normalise depths, assemble x / x_dst."""
+        dev = self.device
+        if batch["dst_img"].device != dev:
+            for k in batch:
+                if hasattr(batch[k], "to"):
+                    batch[k] = batch[k].to(device=dev)
+        if dataset not in ops.DATASET_NORM:
+            raise NotImplementedError
+        x_dst = self.get_input("dst_img", batch)
+        x_depth = self.get_input("dst_depth", batch)
+        if 'warped_tgt_features' in batch:
+            x_rgb = batch['warped_tgt_features']
+            wd, em = ops.depth_normalise(batch['warped_tgt_depth'][:, None], dataset, compute_mask=True)
+            x = torch.cat([x_rgb, wd], 1)
+            extrapolation_mask = em.bool()
+            warped_depth = wd
+        else:
+            x, extrapolation_mask, warped_depth = splat_to_model_input(
+                batch, dataset, depth_range=None if no_depth_range else self.depth_range)
+        x_scaled_inverse_depth, _ = ops.depth_normalise(x_depth, dataset, compute_mask=False)
+        x_dst = torch.cat([x_dst, x_scaled_inverse_depth], 1)
+        if return_extrapolation_mask:
+            return x, x_dst, extrapolation_mask, warped_depth
+        return x, x_dst

@@ -1,0 +1,281 @@
+"""Encoder / Decoder of the conditional VQGAN on the HIP backend.
+
+Same constructor kwargs, attribute names and ``state_dict`` keys as the reference's
+``sgam/generative_sensing_module/modules/diffusionmodules/model.py`` (Encoder :342-433, Decoder
+:437-539, ResnetBlock :78-137, AttnBlock :140-192, Upsample :38-53, Downsample :56-75, Normalize
+:34-35), so checkpoints and callers drop in unchanged — but no layer ever runs a torch op: the
+``nn.Conv2d`` / ``nn.GroupNorm`` objects are parameter containers only, and every ``forward`` is a
+sequence of calls into libsgam_hip.so (MFMA implicit-GEMM convolutions, GroupNorm+swish, softmax).
+
+Activations stay NHWC between layers (``forward_nhwc``); the public ``forward`` of each module takes
+and returns NCHW like the reference and pays one layout hop on each side.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .... import ops
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d as a parameter container + HIP execution.  Packed weights ([Cout_pad][taps][Cin_pad],
+    K contiguous — the B operand layout of the implicit GEMM) are cached per (storage, version)."""
+
+    def _packed(self):
+        w = self.weight
+        key = (w.data_ptr(), w._version, str(w.device))
+        if getattr(self, "_pack_key", None) != key:
+            self._pack = ops.pack_conv_weight(w)
+            self._pack_bias = None if self.bias is None else self.bias.detach().float().contiguous()
+            self._pack_key = key
+        return self._pack, self._pack_bias
+
+    def forward_nhwc(self, x, residual=None, upsample2x=False, pad=None):
+        wp, b = self._packed()
+        kh, kw = self.kernel_size
+        if pad is None:
+            pad = (self.padding[0], self.padding[1], self.padding[0], self.padding[1])  # t, l, b, r
+        return ops.conv2d_nhwc(x, wp, b, cout=self.out_channels, kh=kh, kw=kw, stride=self.stride[0],
+                               pad_t=pad[0], pad_l=pad[1], pad_b=pad[2], pad_r=pad[3], upsample2x=upsample2x,
+                               residual=residual, cin=wp.shape[1] // (kh * kw))
+
+    def forward(self, x):
+        cin_pad = self._packed()[0].shape[1] // (self.kernel_size[0] * self.kernel_size[1])
+        return ops.nhwc_to_nchw(self.forward_nhwc(ops.nchw_to_nhwc(x, c_pad=cin_pad)))
+
+
+class GroupNorm(nn.GroupNorm):
+    def forward_nhwc(self, x, swish=False):
+        return ops.groupnorm_nhwc(x, self.weight.detach(), self.bias.detach(), swish, groups=self.num_groups,
+                                  eps=self.eps)
+
+    def forward(self, x):
+        return ops.nhwc_to_nchw(self.forward_nhwc(ops.nchw_to_nhwc(x)))
+
+
+def Normalize(in_channels):
+    return GroupNorm(num_groups=32, num_channels=in_channels, eps=1e-6, affine=True)
+
+
+def nonlinearity(x):
+    """swish; standalone NCHW use only — inside the network swish is fused into the GroupNorm kernel."""
+    raise ops.SgamHipError("nonlinearity() is fused into GroupNorm on the HIP backend (GroupNorm.forward_nhwc(swish=True))")
+
+
+class _NHWCModule(nn.Module):
+    def forward(self, x, *unused):
+        return ops.nhwc_to_nchw(self.forward_nhwc(ops.nchw_to_nhwc(x)))
+
+
+class Upsample(_NHWCModule):
+    def __init__(self, in_channels, with_conv):
+        super().__init__()
+        self.with_conv = with_conv
+        if not with_conv:
+            raise NotImplementedError("Upsample(with_conv=False) is not on the SGAM hot path")
+        self.conv = Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
+
+    def forward_nhwc(self, x):
+        # nearest 2x folded into the conv's gather (K6 + K1)
+        return self.conv.forward_nhwc(x, upsample2x=True)
+
+
+class Downsample(_NHWCModule):
+    def __init__(self, in_channels, with_conv):
+        super().__init__()
+        self.with_conv = with_conv
+        if not with_conv:
+            raise NotImplementedError("Downsample(with_conv=False) is not on the SGAM hot path")
+        self.conv = Conv2d(in_channels, in_channels, kernel_size=3, stride=2, padding=0)
+
+    def forward_nhwc(self, x):
+        # F.pad(x, (0,1,0,1)) + stride-2 conv: zero padding on the right/bottom only (K2)
+        return self.conv.forward_nhwc(x, pad=(0, 0, 1, 1))
+
+
+class ResnetBlock(_NHWCModule):
+    def __init__(self, *, in_channels, out_channels=None, conv_shortcut=False, dropout=0.0, temb_channels=512):
+        super().__init__()
+        out_channels = in_channels if out_channels is None else out_channels
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.use_conv_shortcut = conv_shortcut
+        self.norm1 = Normalize(in_channels)
+        self.conv1 = Conv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=1)
+        if temb_channels > 0:
+            self.temb_proj = nn.Linear(temb_channels, out_channels)  # never used: temb is None on this path
+        self.norm2 = Normalize(out_channels)
+        self.dropout = nn.Dropout(dropout)  # p = 0 in every SGAM config; identity at inference
+        self.conv2 = Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1)
+        if in_channels != out_channels:
+            if conv_shortcut:
+                self.conv_shortcut = Conv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=1)
+            else:
+                self.nin_shortcut = Conv2d(in_channels, out_channels, kernel_size=1, stride=1, padding=0)
+
+    def forward_nhwc(self, x):
+        h = self.conv1.forward_nhwc(self.norm1.forward_nhwc(x, swish=True))
+        h = self.norm2.forward_nhwc(h, swish=True)
+        if self.in_channels != self.out_channels:
+            x = (self.conv_shortcut if self.use_conv_shortcut else self.nin_shortcut).forward_nhwc(x)
+        return self.conv2.forward_nhwc(h, residual=x)  # x + h in the conv epilogue
+
+    def forward(self, x, temb=None):
+        if temb is not None:
+            raise NotImplementedError("timestep embeddings are not used by SGAM's VQGAN")
+        return super().forward(x)
+
+
+class AttnBlock(_NHWCModule):
+    """Single-head spatial self-attention (reference :168-192) as four MFMA GEMMs + a row softmax:
+    [q|k] = h Wqk^T, v^T = Wv h^T, S = q k^T, P = softmax(S c^-1/2), O = P v, out = x + O Wp^T."""
+
+    def __init__(self, in_channels):
+        super().__init__()
+        self.in_channels = in_channels
+        self.norm = Normalize(in_channels)
+        self.q = Conv2d(in_channels, in_channels, kernel_size=1, stride=1, padding=0)
+        self.k = Conv2d(in_channels, in_channels, kernel_size=1, stride=1, padding=0)
+        self.v = Conv2d(in_channels, in_channels, kernel_size=1, stride=1, padding=0)
+        self.proj_out = Conv2d(in_channels, in_channels, kernel_size=1, stride=1, padding=0)
+
+    def _packed_qkv(self):
+        ws = (self.q.weight, self.k.weight, self.v.weight)
+        key = tuple((w.data_ptr(), w._version) for w in ws) + (str(ws[0].device),)
+        if getattr(self, "_qkv_key", None) != key:
+            c = self.in_channels
+            self._wqk = torch.cat([self.q.weight.detach().reshape(c, c), self.k.weight.detach().reshape(c, c)],
+                                  0).float().contiguous()
+            self._bqk = torch.cat([self.q.bias.detach(), self.k.bias.detach()]).float().contiguous()
+            self._wv = self.v.weight.detach().reshape(c, c).float().contiguous()
+            self._bv = self.v.bias.detach().float().contiguous()
+            self._qkv_key = key
+        return self._wqk, self._bqk, self._wv, self._bv
+
+    def forward_nhwc(self, x):
+        B, H, W, C = x.shape
+        n = H * W
+        wqk, bqk, wv, bv = self._packed_qkv()
+        wp, bp = self.proj_out._packed()
+        h = self.norm.forward_nhwc(x, swish=False)
+        out = torch.empty_like(x)
+        scale = int(C) ** (-0.5)
+        for b in range(B):
+            hb = h[b].reshape(n, C)
+            qk = ops.gemm_nt(hb, wqk, bias=bqk)                        # (n, 2C)
+            vt = ops.gemm_nt(wv, hb, bias=bv, bias_per_row=True)       # (C, n) = v^T
+            s = ops.gemm_nt(qk[:, :C], qk[:, C:])                      # (n, n) scores
+            ops.softmax_rows_(s, scale)
+            o = ops.gemm_nt(s, vt)                                     # (n, C)
+            ops.gemm_nt(o, wp, bias=bp, residual=x[b].reshape(n, C), out=out[b].reshape(n, C))
+        return out
+
+
+def _make_attn_list():
+    return nn.ModuleList()
+
+
+class Encoder(_NHWCModule):
+    def __init__(self, *, ch, out_ch, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions, dropout=0.0,
+                 resamp_with_conv=True, in_channels, resolution, z_channels, double_z=True, **ignore_kwargs):
+        super().__init__()
+        self.ch, self.temb_ch = ch, 0
+        self.num_resolutions = len(ch_mult)
+        self.num_res_blocks = num_res_blocks
+        self.resolution = resolution
+        self.in_channels = in_channels
+        self.conv_in = Conv2d(in_channels, ch, kernel_size=3, stride=1, padding=1)
+        # attention placement follows ddconfig.resolution bookkeeping, NOT the real input size
+        res = resolution
+        widths = [ch * m for m in (1,) + tuple(ch_mult)]
+        self.down = nn.ModuleList()
+        for lv in range(self.num_resolutions):
+            stage = nn.Module()
+            stage.block, stage.attn = nn.ModuleList(), _make_attn_list()
+            cin, cout = widths[lv], widths[lv + 1]
+            for _ in range(num_res_blocks):
+                stage.block.append(ResnetBlock(in_channels=cin, out_channels=cout, temb_channels=0, dropout=dropout))
+                cin = cout
+                if res in attn_resolutions:
+                    stage.attn.append(AttnBlock(cin))
+            if lv != self.num_resolutions - 1:
+                stage.downsample = Downsample(cin, resamp_with_conv)
+                res //= 2
+            self.down.append(stage)
+        top = widths[-1]
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(in_channels=top, out_channels=top, temb_channels=0, dropout=dropout)
+        self.mid.attn_1 = AttnBlock(top)
+        self.mid.block_2 = ResnetBlock(in_channels=top, out_channels=top, temb_channels=0, dropout=dropout)
+        self.norm_out = Normalize(top)
+        self.conv_out = Conv2d(top, 2 * z_channels if double_z else z_channels, kernel_size=3, stride=1, padding=1)
+
+    def forward_nhwc(self, x):
+        """x: (B,H,W,32) NHWC with the in_channels real channels first, rest zero."""
+        h = self.conv_in.forward_nhwc(x)
+        for lv, stage in enumerate(self.down):
+            for ib, blk in enumerate(stage.block):
+                h = blk.forward_nhwc(h)
+                if len(stage.attn) > 0:
+                    h = stage.attn[ib].forward_nhwc(h)
+            if lv != self.num_resolutions - 1:
+                h = stage.downsample.forward_nhwc(h)
+        h = self.mid.block_2.forward_nhwc(self.mid.attn_1.forward_nhwc(self.mid.block_1.forward_nhwc(h)))
+        return self.conv_out.forward_nhwc(self.norm_out.forward_nhwc(h, swish=True))
+
+    def forward(self, x):
+        return ops.nhwc_to_nchw(self.forward_nhwc(ops.nchw_to_nhwc(x, c_pad=32)))
+
+
+class Decoder(_NHWCModule):
+    def __init__(self, *, ch, out_ch, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions, dropout=0.0,
+                 resamp_with_conv=True, in_channels, resolution, z_channels, give_pre_end=False, **ignorekwargs):
+        super().__init__()
+        self.ch, self.temb_ch = ch, 0
+        self.num_resolutions = len(ch_mult)
+        self.num_res_blocks = num_res_blocks
+        self.resolution = resolution
+        self.in_channels = in_channels
+        self.give_pre_end = give_pre_end
+        self.out_ch = out_ch
+        width = ch * ch_mult[-1]
+        res = resolution // 2 ** (self.num_resolutions - 1)
+        self.z_shape = (1, z_channels, res, res)
+        print("Working with z of shape {} = {} dimensions.".format(self.z_shape, int(np.prod(self.z_shape))))
+        self.conv_in = Conv2d(z_channels, width, kernel_size=3, stride=1, padding=1)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(in_channels=width, out_channels=width, temb_channels=0, dropout=dropout)
+        self.mid.attn_1 = AttnBlock(width)
+        self.mid.block_2 = ResnetBlock(in_channels=width, out_channels=width, temb_channels=0, dropout=dropout)
+        stages = []
+        for lv in reversed(range(self.num_resolutions)):
+            stage = nn.Module()
+            stage.block, stage.attn = nn.ModuleList(), _make_attn_list()
+            cout = ch * ch_mult[lv]
+            for _ in range(num_res_blocks + 1):
+                stage.block.append(ResnetBlock(in_channels=width, out_channels=cout, temb_channels=0, dropout=dropout))
+                width = cout
+                if res in attn_resolutions:
+                    stage.attn.append(AttnBlock(width))
+            if lv != 0:
+                stage.upsample = Upsample(width, resamp_with_conv)
+                res *= 2
+            stages.append(stage)
+        self.up = nn.ModuleList(reversed(stages))  # index = resolution level, like the reference
+        self.norm_out = Normalize(width)
+        self.conv_out = Conv2d(width, out_ch, kernel_size=3, stride=1, padding=1)
+
+    def forward_nhwc(self, z):
+        self.last_z_shape = (z.shape[0], z.shape[3], z.shape[1], z.shape[2])
+        h = self.conv_in.forward_nhwc(z)
+        h = self.mid.block_2.forward_nhwc(self.mid.attn_1.forward_nhwc(self.mid.block_1.forward_nhwc(h)))
+        for lv in reversed(range(self.num_resolutions)):
+            stage = self.up[lv]
+            for ib, blk in enumerate(stage.block):
+                h = blk.forward_nhwc(h)
+                if len(stage.attn) > 0:
+                    h = stage.attn[ib].forward_nhwc(h)
+            if lv != 0:
+                h = stage.upsample.forward_nhwc(h)
+        if self.give_pre_end:
+            return h
+        return self.conv_out.forward_nhwc(self.norm_out.forward_nhwc(h, swish=True))

@@ -1,0 +1,115 @@
+"""VectorQuantizer2 on the HIP backend — same constructor / attributes / return structure as the reference
+(sgam/generative_sensing_module/modules/vqvae/quantize.py:213-381).
+
+forward                : L2 nearest codeword (MFMA z.e^T + exact-order distance/arg-min kernel), embedding
+                         gather, straight-through value z + (z_q - z)            (reference :275-319)
+get_multiple_codewords : top-k infill sampler (reference :344-381) — distances / top-k on the GPU, the
+                         softmax + multinomial draws on the host CPU RNG stream exactly like the reference
+                         (it samples every token from row 0's distribution, :358 — preserved).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .... import ops
+
+
+class VectorQuantizer2(nn.Module):
+    def __init__(self, n_e, e_dim, beta, remap=None, unknown_index="random", sane_index_shape=False, legacy=True,
+                 kmean_init_codebook_path=None):
+        super().__init__()
+        self.n_e, self.e_dim, self.beta, self.legacy = n_e, e_dim, beta, legacy
+        self.kmean_init_codebook_path = kmean_init_codebook_path
+        self.embedding = nn.Embedding(n_e, e_dim)
+        if kmean_init_codebook_path is None:
+            self.embedding.weight.data.uniform_(-1.0 / n_e, 1.0 / n_e)
+        else:
+            self.embedding.weight.data.copy_(torch.from_numpy(np.load(kmean_init_codebook_path)))
+        if remap is not None:
+            raise NotImplementedError("index remapping is unused by SGAM (remap=None in every config)")
+        self.remap = None
+        self.re_embed = n_e
+        self.sane_index_shape = sane_index_shape
+        self.consume_host_rng = False
+
+    # ---- codebook cache: contiguous fp32 copy + |e|^2, refreshed when the weight changes ----
+    def _codebook(self):
+        w = self.embedding.weight
+        key = (w.data_ptr(), w._version, str(w.device))
+        if getattr(self, "_cb_key", None) != key:
+            self._cb = w.detach().float().contiguous()
+            self._cb_sq = ops.row_sumsq(self._cb)
+            self._cb_key = key
+        return self._cb, self._cb_sq
+
+    def quantize_nhwc(self, z_nhwc, want_dist=False):
+        """z (B,h,w,D) -> (z_q (B,h,w,D) straight-through value, idx (B,h,w) int64, dist or None)."""
+        B, h, w, D = z_nhwc.shape
+        cb, cb_sq = self._codebook()
+        idx, zq, dist = ops.vq_nearest(z_nhwc.reshape(B * h * w, D), cb, cb_sq, straight_through=True,
+                                       want_dist=want_dist)
+        return zq.view(B, h, w, D), idx.view(B, h, w), dist
+
+    def forward(self, z, temp=None, rescale_logits=False, return_logits=False, encoding_indices=None, valid_mask=None):
+        assert temp is None or temp == 1.0, "Only for interface compatible with Gumbel"
+        assert rescale_logits is False, "Only for interface compatible with Gumbel"
+        assert return_logits is False, "Only for interface compatible with Gumbel"
+        zn = ops.nchw_to_nhwc(z)
+        if encoding_indices is None:
+            zq, idx, _ = self.quantize_nhwc(zn)
+        else:
+            B, h, w, D = zn.shape
+            idx = encoding_indices.reshape(B, h, w)
+            zq = ops.vq_gather(self._codebook()[0], idx).view(B, h, w, D)
+        loss = None  # commitment loss is a training quantity (reference :296-301); not computed at inference
+        if self.sane_index_shape:
+            idx = idx.reshape(zq.shape[0], zq.shape[1], zq.shape[2])
+        return ops.nhwc_to_nchw(zq), loss, (None, None, idx)
+
+    def get_codebook_entry(self, indices, shape):
+        zq = ops.vq_gather(self._codebook()[0], indices.reshape(-1))
+        if shape is not None:
+            zq = ops.nhwc_to_nchw(zq.view(shape))
+        return zq
+
+    def update_codebook(self, features, codebook_indices):
+        w = self.embedding.weight.data
+        for i, ci in enumerate(codebook_indices):
+            w[ci] = torch.from_numpy(features[i]).to(w.device)
+        self.embedding.weight.data.copy_(w)
+
+    def sample_nhwc(self, z_nhwc, topk, sample_number, extrapolation_mask):
+        """get_multiple_codewords on an NHWC latent.  Returns z_qs (1,S,h,w,D) NHWC-per-sample and
+        indices (1,S,h,w).  Batch 1 / 16x16 only, like the reference (:345, :368, :381)."""
+        B, h, w, D = z_nhwc.shape
+        if B != 1 or (h, w) != (16, 16):
+            raise RuntimeError("get_multiple_codewords supports batch 1 and a 16x16 latent only "
+                               "(reference quantize.py:345-381)")
+        dev = z_nhwc.device
+        cb, cb_sq = self._codebook()
+        if topk == 1 and not self.consume_host_rng:
+            # softmax over one candidate is 1.0 and multinomial can only return slot 0: every token gets its
+            # arg-min whatever the mask says, so nothing has to leave the GPU (the reference's 256 CPU draws
+            # per frame change no output; set consume_host_rng=True to also advance the CPU RNG like it does).
+            idx1, _, _ = ops.vq_nearest(z_nhwc.reshape(h * w, D), cb, cb_sq, want_zq=False)
+            sampled = idx1.view(-1, 1).expand(-1, sample_number)
+        else:
+            idx1, _, dist = ops.vq_nearest(z_nhwc.reshape(h * w, D), cb, cb_sq, want_dist=True, want_zq=False)
+            vals, tk_idx = ops.vq_topk(dist, topk)
+            # host side, CPU RNG stream — identical draws to the reference (row 0's distribution for all tokens)
+            dist0 = F.softmax(-vals[0].cpu() / 1, dim=-1)
+            draws = torch.stack([torch.multinomial(dist0, sample_number, replacement=True) for _ in range(h * w)])
+            em = extrapolation_mask.reshape(1, 1, *extrapolation_mask.shape[-2:]).float().cpu()
+            em = F.interpolate(em, size=(16, 16)).view(-1)
+            draws[(1 - em) != 0] = 0  # outside the hole: arg-min (= top-1)
+            sampled = torch.gather(tk_idx, 1, draws.to(dev))                    # (T, S)
+        zq = ops.vq_gather(cb, sampled.t().contiguous().reshape(-1))            # (S*T, D), pure gather
+        return zq.view(1, sample_number, h, w, D), sampled.t().reshape(1, sample_number, h, w)
+
+    def get_multiple_codewords(self, z, topk=10, sample_number=1, extrapolation_mask=None, return_exp_probility=None,
+                               temp=1):
+        zqs, idx = self.sample_nhwc(ops.nchw_to_nhwc(z), topk, sample_number, extrapolation_mask)
+        S = zqs.shape[1]
+        out = torch.stack([ops.nhwc_to_nchw(zqs[:, i]) for i in range(S)], 1)  # (1,S,D,h,w)
+        return out, None, (None, None, idx)

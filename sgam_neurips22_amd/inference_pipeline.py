@@ -1,0 +1,302 @@
+"""InfiniteSceneGeneration — the frame-autoregressive scene-expansion loop on the HIP backend.
+
+Counterpart of the reference harness ``sgam/inference_pipeline.py`` (constructor :23-142, prepare_grid
+:157-204, zig_zag_order :452-474, get_src_grid_coords :507-531, prepare_batch_data :533-609,
+inverse_warping :662-743, one_step_prediction :860-926, save_to_disk :928-959), rebuilt around an
+IN-MEMORY frame store: generated frames never leave HBM between steps.  What the reference does through
+its PNG / NPY round trip is reproduced bit-for-bit on the GPU by ``ops.frame_feedback``:
+RGB is quantised to uint8 by truncation and re-expanded as float32(u/127.5-1), depth is de-normalised in
+the reference's fp32 expression order.  Files are written only by ``export_to_disk`` after the run.
+
+Pose grid, zig-zag order, source selection (radius 0.3 / 1.0, nearest ``num_src``) and
+``T_rel = T_tgt @ inv(T_src)`` are the reference's float64 numpy formulas (host logic, a few 4x4s per
+step).  Not built here: Open3D TSDF fusion (``rgbd_integration``, reference :745-838);
+``use_rgbd_integration=True`` therefore needs a ``tgt_depth_provider`` callback that supplies the target
+depth the TSDF render would have produced; ``inverse_warping`` itself is a HIP kernel.
+"""
+import os
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from . import ops
+from .generative_sensing_module.model import VQModel
+
+_GL2CV = np.array([[1, 0, 0, 0], [0, -1, 0, 0], [0, 0, -1, 0], [0, 0, 0, 1]], dtype=np.float64)
+
+_START = {
+    "google_earth": (np.array([[1., 0., 0., -3.], [0., 0.86602527, -0.50000024, -6.],
+                               [0., 0.50000024, 0.86602527, 2.], [0., 0., 0., 1.]]),
+                     np.array([0., 0.11878788, 0.]), np.array([0.12, 0, 0.])),
+    "clevr-infinite": (np.array([[1., 0., 0., -20.], [0., 0.95533651, -0.29552022, -20.],
+                                 [0., 0.29552022, 0.95533651, 0.], [0., 0., 0., 1.]]),
+                       np.array([0, 0.81632614, 0.]), np.array([0.81632614, 0, 0.])),
+}
+
+
+def intrinsics(data, image_resolution=(256, 256)):
+    """reference :61-65 (CLEVR) and :83-89 (GoogleEarth, rows scaled by res/512)."""
+    if data == "clevr-infinite":
+        return np.array([[355.5555, 0, 128], [0, 355.5555, 128], [0, 0, 1]], dtype=np.float64)
+    if data == "google_earth":
+        K = np.array([[497.77774, 0, 256], [0, 497.77774, 256], [0, 0, 1]], dtype=np.float64)
+        K[0] = K[0] * image_resolution[1] / 512
+        K[1] = K[1] * image_resolution[0] / 512
+        return K
+    raise NotImplementedError(data)
+
+
+def ray_to_z_depth(depth, K):
+    """CLEVR ray-length -> z-depth conversion (reference :71-79 / :582-590), float64 numpy."""
+    h, w = depth.shape[:2]
+    xs, ys = np.meshgrid(np.linspace(0, w - 1, w), np.linspace(0, h - 1, h))
+    return depth * K[0][0] / np.sqrt(K[0][0] ** 2 + (K[0][2] - ys - 0.5) ** 2 + (K[1][2] - xs - 0.5) ** 2)
+
+
+def synthetic_seed_frame(data, seed_index=0, res=256):
+    """Seeded smooth RGB-D seed frame for boxes without the reference's templates/ (bench, GPU tests):
+    RGB uint8, depth fp32 in the template range ([1.4,3.4] GoogleEarth, [10.3,15.5] CLEVR)."""
+    rs = np.random.RandomState(1000 + seed_index)
+    yy, xx = np.meshgrid(np.linspace(0, 1, res), np.linspace(0, 1, res), indexing="ij")
+    acc = np.zeros((res, res, 4))
+    for _ in range(12):
+        fx, fy = rs.uniform(0.5, 6, 2)
+        ph = rs.uniform(0, 2 * np.pi, 4)
+        amp = rs.uniform(0.2, 1.0, 4)
+        acc += amp * np.sin(2 * np.pi * (fx * xx + fy * yy)[..., None] + ph)
+    acc = (acc - acc.min((0, 1))) / (acc.max((0, 1)) - acc.min((0, 1)))
+    rgb = (acc[..., :3] * 255).astype(np.uint8)
+    lo, hi = (1.4, 3.4) if data == "google_earth" else (10.3, 15.5)
+    depth = (lo + (hi - lo) * acc[..., 3]).astype(np.float32)
+    return rgb, depth
+
+
+def load_template_seed(data, seed_index, image_resolution, templates_root="templates"):
+    """The reference's seed frame exactly as prepare_batch_data reads it (:534-537): PIL LANCZOS resize of the
+    PNG, nearest resize of the depth map.  Host codec boundary."""
+    from PIL import Image
+    import torch.nn.functional as F
+    if data == "google_earth":
+        d = Path(templates_root) / "google_earth" / f"seed{seed_index}"
+        img_fn = sorted(d.glob("im*"))[0]
+        dm_fn = Path(str(img_fn).replace("im", "dm").replace(".png", ".npy"))
+    else:
+        d = Path(templates_root) / "clevr-infinite"
+        img_fn, dm_fn = d / "im_00000_00_00.png", d / "dm_00000_00_00.npy"
+    rgb = np.array(Image.open(img_fn).convert("RGB").resize((image_resolution[1], image_resolution[0]),
+                                                            resample=Image.LANCZOS))
+    depth = np.load(dm_fn)
+    if data == "clevr-infinite":  # the reference rewrites the template depth at construction (:71-79)
+        depth = ray_to_z_depth(depth, intrinsics(data))
+    depth = F.interpolate(torch.from_numpy(depth[None, None]), size=image_resolution)[0][0].numpy().squeeze()
+    return rgb, depth.astype(np.float32)
+
+
+class InfiniteSceneGeneration:
+    def __init__(self, dynamic_model, data, topk=1, step_size_denom=2, use_rgbd_integration=False,
+                 use_discriminator_loss=False, discriminator_loss_weight=0, recon_on_visible=False,
+                 offscreen_rendering=True, output_dim=None, seed_index=0, num_src=None, seed_frame=None,
+                 templates_root="templates", tgt_depth_provider=None, image_resolution=(256, 256)):
+        if data not in _START:
+            raise NotImplementedError(data)
+        self.dynamic_model, self.data, self.topk = dynamic_model, data, topk
+        self.seed_index, self.step_size_denom = seed_index, step_size_denom
+        self.use_rgbd_integration = use_rgbd_integration
+        self.tgt_depth_provider = tgt_depth_provider
+        self.image_resolution = tuple(image_resolution)
+        self.output_dim = output_dim if output_dim is not None else ((20, 20) if data == "clevr-infinite" else (100, 1))
+        self.K = intrinsics(data, self.image_resolution)
+        self.K_inv = np.linalg.inv(self.K)
+        is_vq = isinstance(dynamic_model, VQModel)
+        default_src = 5 if data == "clevr-infinite" else 3
+        self.num_src = (default_src if num_src is None else num_src) if is_vq else 1
+        self.curr = 1
+        self.trajectory_shape = "grid"
+        self.device = dynamic_model.device
+        if seed_frame is None:
+            if os.path.isdir(os.path.join(templates_root, data)):
+                seed_frame = load_template_seed(data, seed_index, self.image_resolution, templates_root)
+            else:
+                seed_frame = synthetic_seed_frame(data, seed_index, self.image_resolution[0])
+        self.frames = {}        # grid coord -> dict(rgb_f (H,W,3) fp32, depth (H,W) fp32, rgb_u8, index)
+        self.prepare_grid(self.output_dim)
+        self._ordered_grid_coords = self.zig_zag_order()
+        self._store_seed(seed_frame)
+        self.dynamic_model.use_rgbd_integration = use_rgbd_integration
+        K32 = torch.from_numpy(self.K.astype(np.float32))
+        # host-side fp32 inverse like the reference (warp.py:210 / inference_pipeline.py:694), done once
+        self._K_dev = K32.to(self.device)
+        self._Kinv_dev = torch.inverse(K32).to(self.device)
+
+    # ---------------------------------------------------------------- grid / order / source choice
+    def prepare_grid(self, grid_size):
+        start, step_i, step_j = _START[self.data]
+        step_i, step_j = step_i / self.step_size_denom, step_j / self.step_size_denom
+        self.transform_grid = []
+        for i in range(grid_size[0]):
+            row = []
+            for j in range(grid_size[1]):
+                c2w = np.eye(4)
+                c2w[:3, :3] = start[:3, :3]
+                c2w[:3, 3] = start[:3, 3] + step_unit(step_j, j) + step_unit(step_i, i)
+                w2c = np.linalg.inv(c2w @ _GL2CV)
+                R, t = w2c[:3, :3], w2c[:3, 3]
+                row.append({"R": R, "t": t, "K": self.K, "position": -R.T @ t, "visited": False,
+                            "grid_coord": (i, j)})
+            self.transform_grid.append(row)
+
+    def zig_zag_order(self):
+        rows, cols = self.output_dim
+        diag = [[] for _ in range(rows + cols - 1)]
+        for i in range(rows):
+            for j in range(cols):
+                if (i + j) % 2 == 0:
+                    diag[i + j].insert(0, (i, j))
+                else:
+                    diag[i + j].append((i, j))
+        order = [c for d in diag for c in d]
+        self.transform_grid[order[0][0]][order[0][1]]["visited"] = True
+        return order
+
+    def next_pose(self, curr):
+        return self._ordered_grid_coords[curr]
+
+    def get_src_grid_coords(self, tgt_grid_coord):
+        tgt = self.transform_grid[tgt_grid_coord[0]][tgt_grid_coord[1]]
+        radius = 0.3 if self.data != "clevr-infinite" else 1
+        found = []
+        for i in range(self.curr):
+            cc = self._ordered_grid_coords[i]
+            cand = self.transform_grid[cc[0]][cc[1]]
+            dist = np.linalg.norm(cand["position"] - tgt["position"])
+            if cand["visited"] and dist <= radius:
+                found.append((cc, dist))
+        found = sorted(found, key=lambda x: x[1])[: self.num_src]
+        return [c for c, _ in found], None
+
+    # ---------------------------------------------------------------- frame store
+    def _store_seed(self, seed_frame):
+        rgb_u8, depth = seed_frame
+        u8 = torch.from_numpy(np.ascontiguousarray(rgb_u8)).to(self.device)
+        self.frames[(0, 0)] = {
+            "rgb_u8": u8, "rgb_f": ops.rgb_lut(self.device)[u8.long()],  # table lookup = the PNG re-read
+            "depth": torch.from_numpy(np.ascontiguousarray(depth, dtype=np.float32)).to(self.device),
+            "index": 0,
+        }
+        self.transform_grid[0][0]["visited"] = True
+
+    def _src_depth(self, coord):
+        fr = self.frames[coord]
+        if fr["index"] == 0 and self.data == "clevr-infinite":
+            # the reference converts the seed depth AGAIN on every load (:582-590); float64 host math
+            if "depth_reconv" not in fr:
+                d = ray_to_z_depth(fr["depth"].cpu().numpy(), self.K)
+                fr["depth_reconv"] = torch.from_numpy(d.astype(np.float32)).to(self.device)
+            return fr["depth_reconv"]
+        return fr["depth"]
+
+    # ---------------------------------------------------------------- batch assembly
+    def relative_poses(self, tgt_node, src_nodes):
+        T_tgt = np.eye(4)
+        T_tgt[:3, :3], T_tgt[:3, 3] = tgt_node["R"], tgt_node["t"]
+        R_rels, t_rels, T_tgt2srcs = [], [], []
+        for s in src_nodes:
+            T_src = np.eye(4)
+            T_src[:3, :3], T_src[:3, 3] = s["R"], s["t"]
+            T_rel = T_tgt @ np.linalg.inv(T_src)
+            T_tgt2srcs.append(np.linalg.inv(T_rel))
+            R_rels.append(T_rel[:3, :3])
+            t_rels.append(T_rel[:3, 3])
+        return np.stack(R_rels), np.stack(t_rels), np.stack(T_tgt2srcs)
+
+    def prepare_batch_data(self, tgt_node, src_nodes, num_src):
+        dev = self.device
+        coords = [s["grid_coord"] for s in src_nodes]
+        n = len(coords)
+        H, W = self.image_resolution
+        R_rels, t_rels, T_tgt2srcs = self.relative_poses(tgt_node, src_nodes)
+        src_imgs = torch.stack([self.frames[c]["rgb_f"] for c in coords])[None]          # (1,N,H,W,3)
+        src_depths = torch.stack([self._src_depth(c) for c in coords])[None]              # (1,N,H,W)
+        f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)  # noqa: E731
+        batch = {
+            "Ks": self._K_dev.expand(1, n, 3, 3),
+            "_src_Kinv": self._Kinv_dev.expand(n, 3, 3).contiguous(),
+            "R_rels": f32(R_rels)[None], "t_rels": f32(t_rels)[None],
+            "dst_img": torch.zeros((1, H, W, 3), device=dev), "dst_depth": torch.zeros((1, H, W), device=dev),
+            "src_imgs": src_imgs, "src_depths": src_depths,
+        }
+        if self.use_rgbd_integration:
+            if self.tgt_depth_provider is None:
+                raise NotImplementedError(
+                    "use_rgbd_integration needs the Open3D TSDF depth render (reference :745-838), which is not "
+                    "part of this backend yet: pass tgt_depth_provider=callable(scene, tgt_node, src_nodes, batch)")
+            tgt_depth = self.tgt_depth_provider(self, tgt_node, src_nodes, batch)      # (H,W) device fp32
+            warped = self.inverse_warping(src_imgs.permute(0, 1, 4, 2, 3).contiguous(), src_depths, tgt_depth[None],
+                                          batch["Ks"], self._K_dev[None], f32(T_tgt2srcs)[None], as_numpy=False)
+            batch["warped_tgt_features"] = warped[None]
+            batch["warped_tgt_depth"] = tgt_depth[None]
+        return batch
+
+    def inverse_warping(self, src_imgs, src_depths, tgt_depth, src_intrinsics, tgt_intrinsic, T_tgt2srcs,
+                        padding_mode='zeros', depth_threshold=100, as_numpy=True):
+        """reference :662-743; returns item 0 of the (B,3,H,W) result ((3,H,W) numpy like the reference, or a
+        device tensor with as_numpy=False)."""
+        B, N = src_imgs.shape[:2]
+        dev = src_imgs.device
+        Kinv = torch.inverse(tgt_intrinsic.detach().to("cpu", torch.float32).reshape(B, 3, 3)).to(dev)
+        out = ops.inverse_warp(src_imgs, src_depths, tgt_depth, src_intrinsics.reshape(B * N, 3, 3), Kinv,
+                               T_tgt2srcs.reshape(B * N, 4, 4))
+        return out.cpu().numpy()[0] if as_numpy else out[0]
+
+    # ---------------------------------------------------------------- the step
+    @torch.no_grad()
+    def one_step_prediction(self, tgt_pose_grid_coord, save_res_to_disk=True):
+        src_coords, _ = self.get_src_grid_coords(tgt_pose_grid_coord)
+        tgt_meta = self.transform_grid[tgt_pose_grid_coord[0]][tgt_pose_grid_coord[1]]
+        src_metas = [self.transform_grid[c[0]][c[1]] for c in src_coords]
+        batch = self.prepare_batch_data(tgt_meta, src_metas, self.num_src)
+        batch['src_depths'] = batch['src_depths'][..., None]
+        x, x_dst, extrapolation_mask, warped_depth = self.dynamic_model.get_x(
+            batch, self.data, return_extrapolation_mask=True, no_depth_range=True, parallel=True)
+        x_sample_dets, _, pre_q, quant = self.dynamic_model(
+            x, topk=self.topk, extrapolation_mask=extrapolation_mask, get_pre_quantized_feature=True,
+            get_quantized_feature=True, sample_number=1)
+        x_sample_det = x_sample_dets[0][0]                      # (B,4,H,W); sample number is 1
+        rgb_f, depth, rgb_u8 = ops.frame_feedback(x_sample_det, self.data, want_u8=True)
+        if save_res_to_disk:  # name kept from the reference; here "disk" is the in-HBM frame store
+            self.save_to_store(tgt_pose_grid_coord, rgb_u8[0], rgb_f[0], depth[0])
+        return {
+            "rgbd": x_sample_dets[0].squeeze().detach(), "feature": quant.squeeze().detach(),
+            "pre_quantized_features": pre_q.squeeze().detach(), "fixed": False, "x": x.detach(),
+            "batch_src_imgs": batch['src_imgs'], "batch_src_depths": batch['src_depths'],
+            "batch_R_rels": batch['R_rels'], "batch_t_rels": batch['t_rels'], "warped_depth": warped_depth,
+            "extrapolation_mask": extrapolation_mask, "src_coords": src_coords,
+        }
+
+    def save_to_store(self, coord, rgb_u8, rgb_f, depth):
+        self.frames[coord] = {"rgb_u8": rgb_u8, "rgb_f": rgb_f, "depth": depth, "index": self.curr}
+        self.transform_grid[coord[0]][coord[1]]["visited"] = True
+
+    def scene_expansion(self, return_hs=False):
+        for _ in range(self.output_dim[0] * self.output_dim[1] - 1):
+            self.one_step_prediction(self.next_pose(self.curr))
+            self.curr += 1
+        return self.frames
+
+    # ---------------------------------------------------------------- export (after the run)
+    def export_to_disk(self, out_dir):
+        """Write im_XXXXX_ii_jj.png / dm_*.npy / R_*.npy / t_*.npy like the reference's save_to_disk (:928-942)."""
+        from PIL import Image
+        os.makedirs(out_dir, exist_ok=True)
+        for (i, j), fr in self.frames.items():
+            suffix = f"_{i:02d}_{j:02d}"
+            node = self.transform_grid[i][j]
+            np.save(os.path.join(out_dir, f"R_{fr['index']:05d}{suffix}.npy"), node["R"])
+            np.save(os.path.join(out_dir, f"t_{fr['index']:05d}{suffix}.npy"), node["t"])
+            np.save(os.path.join(out_dir, f"dm_{fr['index']:05d}{suffix}.npy"), fr["depth"].cpu().numpy())
+            Image.fromarray(fr["rgb_u8"].cpu().numpy()).save(os.path.join(out_dir, f"im_{fr['index']:05d}{suffix}.png"))
+
+
+def step_unit(step, k):
+    return step * k

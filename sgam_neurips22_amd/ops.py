@@ -1,0 +1,317 @@
+"""Tensor-level wrappers over the C ABI of libsgam_hip.so.
+
+torch is used here only as plumbing: device allocations (`torch.empty`), the current HIP stream and
+`data_ptr()`.  Every arithmetic result comes from a hand-written HIP kernel; a non-CUDA tensor raises
+(there is no CPU path in the product).
+
+Internal activation layout is NHWC fp32: tensors of shape (B, H, W, C), contiguous.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, SgamHipError, check
+
+GE, CLEVR = 1, 2
+DATASET_NORM = {"google_earth": GE, "clevr-infinite": CLEVR}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise SgamHipError("sgam_neurips22_amd runs on the HIP backend only: got a CPU tensor "
+                               "(move the model and inputs to 'cuda'; there is no CPU fallback)")
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+# ------------------------------------------------------------------------------------------------
+# weights
+# ------------------------------------------------------------------------------------------------
+def pack_conv_weight(w_oihw, cout_pad=None, cin_pad=None):
+    """torch Conv2d.weight (Cout,Cin,KH,KW) -> packed (Cout_pad, KH*KW*Cin_pad), zero padded."""
+    _need_cuda(w_oihw)
+    w = _f32c(w_oihw.detach())
+    cout, cin, kh, kw = w.shape
+    cout_pad = cout_pad or round_up(cout, 64)
+    cin_pad = cin_pad or round_up(cin, 32)
+    out = torch.empty((cout_pad, kh * kw * cin_pad), device=w.device, dtype=torch.float32)
+    check(_lib.load().sgam_pack_conv_weight(_p(w), _p(out), cout, cin, kh, kw, cout_pad, cin_pad, _stream()),
+          "sgam_pack_conv_weight")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# conv / GEMM (MFMA implicit GEMM)
+# ------------------------------------------------------------------------------------------------
+def _run_conv(desc, x, w, bias, residual, out):
+    lib = _lib.load()
+    ws_bytes = lib.sgam_conv2d_workspace_bytes(ctypes.byref(desc))
+    if ws_bytes < 0:
+        raise SgamHipError(f"sgam_conv2d: unsupported shape {[(f, getattr(desc, f)) for f, _ in desc._fields_]}")
+    ws = torch.empty((ws_bytes,), device=x.device, dtype=torch.uint8) if ws_bytes else None
+    check(lib.sgam_conv2d_nhwc_f32(ctypes.byref(desc), _p(x), _p(w), _p(bias), _p(residual), _p(out), _p(ws),
+                                   ws_bytes, _stream()), "sgam_conv2d_nhwc_f32")
+    return out
+
+
+def conv2d_nhwc(x, w_packed, bias, *, cout, kh, kw, stride=1, pad_t=0, pad_l=0, pad_b=None, pad_r=None,
+                upsample2x=False, residual=None, cin=None):
+    """x (B,Hi,Wi,Cx) NHWC fp32 -> (B,Ho,Wo,cout).  w_packed from pack_conv_weight (rows padded to 64,
+    Cin padded to 32).  `cin` = channels of x actually contracted (defaults to Cx, must be % 32)."""
+    _need_cuda(x, w_packed)
+    B, Hi, Wi, Cx = x.shape
+    cin = cin or Cx
+    pad_b = pad_t if pad_b is None else pad_b
+    pad_r = pad_l if pad_r is None else pad_r
+    Hl, Wl = (2 * Hi, 2 * Wi) if upsample2x else (Hi, Wi)
+    Ho = (Hl + pad_t + pad_b - kh) // stride + 1
+    Wo = (Wl + pad_l + pad_r - kw) // stride + 1
+    N = w_packed.shape[0]
+    out = torch.empty((B, Ho, Wo, cout), device=x.device, dtype=torch.float32)
+    d = ConvDesc(B=B, Hi=Hi, Wi=Wi, Cin=cin, Ho=Ho, Wo=Wo, N=N, KH=kh, KW=kw, stride=stride, pad_t=pad_t,
+                 pad_l=pad_l, upsample2x=int(upsample2x), lda=x.stride(2), ldb=w_packed.stride(0), ldc=cout,
+                 ldr=(residual.stride(2) if residual is not None else 0), n_valid=cout, bias_per_row=0)
+    return _run_conv(d, x, w_packed, bias, residual, out)
+
+
+def gemm_nt(a, b, bias=None, residual=None, bias_per_row=False, out=None):
+    """out[M][N] = a[M][K] @ b[N][K]^T (+bias) (+residual).  a, b: 2-D fp32 CUDA tensors with unit
+    inner stride (row strides free, so column slices of a fused projection can be passed directly).
+    K % 32 == 0, N % 4 == 0."""
+    _need_cuda(a, b)
+    M, K = a.shape
+    N, K2 = b.shape
+    assert K == K2 and a.stride(1) == 1 and b.stride(1) == 1
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+    d = ConvDesc(B=1, Hi=1, Wi=M, Cin=K, Ho=1, Wo=M, N=N, KH=1, KW=1, stride=1, pad_t=0, pad_l=0, upsample2x=0,
+                 lda=a.stride(0), ldb=b.stride(0), ldc=out.stride(0),
+                 ldr=(residual.stride(0) if residual is not None else 0), n_valid=N,
+                 bias_per_row=int(bias_per_row))
+    return _run_conv(d, a, b, bias, residual, out)
+
+
+# ------------------------------------------------------------------------------------------------
+# GroupNorm(+swish), softmax
+# ------------------------------------------------------------------------------------------------
+def groupnorm_nhwc(x, gamma, beta, swish, groups=32, eps=1e-6):
+    _need_cuda(x, gamma, beta)
+    B, H, W, C = x.shape
+    lib = _lib.load()
+    ws_bytes = lib.sgam_groupnorm_workspace_bytes(B, H * W, C)
+    if ws_bytes < 0:
+        raise SgamHipError(f"sgam_groupnorm: unsupported shape B={B} HW={H * W} C={C}")
+    ws = torch.empty((ws_bytes,), device=x.device, dtype=torch.uint8)
+    y = torch.empty_like(x)
+    check(lib.sgam_groupnorm_nhwc_f32(_p(x), _p(gamma), _p(beta), _p(y), B, H * W, C, groups, eps, int(swish),
+                                      _p(ws), ws_bytes, _stream()), "sgam_groupnorm_nhwc_f32")
+    return y
+
+
+def softmax_rows_(s, scale):
+    _need_cuda(s)
+    rows, cols = s.shape
+    check(_lib.load().sgam_softmax_rows_f32(_p(s), rows, cols, s.stride(0), float(scale), _stream()),
+          "sgam_softmax_rows_f32")
+    return s
+
+
+# ------------------------------------------------------------------------------------------------
+# layout hops
+# ------------------------------------------------------------------------------------------------
+def nchw_to_nhwc(x, c_pad=None):
+    _need_cuda(x)
+    x = _f32c(x)
+    B, C, H, W = x.shape
+    ld = c_pad or C
+    y = (torch.zeros if ld != C else torch.empty)((B, H, W, ld), device=x.device, dtype=torch.float32)
+    check(_lib.load().sgam_nchw_to_nhwc_f32(_p(x), _p(y), B, C, H * W, ld, _stream()), "sgam_nchw_to_nhwc_f32")
+    return y
+
+
+def nhwc_to_nchw(x, c=None):
+    _need_cuda(x)
+    B, H, W, ld = x.shape
+    c = c or ld
+    y = torch.empty((B, c, H, W), device=x.device, dtype=torch.float32)
+    check(_lib.load().sgam_nhwc_to_nchw_f32(_p(x), _p(y), B, c, H * W, x.stride(2), _stream()),
+          "sgam_nhwc_to_nchw_f32")
+    return y
+
+
+def encode_head(x_nchw, mask, w, bias, ld=32):
+    """cat(x, mask) -> conv1x1(5->4) -> NHWC (B,H,W,ld) with channels 4.. zero (model.py:107-113)."""
+    _need_cuda(x_nchw, w, bias)
+    x = _f32c(x_nchw)
+    B, C, H, W = x.shape
+    assert C == 4
+    m = None
+    if mask is not None:
+        m = mask.reshape(B, H * W)
+        m = (m != 0).to(torch.uint8).contiguous()
+    y = torch.empty((B, H, W, ld), device=x.device, dtype=torch.float32)
+    check(_lib.load().sgam_encode_head_f32(_p(x), _p(m), _p(_f32c(w.detach().reshape(4, 5))), _p(_f32c(bias.detach())),
+                                           _p(y), B, H * W, ld, _stream()), "sgam_encode_head_f32")
+    return y
+
+
+# ------------------------------------------------------------------------------------------------
+# vector quantiser
+# ------------------------------------------------------------------------------------------------
+def row_sumsq(x):
+    _need_cuda(x)
+    x = _f32c(x.detach())
+    out = torch.empty((x.shape[0],), device=x.device, dtype=torch.float32)
+    check(_lib.load().sgam_row_sumsq_f32(_p(x), _p(out), x.shape[0], x.shape[1], _stream()), "sgam_row_sumsq_f32")
+    return out
+
+
+def vq_nearest(z_tokens, codebook, e_sq, straight_through=True, want_dist=False, want_zq=True):
+    """z_tokens (T,D) -> (idx int64 (T,), z_q (T,D) or None, dist (T,n_e) or None)."""
+    _need_cuda(z_tokens, codebook, e_sq)
+    z = _f32c(z_tokens)
+    T, D = z.shape
+    n_e = codebook.shape[0]
+    lib = _lib.load()
+    dots = torch.empty((T, n_e), device=z.device, dtype=torch.float32)
+    idx = torch.empty((T,), device=z.device, dtype=torch.int64)
+    zq = torch.empty((T, D), device=z.device, dtype=torch.float32) if want_zq else None
+    dist = torch.empty((T, n_e), device=z.device, dtype=torch.float32) if want_dist else None
+    ws_bytes = lib.sgam_vq_workspace_bytes(T, D, n_e)
+    if ws_bytes < 0:
+        raise SgamHipError(f"sgam_vq: unsupported shape T={T} D={D} n_e={n_e}")
+    ws = torch.empty((ws_bytes,), device=z.device, dtype=torch.uint8) if ws_bytes else None
+    check(lib.sgam_vq_nearest_f32(_p(z), _p(codebook), _p(e_sq), _p(dots), _p(idx), _p(zq), _p(dist), T, D, n_e,
+                                  int(straight_through), _p(ws), ws_bytes, _stream()), "sgam_vq_nearest_f32")
+    return idx, zq, dist
+
+
+def vq_gather(codebook, idx):
+    _need_cuda(codebook, idx)
+    idx = idx.reshape(-1).to(torch.int64).contiguous()
+    T, D = idx.numel(), codebook.shape[1]
+    out = torch.empty((T, D), device=codebook.device, dtype=torch.float32)
+    check(_lib.load().sgam_vq_gather_f32(_p(codebook), _p(idx), _p(out), T, D, codebook.shape[0], _stream()),
+          "sgam_vq_gather_f32")
+    return out
+
+
+def vq_topk(dist, k):
+    _need_cuda(dist)
+    T, n_e = dist.shape
+    vals = torch.empty((T, k), device=dist.device, dtype=torch.float32)
+    inds = torch.empty((T, k), device=dist.device, dtype=torch.int64)
+    check(_lib.load().sgam_vq_topk_f32(_p(dist), _p(vals), _p(inds), T, n_e, k, _stream()), "sgam_vq_topk_f32")
+    return vals, inds
+
+
+# ------------------------------------------------------------------------------------------------
+# warps and frame feedback
+# ------------------------------------------------------------------------------------------------
+def forward_splat(src_feats, src_depths, tgt_K, src_Kinv, T, *, channels_last=False, depth_range=None,
+                  dataset=None, want=("merge_depths", "merge_feats", "extrap")):
+    """Forward splat + median fill + mask (+ normalised x).  src_feats (B,N,3,H,W) or, with
+    channels_last, (B,N,H,W,3); src_depths (B,N,H,W); tgt_K (B,3,3); src_Kinv (B*N,3,3); T (B*N,4,4).
+    Returns a dict with the tensors named in `want` (any of merge_depths, merge_feats, extrap, x,
+    proj_feats, proj_depth, inb_mask, pix_xy)."""
+    _need_cuda(src_feats, src_depths, tgt_K, src_Kinv, T)
+    f = _f32c(src_feats)
+    d = _f32c(src_depths)
+    B, N, H, W = d.shape
+    HW = H * W
+    dev = d.device
+    cs, ps = (1, 3) if channels_last else (HW, 1)
+    o = {}
+    mk = lambda shape, dt=torch.float32: torch.empty(shape, device=dev, dtype=dt)  # noqa: E731
+    if "merge_depths" in want: o["merge_depths"] = mk((B, 1, H, W))
+    if "merge_feats" in want: o["merge_feats"] = mk((B, 3, H, W))
+    if "extrap" in want: o["extrap"] = mk((B, 1, H, W), torch.uint8)
+    if "x" in want: o["x"] = mk((B, 4, H, W))
+    if "proj_feats" in want: o["proj_feats"] = mk((B, 3, H, W))
+    if "proj_depth" in want: o["proj_depth"] = mk((B, 1, H, W))
+    if "inb_mask" in want: o["inb_mask"] = mk((B * HW * N,), torch.uint8)
+    if "pix_xy" in want: o["pix_xy"] = mk((B * HW * N, 2), torch.int32)
+    winner = mk((B, HW), torch.int32)
+    dr = None
+    if depth_range is not None:
+        dr = (ctypes.c_float * 2)(float(depth_range[0]), float(depth_range[1]))
+    norm = DATASET_NORM.get(dataset, 0) if dataset else 0
+    if "x" in want and norm == 0:
+        raise NotImplementedError(f"dataset {dataset!r}")
+    check(_lib.load().sgam_forward_splat_f32(
+        _p(f), cs, ps, _p(d), _p(_f32c(tgt_K)), _p(_f32c(src_Kinv)), _p(_f32c(T)), B, N, H, W, dr, norm, _p(winner),
+        _p(o.get("merge_depths")), _p(o.get("merge_feats")), _p(o.get("extrap")), _p(o.get("x")),
+        _p(o.get("proj_feats")), _p(o.get("proj_depth")), _p(o.get("inb_mask")), _p(o.get("pix_xy")), _stream()),
+        "sgam_forward_splat_f32")
+    return o
+
+
+def depth_normalise(depth, dataset, compute_mask=True):
+    """depth (any shape) -> (normalised inverse depth, extrap mask uint8 or None)  [model.py:196-229]"""
+    _need_cuda(depth)
+    d = _f32c(depth)
+    out = torch.empty_like(d)
+    em = torch.empty(d.shape, device=d.device, dtype=torch.uint8) if compute_mask else None
+    if dataset not in DATASET_NORM:
+        raise NotImplementedError(f"dataset {dataset!r}")
+    check(_lib.load().sgam_depth_normalise_f32(_p(d), int(compute_mask), _p(em), _p(out), DATASET_NORM[dataset],
+                                               d.numel(), _stream()), "sgam_depth_normalise_f32")
+    return out, em
+
+
+def inverse_warp(src_imgs, src_depths, tgt_depth, src_K, tgt_Kinv, T_tgt2src, want_zbuf=False):
+    _need_cuda(src_imgs, src_depths, tgt_depth, src_K, tgt_Kinv, T_tgt2src)
+    im = _f32c(src_imgs)
+    B, N, _, H, W = im.shape
+    out = torch.empty((B, 3, H, W), device=im.device, dtype=torch.float32)
+    zb = torch.empty((B, H, W), device=im.device, dtype=torch.float32) if want_zbuf else None
+    check(_lib.load().sgam_inverse_warp_f32(_p(im), _p(_f32c(src_depths)), _p(_f32c(tgt_depth)), _p(_f32c(src_K)),
+                                            _p(_f32c(tgt_Kinv)), _p(_f32c(T_tgt2src)), B, N, H, W, _p(out), _p(zb),
+                                            _stream()), "sgam_inverse_warp_f32")
+    return (out, zb) if want_zbuf else out
+
+
+_LUT = {}
+
+
+def rgb_lut(device):
+    """lut[u] = float32(float64(u) / 127.5 - 1.0): what prepare_batch_data reads back from the uint8 PNG
+    (inference_pipeline.py:534 then the .astype(np.float32) at :607)."""
+    key = str(device)
+    if key not in _LUT:
+        import numpy as np
+        lut = (np.arange(256, dtype=np.float64) / 127.5 - 1.0).astype(np.float32)
+        _LUT[key] = torch.from_numpy(lut).to(device)
+    return _LUT[key]
+
+
+def frame_feedback(dec, dataset, want_u8=False):
+    """dec (B,4,H,W) -> (rgb_f (B,H,W,3) fp32, depth (B,H,W) fp32[, rgb_u8 (B,H,W,3) uint8])."""
+    _need_cuda(dec)
+    dec = _f32c(dec)
+    B, C, H, W = dec.shape
+    assert C == 4
+    rgb_f = torch.empty((B, H, W, 3), device=dec.device, dtype=torch.float32)
+    depth = torch.empty((B, H, W), device=dec.device, dtype=torch.float32)
+    u8 = torch.empty((B, H, W, 3), device=dec.device, dtype=torch.uint8) if want_u8 else None
+    check(_lib.load().sgam_frame_feedback_f32(_p(dec), _p(rgb_lut(dec.device)), DATASET_NORM[dataset], _p(u8), _p(rgb_f),
+                                              _p(depth), B, H * W, _stream()), "sgam_frame_feedback_f32")
+    return (rgb_f, depth, u8) if want_u8 else (rgb_f, depth)

@@ -1,0 +1,141 @@
+"""Seeded synthetic weights and inputs shared by the tests, the golden-vector generator, smoke() and
+bench.py (trained checkpoints live on Google Drive and cannot be fetched: SURVEY §8c)."""
+import zlib
+
+import numpy as np
+import torch
+
+
+def synthetic_state_dict(reference_state_dict, seed=0, codebook_sigma=1.0):
+    """Deterministic fp32 weights for every tensor of `reference_state_dict` (name -> tensor or shape):
+    conv/linear weights ~ U(-b, b) with b = sqrt(3 / fan_in) (unit-gain variance), biases ~ U(-0.1, 0.1),
+    GroupNorm weight 1 + 0.1 N(0,1) / bias 0.1 N(0,1), codebook rows ~ N(0, codebook_sigma^2).
+    One independent generator per tensor (seeded by crc32 of its name) so the result does not depend on
+    module construction order."""
+    out = {}
+    for name in sorted(reference_state_dict.keys()):
+        ref = reference_state_dict[name]
+        shape = tuple(ref.shape) if hasattr(ref, "shape") else tuple(ref)
+        g = torch.Generator().manual_seed((zlib.crc32(name.encode()) + 7919 * seed) % (2 ** 31))
+        if name.endswith("embedding.weight"):
+            t = torch.randn(shape, generator=g) * codebook_sigma
+        elif ".norm" in name or name.startswith("norm") or "norm_out" in name:
+            t = torch.randn(shape, generator=g) * 0.1
+            if name.endswith("weight"):
+                t = t + 1.0
+        elif name.endswith("bias"):
+            t = (torch.rand(shape, generator=g) * 2 - 1) * 0.1
+        else:
+            fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else shape[0]
+            b = (3.0 / fan_in) ** 0.5
+            t = (torch.rand(shape, generator=g) * 2 - 1) * b
+        out[name] = t.float()
+    return out
+
+
+def hot_path_keys(state_dict):
+    """state_dict keys the inference hot path owns (drops loss.* / perceptual_loss.* of a full checkpoint)."""
+    return {k: v for k, v in state_dict.items() if not (k.startswith("loss.") or k.startswith("perceptual_loss."))}
+
+
+def codebook_from_stats(zmean, zstd, n_e, dim, seed=0):
+    """Seeded codebook with rows ~ N(zmean, zstd^2): matched to the latent statistics so that the nearest-
+    neighbour structure is well conditioned (the reference's default init U(+-1/n_e) gives exact fp32 ties,
+    SURVEY D4).  Fixtures store (zmean, zstd, seed) and assert the top-2 margin."""
+    g = torch.Generator().manual_seed(4242 + int(seed))
+    return (torch.randn((n_e, dim), generator=g) * float(zstd) + float(zmean)).float()
+
+
+def top2_relative_gap(z_tokens, codebook):
+    """Relative gap between the nearest and second-nearest codeword distance of each token (float64)."""
+    z, cb = z_tokens.detach().double().cpu(), codebook.detach().double().cpu()
+    d = (z ** 2).sum(1, keepdim=True) + (cb ** 2).sum(1) - 2 * z @ cb.t()
+    top2 = torch.topk(d, 2, dim=1, largest=False).values
+    return (top2[:, 1] - top2[:, 0]) / top2[:, 0].abs().clamp_min(1e-12)
+
+
+def rect_hole_input(B, H, W, seed=3, hole_frac=0.3):
+    """Seeded model input: x (B,4,H,W) ~ U(-1,1) with a rectangular hole (rgb 0, depth -2, mask 1)."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand((B, 4, H, W), generator=g) * 2 - 1
+    mask = torch.zeros((B, 1, H, W), dtype=torch.bool)
+    hh = int(H * hole_frac ** 0.5)
+    ww = int(W * hole_frac ** 0.5)
+    y0, x0 = H // 5, W // 4
+    mask[:, :, y0:y0 + hh, x0:x0 + ww] = True
+    x[:, :3][mask.expand(B, 3, H, W)] = 0.0
+    x[:, 3:][mask] = -2.0
+    return x, mask
+
+
+def seeded_tensor(tag, shape, scale=1.0, shift=0.0):
+    """Deterministic N(shift, scale^2) fp32 tensor keyed by a string tag (inputs of the per-op fixtures)."""
+    g = torch.Generator().manual_seed(zlib.crc32(tag.encode()) % (2 ** 31))
+    return torch.randn(tuple(shape), generator=g) * scale + shift
+
+
+def _small_rotation(rs, s):
+    w = rs.randn(3) * s
+    th = np.linalg.norm(w)
+    k = w / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+
+
+def synth_warp_inputs(seed, B, N, H, W, rot_scale=0.05, bad_depth=False):
+    """Seeded forward-splat inputs: features (B,N,3,H,W) with ~2% exact zeros, depths in the GoogleEarth
+    template range (optionally 5% zeros / 2% negatives), pinhole K, random small rigid motions."""
+    rs = np.random.RandomState(seed)
+    f = rs.uniform(-1, 1, (B, N, 3, H, W)).astype(np.float32)
+    f[rs.rand(*f.shape) < 0.02] = 0
+    d = rs.uniform(1.4, 3.4, (B, N, H, W)).astype(np.float32)
+    if bad_depth:
+        d[rs.rand(*d.shape) < 0.05] = 0
+        d[rs.rand(*d.shape) < 0.02] *= -1
+    fx = W * 0.97
+    K = np.array([[fx, 0, W / 2], [0, fx, H / 2], [0, 0, 1]], np.float32)
+    Ks = np.tile(K, (B, N, 1, 1))
+    T = np.tile(np.eye(4, dtype=np.float32), (B, N, 1, 1))
+    for b in range(B):
+        for n in range(N):
+            T[b, n, :3, :3] = _small_rotation(rs, rot_scale)
+            T[b, n, :3, 3] = rs.randn(3) * 0.1
+    return f, d, Ks, T
+
+
+def synth_invwarp_inputs(seed, N, H, W, rot_scale=0.05, bad=False):
+    """Seeded inverse-warp inputs (B=1): src images / depths, a target depth (optionally with zeros,
+    negatives and -1 pixels that defeat the `sum > 0` validity test), K, target->source motions."""
+    rs = np.random.RandomState(seed)
+    im = rs.uniform(-1, 1, (1, N, 3, H, W)).astype(np.float32)
+    d = rs.uniform(1.4, 3.4, (1, N, H, W)).astype(np.float32)
+    td = rs.uniform(1.4, 3.4, (1, H, W)).astype(np.float32)
+    if bad:
+        td[rs.rand(*td.shape) < 0.05] = 0
+        td[rs.rand(*td.shape) < 0.03] *= -1
+        im[rs.rand(*im.shape) < 0.1] = -1
+    fx = W * 0.97
+    K = np.array([[fx, 0, W / 2], [0, fx, H / 2], [0, 0, 1]], np.float32)
+    Ks = np.tile(K, (1, N, 1, 1))
+    T = np.tile(np.eye(4, dtype=np.float32), (1, N, 1, 1))
+    for n in range(N):
+        T[0, n, :3, :3] = _small_rotation(rs, rot_scale)
+        T[0, n, :3, 3] = rs.randn(3) * 0.1
+    return im, d, td, Ks, K, T
+
+
+# (tag, seed, B, N, H, W, rot_scale, depth_range, bad_depth) — shared by gen_golden.py and the tests
+SPLAT_CASES = [("a", 1, 1, 1, 64, 64, 0.05, None, False), ("b", 2, 1, 3, 64, 64, 0.05, None, False),
+               ("c", 3, 2, 3, 48, 80, 0.05, None, False), ("d", 4, 1, 5, 64, 64, 0.2, None, False),
+               ("e", 5, 1, 3, 64, 64, 0.05, (0.5, 3.0), False), ("f", 6, 2, 2, 64, 64, 0.1, None, True)]
+# (tag, seed, N, H, W, rot_scale, bad)
+INVWARP_CASES = [("a", 1, 1, 64, 64, 0.05, False), ("b", 2, 3, 64, 64, 0.05, False), ("c", 3, 3, 48, 80, 0.2, False),
+                 ("d", 5, 3, 64, 64, 0.1, True)]
+# (tag, module kind, ctor args, input shape NCHW)
+OP_CASES = [("res128", "ResnetBlock", dict(in_channels=128, out_channels=128), (1, 128, 24, 20)),
+            ("res128_256", "ResnetBlock", dict(in_channels=128, out_channels=256), (2, 128, 16, 16)),
+            ("res512_256", "ResnetBlock", dict(in_channels=512, out_channels=256), (1, 512, 8, 8)),
+            ("attn256", "AttnBlock", dict(in_channels=256), (1, 256, 16, 24)),
+            ("attn512", "AttnBlock", dict(in_channels=512), (2, 512, 8, 8)),
+            ("down128", "Downsample", dict(in_channels=128, with_conv=True), (1, 128, 16, 20)),
+            ("up256", "Upsample", dict(in_channels=256, with_conv=True), (1, 256, 8, 12))]
