@@ -45,7 +45,7 @@ const char *sgam_build_info(void);
  *   zero outside the (logical) input; when `upsample2x` != 0 the logical input is the nearest-
  *   neighbour 2x enlargement of the physical [Hi][Wi] map (X[b][iy>>1][ix>>1]).
  *
- *   x        [B][Hi][Wi] pixels, `lda` floats apart, first Cin floats used (Cin % 32 == 0)
+ *   x        [B][Hi][Wi] pixels, `lda` floats apart, first Cin floats used (Cin % 4 == 0; 32-wide K slabs, ragged tail masked)
  *   w_packed [N] rows, `ldb` floats apart, K = KH*KW*Cin contiguous (see sgam_pack_conv_weight)
  *   bias     [N] or NULL;  residual [M] rows `ldr` apart or NULL
  *   out      [M] rows `ldc` apart; only columns n < n_valid are written
@@ -63,6 +63,8 @@ typedef struct sgam_conv_desc {
 } sgam_conv_desc;
 
 int64_t sgam_conv2d_workspace_bytes(const sgam_conv_desc *d);
+/* which kernel instantiation a descriptor maps to: workgroup tile BMxBN and split-K factor (for profiling). */
+int sgam_conv2d_plan(const sgam_conv_desc *d, int32_t *bm, int32_t *bn, int32_t *ksplit);
 int sgam_conv2d_nhwc_f32(const sgam_conv_desc *d, const float *x, const float *w_packed,
                          const float *bias, const float *residual, float *out, void *workspace,
                          int64_t workspace_bytes, void *stream);

@@ -21,6 +21,8 @@ PROTOTYPES = {
     "sgam_abi_version": (c_i32, []),
     "sgam_build_info": (ctypes.c_char_p, []),
     "sgam_conv2d_workspace_bytes": (c_i64, [ctypes.POINTER(ConvDesc)]),
+    "sgam_conv2d_plan": (c_i32, [ctypes.POINTER(ConvDesc), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32),
+                                 ctypes.POINTER(c_i32)]),
     "sgam_conv2d_nhwc_f32": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "sgam_pack_conv_weight": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "sgam_groupnorm_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
@@ -61,6 +63,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own HIP runtime (torch/lib/libamdhip64.so, soname libamdhip64.so.7).  It must be in the
+    # process BEFORE this library so that our DT_NEEDED libamdhip64.so.7 binds to that same runtime instance;
+    # loading /opt/rocm's copy first gives two runtimes in one process (hipErrorNoDevice on the second).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise SgamHipError(
             f"{LIB_PATH} is missing: the HIP backend has not been built. Run "

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void conv_gemm_f32_kernel(const ConvKernelPara
     const int m0 = blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
 
-    const int chunks = p.Cin / BK;
+    const int chunks = (p.Cin + BK - 1) / BK;  // the last K slab of a tap may be partial (Cin % 4 == 0)
     const int it0 = blockIdx.z * p.iters_per_split;
     const int it1 = min(p.iters_total, it0 + p.iters_per_split);
 
@@ -98,10 +98,11 @@ __global__ __launch_bounds__(256) void conv_gemm_f32_kernel(const ConvKernelPara
         const int ky = tap / p.KW;
         const int kx = tap - ky * p.KW;
         const int coff = ch * BK + col4 * 4;
+        const bool k_ok = coff < p.Cin;  // K tail: columns past Cin contribute zeros on both operands
 #pragma unroll
         for (int r = 0; r < AR; ++r) {
             const int iy = a_iy0[r] + ky, ix = a_ix0[r] + kx;
-            const bool ok = a_ok[r] && iy >= 0 && iy < Hl && ix >= 0 && ix < Wl;
+            const bool ok = k_ok && a_ok[r] && iy >= 0 && iy < Hl && ix >= 0 && ix < Wl;
             const int py = p.ups ? (iy >> 1) : iy, px = p.ups ? (ix >> 1) : ix;
             const float *src = p.x + (a_base[r] + (int64_t)py * p.Wi + px) * p.lda + coff;
             areg[r] = ok ? *reinterpret_cast<const f32x4 *>(src) : zero4;
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) void conv_gemm_f32_kernel(const ConvKernelPara
         const int64_t koff = (int64_t)tap * p.Cin + ch * BK;
 #pragma unroll
         for (int r = 0; r < BR; ++r) {
-            breg[r] = b_ok[r] ? *reinterpret_cast<const f32x4 *>(p.w + b_off[r] + koff) : zero4;
+            breg[r] = (k_ok && b_ok[r]) ? *reinterpret_cast<const f32x4 *>(p.w + b_off[r] + koff) : zero4;
         }
     };
     auto store_lds = [&](int buf) {
@@ -235,7 +236,7 @@ struct Plan {
 Plan make_plan(const sgam_conv_desc *d) {
     const int64_t M = (int64_t)d->B * d->Ho * d->Wo;
     Plan pl;
-    pl.iters_total = d->KH * d->KW * (d->Cin / BK);
+    pl.iters_total = d->KH * d->KW * ((d->Cin + BK - 1) / BK);
     auto blocks = [&](int bm, int bn) { return (int64_t)sgam_cdiv(M, bm) * sgam_cdiv(d->N, bn); };
     if (d->N % 128 == 0 && blocks(128, 128) >= 224) {
         pl.bm = 128; pl.bn = 128;
@@ -261,7 +262,7 @@ Plan make_plan(const sgam_conv_desc *d) {
 int validate(const sgam_conv_desc *d) {
     if (!d) return SGAM_EINVAL;
     if (d->B <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->N <= 0) return SGAM_EINVAL;
-    if (d->Cin <= 0 || d->Cin % BK != 0) return SGAM_EINVAL;
+    if (d->Cin <= 0 || d->Cin % 4 != 0) return SGAM_EINVAL;
     if (d->N % 4 != 0) return SGAM_EINVAL;
     if (d->KH <= 0 || d->KW <= 0 || d->stride <= 0) return SGAM_EINVAL;
     if (d->lda < d->Cin || d->lda % 4 != 0) return SGAM_EALIGN;
@@ -277,6 +278,16 @@ extern "C" int64_t sgam_conv2d_workspace_bytes(const sgam_conv_desc *d) {
     const Plan pl = make_plan(d);
     if (pl.ksplit <= 1) return 0;
     return (int64_t)pl.ksplit * d->B * d->Ho * d->Wo * d->N * (int64_t)sizeof(float);
+}
+
+extern "C" int sgam_conv2d_plan(const sgam_conv_desc *d, int32_t *bm, int32_t *bn, int32_t *ksplit) {
+    const int rc = validate(d);
+    if (rc != SGAM_OK) return rc;
+    const Plan pl = make_plan(d);
+    if (bm) *bm = pl.bm;
+    if (bn) *bn = pl.bn;
+    if (ksplit) *ksplit = pl.ksplit;
+    return SGAM_OK;
 }
 
 extern "C" int sgam_conv2d_nhwc_f32(const sgam_conv_desc *d, const float *x, const float *w_packed,

@@ -1,0 +1,52 @@
+"""Scene-parallel multi-GPU support: independent trajectories shard across ranks, one process
+per GPU, weights replicated, NO data-path collective.  The only communication is one tiny all-gather of the
+per-rank (frames, seconds, checksum) record at the end — RCCL over xGMI on the GPU box (backend "nccl"),
+gloo in the CPU tests."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+def init(backend=None):
+    """Initialise torch.distributed from the torchrun environment; no-op for a single process."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_scenes(num_scenes, rank, world):
+    """rank r owns scenes {s : s mod world == r} (round-robin)."""
+    return [s for s in range(num_scenes) if s % world == rank]
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def gather_metrics(frames, seconds, checksum, device):
+    """All-gather one (frames, seconds, checksum) record per rank.  Returns dict(total_frames, max_seconds,
+    frames_per_s, per_rank=[...]) on every rank.  24 bytes per rank: latency-bound, no bandwidth tuning."""
+    rec = torch.tensor([float(frames), float(seconds), float(checksum)], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        out = [torch.zeros_like(rec) for _ in range(dist.get_world_size())]
+        dist.all_gather(out, rec)
+    else:
+        out = [rec]
+    per_rank = [tuple(t.tolist()) for t in out]
+    total = sum(r[0] for r in per_rank)
+    tmax = max(r[1] for r in per_rank)
+    return {"total_frames": total, "max_seconds": tmax, "frames_per_s": total / tmax if tmax > 0 else 0.0,
+            "per_rank": per_rank}

@@ -61,8 +61,31 @@ def pack_conv_weight(w_oihw, cout_pad=None, cin_pad=None):
 # ------------------------------------------------------------------------------------------------
 # conv / GEMM (MFMA implicit GEMM)
 # ------------------------------------------------------------------------------------------------
+CONV_TRACE = None  # set to a list by bench.py's profiling pass: (desc copy, flops, start event, end event)
+
+
+def conv_plan(desc):
+    bm, bn, ks = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    check(_lib.load().sgam_conv2d_plan(ctypes.byref(desc), ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(ks)),
+          "sgam_conv2d_plan")
+    return bm.value, bn.value, ks.value
+
+
 def _run_conv(desc, x, w, bias, residual, out):
     lib = _lib.load()
+    if CONV_TRACE is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        _run_conv_inner(lib, desc, x, w, bias, residual, out)
+        ev1.record()
+        flops = 2.0 * desc.B * desc.Ho * desc.Wo * desc.n_valid * desc.KH * desc.KW * desc.Cin
+        CONV_TRACE.append((conv_plan(desc), (desc.B * desc.Ho * desc.Wo, desc.n_valid, desc.KH * desc.KW * desc.Cin),
+                           flops, ev0, ev1))
+        return out
+    return _run_conv_inner(lib, desc, x, w, bias, residual, out)
+
+
+def _run_conv_inner(lib, desc, x, w, bias, residual, out):
     ws_bytes = lib.sgam_conv2d_workspace_bytes(ctypes.byref(desc))
     if ws_bytes < 0:
         raise SgamHipError(f"sgam_conv2d: unsupported shape {[(f, getattr(desc, f)) for f, _ in desc._fields_]}")

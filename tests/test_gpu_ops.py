@@ -1,0 +1,182 @@
+"""GPU: every HIP kernel family of the VQGAN against the oracle's torch-CPU fp32 op on the same seeded input
+(tolerances are fp32-roundoff class: both sides accumulate in fp32, only the summation order differs)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from sgam_neurips22_amd import ops, testing
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _close(a, b, atol, what=""):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    err = (a - b).abs().max().item()
+    scale = max(1.0, b.abs().max().item())
+    assert err <= atol * scale, f"{what}: max abs err {err:.3e} (scale {scale:.3g})"
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("B,C,HW", [(1, 4, 64 * 64), (2, 256, 16 * 16), (1, 130, 77)])
+def test_layout_hops(B, C, HW):
+    x = testing.seeded_tensor("layout", (B, C, HW, 1)).to(DEV)
+    y = ops.nchw_to_nhwc(x)
+    assert torch.equal(y.cpu(), x.permute(0, 2, 3, 1).cpu())
+    assert torch.equal(ops.nhwc_to_nchw(y).cpu(), x.cpu())
+
+
+# (tag, B, Cin, Cout, H, W, k, stride, pad(t,l,b,r), upsample)
+CONV_CASES = [
+    ("3x3_128_128_big", 1, 128, 128, 64, 64, 3, 1, (1, 1, 1, 1), False),     # 128x128 tile path (M=4096? -> 64 tiles)
+    ("3x3_128_128_ragged", 1, 128, 128, 23, 19, 3, 1, (1, 1, 1, 1), False),  # M not a tile multiple
+    ("3x3_256_256", 2, 256, 256, 16, 16, 3, 1, (1, 1, 1, 1), False),
+    ("3x3_512_512_splitk", 1, 512, 512, 8, 8, 3, 1, (1, 1, 1, 1), False),    # split-K path
+    ("3x3_256_512", 1, 256, 512, 16, 16, 3, 1, (1, 1, 1, 1), False),
+    ("down_s2_asym", 1, 128, 128, 32, 32, 3, 2, (0, 0, 1, 1), False),
+    ("down_s2_odd", 1, 128, 128, 17, 21, 3, 2, (0, 0, 1, 1), False),
+    ("up2x_256", 1, 256, 256, 16, 12, 3, 1, (1, 1, 1, 1), True),
+    ("1x1_256_256", 1, 256, 256, 24, 24, 1, 1, (0, 0, 0, 0), False),
+    ("1x1_128_256_nin", 2, 128, 256, 16, 16, 1, 1, (0, 0, 0, 0), False),
+    ("3x3_128_4_out", 1, 128, 4, 32, 32, 3, 1, (1, 1, 1, 1), False),         # Cout padded to 64, n_valid 4
+    ("3x3_512_256_out", 1, 512, 256, 16, 16, 3, 1, (1, 1, 1, 1), False),
+    ("3x3_128_128_256sq", 1, 128, 128, 256, 256, 3, 1, (1, 1, 1, 1), False),  # the dominant layer shape
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: c[0])
+def test_conv2d_matches_oracle(case):
+    tag, B, Cin, Cout, H, W, k, stride, pad, ups = case
+    x = testing.seeded_tensor(tag + ".x", (B, Cin, H, W))
+    w = testing.seeded_tensor(tag + ".w", (Cout, Cin, k, k), scale=(1.0 / (Cin * k * k)) ** 0.5)
+    b = testing.seeded_tensor(tag + ".b", (Cout,), scale=0.1)
+    xr = F.interpolate(x, scale_factor=2.0, mode="nearest") if ups else x
+    xr = F.pad(xr, (pad[1], pad[3], pad[0], pad[2]))
+    ref = F.conv2d(xr, w, b, stride=stride)
+    res_in = testing.seeded_tensor(tag + ".r", tuple(ref.shape))
+    wp = ops.pack_conv_weight(w.to(DEV))
+    out = ops.conv2d_nhwc(_nhwc(x).to(DEV), wp, b.to(DEV), cout=Cout, kh=k, kw=k, stride=stride, pad_t=pad[0],
+                          pad_l=pad[1], pad_b=pad[2], pad_r=pad[3], upsample2x=ups)
+    assert tuple(out.shape) == (B, ref.shape[2], ref.shape[3], Cout)
+    _close(out.permute(0, 3, 1, 2), ref, 2e-5, tag)
+    out2 = ops.conv2d_nhwc(_nhwc(x).to(DEV), wp, b.to(DEV), cout=Cout, kh=k, kw=k, stride=stride, pad_t=pad[0],
+                           pad_l=pad[1], pad_b=pad[2], pad_r=pad[3], upsample2x=ups, residual=_nhwc(res_in).to(DEV))
+    _close(out2.permute(0, 3, 1, 2), ref + res_in, 2e-5, tag + "+res")
+
+
+def test_conv_is_run_to_run_deterministic():
+    x = _nhwc(testing.seeded_tensor("det.x", (1, 512, 8, 8))).to(DEV)
+    wp = ops.pack_conv_weight(testing.seeded_tensor("det.w", (512, 512, 3, 3), scale=0.02).to(DEV))
+    a = ops.conv2d_nhwc(x, wp, None, cout=512, kh=3, kw=3, pad_t=1, pad_l=1)
+    for _ in range(3):
+        assert torch.equal(a, ops.conv2d_nhwc(x, wp, None, cout=512, kh=3, kw=3, pad_t=1, pad_l=1))
+
+
+@pytest.mark.parametrize("M,N,K,strided", [(256, 256, 256, False), (4096, 4096, 256, True), (300, 68, 64, False),
+                                           (256, 4096, 256, False), (64, 256, 4096, False), (16, 512, 16, False),
+                                           (64, 64, 48, False)])
+def test_gemm_nt_transpose_detecting(M, N, K, strided):
+    """asymmetric operands (so a swapped C-write cannot pass), optional row-strided A/B views."""
+    a = testing.seeded_tensor("gemm.a", (M, 2 * K if strided else K))
+    b = testing.seeded_tensor("gemm.b", (N, 2 * K if strided else K)) * torch.linspace(0.5, 1.5, N)[:, None]
+    bias = testing.seeded_tensor("gemm.bias", (N,))
+    av, bv = (a[:, :K], b[:, K:]) if strided else (a, b)
+    ref = av.double() @ bv.double().t() + bias.double()
+    ad, bd = a.to(DEV), b.to(DEV)
+    avd, bvd = (ad[:, :K], bd[:, K:]) if strided else (ad, bd)
+    out = ops.gemm_nt(avd, bvd, bias=bias.to(DEV))
+    _close(out, ref.float(), 3e-6 * K ** 0.5, "gemm")
+    rb = testing.seeded_tensor("gemm.rb", (M,))
+    out = ops.gemm_nt(avd, bvd, bias=rb.to(DEV), bias_per_row=True)
+    _close(out, (av.double() @ bv.double().t() + rb.double()[:, None]).float(), 3e-6 * K ** 0.5, "gemm row-bias")
+
+
+@pytest.mark.parametrize("B,C,H,W", [(1, 128, 64, 64), (2, 256, 12, 12), (1, 512, 16, 16), (1, 128, 256, 256),
+                                     (1, 256, 7, 5)])
+@pytest.mark.parametrize("swish", [False, True])
+def test_groupnorm_swish(B, C, H, W, swish):
+    x = testing.seeded_tensor("gn.x", (B, C, H, W), 3.0, 0.5)
+    g = 1 + 0.1 * testing.seeded_tensor("gn.g", (C,))
+    bt = 0.1 * testing.seeded_tensor("gn.b", (C,))
+    ref = F.group_norm(x, 32, g, bt, eps=1e-6)
+    if swish:
+        ref = ref * torch.sigmoid(ref)
+    out = ops.groupnorm_nhwc(_nhwc(x).to(DEV), g.to(DEV), bt.to(DEV), swish)
+    _close(out.permute(0, 3, 1, 2), ref, 2e-5, "groupnorm")
+
+
+@pytest.mark.parametrize("rows,cols", [(64, 256), (128, 4096), (8, 16384), (5, 1024)])
+def test_softmax_rows(rows, cols):
+    s = testing.seeded_tensor("sm", (rows, cols), 4.0)
+    s[0, 3] = 60.0  # a spike
+    ref = F.softmax(s * 0.0625, dim=1)
+    out = ops.softmax_rows_(s.to(DEV).clone(), 0.0625)
+    _close(out, ref, 1e-6, "softmax")
+    assert torch.allclose(out.sum(1).cpu(), torch.ones(rows), atol=1e-5)
+
+
+def test_encode_head():
+    x, mask = testing.rect_hole_input(2, 32, 48)
+    w = testing.seeded_tensor("head.w", (4, 5, 1, 1), 0.4)
+    b = testing.seeded_tensor("head.b", (4,), 0.1)
+    ref = F.conv2d(torch.cat([x, mask.float()], 1), w, b)
+    out = ops.encode_head(x.to(DEV), mask.to(DEV), w.to(DEV), b.to(DEV), ld=32)
+    assert out.shape == (2, 32, 48, 32)
+    _close(out[..., :4].permute(0, 3, 1, 2), ref, 1e-6, "encode head")
+    assert torch.count_nonzero(out[..., 4:]).item() == 0
+    out0 = ops.encode_head(x.to(DEV), None, w.to(DEV), b.to(DEV))
+    _close(out0[..., :4].permute(0, 3, 1, 2), F.conv2d(torch.cat([x, torch.zeros_like(mask).float()], 1), w, b), 1e-6, "no mask")
+
+
+@pytest.mark.parametrize("T,n_e", [(256, 4096), (256, 16384), (1024, 4096), (16, 4096)])
+def test_vq_nearest_bit_exact_indices(T, n_e):
+    from oracle import vqgan as OV
+    z = testing.seeded_tensor("vq.z", (T, 256), 0.5, 0.1)
+    seed = 0
+    while True:
+        cb = testing.codebook_from_stats(0.1, 0.5, n_e, 256, seed)
+        if float(testing.top2_relative_gap(z, cb).min()) >= 1e-4:
+            break
+        seed += 1
+    sd = {"quantize.embedding.weight": cb}
+    side = int(T ** 0.5)
+    zq_ref, idx_ref, d_ref = OV.quantize(sd, z.view(1, side, T // side, 256).permute(0, 3, 1, 2))
+    cbd = cb.to(DEV)
+    idx, zq, dist = ops.vq_nearest(z.to(DEV), cbd, ops.row_sumsq(cbd), straight_through=True, want_dist=True)
+    assert torch.equal(idx.cpu(), idx_ref.reshape(-1)), "codebook indices must be bit-exact on margin-guarded inputs"
+    # z + (e - z) evaluated in the reference's order: bit-exact given equal indices
+    assert torch.equal(zq.cpu(), zq_ref.permute(0, 2, 3, 1).reshape(T, 256))
+    _close(dist, d_ref, 2e-6, "distances")
+    # pure gather is a copy
+    assert torch.equal(ops.vq_gather(cbd, idx).cpu(), cb[idx_ref.reshape(-1)])
+
+
+def test_vq_first_index_wins_exact_ties():
+    z = torch.zeros((64, 256))
+    z[:, 0] = 1.0
+    cb = testing.codebook_from_stats(0.0, 1.0, 4096, 256, 0)
+    cb[7] = 0.0; cb[7, 0] = 1.0      # two identical nearest rows: 7 and 3000
+    cb[3000] = cb[7]
+    cbd = cb.to(DEV)
+    idx, _, _ = ops.vq_nearest(z.to(DEV), cbd, ops.row_sumsq(cbd))
+    assert torch.all(idx.cpu() == 7)
+
+
+def test_vq_topk_order():
+    d = testing.seeded_tensor("topk", (32, 4096)).abs()
+    d[:, 100] = d[:, 5]  # a tie
+    vals, inds = ops.vq_topk(d.to(DEV), 8)
+    ref = torch.topk(d, 8, dim=1, largest=False)
+    assert torch.equal(vals.cpu(), ref.values)
+    for r in range(32):
+        got, want = inds[r].cpu().tolist(), sorted(range(4096), key=lambda j: (float(d[r, j]), j))[:8]
+        assert got == want
+
+
+def test_cpu_tensor_is_rejected_loudly():
+    with pytest.raises(ops.SgamHipError):
+        ops.groupnorm_nhwc(torch.zeros(1, 4, 4, 128), torch.ones(128), torch.zeros(128), True)
