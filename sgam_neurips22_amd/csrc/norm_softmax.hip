@@ -56,22 +56,40 @@ __global__ __launch_bounds__(GN_THREADS) void gn_partial_kernel(const float *__r
     }
 }
 
-__global__ void gn_finalize_kernel(const double *__restrict__ partial, const float *__restrict__ gamma,
-                                   const float *__restrict__ beta, float *__restrict__ scale_shift, int HW, int C,
-                                   int groups, int nchunk, float eps) {
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double *__restrict__ partial,
+                                                          const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta,
+                                                          float *__restrict__ scale_shift, int HW, int C, int groups,
+                                                          int nchunk, float eps) {
+    // 256 lanes: lane -> (group g = t % groups, part = t / groups); each lane sums chunks part, part+np, ...
+    // (independent loads, unrolled), then `np` partials per group are combined in a fixed order.
     const int b = blockIdx.x;
+    __shared__ double sh_s[256], sh_ss[256];
     __shared__ float sh_mean[64], sh_rstd[64];
+    const int np = 256 / groups;
+    const int g = threadIdx.x % groups, part = threadIdx.x / groups;
+    double s = 0.0, ss = 0.0;
+    if (part < np) {
+        const double *base = partial + ((int64_t)b * nchunk * groups + g) * 2;
+#pragma unroll 4
+        for (int k = part; k < nchunk; k += np) {
+            const double2 v = *reinterpret_cast<const double2 *>(base + (int64_t)k * groups * 2);
+            s += v.x;
+            ss += v.y;
+        }
+    }
+    sh_s[threadIdx.x] = s;
+    sh_ss[threadIdx.x] = ss;
+    __syncthreads();
     if ((int)threadIdx.x < groups) {
-        const int g = threadIdx.x;
-        double s = 0.0, ss = 0.0;
-        for (int k = 0; k < nchunk; ++k) {
-            const double *o = partial + (((int64_t)b * nchunk + k) * groups + g) * 2;
-            s += o[0];
-            ss += o[1];
+        double ts = 0.0, tss = 0.0;
+        for (int q = 0; q < np; ++q) {
+            ts += sh_s[q * groups + g];
+            tss += sh_ss[q * groups + g];
         }
         const double n = (double)HW * (double)(C / groups);
-        const double mean = s / n;
-        double var = ss / n - mean * mean;
+        const double mean = ts / n;
+        double var = tss / n - mean * mean;
         if (var < 0.0) var = 0.0;
         sh_mean[g] = (float)mean;
         sh_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
@@ -79,10 +97,10 @@ __global__ void gn_finalize_kernel(const double *__restrict__ partial, const flo
     __syncthreads();
     const int cpg = C / groups;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const int g = c / cpg;
-        const float sc = sh_rstd[g] * gamma[c];
+        const int gg = c / cpg;
+        const float sc = sh_rstd[gg] * gamma[c];
         scale_shift[((int64_t)b * C + c) * 2 + 0] = sc;
-        scale_shift[((int64_t)b * C + c) * 2 + 1] = beta[c] - sh_mean[g] * sc;
+        scale_shift[((int64_t)b * C + c) * 2 + 1] = beta[c] - sh_mean[gg] * sc;
     }
 }
 
