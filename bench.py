@@ -57,6 +57,16 @@ def profile_conv_launches(scene):
     torch.cuda.synchronize()
     trace, ops.CONV_TRACE = ops.CONV_TRACE, None
     agg = {}
+    if os.environ.get("SGAM_DUMP_SHAPES"):
+        shapes = {}
+        for plan, mnk, flops, e0, e1 in trace:
+            s = shapes.setdefault((plan, mnk), [0, 0.0, flops])
+            s[0] += 1
+            s[1] += e0.elapsed_time(e1)
+        print("plan(bm,bn,ks)        M      N      K   n   avg_us   TF/s   total_ms", file=sys.stderr)
+        for (plan, mnk), (n, ms, fl) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+            print(f"{str(plan):16s} {mnk[0]:7d} {mnk[1]:6d} {mnk[2]:6d} {n:3d} {1e3 * ms / n:8.1f} {fl / (ms / n * 1e-3) / 1e12:6.1f} "
+                  f"{ms:9.3f}", file=sys.stderr)
     for plan, mnk, flops, e0, e1 in trace:
         a = agg.setdefault(plan[:2], {"launches": 0, "flops": 0.0, "ms": 0.0})
         a["launches"] += 1

@@ -68,6 +68,13 @@ int sgam_conv2d_plan(const sgam_conv_desc *d, int32_t *bm, int32_t *bn, int32_t 
 int sgam_conv2d_nhwc_f32(const sgam_conv_desc *d, const float *x, const float *w_packed,
                          const float *bias, const float *residual, float *out, void *workspace,
                          int64_t workspace_bytes, void *stream);
+/* Same, with the GroupNorm(+swish) of the INPUT fused into the operand staging (ResnetBlock norm1/norm2,
+ * AttnBlock.norm, norm_out: diffusionmodules/model.py:119-127, 170, 429-430, 536-537): x is the RAW activation,
+ * gn_scale_shift the [B][Cin][2] table of sgam_groupnorm_stats_nhwc_f32 (NULL = plain conv), gn_swish 0/1.
+ * Zero padding stays zero (it pads the normalised map, as in the reference). */
+int sgam_conv2d_gn_nhwc_f32(const sgam_conv_desc *d, const float *x, const float *gn_scale_shift,
+                            int32_t gn_swish, const float *w_packed, const float *bias, const float *residual,
+                            float *out, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* [Cout][Cin][KH][KW] (torch Conv2d.weight) -> [Cout_pad][KH*KW][Cin_pad], zero padded. */
 int sgam_pack_conv_weight(const float *w_oihw, float *w_packed, int32_t Cout, int32_t Cin, int32_t KH,
@@ -84,6 +91,14 @@ int64_t sgam_groupnorm_workspace_bytes(int32_t B, int32_t HW, int32_t C);
 int sgam_groupnorm_nhwc_f32(const float *x, const float *gamma, const float *beta, float *y, int32_t B,
                             int32_t HW, int32_t C, int32_t groups, float eps, int32_t fuse_swish,
                             void *workspace, int64_t workspace_bytes, void *stream);
+
+/* Statistics half of K4 for the FUSED path: writes the per-(batch, channel) table
+ *   scale_shift[b][c] = { rstd[b,g(c)] * gamma[c],  beta[c] - mean[b,g(c)] * rstd[b,g(c)] * gamma[c] }   ([B][C][2] floats)
+ * which sgam_conv2d_gn_nhwc_f32 applies (with optional swish) to its A operand while staging it — the
+ * normalised activation is never written to HBM.  Same constraints / workspace as sgam_groupnorm_nhwc_f32. */
+int sgam_groupnorm_stats_nhwc_f32(const float *x, const float *gamma, const float *beta, float *scale_shift,
+                                  int32_t B, int32_t HW, int32_t C, int32_t groups, float eps, void *workspace,
+                                  int64_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * K5 — row softmax of the attention scores, in place: s[r][:] = softmax(scale * s[r][:]).

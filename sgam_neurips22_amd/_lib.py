@@ -24,10 +24,14 @@ PROTOTYPES = {
     "sgam_conv2d_plan": (c_i32, [ctypes.POINTER(ConvDesc), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32),
                                  ctypes.POINTER(c_i32)]),
     "sgam_conv2d_nhwc_f32": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "sgam_conv2d_gn_nhwc_f32": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64,
+                                        c_vp]),
     "sgam_pack_conv_weight": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "sgam_groupnorm_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
     "sgam_groupnorm_nhwc_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp,
                                         c_i64, c_vp]),
+    "sgam_groupnorm_stats_nhwc_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_i64,
+                                              c_vp]),
     "sgam_softmax_rows_f32": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_f32, c_vp]),
     "sgam_row_sumsq_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
     "sgam_vq_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),

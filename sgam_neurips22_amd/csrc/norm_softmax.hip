@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double *__restri
 }
 
 // x * sigmoid(x) with sigmoid = 1/(1+exp(-x)), the expression order of diffusionmodules/model.py:29-31
-__device__ __forceinline__ float swish_f(float v) { return v * (1.0f / (1.0f + expf(-v))); }
+__device__ __forceinline__ float swish_f(float v) { return sgam_swish(v); }  // same function as the fused conv prologue
 
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__ x, const float *__restrict__ scale_shift,
                                                        float *__restrict__ y, int64_t total4, int HW, int C,
@@ -232,6 +232,27 @@ extern "C" int sgam_groupnorm_nhwc_f32(const float *x, const float *gamma, const
     int blocks = sgam_cdiv(total4, 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), 0, s, x, scale_shift, y, total4, HW, C, fuse_swish);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+extern "C" int sgam_groupnorm_stats_nhwc_f32(const float *x, const float *gamma, const float *beta,
+                                             float *scale_shift, int32_t B, int32_t HW, int32_t C, int32_t groups,
+                                             float eps, void *workspace, int64_t workspace_bytes, void *stream) {
+    if (!x || !scale_shift || !gamma || !beta || B <= 0 || HW <= 0) return SGAM_EINVAL;
+    if (C <= 0 || C % 128 != 0 || C > 1024 || groups <= 0 || groups > 64 || C % groups != 0) return SGAM_EINVAL;
+    if ((C / groups) % 4 != 0 || (C / 4) % groups != 0 || GN_THREADS % (C / 4) != 0 || 256 % groups != 0) return SGAM_EINVAL;
+    if (!sgam_aligned16(x) || !sgam_aligned16(scale_shift) || !sgam_aligned16(workspace)) return SGAM_EALIGN;
+    if (!workspace || workspace_bytes < sgam_groupnorm_workspace_bytes(B, HW, C)) return SGAM_EWORKSPACE;
+    hipStream_t s = sgam_stream(stream);
+    const int nchunk = gn_nchunk(HW, C);
+    const int pix_per_chunk = sgam_cdiv(HW, nchunk);
+    double *partial = (double *)workspace;
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, B), dim3(GN_THREADS), 0, s, x, partial, HW, C, groups,
+                       pix_per_chunk);
+    SGAM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, partial, gamma, beta, scale_shift, HW, C, groups,
+                       nchunk, eps);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
 }

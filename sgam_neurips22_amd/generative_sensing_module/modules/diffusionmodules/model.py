@@ -30,14 +30,16 @@ class Conv2d(nn.Conv2d):
             self._pack_key = key
         return self._pack, self._pack_bias
 
-    def forward_nhwc(self, x, residual=None, upsample2x=False, pad=None):
+    def forward_nhwc(self, x, residual=None, upsample2x=False, pad=None, gn=None):
+        """gn = (scale/shift table from GroupNorm.stats_nhwc, swish flag): GroupNorm(+swish) of the input fused
+        into the operand staging of the implicit GEMM."""
         wp, b = self._packed()
         kh, kw = self.kernel_size
         if pad is None:
             pad = (self.padding[0], self.padding[1], self.padding[0], self.padding[1])  # t, l, b, r
         return ops.conv2d_nhwc(x, wp, b, cout=self.out_channels, kh=kh, kw=kw, stride=self.stride[0],
                                pad_t=pad[0], pad_l=pad[1], pad_b=pad[2], pad_r=pad[3], upsample2x=upsample2x,
-                               residual=residual, cin=wp.shape[1] // (kh * kw))
+                               residual=residual, cin=wp.shape[1] // (kh * kw), gn=gn)
 
     def forward(self, x):
         cin_pad = self._packed()[0].shape[1] // (self.kernel_size[0] * self.kernel_size[1])
@@ -45,12 +47,30 @@ class Conv2d(nn.Conv2d):
 
 
 class GroupNorm(nn.GroupNorm):
+    def stats_nhwc(self, x):
+        """(B,C,2) scale/shift table for the fused conv prologue."""
+        return ops.groupnorm_stats(x, self.weight.detach(), self.bias.detach(), groups=self.num_groups, eps=self.eps)
+
     def forward_nhwc(self, x, swish=False):
         return ops.groupnorm_nhwc(x, self.weight.detach(), self.bias.detach(), swish, groups=self.num_groups,
                                   eps=self.eps)
 
     def forward(self, x):
         return ops.nhwc_to_nchw(self.forward_nhwc(ops.nchw_to_nhwc(x)))
+
+
+# Measured on MI355X (profiles/, DESIGN.md §5): with fp32-in MFMA the convolution is matrix-pipe bound and the
+# per-tap re-normalisation of the fused prologue (9x the swish work, on the same wavefronts that feed the MFMAs)
+# costs more (+19 us on the 128->128 @256^2 layer) than the stand-alone HBM-bound normalise pass it removes
+# (~12 us).  The fused kernel stays available (and parity-tested) behind this switch.
+FUSE_GROUPNORM_INTO_CONV = False
+
+
+def _norm_conv(norm, swish, conv, x, **kw):
+    """GroupNorm(+swish) followed by a convolution."""
+    if FUSE_GROUPNORM_INTO_CONV:
+        return conv.forward_nhwc(x, gn=(norm.stats_nhwc(x), swish), **kw)
+    return conv.forward_nhwc(norm.forward_nhwc(x, swish=swish), **kw)
 
 
 def Normalize(in_channels):
@@ -113,11 +133,10 @@ class ResnetBlock(_NHWCModule):
                 self.nin_shortcut = Conv2d(in_channels, out_channels, kernel_size=1, stride=1, padding=0)
 
     def forward_nhwc(self, x):
-        h = self.conv1.forward_nhwc(self.norm1.forward_nhwc(x, swish=True))
-        h = self.norm2.forward_nhwc(h, swish=True)
+        h = _norm_conv(self.norm1, True, self.conv1, x)
         if self.in_channels != self.out_channels:
             x = (self.conv_shortcut if self.use_conv_shortcut else self.nin_shortcut).forward_nhwc(x)
-        return self.conv2.forward_nhwc(h, residual=x)  # x + h in the conv epilogue
+        return _norm_conv(self.norm2, True, self.conv2, h, residual=x)  # x + h in the conv epilogue
 
     def forward(self, x, temb=None):
         if temb is not None:
@@ -126,8 +145,9 @@ class ResnetBlock(_NHWCModule):
 
 
 class AttnBlock(_NHWCModule):
-    """Single-head spatial self-attention (reference :168-192) as four MFMA GEMMs + a row softmax:
-    [q|k] = h Wqk^T, v^T = Wv h^T, S = q k^T, P = softmax(S c^-1/2), O = P v, out = x + O Wp^T."""
+    """Single-head spatial self-attention (reference :168-192) as MFMA GEMMs + a row softmax:
+    [q|k|v] = GN(x) Wqkv^T (GroupNorm fused into the operand staging), S = q k^T, P = softmax(S c^-1/2),
+    O = P v (v transposed once so that the key axis is contiguous), out = x + O Wp^T."""
 
     def __init__(self, in_channels):
         super().__init__()
@@ -143,30 +163,31 @@ class AttnBlock(_NHWCModule):
         key = tuple((w.data_ptr(), w._version) for w in ws) + (str(ws[0].device),)
         if getattr(self, "_qkv_key", None) != key:
             c = self.in_channels
-            self._wqk = torch.cat([self.q.weight.detach().reshape(c, c), self.k.weight.detach().reshape(c, c)],
-                                  0).float().contiguous()
-            self._bqk = torch.cat([self.q.bias.detach(), self.k.bias.detach()]).float().contiguous()
-            self._wv = self.v.weight.detach().reshape(c, c).float().contiguous()
-            self._bv = self.v.bias.detach().float().contiguous()
+            self._wqkv = torch.cat([m.weight.detach().reshape(c, c) for m in (self.q, self.k, self.v)], 0).float().contiguous()
+            self._bqkv = torch.cat([m.bias.detach() for m in (self.q, self.k, self.v)]).float().contiguous()
             self._qkv_key = key
-        return self._wqk, self._bqk, self._wv, self._bv
+        return self._wqkv, self._bqkv
 
     def forward_nhwc(self, x):
         B, H, W, C = x.shape
         n = H * W
-        wqk, bqk, wv, bv = self._packed_qkv()
+        wqkv, bqkv = self._packed_qkv()
         wp, bp = self.proj_out._packed()
-        h = self.norm.forward_nhwc(x, swish=False)
+        if FUSE_GROUPNORM_INTO_CONV:
+            table, h = self.norm.stats_nhwc(x), x                         # (B, C, 2), no swish for attention
+        else:
+            table, h = None, self.norm.forward_nhwc(x, swish=False)
         out = torch.empty_like(x)
         scale = int(C) ** (-0.5)
         for b in range(B):
-            hb = h[b].reshape(n, C)
-            qk = ops.gemm_nt(hb, wqk, bias=bqk)                        # (n, 2C)
-            vt = ops.gemm_nt(wv, hb, bias=bv, bias_per_row=True)       # (C, n) = v^T
-            s = ops.gemm_nt(qk[:, :C], qk[:, C:])                      # (n, n) scores
+            xb = x[b].reshape(n, C)
+            qkv = ops.gemm_nt(h[b].reshape(n, C), wqkv, bias=bqkv,
+                              gn=None if table is None else (table[b:b + 1], False))   # (n, 3C)
+            vt = ops.nhwc_to_nchw(qkv[:, 2 * C:].unsqueeze(0).unsqueeze(0), c=C).view(C, n)   # (C, n) = v^T
+            s = ops.gemm_nt(qkv[:, :C], qkv[:, C:2 * C])                   # (n, n) scores
             ops.softmax_rows_(s, scale)
-            o = ops.gemm_nt(s, vt)                                     # (n, C)
-            ops.gemm_nt(o, wp, bias=bp, residual=x[b].reshape(n, C), out=out[b].reshape(n, C))
+            o = ops.gemm_nt(s, vt)                                         # (n, C)
+            ops.gemm_nt(o, wp, bias=bp, residual=xb, out=out[b].reshape(n, C))
         return out
 
 
@@ -220,7 +241,7 @@ class Encoder(_NHWCModule):
             if lv != self.num_resolutions - 1:
                 h = stage.downsample.forward_nhwc(h)
         h = self.mid.block_2.forward_nhwc(self.mid.attn_1.forward_nhwc(self.mid.block_1.forward_nhwc(h)))
-        return self.conv_out.forward_nhwc(self.norm_out.forward_nhwc(h, swish=True))
+        return _norm_conv(self.norm_out, True, self.conv_out, h)
 
     def forward(self, x):
         return ops.nhwc_to_nchw(self.forward_nhwc(ops.nchw_to_nhwc(x, c_pad=32)))
@@ -278,4 +299,4 @@ class Decoder(_NHWCModule):
                 h = stage.upsample.forward_nhwc(h)
         if self.give_pre_end:
             return h
-        return self.conv_out.forward_nhwc(self.norm_out.forward_nhwc(h, swish=True))
+        return _norm_conv(self.norm_out, True, self.conv_out, h)

@@ -71,32 +71,33 @@ def conv_plan(desc):
     return bm.value, bn.value, ks.value
 
 
-def _run_conv(desc, x, w, bias, residual, out):
+def _run_conv(desc, x, w, bias, residual, out, gn=None):
     lib = _lib.load()
     if CONV_TRACE is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-        _run_conv_inner(lib, desc, x, w, bias, residual, out)
+        _run_conv_inner(lib, desc, x, w, bias, residual, out, gn)
         ev1.record()
         flops = 2.0 * desc.B * desc.Ho * desc.Wo * desc.n_valid * desc.KH * desc.KW * desc.Cin
         CONV_TRACE.append((conv_plan(desc), (desc.B * desc.Ho * desc.Wo, desc.n_valid, desc.KH * desc.KW * desc.Cin),
                            flops, ev0, ev1))
         return out
-    return _run_conv_inner(lib, desc, x, w, bias, residual, out)
+    return _run_conv_inner(lib, desc, x, w, bias, residual, out, gn)
 
 
-def _run_conv_inner(lib, desc, x, w, bias, residual, out):
+def _run_conv_inner(lib, desc, x, w, bias, residual, out, gn=None):
     ws_bytes = lib.sgam_conv2d_workspace_bytes(ctypes.byref(desc))
     if ws_bytes < 0:
         raise SgamHipError(f"sgam_conv2d: unsupported shape {[(f, getattr(desc, f)) for f, _ in desc._fields_]}")
     ws = torch.empty((ws_bytes,), device=x.device, dtype=torch.uint8) if ws_bytes else None
-    check(lib.sgam_conv2d_nhwc_f32(ctypes.byref(desc), _p(x), _p(w), _p(bias), _p(residual), _p(out), _p(ws),
-                                   ws_bytes, _stream()), "sgam_conv2d_nhwc_f32")
+    table, swish = gn if gn is not None else (None, False)
+    check(lib.sgam_conv2d_gn_nhwc_f32(ctypes.byref(desc), _p(x), _p(table), int(swish), _p(w), _p(bias), _p(residual),
+                                      _p(out), _p(ws), ws_bytes, _stream()), "sgam_conv2d_gn_nhwc_f32")
     return out
 
 
 def conv2d_nhwc(x, w_packed, bias, *, cout, kh, kw, stride=1, pad_t=0, pad_l=0, pad_b=None, pad_r=None,
-                upsample2x=False, residual=None, cin=None):
+                upsample2x=False, residual=None, cin=None, gn=None):
     """x (B,Hi,Wi,Cx) NHWC fp32 -> (B,Ho,Wo,cout).  w_packed from pack_conv_weight (rows padded to 64,
     Cin padded to 32).  `cin` = channels of x actually contracted (defaults to Cx, must be % 32)."""
     _need_cuda(x, w_packed)
@@ -112,10 +113,10 @@ def conv2d_nhwc(x, w_packed, bias, *, cout, kh, kw, stride=1, pad_t=0, pad_l=0, 
     d = ConvDesc(B=B, Hi=Hi, Wi=Wi, Cin=cin, Ho=Ho, Wo=Wo, N=N, KH=kh, KW=kw, stride=stride, pad_t=pad_t,
                  pad_l=pad_l, upsample2x=int(upsample2x), lda=x.stride(2), ldb=w_packed.stride(0), ldc=cout,
                  ldr=(residual.stride(2) if residual is not None else 0), n_valid=cout, bias_per_row=0)
-    return _run_conv(d, x, w_packed, bias, residual, out)
+    return _run_conv(d, x, w_packed, bias, residual, out, gn)
 
 
-def gemm_nt(a, b, bias=None, residual=None, bias_per_row=False, out=None):
+def gemm_nt(a, b, bias=None, residual=None, bias_per_row=False, out=None, gn=None):
     """out[M][N] = a[M][K] @ b[N][K]^T (+bias) (+residual).  a, b: 2-D fp32 CUDA tensors with unit
     inner stride (row strides free, so column slices of a fused projection can be passed directly).
     K % 32 == 0, N % 4 == 0."""
@@ -129,7 +130,7 @@ def gemm_nt(a, b, bias=None, residual=None, bias_per_row=False, out=None):
                  lda=a.stride(0), ldb=b.stride(0), ldc=out.stride(0),
                  ldr=(residual.stride(0) if residual is not None else 0), n_valid=N,
                  bias_per_row=int(bias_per_row))
-    return _run_conv(d, a, b, bias, residual, out)
+    return _run_conv(d, a, b, bias, residual, out, gn)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -147,6 +148,22 @@ def groupnorm_nhwc(x, gamma, beta, swish, groups=32, eps=1e-6):
     check(lib.sgam_groupnorm_nhwc_f32(_p(x), _p(gamma), _p(beta), _p(y), B, H * W, C, groups, eps, int(swish),
                                       _p(ws), ws_bytes, _stream()), "sgam_groupnorm_nhwc_f32")
     return y
+
+
+def groupnorm_stats(x, gamma, beta, groups=32, eps=1e-6):
+    """Statistics-only GroupNorm: returns the (B, C, 2) {scale, shift} table consumed by the fused conv prologue
+    (`gn=(table, swish)` of conv2d_nhwc / gemm_nt)."""
+    _need_cuda(x, gamma, beta)
+    B, H, W, C = x.shape
+    lib = _lib.load()
+    ws_bytes = lib.sgam_groupnorm_workspace_bytes(B, H * W, C)
+    if ws_bytes < 0:
+        raise SgamHipError(f"sgam_groupnorm: unsupported shape B={B} HW={H * W} C={C}")
+    ws = torch.empty((ws_bytes,), device=x.device, dtype=torch.uint8)
+    table = torch.empty((B, C, 2), device=x.device, dtype=torch.float32)
+    check(lib.sgam_groupnorm_stats_nhwc_f32(_p(x), _p(gamma), _p(beta), _p(table), B, H * W, C, groups, eps, _p(ws),
+                                            ws_bytes, _stream()), "sgam_groupnorm_stats_nhwc_f32")
+    return table
 
 
 def softmax_rows_(s, scale):

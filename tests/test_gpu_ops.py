@@ -68,6 +68,35 @@ def test_conv2d_matches_oracle(case):
     _close(out2.permute(0, 3, 1, 2), ref + res_in, 2e-5, tag + "+res")
 
 
+@pytest.mark.parametrize("B,C,Cout,H,W,k,swish,ups", [(1, 128, 128, 40, 36, 3, True, False), (2, 256, 128, 16, 16, 3, True, False),
+                                                       (1, 512, 512, 8, 8, 3, True, False), (1, 256, 256, 12, 12, 1, False, False),
+                                                       (1, 256, 256, 10, 14, 3, True, True)])
+def test_conv_with_fused_groupnorm_prologue(B, C, Cout, H, W, k, swish, ups):
+    """GroupNorm(+swish) applied inside the conv's operand staging == normalise-then-conv of the reference, and
+    bit-identical to this backend's own unfused path (same expression order)."""
+    x = testing.seeded_tensor("gnconv.x", (B, C, H, W), 2.0, 0.3)
+    g = 1 + 0.1 * testing.seeded_tensor("gnconv.g", (C,))
+    bt = 0.1 * testing.seeded_tensor("gnconv.b", (C,))
+    w = testing.seeded_tensor("gnconv.w", (Cout, C, k, k), scale=(1.0 / (C * k * k)) ** 0.5)
+    b = testing.seeded_tensor("gnconv.bias", (Cout,), scale=0.1)
+    h = F.group_norm(x, 32, g, bt, eps=1e-6)
+    if swish:
+        h = h * torch.sigmoid(h)
+    if ups:
+        h = F.interpolate(h, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(h, w, b, padding=k // 2)
+    xd = _nhwc(x).to(DEV)
+    wp = ops.pack_conv_weight(w.to(DEV))
+    table = ops.groupnorm_stats(xd, g.to(DEV), bt.to(DEV))
+    assert table.shape == (B, C, 2)
+    fused = ops.conv2d_nhwc(xd, wp, b.to(DEV), cout=Cout, kh=k, kw=k, pad_t=k // 2, pad_l=k // 2, upsample2x=ups,
+                            gn=(table, swish))
+    _close(fused.permute(0, 3, 1, 2), ref, 3e-5, "fused GN conv")
+    unfused = ops.conv2d_nhwc(ops.groupnorm_nhwc(xd, g.to(DEV), bt.to(DEV), swish), wp, b.to(DEV), cout=Cout, kh=k, kw=k,
+                              pad_t=k // 2, pad_l=k // 2, upsample2x=ups)
+    assert torch.equal(fused, unfused)
+
+
 def test_conv_is_run_to_run_deterministic():
     x = _nhwc(testing.seeded_tensor("det.x", (1, 512, 8, 8))).to(DEV)
     wp = ops.pack_conv_weight(testing.seeded_tensor("det.w", (512, 512, 3, 3), scale=0.02).to(DEV))
