@@ -36,6 +36,7 @@ from sgam_neurips22_amd.inference_pipeline import InfiniteSceneGeneration, synth
 
 DATASET = "google_earth"
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 256 CUs x 2.4 GHz
+H16_MFMA_PEAK_TFLOPS = 2500.0   # dense bf16/fp16 MFMA peak (AMD's 5 PF figure includes 2:1 sparsity)
 GFLOP_PER_FRAME = 486.4         # VQGAN at 256x256, B=1
 
 
@@ -68,7 +69,7 @@ def profile_conv_launches(scene):
             print(f"{str(plan):16s} {mnk[0]:7d} {mnk[1]:6d} {mnk[2]:6d} {n:3d} {1e3 * ms / n:8.1f} {fl / (ms / n * 1e-3) / 1e12:6.1f} "
                   f"{ms:9.3f}", file=sys.stderr)
     for plan, mnk, flops, e0, e1 in trace:
-        a = agg.setdefault(plan[:2], {"launches": 0, "flops": 0.0, "ms": 0.0})
+        a = agg.setdefault(plan[:2] + (plan[3],), {"launches": 0, "flops": 0.0, "ms": 0.0})
         a["launches"] += 1
         a["flops"] += flops
         a["ms"] += e0.elapsed_time(e1)
@@ -116,6 +117,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-frames", type=int, default=6, help="frames of the CPU oracle baseline (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "fp16"],
+                    help="arithmetic of the VQGAN body: f32 = parity path (fp32-in MFMA), bf16/fp16 = 16-bit MFMA path")
     args = ap.parse_args()
 
     rank, local_rank, world = sdist.init()
@@ -123,6 +126,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     model, sd, p = build_model(dev)
+    model.set_compute_dtype(args.dtype)
     seed_frame = synthetic_seed_frame(DATASET, seed_index=rank)
     n_frames = args.warmup + args.steps + 2
     scene = InfiniteSceneGeneration(model, DATASET, seed_index=rank, output_dim=(n_frames + 1, 1), seed_frame=seed_frame)
@@ -149,15 +153,19 @@ def main():
     roofline = None
     if rank == 0 and not args.no_roofline:
         agg = profile_conv_launches(scene)
-        dom = agg.get((128, 128))
+        tname = {"f32": "float32", "bf16": "bfloat16", "fp16": "float16"}[args.dtype]
+        dom = agg.get((128, 128, tname))
+        peak = FP32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else H16_MFMA_PEAK_TFLOPS
+        kname = ("conv_gemm_f32_v2_kernel<128,128> (fp32-in MFMA 32x32x2 implicit-GEMM conv)" if args.dtype == "f32" else
+                 f"conv_gemm_h16_kernel<128,128> ({args.dtype} MFMA 32x32x16 implicit-GEMM conv)")
         if dom:
             tf = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                        "kernel": "conv_gemm_f32_kernel<128,128> (fp32-in MFMA 32x32x2 implicit-GEMM conv)",
+            roofline = {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(tf / peak, 4), "traffic": None,
+                        "kernel": kname,
                         "launches_per_frame": dom["launches"], "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 1),
                         "gflop_per_frame_in_kernel": round(dom["flops"] / 1e9, 1),
-                        "all_conv_kernels": {f"{k[0]}x{k[1]}": {"launches": v["launches"], "gflop": round(v["flops"] / 1e9, 1),
+                        "all_conv_kernels": {f"{k[0]}x{k[1]}/{k[2]}": {"launches": v["launches"], "gflop": round(v["flops"] / 1e9, 1),
                                                                "ms": round(v["ms"], 3)} for k, v in agg.items()}}
     cpu = None
     if rank == 0 and world == 1 and args.cpu_frames > 0:
@@ -168,7 +176,7 @@ def main():
             "metric": "generated RGB-D frames/sec (256x256, GoogleEarth)", "value": round(g["total_frames"] / t_max, 3),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * t_max / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "GoogleEarth-Infinite 256x256 inference loop: forward-splat warp (N<=3) + VQGAN "
                                    "encode/quantise(4096)/decode + frame feedback, in-HBM frame store",
                        "frames_per_gpu": args.steps, "scenes": world, "parallelism": f"scene-parallel x{world}",

@@ -81,6 +81,34 @@ int sgam_pack_conv_weight(const float *w_oihw, float *w_packed, int32_t Cout, in
                           int32_t KW, int32_t Cout_pad, int32_t Cin_pad, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * 16-bit THROUGHPUT path (h16.hip): the same operators on bf16 (`ht` = 0) or fp16 (`ht` = 1) activations and
+ * weights, fp32 accumulation on v_mfma_f32_32x32x16_{bf16,f16}; statistics / softmax / bias / residual math in
+ * fp32.  Strides (lda, ldb, ldc, ldr) are in ELEMENTS of the respective buffer; Cin % 8 == 0.  `out_f32` != 0
+ * keeps the result in fp32 (attention scores, the latent handed to the fp32 quantiser, the final RGB-D).
+ * Not a parity path: index agreement with the fp32 path is reported, not guaranteed.
+ * ------------------------------------------------------------------------------------------ */
+int64_t sgam_conv2d_h16_workspace_bytes(const sgam_conv_desc *d);
+int sgam_conv2d_h16_plan(const sgam_conv_desc *d, int32_t *bm, int32_t *bn, int32_t *ksplit);
+int sgam_conv2d_nhwc_h16(const sgam_conv_desc *d, int32_t ht, const void *x, const void *w_packed,
+                         const float *bias, const void *residual, void *out, int32_t out_f32, void *workspace,
+                         int64_t workspace_bytes, void *stream);
+int sgam_pack_conv_weight_h16(const float *w_oihw, void *w_packed, int32_t ht, int32_t Cout, int32_t Cin,
+                              int32_t KH, int32_t KW, int32_t Cout_pad, int32_t Cin_pad, void *stream);
+int sgam_cast_f32_h16(const float *x, void *y, int32_t ht, int64_t n, void *stream);
+int sgam_cast_h16_f32(const void *x, float *y, int32_t ht, int64_t n, void *stream);
+int64_t sgam_groupnorm_h16_workspace_bytes(int32_t B, int32_t HW, int32_t C);
+int sgam_groupnorm_nhwc_h16(const void *x, const float *gamma, const float *beta, void *y, int32_t ht, int32_t B,
+                            int32_t HW, int32_t C, int32_t groups, float eps, int32_t fuse_swish, void *workspace,
+                            int64_t workspace_bytes, void *stream);
+/* p_out[r][:] (16-bit) = softmax(scale * s_in[r][:]) (fp32 scores) */
+int sgam_softmax_rows_h16(const float *s_in, void *p_out, int32_t ht, int32_t rows, int32_t cols, int32_t lds,
+                          int32_t ldp, float scale, void *stream);
+int sgam_encode_head_h16(const float *x, const uint8_t *mask, const float *w, const float *bias, void *y,
+                         int32_t ht, int32_t B, int32_t HW, int32_t ldy, void *stream);
+/* y[c][p] = x[p][c] for a [HW][ldx] 16-bit matrix (v -> v^T for the P.V product) */
+int sgam_transpose_h16(const void *x, void *y, int32_t ht, int32_t C, int32_t HW, int32_t ldx, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * K4 — GroupNorm(32 groups, eps, affine) with optional fused swish, NHWC.
  * Replaces Normalize + nonlinearity: diffusionmodules/model.py:29-35, used at :119-127, :170,
  * :429-430, :536-537.  Biased variance, fp32 data, fp64 cross-thread accumulation.

@@ -27,6 +27,20 @@ PROTOTYPES = {
     "sgam_conv2d_gn_nhwc_f32": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64,
                                         c_vp]),
     "sgam_pack_conv_weight": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "sgam_conv2d_h16_workspace_bytes": (c_i64, [ctypes.POINTER(ConvDesc)]),
+    "sgam_conv2d_h16_plan": (c_i32, [ctypes.POINTER(ConvDesc), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32),
+                                     ctypes.POINTER(c_i32)]),
+    "sgam_conv2d_nhwc_h16": (c_i32, [ctypes.POINTER(ConvDesc), c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i64,
+                                     c_vp]),
+    "sgam_pack_conv_weight_h16": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "sgam_cast_f32_h16": (c_i32, [c_vp, c_vp, c_i32, c_i64, c_vp]),
+    "sgam_cast_h16_f32": (c_i32, [c_vp, c_vp, c_i32, c_i64, c_vp]),
+    "sgam_groupnorm_h16_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
+    "sgam_groupnorm_nhwc_h16": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp,
+                                        c_i64, c_vp]),
+    "sgam_softmax_rows_h16": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp]),
+    "sgam_encode_head_h16": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "sgam_transpose_h16": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "sgam_groupnorm_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
     "sgam_groupnorm_nhwc_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp,
                                         c_i64, c_vp]),

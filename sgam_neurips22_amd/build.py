@@ -14,9 +14,9 @@ ARCH = "gfx950"
 
 # exact-semantics translation units: no fp contraction (every fused op is an explicit __fmaf_rn)
 SOURCES = {
-    "conv_gemm.hip": [],
+    "conv_gemm.hip": [f"-DSGAM_SCHED={os.environ.get('SGAM_SCHED', '2')}"],
     "norm_softmax.hip": [],
-    "attention.hip": [],
+    "h16.hip": [],
     "vq.hip": ["-ffp-contract=off"],
     "layout.hip": ["-ffp-contract=off"],
     "warp.hip": ["-ffp-contract=off"],

@@ -24,6 +24,10 @@
 // (deterministic: no float atomics anywhere) and applies bias + residual.
 #include <stdlib.h>
 
+#ifndef SGAM_SCHED
+#define SGAM_SCHED 0
+#endif
+
 #include "sgam_common.h"
 
 namespace {
@@ -35,6 +39,8 @@ struct ConvKernelParams {
     const float *gn;  // fused GroupNorm prologue: per-(batch, input channel) {scale, shift} pairs, or nullptr
     int gn_swish;
     unsigned x_bytes, w_bytes;  // extents of the A / B operands for the bounds-checked buffer loads
+    int stagger_shift;
+    int stagger;  // experiment: phase-shift every second resident workgroup by this many 64-cycle sleeps
     int B, Hi, Wi, Cin, Ho, Wo, N, KH, KW, stride, pad_t, pad_l, ups;
     int lda, ldb, ldc, ldr, n_valid, bias_per_row;
     int M, ksplit, iters_total, iters_per_split;
@@ -215,15 +221,275 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned by
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
 }
 
-template <int BM, int BN, bool GN>
+template <int BM, int BN, bool GN, int BKT>
 __global__ __launch_bounds__(256) void conv_gemm_f32_v2_kernel(const ConvKernelParams p) {
+    // BKT = K slab width per barrier (32 or 64 floats); LDS rows are BKT + 4 floats
+    constexpr int BK = BKT;
+    constexpr int LDSLD = BK + 4;
+    constexpr int C4 = BK / 4;             // float4 columns per slab row
+    constexpr int RPP = 256 / C4;          // rows staged per pass of the 256 threads
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int AR = BM / RPP, BR = BN / RPP;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDSLD];
+    float *As = smem;
+    float *Bs = smem + 2 * BM * LDSLD;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, (int)p.w_bytes, 0x00020000);
+    const unsigned gn_bytes = GN ? (unsigned)(p.B * p.Cin * 2) * 4u : 0u;
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void *)p.gn, 0, (int)gn_bytes, 0x00020000);
+
+    const int it0 = blockIdx.z * p.iters_per_split;
+    const int it1 = min(p.iters_total, it0 + p.iters_per_split);
+
+    const int col4 = tid % C4;
+    const int row_in_pass = tid / C4;
+    const int Hl = p.ups ? 2 * p.Hi : p.Hi;
+    const int Wl = p.ups ? 2 * p.Wi : p.Wi;
+
+    int a_iy0[AR], a_ix0[AR], a_base[AR], a_gn[AR];
+#pragma unroll
+    for (int r = 0; r < AR; ++r) {
+        const int m = m0 + row_in_pass + RPP * r;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int hw = p.Ho * p.Wo;
+        const int b = mm / hw;
+        const int rem = mm - b * hw;
+        const int oy = rem / p.Wo;
+        const int ox = rem - oy * p.Wo;
+        // rows past M get a coordinate that fails every bounds test
+        a_iy0[r] = ok ? oy * p.stride - p.pad_t : -(1 << 28);
+        a_ix0[r] = ox * p.stride - p.pad_l;
+        a_base[r] = b * p.Hi * p.Wi;
+        a_gn[r] = b * p.Cin * 2;
+    }
+    unsigned b_off[BR];
+#pragma unroll
+    for (int r = 0; r < BR; ++r) {
+        const int n = n0 + row_in_pass + RPP * r;
+        b_off[r] = n < p.N ? (unsigned)(n * p.ldb + col4 * 4) * 4u : 0xC0000000u;  // + koff stays out of range
+    }
+
+    // K walk of this split, channel-slab major: it -> (ch = it / taps, tap = it % taps).  All taps of one
+    // 32-channel slab are visited back to back (the GroupNorm table of the slab is fetched once per slab and the
+    // 9 shifted reads of the same channels hit L1/L2); no divisions inside the loop.
+    const int taps = p.KH * p.KW;
+    int ch = it0 / taps;
+    int tap = it0 - ch * taps;
+    int ky = tap / p.KW;
+    int kx = tap - ky * p.KW;
+    bool gn_reload = true;
+
+    f32x4 areg[AR], breg[BR];
+    f32x4 gsc[GN ? AR : 1][2];
+    unsigned amask = 0;  // which staged A rows are real data (padding / tails must stay exactly zero)
+
+    // select without control flow (the compiler otherwise builds exec-masked regions around the address math)
+    auto sel = [](bool c, unsigned a, unsigned b) -> unsigned {
+        const unsigned m = 0u - (unsigned)c;
+        return (a & m) | (b & ~m);
+    };
+    auto issue_loads = [&](bool live) {
+        const int coff = ch * BK + col4 * 4;
+        const bool k_ok = live && coff < p.Cin;
+#pragma unroll
+        for (int r = 0; r < AR; ++r) {
+            const int iy = a_iy0[r] + ky, ix = a_ix0[r] + kx;
+            const bool ok = k_ok && (unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl;
+            const int py = iy >> p.ups, px = ix >> p.ups;
+            const unsigned off = (unsigned)((a_base[r] + py * p.Wi + px) * p.lda + coff) * 4u;
+            areg[r] = buf_load4(rx, sel(ok, off, p.x_bytes));
+            amask = (amask & ~(1u << r)) | ((ok ? 1u : 0u) << r);
+        }
+        if constexpr (GN) {
+            if (gn_reload) {  // wave-uniform: first slab of the split or a new channel slab
+#pragma unroll
+                for (int r = 0; r < AR; ++r) {
+                    // {sc0,sh0,sc1,sh1},{sc2,sh2,sc3,sh3}; past Cin the table reads as scale = shift = 0
+                    const unsigned goff = (unsigned)(a_gn[r] + coff * 2) * 4u;
+                    gsc[r][0] = buf_load4(rg, sel(k_ok, goff, gn_bytes));
+                    gsc[r][1] = buf_load4(rg, sel(k_ok, goff + 16u, gn_bytes));
+                }
+            }
+        }
+        const unsigned koff = (unsigned)(tap * p.Cin + ch * BK) * 4u;
+#pragma unroll
+        for (int r = 0; r < BR; ++r) breg[r] = buf_load4(rw, sel(k_ok, b_off[r] + koff, p.w_bytes));
+        // advance the walk
+        gn_reload = false;
+        ++tap;
+        if (++kx == p.KW) {
+            kx = 0;
+            ++ky;
+        }
+        if (tap == taps) {
+            tap = 0; ky = 0; kx = 0;
+            ++ch;
+            gn_reload = true;
+        }
+    };
+    auto store_lds = [&](int buf) {
+        float *a = As + buf * BM * LDSLD;
+        float *b = Bs + buf * BN * LDSLD;
+#pragma unroll
+        for (int r = 0; r < AR; ++r) {
+            f32x4 v = areg[r];
+            if constexpr (GN) {
+                const float live = (amask >> r) & 1u ? 1.0f : 0.0f;  // zero padding stays exactly zero
+                v[0] = (v[0] * gsc[r][0][0] + gsc[r][0][1]) * live;
+                v[1] = (v[1] * gsc[r][0][2] + gsc[r][0][3]) * live;
+                v[2] = (v[2] * gsc[r][1][0] + gsc[r][1][1]) * live;
+                v[3] = (v[3] * gsc[r][1][2] + gsc[r][1][3]) * live;
+                if (p.gn_swish) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = sgam_swish(v[e]);
+                }
+            }
+            *reinterpret_cast<f32x4 *>(a + (row_in_pass + RPP * r) * LDSLD + col4 * 4) = v;
+        }
+#pragma unroll
+        for (int r = 0; r < BR; ++r)
+            *reinterpret_cast<f32x4 *>(b + (row_in_pass + RPP * r) * LDSLD + col4 * 4) = breg[r];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int frag_row = lane & 31;
+    const int frag_k = (lane >> 5) * 4;
+
+    issue_loads(it0 < it1);
+    store_lds(0);
+    __syncthreads();
+    if (p.stagger > 0) {
+        // co-resident workgroups start in lock-step (same launch instant, same work): shift every second
+        // "round" of 256 workgroups by ~half a K slab so that one group's staging gaps meet the other's MFMAs
+        const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if ((lin >> p.stagger_shift) & 1) {
+            for (int k = 0; k < p.stagger; ++k) __builtin_amdgcn_s_sleep(16);
+        }
+    }
+
+    for (int it = it0; it < it1; ++it) {
+        const int buf = (it - it0) & 1;
+        const float *a = As + buf * BM * LDSLD + (wm * (BM / 2) + frag_row) * LDSLD + frag_k;
+        const float *b = Bs + buf * BN * LDSLD + (wn * (BN / 2) + frag_row) * LDSLD + frag_k;
+        // straight-line body: past the last slab the loads are all out of range (zeros) and the LDS store is
+        // a harmless write to the buffer nobody reads again
+        issue_loads((it + 1) < it1);
+#if SGAM_SCHED == 2
+        // ask the scheduler for an MFMA-paced interleave: each 64-cycle MFMA shadows a few VALU/SALU/DS/VMEM issues
+#pragma unroll
+        for (int q = 0; q < TM * TN * 16; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);  // up to 3 VALU/SALU
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // up to 1 DS read
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // up to 1 VMEM read
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // up to 1 DS write
+        }
+#endif
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
+            if (g == BK / 16) {
+#if SGAM_SCHED == 0
+                if constexpr (!GN) __builtin_amdgcn_sched_barrier(0);
+#endif
+                store_lds(buf ^ 1);  // the other buffer: last read before the previous barrier
+#if SGAM_SCHED == 0
+                if constexpr (!GN) __builtin_amdgcn_sched_barrier(0);
+#endif
+            }
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4 *>(a + i * 32 * LDSLD + g * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4 *>(b + j * 32 * LDSLD + g * 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
+    // Bias / residual come in through bounds-checked buffer loads and results leave through bounds-checked
+    // buffer stores (out-of-range lanes are dropped by the hardware): no per-element branches.
+    const int col_l = lane & 31;
+    const int row_h = 4 * (lane >> 5);
+    const bool to_ws = p.ws != nullptr;
+    const int n_lim = to_ws ? p.N : p.n_valid;
+    const int ldo = to_ws ? p.N : p.ldc;
+    float *obase = to_ws ? p.ws + (int64_t)blockIdx.z * p.M * p.N : p.out;
+    const unsigned o_bytes = (unsigned)(((int64_t)(p.M - 1) * ldo + n_lim) * 4);
+    const unsigned r_bytes = (p.res && !to_ws) ? (unsigned)(((int64_t)(p.M - 1) * p.ldr + p.n_valid) * 4) : 0u;
+    const unsigned bias_bytes = (p.bias && !to_ws) ? (unsigned)((p.bias_per_row ? p.M : p.N) * 4) : 0u;
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)obase, 0, (int)o_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void *)p.res, 0, (int)r_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)p.bias, 0, (int)bias_bytes, 0x00020000);
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / 2) + j * 32 + col_l;
+            const bool n_ok = n < n_lim;
+            const float bias_n = p.bias_per_row ? 0.f
+                                                : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                      rb, (int)sel(n_ok, (unsigned)n * 4u, OOB), 0, 0));
+            float rv[16], bv[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + row_h;
+                const bool ok = n_ok && m < p.M;
+                rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                      rr, (int)sel(ok, (unsigned)(m * p.ldr + n) * 4u, OOB), 0, 0));
+                bv[e] = p.bias_per_row ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                                       rb, (int)sel(ok, (unsigned)m * 4u, OOB), 0, 0))
+                                       : bias_n;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + row_h;
+                const bool ok = n_ok && m < p.M;
+                const float v = (acc[i][j][e] + bv[e]) + rv[e];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro,
+                                                      (int)sel(ok, (unsigned)(m * ldo + n) * 4u, OOB), 0, 0);
+            }
+        }
+    }
+}
+
+
+template <int BM, int BN, bool GN>
+__global__ __launch_bounds__(512) void conv_gemm_f32_v3_kernel(const ConvKernelParams p) {
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int AR = BM / 32, BR = BN / 32;
     __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDSLD];
     float *As = smem;
     float *Bs = smem + 2 * BM * LDSLD;
 
-    const int tid = threadIdx.x;
+    // 8 wavefronts: 0-3 feed the matrix cores (ds_read + MFMA only), 4-7 stream the next K slab HBM/L2 -> LDS.
+    // Each SIMD hosts one wave of each role, so address arithmetic, buffer loads and ds_writes issue from a
+    // different wave than the MFMAs and never sit in the MFMA wave's in-order instruction stream.
+    const bool producer = __builtin_amdgcn_readfirstlane((int)threadIdx.x) >= 256;
+    const int tid = threadIdx.x & 255;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -360,39 +626,42 @@ __global__ __launch_bounds__(256) void conv_gemm_f32_v2_kernel(const ConvKernelP
     const int frag_row = lane & 31;
     const int frag_k = (lane >> 5) * 4;
 
-    issue_loads(it0 < it1);
-    store_lds(0);
+    if (producer) {
+        issue_loads(it0 < it1);
+        store_lds(0);
+    }
     __syncthreads();
 
     for (int it = it0; it < it1; ++it) {
         const int buf = (it - it0) & 1;
-        const float *a = As + buf * BM * LDSLD + (wm * (BM / 2) + frag_row) * LDSLD + frag_k;
-        const float *b = Bs + buf * BN * LDSLD + (wn * (BN / 2) + frag_row) * LDSLD + frag_k;
-        // straight-line body: past the last slab the loads are all out of range (zeros) and the LDS store is
-        // a harmless write to the buffer nobody reads again
-        issue_loads((it + 1) < it1);
-#pragma unroll
-        for (int g = 0; g < BK / 8; ++g) {
-            if (g == BK / 16) {
-                if constexpr (!GN) __builtin_amdgcn_sched_barrier(0);
-                store_lds(buf ^ 1);  // the other buffer: last read before the previous barrier
-                if constexpr (!GN) __builtin_amdgcn_sched_barrier(0);
+        if (producer) {
+            // slab it+1 -> the other LDS buffer (its last readers passed the previous barrier)
+            if ((it + 1) < it1) {
+                issue_loads(true);
+                store_lds(buf ^ 1);
             }
-            f32x4 af[TM], bf[TN];
+        } else {
+            const float *a = As + buf * BM * LDSLD + (wm * (BM / 2) + frag_row) * LDSLD + frag_k;
+            const float *b = Bs + buf * BN * LDSLD + (wn * (BN / 2) + frag_row) * LDSLD + frag_k;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4 *>(a + i * 32 * LDSLD + g * 8);
+            for (int g = 0; g < BK / 8; ++g) {
+                f32x4 af[TM], bf[TN];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4 *>(b + j * 32 * LDSLD + g * 8);
+                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4 *>(a + i * 32 * LDSLD + g * 8);
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+                for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4 *>(b + j * 32 * LDSLD + g * 8);
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                for (int s = 0; s < 4; ++s)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+            }
         }
         __syncthreads();
     }
+    if (producer) return;
 
     // ---- epilogue: D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
     // Bias / residual come in through bounds-checked buffer loads and results leave through bounds-checked
@@ -480,21 +749,24 @@ __global__ void pack_weight_kernel(const float *w, float *o, int Cout, int Cin, 
 }
 
 struct Plan {
-    int bm, bn, ksplit, iters_total, iters_per_split;
+    int bm, bn, bk, ksplit, iters_total, iters_per_split;
 };
 
 Plan make_plan(const sgam_conv_desc *d) {
     const int64_t M = (int64_t)d->B * d->Ho * d->Wo;
     Plan pl;
-    pl.iters_total = d->KH * d->KW * ((d->Cin + BK - 1) / BK);
+    pl.bk = BK;
     auto blocks = [&](int bm, int bn) { return (int64_t)sgam_cdiv(M, bm) * sgam_cdiv(d->N, bn); };
     if (d->N % 128 == 0 && blocks(128, 128) >= 224) {
         pl.bm = 128; pl.bn = 128;
+        static const int bk128 = [] { const char *e = getenv("SGAM_BK128"); return e ? atoi(e) : 32; }();
+        if (d->Cin % 64 == 0) pl.bk = bk128;   // wider K slab: half the barriers per MFMA (one workgroup per CU)
     } else if (d->N % 128 == 0 && blocks(64, 128) >= 224) {
         pl.bm = 64; pl.bn = 128;
     } else {
         pl.bm = 64; pl.bn = 64;
     }
+    pl.iters_total = d->KH * d->KW * ((d->Cin + pl.bk - 1) / pl.bk);
     const int64_t nb = blocks(pl.bm, pl.bn);
     int ks = 1;
     if (nb < 192) {
@@ -545,14 +817,32 @@ static bool use_v1() {
     return v != 0;
 }
 
+static int conv_variant() {  // 2 = single-role v2 (default), 3 = producer/consumer wave specialisation (measured slower)
+    static const int v = [] { const char *e = getenv("SGAM_CONV_VARIANT"); return e ? atoi(e) : 2; }();
+    return v;
+}
+
+template <bool GN>
+static void launch_v3(const Plan &pl, const dim3 &grid, hipStream_t s, const ConvKernelParams &p) {
+    if (pl.bm == 128 && pl.bn == 128) {
+        hipLaunchKernelGGL((conv_gemm_f32_v3_kernel<128, 128, GN>), grid, dim3(512), 0, s, p);
+    } else if (pl.bm == 64 && pl.bn == 128) {
+        hipLaunchKernelGGL((conv_gemm_f32_v3_kernel<64, 128, GN>), grid, dim3(512), 0, s, p);
+    } else {
+        hipLaunchKernelGGL((conv_gemm_f32_v3_kernel<64, 64, GN>), grid, dim3(512), 0, s, p);
+    }
+}
+
 template <bool GN>
 static void launch_v2(const Plan &pl, const dim3 &grid, hipStream_t s, const ConvKernelParams &p) {
-    if (pl.bm == 128 && pl.bn == 128) {
-        hipLaunchKernelGGL((conv_gemm_f32_v2_kernel<128, 128, GN>), grid, dim3(256), 0, s, p);
+    if (pl.bm == 128 && pl.bn == 128 && pl.bk == 64) {
+        hipLaunchKernelGGL((conv_gemm_f32_v2_kernel<128, 128, GN, 64>), grid, dim3(256), 0, s, p);
+    } else if (pl.bm == 128 && pl.bn == 128) {
+        hipLaunchKernelGGL((conv_gemm_f32_v2_kernel<128, 128, GN, 32>), grid, dim3(256), 0, s, p);
     } else if (pl.bm == 64 && pl.bn == 128) {
-        hipLaunchKernelGGL((conv_gemm_f32_v2_kernel<64, 128, GN>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((conv_gemm_f32_v2_kernel<64, 128, GN, 32>), grid, dim3(256), 0, s, p);
     } else {
-        hipLaunchKernelGGL((conv_gemm_f32_v2_kernel<64, 64, GN>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((conv_gemm_f32_v2_kernel<64, 64, GN, 32>), grid, dim3(256), 0, s, p);
     }
 }
 
@@ -580,6 +870,10 @@ extern "C" int sgam_conv2d_gn_nhwc_f32(const sgam_conv_desc *d, const float *x, 
     const int64_t wb = (((int64_t)d->N - 1) * d->ldb + (int64_t)d->KH * d->KW * d->Cin) * 4;
     if (xb >= (1ll << 32) - 64 || wb >= (1ll << 32) - 64) return SGAM_EINVAL;  // 32-bit buffer offsets
     p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
+    static const int stagger = [] { const char *e = getenv("SGAM_STAGGER"); return e ? atoi(e) : 0; }();
+    p.stagger = stagger;
+    static const int sshift = [] { const char *e = getenv("SGAM_STAGGER_SHIFT"); return e ? atoi(e) : 8; }();
+    p.stagger_shift = sshift;
     if (pl.ksplit > 1) {
         const int64_t need = (int64_t)pl.ksplit * p.M * p.N * (int64_t)sizeof(float);
         if (!workspace || workspace_bytes < need || !sgam_aligned16(workspace)) return SGAM_EWORKSPACE;
@@ -596,9 +890,9 @@ extern "C" int sgam_conv2d_gn_nhwc_f32(const sgam_conv_desc *d, const float *x, 
             hipLaunchKernelGGL((conv_gemm_f32_kernel<64, 64>), grid, dim3(256), 0, s, p);
         }
     } else if (gn_scale_shift) {
-        launch_v2<true>(pl, grid, s, p);
+        if (conv_variant() == 3) launch_v3<true>(pl, grid, s, p); else launch_v2<true>(pl, grid, s, p);
     } else {
-        launch_v2<false>(pl, grid, s, p);
+        if (conv_variant() == 3) launch_v3<false>(pl, grid, s, p); else launch_v2<false>(pl, grid, s, p);
     }
     SGAM_LAUNCH_CHECK();
     if (pl.ksplit > 1) {

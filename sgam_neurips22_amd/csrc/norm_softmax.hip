@@ -202,6 +202,16 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float *__restrict__ s
 
 }  // namespace
 
+// shared with the 16-bit path (h16.hip): statistics are finalised in fp64 -> fp32 table for both
+extern "C" int sgam_gn_finalize_launch(const double *partial, const float *gamma, const float *beta, float *scale_shift,
+                                       int B, int HW, int C, int groups, int nchunk, float eps, hipStream_t s) {
+    if (256 % groups != 0) return SGAM_EINVAL;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, partial, gamma, beta, scale_shift, HW, C, groups,
+                       nchunk, eps);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
 extern "C" int64_t sgam_groupnorm_workspace_bytes(int32_t B, int32_t HW, int32_t C) {
     if (B <= 0 || HW <= 0 || C <= 0 || C % 128 != 0 || C > 1024) return -1;
     const int nchunk = gn_nchunk(HW, C);

@@ -40,6 +40,9 @@ class VQModel(nn.Module):
         self.vq_step_threshold = vq_step_threshold
         self.image_key = image_key
         self.use_rgbd_integration = False
+        # arithmetic of the VQGAN body: float32 = parity path (fp32-in MFMA); bfloat16 / float16 = throughput
+        # path (16-bit MFMA, fp32 accumulate).  The quantiser always runs in fp32 on the fp32 latent.
+        self.compute_dtype = torch.float32
         if self.use_extrapolation_mask:
             self.conv_in = Conv2d(5, 4, kernel_size=1)
         self.encoder = Encoder(**ddconfig)
@@ -74,17 +77,25 @@ class VQModel(nn.Module):
         self.load_state_dict(sd, strict=False)
         print(f"Restored from {path}")
 
+    def set_compute_dtype(self, dtype):
+        """'f32' (default, parity), 'bf16' or 'fp16' (throughput).  Returns self."""
+        self.compute_dtype = ops.DTYPES[dtype] if isinstance(dtype, str) else dtype
+        return self
+
     # ---- NHWC core ----
     def _encode_nhwc(self, x, extrapolation_mask):
-        """x (B,4,H,W) NCHW + mask -> pre-quant latent (B,h,w,D) NHWC."""
+        """x (B,4,H,W) NCHW + mask -> pre-quant latent (B,h,w,D) NHWC fp32."""
+        dt = self.compute_dtype
         if self.use_extrapolation_mask:
-            h = ops.encode_head(x, extrapolation_mask, self.conv_in.weight, self.conv_in.bias, ld=32)
+            h = ops.encode_head(x, extrapolation_mask, self.conv_in.weight, self.conv_in.bias, ld=32, dtype=dt)
         else:
-            h = ops.nchw_to_nhwc(x, c_pad=32)
-        return self.quant_conv.forward_nhwc(self.encoder.forward_nhwc(h))
+            h = ops.cast(ops.nchw_to_nhwc(x, c_pad=32), dt)
+        return self.quant_conv.forward_nhwc(self.encoder.forward_nhwc(h), out_dtype=torch.float32)
 
     def _decode_nhwc(self, quant_nhwc):
-        return self.decoder.forward_nhwc(self.post_quant_conv.forward_nhwc(quant_nhwc))
+        """fp32 quantised latent (B,h,w,D) -> fp32 RGB-D (B,H,W,4)."""
+        q = ops.cast(quant_nhwc, self.compute_dtype)
+        return self.decoder.forward_nhwc(self.post_quant_conv.forward_nhwc(q))
 
     # ---- reference API ----
     def encode(self, x, topk=None, encoding_indices=None, extrapolation_mask=None, use_old=False, sample_number=1):

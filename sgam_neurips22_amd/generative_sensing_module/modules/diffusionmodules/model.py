@@ -21,25 +21,28 @@ class Conv2d(nn.Conv2d):
     """nn.Conv2d as a parameter container + HIP execution.  Packed weights ([Cout_pad][taps][Cin_pad],
     K contiguous — the B operand layout of the implicit GEMM) are cached per (storage, version)."""
 
-    def _packed(self):
+    def _packed(self, dtype=torch.float32):
         w = self.weight
         key = (w.data_ptr(), w._version, str(w.device))
         if getattr(self, "_pack_key", None) != key:
-            self._pack = ops.pack_conv_weight(w)
+            self._packs = {}
             self._pack_bias = None if self.bias is None else self.bias.detach().float().contiguous()
             self._pack_key = key
-        return self._pack, self._pack_bias
+        if dtype not in self._packs:
+            self._packs[dtype] = ops.pack_conv_weight(w, dtype=dtype)
+        return self._packs[dtype], self._pack_bias
 
-    def forward_nhwc(self, x, residual=None, upsample2x=False, pad=None, gn=None):
+    def forward_nhwc(self, x, residual=None, upsample2x=False, pad=None, gn=None, out_dtype=None):
         """gn = (scale/shift table from GroupNorm.stats_nhwc, swish flag): GroupNorm(+swish) of the input fused
-        into the operand staging of the implicit GEMM."""
-        wp, b = self._packed()
+        into the operand staging of the implicit GEMM (fp32 path only).  The kernel family follows x.dtype:
+        fp32 -> fp32-in MFMA parity path, bf16/fp16 -> 16-bit MFMA throughput path."""
+        wp, b = self._packed(x.dtype)
         kh, kw = self.kernel_size
         if pad is None:
             pad = (self.padding[0], self.padding[1], self.padding[0], self.padding[1])  # t, l, b, r
         return ops.conv2d_nhwc(x, wp, b, cout=self.out_channels, kh=kh, kw=kw, stride=self.stride[0],
                                pad_t=pad[0], pad_l=pad[1], pad_b=pad[2], pad_r=pad[3], upsample2x=upsample2x,
-                               residual=residual, cin=wp.shape[1] // (kh * kw), gn=gn)
+                               residual=residual, cin=wp.shape[1] // (kh * kw), gn=gn, out_dtype=out_dtype)
 
     def forward(self, x):
         cin_pad = self._packed()[0].shape[1] // (self.kernel_size[0] * self.kernel_size[1])
@@ -163,7 +166,8 @@ class AttnBlock(_NHWCModule):
         key = tuple((w.data_ptr(), w._version) for w in ws) + (str(ws[0].device),)
         if getattr(self, "_qkv_key", None) != key:
             c = self.in_channels
-            self._wqkv = torch.cat([m.weight.detach().reshape(c, c) for m in (self.q, self.k, self.v)], 0).float().contiguous()
+            self._wqkv = {torch.float32: torch.cat([m.weight.detach().reshape(c, c) for m in (self.q, self.k, self.v)],
+                                                   0).float().contiguous()}
             self._bqkv = torch.cat([m.bias.detach() for m in (self.q, self.k, self.v)]).float().contiguous()
             self._qkv_key = key
         return self._wqkv, self._bqkv
@@ -171,8 +175,13 @@ class AttnBlock(_NHWCModule):
     def forward_nhwc(self, x):
         B, H, W, C = x.shape
         n = H * W
-        wqkv, bqkv = self._packed_qkv()
-        wp, bp = self.proj_out._packed()
+        wqkvs, bqkv = self._packed_qkv()
+        if x.dtype not in wqkvs:
+            wqkvs[x.dtype] = ops.cast(wqkvs[torch.float32], x.dtype)
+        wqkv = wqkvs[x.dtype]
+        wp, bp = self.proj_out._packed(x.dtype)
+        if x.dtype in ops.H16:
+            return self._forward_nhwc_h16(x, wqkv, bqkv, wp, bp)
         if FUSE_GROUPNORM_INTO_CONV:
             table, h = self.norm.stats_nhwc(x), x                         # (B, C, 2), no swish for attention
         else:
@@ -189,6 +198,26 @@ class AttnBlock(_NHWCModule):
             o = ops.gemm_nt(s, vt)                                         # (n, C)
             ops.gemm_nt(o, wp, bias=bp, residual=xb, out=out[b].reshape(n, C))
         return out
+
+
+def _attn_h16(self, x, wqkv, bqkv, wp, bp):
+    """16-bit attention: q/k/v and P in bf16/fp16, scores and softmax in fp32."""
+    B, H, W, C = x.shape
+    n = H * W
+    h = self.norm.forward_nhwc(x, swish=False)
+    out = torch.empty_like(x)
+    scale = int(C) ** (-0.5)
+    for b in range(B):
+        qkv = ops.gemm_nt(h[b].reshape(n, C), wqkv, bias=bqkv)                     # (n, 3C) 16-bit
+        vt = ops.transpose_h16(qkv[:, 2 * C:])                                     # (C, n)
+        s = ops.gemm_nt(qkv[:, :C], qkv[:, C:2 * C], out_dtype=torch.float32)      # (n, n) fp32 scores
+        p = ops.softmax_rows_h16(s, scale, x.dtype)                                # (n, n) 16-bit probabilities
+        o = ops.gemm_nt(p, vt)                                                     # (n, C)
+        ops.gemm_nt(o, wp, bias=bp, residual=x[b].reshape(n, C), out=out[b].reshape(n, C))
+    return out
+
+
+AttnBlock._forward_nhwc_h16 = _attn_h16
 
 
 def _make_attn_list():
@@ -299,4 +328,4 @@ class Decoder(_NHWCModule):
                 h = stage.upsample.forward_nhwc(h)
         if self.give_pre_end:
             return h
-        return _norm_conv(self.norm_out, True, self.conv_out, h)
+        return _norm_conv(self.norm_out, True, self.conv_out, h, out_dtype=torch.float32)  # RGB-D leaves in fp32

@@ -42,19 +42,50 @@ def round_up(v, m):
     return (v + m - 1) // m * m
 
 
+# 16-bit throughput path: `ht` code of the C ABI per torch dtype
+H16 = {torch.bfloat16: 0, torch.float16: 1}
+DTYPES = {"f32": torch.float32, "fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16,
+          "f16": torch.float16}
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def cast(x, dtype):
+    """fp32 <-> 16-bit conversion on the GPU (RNE)."""
+    _need_cuda(x)
+    if x.dtype == dtype:
+        return x
+    x = _c(x)
+    y = torch.empty(x.shape, device=x.device, dtype=dtype)
+    lib = _lib.load()
+    if x.dtype == torch.float32 and dtype in H16:
+        check(lib.sgam_cast_f32_h16(_p(x), _p(y), H16[dtype], x.numel(), _stream()), "sgam_cast_f32_h16")
+    elif x.dtype in H16 and dtype == torch.float32:
+        check(lib.sgam_cast_h16_f32(_p(x), _p(y), H16[x.dtype], x.numel(), _stream()), "sgam_cast_h16_f32")
+    else:
+        raise SgamHipError(f"cast {x.dtype} -> {dtype} not supported")
+    return y
+
+
 # ------------------------------------------------------------------------------------------------
 # weights
 # ------------------------------------------------------------------------------------------------
-def pack_conv_weight(w_oihw, cout_pad=None, cin_pad=None):
-    """torch Conv2d.weight (Cout,Cin,KH,KW) -> packed (Cout_pad, KH*KW*Cin_pad), zero padded."""
+def pack_conv_weight(w_oihw, cout_pad=None, cin_pad=None, dtype=torch.float32):
+    """torch Conv2d.weight (Cout,Cin,KH,KW) -> packed (Cout_pad, KH*KW*Cin_pad), zero padded, in `dtype`."""
     _need_cuda(w_oihw)
     w = _f32c(w_oihw.detach())
     cout, cin, kh, kw = w.shape
     cout_pad = cout_pad or round_up(cout, 64)
     cin_pad = cin_pad or round_up(cin, 32)
-    out = torch.empty((cout_pad, kh * kw * cin_pad), device=w.device, dtype=torch.float32)
-    check(_lib.load().sgam_pack_conv_weight(_p(w), _p(out), cout, cin, kh, kw, cout_pad, cin_pad, _stream()),
-          "sgam_pack_conv_weight")
+    out = torch.empty((cout_pad, kh * kw * cin_pad), device=w.device, dtype=dtype)
+    if dtype == torch.float32:
+        check(_lib.load().sgam_pack_conv_weight(_p(w), _p(out), cout, cin, kh, kw, cout_pad, cin_pad, _stream()),
+              "sgam_pack_conv_weight")
+    else:
+        check(_lib.load().sgam_pack_conv_weight_h16(_p(w), _p(out), H16[dtype], cout, cin, kh, kw, cout_pad, cin_pad,
+                                                    _stream()), "sgam_pack_conv_weight_h16")
     return out
 
 
@@ -64,10 +95,10 @@ def pack_conv_weight(w_oihw, cout_pad=None, cin_pad=None):
 CONV_TRACE = None  # set to a list by bench.py's profiling pass: (desc copy, flops, start event, end event)
 
 
-def conv_plan(desc):
+def conv_plan(desc, h16=False):
     bm, bn, ks = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
-    check(_lib.load().sgam_conv2d_plan(ctypes.byref(desc), ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(ks)),
-          "sgam_conv2d_plan")
+    fn = _lib.load().sgam_conv2d_h16_plan if h16 else _lib.load().sgam_conv2d_plan
+    check(fn(ctypes.byref(desc), ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(ks)), "sgam_conv2d_plan")
     return bm.value, bn.value, ks.value
 
 
@@ -79,13 +110,24 @@ def _run_conv(desc, x, w, bias, residual, out, gn=None):
         _run_conv_inner(lib, desc, x, w, bias, residual, out, gn)
         ev1.record()
         flops = 2.0 * desc.B * desc.Ho * desc.Wo * desc.n_valid * desc.KH * desc.KW * desc.Cin
-        CONV_TRACE.append((conv_plan(desc), (desc.B * desc.Ho * desc.Wo, desc.n_valid, desc.KH * desc.KW * desc.Cin),
-                           flops, ev0, ev1))
+        CONV_TRACE.append((conv_plan(desc, x.dtype in H16) + (str(x.dtype).replace("torch.", ""),),
+                           (desc.B * desc.Ho * desc.Wo, desc.n_valid, desc.KH * desc.KW * desc.Cin), flops, ev0, ev1))
         return out
     return _run_conv_inner(lib, desc, x, w, bias, residual, out, gn)
 
 
 def _run_conv_inner(lib, desc, x, w, bias, residual, out, gn=None):
+    if x.dtype in H16:
+        if gn is not None or w.dtype != x.dtype or (residual is not None and residual.dtype != x.dtype):
+            raise SgamHipError("16-bit conv: operands must share one 16-bit dtype; no fused GroupNorm prologue")
+        ws_bytes = lib.sgam_conv2d_h16_workspace_bytes(ctypes.byref(desc))
+        if ws_bytes < 0:
+            raise SgamHipError(f"sgam_conv2d_h16: unsupported shape {[(f, getattr(desc, f)) for f, _ in desc._fields_]}")
+        ws = torch.empty((ws_bytes,), device=x.device, dtype=torch.uint8) if ws_bytes else None
+        check(lib.sgam_conv2d_nhwc_h16(ctypes.byref(desc), H16[x.dtype], _p(x), _p(w), _p(bias), _p(residual), _p(out),
+                                       int(out.dtype == torch.float32), _p(ws), ws_bytes, _stream()),
+              "sgam_conv2d_nhwc_h16")
+        return out
     ws_bytes = lib.sgam_conv2d_workspace_bytes(ctypes.byref(desc))
     if ws_bytes < 0:
         raise SgamHipError(f"sgam_conv2d: unsupported shape {[(f, getattr(desc, f)) for f, _ in desc._fields_]}")
@@ -97,7 +139,7 @@ def _run_conv_inner(lib, desc, x, w, bias, residual, out, gn=None):
 
 
 def conv2d_nhwc(x, w_packed, bias, *, cout, kh, kw, stride=1, pad_t=0, pad_l=0, pad_b=None, pad_r=None,
-                upsample2x=False, residual=None, cin=None, gn=None):
+                upsample2x=False, residual=None, cin=None, gn=None, out_dtype=None):
     """x (B,Hi,Wi,Cx) NHWC fp32 -> (B,Ho,Wo,cout).  w_packed from pack_conv_weight (rows padded to 64,
     Cin padded to 32).  `cin` = channels of x actually contracted (defaults to Cx, must be % 32)."""
     _need_cuda(x, w_packed)
@@ -109,14 +151,14 @@ def conv2d_nhwc(x, w_packed, bias, *, cout, kh, kw, stride=1, pad_t=0, pad_l=0, 
     Ho = (Hl + pad_t + pad_b - kh) // stride + 1
     Wo = (Wl + pad_l + pad_r - kw) // stride + 1
     N = w_packed.shape[0]
-    out = torch.empty((B, Ho, Wo, cout), device=x.device, dtype=torch.float32)
+    out = torch.empty((B, Ho, Wo, cout), device=x.device, dtype=out_dtype or x.dtype)
     d = ConvDesc(B=B, Hi=Hi, Wi=Wi, Cin=cin, Ho=Ho, Wo=Wo, N=N, KH=kh, KW=kw, stride=stride, pad_t=pad_t,
                  pad_l=pad_l, upsample2x=int(upsample2x), lda=x.stride(2), ldb=w_packed.stride(0), ldc=cout,
                  ldr=(residual.stride(2) if residual is not None else 0), n_valid=cout, bias_per_row=0)
     return _run_conv(d, x, w_packed, bias, residual, out, gn)
 
 
-def gemm_nt(a, b, bias=None, residual=None, bias_per_row=False, out=None, gn=None):
+def gemm_nt(a, b, bias=None, residual=None, bias_per_row=False, out=None, gn=None, out_dtype=None):
     """out[M][N] = a[M][K] @ b[N][K]^T (+bias) (+residual).  a, b: 2-D fp32 CUDA tensors with unit
     inner stride (row strides free, so column slices of a fused projection can be passed directly).
     K % 32 == 0, N % 4 == 0."""
@@ -125,7 +167,7 @@ def gemm_nt(a, b, bias=None, residual=None, bias_per_row=False, out=None, gn=Non
     N, K2 = b.shape
     assert K == K2 and a.stride(1) == 1 and b.stride(1) == 1
     if out is None:
-        out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+        out = torch.empty((M, N), device=a.device, dtype=out_dtype or a.dtype)
     d = ConvDesc(B=1, Hi=1, Wi=M, Cin=K, Ho=1, Wo=M, N=N, KH=1, KW=1, stride=1, pad_t=0, pad_l=0, upsample2x=0,
                  lda=a.stride(0), ldb=b.stride(0), ldc=out.stride(0),
                  ldr=(residual.stride(0) if residual is not None else 0), n_valid=N,
@@ -140,6 +182,15 @@ def groupnorm_nhwc(x, gamma, beta, swish, groups=32, eps=1e-6):
     _need_cuda(x, gamma, beta)
     B, H, W, C = x.shape
     lib = _lib.load()
+    if x.dtype in H16:
+        ws_bytes = lib.sgam_groupnorm_h16_workspace_bytes(B, H * W, C)
+        if ws_bytes < 0:
+            raise SgamHipError(f"sgam_groupnorm_h16: unsupported shape B={B} HW={H * W} C={C}")
+        ws = torch.empty((ws_bytes,), device=x.device, dtype=torch.uint8)
+        y = torch.empty_like(x)
+        check(lib.sgam_groupnorm_nhwc_h16(_p(x), _p(gamma), _p(beta), _p(y), H16[x.dtype], B, H * W, C, groups, eps,
+                                          int(swish), _p(ws), ws_bytes, _stream()), "sgam_groupnorm_nhwc_h16")
+        return y
     ws_bytes = lib.sgam_groupnorm_workspace_bytes(B, H * W, C)
     if ws_bytes < 0:
         raise SgamHipError(f"sgam_groupnorm: unsupported shape B={B} HW={H * W} C={C}")
@@ -164,6 +215,26 @@ def groupnorm_stats(x, gamma, beta, groups=32, eps=1e-6):
     check(lib.sgam_groupnorm_stats_nhwc_f32(_p(x), _p(gamma), _p(beta), _p(table), B, H * W, C, groups, eps, _p(ws),
                                             ws_bytes, _stream()), "sgam_groupnorm_stats_nhwc_f32")
     return table
+
+
+def softmax_rows_h16(s, scale, dtype):
+    """fp32 scores (rows, cols) -> 16-bit probabilities softmax(scale * s)."""
+    _need_cuda(s)
+    rows, cols = s.shape
+    p = torch.empty((rows, cols), device=s.device, dtype=dtype)
+    check(_lib.load().sgam_softmax_rows_h16(_p(s), _p(p), H16[dtype], rows, cols, s.stride(0), p.stride(0), float(scale),
+                                            _stream()), "sgam_softmax_rows_h16")
+    return p
+
+
+def transpose_h16(x2d):
+    """(HW, C) 16-bit view with unit inner stride -> contiguous (C, HW)."""
+    _need_cuda(x2d)
+    HW, C = x2d.shape
+    y = torch.empty((C, HW), device=x2d.device, dtype=x2d.dtype)
+    check(_lib.load().sgam_transpose_h16(_p(x2d), _p(y), H16[x2d.dtype], C, HW, x2d.stride(0), _stream()),
+          "sgam_transpose_h16")
+    return y
 
 
 def softmax_rows_(s, scale):
@@ -197,7 +268,7 @@ def nhwc_to_nchw(x, c=None):
     return y
 
 
-def encode_head(x_nchw, mask, w, bias, ld=32):
+def encode_head(x_nchw, mask, w, bias, ld=32, dtype=torch.float32):
     """cat(x, mask) -> conv1x1(5->4) -> NHWC (B,H,W,ld) with channels 4.. zero (model.py:107-113)."""
     _need_cuda(x_nchw, w, bias)
     x = _f32c(x_nchw)
@@ -207,9 +278,14 @@ def encode_head(x_nchw, mask, w, bias, ld=32):
     if mask is not None:
         m = mask.reshape(B, H * W)
         m = (m != 0).to(torch.uint8).contiguous()
-    y = torch.empty((B, H, W, ld), device=x.device, dtype=torch.float32)
-    check(_lib.load().sgam_encode_head_f32(_p(x), _p(m), _p(_f32c(w.detach().reshape(4, 5))), _p(_f32c(bias.detach())),
-                                           _p(y), B, H * W, ld, _stream()), "sgam_encode_head_f32")
+    y = torch.empty((B, H, W, ld), device=x.device, dtype=dtype)
+    wf, bf = _f32c(w.detach().reshape(4, 5)), _f32c(bias.detach())
+    if dtype == torch.float32:
+        check(_lib.load().sgam_encode_head_f32(_p(x), _p(m), _p(wf), _p(bf), _p(y), B, H * W, ld, _stream()),
+              "sgam_encode_head_f32")
+    else:
+        check(_lib.load().sgam_encode_head_h16(_p(x), _p(m), _p(wf), _p(bf), _p(y), H16[dtype], B, H * W, ld, _stream()),
+              "sgam_encode_head_h16")
     return y
 
 

@@ -1,0 +1,101 @@
+"""GPU: the 16-bit (bf16 / fp16) throughput path.  It is NOT a parity path: kernels are checked against the
+fp32 operator evaluated on the SAME 16-bit-rounded operands (so only accumulation order + the single output
+rounding differ), and the full model reports codebook-index agreement and RGB-D error versus the fp32 path."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from sgam_neurips22_amd import ops, testing
+from sgam_neurips22_amd.config import default_params
+from sgam_neurips22_amd.generative_sensing_module.model import VQModel
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+DT = [torch.bfloat16, torch.float16]
+EPS = {torch.bfloat16: 2 ** -8, torch.float16: 2 ** -11}
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _rel(a, b):
+    a, b = a.detach().float().cpu().double(), b.detach().float().cpu().double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-9)).item()
+
+
+@pytest.mark.parametrize("dt", DT, ids=["bf16", "fp16"])
+@pytest.mark.parametrize("case", [("3x3_128", 1, 128, 128, 40, 36, 3, 1, (1, 1, 1, 1), False),
+                                  ("3x3_512_splitk", 1, 512, 512, 8, 8, 3, 1, (1, 1, 1, 1), False),
+                                  ("down", 1, 128, 128, 17, 21, 3, 2, (0, 0, 1, 1), False),
+                                  ("up", 1, 256, 256, 16, 12, 3, 1, (1, 1, 1, 1), True),
+                                  ("1x1", 2, 128, 256, 16, 16, 1, 1, (0, 0, 0, 0), False),
+                                  ("in32", 1, 32, 128, 24, 24, 3, 1, (1, 1, 1, 1), False),
+                                  ("out4", 1, 128, 4, 32, 32, 3, 1, (1, 1, 1, 1), False),
+                                  ("big", 1, 128, 128, 256, 256, 3, 1, (1, 1, 1, 1), False)], ids=lambda c: c[0])
+def test_conv_h16(dt, case):
+    tag, B, Cin, Cout, H, W, k, stride, pad, ups = case
+    x = testing.seeded_tensor(tag + ".x", (B, Cin, H, W)).to(dt)
+    w = testing.seeded_tensor(tag + ".w", (Cout, Cin, k, k), scale=(1.0 / (Cin * k * k)) ** 0.5)
+    b = testing.seeded_tensor(tag + ".b", (Cout,), scale=0.1)
+    xr = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if ups else x.float()
+    ref = F.conv2d(F.pad(xr, (pad[1], pad[3], pad[0], pad[2])), w.to(dt).float(), b, stride=stride)
+    res = testing.seeded_tensor(tag + ".r", tuple(ref.shape)).to(dt)
+    wp = ops.pack_conv_weight(w.to(DEV), dtype=dt)
+    kw = dict(cout=Cout, kh=k, kw=k, stride=stride, pad_t=pad[0], pad_l=pad[1], pad_b=pad[2], pad_r=pad[3], upsample2x=ups)
+    out32 = ops.conv2d_nhwc(_nhwc(x).to(DEV), wp, b.to(DEV), out_dtype=torch.float32, **kw)
+    assert out32.dtype == torch.float32 and _rel(out32.permute(0, 3, 1, 2), ref) <= 2e-5, "fp32-output variant"
+    out = ops.conv2d_nhwc(_nhwc(x).to(DEV), wp, b.to(DEV), residual=_nhwc(res).to(DEV), **kw)
+    assert out.dtype == dt and _rel(out.permute(0, 3, 1, 2), ref + res.float()) <= 1.5 * EPS[dt]
+
+
+@pytest.mark.parametrize("dt", DT, ids=["bf16", "fp16"])
+@pytest.mark.parametrize("B,C,H,W", [(1, 128, 64, 64), (2, 256, 12, 12), (1, 512, 16, 16)])
+def test_groupnorm_h16(dt, B, C, H, W):
+    x = testing.seeded_tensor("gn16.x", (B, C, H, W), 3.0, 0.5).to(dt)
+    g = 1 + 0.1 * testing.seeded_tensor("gn16.g", (C,))
+    bt = 0.1 * testing.seeded_tensor("gn16.b", (C,))
+    ref = F.group_norm(x.float(), 32, g, bt, eps=1e-6)
+    for swish in (False, True):
+        r = ref * torch.sigmoid(ref) if swish else ref
+        y = ops.groupnorm_nhwc(_nhwc(x).to(DEV), g.to(DEV), bt.to(DEV), swish)
+        assert y.dtype == dt and _rel(y.permute(0, 3, 1, 2), r) <= 1.5 * EPS[dt]
+
+
+@pytest.mark.parametrize("dt", DT, ids=["bf16", "fp16"])
+def test_softmax_transpose_cast_h16(dt):
+    s = testing.seeded_tensor("sm16", (64, 4096), 4.0)
+    p = ops.softmax_rows_h16(s.to(DEV), 0.0625, dt)
+    assert _rel(p, F.softmax(s * 0.0625, dim=1)) <= 2 * EPS[dt]
+    x = testing.seeded_tensor("tr16", (100, 3 * 256)).to(dt).to(DEV)
+    assert torch.equal(ops.transpose_h16(x[:, 512:]), x[:, 512:].t().contiguous())
+    f = testing.seeded_tensor("cast", (1000,), 10.0)
+    assert torch.equal(ops.cast(f.to(DEV), dt).cpu(), f.to(dt))
+    assert torch.equal(ops.cast(f.to(dt).to(DEV), torch.float32).cpu(), f.to(dt).float())
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_full_model_h16_vs_fp32(golden, dt):
+    """Throughput mode vs the parity mode on the golden 256x256 input: report agreement, bound the error."""
+    g = golden("vqgan_full_ge256.npz")
+    p = default_params("google_earth")
+    m = VQModel(**p)
+    sd = testing.synthetic_state_dict(m.state_dict(), seed=0)
+    sd["quantize.embedding.weight"] = testing.codebook_from_stats(float(g["zmean"]), float(g["zstd"]), 4096, 256, int(g["cb_seed"]))
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    x, mask = testing.rect_hole_input(1, 256, 256, seed=3)
+    with torch.no_grad():
+        dec32, _, idx32, pre32 = m(x.to(DEV), extrapolation_mask=mask.to(DEV), get_codebook_count=True, get_pre_quantized_feature=True)
+        m.set_compute_dtype(dt)
+        dec16, _, idx16, pre16 = m(x.to(DEV), extrapolation_mask=mask.to(DEV), get_codebook_count=True, get_pre_quantized_feature=True)
+        # decoder alone on identical (fp32-path) codes: isolates decoder error from index flips
+        dec16_same = m.decode(m.quantize.get_codebook_entry(idx32.reshape(-1), (1, 16, 16, 256)))
+    agree = (idx32 == idx16).float().mean().item()
+    err_pre = _rel(pre16, pre32)
+    err_dec_same = (dec16_same - dec32).abs().max().item() / dec32.abs().max().item()
+    print(f"[{dt}] index agreement {agree:.3f}, latent rel err {err_pre:.3e}, decoder (same codes) rel err {err_dec_same:.3e}")
+    assert dec16.dtype == torch.float32 and torch.isfinite(dec16).all()
+    assert agree >= (0.80 if dt == "bf16" else 0.93)
+    assert err_pre <= (8e-2 if dt == "bf16" else 1.5e-2)
+    assert err_dec_same <= (8e-2 if dt == "bf16" else 1.5e-2)
