@@ -16,6 +16,7 @@ ARCH = "gfx950"
 SOURCES = {
     "conv_gemm.hip": [f"-DSGAM_SCHED={os.environ.get('SGAM_SCHED', '2')}"],
     "norm_softmax.hip": [],
+    "groupnorm.hip": [],
     "h16.hip": [],
     "vq.hip": ["-ffp-contract=off"],
     "layout.hip": ["-ffp-contract=off"],

@@ -275,81 +275,6 @@ __global__ void cast_h16_to_f32_kernel(const unsigned short *x, float *y, int64_
     if (i < n) y[i] = H<HT>::to_f(x[i]);
 }
 
-// ---------------- GroupNorm on 16-bit NHWC maps: fp32/fp64 statistics, 16-bit output ----------------
-// A lane owns 8 consecutive channels (one 16-byte load) = two 4-channel halves; with 32 groups and C in
-// {128, 256, 512} a 4-channel half never straddles a group (cpg = 4, 8, 16).
-constexpr int GT = 256;
-
-template <int HT>
-__global__ __launch_bounds__(GT) void gn16_partial_kernel(const unsigned short *__restrict__ x, double *__restrict__ partial,
-                                                          int HW, int C, int groups, int pix_per_chunk) {
-    const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
-    const int c8 = C >> 3;             // 16-byte columns per pixel: 16, 32 or 64
-    const int rows = GT / c8;          // pixels per pass
-    const int col = threadIdx.x % c8, row = threadIdx.x / c8;
-    const int p0 = chunk * pix_per_chunk, p1 = min(HW, p0 + pix_per_chunk);
-    const u32x4 *xb = reinterpret_cast<const u32x4 *>(x + (int64_t)b * HW * C);
-    float s0 = 0.f, ss0 = 0.f, s1 = 0.f, ss1 = 0.f;
-    for (int pix = p0 + row; pix < p1; pix += rows) {
-        const u32x4 v = xb[(int64_t)pix * c8 + col];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float lo = H<HT>::to_f((unsigned short)(v[e] & 0xffffu)), hi = H<HT>::to_f((unsigned short)(v[e] >> 16));
-            if (e < 2) { s0 += lo + hi; ss0 += lo * lo + hi * hi; }
-            else { s1 += lo + hi; ss1 += lo * lo + hi * hi; }
-        }
-    }
-    __shared__ float sh[4][GT];
-    sh[0][threadIdx.x] = s0; sh[1][threadIdx.x] = ss0; sh[2][threadIdx.x] = s1; sh[3][threadIdx.x] = ss1;
-    __syncthreads();
-    if ((int)threadIdx.x < groups) {
-        const int g = threadIdx.x;
-        const int cpg = C / groups;
-        double ds = 0.0, dss = 0.0;
-        // halves (4 channels) of this group: channel range [g*cpg, (g+1)*cpg) -> half index h = c/4
-        for (int r = 0; r < rows; ++r)
-            for (int h = g * cpg / 4; h < (g + 1) * cpg / 4; ++h) {
-                const int t = r * c8 + (h >> 1);
-                ds += (double)sh[(h & 1) * 2][t];
-                dss += (double)sh[(h & 1) * 2 + 1][t];
-            }
-        double *o = partial + (((int64_t)b * nchunk + chunk) * groups + g) * 2;
-        o[0] = ds;
-        o[1] = dss;
-    }
-}
-
-template <int HT>
-__global__ __launch_bounds__(256) void gn16_apply_kernel(const unsigned short *__restrict__ x, const float *__restrict__ scale_shift,
-                                                         unsigned short *__restrict__ y, int64_t total8, int HW, int C,
-                                                         int fuse_swish) {
-    const int c8 = C >> 3;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (int64_t)gridDim.x * blockDim.x) {
-        const int col = (int)(i % c8);
-        const int b = (int)(i / ((int64_t)HW * c8));
-        const u32x4 v = reinterpret_cast<const u32x4 *>(x)[i];
-        const float *ssp = scale_shift + ((int64_t)b * C + col * 8) * 2;
-        u32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const f32x4 ss = *reinterpret_cast<const f32x4 *>(ssp + e * 4);  // sc,sh,sc,sh of channels 2e, 2e+1
-            float lo = H<HT>::to_f((unsigned short)(v[e] & 0xffffu)) * ss[0] + ss[1];
-            float hi = H<HT>::to_f((unsigned short)(v[e] >> 16)) * ss[2] + ss[3];
-            if (fuse_swish) { lo = sgam_swish(lo); hi = sgam_swish(hi); }
-            o[e] = (unsigned)H<HT>::from_f(lo) | ((unsigned)H<HT>::from_f(hi) << 16);
-        }
-        reinterpret_cast<u32x4 *>(y)[i] = o;
-    }
-}
-
-// the fp32 finalize kernel (scale/shift table) is shared with the fp32 path: declared in norm_softmax.hip
-}  // namespace
-
-extern "C" int sgam_gn_finalize_launch(const double *partial, const float *gamma, const float *beta, float *scale_shift,
-                                       int B, int HW, int C, int groups, int nchunk, float eps, hipStream_t s);
-
-namespace {
-
 // softmax over fp32 scores, probabilities written in the 16-bit type (the A operand of the P.V GEMM)
 template <int HT, int MAXV>
 __global__ __launch_bounds__(256) void softmax_rows_h16_kernel(const float *__restrict__ s, unsigned short *__restrict__ pout,
@@ -521,14 +446,6 @@ int conv_h16_launch(const sgam_conv_desc *d, const void *x, const void *w, const
     return SGAM_OK;
 }
 
-int gn16_nchunk(int HW, int C) {
-    const int rows = GT / (C / 8);
-    int n = HW / (rows * 16);
-    if (n > 256) n = 256;
-    if (n < 1) n = 1;
-    return n;
-}
-
 }  // namespace
 
 #define HT_DISPATCH(ht, CALL0, CALL1) \
@@ -594,37 +511,6 @@ extern "C" int sgam_cast_h16_f32(const void *x, float *y, int32_t ht, int64_t n,
     hipStream_t s = sgam_stream(stream);
     HT_DISPATCH(ht, hipLaunchKernelGGL(cast_h16_to_f32_kernel<0>, dim3(sgam_cdiv(n, 256)), dim3(256), 0, s, (const unsigned short *)x, y, n),
                 hipLaunchKernelGGL(cast_h16_to_f32_kernel<1>, dim3(sgam_cdiv(n, 256)), dim3(256), 0, s, (const unsigned short *)x, y, n));
-    SGAM_LAUNCH_CHECK();
-    return SGAM_OK;
-}
-
-extern "C" int64_t sgam_groupnorm_h16_workspace_bytes(int32_t B, int32_t HW, int32_t C) {
-    if (B <= 0 || HW <= 0 || C <= 0 || C % 128 != 0 || C > 1024) return -1;
-    return (int64_t)B * gn16_nchunk(HW, C) * 64 * 2 * (int64_t)sizeof(double) + (int64_t)B * C * 2 * (int64_t)sizeof(float);
-}
-
-extern "C" int sgam_groupnorm_nhwc_h16(const void *x, const float *gamma, const float *beta, void *y, int32_t ht, int32_t B,
-                                       int32_t HW, int32_t C, int32_t groups, float eps, int32_t fuse_swish, void *workspace,
-                                       int64_t workspace_bytes, void *stream) {
-    if (!x || !y || !gamma || !beta || B <= 0 || HW <= 0) return SGAM_EINVAL;
-    if (C <= 0 || C % 128 != 0 || C > 1024 || groups != 32) return SGAM_EINVAL;
-    if (!sgam_aligned16(x) || !sgam_aligned16(y) || !sgam_aligned16(workspace)) return SGAM_EALIGN;
-    if (!workspace || workspace_bytes < sgam_groupnorm_h16_workspace_bytes(B, HW, C)) return SGAM_EWORKSPACE;
-    hipStream_t s = sgam_stream(stream);
-    const int nchunk = gn16_nchunk(HW, C);
-    const int ppc = sgam_cdiv(HW, nchunk);
-    double *partial = (double *)workspace;
-    float *scale_shift = (float *)((char *)workspace + (int64_t)B * nchunk * 64 * 2 * sizeof(double));
-    HT_DISPATCH(ht, hipLaunchKernelGGL(gn16_partial_kernel<0>, dim3(nchunk, B), dim3(GT), 0, s, (const unsigned short *)x, partial, HW, C, groups, ppc),
-                hipLaunchKernelGGL(gn16_partial_kernel<1>, dim3(nchunk, B), dim3(GT), 0, s, (const unsigned short *)x, partial, HW, C, groups, ppc));
-    SGAM_LAUNCH_CHECK();
-    int rc = sgam_gn_finalize_launch(partial, gamma, beta, scale_shift, B, HW, C, groups, nchunk, eps, s);
-    if (rc != SGAM_OK) return rc;
-    const int64_t total8 = (int64_t)B * HW * (C / 8);
-    int blocks = sgam_cdiv(total8, 256);
-    if (blocks > 4096) blocks = 4096;
-    HT_DISPATCH(ht, hipLaunchKernelGGL(gn16_apply_kernel<0>, dim3(blocks), dim3(256), 0, s, (const unsigned short *)x, scale_shift, (unsigned short *)y, total8, HW, C, fuse_swish),
-                hipLaunchKernelGGL(gn16_apply_kernel<1>, dim3(blocks), dim3(256), 0, s, (const unsigned short *)x, scale_shift, (unsigned short *)y, total8, HW, C, fuse_swish));
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
 }

@@ -50,7 +50,7 @@ def test_conv_h16(dt, case):
 
 
 @pytest.mark.parametrize("dt", DT, ids=["bf16", "fp16"])
-@pytest.mark.parametrize("B,C,H,W", [(1, 128, 64, 64), (2, 256, 12, 12), (1, 512, 16, 16)])
+@pytest.mark.parametrize("B,C,H,W", [(1, 128, 64, 64), (2, 256, 12, 12), (1, 512, 16, 16), (1, 128, 256, 256), (2, 256, 80, 80)])
 def test_groupnorm_h16(dt, B, C, H, W):
     x = testing.seeded_tensor("gn16.x", (B, C, H, W), 3.0, 0.5).to(dt)
     g = 1 + 0.1 * testing.seeded_tensor("gn16.g", (C,))

@@ -94,7 +94,8 @@ def test_conv_with_fused_groupnorm_prologue(B, C, Cout, H, W, k, swish, ups):
     _close(fused.permute(0, 3, 1, 2), ref, 3e-5, "fused GN conv")
     unfused = ops.conv2d_nhwc(ops.groupnorm_nhwc(xd, g.to(DEV), bt.to(DEV), swish), wp, b.to(DEV), cout=Cout, kh=k, kw=k,
                               pad_t=k // 2, pad_l=k // 2, upsample2x=ups)
-    assert torch.equal(fused, unfused)
+    # same normalise/swish expression; statistics come from differently ordered fp64 sums -> last-bit agreement
+    assert (fused - unfused).abs().max().item() <= 2e-6 * max(1.0, unfused.abs().max().item())
 
 
 def test_conv_is_run_to_run_deterministic():
@@ -125,7 +126,7 @@ def test_gemm_nt_transpose_detecting(M, N, K, strided):
 
 
 @pytest.mark.parametrize("B,C,H,W", [(1, 128, 64, 64), (2, 256, 12, 12), (1, 512, 16, 16), (1, 128, 256, 256),
-                                     (1, 256, 7, 5)])
+                                     (1, 256, 7, 5), (2, 256, 128, 128), (1, 512, 70, 70)])
 @pytest.mark.parametrize("swish", [False, True])
 def test_groupnorm_swish(B, C, H, W, swish):
     x = testing.seeded_tensor("gn.x", (B, C, H, W), 3.0, 0.5)
