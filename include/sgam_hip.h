@@ -60,6 +60,9 @@ typedef struct sgam_conv_desc {
     int32_t lda, ldb, ldc, ldr;   /* row strides in floats of x, w_packed, out, residual */
     int32_t n_valid;              /* columns actually stored (<= N) */
     int32_t bias_per_row;         /* 0: bias[n]; 1: bias[m] (used for the transposed V projection) */
+    /* optional plan override (autotuner, sgam_neurips22_amd/tune.py); 0 = built-in heuristic.
+     * (plan_bm, plan_bn) in {(128,128), (64,128), (64,64)}; plan_ksplit >= 1. */
+    int32_t plan_bm, plan_bn, plan_ksplit;
 } sgam_conv_desc;
 
 int64_t sgam_conv2d_workspace_bytes(const sgam_conv_desc *d);

@@ -13,7 +13,7 @@ class ConvDesc(ctypes.Structure):
     """mirror of struct sgam_conv_desc"""
     _fields_ = [(n, c_i32) for n in (
         "B", "Hi", "Wi", "Cin", "Ho", "Wo", "N", "KH", "KW", "stride", "pad_t", "pad_l", "upsample2x",
-        "lda", "ldb", "ldc", "ldr", "n_valid", "bias_per_row")]
+        "lda", "ldb", "ldc", "ldr", "n_valid", "bias_per_row", "plan_bm", "plan_bn", "plan_ksplit")]
 
 
 # name -> (restype, argtypes); must list every symbol include/sgam_hip.h declares

@@ -766,10 +766,16 @@ Plan make_plan(const sgam_conv_desc *d) {
     } else {
         pl.bm = 64; pl.bn = 64;
     }
+    if (d->plan_bm > 0 && d->plan_bn > 0) {   // autotuned override
+        pl.bm = d->plan_bm; pl.bn = d->plan_bn; pl.bk = BK;
+    }
     pl.iters_total = d->KH * d->KW * ((d->Cin + pl.bk - 1) / pl.bk);
     const int64_t nb = blocks(pl.bm, pl.bn);
     int ks = 1;
-    if (nb < 192) {
+    if (d->plan_ksplit > 0) {
+        ks = d->plan_ksplit;
+        if (ks > pl.iters_total) ks = pl.iters_total;
+    } else if (nb < 192) {
         ks = (int)((384 + nb - 1) / nb);              // aim for ~1.5 workgroups per CU
         const int max_by_iters = pl.iters_total / 4;  // keep >= 4 K-slabs per split
         if (ks > max_by_iters) ks = max_by_iters;
@@ -790,6 +796,12 @@ int validate(const sgam_conv_desc *d) {
     if (d->lda < d->Cin || d->lda % 4 != 0) return SGAM_EALIGN;
     if (d->ldb < d->KH * d->KW * d->Cin || d->ldb % 4 != 0) return SGAM_EALIGN;
     if (d->n_valid <= 0 || d->n_valid > d->N || d->ldc < d->n_valid) return SGAM_EINVAL;
+    if (d->plan_bm != 0 || d->plan_bn != 0) {
+        const bool ok = (d->plan_bm == 128 && d->plan_bn == 128) || (d->plan_bm == 64 && d->plan_bn == 128) ||
+                        (d->plan_bm == 64 && d->plan_bn == 64);
+        if (!ok || (d->plan_bn == 128 && d->N % 128 != 0)) return SGAM_EINVAL;
+    }
+    if (d->plan_ksplit < 0 || d->plan_ksplit > 64) return SGAM_EINVAL;
     return SGAM_OK;
 }
 

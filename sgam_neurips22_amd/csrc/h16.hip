@@ -386,9 +386,13 @@ HPlan make_hplan(const sgam_conv_desc *d) {
     if (d->N % 128 == 0 && blocks(128, 128) >= 224) { pl.bm = 128; pl.bn = 128; }
     else if (d->N % 128 == 0 && blocks(64, 128) >= 224) { pl.bm = 64; pl.bn = 128; }
     else { pl.bm = 64; pl.bn = 64; }
+    if (d->plan_bm > 0 && d->plan_bn > 0) { pl.bm = d->plan_bm; pl.bn = d->plan_bn; }   // autotuned override
     const int64_t nb = blocks(pl.bm, pl.bn);
     int ks = 1;
-    if (nb < 192) {
+    if (d->plan_ksplit > 0) {
+        ks = d->plan_ksplit;
+        if (ks > pl.iters_total) ks = pl.iters_total;
+    } else if (nb < 192) {
         ks = (int)((384 + nb - 1) / nb);
         const int max_by_iters = pl.iters_total / 4;
         if (ks > max_by_iters) ks = max_by_iters;
@@ -408,6 +412,12 @@ int hvalidate(const sgam_conv_desc *d) {
     if (d->lda < d->Cin || d->lda % 8 != 0) return SGAM_EALIGN;
     if (d->ldb < d->KH * d->KW * d->Cin || d->ldb % 8 != 0) return SGAM_EALIGN;
     if (d->n_valid <= 0 || d->n_valid > d->N || d->ldc < d->n_valid) return SGAM_EINVAL;
+    if (d->plan_bm != 0 || d->plan_bn != 0) {
+        const bool ok = (d->plan_bm == 128 && d->plan_bn == 128) || (d->plan_bm == 64 && d->plan_bn == 128) ||
+                        (d->plan_bm == 64 && d->plan_bn == 64);
+        if (!ok || (d->plan_bn == 128 && d->N % 128 != 0)) return SGAM_EINVAL;
+    }
+    if (d->plan_ksplit < 0 || d->plan_ksplit > 64) return SGAM_EINVAL;
     return SGAM_OK;
 }
 

@@ -7,6 +7,7 @@ torch is used here only as plumbing: device allocations (`torch.empty`), the cur
 Internal activation layout is NHWC fp32: tensors of shape (B, H, W, C), contiguous.
 """
 import ctypes
+import os
 
 import torch
 
@@ -94,6 +95,34 @@ def pack_conv_weight(w_oihw, cout_pad=None, cin_pad=None, dtype=torch.float32):
 # ------------------------------------------------------------------------------------------------
 CONV_TRACE = None  # set to a list by bench.py's profiling pass: (desc copy, flops, start event, end event)
 
+# ---- autotuned launch plans (sgam_neurips22_amd/tune.py): shape key -> (bm, bn, ksplit) ----
+PLAN_CACHE = {}
+PLAN_RECORD = None  # set to a dict by the tuner to collect the distinct shapes of a model run
+_PLAN_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_plans_gfx950.json")
+
+
+def plan_key(desc, dtype):
+    return (f"{str(dtype).replace('torch.', '')}|B{desc.B}|{desc.Hi}x{desc.Wi}x{desc.Cin}|{desc.Ho}x{desc.Wo}|N{desc.N}|"
+            f"k{desc.KH}x{desc.KW}s{desc.stride}u{desc.upsample2x}")
+
+
+def load_plans(path=_PLAN_FILE):
+    PLAN_CACHE.clear()
+    if os.path.exists(path) and not os.environ.get("SGAM_NO_TUNED_PLANS"):
+        import json
+        with open(path) as f:
+            PLAN_CACHE.update({k: tuple(v) for k, v in json.load(f).get("plans", {}).items()})
+    return len(PLAN_CACHE)
+
+
+def _apply_plan(desc, dtype):
+    if PLAN_RECORD is not None:
+        PLAN_RECORD.setdefault(plan_key(desc, dtype), None)
+    if desc.plan_bm == 0 and desc.plan_ksplit == 0:
+        pl = PLAN_CACHE.get(plan_key(desc, dtype))
+        if pl:
+            desc.plan_bm, desc.plan_bn, desc.plan_ksplit = pl
+
 
 def conv_plan(desc, h16=False):
     bm, bn, ks = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
@@ -104,6 +133,7 @@ def conv_plan(desc, h16=False):
 
 def _run_conv(desc, x, w, bias, residual, out, gn=None):
     lib = _lib.load()
+    _apply_plan(desc, x.dtype)
     if CONV_TRACE is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
@@ -431,3 +461,6 @@ def frame_feedback(dec, dataset, want_u8=False):
     check(_lib.load().sgam_frame_feedback_f32(_p(dec), _p(rgb_lut(dec.device)), DATASET_NORM[dataset], _p(u8), _p(rgb_f),
                                               _p(depth), B, H * W, _stream()), "sgam_frame_feedback_f32")
     return (rgb_f, depth, u8) if want_u8 else (rgb_f, depth)
+
+
+load_plans()

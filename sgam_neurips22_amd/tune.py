@@ -1,0 +1,148 @@
+"""Launch-plan autotuner for the implicit-GEMM convolutions / GEMMs of the VQGAN.
+
+For every distinct (dtype, shape) the model launches, time each legal (tile, split-K) candidate of
+sgam_conv2d_nhwc_{f32,h16} on the GPU and keep the fastest; the table is stored in
+``tuned_plans_gfx950.json`` next to this file and applied transparently by ``ops`` (descriptor fields
+plan_bm / plan_bn / plan_ksplit).  Results are unaffected up to fp32 summation order (split-K changes the
+order of the K reduction, never the set of products).
+
+    python -m sgam_neurips22_amd.tune [--dtypes f32,fp16] [--out path]
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+
+import torch
+
+from . import _lib, ops, testing
+from ._lib import ConvDesc
+
+TILES = [(128, 128), (64, 128), (64, 64)]
+
+
+def _parse(key):
+    dt, b, ishape, oshape, n, rest = key.split("|")
+    Hi, Wi, Cin = map(int, ishape.split("x"))
+    Ho, Wo = map(int, oshape.split("x"))
+    k, su = rest[1:].split("s")
+    KH, KW = map(int, k.split("x"))
+    stride, ups = map(int, su.split("u"))
+    return dt, int(b[1:]), Hi, Wi, Cin, Ho, Wo, int(n[1:]), KH, KW, stride, ups
+
+
+def _time(desc, x, w, out, reps=6):
+    lib = _lib.load()
+    h16 = x.dtype in ops.H16
+
+    def run():
+        nb = (lib.sgam_conv2d_h16_workspace_bytes if h16 else lib.sgam_conv2d_workspace_bytes)(ctypes.byref(desc))
+        if nb < 0:
+            return False
+        ws = torch.empty((max(nb, 16),), device=x.device, dtype=torch.uint8)
+        if h16:
+            rc = lib.sgam_conv2d_nhwc_h16(ctypes.byref(desc), ops.H16[x.dtype], ops._p(x), ops._p(w), None, None, ops._p(out),
+                                          0, ops._p(ws), nb, ops._stream())
+        else:
+            rc = lib.sgam_conv2d_nhwc_f32(ctypes.byref(desc), ops._p(x), ops._p(w), None, None, ops._p(out), ops._p(ws), nb,
+                                          ops._stream())
+        return rc == 0
+
+    if not run():
+        return None
+    run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def tune_shape(key, verbose=True):
+    dt, B, Hi, Wi, Cin, Ho, Wo, N, KH, KW, stride, ups = _parse(key)
+    dtype = ops.DTYPES["f32" if dt == "float32" else ("bf16" if dt == "bfloat16" else "fp16")]
+    dev = "cuda"
+    x = testing.seeded_tensor("tune.x", (B * Hi * Wi, Cin)).to(dev).to(dtype)
+    K = KH * KW * Cin
+    w = (testing.seeded_tensor("tune.w", (N, K)) * 0.03).to(dev).to(dtype)
+    out = torch.empty((B * Ho * Wo, N), device=dev, dtype=dtype)
+    pad = (KH // 2) if stride == 1 else 0
+    base = dict(B=B, Hi=Hi, Wi=Wi, Cin=Cin, Ho=Ho, Wo=Wo, N=N, KH=KH, KW=KW, stride=stride, pad_t=pad, pad_l=pad,
+                upsample2x=ups, lda=Cin, ldb=K, ldc=N, ldr=0, n_valid=N, bias_per_row=0)
+    slab = 64 if dtype in ops.H16 else 32
+    iters = KH * KW * ((Cin + slab - 1) // slab)
+    M = B * Ho * Wo
+    results = []
+    t_auto = _time(ConvDesc(**base, plan_bm=0, plan_bn=0, plan_ksplit=0), x, w, out)
+    for bm, bn in TILES:
+        if bn == 128 and N % 128:
+            continue
+        blocks = -(-M // bm) * -(-N // bn)
+        cands = {1}
+        for target in (256, 512, 768, 1024):
+            ks = max(1, round(target / blocks))
+            if ks <= iters // 2 and ks <= 64:
+                cands.add(ks)
+        for ks in sorted(cands):
+            if blocks * ks > 8192:
+                continue
+            t = _time(ConvDesc(**base, plan_bm=bm, plan_bn=bn, plan_ksplit=ks), x, w, out)
+            if t is not None:
+                results.append((t, bm, bn, ks))
+    results.sort()
+    best = results[0]
+    if verbose:
+        gf = 2.0 * M * N * K / 1e9
+        print(f"{key:70s} auto {t_auto * 1e3:7.1f} us -> best {best[0] * 1e3:7.1f} us {best[1:]}  "
+              f"({gf / best[0] / 1e3:6.1f} TFLOP/s)", flush=True)
+    # keep the heuristic unless the tuned plan wins by >3% (run-to-run noise)
+    if t_auto is not None and best[0] > 0.97 * t_auto:
+        return None, t_auto, best
+    return best[1:], t_auto, best
+
+
+def collect_shapes(dtypes, dataset="google_earth", res=256):
+    from .config import default_params
+    from .generative_sensing_module.model import VQModel
+    keys = {}
+    m = VQModel(**default_params(dataset))
+    m.load_state_dict(testing.synthetic_state_dict(m.state_dict(), seed=0))
+    m = m.to("cuda").eval()
+    x, mask = testing.rect_hole_input(1, res, res)
+    for dt in dtypes:
+        m.set_compute_dtype(dt)
+        ops.PLAN_RECORD = {}
+        with torch.no_grad():
+            m(x.cuda(), topk=1, extrapolation_mask=mask.cuda())
+        keys.update(ops.PLAN_RECORD)
+        ops.PLAN_RECORD = None
+    return sorted(keys)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dtypes", default="f32,fp16,bf16")
+    ap.add_argument("--out", default=ops._PLAN_FILE)
+    a = ap.parse_args()
+    os.environ["SGAM_NO_TUNED_PLANS"] = "1"
+    ops.load_plans()
+    keys = collect_shapes(a.dtypes.split(","))
+    print(f"{len(keys)} distinct conv/GEMM shapes", flush=True)
+    plans, saved = {}, 0.0
+    for k in keys:
+        pl, t_auto, best = tune_shape(k)
+        if pl:
+            plans[k] = list(pl)
+            saved += (t_auto - best[0])
+    print(f"tuned {len(plans)} of {len(keys)} shapes; sum of per-shape savings {saved * 1e3:.0f} us (one launch each)")
+    with open(a.out, "w") as f:
+        json.dump({"device": torch.cuda.get_device_name(0), "plans": plans}, f, indent=0, sort_keys=True)
+    print("wrote", a.out)
+
+
+if __name__ == "__main__":
+    sys.exit(main())
