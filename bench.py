@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=6, help="frames of the CPU oracle baseline (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the fp16 throughput-mode leg")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying HIP graphs")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "fp16"],
                     help="arithmetic of the VQGAN body: f32 = parity path (fp32-in MFMA), bf16/fp16 = 16-bit MFMA path")
     args = ap.parse_args()
@@ -128,6 +129,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     model, sd, p = build_model(dev)
     model.set_compute_dtype(args.dtype)
+    model.enable_hip_graph(not args.no_graph)
     seed_frame = synthetic_seed_frame(DATASET, seed_index=rank)
     n_frames = args.warmup + args.steps + 2
     scene = InfiniteSceneGeneration(model, DATASET, seed_index=rank, output_dim=(n_frames + 1, 1), seed_frame=seed_frame)
@@ -217,7 +219,8 @@ def main():
             "config": {"workload": "GoogleEarth-Infinite 256x256 inference loop: forward-splat warp (N<=3) + VQGAN "
                                    "encode/quantise(4096)/decode + frame feedback, in-HBM frame store",
                        "frames_per_gpu": args.steps, "scenes": world, "parallelism": f"scene-parallel x{world}",
-                       "weights": "seeded synthetic (68 990 620 params)", "topk": 1},
+                       "weights": "seeded synthetic (68 990 620 params)", "topk": 1,
+                       "launch": "eager" if args.no_graph else "hip-graph replay of the VQGAN forward"},
             "vqgan_tflops_wallclock": round(GFLOP_PER_FRAME * g["total_frames"] / t_max / 1e3 / world, 2),
             "roofline": roofline, "cpu_baseline": cpu, "throughput_mode": secondary, "frame_checksums": [r[2] for r in g["per_rank"]],
         }

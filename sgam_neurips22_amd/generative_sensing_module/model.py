@@ -43,6 +43,9 @@ class VQModel(nn.Module):
         # arithmetic of the VQGAN body: float32 = parity path (fp32-in MFMA); bfloat16 / float16 = throughput
         # path (16-bit MFMA, fp32 accumulate).  The quantiser always runs in fp32 on the fp32 latent.
         self.compute_dtype = torch.float32
+        # replay the ~340 kernel launches of one forward from a captured HIP graph (opt-in: enable_hip_graph())
+        self.use_hip_graph = False
+        self._graphs = {}
         if self.use_extrapolation_mask:
             self.conv_in = Conv2d(5, 4, kernel_size=1)
         self.encoder = Encoder(**ddconfig)
@@ -82,6 +85,42 @@ class VQModel(nn.Module):
         self.compute_dtype = ops.DTYPES[dtype] if isinstance(dtype, str) else dtype
         return self
 
+    def enable_hip_graph(self, on=True):
+        """Capture `forward` once per (input shape, flags, dtype) into a HIP graph (hipStreamBeginCapture through
+        torch.cuda.graph — the kernels are this library's, launched on the capturing stream) and replay it on later
+        calls: one graph launch instead of ~340 kernel launches, no per-launch host work, intermediates in a
+        graph-private pool.  Outputs of a replay are the graph's static tensors: they are overwritten by the next
+        call with the same signature (the scene loop consumes them before that).  Weights must not change while
+        graphs exist (call enable_hip_graph(False) first)."""
+        self.use_hip_graph = bool(on)
+        if not on:
+            self._graphs = {}
+        return self
+
+    def _forward_graphed(self, input, topk, extrapolation_mask, sample_number, flags):
+        key = (tuple(input.shape), None if extrapolation_mask is None else tuple(extrapolation_mask.shape), topk,
+               sample_number, flags, self.compute_dtype, str(input.device))
+        ent = self._graphs.get(key)
+        if ent is None:
+            sx = input.detach().clone()
+            sm = None if extrapolation_mask is None else extrapolation_mask.detach().clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):          # eager warm-up: weight packing, codebook norms, allocator pools
+                for _ in range(2):
+                    self._forward_eager(sx, topk, sm, sample_number, *flags)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self._forward_eager(sx, topk, sm, sample_number, *flags)
+            ent = self._graphs[key] = (graph, sx, sm, out)
+        graph, sx, sm, out = ent
+        sx.copy_(input)
+        if sm is not None:
+            sm.copy_(extrapolation_mask)
+        graph.replay()
+        return out
+
     # ---- NHWC core ----
     def _encode_nhwc(self, x, extrapolation_mask):
         """x (B,4,H,W) NCHW + mask -> pre-quant latent (B,h,w,D) NHWC fp32."""
@@ -119,6 +158,14 @@ class VQModel(nn.Module):
 
     def forward(self, input, topk=None, extrapolation_mask=None, sample_number=1, get_codebook_count=False,
                 get_pre_quantized_feature=False, get_quantized_feature=False):
+        flags = (bool(get_codebook_count), bool(get_pre_quantized_feature), bool(get_quantized_feature))
+        replay_safe = topk is None or (topk == 1 and not self.quantize.consume_host_rng)   # no host RNG in the graph
+        if self.use_hip_graph and ops.CONV_TRACE is None and replay_safe and input.is_cuda and not torch.is_grad_enabled():
+            return self._forward_graphed(input, topk, extrapolation_mask, sample_number, flags)
+        return self._forward_eager(input, topk, extrapolation_mask, sample_number, *flags)
+
+    def _forward_eager(self, input, topk=None, extrapolation_mask=None, sample_number=1, get_codebook_count=False,
+                       get_pre_quantized_feature=False, get_quantized_feature=False):
         pre = self._encode_nhwc(input, extrapolation_mask)
         if not self.use_vq():
             dec = ops.nhwc_to_nchw(self._decode_nhwc(pre))

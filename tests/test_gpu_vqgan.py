@@ -184,3 +184,37 @@ def test_config5_512sq_batched(golden):
     assert agree == 1.0 or gap < 1e-4, f"index agreement {agree} with top-2 margin {gap:.1e}"
     if agree == 1.0:
         assert _maxerr(dec[:1], o["dec"]) <= TOL
+
+
+@pytest.mark.parametrize("dt", ["f32", "fp16"])
+def test_hip_graph_replay_is_bit_identical_to_eager(golden, dt):
+    """enable_hip_graph(): captured replay == eager launches, bit for bit, across different inputs and for the
+    three-step scene loop (the graph's static outputs are consumed before the next replay)."""
+    g = golden("vqgan_full_ge256.npz")
+    m, sd, p = _model("google_earth", g)
+    m.set_compute_dtype(dt)
+    outs = []
+    for graphed in (False, True):
+        m.enable_hip_graph(graphed)
+        res = []
+        for seed in (3, 4, 5):
+            x, mask = testing.rect_hole_input(1, 256, 256, seed=seed)
+            with torch.no_grad():
+                decs, _, idx, pre, quant = m(x.to(DEV), topk=1, extrapolation_mask=mask.to(DEV), get_codebook_count=True,
+                                             get_pre_quantized_feature=True, get_quantized_feature=True)
+            res.append((decs[0].clone(), idx.clone(), pre.clone(), quant.clone()))
+        outs.append(res)
+    assert len(m._graphs) == 1
+    for e, r in zip(*outs):
+        assert all(torch.equal(a, b) for a, b in zip(e, r))
+    # scene loop under graphs == eager scene loop
+    tr = golden("trajectory_ge.npz")
+    frames = []
+    for graphed in (False, True):
+        m.enable_hip_graph(graphed)
+        scene = InfiniteSceneGeneration(m, "google_earth", seed_index=0, output_dim=(4, 1), seed_frame=(tr["seed_rgb"], tr["seed_depth"]))
+        scene.scene_expansion()
+        frames.append(scene.frames)
+    for c in frames[0]:
+        assert torch.equal(frames[0][c]["rgb_u8"], frames[1][c]["rgb_u8"]) and torch.equal(frames[0][c]["depth"], frames[1][c]["depth"])
+    m.enable_hip_graph(False)
