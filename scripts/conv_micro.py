@@ -15,11 +15,13 @@ ap.add_argument("--shape", default="1,128,128,256,256,3")
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--ups", action="store_true")
 ap.add_argument("--gn", action="store_true")
+ap.add_argument("--dtype", default="f32")
 a = ap.parse_args()
 B, Cin, Cout, H, W, k = map(int, a.shape.split(","))
 dev = "cuda"
-x = testing.seeded_tensor("micro.x", (B, H, W, Cin)).to(dev)
-w = ops.pack_conv_weight(testing.seeded_tensor("micro.w", (Cout, Cin, k, k), 0.03).to(dev))
+dt = ops.DTYPES[a.dtype]
+x = testing.seeded_tensor("micro.x", (B, H, W, Cin)).to(dev).to(dt)
+w = ops.pack_conv_weight(testing.seeded_tensor("micro.w", (Cout, Cin, k, k), 0.03).to(dev), dtype=dt)
 b = testing.seeded_tensor("micro.b", (Cout,)).to(dev)
 gn = None
 if a.gn:

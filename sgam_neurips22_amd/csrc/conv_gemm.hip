@@ -39,8 +39,6 @@ struct ConvKernelParams {
     const float *gn;  // fused GroupNorm prologue: per-(batch, input channel) {scale, shift} pairs, or nullptr
     int gn_swish;
     unsigned x_bytes, w_bytes;  // extents of the A / B operands for the bounds-checked buffer loads
-    int stagger_shift;
-    int stagger;  // experiment: phase-shift every second resident workgroup by this many 64-cycle sleeps
     int B, Hi, Wi, Cin, Ho, Wo, N, KH, KW, stride, pad_t, pad_l, ups;
     int lda, ldb, ldc, ldr, n_valid, bias_per_row;
     int M, ksplit, iters_total, iters_per_split;
@@ -374,14 +372,6 @@ __global__ __launch_bounds__(256) void conv_gemm_f32_v2_kernel(const ConvKernelP
     issue_loads(it0 < it1);
     store_lds(0);
     __syncthreads();
-    if (p.stagger > 0) {
-        // co-resident workgroups start in lock-step (same launch instant, same work): shift every second
-        // "round" of 256 workgroups by ~half a K slab so that one group's staging gaps meet the other's MFMAs
-        const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        if ((lin >> p.stagger_shift) & 1) {
-            for (int k = 0; k < p.stagger; ++k) __builtin_amdgcn_s_sleep(16);
-        }
-    }
 
     for (int it = it0; it < it1; ++it) {
         const int buf = (it - it0) & 1;
@@ -882,10 +872,6 @@ extern "C" int sgam_conv2d_gn_nhwc_f32(const sgam_conv_desc *d, const float *x, 
     const int64_t wb = (((int64_t)d->N - 1) * d->ldb + (int64_t)d->KH * d->KW * d->Cin) * 4;
     if (xb >= (1ll << 32) - 64 || wb >= (1ll << 32) - 64) return SGAM_EINVAL;  // 32-bit buffer offsets
     p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
-    static const int stagger = [] { const char *e = getenv("SGAM_STAGGER"); return e ? atoi(e) : 0; }();
-    p.stagger = stagger;
-    static const int sshift = [] { const char *e = getenv("SGAM_STAGGER_SHIFT"); return e ? atoi(e) : 8; }();
-    p.stagger_shift = sshift;
     if (pl.ksplit > 1) {
         const int64_t need = (int64_t)pl.ksplit * p.M * p.N * (int64_t)sizeof(float);
         if (!workspace || workspace_bytes < need || !sgam_aligned16(workspace)) return SGAM_EWORKSPACE;

@@ -10,6 +10,9 @@
 //     (attention scores, the latent fed to the fp32 quantiser, the final RGB-D);
 //   * GroupNorm statistics, softmax, bias and residual arithmetic stay in fp32.
 // `ht` selects the type at run time: 0 = bf16, 1 = fp16.
+#include <stdlib.h>
+#include <type_traits>
+
 #include "sgam_common.h"
 
 namespace {
@@ -107,8 +110,12 @@ __global__ __launch_bounds__(256) void conv_gemm_h16_kernel(const H16Params p) {
     int ky = tap / p.KW;
     int kx = tap - ky * p.KW;
 
-    u32x4 areg[AR], breg[BR];
-    auto issue_loads = [&](bool live) {
+    // two register stages: a slab requested in step t is written to LDS in step t+1 and consumed in step t+2,
+    // so every buffer load has TWO K steps (not one) to come back — with 16-bit operands a step is only
+    // 16 MFMAs (~0.5k cycles) per wavefront, far less than an L2 round trip.
+    u32x4 areg[2][AR], breg[2][BR];
+    auto issue_loads = [&](bool live, auto stage_tag) {
+        constexpr int ST = decltype(stage_tag)::value;
         const int coff = ch * HBK + col8 * 8;
         const bool k_ok = live && coff < p.Cin;
 #pragma unroll
@@ -117,12 +124,12 @@ __global__ __launch_bounds__(256) void conv_gemm_h16_kernel(const H16Params p) {
             const bool ok = k_ok && (unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl;
             const int py = iy >> p.ups, px = ix >> p.ups;
             const unsigned off = (unsigned)((a_base[r] + py * p.Wi + px) * p.lda + coff) * 2u;
-            areg[r] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)selu(ok, off, p.x_bytes), 0, 0);
+            areg[ST][r] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)selu(ok, off, p.x_bytes), 0, 0);
         }
         const unsigned koff = (unsigned)(tap * p.Cin + ch * HBK) * 2u;
 #pragma unroll
         for (int r = 0; r < BR; ++r)
-            breg[r] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)selu(k_ok, b_off[r] + koff, p.w_bytes), 0, 0);
+            breg[ST][r] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)selu(k_ok, b_off[r] + koff, p.w_bytes), 0, 0);
         ++tap;
         if (++kx == p.KW) {
             kx = 0;
@@ -133,14 +140,17 @@ __global__ __launch_bounds__(256) void conv_gemm_h16_kernel(const H16Params p) {
             ++ch;
         }
     };
-    auto store_lds = [&](int buf) {
+    auto store_lds = [&](int buf, auto stage_tag) {
+        constexpr int ST = decltype(stage_tag)::value;
         unsigned short *a = As + buf * BM * HLD;
         unsigned short *b = Bs + buf * BN * HLD;
 #pragma unroll
-        for (int r = 0; r < AR; ++r) *reinterpret_cast<u32x4 *>(a + (row_in_pass + 32 * r) * HLD + col8 * 8) = areg[r];
+        for (int r = 0; r < AR; ++r) *reinterpret_cast<u32x4 *>(a + (row_in_pass + 32 * r) * HLD + col8 * 8) = areg[ST][r];
 #pragma unroll
-        for (int r = 0; r < BR; ++r) *reinterpret_cast<u32x4 *>(b + (row_in_pass + 32 * r) * HLD + col8 * 8) = breg[r];
+        for (int r = 0; r < BR; ++r) *reinterpret_cast<u32x4 *>(b + (row_in_pass + 32 * r) * HLD + col8 * 8) = breg[ST][r];
     };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -153,18 +163,11 @@ __global__ __launch_bounds__(256) void conv_gemm_h16_kernel(const H16Params p) {
     const int frag_row = lane & 31;
     const int frag_k = (lane >> 5) * 8;
 
-    issue_loads(it0 < it1);
-    store_lds(0);
-    __syncthreads();
-
-    for (int it = it0; it < it1; ++it) {
-        const int buf = (it - it0) & 1;
+    auto mfma_half = [&](int buf, int kk0) {
         const unsigned short *a = As + buf * BM * HLD + (wm * (BM / 2) + frag_row) * HLD + frag_k;
         const unsigned short *b = Bs + buf * BN * HLD + (wn * (BN / 2) + frag_row) * HLD + frag_k;
-        issue_loads((it + 1) < it1);
 #pragma unroll
-        for (int kk = 0; kk < HBK / 16; ++kk) {
-            if (kk == HBK / 32) store_lds(buf ^ 1);
+        for (int kk = kk0; kk < kk0 + HBK / 32; ++kk) {
             u32x4 af[TM], bf[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const u32x4 *>(a + i * 32 * HLD + kk * 16);
@@ -175,6 +178,27 @@ __global__ __launch_bounds__(256) void conv_gemm_h16_kernel(const H16Params p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = H<HT>::mfma(af[i], bf[j], acc[i][j]);
         }
+    };
+
+    int nleft = it1 - it0;                 // slabs not yet requested
+    issue_loads(nleft-- > 0, S0{});        // slab 0 -> stage 0
+    store_lds(0, S0{});
+    issue_loads(nleft-- > 0, S1{});        // slab 1 -> stage 1 (in flight across the barrier)
+    __syncthreads();
+
+    // slabs past the end are requested out of range (zeros) and contribute nothing: the loop can always run in pairs
+    for (int it = it0; it < it1; it += 2) {
+        // even step: LDS buffer 0 holds slab `it`; stage 1 holds slab it+1 (in flight); request slab it+2 into stage 0
+        issue_loads(nleft-- > 0, S0{});
+        mfma_half(0, 0);
+        store_lds(1, S1{});
+        mfma_half(0, HBK / 32);
+        __syncthreads();
+        // odd step: buffer 1 holds slab it+1; stage 0 holds slab it+2 (in flight); request slab it+3 into stage 1
+        issue_loads(nleft-- > 0, S1{});
+        mfma_half(1, 0);
+        store_lds(0, S0{});
+        mfma_half(1, HBK / 32);
         __syncthreads();
     }
 

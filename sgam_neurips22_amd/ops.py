@@ -402,8 +402,12 @@ def forward_splat(src_feats, src_depths, tgt_K, src_Kinv, T, *, channels_last=Fa
     norm = DATASET_NORM.get(dataset, 0) if dataset else 0
     if "x" in want and norm == 0:
         raise NotImplementedError(f"dataset {dataset!r}")
+    # keep every contiguous copy alive in a local until the launch is enqueued: a temporary passed as
+    # `_p(_f32c(t))` is freed right after `_p` returns, and the caching allocator may hand its block to the NEXT
+    # temporary, whose copy kernel then lands before ours on the same stream
+    kt, kinv, tt = _f32c(tgt_K), _f32c(src_Kinv), _f32c(T)
     check(_lib.load().sgam_forward_splat_f32(
-        _p(f), cs, ps, _p(d), _p(_f32c(tgt_K)), _p(_f32c(src_Kinv)), _p(_f32c(T)), B, N, H, W, dr, norm, _p(winner),
+        _p(f), cs, ps, _p(d), _p(kt), _p(kinv), _p(tt), B, N, H, W, dr, norm, _p(winner),
         _p(o.get("merge_depths")), _p(o.get("merge_feats")), _p(o.get("extrap")), _p(o.get("x")),
         _p(o.get("proj_feats")), _p(o.get("proj_depth")), _p(o.get("inb_mask")), _p(o.get("pix_xy")), _stream()),
         "sgam_forward_splat_f32")
@@ -429,8 +433,8 @@ def inverse_warp(src_imgs, src_depths, tgt_depth, src_K, tgt_Kinv, T_tgt2src, wa
     B, N, _, H, W = im.shape
     out = torch.empty((B, 3, H, W), device=im.device, dtype=torch.float32)
     zb = torch.empty((B, H, W), device=im.device, dtype=torch.float32) if want_zbuf else None
-    check(_lib.load().sgam_inverse_warp_f32(_p(im), _p(_f32c(src_depths)), _p(_f32c(tgt_depth)), _p(_f32c(src_K)),
-                                            _p(_f32c(tgt_Kinv)), _p(_f32c(T_tgt2src)), B, N, H, W, _p(out), _p(zb),
+    sd, td, sk, tk, tt = _f32c(src_depths), _f32c(tgt_depth), _f32c(src_K), _f32c(tgt_Kinv), _f32c(T_tgt2src)  # keep alive
+    check(_lib.load().sgam_inverse_warp_f32(_p(im), _p(sd), _p(td), _p(sk), _p(tk), _p(tt), B, N, H, W, _p(out), _p(zb),
                                             _stream()), "sgam_inverse_warp_f32")
     return (out, zb) if want_zbuf else out
 

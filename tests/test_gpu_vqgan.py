@@ -218,3 +218,57 @@ def test_hip_graph_replay_is_bit_identical_to_eager(golden, dt):
     for c in frames[0]:
         assert torch.equal(frames[0][c]["rgb_u8"], frames[1][c]["rgb_u8"]) and torch.equal(frames[0][c]["depth"], frames[1][c]["depth"])
     m.enable_hip_graph(False)
+
+
+def test_rgbd_branch_with_depth_provider_matches_oracle():
+    """Config 3(B): the `use_rgbd_integration` conditioning branch — inverse_warping fed with a target depth
+    (here: the forward-splat depth, standing in for the Open3D TSDF render that is out of scope), then
+    get_x's warped_tgt_features path (model.py:196-199).  Checked bit-for-bit against the oracle's inverse warp
+    and depth codec."""
+    m = VQModel(**default_params("google_earth")).to(DEV).eval()
+
+    def provider(scene, tgt_node, src_nodes, batch):
+        Kinv = batch["_src_Kinv"]
+        R, t, _ = scene.relative_poses(tgt_node, src_nodes)
+        T = torch.zeros((len(src_nodes), 4, 4), device=DEV)
+        T[:, :3, :3] = torch.from_numpy(R.astype(np.float32)).to(DEV)
+        T[:, :3, 3] = torch.from_numpy(t.astype(np.float32)).to(DEV)
+        T[:, 3, 3] = 1
+        o = ops.forward_splat(batch["src_imgs"], batch["src_depths"], batch["Ks"][:, 0], Kinv, T, channels_last=True,
+                              want=("merge_depths",))
+        return o["merge_depths"][0, 0]
+
+    scene = InfiniteSceneGeneration(m, "google_earth", seed_index=2, output_dim=(4, 1), use_rgbd_integration=True,
+                                    tgt_depth_provider=provider)
+    for step in range(3):
+        tgt = scene.next_pose(scene.curr)
+        srcs, _ = scene.get_src_grid_coords(tgt)
+        tgt_meta = scene.transform_grid[tgt[0]][tgt[1]]
+        src_metas = [scene.transform_grid[c[0]][c[1]] for c in srcs]
+        batch = scene.prepare_batch_data(tgt_meta, src_metas, scene.num_src)
+        # oracle inverse warp on the same operands
+        _, _, T_t2s = scene.relative_poses(tgt_meta, src_metas)
+        want = OW.inverse_warp(batch["src_imgs"].permute(0, 1, 4, 2, 3).cpu().numpy(), batch["src_depths"].cpu().numpy(),
+                               batch["warped_tgt_depth"].cpu().numpy(), batch["Ks"].cpu().numpy(), scene.K.astype(np.float32)[None],
+                               T_t2s.astype(np.float32)[None])
+        assert np.array_equal(batch["warped_tgt_features"].cpu().numpy().view(np.uint32), want.view(np.uint32))
+        res = scene.one_step_prediction(tgt)
+        wd = OW.normalise_depth(batch["warped_tgt_depth"][:, None].cpu(), (batch["warped_tgt_depth"][:, None] <= 0).cpu(), "google_earth")
+        assert np.array_equal(res["x"][:, 3:].cpu().numpy().view(np.uint32), wd.numpy().view(np.uint32))
+        assert torch.isfinite(res["rgbd"]).all()
+        scene.curr += 1
+
+
+def test_clevr_scene_loop_runs_and_reconverts_seed_depth():
+    """CLEVR-Infinite harness path: 20x20 zig-zag grid semantics on a 3x3 grid, num_src 5, 16384 codes, and the
+    reference's quirk of converting the seed frame's ray depth to z-depth again on every load (:582-590)."""
+    from sgam_neurips22_amd.inference_pipeline import ray_to_z_depth, synthetic_seed_frame
+    m = VQModel(**default_params("clevr-infinite")).to(DEV).eval()
+    seed = synthetic_seed_frame("clevr-infinite", 0)
+    scene = InfiniteSceneGeneration(m, "clevr-infinite", output_dim=(3, 3), seed_frame=seed)
+    assert scene.num_src == 5 and scene._ordered_grid_coords[:4] == [(0, 0), (0, 1), (1, 0), (2, 0)]
+    d0 = scene._src_depth((0, 0)).cpu().numpy()
+    assert np.allclose(d0, ray_to_z_depth(seed[1], scene.K).astype(np.float32))
+    scene.scene_expansion()
+    assert len(scene.frames) == 9 and all(torch.isfinite(f["depth"]).all() for f in scene.frames.values())
+    assert scene.frames[(1, 1)]["index"] == 4 and scene.frames[(2, 2)]["rgb_u8"].dtype == torch.uint8
