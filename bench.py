@@ -118,11 +118,15 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=6, help="frames of the CPU oracle baseline (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the fp16 throughput-mode leg")
+    ap.add_argument("--f32-mode", default=None, choices=["split", "mfma"],
+                    help="fp32 products: fp16-split MFMA (default) or fp32-in MFMA")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying HIP graphs")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "fp16"],
                     help="arithmetic of the VQGAN body: f32 = parity path (fp32-in MFMA), bf16/fp16 = 16-bit MFMA path")
     args = ap.parse_args()
 
+    if args.f32_mode:
+        ops.set_f32_mode(args.f32_mode)
     rank, local_rank, world = sdist.init()
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
@@ -156,11 +160,17 @@ def main():
     roofline = None
     if rank == 0 and not args.no_roofline:
         agg = profile_conv_launches(scene)
-        tname = {"f32": "float32", "bf16": "bfloat16", "fp16": "float16"}[args.dtype]
+        split = args.dtype == "f32" and ops.F32_MODE == "split"
+        tname = "f32x" if split else {"f32": "float32", "bf16": "bfloat16", "fp16": "float16"}[args.dtype]
         dom = agg.get((128, 128, tname))
-        peak = FP32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else H16_MFMA_PEAK_TFLOPS
-        kname = ("conv_gemm_f32_v2_kernel<128,128> (fp32-in MFMA 32x32x2 implicit-GEMM conv)" if args.dtype == "f32" else
-                 f"conv_gemm_h16_kernel<128,128> ({args.dtype} MFMA 32x32x16 implicit-GEMM conv)")
+        if split:
+            # 3 fp16 MFMAs per fp32 product: the matrix-pipe roof for ALGORITHMIC fp32 flops is 2500 / 3 TFLOP/s
+            peak = round(H16_MFMA_PEAK_TFLOPS / 3.0, 1)
+            kname = "conv_gemm_f32x_kernel<128,128> (fp32 via exact hi/lo fp16 split, 3x MFMA 32x32x16 f16, fp32 accumulate)"
+        elif args.dtype == "f32":
+            peak, kname = FP32_MFMA_PEAK_TFLOPS, "conv_gemm_f32_v2_kernel<128,128> (fp32-in MFMA 32x32x2 implicit-GEMM conv)"
+        else:
+            peak, kname = H16_MFMA_PEAK_TFLOPS, f"conv_gemm_h16_kernel<128,128> ({args.dtype} MFMA 32x32x16 implicit-GEMM conv)"
         if dom:
             tf = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             roofline = {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
@@ -170,7 +180,7 @@ def main():
                         "gflop_per_frame_in_kernel": round(dom["flops"] / 1e9, 1),
                         "all_conv_kernels": {f"{k[0]}x{k[1]}/{k[2]}": {"launches": v["launches"], "gflop": round(v["flops"] / 1e9, 1),
                                                                "ms": round(v["ms"], 3)} for k, v in agg.items()}}
-    if roofline is not None and args.dtype == "f32":
+    if roofline is not None and args.dtype == "f32" and ops.F32_MODE == "mfma":
         # HBM traffic of the dominant kernel: PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) collected
         # with rocprofv3 --pmc in separate passes on the dominant layer shape and committed under profiles/
         pmc = os.path.join(ROOT, "profiles", "r01b_pmc_conv128_f32.json")
@@ -220,7 +230,9 @@ def main():
                                    "encode/quantise(4096)/decode + frame feedback, in-HBM frame store",
                        "frames_per_gpu": args.steps, "scenes": world, "parallelism": f"scene-parallel x{world}",
                        "weights": "seeded synthetic (68 990 620 params)", "topk": 1,
-                       "launch": "eager" if args.no_graph else "hip-graph replay of the VQGAN forward"},
+                       "launch": "eager" if args.no_graph else "hip-graph replay of the VQGAN forward",
+                       "f32_products": ("exact hi/lo fp16 split on the fp16 matrix cores, fp32 accumulate (fp32-class accuracy)"
+                                        if ops.F32_MODE == "split" else "fp32-in MFMA") if args.dtype == "f32" else None},
             "vqgan_tflops_wallclock": round(GFLOP_PER_FRAME * g["total_frames"] / t_max / 1e3 / world, 2),
             "roofline": roofline, "cpu_baseline": cpu, "throughput_mode": secondary, "frame_checksums": [r[2] for r in g["per_rank"]],
         }

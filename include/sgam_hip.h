@@ -84,6 +84,26 @@ int sgam_pack_conv_weight(const float *w_oihw, float *w_packed, int32_t Cout, in
                           int32_t KW, int32_t Cout_pad, int32_t Cin_pad, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * "Split" fp32 path (conv_f32x.hip): the same fp32 convolution / GEMM as sgam_conv2d_nhwc_f32 (same descriptor, fp32
+ * activations in and out) evaluated on the fp16 matrix cores with fp32-class accuracy: every operand is split
+ * exactly into hi + lo fp16 pieces and a.b = a_hi.b_hi + a_hi.b_lo + a_lo.b_hi is accumulated in fp32 (products of
+ * fp16 values are exact in fp32; the dropped term is <= 2^-22 |a||b|).  Held to the same parity tests as the
+ * fp32-MFMA path.  Weights are pre-split by sgam_pack_conv_weight_f32x into two fp16 planes [2][N][ldb] of
+ * w_scale * w (w_scale a power of two lifting max|w| into (512, 1024]); activations are split while staged, after
+ * multiplication by the power of two a_scale (1 for ordinary activations, 1024 for softmax probabilities).
+ * ldb is in halfs per plane row; Cin % 8 == 0; |a_scale * x| must stay below 65504.
+ * ------------------------------------------------------------------------------------------ */
+int64_t sgam_conv2d_f32x_workspace_bytes(const sgam_conv_desc *d);
+int sgam_conv2d_f32x_plan(const sgam_conv_desc *d, int32_t *bm, int32_t *bn, int32_t *ksplit);
+int sgam_conv2d_nhwc_f32x(const sgam_conv_desc *d, const float *x, float a_scale, const void *w_planes,
+                          float w_scale, const float *bias, const float *residual, float *out, void *workspace,
+                          int64_t workspace_bytes, void *stream);
+int sgam_pack_conv_weight_f32x(const float *w_oihw, void *w_planes, float w_scale, int32_t Cout, int32_t Cin,
+                               int32_t KH, int32_t KW, int32_t Cout_pad, int32_t Cin_pad, void *stream);
+/* split a row-major fp32 matrix [N][K] (row stride ld) into planes [2][N][K]: the B operand when it is an activation */
+int sgam_split_rows_f32x(const float *x, void *planes, float scale, int32_t N, int32_t K, int32_t ld, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * 16-bit THROUGHPUT path (h16.hip): the same operators on bf16 (`ht` = 0) or fp16 (`ht` = 1) activations and
  * weights, fp32 accumulation on v_mfma_f32_32x32x16_{bf16,f16}; statistics / softmax / bias / residual math in
  * fp32.  Strides (lda, ldb, ldc, ldr) are in ELEMENTS of the respective buffer; Cin % 8 == 0.  `out_f32` != 0

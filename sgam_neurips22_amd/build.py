@@ -18,6 +18,7 @@ SOURCES = {
     "norm_softmax.hip": [],
     "groupnorm.hip": [],
     "h16.hip": [],
+    "conv_f32x.hip": [],
     "vq.hip": ["-ffp-contract=off"],
     "layout.hip": ["-ffp-contract=off"],
     "warp.hip": ["-ffp-contract=off"],

@@ -1,0 +1,457 @@
+// conv_f32x.hip — fp32 convolution / GEMM on the fp16 matrix cores with fp32-class accuracy ("split" mode).
+//
+// The fp32-in MFMA of conv_gemm.hip runs at 1/16 of the 16-bit matrix rate and that kernel is pinned at ~75 % of
+// it.  Here every fp32 operand is split exactly into two fp16 pieces,
+//        a = a_hi + a_lo,   a_hi = fp16(a) (RNE),  a_lo = fp16(a - a_hi)        (22 significant bits)
+// and the product is evaluated as three fp16 MFMAs with fp32 accumulation,
+//        a.b  ~=  a_hi.b_hi + a_hi.b_lo + a_lo.b_hi                              (dropped a_lo.b_lo <= 2^-22 |a||b|)
+// Products of fp16 values are exact in fp32, so the only errors are the 2^-22-class representation residue and the
+// usual fp32 accumulation round-off: the result is as accurate as an fp32 GEMM with a different summation order
+// (and is held to the same acceptance tests: bit-exact codebook indices on the margin-guarded fixtures, RGB-D within
+// 1e-4 of the reference) at 3/16 of the fp32-MFMA issue time — the kernel then sits on the LDS / L1 data path
+// instead of the matrix pipe.
+//
+//   * weights are split OFFLINE (sgam_pack_conv_weight_f32x) after multiplying by a power of two `w_scale` that
+//     lifts max|w| to (512, 1024]: both pieces stay in fp16's normal range; the accumulator is multiplied by the
+//     exact inverse in the epilogue;
+//   * activations are split while they are staged into LDS (the A operand arrives as fp32 NHWC exactly as in
+//     conv_gemm.hip: same descriptor, same addressing, same bounds-checked buffer loads).  |x| must stay below
+//     65504 (GroupNorm keeps the VQGAN's activations within a few hundred); pieces below fp16's normal range lose
+//     relative, not absolute, accuracy (<= 3e-8 per element).
+//   * LDS: per K slab of 32, four fp16 planes A_hi, A_lo [BM][40], B_hi, B_lo [BN][40] (80-byte rows: 16-byte aligned
+//     and conflict-free for the 16-lane ds_read_b128 groups), double buffered = 80 KiB for 128x128 (two workgroups
+//     per CU).  One ds_read_b128 = the 8 halfs a lane feeds to one 32x32x16 MFMA.
+#include <stdlib.h>
+
+#include "sgam_common.h"
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct XParams {
+    const float *x, *bias, *res;
+    const unsigned short *w;   // [2][N][ldb] : hi plane then lo plane
+    float *out, *ws;
+    int B, Hi, Wi, Cin, Ho, Wo, N, KH, KW, stride, pad_t, pad_l, ups;
+    int lda, ldb, ldc, ldr, n_valid, bias_per_row;
+    int M, ksplit, iters_total, iters_per_split;
+    unsigned x_bytes, w_plane_bytes;
+    float inv_w_scale;   // 1 / (a_scale * w_scale), an exact power of two
+    float a_scale;       // power of two applied to the A operand before the split (e.g. 1024 for softmax probabilities)
+};
+
+constexpr int XBK = 32;          // fp32 elements of K per slab
+constexpr int XLD = XBK + 8;     // LDS row stride in halfs (80 bytes)
+
+__device__ __forceinline__ unsigned xsel(bool c, unsigned a, unsigned b) {
+    const unsigned m = 0u - (unsigned)c;
+    return (a & m) | (b & ~m);
+}
+
+// exact two-piece split of four fp32 values -> 4 hi halfs (8 bytes) + 4 lo halfs (8 bytes)
+__device__ __forceinline__ void split4(const f32x4 v, u32x2 &hi, u32x2 &lo) {
+    unsigned short h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const _Float16 fh = (_Float16)v[e];
+        const _Float16 fl = (_Float16)(v[e] - (float)fh);
+        h[e] = __builtin_bit_cast(unsigned short, fh);
+        l[e] = __builtin_bit_cast(unsigned short, fl);
+    }
+    hi[0] = (unsigned)h[0] | ((unsigned)h[1] << 16);
+    hi[1] = (unsigned)h[2] | ((unsigned)h[3] << 16);
+    lo[0] = (unsigned)l[0] | ((unsigned)l[1] << 16);
+    lo[1] = (unsigned)l[2] | ((unsigned)l[3] << 16);
+}
+
+__device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv_gemm_f32x_kernel(const XParams p) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int AR = BM / 32;            // float4 rows of A per thread (8 float4 columns x 32 rows per pass)
+    constexpr int BRW = BN / 64;           // 16-byte chunks of each B plane per thread (4 chunks per 64-byte row)
+    constexpr int PLANE_A = BM * XLD, PLANE_B = BN * XLD;
+    constexpr int STAGE = 2 * PLANE_A + 2 * PLANE_B;   // halfs per pipeline stage
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwh = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, (int)p.w_plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwl = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.w + p.w_plane_bytes), 0,
+                                                                         (int)p.w_plane_bytes, 0x00020000);
+
+    const int it0 = blockIdx.z * p.iters_per_split;
+    const int it1 = min(p.iters_total, it0 + p.iters_per_split);
+
+    // A staging: thread -> (float4 column col4 of the 32-wide slab, rows row_in_pass + 32 r)
+    const int col4 = tid & 7;
+    const int row_in_pass = tid >> 3;
+    // B staging: thread -> (16-byte chunk c16 of the 64-byte plane row, rows brow + 64 r)
+    const int c16 = tid & 3;
+    const int brow = tid >> 2;
+    const int Hl = p.ups ? 2 * p.Hi : p.Hi;
+    const int Wl = p.ups ? 2 * p.Wi : p.Wi;
+
+    int a_iy0[AR], a_ix0[AR], a_base[AR];
+#pragma unroll
+    for (int r = 0; r < AR; ++r) {
+        const int m = m0 + row_in_pass + 32 * r;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int hw = p.Ho * p.Wo;
+        const int b = mm / hw;
+        const int rem = mm - b * hw;
+        const int oy = rem / p.Wo;
+        const int ox = rem - oy * p.Wo;
+        a_iy0[r] = ok ? oy * p.stride - p.pad_t : -(1 << 28);
+        a_ix0[r] = ox * p.stride - p.pad_l;
+        a_base[r] = b * p.Hi * p.Wi;
+    }
+    unsigned b_off[BRW];
+#pragma unroll
+    for (int r = 0; r < BRW; ++r) {
+        const int n = n0 + brow + 64 * r;
+        b_off[r] = n < p.N ? (unsigned)(n * p.ldb + c16 * 8) * 2u : 0xC0000000u;
+    }
+
+    const int taps = p.KH * p.KW;
+    int ch = it0 / taps;
+    int tap = it0 - ch * taps;
+    int ky = tap / p.KW;
+    int kx = tap - ky * p.KW;
+
+    f32x4 areg[AR];
+    u32x4 bh[BRW], bl[BRW];
+    auto issue_loads = [&](bool live) {
+        const int coff = ch * XBK + col4 * 4;
+        const bool k_ok = live && coff < p.Cin;
+#pragma unroll
+        for (int r = 0; r < AR; ++r) {
+            const int iy = a_iy0[r] + ky, ix = a_ix0[r] + kx;
+            const bool ok = k_ok && (unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl;
+            const int py = iy >> p.ups, px = ix >> p.ups;
+            const unsigned off = (unsigned)((a_base[r] + py * p.Wi + px) * p.lda + coff) * 4u;
+            areg[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)xsel(ok, off, p.x_bytes), 0, 0));
+        }
+        const bool kb_ok = live && (ch * XBK + c16 * 8) < p.Cin;
+        const unsigned koff = (unsigned)(tap * p.Cin + ch * XBK) * 2u;
+#pragma unroll
+        for (int r = 0; r < BRW; ++r) {
+            const unsigned o = xsel(kb_ok, b_off[r] + koff, p.w_plane_bytes);
+            bh[r] = __builtin_amdgcn_raw_buffer_load_b128(rwh, (int)o, 0, 0);
+            bl[r] = __builtin_amdgcn_raw_buffer_load_b128(rwl, (int)o, 0, 0);
+        }
+        ++tap;
+        if (++kx == p.KW) {
+            kx = 0;
+            ++ky;
+        }
+        if (tap == taps) {
+            tap = 0; ky = 0; kx = 0;
+            ++ch;
+        }
+    };
+    auto store_lds = [&](int buf) {
+        unsigned short *ah = smem + buf * STAGE;
+        unsigned short *al = ah + PLANE_A;
+        unsigned short *bhp = al + PLANE_A;
+        unsigned short *blp = bhp + PLANE_B;
+#pragma unroll
+        for (int r = 0; r < AR; ++r) {
+            u32x2 hi, lo;
+            split4(areg[r] * p.a_scale, hi, lo);
+            const int o = (row_in_pass + 32 * r) * XLD + col4 * 4;
+            *reinterpret_cast<u32x2 *>(ah + o) = hi;
+            *reinterpret_cast<u32x2 *>(al + o) = lo;
+        }
+#pragma unroll
+        for (int r = 0; r < BRW; ++r) {
+            const int o = (brow + 64 * r) * XLD + c16 * 8;
+            *reinterpret_cast<u32x4 *>(bhp + o) = bh[r];
+            *reinterpret_cast<u32x4 *>(blp + o) = bl[r];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int frag_row = lane & 31;
+    const int frag_k = (lane >> 5) * 8;
+
+    issue_loads(it0 < it1);
+    store_lds(0);
+    __syncthreads();
+
+    for (int it = it0; it < it1; ++it) {
+        const int buf = (it - it0) & 1;
+        const unsigned short *ah = smem + buf * STAGE + (wm * (BM / 2) + frag_row) * XLD + frag_k;
+        const unsigned short *al = ah + PLANE_A;
+        const unsigned short *bhp = smem + buf * STAGE + 2 * PLANE_A + (wn * (BN / 2) + frag_row) * XLD + frag_k;
+        const unsigned short *blp = bhp + PLANE_B;
+        issue_loads((it + 1) < it1);
+#pragma unroll
+        for (int kk = 0; kk < XBK / 16; ++kk) {
+            if (kk == XBK / 32) store_lds(buf ^ 1);
+            u32x4 fah[TM], fal[TM], fbh[TN], fbl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                fah[i] = *reinterpret_cast<const u32x4 *>(ah + i * 32 * XLD + kk * 16);
+                fal[i] = *reinterpret_cast<const u32x4 *>(al + i * 32 * XLD + kk * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                fbh[j] = *reinterpret_cast<const u32x4 *>(bhp + j * 32 * XLD + kk * 16);
+                fbl[j] = *reinterpret_cast<const u32x4 *>(blp + j * 32 * XLD + kk * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    // small terms first so that they are not swamped one by one by the running sum
+                    acc[i][j] = mfma16(fal[i], fbh[j], acc[i][j]);
+                    acc[i][j] = mfma16(fah[i], fbl[j], acc[i][j]);
+                    acc[i][j] = mfma16(fah[i], fbh[j], acc[i][j]);
+                }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue (as conv_gemm.hip v2): un-scale, bias, residual, bounds-checked stores ----
+    auto sel = xsel;
+    const int col_l = lane & 31;
+    const int row_h = 4 * (lane >> 5);
+    const bool to_ws = p.ws != nullptr;
+    const int n_lim = to_ws ? p.N : p.n_valid;
+    const int ldo = to_ws ? p.N : p.ldc;
+    float *obase = to_ws ? p.ws + (int64_t)blockIdx.z * p.M * p.N : p.out;
+    const unsigned o_bytes = (unsigned)(((int64_t)(p.M - 1) * ldo + n_lim) * 4);
+    const unsigned r_bytes = (p.res && !to_ws) ? (unsigned)(((int64_t)(p.M - 1) * p.ldr + p.n_valid) * 4) : 0u;
+    const unsigned bias_bytes = (p.bias && !to_ws) ? (unsigned)((p.bias_per_row ? p.M : p.N) * 4) : 0u;
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)obase, 0, (int)o_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void *)p.res, 0, (int)r_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)p.bias, 0, (int)bias_bytes, 0x00020000);
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    const float inv = p.inv_w_scale;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / 2) + j * 32 + col_l;
+            const bool n_ok = n < n_lim;
+            const float bias_n = p.bias_per_row ? 0.f
+                                                : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                      rb, (int)sel(n_ok, (unsigned)n * 4u, OOB), 0, 0));
+            float rv[16], bv[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + row_h;
+                const bool ok = n_ok && m < p.M;
+                rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                      rr, (int)sel(ok, (unsigned)(m * p.ldr + n) * 4u, OOB), 0, 0));
+                bv[e] = p.bias_per_row ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                                       rb, (int)sel(ok, (unsigned)m * 4u, OOB), 0, 0))
+                                       : bias_n;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + row_h;
+                const bool ok = n_ok && m < p.M;
+                const float v = to_ws ? acc[i][j][e] : (acc[i][j][e] * inv + bv[e]) + rv[e];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro,
+                                                      (int)sel(ok, (unsigned)(m * ldo + n) * 4u, OOB), 0, 0);
+            }
+        }
+    }
+}
+
+// fixed-order split-K reduction (partials are still weight-scaled) + un-scale + bias + residual
+__global__ __launch_bounds__(256) void splitk_reduce_f32x_kernel(const XParams p) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nq = p.N / 4;
+    if (q >= (int64_t)p.M * nq) return;
+    const int m = (int)(q / nq);
+    const int n = (int)(q - (int64_t)m * nq) * 4;
+    f32x4 s = *reinterpret_cast<const f32x4 *>(p.ws + (int64_t)m * p.N + n);
+    for (int z = 1; z < p.ksplit; ++z) s += *reinterpret_cast<const f32x4 *>(p.ws + ((int64_t)z * p.M + m) * p.N + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (n + e >= p.n_valid) continue;
+        float v = s[e] * p.inv_w_scale;
+        if (p.bias) v += p.bias_per_row ? p.bias[m] : p.bias[n + e];
+        if (p.res) v += p.res[(int64_t)m * p.ldr + n + e];
+        p.out[(int64_t)m * p.ldc + n + e] = v;
+    }
+}
+
+// [Cout][Cin][KH][KW] fp32 -> two fp16 planes [2][Cout_pad][KH*KW][Cin_pad] of scale * w (hi, lo), zero padded
+__global__ void pack_weight_f32x_kernel(const float *w, unsigned short *o, int Cout, int Cin, int KH, int KW, int Cout_pad,
+                                        int Cin_pad, float scale) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int taps = KH * KW;
+    const int64_t total = (int64_t)Cout_pad * taps * Cin_pad;
+    if (i >= total) return;
+    const int c = (int)(i % Cin_pad);
+    const int t = (int)((i / Cin_pad) % taps);
+    const int n = (int)(i / ((int64_t)Cin_pad * taps));
+    float v = 0.f;
+    if (n < Cout && c < Cin) v = w[((int64_t)n * Cin + c) * taps + t] * scale;
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)(v - (float)h);
+    o[i] = __builtin_bit_cast(unsigned short, h);
+    o[total + i] = __builtin_bit_cast(unsigned short, l);
+}
+
+// generic [N][K] fp32 matrix (row stride ld) -> planes [2][N][K] (the B operand of activation x activation GEMMs)
+__global__ void split_rows_f32x_kernel(const float *x, unsigned short *o, int N, int K, int ld, float scale) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)N * K;
+    if (i >= total) return;
+    const int n = (int)(i / K), k = (int)(i - (int64_t)n * K);
+    const float v = x[(int64_t)n * ld + k] * scale;
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)(v - (float)h);
+    o[i] = __builtin_bit_cast(unsigned short, h);
+    o[total + i] = __builtin_bit_cast(unsigned short, l);
+}
+
+struct XPlan {
+    int bm, bn, ksplit, iters_total, iters_per_split;
+};
+
+XPlan make_xplan(const sgam_conv_desc *d) {
+    const int64_t M = (int64_t)d->B * d->Ho * d->Wo;
+    XPlan pl;
+    pl.iters_total = d->KH * d->KW * ((d->Cin + XBK - 1) / XBK);
+    auto blocks = [&](int bm, int bn) { return (int64_t)sgam_cdiv(M, bm) * sgam_cdiv(d->N, bn); };
+    if (d->N % 128 == 0 && blocks(128, 128) >= 224) { pl.bm = 128; pl.bn = 128; }
+    else if (d->N % 128 == 0 && blocks(64, 128) >= 224) { pl.bm = 64; pl.bn = 128; }
+    else { pl.bm = 64; pl.bn = 64; }
+    if (d->plan_bm > 0 && d->plan_bn > 0) { pl.bm = d->plan_bm; pl.bn = d->plan_bn; }
+    const int64_t nb = blocks(pl.bm, pl.bn);
+    int ks = 1;
+    if (d->plan_ksplit > 0) {
+        ks = d->plan_ksplit;
+        if (ks > pl.iters_total) ks = pl.iters_total;
+    } else if (nb < 192) {
+        ks = (int)((384 + nb - 1) / nb);
+        const int max_by_iters = pl.iters_total / 4;
+        if (ks > max_by_iters) ks = max_by_iters;
+        if (ks > 32) ks = 32;
+        if (ks < 1) ks = 1;
+    }
+    pl.iters_per_split = (pl.iters_total + ks - 1) / ks;
+    pl.ksplit = (pl.iters_total + pl.iters_per_split - 1) / pl.iters_per_split;
+    return pl;
+}
+
+int xvalidate(const sgam_conv_desc *d) {
+    if (!d) return SGAM_EINVAL;
+    if (d->B <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->N <= 0) return SGAM_EINVAL;
+    if (d->Cin <= 0 || d->Cin % 8 != 0 || d->N % 4 != 0) return SGAM_EINVAL;
+    if (d->KH <= 0 || d->KW <= 0 || d->stride <= 0) return SGAM_EINVAL;
+    if (d->lda < d->Cin || d->lda % 4 != 0) return SGAM_EALIGN;
+    if (d->ldb < d->KH * d->KW * d->Cin || d->ldb % 8 != 0) return SGAM_EALIGN;
+    if (d->n_valid <= 0 || d->n_valid > d->N || d->ldc < d->n_valid) return SGAM_EINVAL;
+    if (d->plan_bm != 0 || d->plan_bn != 0) {
+        const bool ok = (d->plan_bm == 128 && d->plan_bn == 128) || (d->plan_bm == 64 && d->plan_bn == 128) ||
+                        (d->plan_bm == 64 && d->plan_bn == 64);
+        if (!ok || (d->plan_bn == 128 && d->N % 128 != 0)) return SGAM_EINVAL;
+    }
+    if (d->plan_ksplit < 0 || d->plan_ksplit > 64) return SGAM_EINVAL;
+    return SGAM_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t sgam_conv2d_f32x_workspace_bytes(const sgam_conv_desc *d) {
+    if (xvalidate(d) != SGAM_OK) return -1;
+    const XPlan pl = make_xplan(d);
+    if (pl.ksplit <= 1) return 0;
+    return (int64_t)pl.ksplit * d->B * d->Ho * d->Wo * d->N * (int64_t)sizeof(float);
+}
+
+extern "C" int sgam_conv2d_f32x_plan(const sgam_conv_desc *d, int32_t *bm, int32_t *bn, int32_t *ksplit) {
+    const int rc = xvalidate(d);
+    if (rc != SGAM_OK) return rc;
+    const XPlan pl = make_xplan(d);
+    if (bm) *bm = pl.bm;
+    if (bn) *bn = pl.bn;
+    if (ksplit) *ksplit = pl.ksplit;
+    return SGAM_OK;
+}
+
+extern "C" int sgam_conv2d_nhwc_f32x(const sgam_conv_desc *d, const float *x, float a_scale, const void *w_planes,
+                                     float w_scale, const float *bias, const float *residual, float *out,
+                                     void *workspace, int64_t workspace_bytes, void *stream) {
+    const int rc = xvalidate(d);
+    if (rc != SGAM_OK) return rc;
+    if (!x || !w_planes || !out || !(w_scale > 0.f) || !(a_scale > 0.f)) return SGAM_EINVAL;
+    if (!sgam_aligned16(x) || !sgam_aligned16(w_planes)) return SGAM_EALIGN;
+    const XPlan pl = make_xplan(d);
+    XParams p;
+    p.x = x; p.w = (const unsigned short *)w_planes; p.bias = bias; p.res = residual; p.out = out; p.ws = nullptr;
+    p.B = d->B; p.Hi = d->Hi; p.Wi = d->Wi; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.N = d->N;
+    p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.ups = d->upsample2x ? 1 : 0;
+    p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldr = d->ldr; p.n_valid = d->n_valid; p.bias_per_row = d->bias_per_row;
+    p.M = d->B * d->Ho * d->Wo;
+    p.ksplit = pl.ksplit; p.iters_total = pl.iters_total; p.iters_per_split = pl.iters_per_split;
+    p.inv_w_scale = 1.0f / (w_scale * a_scale);
+    p.a_scale = a_scale;
+    const int64_t xb = (((int64_t)d->B * d->Hi * d->Wi - 1) * d->lda + d->Cin) * 4;
+    const int64_t wb = (int64_t)d->N * d->ldb * 2;   // one plane: [N][ldb] halfs, planes are contiguous
+    if (xb >= (1ll << 32) - 64 || wb >= (1ll << 31)) return SGAM_EINVAL;
+    p.x_bytes = (unsigned)xb; p.w_plane_bytes = (unsigned)wb;
+    if (pl.ksplit > 1) {
+        const int64_t need = (int64_t)pl.ksplit * p.M * p.N * (int64_t)sizeof(float);
+        if (!workspace || workspace_bytes < need || !sgam_aligned16(workspace)) return SGAM_EWORKSPACE;
+        p.ws = (float *)workspace;
+    }
+    const dim3 grid(sgam_cdiv(p.M, pl.bm), sgam_cdiv(p.N, pl.bn), pl.ksplit);
+    hipStream_t s = sgam_stream(stream);
+    if (pl.bm == 128 && pl.bn == 128) hipLaunchKernelGGL((conv_gemm_f32x_kernel<128, 128>), grid, dim3(256), 0, s, p);
+    else if (pl.bm == 64 && pl.bn == 128) hipLaunchKernelGGL((conv_gemm_f32x_kernel<64, 128>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((conv_gemm_f32x_kernel<64, 64>), grid, dim3(256), 0, s, p);
+    SGAM_LAUNCH_CHECK();
+    if (pl.ksplit > 1) {
+        const int64_t q = (int64_t)p.M * (p.N / 4);
+        hipLaunchKernelGGL(splitk_reduce_f32x_kernel, dim3(sgam_cdiv(q, 256)), dim3(256), 0, s, p);
+        SGAM_LAUNCH_CHECK();
+    }
+    return SGAM_OK;
+}
+
+extern "C" int sgam_pack_conv_weight_f32x(const float *w_oihw, void *w_planes, float w_scale, int32_t Cout, int32_t Cin,
+                                          int32_t KH, int32_t KW, int32_t Cout_pad, int32_t Cin_pad, void *stream) {
+    if (!w_oihw || !w_planes || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 || Cout_pad < Cout || Cin_pad < Cin) return SGAM_EINVAL;
+    const int64_t total = (int64_t)Cout_pad * KH * KW * Cin_pad;
+    hipLaunchKernelGGL(pack_weight_f32x_kernel, dim3(sgam_cdiv(total, 256)), dim3(256), 0, sgam_stream(stream), w_oihw,
+                       (unsigned short *)w_planes, Cout, Cin, KH, KW, Cout_pad, Cin_pad, w_scale);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+extern "C" int sgam_split_rows_f32x(const float *x, void *planes, float scale, int32_t N, int32_t K, int32_t ld, void *stream) {
+    if (!x || !planes || N <= 0 || K <= 0 || ld < K) return SGAM_EINVAL;
+    const int64_t total = (int64_t)N * K;
+    hipLaunchKernelGGL(split_rows_f32x_kernel, dim3(sgam_cdiv(total, 256)), dim3(256), 0, sgam_stream(stream), x,
+                       (unsigned short *)planes, N, K, ld, scale);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}

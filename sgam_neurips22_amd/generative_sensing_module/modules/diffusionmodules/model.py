@@ -28,6 +28,8 @@ class Conv2d(nn.Conv2d):
             self._packs = {}
             self._pack_bias = None if self.bias is None else self.bias.detach().float().contiguous()
             self._pack_key = key
+        if dtype == torch.float32 and ops.F32_MODE == "split":
+            dtype = "f32x"      # fp32 activations, weights pre-split into fp16 hi/lo planes (conv_f32x.hip)
         if dtype not in self._packs:
             self._packs[dtype] = ops.pack_conv_weight(w, dtype=dtype)
         return self._packs[dtype], self._pack_bias
@@ -176,9 +178,11 @@ class AttnBlock(_NHWCModule):
         B, H, W, C = x.shape
         n = H * W
         wqkvs, bqkv = self._packed_qkv()
-        if x.dtype not in wqkvs:
-            wqkvs[x.dtype] = ops.cast(wqkvs[torch.float32], x.dtype)
-        wqkv = wqkvs[x.dtype]
+        wkey = "f32x" if (x.dtype == torch.float32 and ops.F32_MODE == "split" and not FUSE_GROUPNORM_INTO_CONV) else x.dtype
+        if wkey not in wqkvs:
+            w32 = wqkvs[torch.float32]
+            wqkvs[wkey] = ops.split_rows(w32, ops._pow2_scale(float(w32.abs().max()))) if wkey == "f32x" else ops.cast(w32, x.dtype)
+        wqkv = wqkvs[wkey]
         wp, bp = self.proj_out._packed(x.dtype)
         if x.dtype in ops.H16:
             return self._forward_nhwc_h16(x, wqkv, bqkv, wp, bp)
@@ -195,7 +199,7 @@ class AttnBlock(_NHWCModule):
             vt = ops.nhwc_to_nchw(qkv[:, 2 * C:].unsqueeze(0).unsqueeze(0), c=C).view(C, n)   # (C, n) = v^T
             s = ops.gemm_nt(qkv[:, :C], qkv[:, C:2 * C])                   # (n, n) scores
             ops.softmax_rows_(s, scale)
-            o = ops.gemm_nt(s, vt)                                         # (n, C)
+            o = ops.gemm_nt(s, vt, a_scale=1024.0)                         # (n, C); probabilities lifted before the split
             ops.gemm_nt(o, wp, bias=bp, residual=xb, out=out[b].reshape(n, C))
         return out
 

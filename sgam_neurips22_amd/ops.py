@@ -43,6 +43,58 @@ def round_up(v, m):
     return (v + m - 1) // m * m
 
 
+# How fp32 convolutions / GEMMs are evaluated:
+#   "split" : fp16 matrix cores on exact hi+lo splits of both operands, fp32 accumulate (conv_f32x.hip) — fp32-class
+#             accuracy at 3/16 of the fp32-MFMA issue time; the default parity path
+#   "mfma"  : fp32-in MFMA (conv_gemm.hip) — bit-for-bit an fp32 fmaf chain; the reference implementation of the
+#             parity path and the one the fused GroupNorm prologue / autotuned plans were built on
+F32_MODE = os.environ.get("SGAM_F32_MODE", "split")
+
+
+def set_f32_mode(mode):
+    global F32_MODE
+    if mode not in ("split", "mfma"):
+        raise ValueError(mode)
+    F32_MODE = mode
+
+
+class SplitWeight:
+    """fp32 matrix pre-split into two fp16 planes [2][N][K] of scale * w (conv_f32x.hip)."""
+    __slots__ = ("planes", "scale", "shape")
+
+    def __init__(self, planes, scale):
+        self.planes, self.scale, self.shape = planes, scale, (planes.shape[1], planes.shape[2])
+
+    def stride(self, dim):
+        return self.planes.stride(dim + 1)
+
+    @property
+    def dtype(self):
+        return "f32x"
+
+    @property
+    def is_cuda(self):
+        return self.planes.is_cuda
+
+
+def _pow2_scale(maxabs):
+    """power of two lifting max|w| into (512, 1024]"""
+    import math
+    if not (maxabs > 0) or not math.isfinite(maxabs):
+        return 1.0
+    return float(2.0 ** (10 - math.ceil(math.log2(maxabs))))
+
+
+def split_rows(x2d, scale=1.0):
+    """(N, K) fp32 view with unit inner stride -> SplitWeight planes (the B operand when it is an activation)."""
+    _need_cuda(x2d)
+    N, K = x2d.shape
+    planes = torch.empty((2, N, K), device=x2d.device, dtype=torch.float16)
+    check(_lib.load().sgam_split_rows_f32x(_p(x2d), _p(planes), float(scale), N, K, x2d.stride(0), _stream()),
+          "sgam_split_rows_f32x")
+    return SplitWeight(planes, float(scale))
+
+
 # 16-bit throughput path: `ht` code of the C ABI per torch dtype
 H16 = {torch.bfloat16: 0, torch.float16: 1}
 DTYPES = {"f32": torch.float32, "fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16,
@@ -80,6 +132,12 @@ def pack_conv_weight(w_oihw, cout_pad=None, cin_pad=None, dtype=torch.float32):
     cout, cin, kh, kw = w.shape
     cout_pad = cout_pad or round_up(cout, 64)
     cin_pad = cin_pad or round_up(cin, 32)
+    if dtype == "f32x":
+        planes = torch.empty((2, cout_pad, kh * kw * cin_pad), device=w.device, dtype=torch.float16)
+        scale = _pow2_scale(float(w.abs().max()))          # once per weight version (host sync at pack time only)
+        check(_lib.load().sgam_pack_conv_weight_f32x(_p(w), _p(planes), scale, cout, cin, kh, kw, cout_pad, cin_pad,
+                                                     _stream()), "sgam_pack_conv_weight_f32x")
+        return SplitWeight(planes, scale)
     out = torch.empty((cout_pad, kh * kw * cin_pad), device=w.device, dtype=dtype)
     if dtype == torch.float32:
         check(_lib.load().sgam_pack_conv_weight(_p(w), _p(out), cout, cin, kh, kw, cout_pad, cin_pad, _stream()),
@@ -124,29 +182,41 @@ def _apply_plan(desc, dtype):
             desc.plan_bm, desc.plan_bn, desc.plan_ksplit = pl
 
 
-def conv_plan(desc, h16=False):
+def conv_plan(desc, h16=False, split=False):
     bm, bn, ks = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
-    fn = _lib.load().sgam_conv2d_h16_plan if h16 else _lib.load().sgam_conv2d_plan
+    lib = _lib.load()
+    fn = lib.sgam_conv2d_f32x_plan if split else (lib.sgam_conv2d_h16_plan if h16 else lib.sgam_conv2d_plan)
     check(fn(ctypes.byref(desc), ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(ks)), "sgam_conv2d_plan")
     return bm.value, bn.value, ks.value
 
 
-def _run_conv(desc, x, w, bias, residual, out, gn=None):
+def _run_conv(desc, x, w, bias, residual, out, gn=None, a_scale=1.0):
     lib = _lib.load()
-    _apply_plan(desc, x.dtype)
+    split = isinstance(w, SplitWeight)
+    _apply_plan(desc, "f32x" if split else x.dtype)
     if CONV_TRACE is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-        _run_conv_inner(lib, desc, x, w, bias, residual, out, gn)
+        _run_conv_inner(lib, desc, x, w, bias, residual, out, gn, a_scale)
         ev1.record()
         flops = 2.0 * desc.B * desc.Ho * desc.Wo * desc.n_valid * desc.KH * desc.KW * desc.Cin
-        CONV_TRACE.append((conv_plan(desc, x.dtype in H16) + (str(x.dtype).replace("torch.", ""),),
+        CONV_TRACE.append((conv_plan(desc, x.dtype in H16, split) + ("f32x" if split else str(x.dtype).replace("torch.", ""),),
                            (desc.B * desc.Ho * desc.Wo, desc.n_valid, desc.KH * desc.KW * desc.Cin), flops, ev0, ev1))
         return out
-    return _run_conv_inner(lib, desc, x, w, bias, residual, out, gn)
+    return _run_conv_inner(lib, desc, x, w, bias, residual, out, gn, a_scale)
 
 
-def _run_conv_inner(lib, desc, x, w, bias, residual, out, gn=None):
+def _run_conv_inner(lib, desc, x, w, bias, residual, out, gn=None, a_scale=1.0):
+    if isinstance(w, SplitWeight):
+        if gn is not None or x.dtype != torch.float32:
+            raise SgamHipError("split fp32 conv: fp32 activations only, no fused GroupNorm prologue")
+        ws_bytes = lib.sgam_conv2d_f32x_workspace_bytes(ctypes.byref(desc))
+        if ws_bytes < 0:
+            raise SgamHipError(f"sgam_conv2d_f32x: unsupported shape {[(f, getattr(desc, f)) for f, _ in desc._fields_]}")
+        ws = torch.empty((ws_bytes,), device=x.device, dtype=torch.uint8) if ws_bytes else None
+        check(lib.sgam_conv2d_nhwc_f32x(ctypes.byref(desc), _p(x), float(a_scale), _p(w.planes), float(w.scale), _p(bias),
+                                        _p(residual), _p(out), _p(ws), ws_bytes, _stream()), "sgam_conv2d_nhwc_f32x")
+        return out
     if x.dtype in H16:
         if gn is not None or w.dtype != x.dtype or (residual is not None and residual.dtype != x.dtype):
             raise SgamHipError("16-bit conv: operands must share one 16-bit dtype; no fused GroupNorm prologue")
@@ -188,11 +258,13 @@ def conv2d_nhwc(x, w_packed, bias, *, cout, kh, kw, stride=1, pad_t=0, pad_l=0, 
     return _run_conv(d, x, w_packed, bias, residual, out, gn)
 
 
-def gemm_nt(a, b, bias=None, residual=None, bias_per_row=False, out=None, gn=None, out_dtype=None):
+def gemm_nt(a, b, bias=None, residual=None, bias_per_row=False, out=None, gn=None, out_dtype=None, a_scale=1.0):
     """out[M][N] = a[M][K] @ b[N][K]^T (+bias) (+residual).  a, b: 2-D fp32 CUDA tensors with unit
     inner stride (row strides free, so column slices of a fused projection can be passed directly).
     K % 32 == 0, N % 4 == 0."""
-    _need_cuda(a, b)
+    _need_cuda(a)
+    if a.dtype == torch.float32 and F32_MODE == "split" and gn is None and not isinstance(b, SplitWeight):
+        b = split_rows(b)       # activation x activation product (q k^T, P v): split the B side on the fly
     M, K = a.shape
     N, K2 = b.shape
     assert K == K2 and a.stride(1) == 1 and b.stride(1) == 1
@@ -202,7 +274,7 @@ def gemm_nt(a, b, bias=None, residual=None, bias_per_row=False, out=None, gn=Non
                  lda=a.stride(0), ldb=b.stride(0), ldc=out.stride(0),
                  ldr=(residual.stride(0) if residual is not None else 0), n_valid=N,
                  bias_per_row=int(bias_per_row))
-    return _run_conv(d, a, b, bias, residual, out, gn)
+    return _run_conv(d, a, b, bias, residual, out, gn, a_scale)
 
 
 # ------------------------------------------------------------------------------------------------

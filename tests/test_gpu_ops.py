@@ -11,6 +11,19 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+@pytest.fixture(params=["split", "mfma"])
+def f32_mode(request):
+    """run a test under both evaluations of fp32 products: fp16-split MFMA (default) and fp32-in MFMA"""
+    old = ops.F32_MODE
+    ops.set_f32_mode(request.param)
+    yield request.param
+    ops.set_f32_mode(old)
+
+
+def _pack(w, mode):
+    return ops.pack_conv_weight(w.to(DEV), dtype="f32x" if mode == "split" else torch.float32)
+
+
 def _close(a, b, atol, what=""):
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
     err = (a - b).abs().max().item()
@@ -49,7 +62,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: c[0])
-def test_conv2d_matches_oracle(case):
+def test_conv2d_matches_oracle(case, f32_mode):
     tag, B, Cin, Cout, H, W, k, stride, pad, ups = case
     x = testing.seeded_tensor(tag + ".x", (B, Cin, H, W))
     w = testing.seeded_tensor(tag + ".w", (Cout, Cin, k, k), scale=(1.0 / (Cin * k * k)) ** 0.5)
@@ -58,7 +71,7 @@ def test_conv2d_matches_oracle(case):
     xr = F.pad(xr, (pad[1], pad[3], pad[0], pad[2]))
     ref = F.conv2d(xr, w, b, stride=stride)
     res_in = testing.seeded_tensor(tag + ".r", tuple(ref.shape))
-    wp = ops.pack_conv_weight(w.to(DEV))
+    wp = _pack(w, f32_mode)
     out = ops.conv2d_nhwc(_nhwc(x).to(DEV), wp, b.to(DEV), cout=Cout, kh=k, kw=k, stride=stride, pad_t=pad[0],
                           pad_l=pad[1], pad_b=pad[2], pad_r=pad[3], upsample2x=ups)
     assert tuple(out.shape) == (B, ref.shape[2], ref.shape[3], Cout)
@@ -86,7 +99,7 @@ def test_conv_with_fused_groupnorm_prologue(B, C, Cout, H, W, k, swish, ups):
         h = F.interpolate(h, scale_factor=2.0, mode="nearest")
     ref = F.conv2d(h, w, b, padding=k // 2)
     xd = _nhwc(x).to(DEV)
-    wp = ops.pack_conv_weight(w.to(DEV))
+    wp = ops.pack_conv_weight(w.to(DEV))           # the fused prologue lives in the fp32-MFMA kernel
     table = ops.groupnorm_stats(xd, g.to(DEV), bt.to(DEV))
     assert table.shape == (B, C, 2)
     fused = ops.conv2d_nhwc(xd, wp, b.to(DEV), cout=Cout, kh=k, kw=k, pad_t=k // 2, pad_l=k // 2, upsample2x=ups,
@@ -98,9 +111,9 @@ def test_conv_with_fused_groupnorm_prologue(B, C, Cout, H, W, k, swish, ups):
     assert (fused - unfused).abs().max().item() <= 2e-6 * max(1.0, unfused.abs().max().item())
 
 
-def test_conv_is_run_to_run_deterministic():
+def test_conv_is_run_to_run_deterministic(f32_mode):
     x = _nhwc(testing.seeded_tensor("det.x", (1, 512, 8, 8))).to(DEV)
-    wp = ops.pack_conv_weight(testing.seeded_tensor("det.w", (512, 512, 3, 3), scale=0.02).to(DEV))
+    wp = _pack(testing.seeded_tensor("det.w", (512, 512, 3, 3), scale=0.02), f32_mode)
     a = ops.conv2d_nhwc(x, wp, None, cout=512, kh=3, kw=3, pad_t=1, pad_l=1)
     for _ in range(3):
         assert torch.equal(a, ops.conv2d_nhwc(x, wp, None, cout=512, kh=3, kw=3, pad_t=1, pad_l=1))
@@ -109,7 +122,7 @@ def test_conv_is_run_to_run_deterministic():
 @pytest.mark.parametrize("M,N,K,strided", [(256, 256, 256, False), (4096, 4096, 256, True), (300, 68, 64, False),
                                            (256, 4096, 256, False), (64, 256, 4096, False), (16, 512, 16, False),
                                            (64, 64, 48, False)])
-def test_gemm_nt_transpose_detecting(M, N, K, strided):
+def test_gemm_nt_transpose_detecting(M, N, K, strided, f32_mode):
     """asymmetric operands (so a swapped C-write cannot pass), optional row-strided A/B views."""
     a = testing.seeded_tensor("gemm.a", (M, 2 * K if strided else K))
     b = testing.seeded_tensor("gemm.b", (N, 2 * K if strided else K)) * torch.linspace(0.5, 1.5, N)[:, None]
@@ -205,6 +218,28 @@ def test_vq_topk_order():
     for r in range(32):
         got, want = inds[r].cpu().tolist(), sorted(range(4096), key=lambda j: (float(d[r, j]), j))[:8]
         assert got == want
+
+
+def test_split_mode_is_fp32_class_accurate():
+    """fp16-split evaluation vs an fp64 reference, next to the fp32-MFMA evaluation: same error class, including
+    small-magnitude activations, a wide dynamic range and softmax-like probabilities (a_scale = 1024)."""
+    K, M, N = 4096, 256, 256
+    a = testing.seeded_tensor("acc.a", (M, K)) * torch.logspace(-3, 1, K)[None, :]      # 1e-3 .. 10 columns
+    b = testing.seeded_tensor("acc.b", (N, K), 0.03)
+    ref = a.double() @ b.double().t()
+    scale = (a.double().abs() @ b.double().abs().t()).clamp_min(1e-30)                 # sum |a||b| per output
+    errs = {}
+    for mode in ("mfma", "split"):
+        ops.set_f32_mode(mode)
+        out = ops.gemm_nt(a.to(DEV), b.to(DEV)).cpu().double()
+        errs[mode] = ((out - ref).abs() / scale).max().item()
+    prob = torch.softmax(testing.seeded_tensor("acc.p", (M, K), 3.0), dim=1)
+    v = testing.seeded_tensor("acc.v", (N, K))
+    refp = prob.double() @ v.double().t()
+    outp = ops.gemm_nt(prob.to(DEV), v.to(DEV), a_scale=1024.0).cpu().double()
+    errs["split_prob"] = ((outp - refp).abs().max() / refp.abs().max()).item()
+    print("relative-to-sum|a||b| errors:", errs)
+    assert errs["mfma"] <= 2e-7 and errs["split"] <= 4e-7 and errs["split_prob"] <= 1e-6
 
 
 def test_cpu_tensor_is_rejected_loudly():

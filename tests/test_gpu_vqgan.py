@@ -63,8 +63,18 @@ def _model(dataset, g):
     return m.to(DEV).eval(), sd, p
 
 
+@pytest.mark.parametrize("mode", ["split", "mfma"])
 @pytest.mark.parametrize("name", ["ge64", "ge256"])
-def test_full_model_parity(golden, name):
+def test_full_model_parity(golden, name, mode):
+    """both evaluations of the fp32 products (fp16-split MFMA = default, fp32-in MFMA) meet the same bar"""
+    ops.set_f32_mode(mode)
+    try:
+        _full_model_parity(golden, name)
+    finally:
+        ops.set_f32_mode("split")
+
+
+def _full_model_parity(golden, name):
     g = golden(f"vqgan_full_{name}.npz")
     m, sd, p = _model("google_earth", g)
     res = int(g["res"])
