@@ -32,16 +32,22 @@ def _parse(key):
     return dt, int(b[1:]), Hi, Wi, Cin, Ho, Wo, int(n[1:]), KH, KW, stride, ups
 
 
-def _time(desc, x, w, out, reps=6):
+def _time(desc, x, w, out, reps=20):
     lib = _lib.load()
     h16 = x.dtype in ops.H16
+    split = isinstance(w, ops.SplitWeight)
+    nb0 = (lib.sgam_conv2d_f32x_workspace_bytes if split else
+           (lib.sgam_conv2d_h16_workspace_bytes if h16 else lib.sgam_conv2d_workspace_bytes))(ctypes.byref(desc))
+    ws0 = torch.empty((max(nb0, 16),), device=x.device, dtype=torch.uint8) if nb0 >= 0 else None
 
     def run():
-        nb = (lib.sgam_conv2d_h16_workspace_bytes if h16 else lib.sgam_conv2d_workspace_bytes)(ctypes.byref(desc))
+        nb, ws = nb0, ws0
         if nb < 0:
             return False
-        ws = torch.empty((max(nb, 16),), device=x.device, dtype=torch.uint8)
-        if h16:
+        if split:
+            rc = lib.sgam_conv2d_nhwc_f32x(ctypes.byref(desc), ops._p(x), 1.0, ops._p(w.planes), float(w.scale), None, None,
+                                           ops._p(out), ops._p(ws), nb, ops._stream())
+        elif h16:
             rc = lib.sgam_conv2d_nhwc_h16(ctypes.byref(desc), ops.H16[x.dtype], ops._p(x), ops._p(w), None, None, ops._p(out),
                                           0, ops._p(ws), nb, ops._stream())
         else:
@@ -53,10 +59,21 @@ def _time(desc, x, w, out, reps=6):
         return None
     run()
     torch.cuda.synchronize()
+    # time GPU execution, not host launch rate: replay the reps from a captured HIP graph
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        run()
+    torch.cuda.current_stream().wait_stream(side)
+    with torch.cuda.graph(graph):
+        for _ in range(reps):
+            run()
+    graph.replay()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        run()
+    graph.replay()
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
@@ -64,11 +81,14 @@ def _time(desc, x, w, out, reps=6):
 
 def tune_shape(key, verbose=True):
     dt, B, Hi, Wi, Cin, Ho, Wo, N, KH, KW, stride, ups = _parse(key)
-    dtype = ops.DTYPES["f32" if dt == "float32" else ("bf16" if dt == "bfloat16" else "fp16")]
+    split = dt == "f32x"
+    dtype = ops.DTYPES["f32" if dt in ("float32", "f32x") else ("bf16" if dt == "bfloat16" else "fp16")]
     dev = "cuda"
     x = testing.seeded_tensor("tune.x", (B * Hi * Wi, Cin)).to(dev).to(dtype)
     K = KH * KW * Cin
     w = (testing.seeded_tensor("tune.w", (N, K)) * 0.03).to(dev).to(dtype)
+    if split:
+        w = ops.split_rows(w, 1024.0)
     out = torch.empty((B * Ho * Wo, N), device=dev, dtype=dtype)
     pad = (KH // 2) if stride == 1 else 0
     base = dict(B=B, Hi=Hi, Wi=Wi, Cin=Cin, Ho=Ho, Wo=Wo, N=N, KH=KH, KW=KW, stride=stride, pad_t=pad, pad_l=pad,
@@ -125,7 +145,8 @@ def collect_shapes(dtypes, dataset="google_earth", res=256):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--dtypes", default="f32,fp16,bf16")
+    ap.add_argument("--dtypes", default="f32,fp16,bf16", help="f32 tunes the current ops.F32_MODE (split by default)")
+    ap.add_argument("--merge", action="store_true", help="keep the plans already in the output file for other dtypes")
     ap.add_argument("--out", default=ops._PLAN_FILE)
     a = ap.parse_args()
     os.environ["SGAM_NO_TUNED_PLANS"] = "1"
@@ -139,6 +160,10 @@ def main():
             plans[k] = list(pl)
             saved += (t_auto - best[0])
     print(f"tuned {len(plans)} of {len(keys)} shapes; sum of per-shape savings {saved * 1e3:.0f} us (one launch each)")
+    if a.merge and os.path.exists(ops._PLAN_FILE):
+        old = json.load(open(ops._PLAN_FILE)).get("plans", {})
+        old.update(plans)
+        plans = old
     with open(a.out, "w") as f:
         json.dump({"device": torch.cuda.get_device_name(0), "plans": plans}, f, indent=0, sort_keys=True)
     print("wrote", a.out)
