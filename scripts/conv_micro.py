@@ -21,7 +21,8 @@ B, Cin, Cout, H, W, k = map(int, a.shape.split(","))
 dev = "cuda"
 dt = ops.DTYPES[a.dtype]
 x = testing.seeded_tensor("micro.x", (B, H, W, Cin)).to(dev).to(dt)
-w = ops.pack_conv_weight(testing.seeded_tensor("micro.w", (Cout, Cin, k, k), 0.03).to(dev), dtype=dt)
+w = ops.pack_conv_weight(testing.seeded_tensor("micro.w", (Cout, Cin, k, k), 0.03).to(dev),
+                         dtype="f32x" if (dt == torch.float32 and ops.F32_MODE == "split" and not a.gn) else dt)
 b = testing.seeded_tensor("micro.b", (Cout,)).to(dev)
 gn = None
 if a.gn:

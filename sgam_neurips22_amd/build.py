@@ -18,7 +18,7 @@ SOURCES = {
     "norm_softmax.hip": [],
     "groupnorm.hip": [],
     "h16.hip": [],
-    "conv_f32x.hip": [],
+    "conv_f32x.hip": [f"-DSGAM_XSCHED={os.environ.get('SGAM_XSCHED', '0')}"],
     "vq.hip": ["-ffp-contract=off"],
     "layout.hip": ["-ffp-contract=off"],
     "warp.hip": ["-ffp-contract=off"],

@@ -25,6 +25,10 @@
 
 #include "sgam_common.h"
 
+#ifndef SGAM_XSCHED
+#define SGAM_XSCHED 0
+#endif
+
 namespace {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -71,7 +75,7 @@ __device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool UPS, bool ASCALE>
 __global__ __launch_bounds__(256) void conv_gemm_f32x_kernel(const XParams p) {
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int AR = BM / 32;            // float4 rows of A per thread (8 float4 columns x 32 rows per pass)
@@ -104,7 +108,11 @@ __global__ __launch_bounds__(256) void conv_gemm_f32x_kernel(const XParams p) {
     const int Hl = p.ups ? 2 * p.Hi : p.Hi;
     const int Wl = p.ups ? 2 * p.Wi : p.Wi;
 
+    // per staged row: byte offset of the tap-(0,0) input pixel and a bit mask of the taps that fall inside the image
+    // (non-upsampled convs: the per-step address is rowoff + a wave-uniform tap offset, validity is one bit test);
+    // the nearest-2x upsampling conv keeps the generic coordinate arithmetic.
     int a_iy0[AR], a_ix0[AR], a_base[AR];
+    unsigned a_rowoff[AR], a_tapmask[AR];
 #pragma unroll
     for (int r = 0; r < AR; ++r) {
         const int m = m0 + row_in_pass + 32 * r;
@@ -118,6 +126,13 @@ __global__ __launch_bounds__(256) void conv_gemm_f32x_kernel(const XParams p) {
         a_iy0[r] = ok ? oy * p.stride - p.pad_t : -(1 << 28);
         a_ix0[r] = ox * p.stride - p.pad_l;
         a_base[r] = b * p.Hi * p.Wi;
+        a_rowoff[r] = (unsigned)((a_base[r] + a_iy0[r] * p.Wi + a_ix0[r]) * p.lda + col4 * 4) * 4u;   // may wrap: only used when valid
+        unsigned mk = 0;
+        for (int t = 0; t < p.KH * p.KW; ++t) {
+            const int iy = a_iy0[r] + t / p.KW, ix = a_ix0[r] + t % p.KW;
+            mk |= (((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) ? 1u : 0u) << t;
+        }
+        a_tapmask[r] = mk;
     }
     unsigned b_off[BRW];
 #pragma unroll
@@ -137,13 +152,23 @@ __global__ __launch_bounds__(256) void conv_gemm_f32x_kernel(const XParams p) {
     auto issue_loads = [&](bool live) {
         const int coff = ch * XBK + col4 * 4;
         const bool k_ok = live && coff < p.Cin;
+        if constexpr (UPS) {
 #pragma unroll
-        for (int r = 0; r < AR; ++r) {
-            const int iy = a_iy0[r] + ky, ix = a_ix0[r] + kx;
-            const bool ok = k_ok && (unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl;
-            const int py = iy >> p.ups, px = ix >> p.ups;
-            const unsigned off = (unsigned)((a_base[r] + py * p.Wi + px) * p.lda + coff) * 4u;
-            areg[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)xsel(ok, off, p.x_bytes), 0, 0));
+            for (int r = 0; r < AR; ++r) {
+                const int iy = a_iy0[r] + ky, ix = a_ix0[r] + kx;
+                const bool ok = k_ok && (unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl;
+                const int py = iy >> 1, px = ix >> 1;
+                const unsigned off = (unsigned)((a_base[r] + py * p.Wi + px) * p.lda + coff) * 4u;
+                areg[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)xsel(ok, off, p.x_bytes), 0, 0));
+            }
+        } else {
+            const unsigned tap_off = (unsigned)((ky * p.Wi + kx) * p.lda + ch * XBK) * 4u;   // wave-uniform
+#pragma unroll
+            for (int r = 0; r < AR; ++r) {
+                const bool ok = k_ok && ((a_tapmask[r] >> tap) & 1u);
+                areg[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                        rx, (int)xsel(ok, a_rowoff[r] + tap_off, p.x_bytes), 0, 0));
+            }
         }
         const bool kb_ok = live && (ch * XBK + c16 * 8) < p.Cin;
         const unsigned koff = (unsigned)(tap * p.Cin + ch * XBK) * 2u;
@@ -171,7 +196,7 @@ __global__ __launch_bounds__(256) void conv_gemm_f32x_kernel(const XParams p) {
 #pragma unroll
         for (int r = 0; r < AR; ++r) {
             u32x2 hi, lo;
-            split4(areg[r] * p.a_scale, hi, lo);
+            split4(ASCALE ? areg[r] * p.a_scale : areg[r], hi, lo);
             const int o = (row_in_pass + 32 * r) * XLD + col4 * 4;
             *reinterpret_cast<u32x2 *>(ah + o) = hi;
             *reinterpret_cast<u32x2 *>(al + o) = lo;
@@ -206,6 +231,17 @@ __global__ __launch_bounds__(256) void conv_gemm_f32x_kernel(const XParams p) {
         const unsigned short *bhp = smem + buf * STAGE + 2 * PLANE_A + (wn * (BN / 2) + frag_row) * XLD + frag_k;
         const unsigned short *blp = bhp + PLANE_B;
         issue_loads((it + 1) < it1);
+#if SGAM_XSCHED
+        // MFMA-paced interleave: every 32-cycle MFMA shadows a few VALU (operand split, addresses) / DS / VMEM issues
+#pragma unroll
+        for (int q = 0; q < TM * TN * 3 * (XBK / 16); ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x006, SGAM_XSCHED, 0);   // VALU / SALU
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+        }
+#endif
 #pragma unroll
         for (int kk = 0; kk < XBK / 16; ++kk) {
             if (kk == XBK / 32) store_lds(buf ^ 1);
@@ -233,10 +269,14 @@ __global__ __launch_bounds__(256) void conv_gemm_f32x_kernel(const XParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue (as conv_gemm.hip v2): un-scale, bias, residual, bounds-checked stores ----
-    auto sel = xsel;
-    const int col_l = lane & 31;
-    const int row_h = 4 * (lane >> 5);
+    // ---- epilogue: each wavefront transposes its (32 TM) x (32 TN) fp32 tile through a private LDS region so that a
+    // lane ends up with 4 CONSECUTIVE output channels of one pixel: residual comes in and the result leaves as
+    // 16-byte accesses, 16 lanes covering a 256-byte row segment (the MFMA D layout alone gives 4-byte accesses:
+    // 64 store + 64 load instructions per 32x32 tile instead of 4 + 4).  The loop's final barrier already
+    // guarantees every wavefront is done reading the operand slabs.
+    constexpr int WM = 32 * TM, WN = 32 * TN, LDR = WN + 4;
+    static_assert(4 * WM * LDR * 4 <= 2 * STAGE * 2, "epilogue staging must fit the operand LDS");
+    float *region = reinterpret_cast<float *>(smem) + wave * (WM * LDR);
     const bool to_ws = p.ws != nullptr;
     const int n_lim = to_ws ? p.N : p.n_valid;
     const int ldo = to_ws ? p.N : p.ldc;
@@ -248,36 +288,44 @@ __global__ __launch_bounds__(256) void conv_gemm_f32x_kernel(const XParams p) {
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void *)p.res, 0, (int)r_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)p.bias, 0, (int)bias_bytes, 0x00020000);
     constexpr unsigned OOB = 0xFFFFFFF0u;
-    const float inv = p.inv_w_scale;
+    const float inv = to_ws ? 1.0f : p.inv_w_scale;
+    const int col_l = lane & 31;
+    const int row_h = 4 * (lane >> 5);
+    const int wm0 = m0 + wm * (BM / 2), wn0 = n0 + wn * (BN / 2);
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * (BN / 2) + j * 32 + col_l;
-            const bool n_ok = n < n_lim;
-            const float bias_n = p.bias_per_row ? 0.f
-                                                : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                      rb, (int)sel(n_ok, (unsigned)n * 4u, OOB), 0, 0));
-            float rv[16], bv[16];
+            const int n = wn0 + j * 32 + col_l;
+            const float bias_n = (p.bias_per_row || to_ws) ? 0.f
+                                     : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                           rb, (int)xsel(n < n_lim, (unsigned)n * 4u, OOB), 0, 0));
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + row_h;
-                const bool ok = n_ok && m < p.M;
-                rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                      rr, (int)sel(ok, (unsigned)(m * p.ldr + n) * 4u, OOB), 0, 0));
-                bv[e] = p.bias_per_row ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                                       rb, (int)sel(ok, (unsigned)m * 4u, OOB), 0, 0))
-                                       : bias_n;
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + row_h;
-                const bool ok = n_ok && m < p.M;
-                const float v = to_ws ? acc[i][j][e] : (acc[i][j][e] * inv + bv[e]) + rv[e];
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro,
-                                                      (int)sel(ok, (unsigned)(m * ldo + n) * 4u, OOB), 0, 0);
-            }
+            for (int e = 0; e < 16; ++e)
+                region[(i * 32 + (e & 3) + 8 * (e >> 2) + row_h) * LDR + j * 32 + col_l] = acc[i][j][e] * inv + bias_n;
         }
+    // read back row-major: 16 lanes x float4 cover 64 columns; 4 rows per pass (wave-private region: no barrier)
+    constexpr int C4 = WN / 4;          // float4 chunks per row: 8 or 16
+    constexpr int RPP = 64 / C4;        // rows per pass: 8 or 4
+    const int c4 = lane % C4, rr0 = lane / C4;
+    const int n4 = wn0 + c4 * 4;
+    const bool n_ok = n4 < n_lim;       // n_valid is a multiple of 4
+#pragma unroll
+    for (int pass = 0; pass < WM / RPP; ++pass) {
+        const int row = rr0 + pass * RPP;
+        const int m = wm0 + row;
+        const bool ok = n_ok && m < p.M;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(region + row * LDR + c4 * 4);
+        const f32x4 rv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                       rr, (int)xsel(ok, (unsigned)(m * p.ldr + n4) * 4u, OOB), 0, 0));
+        if (p.bias_per_row) {
+            const float bm = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                           rb, (int)xsel(ok, (unsigned)m * 4u, OOB), 0, 0));
+            v += bm;
+        }
+        v += rv;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro,
+                                               (int)xsel(ok, (unsigned)(m * ldo + n4) * 4u, OOB), 0, 0);
     }
 }
 
@@ -369,6 +417,7 @@ int xvalidate(const sgam_conv_desc *d) {
     if (d->lda < d->Cin || d->lda % 4 != 0) return SGAM_EALIGN;
     if (d->ldb < d->KH * d->KW * d->Cin || d->ldb % 8 != 0) return SGAM_EALIGN;
     if (d->n_valid <= 0 || d->n_valid > d->N || d->ldc < d->n_valid) return SGAM_EINVAL;
+    if (d->n_valid % 4 != 0 || d->ldc % 4 != 0 || d->ldr % 4 != 0) return SGAM_EALIGN;   // 16-byte epilogue accesses
     if (d->plan_bm != 0 || d->plan_bn != 0) {
         const bool ok = (d->plan_bm == 128 && d->plan_bn == 128) || (d->plan_bm == 64 && d->plan_bn == 128) ||
                         (d->plan_bm == 64 && d->plan_bn == 64);
@@ -414,6 +463,7 @@ extern "C" int sgam_conv2d_nhwc_f32x(const sgam_conv_desc *d, const float *x, fl
     p.ksplit = pl.ksplit; p.iters_total = pl.iters_total; p.iters_per_split = pl.iters_per_split;
     p.inv_w_scale = 1.0f / (w_scale * a_scale);
     p.a_scale = a_scale;
+
     const int64_t xb = (((int64_t)d->B * d->Hi * d->Wi - 1) * d->lda + d->Cin) * 4;
     const int64_t wb = (int64_t)d->N * d->ldb * 2;   // one plane: [N][ldb] halfs, planes are contiguous
     if (xb >= (1ll << 32) - 64 || wb >= (1ll << 31)) return SGAM_EINVAL;
@@ -425,9 +475,18 @@ extern "C" int sgam_conv2d_nhwc_f32x(const sgam_conv_desc *d, const float *x, fl
     }
     const dim3 grid(sgam_cdiv(p.M, pl.bm), sgam_cdiv(p.N, pl.bn), pl.ksplit);
     hipStream_t s = sgam_stream(stream);
-    if (pl.bm == 128 && pl.bn == 128) hipLaunchKernelGGL((conv_gemm_f32x_kernel<128, 128>), grid, dim3(256), 0, s, p);
-    else if (pl.bm == 64 && pl.bn == 128) hipLaunchKernelGGL((conv_gemm_f32x_kernel<64, 128>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((conv_gemm_f32x_kernel<64, 64>), grid, dim3(256), 0, s, p);
+#define XLAUNCH(BM_, BN_)                                                                                                   \
+    do {                                                                                                                    \
+        if (p.ups) hipLaunchKernelGGL((conv_gemm_f32x_kernel<BM_, BN_, true, false>), grid, dim3(256), 0, s, p);            \
+        else if (a_scale != 1.0f) hipLaunchKernelGGL((conv_gemm_f32x_kernel<BM_, BN_, false, true>), grid, dim3(256), 0, s, p); \
+        else hipLaunchKernelGGL((conv_gemm_f32x_kernel<BM_, BN_, false, false>), grid, dim3(256), 0, s, p);                 \
+    } while (0)
+    if (p.ups && a_scale != 1.0f) return SGAM_EINVAL;
+    if (d->KH * d->KW > 32) return SGAM_EINVAL;   // tap validity mask is 32 bits
+    if (pl.bm == 128 && pl.bn == 128) XLAUNCH(128, 128);
+    else if (pl.bm == 64 && pl.bn == 128) XLAUNCH(64, 128);
+    else XLAUNCH(64, 64);
+#undef XLAUNCH
     SGAM_LAUNCH_CHECK();
     if (pl.ksplit > 1) {
         const int64_t q = (int64_t)p.M * (p.N / 4);
