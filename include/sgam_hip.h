@@ -100,6 +100,18 @@ int sgam_conv2d_nhwc_f32x(const sgam_conv_desc *d, const float *x, float a_scale
                           int64_t workspace_bytes, void *stream);
 int sgam_pack_conv_weight_f32x(const float *w_oihw, void *w_planes, float w_scale, int32_t Cout, int32_t Cin,
                                int32_t KH, int32_t KW, int32_t Cout_pad, int32_t Cin_pad, void *stream);
+/* Same convolution, additionally emitting the GroupNorm statistics of its OUTPUT from the epilogue (per-chunk
+ * {sum, sumsq} of each of the 32 groups, chunk = half a row-tile of one image): gn_partial holds
+ * [B][chunks][32][2] doubles with chunks = sgam_conv2d_f32x_stats_chunks(d) (0 = not available for this shape: split-K
+ * plan, N % 128 != 0, or tiles straddling images).  sgam_groupnorm_from_partials_f32 then normalises without a
+ * statistics pass over the tensor. */
+int32_t sgam_conv2d_f32x_stats_chunks(const sgam_conv_desc *d);
+int sgam_conv2d_stats_nhwc_f32x(const sgam_conv_desc *d, const float *x, float a_scale, const void *w_planes,
+                                float w_scale, const float *bias, const float *residual, float *out,
+                                double *gn_partial, void *workspace, int64_t workspace_bytes, void *stream);
+int sgam_groupnorm_from_partials_f32(const float *x, const double *partial, int32_t nchunk, const float *gamma,
+                                     const float *beta, float *y, int32_t B, int32_t HW, int32_t C, int32_t groups,
+                                     float eps, int32_t fuse_swish, void *workspace, int64_t workspace_bytes, void *stream);
 /* split a row-major fp32 matrix [N][K] (row stride ld) into planes [2][N][K]: the B operand when it is an activation */
 int sgam_split_rows_f32x(const float *x, void *planes, float scale, int32_t N, int32_t K, int32_t ld, void *stream);
 

@@ -43,6 +43,8 @@ struct XParams {
     int lda, ldb, ldc, ldr, n_valid, bias_per_row;
     int M, ksplit, iters_total, iters_per_split;
     unsigned x_bytes, w_plane_bytes;
+    double *gn_partial;  // optional: per-(row-half of the tile, group) {sum, sumsq} of the OUTPUT for the next GroupNorm
+    int gn_cpg;          // channels per group of that GroupNorm (N / 32)
     float inv_w_scale;   // 1 / (a_scale * w_scale), an exact power of two
     float a_scale;       // power of two applied to the A operand before the split (e.g. 1024 for softmax probabilities)
 };
@@ -310,6 +312,7 @@ __global__ __launch_bounds__(256) void conv_gemm_f32x_kernel(const XParams p) {
     const int c4 = lane % C4, rr0 = lane / C4;
     const int n4 = wn0 + c4 * 4;
     const bool n_ok = n4 < n_lim;       // n_valid is a multiple of 4
+    float gs = 0.f, gss = 0.f;   // this lane's share of the output statistics (4 channels x WM/RPP pixels)
 #pragma unroll
     for (int pass = 0; pass < WM / RPP; ++pass) {
         const int row = rr0 + pass * RPP;
@@ -326,6 +329,41 @@ __global__ __launch_bounds__(256) void conv_gemm_f32x_kernel(const XParams p) {
         v += rv;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro,
                                                (int)xsel(ok, (unsigned)(m * ldo + n4) * 4u, OOB), 0, 0);
+        if (ok) {
+            gs += (v[0] + v[1]) + (v[2] + v[3]);
+            gss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
+    }
+    if (p.gn_partial && !to_ws) {
+        // GroupNorm statistics of the tensor just written, for free: a float4 never straddles a group (cpg is a
+        // multiple of 4).  Lanes -> LDS, then one lane per group of this wavefront's column range folds, in a fixed
+        // order and in fp64, the lanes that hold that group; chunk index = (m-tile, row-half) of the output.
+        float *sl = region;                   // reuse the wave-private region: [64 lanes][2]
+        sl[lane * 2] = gs;
+        sl[lane * 2 + 1] = gss;
+        const int c4_per_group = p.gn_cpg / 4;
+        const int groups_here = C4 / c4_per_group;       // groups inside this wavefront's WN columns
+        if (lane < groups_here) {
+            double ds = 0.0, dss = 0.0;
+            for (int r = 0; r < RPP; ++r)
+                for (int k = 0; k < c4_per_group; ++k) {
+                    const int l = r * C4 + lane * c4_per_group + k;
+                    ds += (double)sl[l * 2];
+                    dss += (double)sl[l * 2 + 1];
+                }
+            const int g = (wn0 / p.gn_cpg) + lane;
+            const int groups = p.N / p.gn_cpg;
+            if (g < groups) {
+                const int chunk = blockIdx.x * 2 + wm;          // every output row belongs to exactly one chunk
+                const int hw = p.Ho * p.Wo;
+                const int b = m0 / hw;                           // host guarantees a tile never straddles two images
+                const int chunks_per_b = ((hw + BM - 1) / BM) * 2;
+                const int cb = chunk - b * chunks_per_b;
+                double *o = p.gn_partial + (((int64_t)b * chunks_per_b + cb) * groups + g) * 2;
+                o[0] = ds;
+                o[1] = dss;
+            }
+        }
     }
 }
 
@@ -446,9 +484,35 @@ extern "C" int sgam_conv2d_f32x_plan(const sgam_conv_desc *d, int32_t *bm, int32
     return SGAM_OK;
 }
 
+static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale, const void *w_planes, float w_scale,
+                          const float *bias, const float *residual, float *out, double *gn_partial, void *workspace,
+                          int64_t workspace_bytes, void *stream);
+
 extern "C" int sgam_conv2d_nhwc_f32x(const sgam_conv_desc *d, const float *x, float a_scale, const void *w_planes,
                                      float w_scale, const float *bias, const float *residual, float *out,
                                      void *workspace, int64_t workspace_bytes, void *stream) {
+    return conv_f32x_impl(d, x, a_scale, w_planes, w_scale, bias, residual, out, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int32_t sgam_conv2d_f32x_stats_chunks(const sgam_conv_desc *d) {
+    if (xvalidate(d) != SGAM_OK) return -1;
+    const XPlan pl = make_xplan(d);
+    const int hw = d->Ho * d->Wo;
+    if (pl.ksplit != 1 || d->N % 128 != 0 || d->n_valid != d->N) return 0;      // statistics need complete sums, 32 groups of >= 4
+    if (d->B > 1 && hw % pl.bm != 0) return 0;                                     // a tile must not straddle two images
+    return ((hw + pl.bm - 1) / pl.bm) * 2;
+}
+
+extern "C" int sgam_conv2d_stats_nhwc_f32x(const sgam_conv_desc *d, const float *x, float a_scale, const void *w_planes,
+                                           float w_scale, const float *bias, const float *residual, float *out,
+                                           double *gn_partial, void *workspace, int64_t workspace_bytes, void *stream) {
+    if (!gn_partial || sgam_conv2d_f32x_stats_chunks(d) <= 0) return SGAM_EINVAL;
+    return conv_f32x_impl(d, x, a_scale, w_planes, w_scale, bias, residual, out, gn_partial, workspace, workspace_bytes, stream);
+}
+
+static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale, const void *w_planes, float w_scale,
+                          const float *bias, const float *residual, float *out, double *gn_partial, void *workspace,
+                          int64_t workspace_bytes, void *stream) {
     const int rc = xvalidate(d);
     if (rc != SGAM_OK) return rc;
     if (!x || !w_planes || !out || !(w_scale > 0.f) || !(a_scale > 0.f)) return SGAM_EINVAL;
@@ -463,6 +527,8 @@ extern "C" int sgam_conv2d_nhwc_f32x(const sgam_conv_desc *d, const float *x, fl
     p.ksplit = pl.ksplit; p.iters_total = pl.iters_total; p.iters_per_split = pl.iters_per_split;
     p.inv_w_scale = 1.0f / (w_scale * a_scale);
     p.a_scale = a_scale;
+    p.gn_partial = gn_partial;
+    p.gn_cpg = d->N / 32;
 
     const int64_t xb = (((int64_t)d->B * d->Hi * d->Wi - 1) * d->lda + d->Cin) * 4;
     const int64_t wb = (int64_t)d->N * d->ldb * 2;   // one plane: [N][ldb] halfs, planes are contiguous

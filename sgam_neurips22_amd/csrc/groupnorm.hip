@@ -345,6 +345,28 @@ extern "C" int sgam_groupnorm_nhwc_h16(const void *x, const float *gamma, const 
     return SGAM_EINVAL;
 }
 
+// GroupNorm whose per-chunk statistics were already produced by the epilogue of the convolution that wrote x
+// (sgam_conv2d_stats_nhwc_f32x): finalize + apply only — the statistics pass over x disappears.
+extern "C" int sgam_groupnorm_from_partials_f32(const float *x, const double *partial, int32_t nchunk, const float *gamma,
+                                                const float *beta, float *y, int32_t B, int32_t HW, int32_t C,
+                                                int32_t groups, float eps, int32_t fuse_swish, void *workspace,
+                                                int64_t workspace_bytes, void *stream) {
+    if (!x || !y || !partial || nchunk <= 0 || !gamma || !beta || !gn_shape_ok(B, HW, C, groups)) return SGAM_EINVAL;
+    if (!sgam_aligned16(x) || !sgam_aligned16(y) || !sgam_aligned16(workspace) || !sgam_aligned16(partial)) return SGAM_EALIGN;
+    if (!workspace || workspace_bytes < (int64_t)B * C * 2 * (int64_t)sizeof(float)) return SGAM_EWORKSPACE;
+    hipStream_t s = sgam_stream(stream);
+    float *table = (float *)workspace;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, partial, gamma, beta, table, HW, C, groups, nchunk, eps);
+    SGAM_LAUNCH_CHECK();
+    const int cv = C / 4;
+    int bpb = sgam_cdiv((int64_t)HW * cv, 256 * 4);
+    if (bpb > 4096) bpb = 4096;
+    if (bpb < 1) bpb = 1;
+    hipLaunchKernelGGL(gn_apply_kernel<2>, dim3(bpb * B), dim3(256), 0, s, x, table, y, HW, C, fuse_swish, bpb);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
 extern "C" int sgam_groupnorm_stats_nhwc_f32(const float *x, const float *gamma, const float *beta,
                                              float *scale_shift, int32_t B, int32_t HW, int32_t C, int32_t groups,
                                              float eps, void *workspace, int64_t workspace_bytes, void *stream) {

@@ -200,7 +200,9 @@ class AttnBlock(_NHWCModule):
             s = ops.gemm_nt(qkv[:, :C], qkv[:, C:2 * C])                   # (n, n) scores
             ops.softmax_rows_(s, scale)
             o = ops.gemm_nt(s, vt, a_scale=1024.0)                         # (n, C); probabilities lifted before the split
-            ops.gemm_nt(o, wp, bias=bp, residual=xb, out=out[b].reshape(n, C))
+            ob = ops.gemm_nt(o, wp, bias=bp, residual=xb, out=out[b].reshape(n, C))
+            if B == 1 and hasattr(ob, "_gn_partials"):
+                out._gn_partials = ob._gn_partials   # statistics of the block output for the next GroupNorm
         return out
 
 

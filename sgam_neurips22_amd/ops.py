@@ -49,6 +49,8 @@ def round_up(v, m):
 #   "mfma"  : fp32-in MFMA (conv_gemm.hip) — bit-for-bit an fp32 fmaf chain; the reference implementation of the
 #             parity path and the one the fused GroupNorm prologue / autotuned plans were built on
 F32_MODE = os.environ.get("SGAM_F32_MODE", "split")
+# split-mode convolutions also emit the GroupNorm statistics of their output from the epilogue (no statistics pass)
+FUSE_GN_STATS = os.environ.get("SGAM_FUSE_GN_STATS", "1") == "1"
 
 
 def set_f32_mode(mode):
@@ -214,6 +216,15 @@ def _run_conv_inner(lib, desc, x, w, bias, residual, out, gn=None, a_scale=1.0):
         if ws_bytes < 0:
             raise SgamHipError(f"sgam_conv2d_f32x: unsupported shape {[(f, getattr(desc, f)) for f, _ in desc._fields_]}")
         ws = torch.empty((ws_bytes,), device=x.device, dtype=torch.uint8) if ws_bytes else None
+        chunks = lib.sgam_conv2d_f32x_stats_chunks(ctypes.byref(desc)) if FUSE_GN_STATS else 0
+        if chunks > 0:
+            # the epilogue also emits the GroupNorm statistics of `out`; the next groupnorm_nhwc(out) picks them up
+            partial = torch.empty((desc.B * chunks * 32 * 2,), device=x.device, dtype=torch.float64)
+            check(lib.sgam_conv2d_stats_nhwc_f32x(ctypes.byref(desc), _p(x), float(a_scale), _p(w.planes), float(w.scale),
+                                                  _p(bias), _p(residual), _p(out), _p(partial), _p(ws), ws_bytes, _stream()),
+                  "sgam_conv2d_stats_nhwc_f32x")
+            out._gn_partials = (partial, chunks)
+            return out
         check(lib.sgam_conv2d_nhwc_f32x(ctypes.byref(desc), _p(x), float(a_scale), _p(w.planes), float(w.scale), _p(bias),
                                         _p(residual), _p(out), _p(ws), ws_bytes, _stream()), "sgam_conv2d_nhwc_f32x")
         return out
@@ -298,6 +309,13 @@ def groupnorm_nhwc(x, gamma, beta, swish, groups=32, eps=1e-6):
         raise SgamHipError(f"sgam_groupnorm: unsupported shape B={B} HW={H * W} C={C}")
     ws = torch.empty((ws_bytes,), device=x.device, dtype=torch.uint8)
     y = torch.empty_like(x)
+    pre = getattr(x, "_gn_partials", None)
+    if pre is not None and H * W > 1024 and groups == 32:
+        partial, chunks = pre     # statistics came with the tensor (conv epilogue): finalize + apply only
+        check(lib.sgam_groupnorm_from_partials_f32(_p(x), _p(partial), chunks, _p(gamma), _p(beta), _p(y), B, H * W, C, groups,
+                                                   eps, int(swish), _p(ws), ws_bytes, _stream()),
+              "sgam_groupnorm_from_partials_f32")
+        return y
     check(lib.sgam_groupnorm_nhwc_f32(_p(x), _p(gamma), _p(beta), _p(y), B, H * W, C, groups, eps, int(swish),
                                       _p(ws), ws_bytes, _stream()), "sgam_groupnorm_nhwc_f32")
     return y

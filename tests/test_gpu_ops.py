@@ -245,3 +245,26 @@ def test_split_mode_is_fp32_class_accurate():
 def test_cpu_tensor_is_rejected_loudly():
     with pytest.raises(ops.SgamHipError):
         ops.groupnorm_nhwc(torch.zeros(1, 4, 4, 128), torch.ones(128), torch.zeros(128), True)
+
+
+@pytest.mark.parametrize("B,C,Cout,H,W,k", [(1, 128, 128, 128, 128, 3), (1, 128, 256, 136, 120, 1), (2, 128, 256, 32, 32, 1),
+                                           (1, 128, 128, 256, 256, 3)])
+def test_conv_epilogue_groupnorm_statistics(B, C, Cout, H, W, k):
+    """split-mode conv emits the GroupNorm statistics of its output; GroupNorm(out) from those partials equals
+    GroupNorm(out) with its own statistics pass (and the torch reference)."""
+    ops.set_f32_mode("split")
+    x = _nhwc(testing.seeded_tensor("cst.x", (B, C, H, W), 1.5, 0.2)).to(DEV)
+    w = testing.seeded_tensor("cst.w", (Cout, C, k, k), scale=(1.0 / (C * k * k)) ** 0.5)
+    res = _nhwc(testing.seeded_tensor("cst.r", (B, Cout, H, W))).to(DEV)
+    g = (1 + 0.1 * testing.seeded_tensor("cst.g", (Cout,))).to(DEV)
+    bt = (0.1 * testing.seeded_tensor("cst.b", (Cout,))).to(DEV)
+    wp = ops.pack_conv_weight(w.to(DEV), dtype="f32x")
+    out = ops.conv2d_nhwc(x, wp, None, cout=Cout, kh=k, kw=k, pad_t=k // 2, pad_l=k // 2, residual=res)
+    if not hasattr(out, "_gn_partials"):
+        pytest.skip("this shape runs split-K on this plan table: statistics come from the GroupNorm pass")
+    y_fused = ops.groupnorm_nhwc(out, g, bt, True)
+    y_plain = ops.groupnorm_nhwc(out.clone(), g, bt, True)        # clone drops the attached statistics
+    ref = F.group_norm(out.permute(0, 3, 1, 2).cpu(), 32, g.cpu(), bt.cpu(), eps=1e-6)
+    ref = ref * torch.sigmoid(ref)
+    _close(y_plain.permute(0, 3, 1, 2), ref, 2e-5, "plain")
+    _close(y_fused.permute(0, 3, 1, 2), ref, 2e-5, "fused statistics")
