@@ -180,16 +180,17 @@ def main():
                         "gflop_per_frame_in_kernel": round(dom["flops"] / 1e9, 1),
                         "all_conv_kernels": {f"{k[0]}x{k[1]}/{k[2]}": {"launches": v["launches"], "gflop": round(v["flops"] / 1e9, 1),
                                                                "ms": round(v["ms"], 3)} for k, v in agg.items()}}
-    if roofline is not None and args.dtype == "f32" and ops.F32_MODE == "mfma":
+    if roofline is not None and args.dtype == "f32":
         # HBM traffic of the dominant kernel: PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) collected
         # with rocprofv3 --pmc in separate passes on the dominant layer shape and committed under profiles/
-        pmc = os.path.join(ROOT, "profiles", "r01b_pmc_conv128_f32.json")
+        name = "r01c_pmc_conv128_f32x.json" if ops.F32_MODE == "split" else "r01b_pmc_conv128_f32.json"
+        pmc = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pmc):
             d = json.load(open(pmc))["derived"]
             roofline["traffic"] = round(d["hbm_traffic_bytes_per_launch"])
             roofline["traffic_note"] = ("bytes/launch on the dominant layer (M=65536,N=128,K=1152; algorithmic "
-                                        f"{d['algorithmic_bytes_per_launch']} B) from profiles/r01b_pmc_conv128_f32.json; "
-                                        f"in-kernel MFMA busy {d['mfma_busy_frac']:.3f} at {d['effective_clock_ghz_at_185us']:.2f} GHz")
+                                        f"{d['algorithmic_bytes_per_launch']} B) from profiles/{name}; "
+                                        f"in-kernel MFMA busy {d['mfma_busy_frac']:.3f}")
 
     secondary = None
     if rank == 0 and world == 1 and args.dtype == "f32" and not args.no_secondary:
