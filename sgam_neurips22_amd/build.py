@@ -18,7 +18,9 @@ SOURCES = {
     "norm_softmax.hip": [],
     "groupnorm.hip": [],
     "h16.hip": [],
-    "conv_f32x.hip": [f"-DSGAM_XSCHED={os.environ.get('SGAM_XSCHED', '0')}"],
+    "conv_f32x.hip": [f"-DSGAM_XPF_BIG={os.environ.get('SGAM_XPF_BIG', '2')}",
+                      f"-DSGAM_XPF_SMALL={os.environ.get('SGAM_XPF_SMALL', '4')}",
+                      f"-DSGAM_XABLATE={os.environ.get('SGAM_XABLATE', '0')}"],
     "vq.hip": ["-ffp-contract=off"],
     "layout.hip": ["-ffp-contract=off"],
     "warp.hip": ["-ffp-contract=off"],

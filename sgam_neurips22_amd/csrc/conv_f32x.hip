@@ -42,6 +42,7 @@ struct XParams {
     int B, Hi, Wi, Cin, Ho, Wo, N, KH, KW, stride, pad_t, pad_l, ups;
     int lda, ldb, ldc, ldr, n_valid, bias_per_row;
     int M, ksplit, iters_total, iters_per_split;
+    int gx, gy, xcd_swizzle;   // logical grid (M tiles, N tiles); the launch is 1-D, see xcd_block()
     unsigned x_bytes, w_plane_bytes;
     double *gn_partial;  // optional: per-(row-half of the tile, group) {sum, sumsq} of the OUTPUT for the next GroupNorm
     int gn_cpg;          // channels per group of that GroupNorm (N / 32)
@@ -49,8 +50,25 @@ struct XParams {
     float a_scale;       // power of two applied to the A operand before the split (e.g. 1024 for softmax probabilities)
 };
 
-constexpr int XBK = 32;          // fp32 elements of K per slab
-constexpr int XLD = XBK + 8;     // LDS row stride in halfs (80 bytes)
+#ifndef SGAM_XPF_BIG
+#define SGAM_XPF_BIG 1
+#endif
+#ifndef SGAM_XPF_SMALL
+#define SGAM_XPF_SMALL 2
+#endif
+#ifndef SGAM_XBK_SMALL
+#define SGAM_XBK_SMALL 64
+#endif
+#ifndef SGAM_XWK_SMALL
+#define SGAM_XWK_SMALL 2
+#endif
+// K slab per pipeline step: 32 fp32 elements for the 128-wide tiles; the 64x64 tile (the latency-bound layers) takes
+// 64 with EIGHT wavefronts — two groups of four, each doing half of the slab's MFMA k-steps on its own accumulators,
+// combined through LDS before the epilogue — so that a barrier round trip buys twice the work and every SIMD has two
+// wavefronts to overlap LDS / VALU / MFMA latencies with.  LDS row stride = slab + 8 halfs (80 / 144 bytes): the
+// 16-lane groups of ds_read_b128 land on distinct banks.
+constexpr int xbk_of(int bm, int bn) { return (bm == 64 && bn == 64) ? SGAM_XBK_SMALL : 32; }
+constexpr int wk_of(int bm, int bn) { return (bm == 64 && bn == 64) ? SGAM_XWK_SMALL : 1; }
 
 __device__ __forceinline__ unsigned xsel(bool c, unsigned a, unsigned b) {
     const unsigned m = 0u - (unsigned)c;
@@ -77,36 +95,71 @@ __device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
+// PF = register prefetch distance in K slabs: the loads of slab t+PF are in flight while slab t is multiplied.  The
+// small tiles run on the latency-bound layers (16^2..64^2 maps, split-K: a few slabs per workgroup, one or two
+// workgroups per CU), where a distance of 1 leaves every slab waiting a full memory round trip.
+// XCD-aware workgroup -> tile map.  The dispatcher deals consecutive workgroups round-robin to the 8 XCDs (observed:
+// workgroup b runs on XCD b % 8), each with a private 4 MB L2, so neighbouring tiles — which share filter-tap halos of
+// the input and the weight panel — would each fetch their operands into a different L2.  The launch is 1-D and
+// workgroup L takes logical tile L' = (L % 8) * T/8 + L / 8 (bijective form for T % 8 != 0): every XCD owns a
+// contiguous run of tiles, M-tile index fastest.  Placement only affects speed, never results.
+__device__ __forceinline__ void xcd_block(const XParams &p, int &bx, int &by, int &bz) {
+    const unsigned L = blockIdx.x, T = gridDim.x;
+    unsigned Lp = L;
+    if (p.xcd_swizzle) {
+        const unsigned q = T >> 3, r = T & 7u, xcd = L & 7u, idx = L >> 3;
+        Lp = xcd * q + (xcd < r ? xcd : r) + idx;
+    }
+    bx = (int)(Lp % (unsigned)p.gx);
+    const unsigned t = Lp / (unsigned)p.gx;
+    by = (int)(t % (unsigned)p.gy);
+    bz = (int)(t / (unsigned)p.gy);
+}
+
 template <int BM, int BN, bool UPS, bool ASCALE>
-__global__ __launch_bounds__(256) void conv_gemm_f32x_kernel(const XParams p) {
+__global__ __launch_bounds__(256 * wk_of(BM, BN)) void conv_gemm_f32x_kernel(const XParams p) {
+    constexpr int XBK = xbk_of(BM, BN), WK = wk_of(BM, BN), NT = 256 * WK;
+    constexpr int XLD = XBK + 8;
     constexpr int TM = BM / 64, TN = BN / 64;
-    constexpr int AR = BM / 32;            // float4 rows of A per thread (8 float4 columns x 32 rows per pass)
-    constexpr int BRW = BN / 64;           // 16-byte chunks of each B plane per thread (4 chunks per 64-byte row)
+    constexpr int PF = (BM * BN >= 128 * 128) ? SGAM_XPF_BIG : SGAM_XPF_SMALL;
+    constexpr int AC = XBK / 4;            // float4 columns of an A slab row
+    constexpr int BC = XBK / 8;            // 16-byte chunks of a B plane row
+    static_assert(NT / AC == 32 && NT / BC == 64, "staging maps assume 32 A rows / 64 B rows per pass");
+    constexpr int AR = BM / 32;            // float4 rows of A per thread
+    constexpr int BRW = BN / 64;           // 16-byte chunks of each B plane per thread
+    constexpr int KS = XBK / 16;           // MFMA k-steps per slab
+    static_assert(KS % WK == 0, "k-steps split evenly over the wavefront groups");
     constexpr int PLANE_A = BM * XLD, PLANE_B = BN * XLD;
     constexpr int STAGE = 2 * PLANE_A + 2 * PLANE_B;   // halfs per pipeline stage
     __shared__ __attribute__((aligned(16))) unsigned short smem[2 * STAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = (tid >> 6) & 3;       // position in the 2x2 wavefront grid of the tile
+    const int wk = tid >> 8;               // k-step group (0 when WK == 1)
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    int bx, by, bz;
+    xcd_block(p, bx, by, bz);
+    const int m0 = bx * BM;
+    const int n0 = by * BN;
 
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rwh = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, (int)p.w_plane_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rwl = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.w + p.w_plane_bytes), 0,
                                                                          (int)p.w_plane_bytes, 0x00020000);
 
-    const int it0 = blockIdx.z * p.iters_per_split;
-    const int it1 = min(p.iters_total, it0 + p.iters_per_split);
+    const int it0 = bz * p.iters_per_split;
+#ifndef SGAM_XABLATE
+#define SGAM_XABLATE 0
+#endif
+    const int it1 = SGAM_XABLATE == 1 ? it0 : min(p.iters_total, it0 + p.iters_per_split);
 
     // A staging: thread -> (float4 column col4 of the 32-wide slab, rows row_in_pass + 32 r)
-    const int col4 = tid & 7;
-    const int row_in_pass = tid >> 3;
+    const int col4 = tid % AC;
+    const int row_in_pass = tid / AC;
     // B staging: thread -> (16-byte chunk c16 of the 64-byte plane row, rows brow + 64 r)
-    const int c16 = tid & 3;
-    const int brow = tid >> 2;
+    const int c16 = tid % BC;
+    const int brow = tid / BC;
     const int Hl = p.ups ? 2 * p.Hi : p.Hi;
     const int Wl = p.ups ? 2 * p.Wi : p.Wi;
 
@@ -149,9 +202,10 @@ __global__ __launch_bounds__(256) void conv_gemm_f32x_kernel(const XParams p) {
     int ky = tap / p.KW;
     int kx = tap - ky * p.KW;
 
-    f32x4 areg[AR];
-    u32x4 bh[BRW], bl[BRW];
-    auto issue_loads = [&](bool live) {
+    f32x4 areg[PF][AR];
+    u32x4 bh[PF][BRW], bl[PF][BRW];
+    auto issue_loads = [&](const int st, bool live) {
+        if (SGAM_XABLATE == 2) live = false;
         const int coff = ch * XBK + col4 * 4;
         const bool k_ok = live && coff < p.Cin;
         if constexpr (UPS) {
@@ -161,15 +215,15 @@ __global__ __launch_bounds__(256) void conv_gemm_f32x_kernel(const XParams p) {
                 const bool ok = k_ok && (unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl;
                 const int py = iy >> 1, px = ix >> 1;
                 const unsigned off = (unsigned)((a_base[r] + py * p.Wi + px) * p.lda + coff) * 4u;
-                areg[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)xsel(ok, off, p.x_bytes), 0, 0));
+                areg[st][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)xsel(ok, off, p.x_bytes), 0, 0));
             }
         } else {
             const unsigned tap_off = (unsigned)((ky * p.Wi + kx) * p.lda + ch * XBK) * 4u;   // wave-uniform
 #pragma unroll
             for (int r = 0; r < AR; ++r) {
                 const bool ok = k_ok && ((a_tapmask[r] >> tap) & 1u);
-                areg[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                        rx, (int)xsel(ok, a_rowoff[r] + tap_off, p.x_bytes), 0, 0));
+                areg[st][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                            rx, (int)xsel(ok, a_rowoff[r] + tap_off, p.x_bytes), 0, 0));
             }
         }
         const bool kb_ok = live && (ch * XBK + c16 * 8) < p.Cin;
@@ -177,8 +231,8 @@ __global__ __launch_bounds__(256) void conv_gemm_f32x_kernel(const XParams p) {
 #pragma unroll
         for (int r = 0; r < BRW; ++r) {
             const unsigned o = xsel(kb_ok, b_off[r] + koff, p.w_plane_bytes);
-            bh[r] = __builtin_amdgcn_raw_buffer_load_b128(rwh, (int)o, 0, 0);
-            bl[r] = __builtin_amdgcn_raw_buffer_load_b128(rwl, (int)o, 0, 0);
+            bh[st][r] = __builtin_amdgcn_raw_buffer_load_b128(rwh, (int)o, 0, 0);
+            bl[st][r] = __builtin_amdgcn_raw_buffer_load_b128(rwl, (int)o, 0, 0);
         }
         ++tap;
         if (++kx == p.KW) {
@@ -190,7 +244,7 @@ __global__ __launch_bounds__(256) void conv_gemm_f32x_kernel(const XParams p) {
             ++ch;
         }
     };
-    auto store_lds = [&](int buf) {
+    auto store_lds = [&](const int st, int buf) {
         unsigned short *ah = smem + buf * STAGE;
         unsigned short *al = ah + PLANE_A;
         unsigned short *bhp = al + PLANE_A;
@@ -198,7 +252,7 @@ __global__ __launch_bounds__(256) void conv_gemm_f32x_kernel(const XParams p) {
 #pragma unroll
         for (int r = 0; r < AR; ++r) {
             u32x2 hi, lo;
-            split4(ASCALE ? areg[r] * p.a_scale : areg[r], hi, lo);
+            split4(ASCALE ? areg[st][r] * p.a_scale : areg[st][r], hi, lo);
             const int o = (row_in_pass + 32 * r) * XLD + col4 * 4;
             *reinterpret_cast<u32x2 *>(ah + o) = hi;
             *reinterpret_cast<u32x2 *>(al + o) = lo;
@@ -206,69 +260,87 @@ __global__ __launch_bounds__(256) void conv_gemm_f32x_kernel(const XParams p) {
 #pragma unroll
         for (int r = 0; r < BRW; ++r) {
             const int o = (brow + 64 * r) * XLD + c16 * 8;
-            *reinterpret_cast<u32x4 *>(bhp + o) = bh[r];
-            *reinterpret_cast<u32x4 *>(blp + o) = bl[r];
+            *reinterpret_cast<u32x4 *>(bhp + o) = bh[st][r];
+            *reinterpret_cast<u32x4 *>(blp + o) = bl[st][r];
         }
     };
 
-    f32x16 acc[TM][TN];
+    // one accumulator per output tile; a wavefront that owns a single tile keeps the cross terms (a_lo b_hi + a_hi b_lo)
+    // in a second one so that consecutive MFMAs never wait on each other's result
+    constexpr bool SEPACC = (TM * TN == 1);
+    f32x16 acc[TM][TN], accs[1];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) accs[0][e] = 0.f;
 
     const int frag_row = lane & 31;
     const int frag_k = (lane >> 5) * 8;
 
-    issue_loads(it0 < it1);
-    store_lds(0);
+    // prologue: slabs it0 .. it0+PF-1 in flight, slab it0 into LDS, its register stage re-armed with slab it0+PF
+#pragma unroll
+    for (int s = 0; s < PF; ++s) issue_loads(s, it0 + s < it1);
+    store_lds(0, 0);
+    issue_loads(0, it0 + PF < it1);
     __syncthreads();
 
-    for (int it = it0; it < it1; ++it) {
-        const int buf = (it - it0) & 1;
-        const unsigned short *ah = smem + buf * STAGE + (wm * (BM / 2) + frag_row) * XLD + frag_k;
-        const unsigned short *al = ah + PLANE_A;
-        const unsigned short *bhp = smem + buf * STAGE + 2 * PLANE_A + (wn * (BN / 2) + frag_row) * XLD + frag_k;
-        const unsigned short *blp = bhp + PLANE_B;
-        issue_loads((it + 1) < it1);
-#if SGAM_XSCHED
-        // MFMA-paced interleave: every 32-cycle MFMA shadows a few VALU (operand split, addresses) / DS / VMEM issues
+    int it = it0;
+    while (it < it1) {
 #pragma unroll
-        for (int q = 0; q < TM * TN * 3 * (XBK / 16); ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x006, SGAM_XSCHED, 0);   // VALU / SALU
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
-        }
-#endif
+        for (int s = 0; s < PF; ++s) {       // unrolled by PF: the register stage index is a compile-time constant
+            if (it < it1) {
+                const int nst = (s + 1) % PF;    // stage holding slab it+1
+                const int buf = (it - it0) & 1;
+                const unsigned short *ah = smem + buf * STAGE + (wm * (BM / 2) + frag_row) * XLD + frag_k;
+                const unsigned short *al = ah + PLANE_A;
+                const unsigned short *bhp = smem + buf * STAGE + 2 * PLANE_A + (wn * (BN / 2) + frag_row) * XLD + frag_k;
+                const unsigned short *blp = bhp + PLANE_B;
 #pragma unroll
-        for (int kk = 0; kk < XBK / 16; ++kk) {
-            if (kk == XBK / 32) store_lds(buf ^ 1);
-            u32x4 fah[TM], fal[TM], fbh[TN], fbl[TN];
+                for (int kq = 0; kq < KS / WK; ++kq) {
+                    const int kk = kq * WK + wk;          // this wavefront group's k-step inside the slab
+                    if (kq == (KS / WK) / 2) {
+                        store_lds(nst, buf ^ 1);                      // slab it+1 -> the other LDS buffer
+                        issue_loads(nst, it + 1 + PF < it1);          // slab it+1+PF -> the freed register stage
+                    }
+                    u32x4 fah[TM], fal[TM], fbh[TN], fbl[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                fah[i] = *reinterpret_cast<const u32x4 *>(ah + i * 32 * XLD + kk * 16);
-                fal[i] = *reinterpret_cast<const u32x4 *>(al + i * 32 * XLD + kk * 16);
-            }
+                    for (int i = 0; i < TM; ++i) {
+                        fah[i] = *reinterpret_cast<const u32x4 *>(ah + i * 32 * XLD + kk * 16);
+                        fal[i] = *reinterpret_cast<const u32x4 *>(al + i * 32 * XLD + kk * 16);
+                    }
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                fbh[j] = *reinterpret_cast<const u32x4 *>(bhp + j * 32 * XLD + kk * 16);
-                fbl[j] = *reinterpret_cast<const u32x4 *>(blp + j * 32 * XLD + kk * 16);
-            }
+                    for (int j = 0; j < TN; ++j) {
+                        fbh[j] = *reinterpret_cast<const u32x4 *>(bhp + j * 32 * XLD + kk * 16);
+                        fbl[j] = *reinterpret_cast<const u32x4 *>(blp + j * 32 * XLD + kk * 16);
+                    }
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    // small terms first so that they are not swamped one by one by the running sum
-                    acc[i][j] = mfma16(fal[i], fbh[j], acc[i][j]);
-                    acc[i][j] = mfma16(fah[i], fbl[j], acc[i][j]);
-                    acc[i][j] = mfma16(fah[i], fbh[j], acc[i][j]);
+                        for (int j = 0; j < TN; ++j) {
+                            // small terms first so that they are not swamped one by one by the running sum
+                            if (SGAM_XABLATE == 3) {
+                                acc[i][j][0] += __builtin_bit_cast(float, fal[i][0] ^ fbh[j][0] ^ fah[i][1] ^ fbl[j][1]);
+                                continue;
+                            }
+                            if constexpr (SEPACC) {
+                                accs[0] = mfma16(fal[i], fbh[j], accs[0]);
+                                acc[i][j] = mfma16(fah[i], fbh[j], acc[i][j]);
+                                accs[0] = mfma16(fah[i], fbl[j], accs[0]);
+                            } else {
+                                acc[i][j] = mfma16(fal[i], fbh[j], acc[i][j]);
+                                acc[i][j] = mfma16(fah[i], fbl[j], acc[i][j]);
+                                acc[i][j] = mfma16(fah[i], fbh[j], acc[i][j]);
+                            }
+                        }
                 }
+                __syncthreads();
+                ++it;
+            }
         }
-        __syncthreads();
     }
 
     // ---- epilogue: each wavefront transposes its (32 TM) x (32 TN) fp32 tile through a private LDS region so that a
@@ -276,13 +348,37 @@ __global__ __launch_bounds__(256) void conv_gemm_f32x_kernel(const XParams p) {
     // 16-byte accesses, 16 lanes covering a 256-byte row segment (the MFMA D layout alone gives 4-byte accesses:
     // 64 store + 64 load instructions per 32x32 tile instead of 4 + 4).  The loop's final barrier already
     // guarantees every wavefront is done reading the operand slabs.
+    if constexpr (SEPACC) acc[0][0] += accs[0];
     constexpr int WM = 32 * TM, WN = 32 * TN, LDR = WN + 4;
     static_assert(4 * WM * LDR * 4 <= 2 * STAGE * 2, "epilogue staging must fit the operand LDS");
+    if constexpr (WK > 1) {
+        // the second k-step group hands its accumulators over through LDS (lane-linear, behind the transposition
+        // regions) and retires; the first group adds them in a fixed order
+        constexpr int XCH = 4 * WM * LDR;      // floats used by the four transposition regions
+        static_assert((XCH + 4 * TM * TN * 1024) * 4 <= 2 * STAGE * 2, "k-group exchange must fit the operand LDS");
+        float *xch = reinterpret_cast<float *>(smem) + XCH + wave * (TM * TN * 1024);
+        if (wk == 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) xch[((i * TN + j) * 16 + e) * 64 + lane] = acc[i][j][e];
+        }
+        __syncthreads();
+        if (wk == 1) return;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] += xch[((i * TN + j) * 16 + e) * 64 + lane];
+    }
     float *region = reinterpret_cast<float *>(smem) + wave * (WM * LDR);
     const bool to_ws = p.ws != nullptr;
     const int n_lim = to_ws ? p.N : p.n_valid;
     const int ldo = to_ws ? p.N : p.ldc;
-    float *obase = to_ws ? p.ws + (int64_t)blockIdx.z * p.M * p.N : p.out;
+    float *obase = to_ws ? p.ws + (int64_t)bz * p.M * p.N : p.out;
     const unsigned o_bytes = (unsigned)(((int64_t)(p.M - 1) * ldo + n_lim) * 4);
     const unsigned r_bytes = (p.res && !to_ws) ? (unsigned)(((int64_t)(p.M - 1) * p.ldr + p.n_valid) * 4) : 0u;
     const unsigned bias_bytes = (p.bias && !to_ws) ? (unsigned)((p.bias_per_row ? p.M : p.N) * 4) : 0u;
@@ -354,7 +450,7 @@ __global__ __launch_bounds__(256) void conv_gemm_f32x_kernel(const XParams p) {
             const int g = (wn0 / p.gn_cpg) + lane;
             const int groups = p.N / p.gn_cpg;
             if (g < groups) {
-                const int chunk = blockIdx.x * 2 + wm;          // every output row belongs to exactly one chunk
+                const int chunk = bx * 2 + wm;          // every output row belongs to exactly one chunk
                 const int hw = p.Ho * p.Wo;
                 const int b = m0 / hw;                           // host guarantees a tile never straddles two images
                 const int chunks_per_b = ((hw + BM - 1) / BM) * 2;
@@ -424,12 +520,13 @@ struct XPlan {
 XPlan make_xplan(const sgam_conv_desc *d) {
     const int64_t M = (int64_t)d->B * d->Ho * d->Wo;
     XPlan pl;
-    pl.iters_total = d->KH * d->KW * ((d->Cin + XBK - 1) / XBK);
     auto blocks = [&](int bm, int bn) { return (int64_t)sgam_cdiv(M, bm) * sgam_cdiv(d->N, bn); };
     if (d->N % 128 == 0 && blocks(128, 128) >= 224) { pl.bm = 128; pl.bn = 128; }
     else if (d->N % 128 == 0 && blocks(64, 128) >= 224) { pl.bm = 64; pl.bn = 128; }
     else { pl.bm = 64; pl.bn = 64; }
     if (d->plan_bm > 0 && d->plan_bn > 0) { pl.bm = d->plan_bm; pl.bn = d->plan_bn; }
+    const int xbk = xbk_of(pl.bm, pl.bn);
+    pl.iters_total = d->KH * d->KW * ((d->Cin + xbk - 1) / xbk);
     const int64_t nb = blocks(pl.bm, pl.bn);
     int ks = 1;
     if (d->plan_ksplit > 0) {
@@ -539,13 +636,18 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
         if (!workspace || workspace_bytes < need || !sgam_aligned16(workspace)) return SGAM_EWORKSPACE;
         p.ws = (float *)workspace;
     }
-    const dim3 grid(sgam_cdiv(p.M, pl.bm), sgam_cdiv(p.N, pl.bn), pl.ksplit);
+    p.gx = sgam_cdiv(p.M, pl.bm);
+    p.gy = sgam_cdiv(p.N, pl.bn);
+    static const int swz = [] { const char *e = getenv("SGAM_XCD_SWIZZLE"); return (e && e[0] == '0') ? 0 : 1; }();
+    p.xcd_swizzle = swz;
+    const dim3 grid((unsigned)((int64_t)p.gx * p.gy * pl.ksplit));   // 1-D: the kernel maps it XCD-aware (xcd_block)
     hipStream_t s = sgam_stream(stream);
 #define XLAUNCH(BM_, BN_)                                                                                                   \
     do {                                                                                                                    \
-        if (p.ups) hipLaunchKernelGGL((conv_gemm_f32x_kernel<BM_, BN_, true, false>), grid, dim3(256), 0, s, p);            \
-        else if (a_scale != 1.0f) hipLaunchKernelGGL((conv_gemm_f32x_kernel<BM_, BN_, false, true>), grid, dim3(256), 0, s, p); \
-        else hipLaunchKernelGGL((conv_gemm_f32x_kernel<BM_, BN_, false, false>), grid, dim3(256), 0, s, p);                 \
+        const dim3 blk(256 * wk_of(BM_, BN_));                                                                              \
+        if (p.ups) hipLaunchKernelGGL((conv_gemm_f32x_kernel<BM_, BN_, true, false>), grid, blk, 0, s, p);                  \
+        else if (a_scale != 1.0f) hipLaunchKernelGGL((conv_gemm_f32x_kernel<BM_, BN_, false, true>), grid, blk, 0, s, p);   \
+        else hipLaunchKernelGGL((conv_gemm_f32x_kernel<BM_, BN_, false, false>), grid, blk, 0, s, p);                       \
     } while (0)
     if (p.ups && a_scale != 1.0f) return SGAM_EINVAL;
     if (d->KH * d->KW > 32) return SGAM_EINVAL;   // tap validity mask is 32 bits

@@ -189,39 +189,6 @@ __global__ __launch_bounds__(GT) void gn_partial_kernel(const typename E<T>::S *
 }
 
 // fold partial[b][0..nchunk)[g] into mean / rstd for every group (256 lanes, fixed order) — LDS result
-__device__ __forceinline__ void fold_partials(const double *__restrict__ partial, int b, int nchunk, int groups, int HW, int C,
-                                              float eps, float *sh_mean, float *sh_rstd, double *sh_s, double *sh_ss) {
-    const int np = 256 / groups;
-    const int g = threadIdx.x % groups, part = threadIdx.x / groups;
-    double s = 0.0, ss = 0.0;
-    if (part < np) {
-        const double *base = partial + ((int64_t)b * nchunk * groups + g) * 2;
-#pragma unroll 4
-        for (int k = part; k < nchunk; k += np) {
-            const double2 v = *reinterpret_cast<const double2 *>(base + (int64_t)k * groups * 2);
-            s += v.x;
-            ss += v.y;
-        }
-    }
-    sh_s[threadIdx.x] = s;
-    sh_ss[threadIdx.x] = ss;
-    __syncthreads();
-    if ((int)threadIdx.x < groups) {
-        double ts = 0.0, tss = 0.0;
-        for (int q = 0; q < np; ++q) {
-            ts += sh_s[q * groups + g];
-            tss += sh_ss[q * groups + g];
-        }
-        const double n = (double)HW * (double)(C / groups);
-        const double mean = ts / n;
-        double var = tss / n - mean * mean;
-        if (var < 0.0) var = 0.0;
-        sh_mean[g] = (float)mean;
-        sh_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
-    }
-    __syncthreads();
-}
-
 template <int T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const typename E<T>::S *__restrict__ x, const float *__restrict__ scale_shift,
                                                        typename E<T>::S *__restrict__ y, int HW, int C, int swish,
@@ -253,20 +220,40 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const typename E<T>::S *_
     }
 }
 
-// statistics-only finalize (scale/shift table for the fused conv prologue)
+// finalize: one workgroup per (group, image) folds the chunk partials (lane-strided, then a fixed shuffle / LDS tree:
+// deterministic) and writes the per-channel scale / shift of its channels
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const double *__restrict__ partial, const float *__restrict__ gamma,
                                                           const float *__restrict__ beta, float *__restrict__ scale_shift,
                                                           int HW, int C, int groups, int nchunk, float eps) {
-    __shared__ double sh_s[256], sh_ss[256];
-    __shared__ float sh_mean[64], sh_rstd[64];
-    const int b = blockIdx.x;
-    fold_partials(partial, b, nchunk, groups, HW, C, eps, sh_mean, sh_rstd, sh_s, sh_ss);
+    __shared__ double sh_s[4], sh_ss[4];
+    const int g = blockIdx.x, b = blockIdx.y;
+    const double *base = partial + ((int64_t)b * nchunk * groups + g) * 2;
+    double s = 0.0, ss = 0.0;
+    for (int k = threadIdx.x; k < nchunk; k += 256) {
+        const double2 v = *reinterpret_cast<const double2 *>(base + (int64_t)k * groups * 2);
+        s += v.x;
+        ss += v.y;
+    }
+    s = sgam_wave_sum_f64(s);
+    ss = sgam_wave_sum_f64(ss);
+    if ((threadIdx.x & 63) == 0) {
+        sh_s[threadIdx.x >> 6] = s;
+        sh_ss[threadIdx.x >> 6] = ss;
+    }
+    __syncthreads();
     const int cpg = C / groups;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const int g = c / cpg;
-        const float s = sh_rstd[g] * gamma[c];
-        scale_shift[((int64_t)b * C + c) * 2 + 0] = s;
-        scale_shift[((int64_t)b * C + c) * 2 + 1] = beta[c] - sh_mean[g] * s;
+    if ((int)threadIdx.x < cpg) {
+        const double ts = (sh_s[0] + sh_s[1]) + (sh_s[2] + sh_s[3]);
+        const double tss = (sh_ss[0] + sh_ss[1]) + (sh_ss[2] + sh_ss[3]);
+        const double n = (double)HW * (double)cpg;
+        const double mean = ts / n;
+        double var = tss / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const int c = g * cpg + threadIdx.x;
+        const float sc = rstd * gamma[c];
+        scale_shift[((int64_t)b * C + c) * 2 + 0] = sc;
+        scale_shift[((int64_t)b * C + c) * 2 + 1] = beta[c] - (float)mean * sc;
     }
 }
 
@@ -302,7 +289,7 @@ int gn_launch(const void *x, const float *gamma, const float *beta, void *y, int
     hipLaunchKernelGGL(gn_partial_kernel<T>, dim3(nchunk, B), dim3(GT), 0, s, (const S *)x, partial, HW, C, groups, ppc);
     SGAM_LAUNCH_CHECK();
     float *table = (float *)((char *)workspace + (int64_t)B * 256 * 64 * 2 * sizeof(double));
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, partial, gamma, beta, table, HW, C, groups, nchunk, eps);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(256), 0, s, partial, gamma, beta, table, HW, C, groups, nchunk, eps);
     SGAM_LAUNCH_CHECK();
     const int cv = C / E<T>::VEC;
     int bpb = sgam_cdiv((int64_t)HW * cv, 256 * 4);   // ~4 vectors per lane
@@ -356,7 +343,7 @@ extern "C" int sgam_groupnorm_from_partials_f32(const float *x, const double *pa
     if (!workspace || workspace_bytes < (int64_t)B * C * 2 * (int64_t)sizeof(float)) return SGAM_EWORKSPACE;
     hipStream_t s = sgam_stream(stream);
     float *table = (float *)workspace;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, partial, gamma, beta, table, HW, C, groups, nchunk, eps);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(256), 0, s, partial, gamma, beta, table, HW, C, groups, nchunk, eps);
     SGAM_LAUNCH_CHECK();
     const int cv = C / 4;
     int bpb = sgam_cdiv((int64_t)HW * cv, 256 * 4);
@@ -378,7 +365,7 @@ extern "C" int sgam_groupnorm_stats_nhwc_f32(const float *x, const float *gamma,
     double *partial = (double *)workspace;
     hipLaunchKernelGGL(gn_partial_kernel<2>, dim3(nchunk, B), dim3(GT), 0, s, x, partial, HW, C, groups, sgam_cdiv(HW, nchunk));
     SGAM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, partial, gamma, beta, scale_shift, HW, C, groups, nchunk, eps);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(256), 0, s, partial, gamma, beta, scale_shift, HW, C, groups, nchunk, eps);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
 }

@@ -162,6 +162,8 @@ def main():
     print(f"tuned {len(plans)} of {len(keys)} shapes; sum of per-shape savings {saved * 1e3:.0f} us (one launch each)")
     if a.merge and os.path.exists(ops._PLAN_FILE):
         old = json.load(open(ops._PLAN_FILE)).get("plans", {})
+        for k in keys:                 # every shape just examined: the new verdict (plan or heuristic) replaces the old one
+            old.pop(k, None)
         old.update(plans)
         plans = old
     with open(a.out, "w") as f:
