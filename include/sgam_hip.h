@@ -88,10 +88,12 @@ int sgam_pack_conv_weight(const float *w_oihw, float *w_packed, int32_t Cout, in
  * activations in and out) evaluated on the fp16 matrix cores with fp32-class accuracy: every operand is split
  * exactly into hi + lo fp16 pieces and a.b = a_hi.b_hi + a_hi.b_lo + a_lo.b_hi is accumulated in fp32 (products of
  * fp16 values are exact in fp32; the dropped term is <= 2^-22 |a||b|).  Held to the same parity tests as the
- * fp32-MFMA path.  Weights are pre-split by sgam_pack_conv_weight_f32x into two fp16 planes [2][N][ldb] of
- * w_scale * w (w_scale a power of two lifting max|w| into (512, 1024]); activations are split while staged, after
- * multiplication by the power of two a_scale (1 for ordinary activations, 1024 for softmax probabilities).
- * ldb is in halfs per plane row; Cin % 8 == 0; |a_scale * x| must stay below 65504.
+ * fp32-MFMA path.  Weights are pre-split by sgam_pack_conv_weight_f32x into fp16 hi / lo halves of w_scale * w
+ * (w_scale a power of two lifting max|w| into (512, 1024]) laid out [N][ldb / 32][2][32] halfs: per 32-element K slab
+ * the 32 hi halfs then the 32 lo halfs, i.e. one 128-byte line per (row, slab); activations are split while staged,
+ * after multiplication by the power of two a_scale (1 for ordinary activations, 1024 for softmax probabilities).
+ * ldb = K elements per row, % 32 == 0 (the buffer holds 2 * ldb halfs per row); Cin % 8 == 0, and % 32 == 0 when
+ * KH * KW > 1; |a_scale * x| must stay below 65504.
  * ------------------------------------------------------------------------------------------ */
 int64_t sgam_conv2d_f32x_workspace_bytes(const sgam_conv_desc *d);
 int sgam_conv2d_f32x_plan(const sgam_conv_desc *d, int32_t *bm, int32_t *bn, int32_t *ksplit);
@@ -112,7 +114,8 @@ int sgam_conv2d_stats_nhwc_f32x(const sgam_conv_desc *d, const float *x, float a
 int sgam_groupnorm_from_partials_f32(const float *x, const double *partial, int32_t nchunk, const float *gamma,
                                      const float *beta, float *y, int32_t B, int32_t HW, int32_t C, int32_t groups,
                                      float eps, int32_t fuse_swish, void *workspace, int64_t workspace_bytes, void *stream);
-/* split a row-major fp32 matrix [N][K] (row stride ld) into planes [2][N][K]: the B operand when it is an activation */
+/* split a row-major fp32 matrix [N][K] (row stride ld) into the B-operand layout [N][Kp / 32][2][32] halfs, Kp = K
+ * rounded up to 32 (zero filled): the B operand when it is an activation (ldb = Kp) */
 int sgam_split_rows_f32x(const float *x, void *planes, float scale, int32_t N, int32_t K, int32_t ld, void *stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -144,9 +144,8 @@ __global__ __launch_bounds__(256 * wk_of(BM, BN)) void conv_gemm_f32x_kernel(con
     const int n0 = by * BN;
 
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rwh = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, (int)p.w_plane_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rwl = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.w + p.w_plane_bytes), 0,
-                                                                         (int)p.w_plane_bytes, 0x00020000);
+    // B operand: [N][ldb / 32][2][32] halfs — the hi and the lo halves of a 32-element K slab share one 128-byte line
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, (int)p.w_plane_bytes, 0x00020000);
 
     const int it0 = bz * p.iters_per_split;
 #ifndef SGAM_XABLATE
@@ -193,7 +192,7 @@ __global__ __launch_bounds__(256 * wk_of(BM, BN)) void conv_gemm_f32x_kernel(con
 #pragma unroll
     for (int r = 0; r < BRW; ++r) {
         const int n = n0 + brow + 64 * r;
-        b_off[r] = n < p.N ? (unsigned)(n * p.ldb + c16 * 8) * 2u : 0xC0000000u;
+        b_off[r] = n < p.N ? (unsigned)(n * 2 * p.ldb + (c16 >> 2) * 64 + (c16 & 3) * 8) * 2u : 0xC0000000u;
     }
 
     const int taps = p.KH * p.KW;
@@ -227,12 +226,12 @@ __global__ __launch_bounds__(256 * wk_of(BM, BN)) void conv_gemm_f32x_kernel(con
             }
         }
         const bool kb_ok = live && (ch * XBK + c16 * 8) < p.Cin;
-        const unsigned koff = (unsigned)(tap * p.Cin + ch * XBK) * 2u;
+        const unsigned koff = (unsigned)(tap * p.Cin + ch * XBK) * 4u;      // 64 halfs (hi | lo) per 32-element slab
 #pragma unroll
         for (int r = 0; r < BRW; ++r) {
             const unsigned o = xsel(kb_ok, b_off[r] + koff, p.w_plane_bytes);
-            bh[st][r] = __builtin_amdgcn_raw_buffer_load_b128(rwh, (int)o, 0, 0);
-            bl[st][r] = __builtin_amdgcn_raw_buffer_load_b128(rwl, (int)o, 0, 0);
+            bh[st][r] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)o, 0, 0);
+            bl[st][r] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(o + 64u), 0, 0);
         }
         ++tap;
         if (++kx == p.KW) {
@@ -252,6 +251,10 @@ __global__ __launch_bounds__(256 * wk_of(BM, BN)) void conv_gemm_f32x_kernel(con
 #pragma unroll
         for (int r = 0; r < AR; ++r) {
             u32x2 hi, lo;
+            if (SGAM_XABLATE == 4) {
+                const u32x4 raw = __builtin_bit_cast(u32x4, areg[st][r]);
+                hi[0] = raw[0]; hi[1] = raw[1]; lo[0] = raw[2]; lo[1] = raw[3];
+            } else
             split4(ASCALE ? areg[st][r] * p.a_scale : areg[st][r], hi, lo);
             const int o = (row_in_pass + 32 * r) * XLD + col4 * 4;
             *reinterpret_cast<u32x2 *>(ah + o) = hi;
@@ -482,7 +485,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_f32x_kernel(const XParams p
     }
 }
 
-// [Cout][Cin][KH][KW] fp32 -> two fp16 planes [2][Cout_pad][KH*KW][Cin_pad] of scale * w (hi, lo), zero padded
+// [Cout][Cin][KH][KW] fp32 -> [Cout_pad][K / 32][2][32] halfs of scale * w, K = (tap, Cin_pad) with Cin_pad % 32 == 0:
+// per 32-element K slab the 32 hi halfs then the 32 lo halfs (one 128-byte line), zero padded
 __global__ void pack_weight_f32x_kernel(const float *w, unsigned short *o, int Cout, int Cin, int KH, int KW, int Cout_pad,
                                         int Cin_pad, float scale) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -496,21 +500,25 @@ __global__ void pack_weight_f32x_kernel(const float *w, unsigned short *o, int C
     if (n < Cout && c < Cin) v = w[((int64_t)n * Cin + c) * taps + t] * scale;
     const _Float16 h = (_Float16)v;
     const _Float16 l = (_Float16)(v - (float)h);
-    o[i] = __builtin_bit_cast(unsigned short, h);
-    o[total + i] = __builtin_bit_cast(unsigned short, l);
+    const int64_t k = (int64_t)t * Cin_pad + c;
+    const int64_t q = ((int64_t)n * taps * Cin_pad + (k >> 5) * 32) * 2 + (k & 31);
+    o[q] = __builtin_bit_cast(unsigned short, h);
+    o[q + 32] = __builtin_bit_cast(unsigned short, l);
 }
 
-// generic [N][K] fp32 matrix (row stride ld) -> planes [2][N][K] (the B operand of activation x activation GEMMs)
-__global__ void split_rows_f32x_kernel(const float *x, unsigned short *o, int N, int K, int ld, float scale) {
+// generic [N][K] fp32 matrix (row stride ld) -> [N][Kp / 32][2][32] halfs, Kp = K rounded up to 32 (zero filled): the B
+// operand of activation x activation GEMMs
+__global__ void split_rows_f32x_kernel(const float *x, unsigned short *o, int N, int K, int Kp, int ld, float scale) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t total = (int64_t)N * K;
+    const int64_t total = (int64_t)N * Kp;
     if (i >= total) return;
-    const int n = (int)(i / K), k = (int)(i - (int64_t)n * K);
-    const float v = x[(int64_t)n * ld + k] * scale;
+    const int n = (int)(i / Kp), k = (int)(i - (int64_t)n * Kp);
+    const float v = k < K ? x[(int64_t)n * ld + k] * scale : 0.f;
     const _Float16 h = (_Float16)v;
     const _Float16 l = (_Float16)(v - (float)h);
-    o[i] = __builtin_bit_cast(unsigned short, h);
-    o[total + i] = __builtin_bit_cast(unsigned short, l);
+    const int64_t q = ((int64_t)n * Kp + (k >> 5) * 32) * 2 + (k & 31);
+    o[q] = __builtin_bit_cast(unsigned short, h);
+    o[q + 32] = __builtin_bit_cast(unsigned short, l);
 }
 
 struct XPlan {
@@ -550,7 +558,8 @@ int xvalidate(const sgam_conv_desc *d) {
     if (d->Cin <= 0 || d->Cin % 8 != 0 || d->N % 4 != 0) return SGAM_EINVAL;
     if (d->KH <= 0 || d->KW <= 0 || d->stride <= 0) return SGAM_EINVAL;
     if (d->lda < d->Cin || d->lda % 4 != 0) return SGAM_EALIGN;
-    if (d->ldb < d->KH * d->KW * d->Cin || d->ldb % 8 != 0) return SGAM_EALIGN;
+    if (d->ldb < d->KH * d->KW * d->Cin || d->ldb % 32 != 0) return SGAM_EALIGN;          // whole 32-element K slabs per row
+    if (d->KH * d->KW > 1 && d->Cin % 32 != 0) return SGAM_EALIGN;                          // taps start on a slab boundary
     if (d->n_valid <= 0 || d->n_valid > d->N || d->ldc < d->n_valid) return SGAM_EINVAL;
     if (d->n_valid % 4 != 0 || d->ldc % 4 != 0 || d->ldr % 4 != 0) return SGAM_EALIGN;   // 16-byte epilogue accesses
     if (d->plan_bm != 0 || d->plan_bn != 0) {
@@ -628,8 +637,8 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
     p.gn_cpg = d->N / 32;
 
     const int64_t xb = (((int64_t)d->B * d->Hi * d->Wi - 1) * d->lda + d->Cin) * 4;
-    const int64_t wb = (int64_t)d->N * d->ldb * 2;   // one plane: [N][ldb] halfs, planes are contiguous
-    if (xb >= (1ll << 32) - 64 || wb >= (1ll << 31)) return SGAM_EINVAL;
+    const int64_t wb = (int64_t)d->N * d->ldb * 4;   // [N][ldb / 32][2][32] halfs
+    if (xb >= (1ll << 32) - 64 || wb >= (1ll << 32) - 256) return SGAM_EINVAL;
     p.x_bytes = (unsigned)xb; p.w_plane_bytes = (unsigned)wb;
     if (pl.ksplit > 1) {
         const int64_t need = (int64_t)pl.ksplit * p.M * p.N * (int64_t)sizeof(float);
@@ -666,7 +675,7 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
 
 extern "C" int sgam_pack_conv_weight_f32x(const float *w_oihw, void *w_planes, float w_scale, int32_t Cout, int32_t Cin,
                                           int32_t KH, int32_t KW, int32_t Cout_pad, int32_t Cin_pad, void *stream) {
-    if (!w_oihw || !w_planes || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 || Cout_pad < Cout || Cin_pad < Cin) return SGAM_EINVAL;
+    if (!w_oihw || !w_planes || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 || Cout_pad < Cout || Cin_pad < Cin || Cin_pad % 32) return SGAM_EINVAL;
     const int64_t total = (int64_t)Cout_pad * KH * KW * Cin_pad;
     hipLaunchKernelGGL(pack_weight_f32x_kernel, dim3(sgam_cdiv(total, 256)), dim3(256), 0, sgam_stream(stream), w_oihw,
                        (unsigned short *)w_planes, Cout, Cin, KH, KW, Cout_pad, Cin_pad, w_scale);
@@ -676,9 +685,10 @@ extern "C" int sgam_pack_conv_weight_f32x(const float *w_oihw, void *w_planes, f
 
 extern "C" int sgam_split_rows_f32x(const float *x, void *planes, float scale, int32_t N, int32_t K, int32_t ld, void *stream) {
     if (!x || !planes || N <= 0 || K <= 0 || ld < K) return SGAM_EINVAL;
-    const int64_t total = (int64_t)N * K;
+    const int Kp = (K + 31) / 32 * 32;
+    const int64_t total = (int64_t)N * Kp;
     hipLaunchKernelGGL(split_rows_f32x_kernel, dim3(sgam_cdiv(total, 256)), dim3(256), 0, sgam_stream(stream), x,
-                       (unsigned short *)planes, N, K, ld, scale);
+                       (unsigned short *)planes, N, K, Kp, ld, scale);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
 }
