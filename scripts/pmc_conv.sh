@@ -15,6 +15,8 @@ run sq2 GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CON
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 run tcc TCC_HIT_sum TCC_MISS_sum
+run sq3 SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_WAIT_INST_ANY
+run sq4 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_MEM_VIOLATIONS SQ_INSTS_LDS
 find $OUT -name "*.csv" | head -20
 python3 - <<'PY'
 import csv,glob,os,collections
@@ -26,6 +28,6 @@ for f in sorted(glob.glob(out+"/*/**/*counter_collection.csv", recursive=True)):
         agg[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     print("==",f.split("/pmc/")[1])
     for k,v in agg.items():
-        if "conv_gemm" in k:
+        if "conv_gemm" in k or "conv3x3" in k:
             print(" ",k, {c:(sum(x)/len(x)) for c,x in v.items()}, "n=",len(next(iter(v.values()))))
 PY

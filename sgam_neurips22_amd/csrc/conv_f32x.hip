@@ -56,6 +56,12 @@ struct XParams {
 #ifndef SGAM_XPF_SMALL
 #define SGAM_XPF_SMALL 2
 #endif
+#ifndef SGAM_XSB
+#define SGAM_XSB 1
+#endif
+#ifndef SGAM_XPRIO
+#define SGAM_XPRIO 1
+#endif
 #ifndef SGAM_XBK_SMALL
 #define SGAM_XBK_SMALL 64
 #endif
@@ -114,6 +120,106 @@ __device__ __forceinline__ void xcd_block(const XParams &p, int &bx, int &by, in
     const unsigned t = Lp / (unsigned)p.gx;
     by = (int)(t % (unsigned)p.gy);
     bz = (int)(t / (unsigned)p.gy);
+}
+
+// ---- epilogue shared by the tile kernels: each wavefront transposes its (32 TM) x (32 TN) fp32 tile through a private
+// LDS region so that a lane ends up with 4 CONSECUTIVE output channels of one pixel: residual comes in and the result
+// leaves as 16-byte accesses, 16 lanes covering a 256-byte row segment (the MFMA D layout alone gives 4-byte accesses:
+// 64 store + 64 load instructions per 32x32 tile instead of 4 + 4).  The caller guarantees every wavefront is done
+// reading the operand LDS.  rowmap(tile row) -> global output pixel index.
+template <int BM, int BN, class RowMap>
+__device__ __forceinline__ void xepilogue(const XParams &p, f32x16 (&acc)[BM / 64][BN / 64], float *smem_f, int wave, int lane,
+                                          int bx, int bz, int n0, RowMap rowmap) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int WM = 32 * TM, WN = 32 * TN, LDR = WN + 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    float *region = smem_f + wave * (WM * LDR);
+    const bool to_ws = p.ws != nullptr;
+    const int n_lim = to_ws ? p.N : p.n_valid;
+    const int ldo = to_ws ? p.N : p.ldc;
+    float *obase = to_ws ? p.ws + (int64_t)bz * p.M * p.N : p.out;
+    const unsigned o_bytes = (unsigned)(((int64_t)(p.M - 1) * ldo + n_lim) * 4);
+    const unsigned r_bytes = (p.res && !to_ws) ? (unsigned)(((int64_t)(p.M - 1) * p.ldr + p.n_valid) * 4) : 0u;
+    const unsigned bias_bytes = (p.bias && !to_ws) ? (unsigned)((p.bias_per_row ? p.M : p.N) * 4) : 0u;
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)obase, 0, (int)o_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void *)p.res, 0, (int)r_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)p.bias, 0, (int)bias_bytes, 0x00020000);
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    const float inv = to_ws ? 1.0f : p.inv_w_scale;
+    const int col_l = lane & 31;
+    const int row_h = 4 * (lane >> 5);
+    const int wn0 = n0 + wn * (BN / 2);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = wn0 + j * 32 + col_l;
+            const float bias_n = (p.bias_per_row || to_ws) ? 0.f
+                                     : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                           rb, (int)xsel(n < n_lim, (unsigned)n * 4u, OOB), 0, 0));
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                region[(i * 32 + (e & 3) + 8 * (e >> 2) + row_h) * LDR + j * 32 + col_l] = acc[i][j][e] * inv + bias_n;
+        }
+    // read back row-major: 16 lanes x float4 cover 64 columns; 4 rows per pass (wave-private region: no barrier)
+    constexpr int C4 = WN / 4;          // float4 chunks per row: 8 or 16
+    constexpr int RPP = 64 / C4;        // rows per pass: 8 or 4
+    const int c4 = lane % C4, rr0 = lane / C4;
+    const int n4 = wn0 + c4 * 4;
+    const bool n_ok = n4 < n_lim;       // n_valid is a multiple of 4
+    float gs = 0.f, gss = 0.f;   // this lane's share of the output statistics (4 channels x WM/RPP pixels)
+#pragma unroll
+    for (int pass = 0; pass < WM / RPP; ++pass) {
+        const int row = rr0 + pass * RPP;
+        const int m = rowmap(wm * (BM / 2) + row);       // global output pixel of this tile row (>= M: outside)
+        const bool ok = n_ok && m < p.M;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(region + row * LDR + c4 * 4);
+        const f32x4 rv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                       rr, (int)xsel(ok, (unsigned)(m * p.ldr + n4) * 4u, OOB), 0, 0));
+        if (p.bias_per_row) {
+            const float bm = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                           rb, (int)xsel(ok, (unsigned)m * 4u, OOB), 0, 0));
+            v += bm;
+        }
+        v += rv;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro,
+                                               (int)xsel(ok, (unsigned)(m * ldo + n4) * 4u, OOB), 0, 0);
+        if (ok) {
+            gs += (v[0] + v[1]) + (v[2] + v[3]);
+            gss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
+    }
+    if (p.gn_partial && !to_ws) {
+        // GroupNorm statistics of the tensor just written, for free: a float4 never straddles a group (cpg is a
+        // multiple of 4).  Lanes -> LDS, then one lane per group of this wavefront's column range folds, in a fixed
+        // order and in fp64, the lanes that hold that group; chunk index = (m-tile, row-half) of the output.
+        float *sl = region;                   // reuse the wave-private region: [64 lanes][2]
+        sl[lane * 2] = gs;
+        sl[lane * 2 + 1] = gss;
+        const int c4_per_group = p.gn_cpg / 4;
+        const int groups_here = C4 / c4_per_group;       // groups inside this wavefront's WN columns
+        if (lane < groups_here) {
+            double ds = 0.0, dss = 0.0;
+            for (int r = 0; r < RPP; ++r)
+                for (int k = 0; k < c4_per_group; ++k) {
+                    const int l = r * C4 + lane * c4_per_group + k;
+                    ds += (double)sl[l * 2];
+                    dss += (double)sl[l * 2 + 1];
+                }
+            const int g = (wn0 / p.gn_cpg) + lane;
+            const int groups = p.N / p.gn_cpg;
+            if (g < groups) {
+                const int chunk = bx * 2 + wm;          // every output row belongs to exactly one chunk
+                const int hw = p.Ho * p.Wo;
+                const int b = (bx * BM) / hw;                    // host guarantees a tile never straddles two images
+                const int chunks_per_b = ((hw + BM - 1) / BM) * 2;
+                const int cb = chunk - b * chunks_per_b;
+                double *o = p.gn_partial + (((int64_t)b * chunks_per_b + cb) * groups + g) * 2;
+                o[0] = ds;
+                o[1] = dss;
+            }
+        }
+    }
 }
 
 template <int BM, int BN, bool UPS, bool ASCALE>
@@ -308,6 +414,9 @@ __global__ __launch_bounds__(256 * wk_of(BM, BN)) void conv_gemm_f32x_kernel(con
                     if (kq == (KS / WK) / 2) {
                         store_lds(nst, buf ^ 1);                      // slab it+1 -> the other LDS buffer
                         issue_loads(nst, it + 1 + PF < it1);          // slab it+1+PF -> the freed register stage
+#if SGAM_XSB
+                        __builtin_amdgcn_sched_barrier(0);            // do not let the scheduler sink the prefetch
+#endif
                     }
                     u32x4 fah[TM], fal[TM], fbh[TN], fbl[TN];
 #pragma unroll
@@ -346,11 +455,7 @@ __global__ __launch_bounds__(256 * wk_of(BM, BN)) void conv_gemm_f32x_kernel(con
         }
     }
 
-    // ---- epilogue: each wavefront transposes its (32 TM) x (32 TN) fp32 tile through a private LDS region so that a
-    // lane ends up with 4 CONSECUTIVE output channels of one pixel: residual comes in and the result leaves as
-    // 16-byte accesses, 16 lanes covering a 256-byte row segment (the MFMA D layout alone gives 4-byte accesses:
-    // 64 store + 64 load instructions per 32x32 tile instead of 4 + 4).  The loop's final barrier already
-    // guarantees every wavefront is done reading the operand slabs.
+    // ---- epilogue (the loop's final barrier guarantees every wavefront is done reading the operand slabs)
     if constexpr (SEPACC) acc[0][0] += accs[0];
     constexpr int WM = 32 * TM, WN = 32 * TN, LDR = WN + 4;
     static_assert(4 * WM * LDR * 4 <= 2 * STAGE * 2, "epilogue staging must fit the operand LDS");
@@ -377,93 +482,203 @@ __global__ __launch_bounds__(256 * wk_of(BM, BN)) void conv_gemm_f32x_kernel(con
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] += xch[((i * TN + j) * 16 + e) * 64 + lane];
     }
-    float *region = reinterpret_cast<float *>(smem) + wave * (WM * LDR);
-    const bool to_ws = p.ws != nullptr;
-    const int n_lim = to_ws ? p.N : p.n_valid;
-    const int ldo = to_ws ? p.N : p.ldc;
-    float *obase = to_ws ? p.ws + (int64_t)bz * p.M * p.N : p.out;
-    const unsigned o_bytes = (unsigned)(((int64_t)(p.M - 1) * ldo + n_lim) * 4);
-    const unsigned r_bytes = (p.res && !to_ws) ? (unsigned)(((int64_t)(p.M - 1) * p.ldr + p.n_valid) * 4) : 0u;
-    const unsigned bias_bytes = (p.bias && !to_ws) ? (unsigned)((p.bias_per_row ? p.M : p.N) * 4) : 0u;
-    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)obase, 0, (int)o_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void *)p.res, 0, (int)r_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)p.bias, 0, (int)bias_bytes, 0x00020000);
-    constexpr unsigned OOB = 0xFFFFFFF0u;
-    const float inv = to_ws ? 1.0f : p.inv_w_scale;
-    const int col_l = lane & 31;
-    const int row_h = 4 * (lane >> 5);
-    const int wm0 = m0 + wm * (BM / 2), wn0 = n0 + wn * (BN / 2);
+    xepilogue<BM, BN>(p, acc, reinterpret_cast<float *>(smem), wave, lane, bx, bz, n0, [&](int row) { return m0 + row; });
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolution with a HALO-staged A operand (the bulk of the network's FLOPs).
+// The generic kernel above fetches, splits and stages the A tile once per filter tap: nine global->LDS passes over
+// (almost) the same pixels for every 32-channel slab.  Here the workgroup owns an 8 x 16 patch of output pixels; per
+// slab it stages the 10 x 18 halo of that patch ONCE (global loads, the fp32 -> hi/lo split and the LDS writes of the A
+// side drop 6.4x) and the nine taps read their MFMA A fragments from it at a wavefront-uniform row offset
+// (ky * 18 + kx); consecutive lanes still read consecutive 80-byte rows, so ds_read_b128 stays conflict-free.  The B
+// (weight) tile is double-buffered per tap exactly as in the generic kernel.  The halo of the next slab is prefetched
+// into registers a whole slab ahead and swapped in behind one extra barrier per nine taps.
+template <int BN>
+__global__ __launch_bounds__(256) void conv3x3_f32x_halo_kernel(const XParams p) {
+    constexpr int BM = 128, TH = 8, TW = 16, HWID = TW + 2, HR = (TH + 2) * HWID;   // 180 halo pixels
+    constexpr int XBK = 32, XLD = XBK + 8;
+    constexpr int TM = BM / 64, TN = BN / 64, BRW = BN / 64;
+    constexpr int HPL = HR * XLD;                       // halfs per halo plane
+    constexpr int PLANE_B = BN * XLD;
+    constexpr int NH = (HR * 8 + 255) / 256;            // float4 halo loads per thread (6)
+    constexpr int OP_BYTES = (2 * HPL + 4 * PLANE_B) * 2;
+    constexpr int EPI_BYTES = 4 * (32 * TM) * (32 * TN + 4) * 4;
+    constexpr int SM_BYTES = OP_BYTES > EPI_BYTES ? OP_BYTES : EPI_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned short smem[SM_BYTES / 2];
+    unsigned short *halo = smem;                        // [2 planes][HR][XLD]
+    unsigned short *bsm = smem + 2 * HPL;               // [2 stages][2 planes][BN][XLD]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int bx, by, bz;
+    xcd_block(p, bx, by, bz);
+    const int n0 = by * BN;
+    const int tiles_x = p.Wo / TW, tiles_img = tiles_x * (p.Ho / TH);
+    const int b = bx / tiles_img;
+    const int t_img = bx - b * tiles_img;
+    const int ty0 = (t_img / tiles_x) * TH, tx0 = (t_img % tiles_x) * TW;
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, (int)p.w_plane_bytes, 0x00020000);
+
+    const int it0 = bz * p.iters_per_split;
+    const int it1 = min(p.iters_total, it0 + p.iters_per_split);
+
+    // halo staging: float4 index tid + 256 j -> (halo pixel, float4 column); byte offset of channel 0, or out of range
+    unsigned h_off[NH];
+    int h_lds[NH];
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+        const int idx = tid + 256 * j;
+        const int row = idx >> 3, col4 = idx & 7;
+        const int hy = row / HWID, hx = row - hy * HWID;
+        const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
+        const bool ok = row < HR && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        h_off[j] = ok ? (unsigned)(((b * p.Hi + iy) * p.Wi + ix) * p.lda + col4 * 4) * 4u : 0xFFFFFFFFu;
+        h_lds[j] = row < HR ? row * XLD + col4 * 4 : -1;
+    }
+    const int c16 = tid & 3, brow = tid >> 2;
+    unsigned b_off[BRW];
+#pragma unroll
+    for (int r = 0; r < BRW; ++r) {
+        const int n = n0 + brow + 64 * r;
+        b_off[r] = n < p.N ? (unsigned)(n * 2 * p.ldb + c16 * 8) * 2u : 0xC0000000u;
+    }
+
+    f32x4 hreg[NH];
+    u32x4 bh[BRW], bl[BRW];
+    auto hload = [&](int ch) {
+        const unsigned coff = (unsigned)ch * (XBK * 4u);
+#pragma unroll
+        for (int j = 0; j < NH; ++j) {
+            const unsigned o = h_off[j] == 0xFFFFFFFFu ? p.x_bytes : h_off[j] + coff;
+            hreg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)o, 0, 0));
+        }
+    };
+    auto hstore = [&]() {
+#pragma unroll
+        for (int j = 0; j < NH; ++j) {
+            u32x2 hi, lo;
+            split4(hreg[j], hi, lo);
+            if (h_lds[j] >= 0) {
+                *reinterpret_cast<u32x2 *>(halo + h_lds[j]) = hi;
+                *reinterpret_cast<u32x2 *>(halo + HPL + h_lds[j]) = lo;
+            }
+        }
+    };
+    auto bload = [&](int tap, int ch, bool live) {
+        const unsigned koff = (unsigned)(tap * p.Cin + ch * XBK) * 4u;
+#pragma unroll
+        for (int r = 0; r < BRW; ++r) {
+            const unsigned o = xsel(live, b_off[r] + koff, p.w_plane_bytes);
+            bh[r] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)o, 0, 0);
+            bl[r] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(o + 64u), 0, 0);
+        }
+    };
+    auto bstore = [&](int buf) {
+        unsigned short *bhp = bsm + buf * 2 * PLANE_B;
+#pragma unroll
+        for (int r = 0; r < BRW; ++r) {
+            const int o = (brow + 64 * r) * XLD + c16 * 8;
+            *reinterpret_cast<u32x4 *>(bhp + o) = bh[r];
+            *reinterpret_cast<u32x4 *>(bhp + PLANE_B + o) = bl[r];
+        }
+    };
+
+    f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = wn0 + j * 32 + col_l;
-            const float bias_n = (p.bias_per_row || to_ws) ? 0.f
-                                     : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                           rb, (int)xsel(n < n_lim, (unsigned)n * 4u, OOB), 0, 0));
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e)
-                region[(i * 32 + (e & 3) + 8 * (e >> 2) + row_h) * LDR + j * 32 + col_l] = acc[i][j][e] * inv + bias_n;
-        }
-    // read back row-major: 16 lanes x float4 cover 64 columns; 4 rows per pass (wave-private region: no barrier)
-    constexpr int C4 = WN / 4;          // float4 chunks per row: 8 or 16
-    constexpr int RPP = 64 / C4;        // rows per pass: 8 or 4
-    const int c4 = lane % C4, rr0 = lane / C4;
-    const int n4 = wn0 + c4 * 4;
-    const bool n_ok = n4 < n_lim;       // n_valid is a multiple of 4
-    float gs = 0.f, gss = 0.f;   // this lane's share of the output statistics (4 channels x WM/RPP pixels)
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int frag_row = lane & 31;
+    const int frag_k = (lane >> 5) * 8;
+    int a_base[TM];          // halo row of this lane's fragment rows at tap (0, 0), in halfs
 #pragma unroll
-    for (int pass = 0; pass < WM / RPP; ++pass) {
-        const int row = rr0 + pass * RPP;
-        const int m = wm0 + row;
-        const bool ok = n_ok && m < p.M;
-        f32x4 v = *reinterpret_cast<const f32x4 *>(region + row * LDR + c4 * 4);
-        const f32x4 rv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                       rr, (int)xsel(ok, (unsigned)(m * p.ldr + n4) * 4u, OOB), 0, 0));
-        if (p.bias_per_row) {
-            const float bm = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                           rb, (int)xsel(ok, (unsigned)m * 4u, OOB), 0, 0));
-            v += bm;
-        }
-        v += rv;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro,
-                                               (int)xsel(ok, (unsigned)(m * ldo + n4) * 4u, OOB), 0, 0);
-        if (ok) {
-            gs += (v[0] + v[1]) + (v[2] + v[3]);
-            gss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-        }
+    for (int i = 0; i < TM; ++i) {
+        const int r = wm * (BM / 2) + i * 32 + frag_row;
+        a_base[i] = ((r >> 4) * HWID + (r & 15)) * XLD + frag_k;
     }
-    if (p.gn_partial && !to_ws) {
-        // GroupNorm statistics of the tensor just written, for free: a float4 never straddles a group (cpg is a
-        // multiple of 4).  Lanes -> LDS, then one lane per group of this wavefront's column range folds, in a fixed
-        // order and in fp64, the lanes that hold that group; chunk index = (m-tile, row-half) of the output.
-        float *sl = region;                   // reuse the wave-private region: [64 lanes][2]
-        sl[lane * 2] = gs;
-        sl[lane * 2 + 1] = gss;
-        const int c4_per_group = p.gn_cpg / 4;
-        const int groups_here = C4 / c4_per_group;       // groups inside this wavefront's WN columns
-        if (lane < groups_here) {
-            double ds = 0.0, dss = 0.0;
-            for (int r = 0; r < RPP; ++r)
-                for (int k = 0; k < c4_per_group; ++k) {
-                    const int l = r * C4 + lane * c4_per_group + k;
-                    ds += (double)sl[l * 2];
-                    dss += (double)sl[l * 2 + 1];
-                }
-            const int g = (wn0 / p.gn_cpg) + lane;
-            const int groups = p.N / p.gn_cpg;
-            if (g < groups) {
-                const int chunk = bx * 2 + wm;          // every output row belongs to exactly one chunk
-                const int hw = p.Ho * p.Wo;
-                const int b = m0 / hw;                           // host guarantees a tile never straddles two images
-                const int chunks_per_b = ((hw + BM - 1) / BM) * 2;
-                const int cb = chunk - b * chunks_per_b;
-                double *o = p.gn_partial + (((int64_t)b * chunks_per_b + cb) * groups + g) * 2;
-                o[0] = ds;
-                o[1] = dss;
+
+    int ch = it0 / 9;
+    int tap = it0 - ch * 9;
+    hload(ch);
+    bload(tap, ch, it0 < it1);
+    hstore();
+    bstore(0);
+    if ((ch + 1) * 9 < it1) hload(ch + 1);              // next slab's halo: in flight for the whole slab
+    __syncthreads();
+
+    for (int it = it0; it < it1; ++it) {
+        const int buf = (it - it0) & 1;
+        int ntap = tap + 1, nch = ch;
+        if (ntap == 9) {
+            ntap = 0;
+            ++nch;
+        }
+        if (SGAM_XABLATE != 11 && SGAM_XABLATE != 12) bload(ntap, nch, it + 1 < it1);
+#if SGAM_XSB
+        __builtin_amdgcn_sched_barrier(0);      // keep the prefetch HERE: the scheduler otherwise sinks the loads to their use
+#endif
+        const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+        const unsigned short *ah = halo + (ky * HWID + kx) * XLD;
+        const unsigned short *bhp = bsm + buf * 2 * PLANE_B + (wn * (BN / 2) + frag_row) * XLD + frag_k;
+        // both k-steps' fragments are requested up front (16 ds_read_b128 in flight); the MFMA clusters run at raised
+        // priority so that the two workgroups sharing a SIMD fall out of phase (one multiplies while the other reads)
+        u32x4 fah[2][TM], fal[2][TM], fbh[2][TN], fbl[2][TN];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                fah[kk][i] = *reinterpret_cast<const u32x4 *>(ah + a_base[i] + kk * 16);
+                fal[kk][i] = *reinterpret_cast<const u32x4 *>(ah + HPL + a_base[i] + kk * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                fbh[kk][j] = *reinterpret_cast<const u32x4 *>(bhp + j * 32 * XLD + kk * 16);
+                fbl[kk][j] = *reinterpret_cast<const u32x4 *>(bhp + PLANE_B + j * 32 * XLD + kk * 16);
             }
         }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            if (kk == 1 && SGAM_XABLATE != 12) bstore(buf ^ 1);
+#if SGAM_XPRIO
+            __builtin_amdgcn_s_setprio(SGAM_XPRIO);
+#endif
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (SGAM_XABLATE == 13) {
+                        acc[i][j][0] += __builtin_bit_cast(float, fal[kk][i][0] ^ fbh[kk][j][0] ^ fah[kk][i][1] ^ fbl[kk][j][1]);
+                        continue;
+                    }
+                    acc[i][j] = mfma16(fal[kk][i], fbh[kk][j], acc[i][j]);
+                    acc[i][j] = mfma16(fah[kk][i], fbl[kk][j], acc[i][j]);
+                    acc[i][j] = mfma16(fah[kk][i], fbh[kk][j], acc[i][j]);
+                }
+#if SGAM_XPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
+        }
+        if (SGAM_XABLATE != 14) __syncthreads();
+        if (ntap == 0 && it + 1 < it1 && SGAM_XABLATE != 15) {                 // slab boundary: every wavefront is done with the old halo
+            hstore();
+            if ((nch + 1) * 9 < it1) hload(nch + 1);
+            __syncthreads();
+        }
+        tap = ntap;
+        ch = nch;
     }
+
+    xepilogue<BM, BN>(p, acc, reinterpret_cast<float *>(smem), wave, lane, bx, bz, n0, [&](int row) {
+        return (b * p.Ho + ty0 + (row >> 4)) * p.Wo + tx0 + (row & 15);
+    });
 }
 
 // fixed-order split-K reduction (partials are still weight-scaled) + un-scale + bias + residual
@@ -660,7 +875,14 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
     } while (0)
     if (p.ups && a_scale != 1.0f) return SGAM_EINVAL;
     if (d->KH * d->KW > 32) return SGAM_EINVAL;   // tap validity mask is 32 bits
-    if (pl.bm == 128 && pl.bn == 128) XLAUNCH(128, 128);
+    static const int halo_on = [] { const char *e = getenv("SGAM_F32X_HALO"); return (e && e[0] == '0') ? 0 : 1; }();
+    const bool halo = halo_on && pl.bm == 128 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 &&
+                      !d->upsample2x && d->Ho == d->Hi && d->Wo == d->Wi && d->Ho % 8 == 0 && d->Wo % 16 == 0 &&
+                      d->Cin % 32 == 0 && a_scale == 1.0f;
+    if (halo) {
+        static const int dyn = [] { const char *e = getenv("SGAM_XDYN_LDS"); return e ? atoi(e) : 0; }();   // occupancy experiments
+        hipLaunchKernelGGL((conv3x3_f32x_halo_kernel<128>), grid, dim3(256), dyn, s, p);   // pl.bm == 128 implies pl.bn == 128
+    } else if (pl.bm == 128 && pl.bn == 128) XLAUNCH(128, 128);
     else if (pl.bm == 64 && pl.bn == 128) XLAUNCH(64, 128);
     else XLAUNCH(64, 64);
 #undef XLAUNCH
@@ -691,4 +913,14 @@ extern "C" int sgam_split_rows_f32x(const float *x, void *planes, float scale, i
                        (unsigned short *)planes, N, K, Kp, ld, scale);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
+}
+
+// diagnostic (not part of the ABI header): resident workgroups per CU of the three tile variants
+extern "C" int sgam_debug_f32x_occupancy(int which) {
+    int n = -1;
+    hipError_t e;
+    if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_gemm_f32x_kernel<128, 128, false, false>, 256, 0);
+    else if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_gemm_f32x_kernel<64, 128, false, false>, 256, 0);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_gemm_f32x_kernel<64, 64, false, false>, 256 * wk_of(64, 64), 0);
+    return e == hipSuccess ? n : -(int)e;
 }
