@@ -114,6 +114,20 @@ int sgam_conv2d_stats_nhwc_f32x(const sgam_conv_desc *d, const float *x, float a
 int sgam_groupnorm_from_partials_f32(const float *x, const double *partial, int32_t nchunk, const float *gamma,
                                      const float *beta, float *y, int32_t B, int32_t HW, int32_t C, int32_t groups,
                                      float eps, int32_t fuse_swish, void *workspace, int64_t workspace_bytes, void *stream);
+/* GroupNorm(+swish) of the INPUT fused into the operand staging: x is normalised with the per-(image, channel)
+ * {scale, shift} table gn_scale_shift [B][Cin][2] (sgam_groupnorm_stats_nhwc_f32 or
+ * sgam_groupnorm_table_from_partials_f32) while the 3x3 kernel stages each channel slab of its input patch — once per
+ * slab, shared by the nine taps — so no normalised copy of the activation is ever written.  Zero padding applies to
+ * the normalised tensor, as in Conv2d(GroupNorm(x)).  Available when sgam_conv2d_f32x_gn_fusable(d) == 1 (3x3,
+ * stride 1, pad 1, no upsampling, Ho % 8 == 0, Wo % 16 == 0, Cin % 32 == 0, a 128-row tile plan); gn_partial may be
+ * NULL or as in sgam_conv2d_stats_nhwc_f32x. */
+int32_t sgam_conv2d_f32x_gn_fusable(const sgam_conv_desc *d);
+int sgam_conv2d_gn_nhwc_f32x(const sgam_conv_desc *d, const float *x, const float *gn_scale_shift, int32_t gn_swish,
+                             const void *w_planes, float w_scale, const float *bias, const float *residual, float *out,
+                             double *gn_partial, void *workspace, int64_t workspace_bytes, void *stream);
+int sgam_groupnorm_table_from_partials_f32(const double *partial, int32_t nchunk, const float *gamma, const float *beta,
+                                           float *scale_shift, int32_t B, int32_t HW, int32_t C, int32_t groups, float eps,
+                                           void *stream);
 /* split a row-major fp32 matrix [N][K] (row stride ld) into the B-operand layout [N][Kp / 32][2][32] halfs, Kp = K
  * rounded up to 32 (zero filled): the B operand when it is an activation (ldb = Kp) */
 int sgam_split_rows_f32x(const float *x, void *planes, float scale, int32_t N, int32_t K, int32_t ld, void *stream);

@@ -37,6 +37,11 @@ PROTOTYPES = {
                                             c_i64, c_vp]),
     "sgam_groupnorm_from_partials_f32": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32,
                                                  c_i32, c_vp, c_i64, c_vp]),
+    "sgam_conv2d_f32x_gn_fusable": (c_i32, [ctypes.POINTER(ConvDesc)]),
+    "sgam_conv2d_gn_nhwc_f32x": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_i32, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp,
+                                         c_vp, c_i64, c_vp]),
+    "sgam_groupnorm_table_from_partials_f32": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32,
+                                                       c_vp]),
     "sgam_pack_conv_weight_f32x": (c_i32, [c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "sgam_split_rows_f32x": (c_i32, [c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_vp]),
     "sgam_conv2d_h16_workspace_bytes": (c_i64, [ctypes.POINTER(ConvDesc)]),

@@ -44,6 +44,8 @@ struct XParams {
     int M, ksplit, iters_total, iters_per_split;
     int gx, gy, xcd_swizzle;   // logical grid (M tiles, N tiles); the launch is 1-D, see xcd_block()
     unsigned x_bytes, w_plane_bytes;
+    const float *gn_tab; // optional (halo kernel): [B][Cin][2] scale/shift of a GroupNorm applied to x while it is staged
+    int gn_swish;        // ... followed by swish
     double *gn_partial;  // optional: per-(row-half of the tile, group) {sum, sumsq} of the OUTPUT for the next GroupNorm
     int gn_cpg;          // channels per group of that GroupNorm (N / 32)
     float inv_w_scale;   // 1 / (a_scale * w_scale), an exact power of two
@@ -494,7 +496,10 @@ __global__ __launch_bounds__(256 * wk_of(BM, BN)) void conv_gemm_f32x_kernel(con
 // (ky * 18 + kx); consecutive lanes still read consecutive 80-byte rows, so ds_read_b128 stays conflict-free.  The B
 // (weight) tile is double-buffered per tap exactly as in the generic kernel.  The halo of the next slab is prefetched
 // into registers a whole slab ahead and swapped in behind one extra barrier per nine taps.
-template <int BN>
+// GN: the input is GroupNorm(+swish)-ed on the fly from a per-(image, channel) scale/shift table while the halo is
+// staged — once per slab, not once per tap, so the normalisation costs 1/6 of what it does in a per-tap prologue and
+// the stand-alone normalise pass (a read and a write of the whole activation) disappears.  Padding pixels stay 0.
+template <int BN, bool GN>
 __global__ __launch_bounds__(256) void conv3x3_f32x_halo_kernel(const XParams p) {
     constexpr int BM = 128, TH = 8, TW = 16, HWID = TW + 2, HR = (TH + 2) * HWID;   // 180 halo pixels
     constexpr int XBK = 32, XLD = XBK + 8;
@@ -549,6 +554,7 @@ __global__ __launch_bounds__(256) void conv3x3_f32x_halo_kernel(const XParams p)
     }
 
     f32x4 hreg[NH];
+    f32x4 gt0, gt1;          // GN: {scale, shift} of this thread's 4 channels (its float4 column is the same for every j)
     u32x4 bh[BRW], bl[BRW];
     auto hload = [&](int ch) {
         const unsigned coff = (unsigned)ch * (XBK * 4u);
@@ -557,11 +563,29 @@ __global__ __launch_bounds__(256) void conv3x3_f32x_halo_kernel(const XParams p)
             const unsigned o = h_off[j] == 0xFFFFFFFFu ? p.x_bytes : h_off[j] + coff;
             hreg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)o, 0, 0));
         }
+        if constexpr (GN) {
+            const float *t = p.gn_tab + ((int64_t)b * p.Cin + ch * XBK + (tid & 7) * 4) * 2;
+            gt0 = *reinterpret_cast<const f32x4 *>(t);          // s0 h0 s1 h1
+            gt1 = *reinterpret_cast<const f32x4 *>(t + 4);      // s2 h2 s3 h3
+        }
     };
     auto hstore = [&]() {
 #pragma unroll
         for (int j = 0; j < NH; ++j) {
             u32x2 hi, lo;
+            if constexpr (GN) {
+                f32x4 v = hreg[j];
+                v[0] = v[0] * gt0[0] + gt0[1];
+                v[1] = v[1] * gt0[2] + gt0[3];
+                v[2] = v[2] * gt1[0] + gt1[1];
+                v[3] = v[3] * gt1[2] + gt1[3];
+                if (p.gn_swish) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = sgam_swish(v[e]);
+                }
+                if (h_off[j] == 0xFFFFFFFFu) v = f32x4{0.f, 0.f, 0.f, 0.f};     // zero padding is applied AFTER the norm
+                hreg[j] = v;
+            }
             split4(hreg[j], hi, lo);
             if (h_lds[j] >= 0) {
                 *reinterpret_cast<u32x2 *>(halo + h_lds[j]) = hi;
@@ -807,7 +831,30 @@ extern "C" int sgam_conv2d_f32x_plan(const sgam_conv_desc *d, int32_t *bm, int32
 
 static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale, const void *w_planes, float w_scale,
                           const float *bias, const float *residual, float *out, double *gn_partial, void *workspace,
-                          int64_t workspace_bytes, void *stream);
+                          int64_t workspace_bytes, void *stream, const float *gn_tab = nullptr, int gn_swish = 0);
+
+// the halo-staged 3x3 kernel takes: 3x3 / stride 1 / pad 1, no upsampling, 8 x 16 output patches, whole 32-channel slabs
+static bool halo_eligible(const sgam_conv_desc *d, const XPlan &pl, float a_scale) {
+    static const int halo_on = [] { const char *e = getenv("SGAM_F32X_HALO"); return (e && e[0] == '0') ? 0 : 1; }();
+    return halo_on && pl.bm == 128 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 &&
+           !d->upsample2x && d->Ho == d->Hi && d->Wo == d->Wi && d->Ho % 8 == 0 && d->Wo % 16 == 0 && d->Cin % 32 == 0 &&
+           a_scale == 1.0f;
+}
+
+extern "C" int32_t sgam_conv2d_f32x_gn_fusable(const sgam_conv_desc *d) {
+    if (xvalidate(d) != SGAM_OK) return 0;
+    return halo_eligible(d, make_xplan(d), 1.0f) ? 1 : 0;
+}
+
+extern "C" int sgam_conv2d_gn_nhwc_f32x(const sgam_conv_desc *d, const float *x, const float *gn_scale_shift, int32_t gn_swish,
+                                        const void *w_planes, float w_scale, const float *bias, const float *residual,
+                                        float *out, double *gn_partial, void *workspace, int64_t workspace_bytes,
+                                        void *stream) {
+    if (!gn_scale_shift || !sgam_aligned16(gn_scale_shift) || sgam_conv2d_f32x_gn_fusable(d) != 1) return SGAM_EINVAL;
+    if (gn_partial && sgam_conv2d_f32x_stats_chunks(d) <= 0) return SGAM_EINVAL;
+    return conv_f32x_impl(d, x, 1.0f, w_planes, w_scale, bias, residual, out, gn_partial, workspace, workspace_bytes, stream,
+                          gn_scale_shift, gn_swish ? 1 : 0);
+}
 
 extern "C" int sgam_conv2d_nhwc_f32x(const sgam_conv_desc *d, const float *x, float a_scale, const void *w_planes,
                                      float w_scale, const float *bias, const float *residual, float *out,
@@ -833,7 +880,7 @@ extern "C" int sgam_conv2d_stats_nhwc_f32x(const sgam_conv_desc *d, const float 
 
 static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale, const void *w_planes, float w_scale,
                           const float *bias, const float *residual, float *out, double *gn_partial, void *workspace,
-                          int64_t workspace_bytes, void *stream) {
+                          int64_t workspace_bytes, void *stream, const float *gn_tab, int gn_swish) {
     const int rc = xvalidate(d);
     if (rc != SGAM_OK) return rc;
     if (!x || !w_planes || !out || !(w_scale > 0.f) || !(a_scale > 0.f)) return SGAM_EINVAL;
@@ -850,6 +897,8 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
     p.a_scale = a_scale;
     p.gn_partial = gn_partial;
     p.gn_cpg = d->N / 32;
+    p.gn_tab = gn_tab;
+    p.gn_swish = gn_swish;
 
     const int64_t xb = (((int64_t)d->B * d->Hi * d->Wi - 1) * d->lda + d->Cin) * 4;
     const int64_t wb = (int64_t)d->N * d->ldb * 4;   // [N][ldb / 32][2][32] halfs
@@ -875,13 +924,13 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
     } while (0)
     if (p.ups && a_scale != 1.0f) return SGAM_EINVAL;
     if (d->KH * d->KW > 32) return SGAM_EINVAL;   // tap validity mask is 32 bits
-    static const int halo_on = [] { const char *e = getenv("SGAM_F32X_HALO"); return (e && e[0] == '0') ? 0 : 1; }();
-    const bool halo = halo_on && pl.bm == 128 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 &&
-                      !d->upsample2x && d->Ho == d->Hi && d->Wo == d->Wi && d->Ho % 8 == 0 && d->Wo % 16 == 0 &&
-                      d->Cin % 32 == 0 && a_scale == 1.0f;
+    const bool halo = halo_eligible(d, pl, a_scale);
+    if (gn_tab && !halo) return SGAM_EINVAL;
     if (halo) {
         static const int dyn = [] { const char *e = getenv("SGAM_XDYN_LDS"); return e ? atoi(e) : 0; }();   // occupancy experiments
-        hipLaunchKernelGGL((conv3x3_f32x_halo_kernel<128>), grid, dim3(256), dyn, s, p);   // pl.bm == 128 implies pl.bn == 128
+        // pl.bm == 128 implies pl.bn == 128
+        if (p.gn_tab) hipLaunchKernelGGL((conv3x3_f32x_halo_kernel<128, true>), grid, dim3(256), dyn, s, p);
+        else hipLaunchKernelGGL((conv3x3_f32x_halo_kernel<128, false>), grid, dim3(256), dyn, s, p);
     } else if (pl.bm == 128 && pl.bn == 128) XLAUNCH(128, 128);
     else if (pl.bm == 64 && pl.bn == 128) XLAUNCH(64, 128);
     else XLAUNCH(64, 64);

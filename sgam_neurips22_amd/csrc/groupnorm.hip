@@ -354,6 +354,19 @@ extern "C" int sgam_groupnorm_from_partials_f32(const float *x, const double *pa
     return SGAM_OK;
 }
 
+// scale/shift table straight from conv-epilogue partials (no pass over the tensor at all): the consumer is a
+// convolution that normalises while staging its input (sgam_conv2d_gn_nhwc_f32x)
+extern "C" int sgam_groupnorm_table_from_partials_f32(const double *partial, int32_t nchunk, const float *gamma,
+                                                      const float *beta, float *scale_shift, int32_t B, int32_t HW, int32_t C,
+                                                      int32_t groups, float eps, void *stream) {
+    if (!partial || nchunk <= 0 || !gamma || !beta || !scale_shift || !gn_shape_ok(B, HW, C, groups)) return SGAM_EINVAL;
+    if (!sgam_aligned16(partial) || !sgam_aligned16(scale_shift)) return SGAM_EALIGN;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(256), 0, sgam_stream(stream), partial, gamma, beta, scale_shift,
+                       HW, C, groups, nchunk, eps);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
 extern "C" int sgam_groupnorm_stats_nhwc_f32(const float *x, const float *gamma, const float *beta,
                                              float *scale_shift, int32_t B, int32_t HW, int32_t C, int32_t groups,
                                              float eps, void *workspace, int64_t workspace_bytes, void *stream) {

@@ -34,7 +34,7 @@ class Conv2d(nn.Conv2d):
             self._packs[dtype] = ops.pack_conv_weight(w, dtype=dtype)
         return self._packs[dtype], self._pack_bias
 
-    def forward_nhwc(self, x, residual=None, upsample2x=False, pad=None, gn=None, out_dtype=None):
+    def forward_nhwc(self, x, residual=None, upsample2x=False, pad=None, gn=None, out_dtype=None, norm=None):
         """gn = (scale/shift table from GroupNorm.stats_nhwc, swish flag): GroupNorm(+swish) of the input fused
         into the operand staging of the implicit GEMM (fp32 path only).  The kernel family follows x.dtype:
         fp32 -> fp32-in MFMA parity path, bf16/fp16 -> 16-bit MFMA throughput path."""
@@ -44,7 +44,7 @@ class Conv2d(nn.Conv2d):
             pad = (self.padding[0], self.padding[1], self.padding[0], self.padding[1])  # t, l, b, r
         return ops.conv2d_nhwc(x, wp, b, cout=self.out_channels, kh=kh, kw=kw, stride=self.stride[0],
                                pad_t=pad[0], pad_l=pad[1], pad_b=pad[2], pad_r=pad[3], upsample2x=upsample2x,
-                               residual=residual, cin=wp.shape[1] // (kh * kw), gn=gn, out_dtype=out_dtype)
+                               residual=residual, cin=wp.shape[1] // (kh * kw), gn=gn, out_dtype=out_dtype, norm=norm)
 
     def forward(self, x):
         cin_pad = self._packed()[0].shape[1] // (self.kernel_size[0] * self.kernel_size[1])
@@ -75,6 +75,9 @@ def _norm_conv(norm, swish, conv, x, **kw):
     """GroupNorm(+swish) followed by a convolution."""
     if FUSE_GROUPNORM_INTO_CONV:
         return conv.forward_nhwc(x, gn=(norm.stats_nhwc(x), swish), **kw)
+    if x.dtype == torch.float32 and ops.F32_MODE == "split":
+        # ops decides per launch: normalise inside the halo-staged 3x3 kernel where that kernel runs, else a separate pass
+        return conv.forward_nhwc(x, norm=(norm.weight.detach(), norm.bias.detach(), swish, norm.num_groups, norm.eps), **kw)
     return conv.forward_nhwc(norm.forward_nhwc(x, swish=swish), **kw)
 
 

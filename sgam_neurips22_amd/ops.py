@@ -51,6 +51,8 @@ def round_up(v, m):
 F32_MODE = os.environ.get("SGAM_F32_MODE", "split")
 # split-mode convolutions also emit the GroupNorm statistics of their output from the epilogue (no statistics pass)
 FUSE_GN_STATS = os.environ.get("SGAM_FUSE_GN_STATS", "1") == "1"
+# ... and normalise(+swish) their INPUT while staging it (halo-staged 3x3 kernel): no stand-alone normalise pass
+FUSE_GN_APPLY = os.environ.get("SGAM_FUSE_GN_APPLY", "1") == "1"
 
 
 def set_f32_mode(mode):
@@ -194,10 +196,19 @@ def conv_plan(desc, h16=False, split=False):
     return bm.value, bn.value, ks.value
 
 
-def _run_conv(desc, x, w, bias, residual, out, gn=None, a_scale=1.0):
+def _run_conv(desc, x, w, bias, residual, out, gn=None, a_scale=1.0, norm=None):
+    """norm = (gamma, beta, swish, groups, eps): GroupNorm(+swish) of x ahead of the product — fused into the operand
+    staging where the kernel family offers it (split fp32, halo-staged 3x3), a stand-alone pass otherwise."""
     lib = _lib.load()
     split = isinstance(w, SplitWeight)
     _apply_plan(desc, "f32x" if split else x.dtype)
+    if norm is not None:
+        gamma, beta, swish, groups, eps = norm
+        if (split and FUSE_GN_APPLY and x.dtype == torch.float32 and x.dim() == 4 and groups == 32
+                and lib.sgam_conv2d_f32x_gn_fusable(ctypes.byref(desc)) == 1):
+            gn = (groupnorm_stats(x, gamma, beta, groups, eps), swish)
+        else:
+            x = groupnorm_nhwc(x, gamma, beta, swish, groups, eps)
     if CONV_TRACE is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
@@ -212,13 +223,25 @@ def _run_conv(desc, x, w, bias, residual, out, gn=None, a_scale=1.0):
 
 def _run_conv_inner(lib, desc, x, w, bias, residual, out, gn=None, a_scale=1.0):
     if isinstance(w, SplitWeight):
-        if gn is not None or x.dtype != torch.float32:
-            raise SgamHipError("split fp32 conv: fp32 activations only, no fused GroupNorm prologue")
+        if x.dtype != torch.float32:
+            raise SgamHipError("split fp32 conv: fp32 activations only")
         ws_bytes = lib.sgam_conv2d_f32x_workspace_bytes(ctypes.byref(desc))
         if ws_bytes < 0:
             raise SgamHipError(f"sgam_conv2d_f32x: unsupported shape {[(f, getattr(desc, f)) for f, _ in desc._fields_]}")
         ws = torch.empty((ws_bytes,), device=x.device, dtype=torch.uint8) if ws_bytes else None
         chunks = lib.sgam_conv2d_f32x_stats_chunks(ctypes.byref(desc)) if FUSE_GN_STATS else 0
+        if gn is not None:
+            # GroupNorm(+swish) of x applied while the 3x3 kernel stages its input patch
+            table, swish = gn
+            if a_scale != 1.0 or lib.sgam_conv2d_f32x_gn_fusable(ctypes.byref(desc)) != 1:
+                raise SgamHipError("split fp32 conv: fused GroupNorm needs the halo-staged 3x3 kernel (sgam_conv2d_f32x_gn_fusable)")
+            partial = torch.empty((desc.B * chunks * 32 * 2,), device=x.device, dtype=torch.float64) if chunks > 0 else None
+            check(lib.sgam_conv2d_gn_nhwc_f32x(ctypes.byref(desc), _p(x), _p(table), int(swish), _p(w.planes), float(w.scale),
+                                               _p(bias), _p(residual), _p(out), _p(partial), _p(ws), ws_bytes, _stream()),
+                  "sgam_conv2d_gn_nhwc_f32x")
+            if partial is not None:
+                out._gn_partials = (partial, chunks)
+            return out
         if chunks > 0:
             # the epilogue also emits the GroupNorm statistics of `out`; the next groupnorm_nhwc(out) picks them up
             partial = torch.empty((desc.B * chunks * 32 * 2,), device=x.device, dtype=torch.float64)
@@ -252,7 +275,7 @@ def _run_conv_inner(lib, desc, x, w, bias, residual, out, gn=None, a_scale=1.0):
 
 
 def conv2d_nhwc(x, w_packed, bias, *, cout, kh, kw, stride=1, pad_t=0, pad_l=0, pad_b=None, pad_r=None,
-                upsample2x=False, residual=None, cin=None, gn=None, out_dtype=None):
+                upsample2x=False, residual=None, cin=None, gn=None, out_dtype=None, norm=None):
     """x (B,Hi,Wi,Cx) NHWC fp32 -> (B,Ho,Wo,cout).  w_packed from pack_conv_weight (rows padded to 64,
     Cin padded to 32).  `cin` = channels of x actually contracted (defaults to Cx, must be % 32)."""
     _need_cuda(x, w_packed)
@@ -268,7 +291,7 @@ def conv2d_nhwc(x, w_packed, bias, *, cout, kh, kw, stride=1, pad_t=0, pad_l=0, 
     d = ConvDesc(B=B, Hi=Hi, Wi=Wi, Cin=cin, Ho=Ho, Wo=Wo, N=N, KH=kh, KW=kw, stride=stride, pad_t=pad_t,
                  pad_l=pad_l, upsample2x=int(upsample2x), lda=x.stride(2), ldb=w_packed.stride(0), ldc=cout,
                  ldr=(residual.stride(2) if residual is not None else 0), n_valid=cout, bias_per_row=0)
-    return _run_conv(d, x, w_packed, bias, residual, out, gn)
+    return _run_conv(d, x, w_packed, bias, residual, out, gn, norm=norm)
 
 
 def gemm_nt(a, b, bias=None, residual=None, bias_per_row=False, out=None, gn=None, out_dtype=None, a_scale=1.0):
@@ -329,11 +352,17 @@ def groupnorm_stats(x, gamma, beta, groups=32, eps=1e-6):
     _need_cuda(x, gamma, beta)
     B, H, W, C = x.shape
     lib = _lib.load()
+    table = torch.empty((B, C, 2), device=x.device, dtype=torch.float32)
+    pre = getattr(x, "_gn_partials", None)
+    if pre is not None and groups == 32:
+        partial, chunks = pre        # the conv that produced x already emitted the statistics: fold them, no pass over x
+        check(lib.sgam_groupnorm_table_from_partials_f32(_p(partial), chunks, _p(gamma), _p(beta), _p(table), B, H * W, C,
+                                                         groups, eps, _stream()), "sgam_groupnorm_table_from_partials_f32")
+        return table
     ws_bytes = lib.sgam_groupnorm_workspace_bytes(B, H * W, C)
     if ws_bytes < 0:
         raise SgamHipError(f"sgam_groupnorm: unsupported shape B={B} HW={H * W} C={C}")
     ws = torch.empty((ws_bytes,), device=x.device, dtype=torch.uint8)
-    table = torch.empty((B, C, 2), device=x.device, dtype=torch.float32)
     check(lib.sgam_groupnorm_stats_nhwc_f32(_p(x), _p(gamma), _p(beta), _p(table), B, H * W, C, groups, eps, _p(ws),
                                             ws_bytes, _stream()), "sgam_groupnorm_stats_nhwc_f32")
     return table

@@ -268,3 +268,30 @@ def test_conv_epilogue_groupnorm_statistics(B, C, Cout, H, W, k):
     ref = ref * torch.sigmoid(ref)
     _close(y_plain.permute(0, 3, 1, 2), ref, 2e-5, "plain")
     _close(y_fused.permute(0, 3, 1, 2), ref, 2e-5, "fused statistics")
+
+
+@pytest.mark.parametrize("B,C,Cout,H,W,swish,with_res", [(1, 128, 128, 64, 64, True, True), (2, 128, 256, 32, 48, False, False),
+                                                        (1, 256, 128, 16, 16, True, False), (1, 128, 128, 256, 256, True, True)])
+def test_conv_groupnorm_fused_into_halo_staging(B, C, Cout, H, W, swish, with_res):
+    """Conv3x3(GroupNorm(+swish)(x)) with the normalisation applied while the halo-staged kernel stages its input
+    equals the two-pass form (GroupNorm kernel, then conv) and the torch reference; zero padding is post-norm."""
+    ops.set_f32_mode("split")
+    x = _nhwc(testing.seeded_tensor("cgf.x", (B, C, H, W), 1.3, 0.4)).to(DEV)
+    w = testing.seeded_tensor("cgf.w", (Cout, C, 3, 3), scale=(1.0 / (C * 9)) ** 0.5)
+    bias = testing.seeded_tensor("cgf.bias", (Cout,), 0.1).to(DEV)
+    res = _nhwc(testing.seeded_tensor("cgf.r", (B, Cout, H, W))).to(DEV) if with_res else None
+    g = (1 + 0.1 * testing.seeded_tensor("cgf.g", (C,))).to(DEV)
+    bt = (0.1 * testing.seeded_tensor("cgf.b", (C,))).to(DEV)
+    wp = ops.pack_conv_weight(w.to(DEV), dtype="f32x")
+    kw = dict(cout=Cout, kh=3, kw=3, pad_t=1, pad_l=1, residual=res)
+    fused = ops.conv2d_nhwc(x, wp, bias, norm=(g, bt, swish, 32, 1e-6), **kw)
+    two_pass = ops.conv2d_nhwc(ops.groupnorm_nhwc(x, g, bt, swish), wp, bias, **kw)
+    ref = F.group_norm(x.permute(0, 3, 1, 2).cpu(), 32, g.cpu(), bt.cpu(), eps=1e-6)
+    if swish:
+        ref = ref * torch.sigmoid(ref)
+    ref = F.conv2d(ref.double(), w.double(), bias.cpu().double(), padding=1).float()
+    if with_res:
+        ref = ref + res.permute(0, 3, 1, 2).cpu()
+    _close(two_pass.permute(0, 3, 1, 2), ref, 2e-5, "two-pass")
+    _close(fused.permute(0, 3, 1, 2), ref, 2e-5, "fused")
+    assert (fused - two_pass).abs().max().item() <= 2e-6 * ref.abs().max().item()
