@@ -499,9 +499,12 @@ __global__ __launch_bounds__(256 * wk_of(BM, BN)) void conv_gemm_f32x_kernel(con
 // GN: the input is GroupNorm(+swish)-ed on the fly from a per-(image, channel) scale/shift table while the halo is
 // staged — once per slab, not once per tap, so the normalisation costs 1/6 of what it does in a per-tap prologue and
 // the stand-alone normalise pass (a read and a write of the whole activation) disappears.  Padding pixels stay 0.
-template <int BN, bool GN>
+// BM = 128: 8 x 16 patches (180 halo pixels); BM = 64: 8 x 8 patches (100 halo pixels) for the maps that would not
+// fill the chip with 128-pixel tiles.
+template <int BM, int BN, bool GN>
 __global__ __launch_bounds__(256) void conv3x3_f32x_halo_kernel(const XParams p) {
-    constexpr int BM = 128, TH = 8, TW = 16, HWID = TW + 2, HR = (TH + 2) * HWID;   // 180 halo pixels
+    constexpr int TH = 8, TW = BM / 8, TWS = (TW == 16) ? 4 : 3, HWID = TW + 2, HR = (TH + 2) * HWID;
+    static_assert(BM == 128 || BM == 64, "8 x 16 or 8 x 8 output patches");
     constexpr int XBK = 32, XLD = XBK + 8;
     constexpr int TM = BM / 64, TN = BN / 64, BRW = BN / 64;
     constexpr int HPL = HR * XLD;                       // halfs per halo plane
@@ -569,12 +572,14 @@ __global__ __launch_bounds__(256) void conv3x3_f32x_halo_kernel(const XParams p)
             gt1 = *reinterpret_cast<const f32x4 *>(t + 4);      // s2 h2 s3 h3
         }
     };
-    auto hstore = [&]() {
+    // hprep: GroupNorm(+swish) and the hi/lo split, in registers ({hi0, hi1, lo0, lo1} replace the four floats) — issued
+    // during the LAST tap of the running slab so that it hides behind that tap's MFMAs; hstore then only writes LDS
+    auto hprep = [&]() {
 #pragma unroll
         for (int j = 0; j < NH; ++j) {
             u32x2 hi, lo;
+            f32x4 v = hreg[j];
             if constexpr (GN) {
-                f32x4 v = hreg[j];
                 v[0] = v[0] * gt0[0] + gt0[1];
                 v[1] = v[1] * gt0[2] + gt0[3];
                 v[2] = v[2] * gt1[0] + gt1[1];
@@ -584,12 +589,18 @@ __global__ __launch_bounds__(256) void conv3x3_f32x_halo_kernel(const XParams p)
                     for (int e = 0; e < 4; ++e) v[e] = sgam_swish(v[e]);
                 }
                 if (h_off[j] == 0xFFFFFFFFu) v = f32x4{0.f, 0.f, 0.f, 0.f};     // zero padding is applied AFTER the norm
-                hreg[j] = v;
             }
-            split4(hreg[j], hi, lo);
+            split4(v, hi, lo);
+            hreg[j] = __builtin_bit_cast(f32x4, u32x4{hi[0], hi[1], lo[0], lo[1]});
+        }
+    };
+    auto hstore = [&]() {
+#pragma unroll
+        for (int j = 0; j < NH; ++j) {
+            const u32x4 q = __builtin_bit_cast(u32x4, hreg[j]);
             if (h_lds[j] >= 0) {
-                *reinterpret_cast<u32x2 *>(halo + h_lds[j]) = hi;
-                *reinterpret_cast<u32x2 *>(halo + HPL + h_lds[j]) = lo;
+                *reinterpret_cast<u32x2 *>(halo + h_lds[j]) = u32x2{q[0], q[1]};
+                *reinterpret_cast<u32x2 *>(halo + HPL + h_lds[j]) = u32x2{q[2], q[3]};
             }
         }
     };
@@ -626,13 +637,14 @@ __global__ __launch_bounds__(256) void conv3x3_f32x_halo_kernel(const XParams p)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int r = wm * (BM / 2) + i * 32 + frag_row;
-        a_base[i] = ((r >> 4) * HWID + (r & 15)) * XLD + frag_k;
+        a_base[i] = ((r >> TWS) * HWID + (r & (TW - 1))) * XLD + frag_k;
     }
 
     int ch = it0 / 9;
     int tap = it0 - ch * 9;
     hload(ch);
     bload(tap, ch, it0 < it1);
+    hprep();
     hstore();
     bstore(0);
     if ((ch + 1) * 9 < it1) hload(ch + 1);              // next slab's halo: in flight for the whole slab
@@ -649,6 +661,7 @@ __global__ __launch_bounds__(256) void conv3x3_f32x_halo_kernel(const XParams p)
 #if SGAM_XSB
         __builtin_amdgcn_sched_barrier(0);      // keep the prefetch HERE: the scheduler otherwise sinks the loads to their use
 #endif
+        if (ntap == 0 && it + 1 < it1) hprep();          // next slab's halo: normalise + split under this tap's MFMAs
         const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
         const unsigned short *ah = halo + (ky * HWID + kx) * XLD;
         const unsigned short *bhp = bsm + buf * 2 * PLANE_B + (wn * (BN / 2) + frag_row) * XLD + frag_k;
@@ -701,7 +714,7 @@ __global__ __launch_bounds__(256) void conv3x3_f32x_halo_kernel(const XParams p)
     }
 
     xepilogue<BM, BN>(p, acc, reinterpret_cast<float *>(smem), wave, lane, bx, bz, n0, [&](int row) {
-        return (b * p.Ho + ty0 + (row >> 4)) * p.Wo + tx0 + (row & 15);
+        return (b * p.Ho + ty0 + (row >> TWS)) * p.Wo + tx0 + (row & (TW - 1));
     });
 }
 
@@ -836,9 +849,9 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
 // the halo-staged 3x3 kernel takes: 3x3 / stride 1 / pad 1, no upsampling, 8 x 16 output patches, whole 32-channel slabs
 static bool halo_eligible(const sgam_conv_desc *d, const XPlan &pl, float a_scale) {
     static const int halo_on = [] { const char *e = getenv("SGAM_F32X_HALO"); return (e && e[0] == '0') ? 0 : 1; }();
-    return halo_on && pl.bm == 128 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 &&
-           !d->upsample2x && d->Ho == d->Hi && d->Wo == d->Wi && d->Ho % 8 == 0 && d->Wo % 16 == 0 && d->Cin % 32 == 0 &&
-           a_scale == 1.0f;
+    const bool tile_ok = (pl.bm == 128 && pl.bn == 128 && d->Wo % 16 == 0) || (pl.bm == 64 && pl.bn == 128 && d->Wo % 8 == 0);
+    return halo_on && tile_ok && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 &&
+           !d->upsample2x && d->Ho == d->Hi && d->Wo == d->Wi && d->Ho % 8 == 0 && d->Cin % 32 == 0 && a_scale == 1.0f;
 }
 
 extern "C" int32_t sgam_conv2d_f32x_gn_fusable(const sgam_conv_desc *d) {
@@ -928,9 +941,13 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
     if (gn_tab && !halo) return SGAM_EINVAL;
     if (halo) {
         static const int dyn = [] { const char *e = getenv("SGAM_XDYN_LDS"); return e ? atoi(e) : 0; }();   // occupancy experiments
-        // pl.bm == 128 implies pl.bn == 128
-        if (p.gn_tab) hipLaunchKernelGGL((conv3x3_f32x_halo_kernel<128, true>), grid, dim3(256), dyn, s, p);
-        else hipLaunchKernelGGL((conv3x3_f32x_halo_kernel<128, false>), grid, dim3(256), dyn, s, p);
+        if (pl.bm == 128) {
+            if (p.gn_tab) hipLaunchKernelGGL((conv3x3_f32x_halo_kernel<128, 128, true>), grid, dim3(256), dyn, s, p);
+            else hipLaunchKernelGGL((conv3x3_f32x_halo_kernel<128, 128, false>), grid, dim3(256), dyn, s, p);
+        } else {
+            if (p.gn_tab) hipLaunchKernelGGL((conv3x3_f32x_halo_kernel<64, 128, true>), grid, dim3(256), dyn, s, p);
+            else hipLaunchKernelGGL((conv3x3_f32x_halo_kernel<64, 128, false>), grid, dim3(256), dyn, s, p);
+        }
     } else if (pl.bm == 128 && pl.bn == 128) XLAUNCH(128, 128);
     else if (pl.bm == 64 && pl.bn == 128) XLAUNCH(64, 128);
     else XLAUNCH(64, 64);

@@ -204,8 +204,9 @@ def _run_conv(desc, x, w, bias, residual, out, gn=None, a_scale=1.0, norm=None):
     _apply_plan(desc, "f32x" if split else x.dtype)
     if norm is not None:
         gamma, beta, swish, groups, eps = norm
+        # maps of <= 1024 pixels normalise in ONE launch (gn_small: statistics + apply): fusing would cost a launch there
         if (split and FUSE_GN_APPLY and x.dtype == torch.float32 and x.dim() == 4 and groups == 32
-                and lib.sgam_conv2d_f32x_gn_fusable(ctypes.byref(desc)) == 1):
+                and x.shape[1] * x.shape[2] > 1024 and lib.sgam_conv2d_f32x_gn_fusable(ctypes.byref(desc)) == 1):
             gn = (groupnorm_stats(x, gamma, beta, groups, eps), swish)
         else:
             x = groupnorm_nhwc(x, gamma, beta, swish, groups, eps)

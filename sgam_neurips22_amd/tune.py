@@ -97,7 +97,12 @@ def tune_shape(key, verbose=True):
     iters = KH * KW * ((Cin + slab - 1) // slab)
     M = B * Ho * Wo
     results = []
-    t_auto = _time(ConvDesc(**base, plan_bm=0, plan_bn=0, plan_ksplit=0), x, w, out)
+    # ResnetBlock / conv_out: GroupNorm(+swish) first (maps of <= 1024 pixels normalise in one launch and are never fused)
+    norm_input = KH == 3 and stride == 1 and not ups and Cin >= 64 and Hi * Wi > 1024
+    auto = ConvDesc(**base, plan_bm=0, plan_bn=0, plan_ksplit=0)
+    t_auto = _time(auto, x, w, out)
+    if t_auto is not None and split and norm_input and _lib.load().sgam_conv2d_f32x_gn_fusable(ctypes.byref(auto)) != 1:
+        t_auto += max(4e-3, 2.0 * B * Hi * Wi * Cin * 4 / 4e12 * 1e3)
     for bm, bn in TILES:
         if bn == 128 and N % 128:
             continue
@@ -110,8 +115,13 @@ def tune_shape(key, verbose=True):
         for ks in sorted(cands):
             if blocks * ks > 8192:
                 continue
-            t = _time(ConvDesc(**base, plan_bm=bm, plan_bn=bn, plan_ksplit=ks), x, w, out)
+            cand = ConvDesc(**base, plan_bm=bm, plan_bn=bn, plan_ksplit=ks)
+            t = _time(cand, x, w, out)
             if t is not None:
+                # a 3x3 conv behind a GroupNorm: plans that run the halo-staged kernel also absorb the normalise pass
+                # (a read + a write of the activation at ~4 TB/s effective, >= 4 us for a launch of its own)
+                if split and norm_input and _lib.load().sgam_conv2d_f32x_gn_fusable(ctypes.byref(cand)) != 1:
+                    t += max(4e-3, 2.0 * B * Hi * Wi * Cin * 4 / 4e12 * 1e3)
                 results.append((t, bm, bn, ks))
     results.sort()
     best = results[0]

@@ -295,3 +295,25 @@ def test_conv_groupnorm_fused_into_halo_staging(B, C, Cout, H, W, swish, with_re
     _close(two_pass.permute(0, 3, 1, 2), ref, 2e-5, "two-pass")
     _close(fused.permute(0, 3, 1, 2), ref, 2e-5, "fused")
     assert (fused - two_pass).abs().max().item() <= 2e-6 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("plan", [(64, 128, 1), (64, 128, 3), (128, 128, 2)])
+def test_halo_kernel_tile_plans(plan):
+    """the halo-staged 3x3 kernel under each of its tile plans (8x8 and 8x16 patches, split-K) against fp64"""
+    ops.set_f32_mode("split")
+    B, C, Cout, H, W = 2, 64, 128, 24, 32
+    x = _nhwc(testing.seeded_tensor("hk.x", (B, C, H, W))).to(DEV)
+    w = testing.seeded_tensor("hk.w", (Cout, C, 3, 3), scale=(1.0 / (C * 9)) ** 0.5)
+    wp = ops.pack_conv_weight(w.to(DEV), dtype="f32x")
+    key = f"f32x|B{B}|{H}x{W}x{C}|{H}x{W}|N{Cout}|k3x3s1u0"
+    old = ops.PLAN_CACHE.get(key)
+    ops.PLAN_CACHE[key] = plan
+    try:
+        out = ops.conv2d_nhwc(x, wp, None, cout=Cout, kh=3, kw=3, pad_t=1, pad_l=1)
+    finally:
+        if old is None:
+            ops.PLAN_CACHE.pop(key, None)
+        else:
+            ops.PLAN_CACHE[key] = old
+    ref = F.conv2d(x.permute(0, 3, 1, 2).cpu().double(), w.double(), padding=1).float()
+    _close(out.permute(0, 3, 1, 2), ref, 2e-5, f"halo plan {plan}")
