@@ -23,6 +23,8 @@
 //     per CU).  One ds_read_b128 = the 8 halfs a lane feeds to one 32x32x16 MFMA.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "sgam_common.h"
 
 #ifndef SGAM_XSCHED
@@ -129,12 +131,14 @@ __device__ __forceinline__ void xcd_block(const XParams &p, int &bx, int &by, in
 // leaves as 16-byte accesses, 16 lanes covering a 256-byte row segment (the MFMA D layout alone gives 4-byte accesses:
 // 64 store + 64 load instructions per 32x32 tile instead of 4 + 4).  The caller guarantees every wavefront is done
 // reading the operand LDS.  rowmap(tile row) -> global output pixel index.
-template <int BM, int BN, class RowMap>
-__device__ __forceinline__ void xepilogue(const XParams &p, f32x16 (&acc)[BM / 64][BN / 64], float *smem_f, int wave, int lane,
-                                          int bx, int bz, int n0, RowMap rowmap) {
-    constexpr int TM = BM / 64, TN = BN / 64;
+// WGM = wavefronts along M (2: the 2 x 2 grid, 1: four wavefronts side by side along N).
+template <int BM, int BN, int WGM, class RowMap>
+__device__ __forceinline__ void xepilogue(const XParams &p, f32x16 (&acc)[BM / (32 * WGM)][BN / (32 * (4 / WGM))], float *smem_f,
+                                          int wave, int lane, int bx, int bz, int n0, RowMap rowmap) {
+    constexpr int WGN = 4 / WGM;
+    constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
     constexpr int WM = 32 * TM, WN = 32 * TN, LDR = WN + 4;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = WGM == 2 ? wave >> 1 : 0, wn = WGM == 2 ? (wave & 1) : wave;
     float *region = smem_f + wave * (WM * LDR);
     const bool to_ws = p.ws != nullptr;
     const int n_lim = to_ws ? p.N : p.n_valid;
@@ -150,7 +154,7 @@ __device__ __forceinline__ void xepilogue(const XParams &p, f32x16 (&acc)[BM / 6
     const float inv = to_ws ? 1.0f : p.inv_w_scale;
     const int col_l = lane & 31;
     const int row_h = 4 * (lane >> 5);
-    const int wn0 = n0 + wn * (BN / 2);
+    const int wn0 = n0 + wn * (BN / WGN);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -173,7 +177,7 @@ __device__ __forceinline__ void xepilogue(const XParams &p, f32x16 (&acc)[BM / 6
 #pragma unroll
     for (int pass = 0; pass < WM / RPP; ++pass) {
         const int row = rr0 + pass * RPP;
-        const int m = rowmap(wm * (BM / 2) + row);       // global output pixel of this tile row (>= M: outside)
+        const int m = rowmap(wm * (BM / WGM) + row);     // global output pixel of this tile row (>= M: outside)
         const bool ok = n_ok && m < p.M;
         f32x4 v = *reinterpret_cast<const f32x4 *>(region + row * LDR + c4 * 4);
         const f32x4 rv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
@@ -219,6 +223,10 @@ __device__ __forceinline__ void xepilogue(const XParams &p, f32x16 (&acc)[BM / 6
                 double *o = p.gn_partial + (((int64_t)b * chunks_per_b + cb) * groups + g) * 2;
                 o[0] = ds;
                 o[1] = dss;
+                if (WGM == 1) {
+                    o[groups * 2] = 0.0;
+                    o[groups * 2 + 1] = 0.0;
+                }
             }
         }
     }
@@ -484,7 +492,7 @@ __global__ __launch_bounds__(256 * wk_of(BM, BN)) void conv_gemm_f32x_kernel(con
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] += xch[((i * TN + j) * 16 + e) * 64 + lane];
     }
-    xepilogue<BM, BN>(p, acc, reinterpret_cast<float *>(smem), wave, lane, bx, bz, n0, [&](int row) { return m0 + row; });
+    xepilogue<BM, BN, 2>(p, acc, reinterpret_cast<float *>(smem), wave, lane, bx, bz, n0, [&](int row) { return m0 + row; });
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -503,6 +511,7 @@ __global__ __launch_bounds__(256 * wk_of(BM, BN)) void conv_gemm_f32x_kernel(con
 // fill the chip with 128-pixel tiles.
 template <int BM, int BN, bool GN>
 __global__ __launch_bounds__(256) void conv3x3_f32x_halo_kernel(const XParams p) {
+    constexpr int WGM_ = 2;
     constexpr int TH = 8, TW = BM / 8, TWS = (TW == 16) ? 4 : 3, HWID = TW + 2, HR = (TH + 2) * HWID;
     static_assert(BM == 128 || BM == 64, "8 x 16 or 8 x 8 output patches");
     constexpr int XBK = 32, XLD = XBK + 8;
@@ -713,7 +722,223 @@ __global__ __launch_bounds__(256) void conv3x3_f32x_halo_kernel(const XParams p)
         ch = nch;
     }
 
-    xepilogue<BM, BN>(p, acc, reinterpret_cast<float *>(smem), wave, lane, bx, bz, n0, [&](int row) {
+    xepilogue<BM, BN, WGM_>(p, acc, reinterpret_cast<float *>(smem), wave, lane, bx, bz, n0, [&](int row) {
+        return (b * p.Ho + ty0 + (row >> TWS)) * p.Wo + tx0 + (row & (TW - 1));
+    });
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Halo kernel, second generation: the B (weight) fragments never touch LDS.  In the [N][K/32][hi 32 | lo 32] layout the
+// MFMA B operand of a lane (8 consecutive halfs of one output channel's K slab) is one aligned 16-byte piece of a
+// 128-byte line, so every wavefront pulls the fragments of its own 64 output channels for the next tap straight into
+// registers (8 x buffer_load_dwordx4, each 128-byte line consumed whole across the four (k-step, plane) pieces; the
+// wavefront that shares the channel range and the co-resident workgroup hit the same lines in the vector L1).  With B
+// out of LDS the only shared operand is the halo, which is double-buffered: ONE barrier per channel slab (nine taps)
+// instead of one per tap, no ds_write of weights, half the ds_reads, and wavefronts drift freely inside a slab so the
+// two workgroups of a CU interleave their load and MFMA phases.
+template <int BM, int BN, bool GN>
+__global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParams p) {
+    constexpr int WGM_ = 1;          // four wavefronts side by side along N: each owns all BM rows x BN / 4 channels
+    constexpr int TH = 8, TW = BM / 8, TWS = (TW == 16) ? 4 : 3, HWID = TW + 2, HR = (TH + 2) * HWID;
+    static_assert(BM == 128 || BM == 64, "8 x 16 or 8 x 8 output patches");
+    constexpr int XBK = 32, XLD = XBK + 8;
+    constexpr int TM = BM / 32, TN = BN / 128;
+    constexpr int HPL = HR * XLD;                       // halfs per halo plane
+    constexpr int HBUF = 2 * HPL;                       // one halo buffer: hi plane, lo plane
+    constexpr int NH = (HR * 8 + 255) / 256;            // float4 halo loads per thread
+    constexpr int OP_BYTES = 2 * HBUF * 2;
+    constexpr int EPI_BYTES = 4 * (32 * TM) * (32 * TN + 4) * 4;
+    constexpr int SM_BYTES = OP_BYTES > EPI_BYTES ? OP_BYTES : EPI_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned short smem[SM_BYTES / 2];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wn = wave;
+    int bx, by, bz;
+    xcd_block(p, bx, by, bz);
+    const int n0 = by * BN;
+    const int tiles_x = p.Wo / TW, tiles_img = tiles_x * (p.Ho / TH);
+    const int b = bx / tiles_img;
+    const int t_img = bx - b * tiles_img;
+    const int ty0 = (t_img / tiles_x) * TH, tx0 = (t_img % tiles_x) * TW;
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, (int)p.w_plane_bytes, 0x00020000);
+
+    const int it0 = bz * p.iters_per_split;
+    const int it1 = min(p.iters_total, it0 + p.iters_per_split);
+
+    unsigned h_off[NH];
+    int h_lds[NH];
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+        const int idx = tid + 256 * j;
+        const int row = idx >> 3, col4 = idx & 7;
+        const int hy = row / HWID, hx = row - hy * HWID;
+        const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
+        const bool ok = row < HR && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        h_off[j] = ok ? (unsigned)(((b * p.Hi + iy) * p.Wi + ix) * p.lda + col4 * 4) * 4u : 0xFFFFFFFFu;
+        h_lds[j] = row < HR ? row * XLD + col4 * 4 : -1;
+    }
+    // B fragments: lane -> output channel n (plan guarantees N % BN == 0), k-half (lane >> 5) of every 16-element k-step
+    unsigned bf_off[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / 4) + j * 32 + (lane & 31);
+        bf_off[j] = (unsigned)n * (unsigned)p.ldb * 4u + (unsigned)(lane >> 5) * 16u;
+    }
+
+    f32x4 hreg[NH];
+    f32x4 gt0, gt1;
+    auto hload = [&](int ch, bool live) {            // !live: out-of-range offsets (zeros come back, no memory traffic)
+        const unsigned coff = (unsigned)ch * (XBK * 4u);
+#pragma unroll
+        for (int j = 0; j < NH; ++j) {
+            const unsigned o = xsel(live && h_off[j] != 0xFFFFFFFFu, h_off[j] + coff, p.x_bytes);
+            hreg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)o, 0, 0));
+        }
+        if constexpr (GN) {
+            const float *t = p.gn_tab + ((int64_t)b * p.Cin + (live ? ch : 0) * XBK + (tid & 7) * 4) * 2;
+            gt0 = *reinterpret_cast<const f32x4 *>(t);
+            gt1 = *reinterpret_cast<const f32x4 *>(t + 4);
+        }
+    };
+    auto hprep_piece = [&](const int j) {
+        {
+            u32x2 hi, lo;
+            f32x4 v = hreg[j];
+            if constexpr (GN) {
+                v[0] = v[0] * gt0[0] + gt0[1];
+                v[1] = v[1] * gt0[2] + gt0[3];
+                v[2] = v[2] * gt1[0] + gt1[1];
+                v[3] = v[3] * gt1[2] + gt1[3];
+                if (p.gn_swish) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = sgam_swish(v[e]);
+                }
+                if (h_off[j] == 0xFFFFFFFFu) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            split4(v, hi, lo);
+            hreg[j] = __builtin_bit_cast(f32x4, u32x4{hi[0], hi[1], lo[0], lo[1]});
+        }
+    };
+    auto hprep = [&]() {
+#pragma unroll
+        for (int j = 0; j < NH; ++j) hprep_piece(j);
+    };
+    auto hstore = [&](int hb) {
+        unsigned short *halo = smem + hb * HBUF;
+#pragma unroll
+        for (int j = 0; j < NH; ++j) {
+            const u32x4 q = __builtin_bit_cast(u32x4, hreg[j]);
+            if (h_lds[j] >= 0) {
+                *reinterpret_cast<u32x2 *>(halo + h_lds[j]) = u32x2{q[0], q[1]};
+                *reinterpret_cast<u32x2 *>(halo + HPL + h_lds[j]) = u32x2{q[2], q[3]};
+            }
+        }
+    };
+
+    // B fragments: two register sets alternate by tap parity; the set of the next tap is in flight during this tap's MFMAs
+    u32x4 bq[2][TN][2][2];                 // [tap parity][n tile][k-step][hi, lo]
+    auto bload = [&](const int set, int tap, int ch, bool live) {
+        const unsigned koff = (unsigned)(tap * p.Cin + ch * XBK) * 4u;     // 128 bytes per (row, slab)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    bq[set][j][kk][pl] = __builtin_amdgcn_raw_buffer_load_b128(
+                        rw, (int)xsel(live, bf_off[j] + koff + (unsigned)(pl * 64 + kk * 32), p.w_plane_bytes), 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int frag_row = lane & 31;
+    const int frag_k = (lane >> 5) * 8;
+    int a_base[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = i * 32 + frag_row;
+        a_base[i] = ((r >> TWS) * HWID + (r & (TW - 1))) * XLD + frag_k;
+    }
+
+    // The host aligns split-K ranges to whole slabs for this kernel (it0, it1 multiples of 9).  One slab = ONE basic
+    // block: nine taps unrolled, no branches (range ends are handled with out-of-range load offsets), so the scheduler
+    // can thread the VALU work on the NEXT slab's halo (GroupNorm, swish, hi/lo split: one float4 piece per tap) and
+    // the weight-fragment loads of the next tap through the 216 MFMAs of the running slab.
+    const int s0 = it0 / 9, s1 = SGAM_XABLATE == 1 ? it0 / 9 : it1 / 9;
+    int hcur = 0;
+    hload(s0, s0 < s1);
+    bload(0, 0, s0, s0 < s1);
+    hprep();
+    hstore(0);
+    hload(s0 + 1, s0 + 1 < s1);
+    __syncthreads();
+
+    u32x4 fa[2][TM][2];                    // [step parity][m tile][hi, lo]
+    const unsigned short *hb = smem;
+    auto afrag = [&](const int set, const int tap, const int kk) {
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        const unsigned short *ah = hb + (ky * HWID + kx) * XLD;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            fa[set][i][0] = *reinterpret_cast<const u32x4 *>(ah + a_base[i] + kk * 16);
+            fa[set][i][1] = *reinterpret_cast<const u32x4 *>(ah + HPL + a_base[i] + kk * 16);
+        }
+    };
+    for (int sl = s0; sl < s1; ++sl) {
+        const bool has_next = sl + 1 < s1;
+        hb = smem + hcur * HBUF;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int set = tap & 1;
+            constexpr bool NOB = SGAM_XABLATE == 21 || SGAM_XABLATE == 24, NOH = SGAM_XABLATE == 24 || SGAM_XABLATE == 25;
+            if (!NOB) {
+                if (tap < 8) bload(set ^ 1, tap + 1, sl, true);
+                else bload(set ^ 1, 0, sl + 1, has_next);
+            }
+            if (!NOH && tap >= 1 && tap <= NH) hprep_piece(tap - 1);    // next slab's halo, one piece per tap
+            if (!NOH && tap == NH + 1) {
+                hstore(hcur ^ 1);                                       // idle buffer: nobody reads it during this slab
+                hload(sl + 2, sl + 2 < s1);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int q = tap * 2 + kk;                 // step inside the slab: 0 .. 17
+                // A fragments are read one step ahead (register double buffer fa[q & 1]); step 0 reads its own
+                if (q == 0) afrag(0, 0, 0);
+                if (q < 17) afrag((q + 1) & 1, (q + 1) >> 1, (q + 1) & 1);
+                // term-major order: the three MFMAs of one accumulator are TM * TN instructions apart
+#pragma unroll
+                for (int term = 0; term < 3; ++term)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = mfma16(fa[q & 1][i][term == 0 ? 1 : 0], bq[set][j][kk][term == 1 ? 1 : 0], acc[i][j]);
+            }
+        }
+        // nine taps flip the parity: the fragments of the next slab's tap 0 sit in set 1 -> move them to set 0
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) bq[0][j][kk][pl] = bq[1][j][kk][pl];
+        __syncthreads();                                               // next halo visible; old one free for re-use
+        hcur ^= 1;
+    }
+    __syncthreads();                                  // every wavefront is done with the halo: LDS becomes the epilogue's
+
+    xepilogue<BM, BN, WGM_>(p, acc, reinterpret_cast<float *>(smem), wave, lane, bx, bz, n0, [&](int row) {
         return (b * p.Ho + ty0 + (row >> TWS)) * p.Wo + tx0 + (row & (TW - 1));
     });
 }
@@ -777,6 +1002,15 @@ struct XPlan {
     int bm, bn, ksplit, iters_total, iters_per_split;
 };
 
+// shapes the halo-staged 3x3 kernels take: 3x3 / stride 1 / pad 1, no upsampling, 8 x 16 (8 x 8) output patches, whole
+// 32-channel slabs
+static bool halo_shape(const sgam_conv_desc *d, int bm, int bn) {
+    static const int halo_on = [] { const char *e = getenv("SGAM_F32X_HALO"); return (e && e[0] == '0') ? 0 : 1; }();
+    const bool tile_ok = (bm == 128 && bn == 128 && d->Wo % 16 == 0) || (bm == 64 && bn == 128 && d->Wo % 8 == 0);
+    return halo_on && tile_ok && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 &&
+           !d->upsample2x && d->Ho == d->Hi && d->Wo == d->Wi && d->Ho % 8 == 0 && d->Cin % 32 == 0;
+}
+
 XPlan make_xplan(const sgam_conv_desc *d) {
     const int64_t M = (int64_t)d->B * d->Ho * d->Wo;
     XPlan pl;
@@ -800,6 +1034,7 @@ XPlan make_xplan(const sgam_conv_desc *d) {
         if (ks < 1) ks = 1;
     }
     pl.iters_per_split = (pl.iters_total + ks - 1) / ks;
+    if (halo_shape(d, pl.bm, pl.bn)) pl.iters_per_split = (pl.iters_per_split + 8) / 9 * 9;   // whole channel slabs (9 taps)
     pl.ksplit = (pl.iters_total + pl.iters_per_split - 1) / pl.iters_per_split;
     return pl;
 }
@@ -846,12 +1081,8 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
                           const float *bias, const float *residual, float *out, double *gn_partial, void *workspace,
                           int64_t workspace_bytes, void *stream, const float *gn_tab = nullptr, int gn_swish = 0);
 
-// the halo-staged 3x3 kernel takes: 3x3 / stride 1 / pad 1, no upsampling, 8 x 16 output patches, whole 32-channel slabs
 static bool halo_eligible(const sgam_conv_desc *d, const XPlan &pl, float a_scale) {
-    static const int halo_on = [] { const char *e = getenv("SGAM_F32X_HALO"); return (e && e[0] == '0') ? 0 : 1; }();
-    const bool tile_ok = (pl.bm == 128 && pl.bn == 128 && d->Wo % 16 == 0) || (pl.bm == 64 && pl.bn == 128 && d->Wo % 8 == 0);
-    return halo_on && tile_ok && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 &&
-           !d->upsample2x && d->Ho == d->Hi && d->Wo == d->Wi && d->Ho % 8 == 0 && d->Cin % 32 == 0 && a_scale == 1.0f;
+    return a_scale == 1.0f && halo_shape(d, pl.bm, pl.bn);
 }
 
 extern "C" int32_t sgam_conv2d_f32x_gn_fusable(const sgam_conv_desc *d) {
@@ -941,7 +1172,16 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
     if (gn_tab && !halo) return SGAM_EINVAL;
     if (halo) {
         static const int dyn = [] { const char *e = getenv("SGAM_XDYN_LDS"); return e ? atoi(e) : 0; }();   // occupancy experiments
-        if (pl.bm == 128) {
+        static const int halo_gen = [] { const char *e = getenv("SGAM_F32X_HALO"); return (e && e[0] == '1') ? 1 : 2; }();
+        if (halo_gen == 2) {
+            if (pl.bm == 128) {
+                if (p.gn_tab) hipLaunchKernelGGL((conv3x3_f32x_halo2_kernel<128, 128, true>), grid, dim3(256), dyn, s, p);
+                else hipLaunchKernelGGL((conv3x3_f32x_halo2_kernel<128, 128, false>), grid, dim3(256), dyn, s, p);
+            } else {
+                if (p.gn_tab) hipLaunchKernelGGL((conv3x3_f32x_halo2_kernel<64, 128, true>), grid, dim3(256), dyn, s, p);
+                else hipLaunchKernelGGL((conv3x3_f32x_halo2_kernel<64, 128, false>), grid, dim3(256), dyn, s, p);
+            }
+        } else if (pl.bm == 128) {
             if (p.gn_tab) hipLaunchKernelGGL((conv3x3_f32x_halo_kernel<128, 128, true>), grid, dim3(256), dyn, s, p);
             else hipLaunchKernelGGL((conv3x3_f32x_halo_kernel<128, 128, false>), grid, dim3(256), dyn, s, p);
         } else {
