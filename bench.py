@@ -68,12 +68,39 @@ def profile_conv_launches(scene):
         for (plan, mnk), (n, ms, fl) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
             print(f"{str(plan):16s} {mnk[0]:7d} {mnk[1]:6d} {mnk[2]:6d} {n:3d} {1e3 * ms / n:8.1f} {fl / (ms / n * 1e-3) / 1e12:6.1f} "
                   f"{ms:9.3f}", file=sys.stderr)
+    # keyed by the kernel instantiation that ran; launches with split-K (conv + fixed-order reduce inside the
+    # bracket) are kept apart so that the roofline entry times the conv kernel alone
     for plan, mnk, flops, e0, e1 in trace:
-        a = agg.setdefault(plan[:2] + (plan[3],), {"launches": 0, "flops": 0.0, "ms": 0.0})
+        a = agg.setdefault((plan[4], plan[2] > 1), {"launches": 0, "flops": 0.0, "ms": 0.0, "shapes": {}})
+        ms = e0.elapsed_time(e1)
         a["launches"] += 1
         a["flops"] += flops
-        a["ms"] += e0.elapsed_time(e1)
+        a["ms"] += ms
+        sh = a["shapes"].setdefault((plan[5], plan[:3]), [0, 0.0, flops])
+        sh[0] += 1
+        sh[1] += ms
     return agg
+
+
+def time_kernel_isolated(key, plan, reps=20):
+    """Average duration of ONE launch of a conv kernel on a layer shape: `reps` launches captured into a HIP graph and
+    replayed between two HIP events on the launch stream (no host gaps between the launches, unlike the eager
+    per-launch brackets of profile_conv_launches).  This is the figure `rocprofv3 --kernel-trace --stats` reports."""
+    from sgam_neurips22_amd import tune
+    from sgam_neurips22_amd._lib import ConvDesc
+    dt, B, Hi, Wi, Cin, Ho, Wo, N, KH, KW, stride, ups = tune._parse(key)
+    dtype = ops.DTYPES["f32" if dt in ("float32", "f32x") else ("bf16" if dt == "bfloat16" else "fp16")]
+    x = testing.seeded_tensor("bench.iso.x", (B * Hi * Wi, Cin)).cuda().to(dtype)
+    K = KH * KW * Cin
+    w = (testing.seeded_tensor("bench.iso.w", (N, K)) * 0.03).cuda().to(dtype)
+    if dt == "f32x":
+        w = ops.split_rows(w, 1024.0)
+    out = torch.empty((B * Ho * Wo, N), device="cuda", dtype=dtype)
+    pad = (KH // 2) if stride == 1 else 0
+    d = ConvDesc(B=B, Hi=Hi, Wi=Wi, Cin=Cin, Ho=Ho, Wo=Wo, N=N, KH=KH, KW=KW, stride=stride, pad_t=pad, pad_l=pad,
+                 upsample2x=ups, lda=Cin, ldb=K, ldc=N, ldr=0, n_valid=N, bias_per_row=0, plan_bm=plan[0], plan_bn=plan[1],
+                 plan_ksplit=plan[2])
+    return tune._time(d, x, w, out, reps=reps)
 
 
 def cpu_baseline(sd, p, seed_frame, n_frames):
@@ -161,36 +188,47 @@ def main():
     if rank == 0 and not args.no_roofline:
         agg = profile_conv_launches(scene)
         split = args.dtype == "f32" and ops.F32_MODE == "split"
-        tname = "f32x" if split else {"f32": "float32", "bf16": "bfloat16", "fp16": "float16"}[args.dtype]
-        dom = agg.get((128, 128, tname))
+        # dominant kernel = the instantiation (without split-K) with the most time in one frame
+        cands = {k: v for k, v in agg.items() if not k[1]}
+        dom_key = max(cands, key=lambda k: cands[k]["ms"]) if cands else None
+        dom = cands.get(dom_key)
         if split:
             # 3 fp16 MFMAs per fp32 product: the matrix-pipe roof for ALGORITHMIC fp32 flops is 2500 / 3 TFLOP/s
             peak = round(H16_MFMA_PEAK_TFLOPS / 3.0, 1)
-            kname = "conv_gemm_f32x_kernel<128,128> (fp32 via exact hi/lo fp16 split, 3x MFMA 32x32x16 f16, fp32 accumulate)"
+            how = "fp32 via exact hi/lo fp16 split, 3x MFMA 32x32x16 f16, fp32 accumulate"
         elif args.dtype == "f32":
-            peak, kname = FP32_MFMA_PEAK_TFLOPS, "conv_gemm_f32_v2_kernel<128,128> (fp32-in MFMA 32x32x2 implicit-GEMM conv)"
+            peak, how = FP32_MFMA_PEAK_TFLOPS, "fp32-in MFMA 32x32x2 implicit-GEMM conv"
         else:
-            peak, kname = H16_MFMA_PEAK_TFLOPS, f"conv_gemm_h16_kernel<128,128> ({args.dtype} MFMA 32x32x16 implicit-GEMM conv)"
+            peak, how = H16_MFMA_PEAK_TFLOPS, f"{args.dtype} MFMA 32x32x16 implicit-GEMM conv"
         if dom:
-            tf = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+            kname = f"{dom_key[0]} ({how})"
+            # the kernel's dominant layer shape, timed back to back from a captured graph between two HIP events
+            (skey, splan), (sn, sms, sflops) = max(dom["shapes"].items(), key=lambda kv: kv[1][1])
+            iso_ms = time_kernel_isolated(skey, splan)
+            tf = sflops / (iso_ms * 1e-3) / 1e12
             roofline = {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
                         "frac": round(tf / peak, 4), "traffic": None,
                         "kernel": kname,
-                        "launches_per_frame": dom["launches"], "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 1),
+                        "layer": skey, "gflop_per_launch": round(sflops / 1e9, 2), "avg_launch_us": round(iso_ms * 1e3, 1),
+                        "launches_of_this_layer_per_frame": sn,
+                        "launches_per_frame": dom["launches"],
+                        "in_frame_event_bracket_us": round(dom["ms"] * 1e3 / dom["launches"], 1),
                         "gflop_per_frame_in_kernel": round(dom["flops"] / 1e9, 1),
-                        "all_conv_kernels": {f"{k[0]}x{k[1]}/{k[2]}": {"launches": v["launches"], "gflop": round(v["flops"] / 1e9, 1),
-                                                               "ms": round(v["ms"], 3)} for k, v in agg.items()}}
+                        "all_conv_kernels": {f"{k[0]}{'+splitK' if k[1] else ''}": {"launches": v["launches"],
+                                                                                   "gflop": round(v["flops"] / 1e9, 1),
+                                                                                   "ms": round(v["ms"], 3)}
+                                             for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}}
     if roofline is not None and args.dtype == "f32":
         # HBM traffic of the dominant kernel: PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) collected
         # with rocprofv3 --pmc in separate passes on the dominant layer shape and committed under profiles/
-        name = "r01c_pmc_conv128_f32x.json" if ops.F32_MODE == "split" else "r01b_pmc_conv128_f32.json"
+        name = "r01d_pmc_halo2_128_f32x.json" if ops.F32_MODE == "split" else "r01b_pmc_conv128_f32.json"
         pmc = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pmc):
             d = json.load(open(pmc))["derived"]
             roofline["traffic"] = round(d["hbm_traffic_bytes_per_launch"])
             roofline["traffic_note"] = ("bytes/launch on the dominant layer (M=65536,N=128,K=1152; algorithmic "
                                         f"{d['algorithmic_bytes_per_launch']} B) from profiles/{name}; "
-                                        f"in-kernel MFMA busy {d['mfma_busy_frac']:.3f}")
+                                        f"in-kernel MFMA pipe busy {d['mfma_busy_frac']:.3f}")
 
     secondary = None
     if rank == 0 and world == 1 and args.dtype == "f32" and not args.no_secondary:
@@ -208,7 +246,7 @@ def main():
         torch.cuda.synchronize()
         dt2 = time.perf_counter() - t1
         agg2 = profile_conv_launches(sc2)
-        d2 = agg2.get((128, 128, "float16"))
+        d2 = agg2.get(("conv_gemm_h16_kernel<128,128>", False))
         secondary = {"dtype": "fp16", "value": round(args.steps / dt2, 3), "unit": "frames/s",
                      "ms_per_step": round(1e3 * dt2 / args.steps, 3),
                      "conv128_tflops": round(d2["flops"] / (d2["ms"] * 1e-3) / 1e12, 1) if d2 else None,

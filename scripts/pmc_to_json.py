@@ -28,9 +28,9 @@ for f in sorted(glob.glob(src + "/*/**/*counter_collection.csv", recursive=True)
 M, N, K = 65536, 128, 1152
 fetch = counters.get("FETCH_SIZE", 0) * 1024      # FETCH_SIZE / WRITE_SIZE are reported in KiB
 write = counters.get("WRITE_SIZE", 0) * 1024
-alg = M * 128 * 4 + M * N * 4 + N * K * 2 * 2     # input + output + the two fp16 weight planes
+alg = M * 128 * 4 + M * N * 4 + N * K * 2 * 2     # input + output + the hi / lo fp16 weight halves
 xcd_cycles = counters.get("GRBM_GUI_ACTIVE", 0) / 8.0
-d = {"kernel": f"{kname}<128,128> on the dominant layer shape (B=1, 128->128, 3x3, 256x256: M=65536 N=128 K=1152)",
+d = {"kernel": f"{kname} (128 x 128 tile) on the dominant layer shape (B=1, 128->128, 3x3, 256x256: M=65536 N=128 K=1152)",
      "command": "scripts/pmc_conv.sh (rocprofv3 --kernel-trace --pmc <group> -- python scripts/conv_micro.py "
                 "--shape 1,128,128,256,256,3 --reps 10; one pass per counter group)",
      "counters": counters, "launches_averaged": n,

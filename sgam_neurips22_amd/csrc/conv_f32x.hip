@@ -743,7 +743,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
     static_assert(BM == 128 || BM == 64, "8 x 16 or 8 x 8 output patches");
     constexpr int XBK = 32, XLD = XBK + 8;
     constexpr int TM = BM / 32, TN = BN / 128;
-    constexpr int HPL = HR * XLD;                       // halfs per halo plane
+    // halo pixel (hy, hx) sits at hy * LP + hx * XLD halfs; the line pitch LP is padded (720 -> 768, 400 -> 448) so that
+    // the 16-lane groups of ds_read_b128, which straddle two or more patch rows, land on 16 distinct bank quads for
+    // every tap offset (found by enumeration over the hardware's lane groups)
+    constexpr int LP = (TW == 16) ? 768 : 448;
+    constexpr int HPL = (TH + 2) * LP;                  // halfs per halo plane
     constexpr int HBUF = 2 * HPL;                       // one halo buffer: hi plane, lo plane
     constexpr int NH = (HR * 8 + 255) / 256;            // float4 halo loads per thread
     constexpr int OP_BYTES = 2 * HBUF * 2;
@@ -779,7 +783,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
         const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
         const bool ok = row < HR && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
         h_off[j] = ok ? (unsigned)(((b * p.Hi + iy) * p.Wi + ix) * p.lda + col4 * 4) * 4u : 0xFFFFFFFFu;
-        h_lds[j] = row < HR ? row * XLD + col4 * 4 : -1;
+        h_lds[j] = row < HR ? hy * LP + hx * XLD + col4 * 4 : -1;
     }
     // B fragments: lane -> output channel n (plan guarantees N % BN == 0), k-half (lane >> 5) of every 16-element k-step
     unsigned bf_off[TN];
@@ -867,7 +871,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int r = i * 32 + frag_row;
-        a_base[i] = ((r >> TWS) * HWID + (r & (TW - 1))) * XLD + frag_k;
+        a_base[i] = (r >> TWS) * LP + (r & (TW - 1)) * XLD + frag_k;
     }
 
     // The host aligns split-K ranges to whole slabs for this kernel (it0, it1 multiples of 9).  One slab = ONE basic
@@ -887,7 +891,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
     const unsigned short *hb = smem;
     auto afrag = [&](const int set, const int tap, const int kk) {
         const int ky = tap / 3, kx = tap - 3 * ky;
-        const unsigned short *ah = hb + (ky * HWID + kx) * XLD;
+        const unsigned short *ah = hb + ky * LP + kx * XLD;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             fa[set][i][0] = *reinterpret_cast<const u32x4 *>(ah + a_base[i] + kk * 16);

@@ -216,7 +216,14 @@ def _run_conv(desc, x, w, bias, residual, out, gn=None, a_scale=1.0, norm=None):
         _run_conv_inner(lib, desc, x, w, bias, residual, out, gn, a_scale)
         ev1.record()
         flops = 2.0 * desc.B * desc.Ho * desc.Wo * desc.n_valid * desc.KH * desc.KW * desc.Cin
-        CONV_TRACE.append((conv_plan(desc, x.dtype in H16, split) + ("f32x" if split else str(x.dtype).replace("torch.", ""),),
+        plan = conv_plan(desc, x.dtype in H16, split)
+        if split:
+            halo = a_scale == 1.0 and lib.sgam_conv2d_f32x_gn_fusable(ctypes.byref(desc)) == 1
+            kernel = f"{'conv3x3_f32x_halo2_kernel' if halo else 'conv_gemm_f32x_kernel'}<{plan[0]},{plan[1]}>"
+        else:
+            kernel = f"{'conv_gemm_h16_kernel' if x.dtype in H16 else 'conv_gemm_f32_v2_kernel'}<{plan[0]},{plan[1]}>"
+        CONV_TRACE.append((plan + ("f32x" if split else str(x.dtype).replace("torch.", ""), kernel,
+                                   plan_key(desc, "f32x" if split else x.dtype)),
                            (desc.B * desc.Ho * desc.Wo, desc.n_valid, desc.KH * desc.KW * desc.Cin), flops, ev0, ev1))
         return out
     return _run_conv_inner(lib, desc, x, w, bias, residual, out, gn, a_scale)
