@@ -843,8 +843,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
         }
     };
 
-    // B fragments: two register sets alternate by tap parity; the set of the next tap is in flight during this tap's MFMAs
-    u32x4 bq[2][TN][2][2];                 // [tap parity][n tile][k-step][hi, lo]
+    // B fragments: three register sets rotate with the tap (9 taps = 3 full turns, so a slab ends where it began); the
+    // fragments are requested TWO taps ahead — one tap of MFMAs (384 cycles on the 64-row tile) does not cover an L2
+    // round trip when a SIMD holds a single wavefront
+    u32x4 bq[3][TN][2][2];                 // [tap % 3][n tile][k-step][hi, lo]
     auto bload = [&](const int set, int tap, int ch, bool live) {
         const unsigned koff = (unsigned)(tap * p.Cin + ch * XBK) * 4u;     // 128 bytes per (row, slab)
 #pragma unroll
@@ -882,6 +884,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
     int hcur = 0;
     hload(s0, s0 < s1);
     bload(0, 0, s0, s0 < s1);
+    bload(1, 1, s0, s0 < s1);
     hprep();
     hstore(0);
     hload(s0 + 1, s0 + 1 < s1);
@@ -903,11 +906,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
         hb = smem + hcur * HBUF;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int set = tap & 1;
+            const int set = tap % 3;
             constexpr bool NOB = SGAM_XABLATE == 21 || SGAM_XABLATE == 24, NOH = SGAM_XABLATE == 24 || SGAM_XABLATE == 25;
             if (!NOB) {
-                if (tap < 8) bload(set ^ 1, tap + 1, sl, true);
-                else bload(set ^ 1, 0, sl + 1, has_next);
+                if (tap < 7) bload((tap + 2) % 3, tap + 2, sl, true);
+                else bload((tap + 2) % 3, tap - 7, sl + 1, has_next);
             }
             if (!NOH && tap >= 1 && tap <= NH) hprep_piece(tap - 1);    // next slab's halo, one piece per tap
             if (!NOH && tap == NH + 1) {
@@ -930,13 +933,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
                             acc[i][j] = mfma16(fa[q & 1][i][term == 0 ? 1 : 0], bq[set][j][kk][term == 1 ? 1 : 0], acc[i][j]);
             }
         }
-        // nine taps flip the parity: the fragments of the next slab's tap 0 sit in set 1 -> move them to set 0
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) bq[0][j][kk][pl] = bq[1][j][kk][pl];
         __syncthreads();                                               // next halo visible; old one free for re-use
         hcur ^= 1;
     }
