@@ -230,6 +230,27 @@ def main():
                                         f"{d['algorithmic_bytes_per_launch']} B) from profiles/{name}; "
                                         f"in-kernel MFMA pipe busy {d['mfma_busy_frac']:.3f}")
 
+    rgbd_leg = None
+    if rank == 0 and world == 1 and args.dtype == "f32" and not args.no_secondary:
+        # BASELINE config 3, branch (B): the rgbd_integration conditioning path — TSDF fusion of the source frames, depth
+        # ray cast at the target pose, target-depth-driven inverse warp — in front of the same VQGAN + feedback
+        sc3 = InfiniteSceneGeneration(model, DATASET, seed_index=rank, output_dim=(args.warmup + args.steps + 2, 1),
+                                      seed_frame=seed_frame, use_rgbd_integration=True)
+        for _ in range(args.warmup):
+            sc3.one_step_prediction(sc3.next_pose(sc3.curr)); sc3.curr += 1
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        for _ in range(args.steps):
+            sc3.one_step_prediction(sc3.next_pose(sc3.curr)); sc3.curr += 1
+        torch.cuda.synchronize()
+        dt3 = time.perf_counter() - t3
+        st = sc3.volume.stats()
+        rgbd_leg = {"value": round(args.steps / dt3, 3), "unit": "frames/s", "ms_per_step": round(1e3 * dt3 / args.steps, 3),
+                    "tsdf_bricks": st[0], "note": "conditioning = TSDF integrate (<= 3 source frames) + depth ray cast + inverse "
+                    "warp (csrc/tsdf.hip, warp.hip); seeded random weights generate noise depths, so this times the branch, "
+                    "it does not validate the fused geometry (tests/test_gpu_tsdf.py does)"}
+        del sc3
+
     secondary = None
     if rank == 0 and world == 1 and args.dtype == "f32" and not args.no_secondary:
         # the 16-bit throughput mode on the same workload (fp16 activations/weights, fp32 accumulate): NOT the
@@ -273,7 +294,7 @@ def main():
                        "f32_products": ("exact hi/lo fp16 split on the fp16 matrix cores, fp32 accumulate (fp32-class accuracy)"
                                         if ops.F32_MODE == "split" else "fp32-in MFMA") if args.dtype == "f32" else None},
             "vqgan_tflops_wallclock": round(GFLOP_PER_FRAME * g["total_frames"] / t_max / 1e3 / world, 2),
-            "roofline": roofline, "cpu_baseline": cpu, "throughput_mode": secondary, "frame_checksums": [r[2] for r in g["per_rank"]],
+            "roofline": roofline, "cpu_baseline": cpu, "rgbd_integration_branch": rgbd_leg, "throughput_mode": secondary, "frame_checksums": [r[2] for r in g["per_rank"]],
         }
         print(json.dumps(out), flush=True)
 

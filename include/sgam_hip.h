@@ -278,6 +278,32 @@ int sgam_inverse_warp_f32(const float *src_imgs, const float *src_depths, const 
 int sgam_frame_feedback_f32(const float *dec, const float *lut256, int32_t dataset_norm, uint8_t *rgb_u8,
                             float *rgb_f, float *depth, int32_t B, int32_t HW, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * f1 — TSDF fusion of the generated RGB-D frames + depth render at the target pose.  Replaces
+ * InfiniteSceneGeneration.rgbd_integration (sgam/inference_pipeline.py:119-133, 745-838: Open3D 0.15.2
+ * ScalableTSDFVolume.integrate / extract_triangle_mesh / OffscreenRenderer.render_to_depth_image).
+ * Integration is Open3D's published rule (16^3-voxel units, stride-4 unit opening, running weighted mean of
+ * min(1, sdf / sdf_trunc)); the depth render is a direct ray cast of the fused surface (first +/- zero crossing of the
+ * trilinear TSDF, view-space z, 0 = nothing hit).  Colour is not fused: the path only consumes the depth.
+ *   unit_table [dims.z][dims.y][dims.x] int32, -1 = closed; unit_stamp same shape, 0-initialised;
+ *   counters int32[4] = {bricks allocated, length of this frame's brick list, samples outside the box, pool overflows};
+ *   brick_tsdf / brick_weight [max_bricks][16*16*16] fp32, 0-initialised; brick_list int32[max_list] scratch.
+ *   cam2world / world2cam: row-major 4x4 DEVICE pointers; intrinsics by value.  frame_id > 0, distinct per call.
+ * All state is caller-owned; nothing is synchronised or read back.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct sgam_tsdf_grid {
+    float voxel_length, sdf_trunc;
+    int32_t unit_base[3];    /* unit index (floor(world / (16 * voxel_length))) of the box's low corner, x y z */
+    int32_t unit_dims[3];    /* units per axis */
+} sgam_tsdf_grid;
+int sgam_tsdf_integrate_f32(const sgam_tsdf_grid *grid, const float *depth, int32_t H, int32_t W, float fx, float fy, float cx,
+                            float cy, const float *cam2world, const float *world2cam, float depth_trunc, int32_t frame_id,
+                            int32_t *unit_table, int32_t *unit_stamp, int32_t *counters, int32_t *brick_list, int32_t max_list,
+                            float *brick_tsdf, float *brick_weight, int32_t max_bricks, void *stream);
+int sgam_tsdf_raycast_depth_f32(const sgam_tsdf_grid *grid, int32_t H, int32_t W, float fx, float fy, float cx, float cy,
+                                const float *cam2world, float z_near, float z_far, const int32_t *unit_table,
+                                const float *brick_tsdf, const float *brick_weight, float *depth_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,128 @@
+"""TEST INFRASTRUCTURE ONLY — CPU restatement (numpy, fp32, same expression order) of csrc/tsdf.hip: Open3D 0.15.2's
+published TSDF integration rule (ScalableTSDFVolume::Integrate / UniformTSDFVolume::IntegrateWith
+DepthToCameraDistanceMultiplier: 16^3-voxel units, stride-4 unit opening, running weighted mean of min(1, sdf/trunc))
+and the direct ray cast of the fused surface.  The reference calls Open3D for this branch
+(sgam/inference_pipeline.py:119-133, 745-838); Open3D is neither vendored nor installable here, so this oracle is
+**parity unpinned** at the Open3D boundary: it pins the HIP kernels to the rule as restated, and analytic scenes pin
+the rule to geometry.  Imported by tests/ only.
+"""
+import numpy as np
+
+F = np.float32
+UR = 16
+
+
+class TsdfOracle:
+    def __init__(self, voxel_length, sdf_trunc):
+        self.voxel, self.trunc = F(voxel_length), F(sdf_trunc)
+        self.unit_len = F(self.voxel * F(UR))
+        self.units = {}          # (ux, uy, uz) -> [tsdf (16,16,16) indexed [z][y][x], weight]
+
+    def integrate(self, depth, K, T_w2c, depth_trunc=20.0, stride=4):
+        depth = np.asarray(depth, dtype=F)
+        H, W = depth.shape
+        fx, fy, cx, cy = F(K[0][0]), F(K[1][1]), F(K[0][2]), F(K[1][2])
+        w2c = np.asarray(T_w2c, dtype=np.float64)
+        c2w = np.linalg.inv(w2c).astype(F)
+        w2c = w2c.astype(F)
+        touched = set()
+        vs, us = np.meshgrid(np.arange(0, H, stride), np.arange(0, W, stride), indexing="ij")
+        d = depth[vs, us]
+        ok = (d > 0) & (d <= F(depth_trunc))
+        xc = ((us.astype(F) - cx) / fx) * d
+        yc = ((vs.astype(F) - cy) / fy) * d
+        p = [(((c2w[r, 0] * xc + c2w[r, 1] * yc) + c2w[r, 2] * d) + c2w[r, 3]).astype(F) for r in range(3)]
+        lo = [np.floor((p[r] - self.trunc) / self.unit_len).astype(np.int64) for r in range(3)]
+        hi = [np.floor((p[r] + self.trunc) / self.unit_len).astype(np.int64) for r in range(3)]
+        for idx in zip(*np.nonzero(ok)):
+            for uz in range(lo[2][idx], hi[2][idx] + 1):
+                for uy in range(lo[1][idx], hi[1][idx] + 1):
+                    for ux in range(lo[0][idx], hi[0][idx] + 1):
+                        touched.add((ux, uy, uz))
+        inv_trunc = F(1.0) / self.trunc
+        safe_w, safe_h = F(W) - F(0.0001), F(H) - F(0.0001)
+        ii = (np.arange(UR, dtype=F) + F(0.5)) * self.voxel
+        for key in touched:
+            ux, uy, uz = key
+            if key not in self.units:
+                self.units[key] = [np.zeros((UR, UR, UR), F), np.zeros((UR, UR, UR), F)]
+            t, w = self.units[key]
+            px = (F(ux) * self.unit_len + ii)[None, None, :]
+            py = (F(uy) * self.unit_len + ii)[None, :, None]
+            pz = (F(uz) * self.unit_len + ii)[:, None, None]
+            c = [(((w2c[r, 0] * px + w2c[r, 1] * py) + w2c[r, 2] * pz) + w2c[r, 3]).astype(F) for r in range(3)]
+            with np.errstate(divide="ignore", invalid="ignore"):
+                uf = ((c[0] * fx) / c[2] + cx) + F(0.5)
+                vf = ((c[1] * fy) / c[2] + cy) + F(0.5)
+            m = (c[2] > 0) & (uf >= F(0.0001)) & (uf < safe_w) & (vf >= F(0.0001)) & (vf < safe_h)
+            u = np.where(m, uf, 0).astype(np.int64)
+            v = np.where(m, vf, 0).astype(np.int64)
+            dd = depth[v, u]
+            m &= (dd > 0) & (dd <= F(depth_trunc))
+            rx = (u.astype(F) - cx) / fx
+            ry = (v.astype(F) - cy) / fy
+            mult = np.sqrt(((rx * rx + ry * ry) + F(1.0)).astype(F)).astype(F)
+            sdf = ((dd - c[2]) * mult).astype(F)
+            m &= sdf > -self.trunc
+            tv = np.minimum(F(1.0), (sdf * inv_trunc).astype(F))
+            new_t = ((t * w + tv) / (w + F(1.0))).astype(F)
+            t[m] = new_t[m]
+            w[m] = (w + F(1.0))[m]
+
+    def _lattice(self, ix, iy, iz):
+        u = self.units.get((ix >> 4, iy >> 4, iz >> 4))
+        if u is None:
+            return None
+        x, y, z = ix & 15, iy & 15, iz & 15
+        if not u[1][z, y, x] > 0:
+            return None
+        return u[0][z, y, x]
+
+    def _sample(self, p, inv_voxel):
+        f, i0 = [], []
+        for r in range(3):
+            t = F(F(p[r] * inv_voxel) - F(0.5))
+            fl = np.floor(t)
+            i0.append(int(fl))
+            f.append(F(t - fl))
+        c = []
+        for k in range(8):
+            val = self._lattice(i0[0] + (k & 1), i0[1] + ((k >> 1) & 1), i0[2] + (k >> 2))
+            if val is None:      # incomplete cell: nearest lattice point, if observed
+                return self._lattice(i0[0] + (1 if f[0] >= F(0.5) else 0), i0[1] + (1 if f[1] >= F(0.5) else 0),
+                                     i0[2] + (1 if f[2] >= F(0.5) else 0))
+            c.append(F(val))
+        c00 = F(c[0] + F(f[0] * F(c[1] - c[0])))
+        c10 = F(c[2] + F(f[0] * F(c[3] - c[2])))
+        c01 = F(c[4] + F(f[0] * F(c[5] - c[4])))
+        c11 = F(c[6] + F(f[0] * F(c[7] - c[6])))
+        c0 = F(c00 + F(f[1] * F(c10 - c00)))
+        c1 = F(c01 + F(f[1] * F(c11 - c01)))
+        return F(c0 + F(f[2] * F(c1 - c0)))
+
+    def render_depth(self, K, T_w2c, H, W, z_near, z_far, pixels=None):
+        """Ray cast; `pixels` = iterable of (v, u) restricts the (slow, pure-Python) march to those pixels."""
+        fx, fy, cx, cy = F(K[0][0]), F(K[1][1]), F(K[0][2]), F(K[1][2])
+        c2w = np.linalg.inv(np.asarray(T_w2c, dtype=np.float64)).astype(F)
+        out = np.zeros((H, W), F)
+        inv_voxel = F(1.0) / self.voxel
+        fine, coarse = F(F(0.5) * self.voxel), F(F(0.25) * self.unit_len)
+        todo = pixels if pixels is not None else [(v, u) for v in range(H) for u in range(W)]
+        for v, u in todo:
+            rx, ry = F((F(u) - cx) / fx), F((F(v) - cy) / fy)
+            o = [c2w[r, 3] for r in range(3)]
+            d = [F(F(F(c2w[r, 0] * rx) + F(c2w[r, 1] * ry)) + c2w[r, 2]) for r in range(3)]
+            t, prev_t, prev_val, prev_ok = F(z_near), F(0), F(0), False
+            while t < F(z_far):
+                p = [F(o[r] + F(d[r] * t)) for r in range(3)]
+                key = tuple(int(np.floor(F(p[r] / self.unit_len))) for r in range(3))
+                is_open = key in self.units
+                val = self._sample(p, inv_voxel) if is_open else None
+                ok = val is not None
+                if ok and prev_ok and prev_val > 0 and val <= 0:
+                    out[v, u] = F(prev_t + F(F(t - prev_t) * F(prev_val / F(prev_val - val))))
+                    break
+                prev_ok, prev_val, prev_t = ok, (val if ok else F(0)), t
+                stride = max(fine, F(F(F(0.8) * val) * self.trunc)) if (ok and val > 0) else fine
+                t = F(t + (stride if is_open else coarse))
+        return out

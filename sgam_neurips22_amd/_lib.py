@@ -16,6 +16,11 @@ class ConvDesc(ctypes.Structure):
         "lda", "ldb", "ldc", "ldr", "n_valid", "bias_per_row", "plan_bm", "plan_bn", "plan_ksplit")]
 
 
+class TsdfGrid(ctypes.Structure):
+    """mirror of struct sgam_tsdf_grid"""
+    _fields_ = [("voxel_length", c_f32), ("sdf_trunc", c_f32), ("unit_base", c_i32 * 3), ("unit_dims", c_i32 * 3)]
+
+
 # name -> (restype, argtypes); must list every symbol include/sgam_hip.h declares
 PROTOTYPES = {
     "sgam_abi_version": (c_i32, []),
@@ -42,6 +47,10 @@ PROTOTYPES = {
                                          c_vp, c_i64, c_vp]),
     "sgam_groupnorm_table_from_partials_f32": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32,
                                                        c_vp]),
+    "sgam_tsdf_integrate_f32": (c_i32, [ctypes.POINTER(TsdfGrid), c_vp, c_i32, c_i32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp,
+                                        c_f32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp]),
+    "sgam_tsdf_raycast_depth_f32": (c_i32, [ctypes.POINTER(TsdfGrid), c_i32, c_i32, c_f32, c_f32, c_f32, c_f32, c_vp, c_f32,
+                                            c_f32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "sgam_pack_conv_weight_f32x": (c_i32, [c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "sgam_split_rows_f32x": (c_i32, [c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_vp]),
     "sgam_conv2d_h16_workspace_bytes": (c_i64, [ctypes.POINTER(ConvDesc)]),

@@ -1,0 +1,296 @@
+// tsdf.hip — truncated-signed-distance fusion of the generated RGB-D frames and a depth render of the fused surface at
+// the next target pose: the `rgbd_integration` conditioning branch of the scene loop
+// (sgam/inference_pipeline.py:119-133 volume set-up, :745-838 integrate + render).
+//
+// The reference delegates this to Open3D 0.15.2 (pinned in its requirement.txt; not vendored, not installable here):
+// ScalableTSDFVolume(voxel_length, sdf_trunc, RGB8).integrate(...) per source frame, then extract_triangle_mesh() and a
+// Filament off-screen render_to_depth_image(z_in_view_space=True).  What is restated here is Open3D's published
+// integration rule (ScalableTSDFVolume::Integrate / UniformTSDFVolume::IntegrateWithDepthToCameraDistanceMultiplier):
+//   * space is cut into volume units of 16^3 voxels, unit (i,j,k) spans [i,i+1) * 16 * voxel_length per axis;
+//   * a frame opens every unit within sdf_trunc (per-axis box) of the back-projected depth pixels, sampled with stride 4;
+//   * every voxel of an opened unit: centre -> camera; (u, v) = (int)(x fx / z + cx + 0.5), likewise v; d = depth[v][u]
+//     (d <= 0: skip); sdf = (d - z) * sqrt(((u-cx)/fx)^2 + ((v-cy)/fy)^2 + 1); if sdf > -sdf_trunc:
+//     tsdf <- (tsdf * w + min(1, sdf / sdf_trunc)) / (w + 1), w <- w + 1.
+// The depth render is NOT Open3D's (marching-cubes mesh + rasteriser): the fused surface is ray-cast directly — per
+// target pixel the ray is marched through the opened units and the first +/- zero crossing of the trilinearly
+// interpolated TSDF (nearest-voxel value where a cell has unobserved corners) is refined linearly; the result is the view-space z
+// of that point, 0 where nothing is hit, like the reference's depth image with inf -> 0.  Parity for this branch is
+// therefore pinned against oracle/tsdf.py (the same rule in numpy) and analytic scenes, not against Open3D: "parity
+// unpinned" at the Open3D boundary, as SURVEY.md §8c anticipates.
+//
+// MI355X-native layout: a direct-mapped unit table (int32 per unit of the scene's bounding box: a few MB even for
+// 50 x 50 x 10 scene units — no hashing, no probing) pointing into a pool of 16^3-voxel bricks {tsdf fp32, weight fp32}
+// = 32 KB each, allocated by atomic bump from a caller-sized pool (288 GB of HBM: sized once per scene, never resized);
+// one workgroup integrates one brick; the brick list of a frame is built on the device (no host round trip, the
+// integrate grid is a fixed-size grid-stride loop).  Built with -ffp-contract=off: every expression is evaluated as
+// written so that oracle/tsdf.py reproduces the bricks bit for bit (sqrtf, not __fsqrt_rn: the latter is the approximate
+// native square root in this toolchain).
+#include "sgam_common.h"
+
+namespace {
+
+constexpr int UR = 16;                 // voxels per unit edge (Open3D volume_unit_resolution)
+constexpr int UV = UR * UR * UR;       // voxels per brick
+
+struct TsdfGrid {
+    float voxel, trunc, unit_len;      // unit_len = 16 * voxel
+    int base[3], dims[3];              // unit index range: [base, base + dims) per axis (x, y, z)
+};
+
+__device__ __forceinline__ int64_t unit_slot(const TsdfGrid &g, int ux, int uy, int uz) {
+    const int x = ux - g.base[0], y = uy - g.base[1], z = uz - g.base[2];
+    if ((unsigned)x >= (unsigned)g.dims[0] || (unsigned)y >= (unsigned)g.dims[1] || (unsigned)z >= (unsigned)g.dims[2]) return -1;
+    return ((int64_t)z * g.dims[1] + y) * g.dims[0] + x;
+}
+
+// pass 1: open the units around the back-projected depth samples; units seen for the first time in this frame
+// (stamp != frame_id) are appended once to the frame's brick list.
+__global__ void tsdf_touch_kernel(const float *__restrict__ depth, int H, int W, float fx, float fy, float cx, float cy,
+                                  const float *__restrict__ c2w, TsdfGrid g, float depth_trunc, int stride,
+                                  int *__restrict__ table, int *__restrict__ stamp, int frame_id, int *__restrict__ counters,
+                                  int max_bricks, int *__restrict__ list, int max_list) {
+    const int sw = (W + stride - 1) / stride, sh = (H + stride - 1) / stride;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= sw * sh) return;
+    const int v = (i / sw) * stride, u = (i % sw) * stride;
+    const float d = depth[v * W + u];
+    if (!(d > 0.f) || d > depth_trunc) return;
+    // camera point, then world (c2w row-major 4x4)
+    const float xc = __fmul_rn(__fdiv_rn(__fsub_rn((float)u, cx), fx), d);
+    const float yc = __fmul_rn(__fdiv_rn(__fsub_rn((float)v, cy), fy), d);
+    float p[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+        p[r] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(c2w[r * 4 + 0], xc), __fmul_rn(c2w[r * 4 + 1], yc)), __fmul_rn(c2w[r * 4 + 2], d)),
+                         c2w[r * 4 + 3]);
+    int lo[3], hi[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        lo[r] = (int)floorf(__fdiv_rn(__fsub_rn(p[r], g.trunc), g.unit_len));
+        hi[r] = (int)floorf(__fdiv_rn(__fadd_rn(p[r], g.trunc), g.unit_len));
+    }
+    for (int uz = lo[2]; uz <= hi[2]; ++uz)
+        for (int uy = lo[1]; uy <= hi[1]; ++uy)
+            for (int ux = lo[0]; ux <= hi[0]; ++ux) {
+                const int64_t s = unit_slot(g, ux, uy, uz);
+                if (s < 0) {
+                    atomicAdd(&counters[2], 1);          // samples outside the scene box (diagnostic)
+                    continue;
+                }
+                if (atomicExch(&stamp[s], frame_id) == frame_id) continue;       // already listed for this frame
+                int brick = table[s];
+                if (brick < 0) {
+                    // first touch ever: allocate.  The exchange above makes this thread the only one handling slot s
+                    // in this frame, so no CAS loop is needed.
+                    brick = atomicAdd(&counters[0], 1);
+                    if (brick >= max_bricks) {
+                        atomicAdd(&counters[3], 1);      // pool exhausted (diagnostic); unit stays closed
+                        continue;
+                    }
+                    table[s] = brick;
+                }
+                const int li = atomicAdd(&counters[1], 1);
+                if (li < max_list) list[li] = (int)s;
+            }
+}
+
+// pass 2: one workgroup per listed brick (grid-stride over the device-side list), 256 lanes x 16 voxels.
+__global__ __launch_bounds__(256) void tsdf_integrate_kernel(const float *__restrict__ depth, int H, int W, float fx, float fy,
+                                                             float cx, float cy, const float *__restrict__ w2c, TsdfGrid g,
+                                                             float depth_trunc, const int *__restrict__ table, const int *__restrict__ counters,
+                                                             const int *__restrict__ list, int max_list,
+                                                             float *__restrict__ tsdf, float *__restrict__ weight) {
+    int n = counters[1];
+    if (n > max_list) n = max_list;
+    const float inv_trunc = __fdiv_rn(1.0f, g.trunc);
+    const float safe_w = __fsub_rn((float)W, 0.0001f), safe_h = __fsub_rn((float)H, 0.0001f);
+    for (int li = blockIdx.x; li < n; li += gridDim.x) {
+        const int s = list[li];
+        const int brick = table[s];
+        const int ux = s % g.dims[0] + g.base[0];
+        const int uy = (s / g.dims[0]) % g.dims[1] + g.base[1];
+        const int uz = s / (g.dims[0] * g.dims[1]) + g.base[2];
+        float *bt = tsdf + (int64_t)brick * UV, *bw = weight + (int64_t)brick * UV;
+        for (int q = threadIdx.x; q < UV; q += 256) {
+            const int x = q & 15, y = (q >> 4) & 15, z = q >> 8;
+            // voxel centre: unit origin + (i + 0.5) * voxel
+            const float px = __fadd_rn(__fmul_rn((float)ux, g.unit_len), __fmul_rn(__fadd_rn((float)x, 0.5f), g.voxel));
+            const float py = __fadd_rn(__fmul_rn((float)uy, g.unit_len), __fmul_rn(__fadd_rn((float)y, 0.5f), g.voxel));
+            const float pz = __fadd_rn(__fmul_rn((float)uz, g.unit_len), __fmul_rn(__fadd_rn((float)z, 0.5f), g.voxel));
+            float c[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                c[r] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(w2c[r * 4 + 0], px), __fmul_rn(w2c[r * 4 + 1], py)),
+                                           __fmul_rn(w2c[r * 4 + 2], pz)),
+                                 w2c[r * 4 + 3]);
+            if (!(c[2] > 0.f)) continue;
+            const float uf = __fadd_rn(__fadd_rn(__fdiv_rn(__fmul_rn(c[0], fx), c[2]), cx), 0.5f);
+            const float vf = __fadd_rn(__fadd_rn(__fdiv_rn(__fmul_rn(c[1], fy), c[2]), cy), 0.5f);
+            if (!(uf >= 0.0001f && uf < safe_w && vf >= 0.0001f && vf < safe_h)) continue;
+            const int u = (int)uf, v = (int)vf;
+            const float d = depth[v * W + u];
+            if (!(d > 0.f) || d > depth_trunc) continue;
+            const float rx = __fdiv_rn(__fsub_rn((float)u, cx), fx), ry = __fdiv_rn(__fsub_rn((float)v, cy), fy);
+            const float mult = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry)), 1.0f));
+            const float sdf = __fmul_rn(__fsub_rn(d, c[2]), mult);
+            if (sdf > -g.trunc) {
+                const float t = fminf(1.0f, __fmul_rn(sdf, inv_trunc));
+                const float w = bw[q];
+                bt[q] = __fdiv_rn(__fadd_rn(__fmul_rn(bt[q], w), t), __fadd_rn(w, 1.0f));
+                bw[q] = __fadd_rn(w, 1.0f);
+            }
+        }
+    }
+}
+
+// TSDF at voxel lattice point (ix, iy, iz) (global voxel indices, centres at (i + 0.5) * voxel); false when unobserved
+__device__ __forceinline__ bool lattice(const TsdfGrid &g, const int *table, const float *tsdf, const float *weight, int ix, int iy,
+                                        int iz, float &val) {
+    const int64_t s = unit_slot(g, ix >> 4, iy >> 4, iz >> 4);        // arithmetic shift = floor division by 16
+    if (s < 0) return false;
+    const int brick = table[s];
+    if (brick < 0) return false;
+    const int q = ((iz & 15) << 8) | ((iy & 15) << 4) | (ix & 15);
+    if (!(weight[(int64_t)brick * UV + q] > 0.f)) return false;
+    val = tsdf[(int64_t)brick * UV + q];
+    return true;
+}
+
+// TSDF at world point p: trilinear when all eight surrounding lattice points are observed, else the nearest lattice
+// point's value, else false
+__device__ __forceinline__ bool sample(const TsdfGrid &g, const int *table, const float *tsdf, const float *weight, const float *p,
+                                       float inv_voxel, float &val) {
+    float f[3];
+    int i0[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float t = __fsub_rn(__fmul_rn(p[r], inv_voxel), 0.5f);      // lattice coordinate
+        const float fl = floorf(t);
+        i0[r] = (int)fl;
+        f[r] = __fsub_rn(t, fl);
+    }
+    float c[8];
+    bool all = true;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        all = lattice(g, table, tsdf, weight, i0[0] + (k & 1), i0[1] + ((k >> 1) & 1), i0[2] + (k >> 2), c[k]) && all;
+    if (!all) {
+        // a cell with an unobserved corner (typically just behind an obliquely seen surface, where the truncation band
+        // is thinner than a voxel diagonal): fall back to the nearest lattice point, if that one was observed
+        return lattice(g, table, tsdf, weight, i0[0] + (f[0] >= 0.5f ? 1 : 0), i0[1] + (f[1] >= 0.5f ? 1 : 0),
+                       i0[2] + (f[2] >= 0.5f ? 1 : 0), val);
+    }
+    // x, then y, then z
+    const float c00 = __fadd_rn(c[0], __fmul_rn(f[0], __fsub_rn(c[1], c[0])));
+    const float c10 = __fadd_rn(c[2], __fmul_rn(f[0], __fsub_rn(c[3], c[2])));
+    const float c01 = __fadd_rn(c[4], __fmul_rn(f[0], __fsub_rn(c[5], c[4])));
+    const float c11 = __fadd_rn(c[6], __fmul_rn(f[0], __fsub_rn(c[7], c[6])));
+    const float c0 = __fadd_rn(c00, __fmul_rn(f[1], __fsub_rn(c10, c00)));
+    const float c1 = __fadd_rn(c01, __fmul_rn(f[1], __fsub_rn(c11, c01)));
+    val = __fadd_rn(c0, __fmul_rn(f[2], __fsub_rn(c1, c0)));
+    return true;
+}
+
+// depth render: per pixel, march the camera ray; parameter t = view-space z (so the result needs no conversion).
+// Unopened units are crossed with coarse steps (a quarter unit), opened ones with half-voxel steps or, in observed free
+// space, 0.8 x the distance the TSDF value guarantees.
+__global__ void tsdf_raycast_kernel(int H, int W, float fx, float fy, float cx, float cy, const float *__restrict__ c2w, TsdfGrid g,
+                                    float z_near, float z_far, const int *__restrict__ table, const float *__restrict__ tsdf,
+                                    const float *__restrict__ weight, float *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= H * W) return;
+    const int v = i / W, u = i - v * W;
+    // pixel centres at integer coordinates, as in the reference's pinhole set-up (cx, cy in pixel units)
+    const float rx = __fdiv_rn(__fsub_rn((float)u, cx), fx), ry = __fdiv_rn(__fsub_rn((float)v, cy), fy);
+    float o[3], dir[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        o[r] = c2w[r * 4 + 3];
+        dir[r] = __fadd_rn(__fadd_rn(__fmul_rn(c2w[r * 4 + 0], rx), __fmul_rn(c2w[r * 4 + 1], ry)), c2w[r * 4 + 2]);   // per unit z
+    }
+    const float inv_voxel = __fdiv_rn(1.0f, g.voxel);
+    const float fine = __fmul_rn(0.5f, g.voxel), coarse = __fmul_rn(0.25f, g.unit_len);
+    float t = z_near, prev_t = 0.f, prev_val = 0.f, depth = 0.f;
+    bool prev_ok = false;
+    while (t < z_far) {
+        float p[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) p[r] = __fadd_rn(o[r], __fmul_rn(dir[r], t));
+        const int64_t s = unit_slot(g, (int)floorf(__fdiv_rn(p[0], g.unit_len)), (int)floorf(__fdiv_rn(p[1], g.unit_len)),
+                                    (int)floorf(__fdiv_rn(p[2], g.unit_len)));
+        const bool open = s >= 0 && table[s] >= 0;
+        float val = 0.f;
+        const bool ok = open && sample(g, table, tsdf, weight, p, inv_voxel, val);
+        if (ok && prev_ok && prev_val > 0.f && val <= 0.f) {
+            // linear zero crossing between the two samples
+            depth = __fadd_rn(prev_t, __fmul_rn(__fsub_rn(t, prev_t), __fdiv_rn(prev_val, __fsub_rn(prev_val, val))));
+            break;
+        }
+        prev_ok = ok;
+        prev_val = val;
+        prev_t = t;
+        // in front of the surface the TSDF itself bounds the free distance (val * trunc along the ray, taken at 0.8)
+        const float stride = ok && val > 0.f ? fmaxf(fine, __fmul_rn(__fmul_rn(0.8f, val), g.trunc)) : fine;
+        t = __fadd_rn(t, open ? stride : coarse);
+    }
+    out[i] = depth;
+}
+
+int grid_ok(const sgam_tsdf_grid *g) {
+    if (!g || !(g->voxel_length > 0.f) || !(g->sdf_trunc > 0.f)) return 0;
+    for (int r = 0; r < 3; ++r)
+        if (g->unit_dims[r] <= 0) return 0;
+    return ((int64_t)g->unit_dims[0] * g->unit_dims[1] * g->unit_dims[2]) < (1ll << 31);
+}
+
+TsdfGrid to_dev(const sgam_tsdf_grid *g) {
+    TsdfGrid d;
+    d.voxel = g->voxel_length;
+    d.trunc = g->sdf_trunc;
+    d.unit_len = g->voxel_length * (float)UR;
+    for (int r = 0; r < 3; ++r) {
+        d.base[r] = g->unit_base[r];
+        d.dims[r] = g->unit_dims[r];
+    }
+    return d;
+}
+
+}  // namespace
+
+extern "C" int sgam_tsdf_integrate_f32(const sgam_tsdf_grid *grid, const float *depth, int32_t H, int32_t W, float fx, float fy,
+                                       float cx, float cy, const float *cam2world, const float *world2cam, float depth_trunc,
+                                       int32_t frame_id,
+                                       int32_t *unit_table, int32_t *unit_stamp, int32_t *counters, int32_t *brick_list,
+                                       int32_t max_list, float *brick_tsdf, float *brick_weight, int32_t max_bricks,
+                                       void *stream) {
+    if (!grid_ok(grid) || !depth || !(fx > 0.f) || !(fy > 0.f) || !cam2world || !world2cam || !unit_table || !unit_stamp || !counters || !brick_list ||
+        !brick_tsdf || !brick_weight || H <= 0 || W <= 0 || max_list <= 0 || max_bricks <= 0 || frame_id <= 0)
+        return SGAM_EINVAL;
+    const TsdfGrid g = to_dev(grid);
+    hipStream_t s = sgam_stream(stream);
+    hipError_t e = hipMemsetAsync(counters + 1, 0, sizeof(int32_t), s);       // this frame's list length
+    if (e != hipSuccess) return (int)e;
+    const int stride = 4;                                                      // Open3D depth_sampling_stride
+    const int ns = ((W + stride - 1) / stride) * ((H + stride - 1) / stride);
+    hipLaunchKernelGGL(tsdf_touch_kernel, dim3(sgam_cdiv(ns, 256)), dim3(256), 0, s, depth, H, W, fx, fy, cx, cy,
+                       cam2world, g, depth_trunc, stride, unit_table, unit_stamp, frame_id, counters, max_bricks, brick_list,
+                       max_list);
+    SGAM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(tsdf_integrate_kernel, dim3(2048), dim3(256), 0, s, depth, H, W, fx, fy, cx, cy, world2cam, g,
+                       depth_trunc, unit_table, counters, brick_list, max_list, brick_tsdf, brick_weight);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+extern "C" int sgam_tsdf_raycast_depth_f32(const sgam_tsdf_grid *grid, int32_t H, int32_t W, float fx, float fy, float cx,
+                                           float cy, const float *cam2world, float z_near, float z_far, const int32_t *unit_table, const float *brick_tsdf,
+                                           const float *brick_weight, float *depth_out, void *stream) {
+    if (!grid_ok(grid) || !(fx > 0.f) || !(fy > 0.f) || !cam2world || !unit_table || !brick_tsdf || !brick_weight || !depth_out || H <= 0 || W <= 0 ||
+        !(z_near > 0.f) || !(z_far > z_near))
+        return SGAM_EINVAL;
+    const TsdfGrid g = to_dev(grid);
+    hipLaunchKernelGGL(tsdf_raycast_kernel, dim3(sgam_cdiv((int64_t)H * W, 128)), dim3(128), 0, sgam_stream(stream), H, W, fx, fy,
+                       cx, cy, cam2world, g, z_near, z_far, unit_table, brick_tsdf, brick_weight, depth_out);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}

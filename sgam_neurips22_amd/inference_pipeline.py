@@ -10,9 +10,11 @@ the reference's fp32 expression order.  Files are written only by ``export_to_di
 
 Pose grid, zig-zag order, source selection (radius 0.3 / 1.0, nearest ``num_src``) and
 ``T_rel = T_tgt @ inv(T_src)`` are the reference's float64 numpy formulas (host logic, a few 4x4s per
-step).  Not built here: Open3D TSDF fusion (``rgbd_integration``, reference :745-838, SURVEY §8 f1);
-``use_rgbd_integration=True`` therefore needs a ``tgt_depth_provider`` callback that supplies the target
-depth the TSDF render would have produced; ``inverse_warping`` itself is a HIP kernel.
+step).  ``use_rgbd_integration=True`` (reference :745-838: Open3D TSDF fusion of the source frames, mesh
+extraction and an off-screen depth render at the target pose) runs on the device: ``tsdf.TsdfVolume``
+integrates the source depth maps with Open3D's published rule and ray-casts the fused surface
+(csrc/tsdf.hip; SURVEY §8 f1 — parity pinned to oracle/tsdf.py and analytic scenes, not to Open3D itself);
+a ``tgt_depth_provider`` callback can still replace it.  ``inverse_warping`` is a HIP kernel.
 """
 import os
 from pathlib import Path
@@ -124,10 +126,43 @@ class InfiniteSceneGeneration:
         self._ordered_grid_coords = self.zig_zag_order()
         self._store_seed(seed_frame)
         self.dynamic_model.use_rgbd_integration = use_rgbd_integration
+        self.volume = None
+        if use_rgbd_integration and tgt_depth_provider is None:
+            self.volume = self._make_volume()
         K32 = torch.from_numpy(self.K.astype(np.float32))
         # host-side fp32 inverse like the reference (warp.py:210 / inference_pipeline.py:694), done once
         self._K_dev = K32.to(self.device)
         self._Kinv_dev = torch.inverse(K32).to(self.device)
+
+    # ---------------------------------------------------------------- TSDF fusion (reference :119-133, 745-838)
+    # view-space z range of valid depths per dataset: the inverse-depth codec's bounds (model.py:210-229)
+    _Z_RANGE = {"google_earth": (0.05, 4.8), "clevr-infinite": (1.0, 16.5)}
+
+    def _make_volume(self):
+        from .tsdf import VOLUME_PARAMS, TsdfVolume, frustum_bounds, UNIT
+        voxel, trunc = VOLUME_PARAMS[self.data]
+        poses = []
+        for row in self.transform_grid:
+            for node in row:
+                T = np.eye(4)
+                T[:3, :3], T[:3, 3] = node["R"], node["t"]
+                poses.append(T)
+        H, W = self.image_resolution
+        lo, hi = frustum_bounds(self.K, poses, H, W, self._Z_RANGE[self.data][1], margin=trunc + voxel * UNIT)
+        return TsdfVolume(voxel, trunc, lo, hi, self.device, memory_budget_bytes=16 << 30)
+
+    def rgbd_integration(self, src_nodes, tgt_node):
+        """reference :745-838: integrate every source frame of this step (again — the volume is cumulative, like the
+        reference's self.volume), then render the fused surface's depth at the target pose.  (H,W) device fp32."""
+        for s in src_nodes:
+            T = np.eye(4)
+            T[:3, :3], T[:3, 3] = s["R"], s["t"]
+            self.volume.integrate(self._src_depth(s["grid_coord"]), self.K, T)
+        T = np.eye(4)
+        T[:3, :3], T[:3, 3] = tgt_node["R"], tgt_node["t"]
+        H, W = self.image_resolution
+        z0, z1 = self._Z_RANGE[self.data]
+        return self.volume.render_depth(self.K, T, H, W, z0, z1)
 
     # ---------------------------------------------------------------- grid / order / source choice
     def prepare_grid(self, grid_size):
@@ -227,11 +262,10 @@ class InfiniteSceneGeneration:
             "src_imgs": src_imgs, "src_depths": src_depths,
         }
         if self.use_rgbd_integration:
-            if self.tgt_depth_provider is None:
-                raise NotImplementedError(
-                    "use_rgbd_integration needs the Open3D TSDF depth render (reference :745-838), which is not "
-                    "part of this backend yet: pass tgt_depth_provider=callable(scene, tgt_node, src_nodes, batch)")
-            tgt_depth = self.tgt_depth_provider(self, tgt_node, src_nodes, batch)      # (H,W) device fp32
+            if self.tgt_depth_provider is not None:
+                tgt_depth = self.tgt_depth_provider(self, tgt_node, src_nodes, batch)      # (H,W) device fp32
+            else:
+                tgt_depth = self.rgbd_integration(src_nodes, tgt_node)
             warped = self.inverse_warping(src_imgs.permute(0, 1, 4, 2, 3).contiguous(), src_depths, tgt_depth[None],
                                           batch["Ks"], self._K_dev[None], f32(T_tgt2srcs)[None], as_numpy=False)
             batch["warped_tgt_features"] = warped[None]

@@ -1,0 +1,95 @@
+"""TSDF fusion of the generated RGB-D frames and the depth render at the next target pose — the
+``rgbd_integration`` conditioning branch (reference sgam/inference_pipeline.py:119-133 and 745-838, which
+delegates to Open3D 0.15.2).  Device side: csrc/tsdf.hip; this file sizes and owns the state.
+
+State for one scene, all in HBM and allocated once (no growth, no host round trip per frame):
+  unit table   int32 [dz][dy][dx]   direct-mapped over the scene's bounding box (units of 16 voxels)
+  brick pool   fp32 tsdf + fp32 weight, 16^3 voxels per brick, bump-allocated on the device
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import TsdfGrid, check
+
+UNIT = 16
+# (voxel_length, sdf_trunc) per dataset: reference inference_pipeline.py:119-133
+VOLUME_PARAMS = {"clevr-infinite": (0.05, 0.5), "google_earth": (0.01, 0.03)}
+DEPTH_TRUNC = 20.0          # RGBDImage.create_from_color_and_depth(depth_trunc=20), :772
+
+
+def frustum_bounds(K, poses_w2c, H, W, z_far, margin):
+    """Axis-aligned world box of the camera frusta (apex + far-plane corners) of all poses, grown by `margin`."""
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    corners = np.array([[(u - cx) / fx * z_far, (v - cy) / fy * z_far, z_far, 1.0]
+                        for u in (0.0, W - 1.0) for v in (0.0, H - 1.0)] + [[0.0, 0.0, 0.0, 1.0]])
+    pts = []
+    for T in poses_w2c:
+        pts.append((np.linalg.inv(np.asarray(T, dtype=np.float64)) @ corners.T).T[:, :3])
+    pts = np.concatenate(pts)
+    return pts.min(0) - margin, pts.max(0) + margin
+
+
+class TsdfVolume:
+    def __init__(self, voxel_length, sdf_trunc, lo, hi, device, max_bricks=None, memory_budget_bytes=48 << 30):
+        """lo / hi: world-space box the scene can occupy (see frustum_bounds).  max_bricks defaults to what
+        `memory_budget_bytes` of brick pool holds (32 KB per brick), capped at the number of units in the box."""
+        self.voxel_length, self.sdf_trunc = float(voxel_length), float(sdf_trunc)
+        unit_len = np.float32(voxel_length) * np.float32(UNIT)
+        base = np.floor(np.asarray(lo, dtype=np.float64) / float(unit_len)).astype(np.int64)
+        top = np.floor(np.asarray(hi, dtype=np.float64) / float(unit_len)).astype(np.int64)
+        dims = top - base + 1
+        n_units = int(dims.prod())
+        if n_units >= 2 ** 31:
+            raise ops.SgamHipError(f"TSDF box of {tuple(dims)} units does not fit the int32 unit table; shrink the scene box")
+        if max_bricks is None:
+            max_bricks = max(1, min(n_units, memory_budget_bytes // (UNIT ** 3 * 8)))
+        self.base, self.dims, self.max_bricks, self.device = base, dims, int(max_bricks), device
+        self.grid = TsdfGrid(np.float32(voxel_length), np.float32(sdf_trunc), (ctypes.c_int32 * 3)(*map(int, base)),
+                             (ctypes.c_int32 * 3)(*map(int, dims)))
+        self.unit_table = torch.full((n_units,), -1, dtype=torch.int32, device=device)
+        self.unit_stamp = torch.zeros((n_units,), dtype=torch.int32, device=device)
+        self.counters = torch.zeros((4,), dtype=torch.int32, device=device)
+        self.brick_tsdf = torch.zeros((self.max_bricks, UNIT ** 3), dtype=torch.float32, device=device)
+        self.brick_weight = torch.zeros((self.max_bricks, UNIT ** 3), dtype=torch.float32, device=device)
+        self.max_list = int(min(n_units, 1 << 22))
+        self.brick_list = torch.empty((self.max_list,), dtype=torch.int32, device=device)
+        self.frame_id = 0
+
+    @staticmethod
+    def _k4(K):
+        K = np.asarray(K, dtype=np.float32)
+        return float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2])
+
+    def integrate(self, depth, K, T_w2c):
+        """depth (H,W) fp32 device tensor, K 3x3, T_w2c 4x4 world->camera (the reference's extrinsic [R|t])."""
+        ops._need_cuda(depth)
+        H, W = depth.shape
+        T = np.asarray(T_w2c, dtype=np.float64)
+        w2c = torch.from_numpy(T.astype(np.float32)).to(self.device)
+        c2w = torch.from_numpy(np.linalg.inv(T).astype(np.float32)).to(self.device)
+        self.frame_id += 1
+        fx, fy, cx, cy = self._k4(K)
+        d = depth.contiguous()
+        check(_lib.load().sgam_tsdf_integrate_f32(
+            ctypes.byref(self.grid), ops._p(d), H, W, fx, fy, cx, cy, ops._p(c2w), ops._p(w2c), DEPTH_TRUNC, self.frame_id,
+            ops._p(self.unit_table), ops._p(self.unit_stamp), ops._p(self.counters), ops._p(self.brick_list), self.max_list,
+            ops._p(self.brick_tsdf), ops._p(self.brick_weight), self.max_bricks, ops._stream()), "sgam_tsdf_integrate_f32")
+
+    def render_depth(self, K, T_w2c, H, W, z_near, z_far):
+        """View-space z of the fused surface at the pose, (H,W) fp32, 0 where nothing is hit."""
+        T = np.asarray(T_w2c, dtype=np.float64)
+        c2w = torch.from_numpy(np.linalg.inv(T).astype(np.float32)).to(self.device)
+        out = torch.empty((H, W), dtype=torch.float32, device=self.device)
+        fx, fy, cx, cy = self._k4(K)
+        check(_lib.load().sgam_tsdf_raycast_depth_f32(
+            ctypes.byref(self.grid), H, W, fx, fy, cx, cy, ops._p(c2w), float(z_near), float(z_far), ops._p(self.unit_table),
+            ops._p(self.brick_tsdf), ops._p(self.brick_weight), ops._p(out), ops._stream()), "sgam_tsdf_raycast_depth_f32")
+        return out
+
+    def stats(self):
+        """(bricks allocated, last frame's brick count, samples outside the box, pool overflows) — host sync."""
+        return tuple(int(v) for v in self.counters.cpu())
