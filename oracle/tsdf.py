@@ -17,6 +17,7 @@ class TsdfOracle:
         self.voxel, self.trunc = F(voxel_length), F(sdf_trunc)
         self.unit_len = F(self.voxel * F(UR))
         self.units = {}          # (ux, uy, uz) -> [tsdf (16,16,16) indexed [z][y][x], weight]
+        self.near = set()        # units the ray cast marches (everything else is crossed like empty space)
 
     def integrate(self, depth, K, T_w2c, depth_trunc=20.0, stride=4):
         depth = np.asarray(depth, dtype=F)
@@ -68,6 +69,8 @@ class TsdfOracle:
             new_t = ((t * w + tv) / (w + F(1.0))).astype(F)
             t[m] = new_t[m]
             w[m] = (w + F(1.0))[m]
+            if (new_t[m] < F(1.0)).any():
+                self.near.add(key)     # holds an observed value inside the truncation band
 
     def _lattice(self, ix, iy, iz):
         u = self.units.get((ix >> 4, iy >> 4, iz >> 4))
@@ -106,23 +109,41 @@ class TsdfOracle:
         c2w = np.linalg.inv(np.asarray(T_w2c, dtype=np.float64)).astype(F)
         out = np.zeros((H, W), F)
         inv_voxel = F(1.0) / self.voxel
-        fine, coarse = F(F(0.5) * self.voxel), F(F(0.25) * self.unit_len)
+        fine, eps = F(F(0.5) * self.voxel), F(F(0.25) * self.voxel)
         todo = pixels if pixels is not None else [(v, u) for v in range(H) for u in range(W)]
         for v, u in todo:
             rx, ry = F((F(u) - cx) / fx), F((F(v) - cy) / fy)
             o = [c2w[r, 3] for r in range(3)]
             d = [F(F(F(c2w[r, 0] * rx) + F(c2w[r, 1] * ry)) + c2w[r, 2]) for r in range(3)]
-            t, prev_t, prev_val, prev_ok = F(z_near), F(0), F(0), False
-            while t < F(z_far):
-                p = [F(o[r] + F(d[r] * t)) for r in range(3)]
-                key = tuple(int(np.floor(F(p[r] / self.unit_len))) for r in range(3))
-                is_open = key in self.units
-                val = self._sample(p, inv_voxel) if is_open else None
-                ok = val is not None
-                if ok and prev_ok and prev_val > 0 and val <= 0:
-                    out[v, u] = F(prev_t + F(F(t - prev_t) * F(prev_val / F(prev_val - val))))
-                    break
-                prev_ok, prev_val, prev_t = ok, (val if ok else F(0)), t
-                stride = max(fine, F(F(F(0.8) * val) * self.trunc)) if (ok and val > 0) else fine
-                t = F(t + (stride if is_open else coarse))
+            RS = 4
+            seg_len = F(F(F(z_far) - F(z_near)) / F(RS))
+            best = None
+            for seg in range(RS):           # the device marches the RS segments on adjacent lanes; nearest hit wins
+                t_begin = F(F(z_near) + F(F(seg) * seg_len))
+                t_end = min(F(z_far), F(F(t_begin + seg_len) + F(F(2.0) * self.voxel)))
+                t, prev_t, prev_val, prev_ok = t_begin, F(0), F(0), False
+                while t < t_end:
+                    p = [F(o[r] + F(d[r] * t)) for r in range(3)]
+                    uf = [np.floor(F(p[r] / self.unit_len)) for r in range(3)]
+                    key = tuple(int(x) for x in uf)
+                    is_open = key in self.near
+                    coarse = F(z_far)
+                    for r in range(3):
+                        if d[r] > 0:
+                            coarse = min(coarse, F(F(F(F(uf[r] + F(1)) * self.unit_len) - p[r]) / d[r]))
+                        elif d[r] < 0:
+                            coarse = min(coarse, F(F(F(F(uf[r]) * self.unit_len) - p[r]) / d[r]))
+                    coarse = F(max(coarse, F(0)) + eps)
+                    val = self._sample(p, inv_voxel) if is_open else None
+                    ok = val is not None
+                    if ok and prev_ok and prev_val > 0 and val <= 0:
+                        hit = F(prev_t + F(F(t - prev_t) * F(prev_val / F(prev_val - val))))
+                        if hit > 0 and (best is None or hit < best):
+                            best = hit
+                        break
+                    prev_ok, prev_val, prev_t = ok, (val if ok else F(0)), t
+                    stride = (max(fine, F(F(F(0.8) * val) * self.trunc)) if val > 0 else fine) if ok else self.voxel
+                    t = F(t + (stride if is_open else coarse))
+            if best is not None:
+                out[v, u] = best
         return out

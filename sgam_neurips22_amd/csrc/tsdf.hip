@@ -31,6 +31,11 @@ namespace {
 
 constexpr int UR = 16;                 // voxels per unit edge (Open3D volume_unit_resolution)
 constexpr int UV = UR * UR * UR;       // voxels per brick
+constexpr int RS = 4;                  // depth segments (lanes) per ray in the ray cast
+
+struct Pose {
+    float m[16];                       // row-major 4x4, passed by value in the kernel arguments
+};
 
 struct TsdfGrid {
     float voxel, trunc, unit_len;      // unit_len = 16 * voxel
@@ -46,9 +51,10 @@ __device__ __forceinline__ int64_t unit_slot(const TsdfGrid &g, int ux, int uy, 
 // pass 1: open the units around the back-projected depth samples; units seen for the first time in this frame
 // (stamp != frame_id) are appended once to the frame's brick list.
 __global__ void tsdf_touch_kernel(const float *__restrict__ depth, int H, int W, float fx, float fy, float cx, float cy,
-                                  const float *__restrict__ c2w, TsdfGrid g, float depth_trunc, int stride,
+                                  const Pose c2w_, TsdfGrid g, float depth_trunc, int stride,
                                   int *__restrict__ table, int *__restrict__ stamp, int frame_id, int *__restrict__ counters,
                                   int max_bricks, int *__restrict__ list, int max_list) {
+    const float *c2w = c2w_.m;
     const int sw = (W + stride - 1) / stride, sh = (H + stride - 1) / stride;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= sw * sh) return;
@@ -96,10 +102,12 @@ __global__ void tsdf_touch_kernel(const float *__restrict__ depth, int H, int W,
 
 // pass 2: one workgroup per listed brick (grid-stride over the device-side list), 256 lanes x 16 voxels.
 __global__ __launch_bounds__(256) void tsdf_integrate_kernel(const float *__restrict__ depth, int H, int W, float fx, float fy,
-                                                             float cx, float cy, const float *__restrict__ w2c, TsdfGrid g,
+                                                             float cx, float cy, const Pose w2c_, TsdfGrid g,
                                                              float depth_trunc, const int *__restrict__ table, const int *__restrict__ counters,
                                                              const int *__restrict__ list, int max_list,
-                                                             float *__restrict__ tsdf, float *__restrict__ weight) {
+                                                             float *__restrict__ tsdf, float *__restrict__ weight,
+                                                             int *__restrict__ near_flag) {
+    const float *w2c = w2c_.m;
     int n = counters[1];
     if (n > max_list) n = max_list;
     const float inv_trunc = __fdiv_rn(1.0f, g.trunc);
@@ -111,6 +119,7 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(const float *__rest
         const int uy = (s / g.dims[0]) % g.dims[1] + g.base[1];
         const int uz = s / (g.dims[0] * g.dims[1]) + g.base[2];
         float *bt = tsdf + (int64_t)brick * UV, *bw = weight + (int64_t)brick * UV;
+        int near = 0;                 // this brick holds an observed voxel inside the truncation band (value < 1)
         for (int q = threadIdx.x; q < UV; q += 256) {
             const int x = q & 15, y = (q >> 4) & 15, z = q >> 8;
             // voxel centre: unit origin + (i + 0.5) * voxel
@@ -136,10 +145,14 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(const float *__rest
             if (sdf > -g.trunc) {
                 const float t = fminf(1.0f, __fmul_rn(sdf, inv_trunc));
                 const float w = bw[q];
-                bt[q] = __fdiv_rn(__fadd_rn(__fmul_rn(bt[q], w), t), __fadd_rn(w, 1.0f));
+                const float nt = __fdiv_rn(__fadd_rn(__fmul_rn(bt[q], w), t), __fadd_rn(w, 1.0f));
+                bt[q] = nt;
                 bw[q] = __fadd_rn(w, 1.0f);
+                near |= nt < 1.0f;
             }
         }
+        // a weighted mean of values <= 1 that is < 1 once stays < 1: the flag is monotone, a plain store suffices
+        if (__syncthreads_or(near) && threadIdx.x == 0) near_flag[brick] = 1;
     }
 }
 
@@ -171,9 +184,24 @@ __device__ __forceinline__ bool sample(const TsdfGrid &g, const int *table, cons
     }
     float c[8];
     bool all = true;
+    if ((i0[0] & 15) < 15 && (i0[1] & 15) < 15 && (i0[2] & 15) < 15) {
+        // the whole cell lies in one brick: one table lookup, eight (weight, value) pairs
+        const int64_t s = unit_slot(g, i0[0] >> 4, i0[1] >> 4, i0[2] >> 4);
+        const int brick = s >= 0 ? table[s] : -1;
+        if (brick < 0) return false;
+        const int q0 = ((i0[2] & 15) << 8) | ((i0[1] & 15) << 4) | (i0[0] & 15);
+        const float *bw = weight + (int64_t)brick * UV + q0, *bt = tsdf + (int64_t)brick * UV + q0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-        all = lattice(g, table, tsdf, weight, i0[0] + (k & 1), i0[1] + ((k >> 1) & 1), i0[2] + (k >> 2), c[k]) && all;
+        for (int k = 0; k < 8; ++k) {
+            const int o = (k & 1) + ((k >> 1) & 1) * 16 + (k >> 2) * 256;
+            all = all && bw[o] > 0.f;
+            c[k] = bt[o];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            all = lattice(g, table, tsdf, weight, i0[0] + (k & 1), i0[1] + ((k >> 1) & 1), i0[2] + (k >> 2), c[k]) && all;
+    }
     if (!all) {
         // a cell with an unobserved corner (typically just behind an obliquely seen surface, where the truncation band
         // is thinner than a voxel diagonal): fall back to the nearest lattice point, if that one was observed
@@ -192,14 +220,21 @@ __device__ __forceinline__ bool sample(const TsdfGrid &g, const int *table, cons
 }
 
 // depth render: per pixel, march the camera ray; parameter t = view-space z (so the result needs no conversion).
-// Unopened units are crossed with coarse steps (a quarter unit), opened ones with half-voxel steps or, in observed free
+// Unopened units are crossed in one step each (exit distance of the unit along the ray + a quarter voxel), opened ones with half-voxel steps or, in observed free
 // space, 0.8 x the distance the TSDF value guarantees.
-__global__ void tsdf_raycast_kernel(int H, int W, float fx, float fy, float cx, float cy, const float *__restrict__ c2w, TsdfGrid g,
+__global__ void tsdf_raycast_kernel(int H, int W, float fx, float fy, float cx, float cy, const Pose c2w_, TsdfGrid g,
                                     float z_near, float z_far, const int *__restrict__ table, const float *__restrict__ tsdf,
-                                    const float *__restrict__ weight, float *__restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= H * W) return;
-    const int v = i / W, u = i - v * W;
+                                    const float *__restrict__ weight, const int *__restrict__ near_flag, float *__restrict__ out) {
+    // The march is a chain of dependent loads (unit table -> brick -> values), i.e. latency-bound, and a 256 x 256 view is
+    // only one wavefront per SIMD: every ray is cut into RS depth segments marched by RS adjacent lanes (each starts with
+    // no history and runs two voxels into the next segment so that a crossing on a boundary is seen by the earlier one);
+    // the nearest hit wins.
+    const float *c2w = c2w_.m;
+    const int gi = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = gi / RS, seg = gi - i * RS;
+    const bool live = i < H * W;
+    const int ii = live ? i : 0;
+    const int v = ii / W, u = ii - v * W;
     // pixel centres at integer coordinates, as in the reference's pinhole set-up (cx, cy in pixel units)
     const float rx = __fdiv_rn(__fsub_rn((float)u, cx), fx), ry = __fdiv_rn(__fsub_rn((float)v, cy), fy);
     float o[3], dir[3];
@@ -209,16 +244,35 @@ __global__ void tsdf_raycast_kernel(int H, int W, float fx, float fy, float cx, 
         dir[r] = __fadd_rn(__fadd_rn(__fmul_rn(c2w[r * 4 + 0], rx), __fmul_rn(c2w[r * 4 + 1], ry)), c2w[r * 4 + 2]);   // per unit z
     }
     const float inv_voxel = __fdiv_rn(1.0f, g.voxel);
-    const float fine = __fmul_rn(0.5f, g.voxel), coarse = __fmul_rn(0.25f, g.unit_len);
-    float t = z_near, prev_t = 0.f, prev_val = 0.f, depth = 0.f;
+    const float fine = __fmul_rn(0.5f, g.voxel), eps = __fmul_rn(0.25f, g.voxel);
+    const float seg_len = __fdiv_rn(__fsub_rn(z_far, z_near), (float)RS);
+    const float t_begin = __fadd_rn(z_near, __fmul_rn((float)seg, seg_len));
+    const float t_end = fminf(z_far, __fadd_rn(__fadd_rn(t_begin, seg_len), __fmul_rn(2.0f, g.voxel)));
+    float t = t_begin, prev_t = 0.f, prev_val = 0.f, depth = 0.f;
     bool prev_ok = false;
-    while (t < z_far) {
+#ifdef SGAM_TSDF_DEBUG_STEPS
+    int n_coarse = 0, n_fine = 0;
+#endif
+    while (live && t < t_end) {
         float p[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) p[r] = __fadd_rn(o[r], __fmul_rn(dir[r], t));
-        const int64_t s = unit_slot(g, (int)floorf(__fdiv_rn(p[0], g.unit_len)), (int)floorf(__fdiv_rn(p[1], g.unit_len)),
-                                    (int)floorf(__fdiv_rn(p[2], g.unit_len)));
-        const bool open = s >= 0 && table[s] >= 0;
+        float uf[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) uf[r] = floorf(__fdiv_rn(p[r], g.unit_len));
+        const int64_t s = unit_slot(g, (int)uf[0], (int)uf[1], (int)uf[2]);
+        // only bricks that hold part of the truncation band can contain the surface: everything else (unopened units,
+        // bricks of observed free space, bricks with nothing observed) is crossed like empty space
+        const int brick_here = s >= 0 ? table[s] : -1;
+        const bool open = brick_here >= 0 && near_flag[brick_here] != 0;
+        // such a unit is left in ONE step: distance (in t) to the nearest of its faces the ray is heading for
+        float coarse = z_far;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            if (dir[r] > 0.f) coarse = fminf(coarse, __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(uf[r], 1.0f), g.unit_len), p[r]), dir[r]));
+            else if (dir[r] < 0.f) coarse = fminf(coarse, __fdiv_rn(__fsub_rn(__fmul_rn(uf[r], g.unit_len), p[r]), dir[r]));
+        }
+        coarse = __fadd_rn(fmaxf(coarse, 0.f), eps);
         float val = 0.f;
         const bool ok = open && sample(g, table, tsdf, weight, p, inv_voxel, val);
         if (ok && prev_ok && prev_val > 0.f && val <= 0.f) {
@@ -230,10 +284,23 @@ __global__ void tsdf_raycast_kernel(int H, int W, float fx, float fy, float cx, 
         prev_val = val;
         prev_t = t;
         // in front of the surface the TSDF itself bounds the free distance (val * trunc along the ray, taken at 0.8)
-        const float stride = ok && val > 0.f ? fmaxf(fine, __fmul_rn(__fmul_rn(0.8f, val), g.trunc)) : fine;
+        // (unobserved space inside an opened unit: whole-voxel steps)
+        const float stride = ok ? (val > 0.f ? fmaxf(fine, __fmul_rn(__fmul_rn(0.8f, val), g.trunc)) : fine) : g.voxel;
         t = __fadd_rn(t, open ? stride : coarse);
+#ifdef SGAM_TSDF_DEBUG_STEPS
+        if (open) ++n_fine; else ++n_coarse;
+#endif
     }
-    out[i] = depth;
+#ifdef SGAM_TSDF_DEBUG_STEPS
+    depth = (float)(n_coarse * 10000 + n_fine);
+    if (live && seg == 0) out[i] = depth;
+    return;
+#endif
+    // nearest hit over the RS lanes of this pixel (0 = no hit)
+    float best = depth > 0.f ? depth : 3.0e38f;
+#pragma unroll
+    for (int o = 1; o < RS; o <<= 1) best = fminf(best, __shfl_xor(best, o, 64));
+    if (live && seg == 0) out[i] = best < 3.0e38f ? best : 0.f;
 }
 
 int grid_ok(const sgam_tsdf_grid *g) {
@@ -261,10 +328,10 @@ extern "C" int sgam_tsdf_integrate_f32(const sgam_tsdf_grid *grid, const float *
                                        float cx, float cy, const float *cam2world, const float *world2cam, float depth_trunc,
                                        int32_t frame_id,
                                        int32_t *unit_table, int32_t *unit_stamp, int32_t *counters, int32_t *brick_list,
-                                       int32_t max_list, float *brick_tsdf, float *brick_weight, int32_t max_bricks,
-                                       void *stream) {
+                                       int32_t max_list, float *brick_tsdf, float *brick_weight, int32_t *brick_near,
+                                       int32_t max_bricks, void *stream) {
     if (!grid_ok(grid) || !depth || !(fx > 0.f) || !(fy > 0.f) || !cam2world || !world2cam || !unit_table || !unit_stamp || !counters || !brick_list ||
-        !brick_tsdf || !brick_weight || H <= 0 || W <= 0 || max_list <= 0 || max_bricks <= 0 || frame_id <= 0)
+        !brick_tsdf || !brick_weight || !brick_near || H <= 0 || W <= 0 || max_list <= 0 || max_bricks <= 0 || frame_id <= 0)
         return SGAM_EINVAL;
     const TsdfGrid g = to_dev(grid);
     hipStream_t s = sgam_stream(stream);
@@ -272,25 +339,34 @@ extern "C" int sgam_tsdf_integrate_f32(const sgam_tsdf_grid *grid, const float *
     if (e != hipSuccess) return (int)e;
     const int stride = 4;                                                      // Open3D depth_sampling_stride
     const int ns = ((W + stride - 1) / stride) * ((H + stride - 1) / stride);
+    Pose c2w, w2c;
+    for (int i = 0; i < 16; ++i) {
+        c2w.m[i] = cam2world[i];
+        w2c.m[i] = world2cam[i];
+    }
     hipLaunchKernelGGL(tsdf_touch_kernel, dim3(sgam_cdiv(ns, 256)), dim3(256), 0, s, depth, H, W, fx, fy, cx, cy,
-                       cam2world, g, depth_trunc, stride, unit_table, unit_stamp, frame_id, counters, max_bricks, brick_list,
+                       c2w, g, depth_trunc, stride, unit_table, unit_stamp, frame_id, counters, max_bricks, brick_list,
                        max_list);
     SGAM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(tsdf_integrate_kernel, dim3(2048), dim3(256), 0, s, depth, H, W, fx, fy, cx, cy, world2cam, g,
-                       depth_trunc, unit_table, counters, brick_list, max_list, brick_tsdf, brick_weight);
+    hipLaunchKernelGGL(tsdf_integrate_kernel, dim3(2048), dim3(256), 0, s, depth, H, W, fx, fy, cx, cy, w2c, g,
+                       depth_trunc, unit_table, counters, brick_list, max_list, brick_tsdf, brick_weight, brick_near);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
 }
 
 extern "C" int sgam_tsdf_raycast_depth_f32(const sgam_tsdf_grid *grid, int32_t H, int32_t W, float fx, float fy, float cx,
                                            float cy, const float *cam2world, float z_near, float z_far, const int32_t *unit_table, const float *brick_tsdf,
-                                           const float *brick_weight, float *depth_out, void *stream) {
-    if (!grid_ok(grid) || !(fx > 0.f) || !(fy > 0.f) || !cam2world || !unit_table || !brick_tsdf || !brick_weight || !depth_out || H <= 0 || W <= 0 ||
+                                           const float *brick_weight, const int32_t *brick_near, float *depth_out,
+                                           void *stream) {
+    if (!grid_ok(grid) || !(fx > 0.f) || !(fy > 0.f) || !cam2world || !unit_table || !brick_tsdf || !brick_weight || !brick_near ||
+        !depth_out || H <= 0 || W <= 0 ||
         !(z_near > 0.f) || !(z_far > z_near))
         return SGAM_EINVAL;
     const TsdfGrid g = to_dev(grid);
-    hipLaunchKernelGGL(tsdf_raycast_kernel, dim3(sgam_cdiv((int64_t)H * W, 128)), dim3(128), 0, sgam_stream(stream), H, W, fx, fy,
-                       cx, cy, cam2world, g, z_near, z_far, unit_table, brick_tsdf, brick_weight, depth_out);
+    Pose c2w;
+    for (int i = 0; i < 16; ++i) c2w.m[i] = cam2world[i];
+    hipLaunchKernelGGL(tsdf_raycast_kernel, dim3(sgam_cdiv((int64_t)H * W * RS, 256)), dim3(256), 0, sgam_stream(stream), H, W, fx, fy,
+                       cx, cy, c2w, g, z_near, z_far, unit_table, brick_tsdf, brick_weight, brick_near, depth_out);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
 }

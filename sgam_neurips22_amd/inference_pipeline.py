@@ -267,18 +267,22 @@ class InfiniteSceneGeneration:
             else:
                 tgt_depth = self.rgbd_integration(src_nodes, tgt_node)
             warped = self.inverse_warping(src_imgs.permute(0, 1, 4, 2, 3).contiguous(), src_depths, tgt_depth[None],
-                                          batch["Ks"], self._K_dev[None], f32(T_tgt2srcs)[None], as_numpy=False)
+                                          batch["Ks"], self._K_dev[None], f32(T_tgt2srcs)[None], as_numpy=False,
+                                          tgt_Kinv=self._Kinv_dev[None])
             batch["warped_tgt_features"] = warped[None]
             batch["warped_tgt_depth"] = tgt_depth[None]
         return batch
 
     def inverse_warping(self, src_imgs, src_depths, tgt_depth, src_intrinsics, tgt_intrinsic, T_tgt2srcs,
-                        padding_mode='zeros', depth_threshold=100, as_numpy=True):
+                        padding_mode='zeros', depth_threshold=100, as_numpy=True, tgt_Kinv=None):
         """reference :662-743; returns item 0 of the (B,3,H,W) result ((3,H,W) numpy like the reference, or a
         device tensor with as_numpy=False)."""
         B, N = src_imgs.shape[:2]
         dev = src_imgs.device
-        Kinv = torch.inverse(tgt_intrinsic.detach().to("cpu", torch.float32).reshape(B, 3, 3)).to(dev)
+        # fp32 inverse on the host like the reference (:694); callers that hold it already (the scene loop: one fixed K)
+        # pass tgt_Kinv and skip the device->host round trip, which would otherwise serialise host and GPU every step
+        Kinv = tgt_Kinv if tgt_Kinv is not None else \
+            torch.inverse(tgt_intrinsic.detach().to("cpu", torch.float32).reshape(B, 3, 3)).to(dev)
         out = ops.inverse_warp(src_imgs, src_depths, tgt_depth, src_intrinsics.reshape(B * N, 3, 3), Kinv,
                                T_tgt2srcs.reshape(B * N, 4, 4))
         return out.cpu().numpy()[0] if as_numpy else out[0]

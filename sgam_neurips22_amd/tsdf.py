@@ -55,6 +55,7 @@ class TsdfVolume:
         self.counters = torch.zeros((4,), dtype=torch.int32, device=device)
         self.brick_tsdf = torch.zeros((self.max_bricks, UNIT ** 3), dtype=torch.float32, device=device)
         self.brick_weight = torch.zeros((self.max_bricks, UNIT ** 3), dtype=torch.float32, device=device)
+        self.brick_near = torch.zeros((self.max_bricks,), dtype=torch.int32, device=device)
         self.max_list = int(min(n_units, 1 << 22))
         self.brick_list = torch.empty((self.max_list,), dtype=torch.int32, device=device)
         self.frame_id = 0
@@ -69,25 +70,27 @@ class TsdfVolume:
         ops._need_cuda(depth)
         H, W = depth.shape
         T = np.asarray(T_w2c, dtype=np.float64)
-        w2c = torch.from_numpy(T.astype(np.float32)).to(self.device)
-        c2w = torch.from_numpy(np.linalg.inv(T).astype(np.float32)).to(self.device)
+        w2c = np.ascontiguousarray(T, dtype=np.float32)                      # host 4x4s: passed by value to the kernels
+        c2w = np.ascontiguousarray(np.linalg.inv(T), dtype=np.float32)
         self.frame_id += 1
         fx, fy, cx, cy = self._k4(K)
         d = depth.contiguous()
         check(_lib.load().sgam_tsdf_integrate_f32(
-            ctypes.byref(self.grid), ops._p(d), H, W, fx, fy, cx, cy, ops._p(c2w), ops._p(w2c), DEPTH_TRUNC, self.frame_id,
+            ctypes.byref(self.grid), ops._p(d), H, W, fx, fy, cx, cy, c2w.ctypes.data, w2c.ctypes.data, DEPTH_TRUNC, self.frame_id,
             ops._p(self.unit_table), ops._p(self.unit_stamp), ops._p(self.counters), ops._p(self.brick_list), self.max_list,
-            ops._p(self.brick_tsdf), ops._p(self.brick_weight), self.max_bricks, ops._stream()), "sgam_tsdf_integrate_f32")
+            ops._p(self.brick_tsdf), ops._p(self.brick_weight), ops._p(self.brick_near), self.max_bricks, ops._stream()),
+            "sgam_tsdf_integrate_f32")
 
     def render_depth(self, K, T_w2c, H, W, z_near, z_far):
         """View-space z of the fused surface at the pose, (H,W) fp32, 0 where nothing is hit."""
         T = np.asarray(T_w2c, dtype=np.float64)
-        c2w = torch.from_numpy(np.linalg.inv(T).astype(np.float32)).to(self.device)
+        c2w = np.ascontiguousarray(np.linalg.inv(T), dtype=np.float32)
         out = torch.empty((H, W), dtype=torch.float32, device=self.device)
         fx, fy, cx, cy = self._k4(K)
         check(_lib.load().sgam_tsdf_raycast_depth_f32(
-            ctypes.byref(self.grid), H, W, fx, fy, cx, cy, ops._p(c2w), float(z_near), float(z_far), ops._p(self.unit_table),
-            ops._p(self.brick_tsdf), ops._p(self.brick_weight), ops._p(out), ops._stream()), "sgam_tsdf_raycast_depth_f32")
+            ctypes.byref(self.grid), H, W, fx, fy, cx, cy, c2w.ctypes.data, float(z_near), float(z_far), ops._p(self.unit_table),
+            ops._p(self.brick_tsdf), ops._p(self.brick_weight), ops._p(self.brick_near), ops._p(out), ops._stream()),
+            "sgam_tsdf_raycast_depth_f32")
         return out
 
     def stats(self):
