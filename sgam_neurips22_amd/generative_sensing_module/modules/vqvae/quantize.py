@@ -80,32 +80,41 @@ class VectorQuantizer2(nn.Module):
         self.embedding.weight.data.copy_(w)
 
     def sample_nhwc(self, z_nhwc, topk, sample_number, extrapolation_mask):
-        """get_multiple_codewords on an NHWC latent.  Returns z_qs (1,S,h,w,D) NHWC-per-sample and
-        indices (1,S,h,w).  Batch 1 / 16x16 only, like the reference (:345, :368, :381)."""
+        """get_multiple_codewords on an NHWC latent.  Returns z_qs (B,S,h,w,D) NHWC-per-sample and indices (B,S,h,w).
+
+        For B = 1 and a 16x16 latent this is the reference (:344-381) draw for draw, including its quirk that every
+        token samples from the distribution of token 0.  The reference hard-codes B = 1 / 16x16 (:345, :368, :381);
+        larger batches and latents are this backend's generalisation (candidate batching): batch items
+        are processed in order, each exactly like a B = 1 call (its own token-0 distribution, its own h*w consecutive
+        CPU-RNG draws, its mask resized to (h, w)), so a batch equals the same items run one after the other."""
         B, h, w, D = z_nhwc.shape
-        if B != 1 or (h, w) != (16, 16):
-            raise RuntimeError("get_multiple_codewords supports batch 1 and a 16x16 latent only "
-                               "(reference quantize.py:345-381)")
         dev = z_nhwc.device
         cb, cb_sq = self._codebook()
+        T = h * w
         if topk == 1 and not self.consume_host_rng:
             # softmax over one candidate is 1.0 and multinomial can only return slot 0: every token gets its
             # arg-min whatever the mask says, so nothing has to leave the GPU (the reference's 256 CPU draws
             # per frame change no output; set consume_host_rng=True to also advance the CPU RNG like it does).
-            idx1, _, _ = ops.vq_nearest(z_nhwc.reshape(h * w, D), cb, cb_sq, want_zq=False)
-            sampled = idx1.view(-1, 1).expand(-1, sample_number)
+            idx1, _, _ = ops.vq_nearest(z_nhwc.reshape(B * T, D), cb, cb_sq, want_zq=False)
+            sampled = idx1.view(B, T, 1).expand(-1, -1, sample_number)
         else:
-            idx1, _, dist = ops.vq_nearest(z_nhwc.reshape(h * w, D), cb, cb_sq, want_dist=True, want_zq=False)
+            idx1, _, dist = ops.vq_nearest(z_nhwc.reshape(B * T, D), cb, cb_sq, want_dist=True, want_zq=False)
             vals, tk_idx = ops.vq_topk(dist, topk)
-            # host side, CPU RNG stream — identical draws to the reference (row 0's distribution for all tokens)
-            dist0 = F.softmax(-vals[0].cpu() / 1, dim=-1)
-            draws = torch.stack([torch.multinomial(dist0, sample_number, replacement=True) for _ in range(h * w)])
-            em = extrapolation_mask.reshape(1, 1, *extrapolation_mask.shape[-2:]).float().cpu()
-            em = F.interpolate(em, size=(16, 16)).view(-1)
-            draws[(1 - em) != 0] = 0  # outside the hole: arg-min (= top-1)
-            sampled = torch.gather(tk_idx, 1, draws.to(dev))                    # (T, S)
-        zq = ops.vq_gather(cb, sampled.t().contiguous().reshape(-1))            # (S*T, D), pure gather
-        return zq.view(1, sample_number, h, w, D), sampled.t().reshape(1, sample_number, h, w)
+            vals_h = vals.view(B, T, topk)[:, 0].cpu()                           # token 0 of every item
+            em_all = extrapolation_mask.reshape(B, 1, *extrapolation_mask.shape[-2:]).float().cpu()
+            draws = []
+            for b in range(B):
+                # host side, CPU RNG stream — identical draws to the reference (row 0's distribution for all tokens)
+                dist0 = F.softmax(-vals_h[b] / 1, dim=-1)
+                d = torch.stack([torch.multinomial(dist0, sample_number, replacement=True) for _ in range(T)])
+                em = F.interpolate(em_all[b:b + 1], size=(h, w)).view(-1)
+                d[(1 - em) != 0] = 0  # outside the hole: arg-min (= top-1)
+                draws.append(d)
+            draws = torch.stack(draws).to(dev)                                   # (B, T, S)
+            sampled = torch.gather(tk_idx.view(B, T, topk), 2, draws)            # (B, T, S)
+        order = sampled.permute(0, 2, 1).contiguous()                            # (B, S, T)
+        zq = ops.vq_gather(cb, order.reshape(-1))                                # (B*S*T, D), pure gather
+        return zq.view(B, sample_number, h, w, D), order.reshape(B, sample_number, h, w)
 
     def get_multiple_codewords(self, z, topk=10, sample_number=1, extrapolation_mask=None, return_exp_probility=None,
                                temp=1):

@@ -4,6 +4,7 @@ and the GoogleEarth trajectory (teacher-forced per step)."""
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from oracle import vqgan as OV
 from oracle import warp as OW
@@ -282,3 +283,25 @@ def test_clevr_scene_loop_runs_and_reconverts_seed_depth():
     scene.scene_expansion()
     assert len(scene.frames) == 9 and all(torch.isfinite(f["depth"]).all() for f in scene.frames.values())
     assert scene.frames[(1, 1)]["index"] == 4 and scene.frames[(2, 2)]["rgb_u8"].dtype == torch.uint8
+
+
+def test_topk_sampler_batched_equals_sequential():
+    """SURVEY §8 f3 generalisation: a batch of latents (and a non-16x16 latent) samples exactly like the items run one
+    after the other through the reference-faithful B = 1 path (same CPU-RNG stream, same per-item token-0 quirk)."""
+    from sgam_neurips22_amd.generative_sensing_module.modules.vqvae.quantize import VectorQuantizer2
+    q = VectorQuantizer2(512, 256, beta=0.25).to(DEV)
+    q.embedding.weight.data.copy_(testing.codebook_from_stats(0.0, 0.5, 512, 256, 5))
+    for (h, w) in ((16, 16), (8, 24)):
+        z = testing.seeded_tensor(f"tkb.z{h}", (3, h, w, 256), 0.5).to(DEV)
+        mask = (testing.seeded_tensor(f"tkb.m{h}", (3, 1, 16 * h, 16 * w)) > 0.3).to(DEV)
+        torch.manual_seed(123)
+        zq_b, idx_b = q.sample_nhwc(z, 4, 2, mask)
+        torch.manual_seed(123)
+        seq = [q.sample_nhwc(z[b:b + 1], 4, 2, mask[b:b + 1]) for b in range(3)]
+        assert idx_b.shape == (3, 2, h, w) and zq_b.shape == (3, 2, h, w, 256)
+        assert torch.equal(idx_b, torch.cat([s[1] for s in seq]))
+        assert torch.equal(zq_b, torch.cat([s[0] for s in seq]))
+        # outside the hole every sample is the arg-min
+        near = q.quantize_nhwc(z)[1].view(3, 1, h, w).expand(-1, 2, -1, -1)
+        em = F.interpolate(mask.float(), size=(h, w)).bool().expand(-1, 2, -1, -1)
+        assert torch.equal(idx_b[~em], near[~em])
