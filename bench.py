@@ -297,6 +297,9 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "rgbd_integration_branch": rgbd_leg, "throughput_mode": secondary, "frame_checksums": [r[2] for r in g["per_rank"]],
         }
         print(json.dumps(out), flush=True)
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        torch.distributed.barrier()          # ranks leave together (rank 0 was still profiling)
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -98,16 +98,36 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const typename E<T>::S *_
     S *yb = y + (int64_t)b * HW * C + g * cpg;
     const int items = HW * nv;
     float s = 0.f, ss = 0.f;
-    for (int i = threadIdx.x; i < items; i += 256) {
-        const int pix = i / nv, k = i - pix * nv;
-        const S *p = xb + (int64_t)pix * C + k * VEC;
-        if (vlen == VEC) {
-            float f[VEC];
-            unpack<T>(*reinterpret_cast<const u32x4 *>(p), f);
+    // full 16-byte vectors and at most KEEP of them per lane (every fp32 map this kernel is used for): the group's
+    // slice is read ONCE and stays in registers between the statistics and the normalisation
+    constexpr int KEEP = 16;
+    const bool keep = vlen == VEC && items <= KEEP * 256;
+    u32x4 held[KEEP];
+    if (keep) {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) { s += f[e]; ss += f[e] * f[e]; }
-        } else {
-            for (int e = 0; e < vlen; ++e) { const float v = E<T>::ld(p + e); s += v; ss += v * v; }
+        for (int j = 0; j < KEEP; ++j) {
+            const int i = threadIdx.x + 256 * j;
+            if (i < items) {
+                const int pix = i / nv, k = i - pix * nv;
+                held[j] = *reinterpret_cast<const u32x4 *>(xb + (int64_t)pix * C + k * VEC);
+                float f[VEC];
+                unpack<T>(held[j], f);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) { s += f[e]; ss += f[e] * f[e]; }
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < items; i += 256) {
+            const int pix = i / nv, k = i - pix * nv;
+            const S *p = xb + (int64_t)pix * C + k * VEC;
+            if (vlen == VEC) {
+                float f[VEC];
+                unpack<T>(*reinterpret_cast<const u32x4 *>(p), f);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) { s += f[e]; ss += f[e] * f[e]; }
+            } else {
+                for (int e = 0; e < vlen; ++e) { const float v = E<T>::ld(p + e); s += v; ss += v * v; }
+            }
         }
     }
     __shared__ double sh[4];
@@ -118,6 +138,26 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const typename E<T>::S *_
     double var = tss / n - mean * mean;
     if (var < 0.0) var = 0.0;
     const float fmean = (float)mean, frstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (keep) {
+#pragma unroll
+        for (int j = 0; j < KEEP; ++j) {
+            const int i = threadIdx.x + 256 * j;
+            if (i < items) {
+                const int pix = i / nv, k = i - pix * nv;
+                const int c0 = g * cpg + k * VEC;
+                float f[VEC];
+                unpack<T>(held[j], f);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float sc = frstd * gamma[c0 + e];
+                    float v = f[e] * sc + (beta[c0 + e] - fmean * sc);
+                    f[e] = swish ? sgam_swish(v) : v;
+                }
+                *reinterpret_cast<u32x4 *>(yb + (int64_t)pix * C + k * VEC) = pack<T>(f);
+            }
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < items; i += 256) {
         const int pix = i / nv, k = i - pix * nv;
         const S *p = xb + (int64_t)pix * C + k * VEC;
