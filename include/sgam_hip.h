@@ -89,10 +89,12 @@ int sgam_pack_conv_weight(const float *w_oihw, float *w_packed, int32_t Cout, in
  * exactly into hi + lo fp16 pieces and a.b = a_hi.b_hi + a_hi.b_lo + a_lo.b_hi is accumulated in fp32 (products of
  * fp16 values are exact in fp32; the dropped term is <= 2^-22 |a||b|).  Held to the same parity tests as the
  * fp32-MFMA path.  Weights are pre-split by sgam_pack_conv_weight_f32x into fp16 hi / lo halves of w_scale * w
- * (w_scale a power of two lifting max|w| into (512, 1024]) laid out [N][ldb / 32][2][32] halfs: per 32-element K slab
- * the 32 hi halfs then the 32 lo halfs, i.e. one 128-byte line per (row, slab); activations are split while staged,
+ * (w_scale a power of two lifting max|w| into (512, 1024]) stored in MFMA-fragment order: [N / 32][ldb / 32][256][8]
+ * halfs, per (32-row tile, 32-element K slab) 256 pieces of 16 bytes with piece = ((plane * 2 + k-step) * 2 + k-half)
+ * * 32 + row (plane 0 = hi, 1 = lo; k-step = 16 elements, k-half = 8), so the B operand of one
+ * v_mfma_f32_32x32x16_f16 is one contiguous kilobyte (N rounded up to 32 rows); activations are split while staged,
  * after multiplication by the power of two a_scale (1 for ordinary activations, 1024 for softmax probabilities).
- * ldb = K elements per row, % 32 == 0 (the buffer holds 2 * ldb halfs per row); Cin % 8 == 0, and % 32 == 0 when
+ * ldb = K elements per row, % 32 == 0 (the buffer holds 2 * ldb halfs per row of the 32-row-padded matrix); Cin % 8 == 0, and % 32 == 0 when
  * KH * KW > 1; |a_scale * x| must stay below 65504.
  * ------------------------------------------------------------------------------------------ */
 int64_t sgam_conv2d_f32x_workspace_bytes(const sgam_conv_desc *d);
@@ -128,7 +130,7 @@ int sgam_conv2d_gn_nhwc_f32x(const sgam_conv_desc *d, const float *x, const floa
 int sgam_groupnorm_table_from_partials_f32(const double *partial, int32_t nchunk, const float *gamma, const float *beta,
                                            float *scale_shift, int32_t B, int32_t HW, int32_t C, int32_t groups, float eps,
                                            void *stream);
-/* split a row-major fp32 matrix [N][K] (row stride ld) into the B-operand layout [N][Kp / 32][2][32] halfs, Kp = K
+/* split a row-major fp32 matrix [N][K] (row stride ld) into the fragment-ordered B-operand layout over [Np][Kp], both
  * rounded up to 32 (zero filled): the B operand when it is an activation (ldb = Kp) */
 int sgam_split_rows_f32x(const float *x, void *planes, float scale, int32_t N, int32_t K, int32_t ld, void *stream);
 

@@ -242,7 +242,8 @@ __global__ __launch_bounds__(256 * wk_of(BM, BN)) void conv_gemm_f32x_kernel(con
     constexpr int BC = XBK / 8;            // 16-byte chunks of a B plane row
     static_assert(NT / AC == 32 && NT / BC == 64, "staging maps assume 32 A rows / 64 B rows per pass");
     constexpr int AR = BM / 32;            // float4 rows of A per thread
-    constexpr int BRW = BN / 64;           // 16-byte chunks of each B plane per thread
+    constexpr int SL = XBK / 32;           // 32-element K slabs per pipeline step
+    constexpr int NPB = (BN / 32) * SL * 256 / NT;   // 16-byte B pieces per thread (see b_piece)
     constexpr int KS = XBK / 16;           // MFMA k-steps per slab
     static_assert(KS % WK == 0, "k-steps split evenly over the wavefront groups");
     constexpr int PLANE_A = BM * XLD, PLANE_B = BN * XLD;
@@ -272,9 +273,9 @@ __global__ __launch_bounds__(256 * wk_of(BM, BN)) void conv_gemm_f32x_kernel(con
     // A staging: thread -> (float4 column col4 of the 32-wide slab, rows row_in_pass + 32 r)
     const int col4 = tid % AC;
     const int row_in_pass = tid / AC;
-    // B staging: thread -> (16-byte chunk c16 of the 64-byte plane row, rows brow + 64 r)
-    const int c16 = tid % BC;
-    const int brow = tid / BC;
+    // B staging: the weights are stored in MFMA-fragment order — per (32-row tile, 32-element slab) 256 pieces of 16
+    // bytes, piece = ((plane * 2 + k-step) * 2 + k-half) * 32 + row — so thread t takes piece t & 255 of block t >> 8 (+
+    // NT / 256 per further piece): every wavefront load is one contiguous kilobyte.
     const int Hl = p.ups ? 2 * p.Hi : p.Hi;
     const int Wl = p.ups ? 2 * p.Wi : p.Wi;
 
@@ -304,11 +305,18 @@ __global__ __launch_bounds__(256 * wk_of(BM, BN)) void conv_gemm_f32x_kernel(con
         }
         a_tapmask[r] = mk;
     }
-    unsigned b_off[BRW];
+    unsigned b_off[NPB];      // byte offset of the piece at slab 0 (or out of range), and where it lands in an LDS stage
+    int b_lds[NPB], b_k[NPB];
+    const unsigned slabs_per_row = (unsigned)p.ldb / 32u;
 #pragma unroll
-    for (int r = 0; r < BRW; ++r) {
-        const int n = n0 + brow + 64 * r;
-        b_off[r] = n < p.N ? (unsigned)(n * 2 * p.ldb + (c16 >> 2) * 64 + (c16 & 3) * 8) * 2u : 0xC0000000u;
+    for (int j = 0; j < NPB; ++j) {
+        const int L = tid + NT * j, blk = L >> 8, pi = L & 255;
+        const int nt = blk / SL, sl = blk - nt * SL;
+        const int plane = pi >> 7, kk = (pi >> 6) & 1, kh = (pi >> 5) & 1, row = pi & 31;
+        const int n = n0 + nt * 32 + row;
+        b_off[j] = n < p.N ? ((((unsigned)(n >> 5) * slabs_per_row + (unsigned)sl) * 256u + (unsigned)pi) * 16u) : 0xC0000000u;
+        b_lds[j] = plane * PLANE_B + (nt * 32 + row) * XLD + sl * 32 + kk * 16 + kh * 8;
+        b_k[j] = sl * 32 + kk * 16 + kh * 8;
     }
 
     const int taps = p.KH * p.KW;
@@ -318,7 +326,7 @@ __global__ __launch_bounds__(256 * wk_of(BM, BN)) void conv_gemm_f32x_kernel(con
     int kx = tap - ky * p.KW;
 
     f32x4 areg[PF][AR];
-    u32x4 bh[PF][BRW], bl[PF][BRW];
+    u32x4 bp[PF][NPB];
     auto issue_loads = [&](const int st, bool live) {
         if (SGAM_XABLATE == 2) live = false;
         const int coff = ch * XBK + col4 * 4;
@@ -341,13 +349,11 @@ __global__ __launch_bounds__(256 * wk_of(BM, BN)) void conv_gemm_f32x_kernel(con
                                                             rx, (int)xsel(ok, a_rowoff[r] + tap_off, p.x_bytes), 0, 0));
             }
         }
-        const bool kb_ok = live && (ch * XBK + c16 * 8) < p.Cin;
-        const unsigned koff = (unsigned)(tap * p.Cin + ch * XBK) * 4u;      // 64 halfs (hi | lo) per 32-element slab
+        const unsigned koff = (unsigned)(tap * p.Cin + ch * XBK) * 128u;    // 4096 bytes per (row tile, 32-element slab)
 #pragma unroll
-        for (int r = 0; r < BRW; ++r) {
-            const unsigned o = xsel(kb_ok, b_off[r] + koff, p.w_plane_bytes);
-            bh[st][r] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)o, 0, 0);
-            bl[st][r] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(o + 64u), 0, 0);
+        for (int j = 0; j < NPB; ++j) {
+            const bool kb_ok = live && (ch * XBK + b_k[j]) < p.Cin;
+            bp[st][j] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)xsel(kb_ok, b_off[j] + koff, p.w_plane_bytes), 0, 0);
         }
         ++tap;
         if (++kx == p.KW) {
@@ -377,11 +383,8 @@ __global__ __launch_bounds__(256 * wk_of(BM, BN)) void conv_gemm_f32x_kernel(con
             *reinterpret_cast<u32x2 *>(al + o) = lo;
         }
 #pragma unroll
-        for (int r = 0; r < BRW; ++r) {
-            const int o = (brow + 64 * r) * XLD + c16 * 8;
-            *reinterpret_cast<u32x4 *>(bhp + o) = bh[st][r];
-            *reinterpret_cast<u32x4 *>(blp + o) = bl[st][r];
-        }
+        for (int j = 0; j < NPB; ++j) *reinterpret_cast<u32x4 *>(bhp + b_lds[j]) = bp[st][j];
+        (void)blp;
     };
 
     // one accumulator per output tile; a wavefront that owns a single tile keeps the cross terms (a_lo b_hi + a_hi b_lo)
@@ -515,7 +518,7 @@ __global__ __launch_bounds__(256) void conv3x3_f32x_halo_kernel(const XParams p)
     constexpr int TH = 8, TW = BM / 8, TWS = (TW == 16) ? 4 : 3, HWID = TW + 2, HR = (TH + 2) * HWID;
     static_assert(BM == 128 || BM == 64, "8 x 16 or 8 x 8 output patches");
     constexpr int XBK = 32, XLD = XBK + 8;
-    constexpr int TM = BM / 64, TN = BN / 64, BRW = BN / 64;
+    constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int HPL = HR * XLD;                       // halfs per halo plane
     constexpr int PLANE_B = BN * XLD;
     constexpr int NH = (HR * 8 + 255) / 256;            // float4 halo loads per thread (6)
@@ -557,17 +560,21 @@ __global__ __launch_bounds__(256) void conv3x3_f32x_halo_kernel(const XParams p)
         h_off[j] = ok ? (unsigned)(((b * p.Hi + iy) * p.Wi + ix) * p.lda + col4 * 4) * 4u : 0xFFFFFFFFu;
         h_lds[j] = row < HR ? row * XLD + col4 * 4 : -1;
     }
-    const int c16 = tid & 3, brow = tid >> 2;
-    unsigned b_off[BRW];
+    constexpr int NPB = BN / 32;          // fragment-ordered weights: thread t takes piece t of each 32-row tile
+    unsigned b_off[NPB];
+    int b_lds[NPB];
+    const unsigned slabs_per_row = (unsigned)p.ldb / 32u;
 #pragma unroll
-    for (int r = 0; r < BRW; ++r) {
-        const int n = n0 + brow + 64 * r;
-        b_off[r] = n < p.N ? (unsigned)(n * 2 * p.ldb + c16 * 8) * 2u : 0xC0000000u;
+    for (int j = 0; j < NPB; ++j) {
+        const int plane = tid >> 7, kk = (tid >> 6) & 1, kh = (tid >> 5) & 1, row = tid & 31;
+        const int n = n0 + j * 32 + row;
+        b_off[j] = n < p.N ? (((unsigned)(n >> 5) * slabs_per_row * 256u + (unsigned)tid) * 16u) : 0xC0000000u;
+        b_lds[j] = plane * PLANE_B + (j * 32 + row) * XLD + kk * 16 + kh * 8;
     }
 
     f32x4 hreg[NH];
     f32x4 gt0, gt1;          // GN: {scale, shift} of this thread's 4 channels (its float4 column is the same for every j)
-    u32x4 bh[BRW], bl[BRW];
+    u32x4 bp[NPB];
     auto hload = [&](int ch) {
         const unsigned coff = (unsigned)ch * (XBK * 4u);
 #pragma unroll
@@ -614,22 +621,15 @@ __global__ __launch_bounds__(256) void conv3x3_f32x_halo_kernel(const XParams p)
         }
     };
     auto bload = [&](int tap, int ch, bool live) {
-        const unsigned koff = (unsigned)(tap * p.Cin + ch * XBK) * 4u;
+        const unsigned koff = (unsigned)(tap * p.Cin + ch * XBK) * 128u;
 #pragma unroll
-        for (int r = 0; r < BRW; ++r) {
-            const unsigned o = xsel(live, b_off[r] + koff, p.w_plane_bytes);
-            bh[r] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)o, 0, 0);
-            bl[r] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(o + 64u), 0, 0);
-        }
+        for (int j = 0; j < NPB; ++j)
+            bp[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)xsel(live, b_off[j] + koff, p.w_plane_bytes), 0, 0);
     };
     auto bstore = [&](int buf) {
         unsigned short *bhp = bsm + buf * 2 * PLANE_B;
 #pragma unroll
-        for (int r = 0; r < BRW; ++r) {
-            const int o = (brow + 64 * r) * XLD + c16 * 8;
-            *reinterpret_cast<u32x4 *>(bhp + o) = bh[r];
-            *reinterpret_cast<u32x4 *>(bhp + PLANE_B + o) = bl[r];
-        }
+        for (int j = 0; j < NPB; ++j) *reinterpret_cast<u32x4 *>(bhp + b_lds[j]) = bp[j];
     };
 
     f32x16 acc[TM][TN];
@@ -789,8 +789,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
     unsigned bf_off[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / 4) + j * 32 + (lane & 31);
-        bf_off[j] = (unsigned)n * (unsigned)p.ldb * 4u + (unsigned)(lane >> 5) * 16u;
+        // fragment-ordered weights: lane l reads piece (plane, k-step) * 64 + l of its 32-row tile: one contiguous KB
+        const int nt = (n0 + wn * (BN / 4) + j * 32) >> 5;
+        bf_off[j] = ((unsigned)nt * ((unsigned)p.ldb / 32u) * 256u + (unsigned)lane) * 16u;
     }
 
     f32x4 hreg[NH];
@@ -848,7 +849,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
     // round trip when a SIMD holds a single wavefront
     u32x4 bq[3][TN][2][2];                 // [tap % 3][n tile][k-step][hi, lo]
     auto bload = [&](const int set, int tap, int ch, bool live) {
-        const unsigned koff = (unsigned)(tap * p.Cin + ch * XBK) * 4u;     // 128 bytes per (row, slab)
+        const unsigned koff = (unsigned)(tap * p.Cin + ch * XBK) * 128u;   // 4096 bytes per (row tile, slab)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -856,7 +857,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl)
                     bq[set][j][kk][pl] = __builtin_amdgcn_raw_buffer_load_b128(
-                        rw, (int)xsel(live, bf_off[j] + koff + (unsigned)(pl * 64 + kk * 32), p.w_plane_bytes), 0, 0);
+                        rw, (int)xsel(live, bf_off[j] + koff + (unsigned)((pl * 2 + kk) * 1024), p.w_plane_bytes), 0, 0);
     };
 
     f32x16 acc[TM][TN];
@@ -962,8 +963,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_f32x_kernel(const XParams p
     }
 }
 
-// [Cout][Cin][KH][KW] fp32 -> [Cout_pad][K / 32][2][32] halfs of scale * w, K = (tap, Cin_pad) with Cin_pad % 32 == 0:
-// per 32-element K slab the 32 hi halfs then the 32 lo halfs (one 128-byte line), zero padded
+// B-operand storage = MFMA-fragment order: [row tile of 32][K slab of 32][plane hi/lo][k-step][k-half][row][8 halfs], i.e.
+// per (row tile, slab) 256 pieces of 16 bytes with piece = ((plane * 2 + k-step) * 2 + k-half) * 32 + row — exactly what
+// the 64 lanes of a wavefront need for one v_mfma_f32_32x32x16_f16 B operand sit in one contiguous kilobyte.
+__device__ __forceinline__ int64_t frag_index(int64_t n, int64_t k, int64_t slabs_per_row) {     // index of the HI half
+    const int64_t slab = k >> 5, kin = k & 31;
+    const int64_t piece = (((kin >> 4) * 2) + ((kin >> 3) & 1)) * 32 + (n & 31);
+    return (((n >> 5) * slabs_per_row + slab) * 256 + piece) * 8 + (kin & 7);
+}
+
+// [Cout][Cin][KH][KW] fp32 -> fragment order of scale * w, K = (tap, Cin_pad) with Cin_pad % 32 == 0, Cout_pad % 32 == 0,
+// zero padded
 __global__ void pack_weight_f32x_kernel(const float *w, unsigned short *o, int Cout, int Cin, int KH, int KW, int Cout_pad,
                                         int Cin_pad, float scale) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -978,24 +988,24 @@ __global__ void pack_weight_f32x_kernel(const float *w, unsigned short *o, int C
     const _Float16 h = (_Float16)v;
     const _Float16 l = (_Float16)(v - (float)h);
     const int64_t k = (int64_t)t * Cin_pad + c;
-    const int64_t q = ((int64_t)n * taps * Cin_pad + (k >> 5) * 32) * 2 + (k & 31);
+    const int64_t q = frag_index(n, k, (int64_t)taps * Cin_pad / 32);
     o[q] = __builtin_bit_cast(unsigned short, h);
-    o[q + 32] = __builtin_bit_cast(unsigned short, l);
+    o[q + 2 * 2 * 32 * 8] = __builtin_bit_cast(unsigned short, l);      // the lo plane: 128 pieces further
 }
 
-// generic [N][K] fp32 matrix (row stride ld) -> [N][Kp / 32][2][32] halfs, Kp = K rounded up to 32 (zero filled): the B
+// generic [N][K] fp32 matrix (row stride ld) -> fragment order over [Np][Kp], both rounded up to 32 (zero filled): the B
 // operand of activation x activation GEMMs
-__global__ void split_rows_f32x_kernel(const float *x, unsigned short *o, int N, int K, int Kp, int ld, float scale) {
+__global__ void split_rows_f32x_kernel(const float *x, unsigned short *o, int N, int Np, int K, int Kp, int ld, float scale) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t total = (int64_t)N * Kp;
+    const int64_t total = (int64_t)Np * Kp;
     if (i >= total) return;
     const int n = (int)(i / Kp), k = (int)(i - (int64_t)n * Kp);
-    const float v = k < K ? x[(int64_t)n * ld + k] * scale : 0.f;
+    const float v = (k < K && n < N) ? x[(int64_t)n * ld + k] * scale : 0.f;
     const _Float16 h = (_Float16)v;
     const _Float16 l = (_Float16)(v - (float)h);
-    const int64_t q = ((int64_t)n * Kp + (k >> 5) * 32) * 2 + (k & 31);
+    const int64_t q = frag_index(n, k, Kp / 32);
     o[q] = __builtin_bit_cast(unsigned short, h);
-    o[q + 32] = __builtin_bit_cast(unsigned short, l);
+    o[q + 2 * 2 * 32 * 8] = __builtin_bit_cast(unsigned short, l);
 }
 
 struct XPlan {
@@ -1145,7 +1155,7 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
     p.gn_swish = gn_swish;
 
     const int64_t xb = (((int64_t)d->B * d->Hi * d->Wi - 1) * d->lda + d->Cin) * 4;
-    const int64_t wb = (int64_t)d->N * d->ldb * 4;   // [N][ldb / 32][2][32] halfs
+    const int64_t wb = (int64_t)((d->N + 31) / 32 * 32) * d->ldb * 4;   // fragment order over [N rounded up to 32][ldb]
     if (xb >= (1ll << 32) - 64 || wb >= (1ll << 32) - 256) return SGAM_EINVAL;
     p.x_bytes = (unsigned)xb; p.w_plane_bytes = (unsigned)wb;
     if (pl.ksplit > 1) {
@@ -1203,7 +1213,7 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
 
 extern "C" int sgam_pack_conv_weight_f32x(const float *w_oihw, void *w_planes, float w_scale, int32_t Cout, int32_t Cin,
                                           int32_t KH, int32_t KW, int32_t Cout_pad, int32_t Cin_pad, void *stream) {
-    if (!w_oihw || !w_planes || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 || Cout_pad < Cout || Cin_pad < Cin || Cin_pad % 32) return SGAM_EINVAL;
+    if (!w_oihw || !w_planes || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 || Cout_pad < Cout || Cin_pad < Cin || Cin_pad % 32 || Cout_pad % 32) return SGAM_EINVAL;
     const int64_t total = (int64_t)Cout_pad * KH * KW * Cin_pad;
     hipLaunchKernelGGL(pack_weight_f32x_kernel, dim3(sgam_cdiv(total, 256)), dim3(256), 0, sgam_stream(stream), w_oihw,
                        (unsigned short *)w_planes, Cout, Cin, KH, KW, Cout_pad, Cin_pad, w_scale);
@@ -1213,10 +1223,10 @@ extern "C" int sgam_pack_conv_weight_f32x(const float *w_oihw, void *w_planes, f
 
 extern "C" int sgam_split_rows_f32x(const float *x, void *planes, float scale, int32_t N, int32_t K, int32_t ld, void *stream) {
     if (!x || !planes || N <= 0 || K <= 0 || ld < K) return SGAM_EINVAL;
-    const int Kp = (K + 31) / 32 * 32;
-    const int64_t total = (int64_t)N * Kp;
+    const int Kp = (K + 31) / 32 * 32, Np = (N + 31) / 32 * 32;
+    const int64_t total = (int64_t)Np * Kp;
     hipLaunchKernelGGL(split_rows_f32x_kernel, dim3(sgam_cdiv(total, 256)), dim3(256), 0, sgam_stream(stream), x,
-                       (unsigned short *)planes, N, K, Kp, ld, scale);
+                       (unsigned short *)planes, N, Np, K, Kp, ld, scale);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
 }

@@ -63,13 +63,14 @@ def set_f32_mode(mode):
 
 
 class SplitWeight:
-    """fp32 matrix (N, K) pre-split into fp16 hi / lo halves of scale * w, laid out [N][Kp/32][2][32] with Kp = K rounded
-    up to 32: per 32-element K slab the hi halfs then the lo halfs, one 128-byte line (conv_f32x.hip)."""
+    """fp32 matrix (N, K) pre-split into fp16 hi / lo halves of scale * w in MFMA-fragment order
+    [Np/32][Kp/32][256 pieces][8 halfs] (N, K rounded up to 32; piece = ((plane*2 + k-step)*2 + k-half)*32 + row): the
+    B operand of one v_mfma_f32_32x32x16_f16 is one contiguous kilobyte (conv_f32x.hip)."""
     __slots__ = ("planes", "scale", "shape")
 
-    def __init__(self, planes, scale, k=None):
-        kp = planes.shape[1] * 32
-        self.planes, self.scale, self.shape = planes, scale, (planes.shape[0], kp if k is None else k)
+    def __init__(self, planes, scale, n=None, k=None):
+        np_, kp = planes.shape[0] * 32, planes.shape[1] * 32
+        self.planes, self.scale, self.shape = planes, scale, (np_ if n is None else n, kp if k is None else k)
 
     def stride(self, dim):
         return self.planes.shape[1] * 32 if dim == 0 else 1       # logical row length (ldb), in K elements
@@ -95,10 +96,10 @@ def split_rows(x2d, scale=1.0):
     """(N, K) fp32 view with unit inner stride -> SplitWeight planes (the B operand when it is an activation)."""
     _need_cuda(x2d)
     N, K = x2d.shape
-    planes = torch.empty((N, round_up(K, 32) // 32, 2, 32), device=x2d.device, dtype=torch.float16)
+    planes = torch.empty((round_up(N, 32) // 32, round_up(K, 32) // 32, 256, 8), device=x2d.device, dtype=torch.float16)
     check(_lib.load().sgam_split_rows_f32x(_p(x2d), _p(planes), float(scale), N, K, x2d.stride(0), _stream()),
           "sgam_split_rows_f32x")
-    return SplitWeight(planes, float(scale), K)
+    return SplitWeight(planes, float(scale), N, K)
 
 
 # 16-bit throughput path: `ht` code of the C ABI per torch dtype
@@ -139,7 +140,7 @@ def pack_conv_weight(w_oihw, cout_pad=None, cin_pad=None, dtype=torch.float32):
     cout_pad = cout_pad or round_up(cout, 64)
     cin_pad = cin_pad or round_up(cin, 32)
     if dtype == "f32x":
-        planes = torch.empty((cout_pad, kh * kw * cin_pad // 32, 2, 32), device=w.device, dtype=torch.float16)
+        planes = torch.empty((cout_pad // 32, kh * kw * cin_pad // 32, 256, 8), device=w.device, dtype=torch.float16)
         scale = _pow2_scale(float(w.abs().max()))          # once per weight version (host sync at pack time only)
         check(_lib.load().sgam_pack_conv_weight_f32x(_p(w), _p(planes), scale, cout, cin, kh, kw, cout_pad, cin_pad,
                                                      _stream()), "sgam_pack_conv_weight_f32x")

@@ -110,7 +110,9 @@ def tune_shape(key, verbose=True):
         cands = {1}
         for target in (256, 512, 768, 1024):
             ks = max(1, round(target / blocks))
-            if ks <= iters // 2 and ks <= 64:
+            # (back-to-back timing keeps the split-K workspace L2-hot; in a frame it is cold: deep splits that win here
+            # lose there, measured — cap them)
+            if ks <= iters // 2 and ks <= 16:
                 cands.add(ks)
         for ks in sorted(cands):
             if blocks * ks > 8192:
