@@ -137,7 +137,10 @@ def pack_conv_weight(w_oihw, cout_pad=None, cin_pad=None, dtype=torch.float32):
     _need_cuda(w_oihw)
     w = _f32c(w_oihw.detach())
     cout, cin, kh, kw = w.shape
-    cout_pad = cout_pad or round_up(cout, 64)
+    # split-fp32 3x3 weights are padded to whole 128-channel tiles so that narrow convs (conv_out: 128 -> 4) run on the
+    # halo-staged kernel too (one tile of mostly-zero columns costs less than the generic kernel's per-tap staging, and
+    # the preceding GroupNorm fuses into it)
+    cout_pad = cout_pad or round_up(cout, 128 if (dtype == "f32x" and kh * kw == 9) else 64)
     cin_pad = cin_pad or round_up(cin, 32)
     if dtype == "f32x":
         planes = torch.empty((cout_pad // 32, kh * kw * cin_pad // 32, 256, 8), device=w.device, dtype=torch.float16)
