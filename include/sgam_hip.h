@@ -104,32 +104,37 @@ int sgam_conv2d_nhwc_f32x(const sgam_conv_desc *d, const float *x, float a_scale
                           int64_t workspace_bytes, void *stream);
 int sgam_pack_conv_weight_f32x(const float *w_oihw, void *w_planes, float w_scale, int32_t Cout, int32_t Cin,
                                int32_t KH, int32_t KW, int32_t Cout_pad, int32_t Cin_pad, void *stream);
-/* Same convolution, additionally emitting the GroupNorm statistics of its OUTPUT from the epilogue (per-chunk
- * {sum, sumsq} of each of the 32 groups, chunk = half a row-tile of one image): gn_partial holds
- * [B][chunks][32][2] doubles with chunks = sgam_conv2d_f32x_stats_chunks(d) (0 = not available for this shape: split-K
- * plan, N % 128 != 0, or tiles straddling images).  sgam_groupnorm_from_partials_f32 then normalises without a
- * statistics pass over the tensor. */
+/* Same convolution, additionally delivering the GroupNorm statistics of its OUTPUT (32 groups) as per-chunk {sum, sumsq}
+ * partial sums: gn_partial holds [B][chunks][32][2] doubles, chunks = sgam_conv2d_f32x_stats_chunks(d) per image — one
+ * per (tile, wavefront row) from the conv epilogue when the plan has no split-K, one per 1024 outputs from the split-K
+ * combine otherwise; 0 = not available for this shape (N % 128 != 0, n_valid != N, tiles straddling images, N not a
+ * divisor of 1024 under split-K).  sgam_groupnorm_stats_from_partials_f32 folds them (one 32-workgroup launch);
+ * sgam_conv2d_f32x_stats_mode(d) = chunks > 0. */
 int32_t sgam_conv2d_f32x_stats_chunks(const sgam_conv_desc *d);
+int32_t sgam_conv2d_f32x_stats_mode(const sgam_conv_desc *d);
 int sgam_conv2d_stats_nhwc_f32x(const sgam_conv_desc *d, const float *x, float a_scale, const void *w_planes,
                                 float w_scale, const float *bias, const float *residual, float *out,
                                 double *gn_partial, void *workspace, int64_t workspace_bytes, void *stream);
 int sgam_groupnorm_from_partials_f32(const float *x, const double *partial, int32_t nchunk, const float *gamma,
                                      const float *beta, float *y, int32_t B, int32_t HW, int32_t C, int32_t groups,
                                      float eps, int32_t fuse_swish, void *workspace, int64_t workspace_bytes, void *stream);
-/* GroupNorm(+swish) of the INPUT fused into the operand staging: x is normalised with the per-(image, channel)
- * {scale, shift} table gn_scale_shift [B][Cin][2] (sgam_groupnorm_stats_nhwc_f32 or
- * sgam_groupnorm_table_from_partials_f32) while the 3x3 kernel stages each channel slab of its input patch — once per
- * slab, shared by the nine taps — so no normalised copy of the activation is ever written.  Zero padding applies to
- * the normalised tensor, as in Conv2d(GroupNorm(x)).  Available when sgam_conv2d_f32x_gn_fusable(d) == 1 (3x3,
- * stride 1, pad 1, no upsampling, Ho % 8 == 0, Wo % 16 == 0, Cin % 32 == 0, a 128-row tile plan); gn_partial may be
- * NULL or as in sgam_conv2d_stats_nhwc_f32x. */
+/* GroupNorm(+swish) of the INPUT fused into the operand staging: x is normalised with the per-(image, group)
+ * {mean, rstd} gn_mean_rstd [B][32][2] and the affine parameters gn_gamma / gn_beta [Cin] (16-byte aligned) while the
+ * 3x3 kernel stages each channel slab of its input patch — once per slab, shared by the nine taps — so no normalised
+ * copy of the activation is ever written.  Zero padding applies to the normalised tensor, as in Conv2d(GroupNorm(x)).
+ * Available when sgam_conv2d_f32x_gn_fusable(d) == 1 (3x3, stride 1, pad 1, no upsampling, Ho % 8 == 0, Wo % 8 (16)
+ * == 0, Cin % 128 == 0, a halo-kernel tile plan).  {mean, rstd} come from sgam_groupnorm_stats_from_partials_f32 (the
+ * producing convolution's partial sums) or from sgam_groupnorm_meanrstd_nhwc_f32 (any tensor).
+ * gn_partial as in sgam_conv2d_stats_nhwc_f32x, may be NULL. */
 int32_t sgam_conv2d_f32x_gn_fusable(const sgam_conv_desc *d);
-int sgam_conv2d_gn_nhwc_f32x(const sgam_conv_desc *d, const float *x, const float *gn_scale_shift, int32_t gn_swish,
-                             const void *w_planes, float w_scale, const float *bias, const float *residual, float *out,
-                             double *gn_partial, void *workspace, int64_t workspace_bytes, void *stream);
-int sgam_groupnorm_table_from_partials_f32(const double *partial, int32_t nchunk, const float *gamma, const float *beta,
-                                           float *scale_shift, int32_t B, int32_t HW, int32_t C, int32_t groups, float eps,
-                                           void *stream);
+int sgam_conv2d_gn_nhwc_f32x(const sgam_conv_desc *d, const float *x, const float *gn_mean_rstd, const float *gn_gamma,
+                             const float *gn_beta, int32_t gn_swish, const void *w_planes, float w_scale, const float *bias,
+                             const float *residual, float *out, double *gn_partial, void *workspace, int64_t workspace_bytes,
+                             void *stream);
+int sgam_groupnorm_stats_from_partials_f32(const double *partial, int32_t nchunk, float *mean_rstd, int32_t B, int32_t HW,
+                                           int32_t C, int32_t groups, float eps, void *stream);
+int sgam_groupnorm_meanrstd_nhwc_f32(const float *x, float *mean_rstd, int32_t B, int32_t HW, int32_t C, int32_t groups,
+                                     float eps, void *workspace, int64_t workspace_bytes, void *stream);
 /* split a row-major fp32 matrix [N][K] (row stride ld) into the fragment-ordered B-operand layout over [Np][Kp], both
  * rounded up to 32 (zero filled): the B operand when it is an activation (ldb = Kp) */
 int sgam_split_rows_f32x(const float *x, void *planes, float scale, int32_t N, int32_t K, int32_t ld, void *stream);

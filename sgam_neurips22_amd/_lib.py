@@ -38,15 +38,16 @@ PROTOTYPES = {
     "sgam_conv2d_nhwc_f32x": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_f32, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_i64,
                                       c_vp]),
     "sgam_conv2d_f32x_stats_chunks": (c_i32, [ctypes.POINTER(ConvDesc)]),
+    "sgam_conv2d_f32x_stats_mode": (c_i32, [ctypes.POINTER(ConvDesc)]),
     "sgam_conv2d_stats_nhwc_f32x": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_f32, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp,
                                             c_i64, c_vp]),
     "sgam_groupnorm_from_partials_f32": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32,
                                                  c_i32, c_vp, c_i64, c_vp]),
     "sgam_conv2d_f32x_gn_fusable": (c_i32, [ctypes.POINTER(ConvDesc)]),
-    "sgam_conv2d_gn_nhwc_f32x": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_i32, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp,
-                                         c_vp, c_i64, c_vp]),
-    "sgam_groupnorm_table_from_partials_f32": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32,
-                                                       c_vp]),
+    "sgam_conv2d_gn_nhwc_f32x": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_f32, c_vp, c_vp,
+                                         c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "sgam_groupnorm_stats_from_partials_f32": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp]),
+    "sgam_groupnorm_meanrstd_nhwc_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_i64, c_vp]),
     "sgam_tsdf_integrate_f32": (c_i32, [ctypes.POINTER(TsdfGrid), c_vp, c_i32, c_i32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp,
                                         c_f32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "sgam_tsdf_raycast_depth_f32": (c_i32, [ctypes.POINTER(TsdfGrid), c_i32, c_i32, c_f32, c_f32, c_f32, c_f32, c_vp, c_f32,

@@ -46,8 +46,11 @@ struct XParams {
     int M, ksplit, iters_total, iters_per_split;
     int gx, gy, xcd_swizzle;   // logical grid (M tiles, N tiles); the launch is 1-D, see xcd_block()
     unsigned x_bytes, w_plane_bytes;
-    const float *gn_tab; // optional (halo kernel): [B][Cin][2] scale/shift of a GroupNorm applied to x while it is staged
+    // optional (halo kernels): GroupNorm(32 groups) applied to x while it is staged: per-(image, group) {mean, rstd}
+    // [B][32][2] + the affine parameters [Cin]; the per-channel scale / shift are formed in the kernel
+    const float *gn_stats, *gn_gamma, *gn_beta;
     int gn_swish;        // ... followed by swish
+
     double *gn_partial;  // optional: per-(row-half of the tile, group) {sum, sumsq} of the OUTPUT for the next GroupNorm
     int gn_cpg;          // channels per group of that GroupNorm (N / 32)
     float inv_w_scale;   // 1 / (a_scale * w_scale), an exact power of two
@@ -124,6 +127,23 @@ __device__ __forceinline__ void xcd_block(const XParams &p, int &bx, int &by, in
     const unsigned t = Lp / (unsigned)p.gx;
     by = (int)(t % (unsigned)p.gy);
     bz = (int)(t / (unsigned)p.gy);
+}
+
+// per-channel {scale, shift} of the fused input GroupNorm for channels c .. c+3 (one group: 32 groups of >= 4 channels):
+// scale = rstd * gamma, shift = beta - mean * scale — the same expressions, in the same order, as the stand-alone
+// GroupNorm kernels, so fused and two-pass results are bit-identical.  t0 = {s0, h0, s1, h1}, t1 = {s2, h2, s3, h3}.
+__device__ __forceinline__ void gn_scale_shift(const XParams &p, int b, int c, f32x4 &t0, f32x4 &t1) {
+    const int g = c / (p.Cin / 32);
+    const float mean = p.gn_stats[(b * 32 + g) * 2], rstd = p.gn_stats[(b * 32 + g) * 2 + 1];
+    const f32x4 ga = *reinterpret_cast<const f32x4 *>(p.gn_gamma + c), be = *reinterpret_cast<const f32x4 *>(p.gn_beta + c);
+    float sc[4], sh[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        sc[e] = rstd * ga[e];
+        sh[e] = be[e] - mean * sc[e];
+    }
+    t0 = f32x4{sc[0], sh[0], sc[1], sh[1]};
+    t1 = f32x4{sc[2], sh[2], sc[3], sh[3]};
 }
 
 // ---- epilogue shared by the tile kernels: each wavefront transposes its (32 TM) x (32 TN) fp32 tile through a private
@@ -583,9 +603,7 @@ __global__ __launch_bounds__(256) void conv3x3_f32x_halo_kernel(const XParams p)
             hreg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)o, 0, 0));
         }
         if constexpr (GN) {
-            const float *t = p.gn_tab + ((int64_t)b * p.Cin + ch * XBK + (tid & 7) * 4) * 2;
-            gt0 = *reinterpret_cast<const f32x4 *>(t);          // s0 h0 s1 h1
-            gt1 = *reinterpret_cast<const f32x4 *>(t + 4);      // s2 h2 s3 h3
+            gn_scale_shift(p, b, ch * XBK + (tid & 7) * 4, gt0, gt1);
         }
     };
     // hprep: GroupNorm(+swish) and the hi/lo split, in registers ({hi0, hi1, lo0, lo1} replace the four floats) — issued
@@ -804,9 +822,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
             hreg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)o, 0, 0));
         }
         if constexpr (GN) {
-            const float *t = p.gn_tab + ((int64_t)b * p.Cin + (live ? ch : 0) * XBK + (tid & 7) * 4) * 2;
-            gt0 = *reinterpret_cast<const f32x4 *>(t);
-            gt1 = *reinterpret_cast<const f32x4 *>(t + 4);
+            gn_scale_shift(p, b, (live ? ch : 0) * XBK + (tid & 7) * 4, gt0, gt1);
         }
     };
     auto hprep_piece = [&](const int j) {
@@ -944,22 +960,53 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
     });
 }
 
-// fixed-order split-K reduction (partials are still weight-scaled) + un-scale + bias + residual
+// fixed-order split-K reduction (partials are still weight-scaled) + un-scale + bias + residual; optionally the GroupNorm
+// statistics of what it writes: a workgroup covers 1024 / N whole output rows (N in {128, 256, 512, 1024}), lanes of one
+// (row, group) are neighbours -> shuffle fold, rows -> LDS fold, one {sum, sumsq} pair per (workgroup = chunk, group).
 __global__ __launch_bounds__(256) void splitk_reduce_f32x_kernel(const XParams p) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int nq = p.N / 4;
-    if (q >= (int64_t)p.M * nq) return;
-    const int m = (int)(q / nq);
-    const int n = (int)(q - (int64_t)m * nq) * 4;
-    f32x4 s = *reinterpret_cast<const f32x4 *>(p.ws + (int64_t)m * p.N + n);
-    for (int z = 1; z < p.ksplit; ++z) s += *reinterpret_cast<const f32x4 *>(p.ws + ((int64_t)z * p.M + m) * p.N + n);
+    const bool live = q < (int64_t)p.M * nq;
+    const int m = live ? (int)(q / nq) : 0;
+    const int n = live ? (int)(q - (int64_t)m * nq) * 4 : 0;
+    float gs = 0.f, gss = 0.f;
+    if (live) {
+        f32x4 s = *reinterpret_cast<const f32x4 *>(p.ws + (int64_t)m * p.N + n);
+        for (int z = 1; z < p.ksplit; ++z) s += *reinterpret_cast<const f32x4 *>(p.ws + ((int64_t)z * p.M + m) * p.N + n);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        if (n + e >= p.n_valid) continue;
-        float v = s[e] * p.inv_w_scale;
-        if (p.bias) v += p.bias_per_row ? p.bias[m] : p.bias[n + e];
-        if (p.res) v += p.res[(int64_t)m * p.ldr + n + e];
-        p.out[(int64_t)m * p.ldc + n + e] = v;
+        for (int e = 0; e < 4; ++e) {
+            if (n + e >= p.n_valid) continue;
+            float v = s[e] * p.inv_w_scale;
+            if (p.bias) v += p.bias_per_row ? p.bias[m] : p.bias[n + e];
+            if (p.res) v += p.res[(int64_t)m * p.ldr + n + e];
+            p.out[(int64_t)m * p.ldc + n + e] = v;
+            gs += v;
+            gss += v * v;
+        }
+    }
+    if (!p.gn_partial) return;
+    // host guarantees: n_valid == N, 1024 % N == 0, whole workgroups inside one image
+    const int c4n = p.gn_cpg / 4;                      // lanes per (row, group): 1, 2, 4 or 8 neighbours
+    for (int o = 1; o < c4n; o <<= 1) {
+        gs += __shfl_xor(gs, o, 64);
+        gss += __shfl_xor(gss, o, 64);
+    }
+    __shared__ float sh[8][32][2];                     // [row in workgroup][group]
+    const int rows = 1024 / p.N, row = threadIdx.x / nq, g = (threadIdx.x - row * nq) / c4n;
+    if ((threadIdx.x % c4n) == 0) {
+        sh[row][g][0] = gs;
+        sh[row][g][1] = gss;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        double ds = 0.0, dss = 0.0;
+        for (int r = 0; r < rows; ++r) {
+            ds += (double)sh[r][threadIdx.x][0];
+            dss += (double)sh[r][threadIdx.x][1];
+        }
+        double *o = p.gn_partial + ((int64_t)blockIdx.x * 32 + threadIdx.x) * 2;     // chunk = workgroup (image-major)
+        o[0] = ds;
+        o[1] = dss;
     }
 }
 
@@ -1087,9 +1134,15 @@ extern "C" int sgam_conv2d_f32x_plan(const sgam_conv_desc *d, int32_t *bm, int32
     return SGAM_OK;
 }
 
+struct XExtra {            // optional fusions around the product
+    const float *gn_stats = nullptr, *gn_gamma = nullptr, *gn_beta = nullptr;   // GroupNorm(+swish) of the input (halo kernels)
+    int gn_swish = 0;
+    double *gn_partial = nullptr;     // statistics of the output: per-chunk partial sums (epilogue or split-K combine)
+};
+
 static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale, const void *w_planes, float w_scale,
-                          const float *bias, const float *residual, float *out, double *gn_partial, void *workspace,
-                          int64_t workspace_bytes, void *stream, const float *gn_tab = nullptr, int gn_swish = 0);
+                          const float *bias, const float *residual, float *out, void *workspace, int64_t workspace_bytes,
+                          void *stream, const XExtra &ex);
 
 static bool halo_eligible(const sgam_conv_desc *d, const XPlan &pl, float a_scale) {
     return a_scale == 1.0f && halo_shape(d, pl.bm, pl.bn);
@@ -1100,41 +1153,63 @@ extern "C" int32_t sgam_conv2d_f32x_gn_fusable(const sgam_conv_desc *d) {
     return halo_eligible(d, make_xplan(d), 1.0f) ? 1 : 0;
 }
 
-extern "C" int sgam_conv2d_gn_nhwc_f32x(const sgam_conv_desc *d, const float *x, const float *gn_scale_shift, int32_t gn_swish,
-                                        const void *w_planes, float w_scale, const float *bias, const float *residual,
-                                        float *out, double *gn_partial, void *workspace, int64_t workspace_bytes,
-                                        void *stream) {
-    if (!gn_scale_shift || !sgam_aligned16(gn_scale_shift) || sgam_conv2d_f32x_gn_fusable(d) != 1) return SGAM_EINVAL;
-    if (gn_partial && sgam_conv2d_f32x_stats_chunks(d) <= 0) return SGAM_EINVAL;
-    return conv_f32x_impl(d, x, 1.0f, w_planes, w_scale, bias, residual, out, gn_partial, workspace, workspace_bytes, stream,
-                          gn_scale_shift, gn_swish ? 1 : 0);
+extern "C" int32_t sgam_conv2d_f32x_stats_chunks(const sgam_conv_desc *d) {
+    if (xvalidate(d) != SGAM_OK) return -1;
+    const XPlan pl = make_xplan(d);
+    const int hw = d->Ho * d->Wo;
+    if (d->N % 128 != 0 || d->n_valid != d->N) return 0;                           // 32 groups of >= 4 channels, complete rows
+    if (pl.ksplit == 1) {
+        // from the conv epilogue: one chunk per (tile, wavefront row)
+        if (d->B > 1 && hw % pl.bm != 0) return 0;                                 // a tile must not straddle two images
+        return ((hw + pl.bm - 1) / pl.bm) * 2;
+    }
+    // from the split-K combine: one chunk per workgroup of 1024 outputs = 1024 / N whole rows
+    if (d->N > 1024 || 1024 % d->N != 0 || ((int64_t)hw * d->N) % 1024 != 0) return 0;
+    return (int32_t)((int64_t)hw * d->N / 1024);
+}
+
+// 1 when a launch of this descriptor can deliver the GroupNorm statistics of its output (per-chunk partial sums,
+// sgam_conv2d_f32x_stats_chunks of them per image: from the epilogue without split-K, from the combine with it), else 0
+extern "C" int32_t sgam_conv2d_f32x_stats_mode(const sgam_conv_desc *d) {
+    return sgam_conv2d_f32x_stats_chunks(d) > 0 ? 1 : 0;
+}
+
+static int check_stats_out(const sgam_conv_desc *d, const XExtra &ex) {
+    return (ex.gn_partial && sgam_conv2d_f32x_stats_mode(d) != 1) ? SGAM_EINVAL : SGAM_OK;
+}
+
+extern "C" int sgam_conv2d_gn_nhwc_f32x(const sgam_conv_desc *d, const float *x, const float *gn_mean_rstd, const float *gn_gamma,
+                                        const float *gn_beta, int32_t gn_swish, const void *w_planes, float w_scale,
+                                        const float *bias, const float *residual, float *out, double *gn_partial,
+                                        void *workspace, int64_t workspace_bytes, void *stream) {
+    if (!gn_mean_rstd || !gn_gamma || !gn_beta || !sgam_aligned16(gn_gamma) || !sgam_aligned16(gn_beta) ||
+        sgam_conv2d_f32x_gn_fusable(d) != 1 || d->Cin % 128 != 0)
+        return SGAM_EINVAL;
+    XExtra ex;
+    ex.gn_stats = gn_mean_rstd; ex.gn_gamma = gn_gamma; ex.gn_beta = gn_beta; ex.gn_swish = gn_swish ? 1 : 0;
+    ex.gn_partial = gn_partial;
+    if (check_stats_out(d, ex) != SGAM_OK) return SGAM_EINVAL;
+    return conv_f32x_impl(d, x, 1.0f, w_planes, w_scale, bias, residual, out, workspace, workspace_bytes, stream, ex);
 }
 
 extern "C" int sgam_conv2d_nhwc_f32x(const sgam_conv_desc *d, const float *x, float a_scale, const void *w_planes,
                                      float w_scale, const float *bias, const float *residual, float *out,
                                      void *workspace, int64_t workspace_bytes, void *stream) {
-    return conv_f32x_impl(d, x, a_scale, w_planes, w_scale, bias, residual, out, nullptr, workspace, workspace_bytes, stream);
-}
-
-extern "C" int32_t sgam_conv2d_f32x_stats_chunks(const sgam_conv_desc *d) {
-    if (xvalidate(d) != SGAM_OK) return -1;
-    const XPlan pl = make_xplan(d);
-    const int hw = d->Ho * d->Wo;
-    if (pl.ksplit != 1 || d->N % 128 != 0 || d->n_valid != d->N) return 0;      // statistics need complete sums, 32 groups of >= 4
-    if (d->B > 1 && hw % pl.bm != 0) return 0;                                     // a tile must not straddle two images
-    return ((hw + pl.bm - 1) / pl.bm) * 2;
+    return conv_f32x_impl(d, x, a_scale, w_planes, w_scale, bias, residual, out, workspace, workspace_bytes, stream, XExtra());
 }
 
 extern "C" int sgam_conv2d_stats_nhwc_f32x(const sgam_conv_desc *d, const float *x, float a_scale, const void *w_planes,
                                            float w_scale, const float *bias, const float *residual, float *out,
                                            double *gn_partial, void *workspace, int64_t workspace_bytes, void *stream) {
-    if (!gn_partial || sgam_conv2d_f32x_stats_chunks(d) <= 0) return SGAM_EINVAL;
-    return conv_f32x_impl(d, x, a_scale, w_planes, w_scale, bias, residual, out, gn_partial, workspace, workspace_bytes, stream);
+    XExtra ex;
+    ex.gn_partial = gn_partial;
+    if (!gn_partial || check_stats_out(d, ex) != SGAM_OK) return SGAM_EINVAL;
+    return conv_f32x_impl(d, x, a_scale, w_planes, w_scale, bias, residual, out, workspace, workspace_bytes, stream, ex);
 }
 
 static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale, const void *w_planes, float w_scale,
-                          const float *bias, const float *residual, float *out, double *gn_partial, void *workspace,
-                          int64_t workspace_bytes, void *stream, const float *gn_tab, int gn_swish) {
+                          const float *bias, const float *residual, float *out, void *workspace, int64_t workspace_bytes,
+                          void *stream, const XExtra &ex) {
     const int rc = xvalidate(d);
     if (rc != SGAM_OK) return rc;
     if (!x || !w_planes || !out || !(w_scale > 0.f) || !(a_scale > 0.f)) return SGAM_EINVAL;
@@ -1149,10 +1224,10 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
     p.ksplit = pl.ksplit; p.iters_total = pl.iters_total; p.iters_per_split = pl.iters_per_split;
     p.inv_w_scale = 1.0f / (w_scale * a_scale);
     p.a_scale = a_scale;
-    p.gn_partial = gn_partial;
+    p.gn_partial = ex.gn_partial;
     p.gn_cpg = d->N / 32;
-    p.gn_tab = gn_tab;
-    p.gn_swish = gn_swish;
+    p.gn_stats = ex.gn_stats; p.gn_gamma = ex.gn_gamma; p.gn_beta = ex.gn_beta;
+    p.gn_swish = ex.gn_swish;
 
     const int64_t xb = (((int64_t)d->B * d->Hi * d->Wi - 1) * d->lda + d->Cin) * 4;
     const int64_t wb = (int64_t)((d->N + 31) / 32 * 32) * d->ldb * 4;   // fragment order over [N rounded up to 32][ldb]
@@ -1179,23 +1254,23 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
     if (p.ups && a_scale != 1.0f) return SGAM_EINVAL;
     if (d->KH * d->KW > 32) return SGAM_EINVAL;   // tap validity mask is 32 bits
     const bool halo = halo_eligible(d, pl, a_scale);
-    if (gn_tab && !halo) return SGAM_EINVAL;
+    if (ex.gn_stats && !halo) return SGAM_EINVAL;
     if (halo) {
         static const int dyn = [] { const char *e = getenv("SGAM_XDYN_LDS"); return e ? atoi(e) : 0; }();   // occupancy experiments
         static const int halo_gen = [] { const char *e = getenv("SGAM_F32X_HALO"); return (e && e[0] == '1') ? 1 : 2; }();
         if (halo_gen == 2) {
             if (pl.bm == 128) {
-                if (p.gn_tab) hipLaunchKernelGGL((conv3x3_f32x_halo2_kernel<128, 128, true>), grid, dim3(256), dyn, s, p);
+                if (p.gn_stats) hipLaunchKernelGGL((conv3x3_f32x_halo2_kernel<128, 128, true>), grid, dim3(256), dyn, s, p);
                 else hipLaunchKernelGGL((conv3x3_f32x_halo2_kernel<128, 128, false>), grid, dim3(256), dyn, s, p);
             } else {
-                if (p.gn_tab) hipLaunchKernelGGL((conv3x3_f32x_halo2_kernel<64, 128, true>), grid, dim3(256), dyn, s, p);
+                if (p.gn_stats) hipLaunchKernelGGL((conv3x3_f32x_halo2_kernel<64, 128, true>), grid, dim3(256), dyn, s, p);
                 else hipLaunchKernelGGL((conv3x3_f32x_halo2_kernel<64, 128, false>), grid, dim3(256), dyn, s, p);
             }
         } else if (pl.bm == 128) {
-            if (p.gn_tab) hipLaunchKernelGGL((conv3x3_f32x_halo_kernel<128, 128, true>), grid, dim3(256), dyn, s, p);
+            if (p.gn_stats) hipLaunchKernelGGL((conv3x3_f32x_halo_kernel<128, 128, true>), grid, dim3(256), dyn, s, p);
             else hipLaunchKernelGGL((conv3x3_f32x_halo_kernel<128, 128, false>), grid, dim3(256), dyn, s, p);
         } else {
-            if (p.gn_tab) hipLaunchKernelGGL((conv3x3_f32x_halo_kernel<64, 128, true>), grid, dim3(256), dyn, s, p);
+            if (p.gn_stats) hipLaunchKernelGGL((conv3x3_f32x_halo_kernel<64, 128, true>), grid, dim3(256), dyn, s, p);
             else hipLaunchKernelGGL((conv3x3_f32x_halo_kernel<64, 128, false>), grid, dim3(256), dyn, s, p);
         }
     } else if (pl.bm == 128 && pl.bn == 128) XLAUNCH(128, 128);

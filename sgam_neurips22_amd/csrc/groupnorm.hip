@@ -297,6 +297,37 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double *__restri
     }
 }
 
+// the same fold, delivering {mean, rstd} per (image, group) for consumers that normalise on the fly
+__global__ __launch_bounds__(256) void gn_finalize_stats_kernel(const double *__restrict__ partial, float *__restrict__ mean_rstd,
+                                                                int HW, int C, int groups, int nchunk, float eps) {
+    __shared__ double sh_s[4], sh_ss[4];
+    const int g = blockIdx.x, b = blockIdx.y;
+    const double *base = partial + ((int64_t)b * nchunk * groups + g) * 2;
+    double s = 0.0, ss = 0.0;
+    for (int k = threadIdx.x; k < nchunk; k += 256) {
+        const double2 v = *reinterpret_cast<const double2 *>(base + (int64_t)k * groups * 2);
+        s += v.x;
+        ss += v.y;
+    }
+    s = sgam_wave_sum_f64(s);
+    ss = sgam_wave_sum_f64(ss);
+    if ((threadIdx.x & 63) == 0) {
+        sh_s[threadIdx.x >> 6] = s;
+        sh_ss[threadIdx.x >> 6] = ss;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double ts = (sh_s[0] + sh_s[1]) + (sh_s[2] + sh_s[3]);
+        const double tss = (sh_ss[0] + sh_ss[1]) + (sh_ss[2] + sh_ss[3]);
+        const double n = (double)HW * (double)(C / groups);
+        const double mean = ts / n;
+        double var = tss / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        mean_rstd[(b * groups + g) * 2] = (float)mean;
+        mean_rstd[(b * groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
 __global__ void gn_finalize_kernel(const double *, const float *, const float *, float *, int, int, int, int, float);
 
 int gn_nchunk(int HW, int C, int vec) {
@@ -394,15 +425,31 @@ extern "C" int sgam_groupnorm_from_partials_f32(const float *x, const double *pa
     return SGAM_OK;
 }
 
-// scale/shift table straight from conv-epilogue partials (no pass over the tensor at all): the consumer is a
-// convolution that normalises while staging its input (sgam_conv2d_gn_nhwc_f32x)
-extern "C" int sgam_groupnorm_table_from_partials_f32(const double *partial, int32_t nchunk, const float *gamma,
-                                                      const float *beta, float *scale_shift, int32_t B, int32_t HW, int32_t C,
-                                                      int32_t groups, float eps, void *stream) {
-    if (!partial || nchunk <= 0 || !gamma || !beta || !scale_shift || !gn_shape_ok(B, HW, C, groups)) return SGAM_EINVAL;
-    if (!sgam_aligned16(partial) || !sgam_aligned16(scale_shift)) return SGAM_EALIGN;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(256), 0, sgam_stream(stream), partial, gamma, beta, scale_shift,
-                       HW, C, groups, nchunk, eps);
+// {mean, rstd} per (image, group) straight from conv-epilogue partials (no pass over the tensor at all): the consumer is
+// a convolution that normalises while staging its input (sgam_conv2d_gn_nhwc_f32x)
+extern "C" int sgam_groupnorm_stats_from_partials_f32(const double *partial, int32_t nchunk, float *mean_rstd, int32_t B,
+                                                      int32_t HW, int32_t C, int32_t groups, float eps, void *stream) {
+    if (!partial || nchunk <= 0 || !mean_rstd || !gn_shape_ok(B, HW, C, groups)) return SGAM_EINVAL;
+    if (!sgam_aligned16(partial)) return SGAM_EALIGN;
+    hipLaunchKernelGGL(gn_finalize_stats_kernel, dim3(groups, B), dim3(256), 0, sgam_stream(stream), partial, mean_rstd, HW, C,
+                       groups, nchunk, eps);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+// {mean, rstd} of any NHWC fp32 tensor: the partial-sum pass + the fold
+extern "C" int sgam_groupnorm_meanrstd_nhwc_f32(const float *x, float *mean_rstd, int32_t B, int32_t HW, int32_t C,
+                                                int32_t groups, float eps, void *workspace, int64_t workspace_bytes,
+                                                void *stream) {
+    if (!x || !mean_rstd || !gn_shape_ok(B, HW, C, groups)) return SGAM_EINVAL;
+    if (!sgam_aligned16(x) || !sgam_aligned16(workspace)) return SGAM_EALIGN;
+    if (!workspace || workspace_bytes < sgam_groupnorm_workspace_bytes(B, HW, C)) return SGAM_EWORKSPACE;
+    hipStream_t s = sgam_stream(stream);
+    const int nchunk = gn_nchunk(HW, C, 4);
+    double *partial = (double *)workspace;
+    hipLaunchKernelGGL(gn_partial_kernel<2>, dim3(nchunk, B), dim3(GT), 0, s, x, partial, HW, C, groups, sgam_cdiv(HW, nchunk));
+    SGAM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn_finalize_stats_kernel, dim3(groups, B), dim3(256), 0, s, partial, mean_rstd, HW, C, groups, nchunk, eps);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
 }

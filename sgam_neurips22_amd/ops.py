@@ -208,10 +208,14 @@ def _run_conv(desc, x, w, bias, residual, out, gn=None, a_scale=1.0, norm=None):
     _apply_plan(desc, "f32x" if split else x.dtype)
     if norm is not None:
         gamma, beta, swish, groups, eps = norm
-        # maps of <= 1024 pixels normalise in ONE launch (gn_small: statistics + apply): fusing would cost a launch there
-        if (split and FUSE_GN_APPLY and x.dtype == torch.float32 and x.dim() == 4 and groups == 32
-                and x.shape[1] * x.shape[2] > 1024 and lib.sgam_conv2d_f32x_gn_fusable(ctypes.byref(desc)) == 1):
-            gn = (groupnorm_stats(x, gamma, beta, groups, eps), swish)
+        fusable = (split and FUSE_GN_APPLY and x.dtype == torch.float32 and x.dim() == 4 and groups == 32 and eps == 1e-6
+                   and x.shape[3] % 128 == 0 and lib.sgam_conv2d_f32x_gn_fusable(ctypes.byref(desc)) == 1)
+        # statistics that travelled with x (the producing conv's epilogue or split-K combine partials) cost one
+        # 32-workgroup launch; computing them is two launches, so a map of <= 1024 pixels without them is cheaper through
+        # the one-launch statistics+apply kernel
+        have = getattr(x, "_gn_partials", None) is not None
+        if fusable and (have or x.shape[1] * x.shape[2] > 1024):
+            gn = (groupnorm_meanrstd(x, eps), gamma, beta, swish)
         else:
             x = groupnorm_nhwc(x, gamma, beta, swish, groups, eps)
     if CONV_TRACE is not None:
@@ -241,27 +245,31 @@ def _run_conv_inner(lib, desc, x, w, bias, residual, out, gn=None, a_scale=1.0):
         if ws_bytes < 0:
             raise SgamHipError(f"sgam_conv2d_f32x: unsupported shape {[(f, getattr(desc, f)) for f, _ in desc._fields_]}")
         ws = torch.empty((ws_bytes,), device=x.device, dtype=torch.uint8) if ws_bytes else None
+        # statistics of `out` for the GroupNorm that usually follows: per-chunk partial sums from the conv epilogue (no
+        # split-K) or from the split-K combine (see include/sgam_hip.h)
         chunks = lib.sgam_conv2d_f32x_stats_chunks(ctypes.byref(desc)) if FUSE_GN_STATS else 0
+        partial = torch.empty((desc.B * chunks * 32 * 2,), device=x.device, dtype=torch.float64) if chunks > 0 else None
+
+        def tag(o):
+            if partial is not None:
+                o._gn_partials = (partial, chunks)
+            return o
+
         if gn is not None:
             # GroupNorm(+swish) of x applied while the 3x3 kernel stages its input patch
-            table, swish = gn
+            mean_rstd, gamma, beta, swish = gn
             if a_scale != 1.0 or lib.sgam_conv2d_f32x_gn_fusable(ctypes.byref(desc)) != 1:
                 raise SgamHipError("split fp32 conv: fused GroupNorm needs the halo-staged 3x3 kernel (sgam_conv2d_f32x_gn_fusable)")
-            partial = torch.empty((desc.B * chunks * 32 * 2,), device=x.device, dtype=torch.float64) if chunks > 0 else None
-            check(lib.sgam_conv2d_gn_nhwc_f32x(ctypes.byref(desc), _p(x), _p(table), int(swish), _p(w.planes), float(w.scale),
-                                               _p(bias), _p(residual), _p(out), _p(partial), _p(ws), ws_bytes, _stream()),
-                  "sgam_conv2d_gn_nhwc_f32x")
-            if partial is not None:
-                out._gn_partials = (partial, chunks)
-            return out
-        if chunks > 0:
-            # the epilogue also emits the GroupNorm statistics of `out`; the next groupnorm_nhwc(out) picks them up
-            partial = torch.empty((desc.B * chunks * 32 * 2,), device=x.device, dtype=torch.float64)
+            gamma, beta = _f32c(gamma), _f32c(beta)
+            check(lib.sgam_conv2d_gn_nhwc_f32x(ctypes.byref(desc), _p(x), _p(mean_rstd), _p(gamma), _p(beta), int(swish),
+                                               _p(w.planes), float(w.scale), _p(bias), _p(residual), _p(out), _p(partial),
+                                               _p(ws), ws_bytes, _stream()), "sgam_conv2d_gn_nhwc_f32x")
+            return tag(out)
+        if partial is not None:
             check(lib.sgam_conv2d_stats_nhwc_f32x(ctypes.byref(desc), _p(x), float(a_scale), _p(w.planes), float(w.scale),
                                                   _p(bias), _p(residual), _p(out), _p(partial), _p(ws), ws_bytes, _stream()),
                   "sgam_conv2d_stats_nhwc_f32x")
-            out._gn_partials = (partial, chunks)
-            return out
+            return tag(out)
         check(lib.sgam_conv2d_nhwc_f32x(ctypes.byref(desc), _p(x), float(a_scale), _p(w.planes), float(w.scale), _p(bias),
                                         _p(residual), _p(out), _p(ws), ws_bytes, _stream()), "sgam_conv2d_nhwc_f32x")
         return out
@@ -365,12 +373,6 @@ def groupnorm_stats(x, gamma, beta, groups=32, eps=1e-6):
     B, H, W, C = x.shape
     lib = _lib.load()
     table = torch.empty((B, C, 2), device=x.device, dtype=torch.float32)
-    pre = getattr(x, "_gn_partials", None)
-    if pre is not None and groups == 32:
-        partial, chunks = pre        # the conv that produced x already emitted the statistics: fold them, no pass over x
-        check(lib.sgam_groupnorm_table_from_partials_f32(_p(partial), chunks, _p(gamma), _p(beta), _p(table), B, H * W, C,
-                                                         groups, eps, _stream()), "sgam_groupnorm_table_from_partials_f32")
-        return table
     ws_bytes = lib.sgam_groupnorm_workspace_bytes(B, H * W, C)
     if ws_bytes < 0:
         raise SgamHipError(f"sgam_groupnorm: unsupported shape B={B} HW={H * W} C={C}")
@@ -378,6 +380,29 @@ def groupnorm_stats(x, gamma, beta, groups=32, eps=1e-6):
     check(lib.sgam_groupnorm_stats_nhwc_f32(_p(x), _p(gamma), _p(beta), _p(table), B, H * W, C, groups, eps, _p(ws),
                                             ws_bytes, _stream()), "sgam_groupnorm_stats_nhwc_f32")
     return table
+
+
+def groupnorm_meanrstd(x, eps=1e-6):
+    """(B, 32, 2) {mean, rstd} per (image, group) of an NHWC fp32 tensor, for convolutions that normalise their input
+    while staging it: one 32-workgroup launch when the conv that produced x left its partial sums (`_gn_partials`), else
+    a statistics pass + the fold."""
+    _need_cuda(x)
+    B, H, W, C = x.shape
+    lib = _lib.load()
+    out = torch.empty((B, 32, 2), device=x.device, dtype=torch.float32)
+    pre = getattr(x, "_gn_partials", None)
+    if pre is not None:
+        partial, chunks = pre
+        check(lib.sgam_groupnorm_stats_from_partials_f32(_p(partial), chunks, _p(out), B, H * W, C, 32, eps, _stream()),
+              "sgam_groupnorm_stats_from_partials_f32")
+        return out
+    ws_bytes = lib.sgam_groupnorm_workspace_bytes(B, H * W, C)
+    if ws_bytes < 0:
+        raise SgamHipError(f"sgam_groupnorm: unsupported shape B={B} HW={H * W} C={C}")
+    ws = torch.empty((ws_bytes,), device=x.device, dtype=torch.uint8)
+    check(lib.sgam_groupnorm_meanrstd_nhwc_f32(_p(x), _p(out), B, H * W, C, 32, eps, _p(ws), ws_bytes, _stream()),
+          "sgam_groupnorm_meanrstd_nhwc_f32")
+    return out
 
 
 def softmax_rows_h16(s, scale, dtype):

@@ -317,3 +317,39 @@ def test_halo_kernel_tile_plans(plan):
             ops.PLAN_CACHE[key] = old
     ref = F.conv2d(x.permute(0, 3, 1, 2).cpu().double(), w.double(), padding=1).float()
     _close(out.permute(0, 3, 1, 2), ref, 2e-5, f"halo plan {plan}")
+
+
+@pytest.mark.parametrize("C,H,W", [(512, 16, 16), (256, 32, 32), (256, 64, 64)])
+def test_splitk_combine_delivers_groupnorm_statistics(C, H, W):
+    """The split-K combine of a conv also leaves the partial GroupNorm sums of its output; the next 3x3 conv normalises
+    with them while staging (one 32-workgroup fold in between, no pass over the tensor).  Equals the explicit form."""
+    ops.set_f32_mode("split")
+    x = _nhwc(testing.seeded_tensor("sms.x", (1, C, H, W), 1.1, 0.3)).to(DEV)
+    w1 = testing.seeded_tensor("sms.w1", (C, C, 3, 3), scale=(1.0 / (C * 9)) ** 0.5)
+    w2 = testing.seeded_tensor("sms.w2", (C, C, 3, 3), scale=(1.0 / (C * 9)) ** 0.5)
+    res = _nhwc(testing.seeded_tensor("sms.r", (1, C, H, W))).to(DEV)
+    g = (1 + 0.1 * testing.seeded_tensor("sms.g", (C,))).to(DEV)
+    bt = (0.1 * testing.seeded_tensor("sms.b", (C,))).to(DEV)
+    p1, p2 = ops.pack_conv_weight(w1.to(DEV), dtype="f32x"), ops.pack_conv_weight(w2.to(DEV), dtype="f32x")
+    kw = dict(cout=C, kh=3, kw=3, pad_t=1, pad_l=1)
+    key = f"f32x|B1|{H}x{W}x{C}|{H}x{W}|N{C}|k3x3s1u0"
+    old = ops.PLAN_CACHE.get(key)
+    ops.PLAN_CACHE[key] = (64, 128, 4)                 # force a split-K plan
+    try:
+        h = ops.conv2d_nhwc(x, p1, None, residual=res, **kw)
+        assert hasattr(h, "_gn_partials")
+        ref_h = F.conv2d(x.permute(0, 3, 1, 2).cpu().double(), w1.double(), padding=1).float() + res.permute(0, 3, 1, 2).cpu()
+        _close(h.permute(0, 3, 1, 2), ref_h, 2e-5, "conv + residual through the combine")
+        st = ops.groupnorm_meanrstd(h).cpu()
+        hg = h.permute(0, 3, 1, 2).cpu().double().reshape(1, 32, -1)
+        assert torch.allclose(st[0, :, 0].double(), hg.mean(-1)[0], rtol=0, atol=2e-6)
+        assert torch.allclose(st[0, :, 1].double(), (hg.var(-1, unbiased=False) + 1e-6).rsqrt()[0], rtol=2e-6, atol=0)
+        fused = ops.conv2d_nhwc(h, p2, None, norm=(g, bt, True, 32, 1e-6), **kw)
+        plain = ops.conv2d_nhwc(ops.groupnorm_nhwc(h.clone(), g, bt, True), p2, None, **kw)
+    finally:
+        if old is None:
+            ops.PLAN_CACHE.pop(key, None)
+        else:
+            ops.PLAN_CACHE[key] = old
+    scale = plain.abs().max().item()
+    assert (fused - plain).abs().max().item() <= 3e-6 * scale
