@@ -127,6 +127,9 @@ int sgam_groupnorm_from_partials_f32(const float *x, const double *partial, int3
  * producing convolution's partial sums) or from sgam_groupnorm_meanrstd_nhwc_f32 (any tensor).
  * gn_partial as in sgam_conv2d_stats_nhwc_f32x, may be NULL. */
 int32_t sgam_conv2d_f32x_gn_fusable(const sgam_conv_desc *d);
+/* 1 when the descriptor runs on a halo-staged 3x3 kernel (3x3 / stride 1 / pad 1 on the input or on its nearest-2x
+ * upsampling), 0 when it runs on the generic implicit-GEMM kernel (diagnostic: profiling labels) */
+int32_t sgam_conv2d_f32x_uses_halo(const sgam_conv_desc *d);
 int sgam_conv2d_gn_nhwc_f32x(const sgam_conv_desc *d, const float *x, const float *gn_mean_rstd, const float *gn_gamma,
                              const float *gn_beta, int32_t gn_swish, const void *w_planes, float w_scale, const float *bias,
                              const float *residual, float *out, double *gn_partial, void *workspace, int64_t workspace_bytes,

@@ -44,6 +44,7 @@ PROTOTYPES = {
     "sgam_groupnorm_from_partials_f32": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32,
                                                  c_i32, c_vp, c_i64, c_vp]),
     "sgam_conv2d_f32x_gn_fusable": (c_i32, [ctypes.POINTER(ConvDesc)]),
+    "sgam_conv2d_f32x_uses_halo": (c_i32, [ctypes.POINTER(ConvDesc)]),
     "sgam_conv2d_gn_nhwc_f32x": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_f32, c_vp, c_vp,
                                          c_vp, c_vp, c_vp, c_i64, c_vp]),
     "sgam_groupnorm_stats_from_partials_f32": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp]),

@@ -754,18 +754,23 @@ __global__ __launch_bounds__(256) void conv3x3_f32x_halo_kernel(const XParams p)
 // out of LDS the only shared operand is the halo, which is double-buffered: ONE barrier per channel slab (nine taps)
 // instead of one per tap, no ds_write of weights, half the ds_reads, and wavefronts drift freely inside a slab so the
 // two workgroups of a CU interleave their load and MFMA phases.
-template <int BM, int BN, bool GN>
+// UPS: the conv runs on the nearest-2x upsampled input without materialising it — the staged halo is the SOURCE patch
+// ((TH/2 + 2) x (TW/2 + 2) pixels: a third of the pixels), and a lane finds the source pixel of (patch pixel, tap) as
+// ((p + k - 1) >> 1) + 1 per axis.
+template <int BM, int BN, bool GN, bool UPS = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParams p) {
     constexpr int WGM_ = 1;          // four wavefronts side by side along N: each owns all BM rows x BN / 4 channels
-    constexpr int TH = 8, TW = BM / 8, TWS = (TW == 16) ? 4 : 3, HWID = TW + 2, HR = (TH + 2) * HWID;
+    constexpr int TH = 8, TW = BM / 8, TWS = (TW == 16) ? 4 : 3;
+    constexpr int HROWS = UPS ? TH / 2 + 2 : TH + 2, HWID = UPS ? TW / 2 + 2 : TW + 2, HR = HROWS * HWID;
+    static_assert(!(UPS && GN), "no GroupNorm precedes an upsampling conv");
     static_assert(BM == 128 || BM == 64, "8 x 16 or 8 x 8 output patches");
     constexpr int XBK = 32, XLD = XBK + 8;
     constexpr int TM = BM / 32, TN = BN / 128;
     // halo pixel (hy, hx) sits at hy * LP + hx * XLD halfs; the line pitch LP is padded (720 -> 768, 400 -> 448) so that
     // the 16-lane groups of ds_read_b128, which straddle two or more patch rows, land on 16 distinct bank quads for
     // every tap offset (found by enumeration over the hardware's lane groups)
-    constexpr int LP = (TW == 16) ? 768 : 448;
-    constexpr int HPL = (TH + 2) * LP;                  // halfs per halo plane
+    constexpr int LP = UPS ? ((TW == 16) ? 408 : 240) : ((TW == 16) ? 768 : 448);
+    constexpr int HPL = HROWS * LP;                     // halfs per halo plane
     constexpr int HBUF = 2 * HPL;                       // one halo buffer: hi plane, lo plane
     constexpr int NH = (HR * 8 + 255) / 256;            // float4 halo loads per thread
     constexpr int OP_BYTES = 2 * HBUF * 2;
@@ -798,7 +803,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
         const int idx = tid + 256 * j;
         const int row = idx >> 3, col4 = idx & 7;
         const int hy = row / HWID, hx = row - hy * HWID;
-        const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
+        const int iy = (UPS ? ty0 / 2 : ty0) + hy - 1, ix = (UPS ? tx0 / 2 : tx0) + hx - 1;     // source pixel of this halo cell
         const bool ok = row < HR && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
         h_off[j] = ok ? (unsigned)(((b * p.Hi + iy) * p.Wi + ix) * p.lda + col4 * 4) * 4u : 0xFFFFFFFFu;
         h_lds[j] = row < HR ? hy * LP + hx * XLD + col4 * 4 : -1;
@@ -886,11 +891,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
 
     const int frag_row = lane & 31;
     const int frag_k = (lane >> 5) * 8;
-    int a_base[TM];
+    int a_base[TM], a_py[TM], a_px[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int r = i * 32 + frag_row;
-        a_base[i] = (r >> TWS) * LP + (r & (TW - 1)) * XLD + frag_k;
+        a_py[i] = r >> TWS;
+        a_px[i] = r & (TW - 1);
+        a_base[i] = a_py[i] * LP + a_px[i] * XLD + frag_k;
     }
 
     // The host aligns split-K ranges to whole slabs for this kernel (it0, it1 multiples of 9).  One slab = ONE basic
@@ -911,11 +918,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
     const unsigned short *hb = smem;
     auto afrag = [&](const int set, const int tap, const int kk) {
         const int ky = tap / 3, kx = tap - 3 * ky;
-        const unsigned short *ah = hb + ky * LP + kx * XLD;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            fa[set][i][0] = *reinterpret_cast<const u32x4 *>(ah + a_base[i] + kk * 16);
-            fa[set][i][1] = *reinterpret_cast<const u32x4 *>(ah + HPL + a_base[i] + kk * 16);
+            const unsigned short *ah;
+            if constexpr (UPS) ah = hb + (((a_py[i] + ky - 1) >> 1) + 1) * LP + (((a_px[i] + kx - 1) >> 1) + 1) * XLD + frag_k;
+            else ah = hb + ky * LP + kx * XLD + a_base[i];
+            fa[set][i][0] = *reinterpret_cast<const u32x4 *>(ah + kk * 16);
+            fa[set][i][1] = *reinterpret_cast<const u32x4 *>(ah + HPL + kk * 16);
         }
     };
     for (int sl = s0; sl < s1; ++sl) {
@@ -1064,8 +1073,11 @@ struct XPlan {
 static bool halo_shape(const sgam_conv_desc *d, int bm, int bn) {
     static const int halo_on = [] { const char *e = getenv("SGAM_F32X_HALO"); return (e && e[0] == '0') ? 0 : 1; }();
     const bool tile_ok = (bm == 128 && bn == 128 && d->Wo % 16 == 0) || (bm == 64 && bn == 128 && d->Wo % 8 == 0);
+    static const int gen1 = [] { const char *e = getenv("SGAM_F32X_HALO"); return (e && e[0] == '1') ? 1 : 0; }();
+    const int up = d->upsample2x ? 2 : 1;
+    if (d->upsample2x && gen1) return false;            // the first-generation halo kernel has no upsampling form
     return halo_on && tile_ok && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 &&
-           !d->upsample2x && d->Ho == d->Hi && d->Wo == d->Wi && d->Ho % 8 == 0 && d->Cin % 32 == 0;
+           d->Ho == up * d->Hi && d->Wo == up * d->Wi && d->Ho % 8 == 0 && d->Cin % 32 == 0;
 }
 
 XPlan make_xplan(const sgam_conv_desc *d) {
@@ -1148,8 +1160,14 @@ static bool halo_eligible(const sgam_conv_desc *d, const XPlan &pl, float a_scal
     return a_scale == 1.0f && halo_shape(d, pl.bm, pl.bn);
 }
 
-extern "C" int32_t sgam_conv2d_f32x_gn_fusable(const sgam_conv_desc *d) {
+// 1 when this descriptor runs on a halo-staged 3x3 kernel (plain or nearest-2x upsampled input), 0: generic kernel
+extern "C" int32_t sgam_conv2d_f32x_uses_halo(const sgam_conv_desc *d) {
     if (xvalidate(d) != SGAM_OK) return 0;
+    return halo_eligible(d, make_xplan(d), 1.0f) ? 1 : 0;
+}
+
+extern "C" int32_t sgam_conv2d_f32x_gn_fusable(const sgam_conv_desc *d) {
+    if (xvalidate(d) != SGAM_OK || d->upsample2x) return 0;
     return halo_eligible(d, make_xplan(d), 1.0f) ? 1 : 0;
 }
 
@@ -1258,7 +1276,10 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
     if (halo) {
         static const int dyn = [] { const char *e = getenv("SGAM_XDYN_LDS"); return e ? atoi(e) : 0; }();   // occupancy experiments
         static const int halo_gen = [] { const char *e = getenv("SGAM_F32X_HALO"); return (e && e[0] == '1') ? 1 : 2; }();
-        if (halo_gen == 2) {
+        if (halo_gen == 2 && p.ups) {
+            if (pl.bm == 128) hipLaunchKernelGGL((conv3x3_f32x_halo2_kernel<128, 128, false, true>), grid, dim3(256), dyn, s, p);
+            else hipLaunchKernelGGL((conv3x3_f32x_halo2_kernel<64, 128, false, true>), grid, dim3(256), dyn, s, p);
+        } else if (halo_gen == 2) {
             if (pl.bm == 128) {
                 if (p.gn_stats) hipLaunchKernelGGL((conv3x3_f32x_halo2_kernel<128, 128, true>), grid, dim3(256), dyn, s, p);
                 else hipLaunchKernelGGL((conv3x3_f32x_halo2_kernel<128, 128, false>), grid, dim3(256), dyn, s, p);

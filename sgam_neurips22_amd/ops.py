@@ -226,7 +226,7 @@ def _run_conv(desc, x, w, bias, residual, out, gn=None, a_scale=1.0, norm=None):
         flops = 2.0 * desc.B * desc.Ho * desc.Wo * desc.n_valid * desc.KH * desc.KW * desc.Cin
         plan = conv_plan(desc, x.dtype in H16, split)
         if split:
-            halo = a_scale == 1.0 and lib.sgam_conv2d_f32x_gn_fusable(ctypes.byref(desc)) == 1
+            halo = a_scale == 1.0 and lib.sgam_conv2d_f32x_uses_halo(ctypes.byref(desc)) == 1
             kernel = f"{'conv3x3_f32x_halo2_kernel' if halo else 'conv_gemm_f32x_kernel'}<{plan[0]},{plan[1]}>"
         else:
             kernel = f"{'conv_gemm_h16_kernel' if x.dtype in H16 else 'conv_gemm_f32_v2_kernel'}<{plan[0]},{plan[1]}>"
