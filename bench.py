@@ -237,7 +237,7 @@ def main():
     if roofline is not None and args.dtype == "f32":
         # HBM traffic of the dominant kernel: PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) collected
         # with rocprofv3 --pmc in separate passes on the dominant layer shape and committed under profiles/
-        name = "r01d_pmc_halo2_128_f32x.json" if ops.F32_MODE == "split" else "r01b_pmc_conv128_f32.json"
+        name = "r01f_pmc_halo2_128_f32x.json" if ops.F32_MODE == "split" else "r01b_pmc_conv128_f32.json"
         pmc = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pmc):
             d = json.load(open(pmc))["derived"]
