@@ -21,7 +21,6 @@ SOURCES = {
     "conv_f32x.hip": [f"-DSGAM_XPF_BIG={os.environ.get('SGAM_XPF_BIG', '2')}",
                       f"-DSGAM_XPF_SMALL={os.environ.get('SGAM_XPF_SMALL', '4')}",
                       f"-DSGAM_XABLATE={os.environ.get('SGAM_XABLATE', '0')}",
-                      f"-DSGAM_XPRIO={os.environ.get('SGAM_XPRIO', '0')}",
                       f"-DSGAM_XSB={os.environ.get('SGAM_XSB', '1')}"],
     "vq.hip": ["-ffp-contract=off"],
     "layout.hip": ["-ffp-contract=off"],

@@ -27,9 +27,6 @@
 
 #include "sgam_common.h"
 
-#ifndef SGAM_XSCHED
-#define SGAM_XSCHED 0
-#endif
 
 namespace {
 
@@ -65,9 +62,6 @@ struct XParams {
 #endif
 #ifndef SGAM_XSB
 #define SGAM_XSB 1
-#endif
-#ifndef SGAM_XPRIO
-#define SGAM_XPRIO 1
 #endif
 #ifndef SGAM_XBK_SMALL
 #define SGAM_XBK_SMALL 64
@@ -259,8 +253,7 @@ __global__ __launch_bounds__(256 * wk_of(BM, BN)) void conv_gemm_f32x_kernel(con
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int PF = (BM * BN >= 128 * 128) ? SGAM_XPF_BIG : SGAM_XPF_SMALL;
     constexpr int AC = XBK / 4;            // float4 columns of an A slab row
-    constexpr int BC = XBK / 8;            // 16-byte chunks of a B plane row
-    static_assert(NT / AC == 32 && NT / BC == 64, "staging maps assume 32 A rows / 64 B rows per pass");
+    static_assert(NT / AC == 32, "the A staging map assumes 32 rows per pass");
     constexpr int AR = BM / 32;            // float4 rows of A per thread
     constexpr int SL = XBK / 32;           // 32-element K slabs per pipeline step
     constexpr int NPB = (BN / 32) * SL * 256 / NT;   // 16-byte B pieces per thread (see b_piece)
@@ -389,7 +382,6 @@ __global__ __launch_bounds__(256 * wk_of(BM, BN)) void conv_gemm_f32x_kernel(con
         unsigned short *ah = smem + buf * STAGE;
         unsigned short *al = ah + PLANE_A;
         unsigned short *bhp = al + PLANE_A;
-        unsigned short *blp = bhp + PLANE_B;
 #pragma unroll
         for (int r = 0; r < AR; ++r) {
             u32x2 hi, lo;
@@ -404,7 +396,6 @@ __global__ __launch_bounds__(256 * wk_of(BM, BN)) void conv_gemm_f32x_kernel(con
         }
 #pragma unroll
         for (int j = 0; j < NPB; ++j) *reinterpret_cast<u32x4 *>(bhp + b_lds[j]) = bp[st][j];
-        (void)blp;
     };
 
     // one accumulator per output tile; a wavefront that owns a single tile keeps the cross terms (a_lo b_hi + a_hi b_lo)
@@ -521,232 +512,11 @@ __global__ __launch_bounds__(256 * wk_of(BM, BN)) void conv_gemm_f32x_kernel(con
 // ---------------------------------------------------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 convolution with a HALO-staged A operand (the bulk of the network's FLOPs).
 // The generic kernel above fetches, splits and stages the A tile once per filter tap: nine global->LDS passes over
-// (almost) the same pixels for every 32-channel slab.  Here the workgroup owns an 8 x 16 patch of output pixels; per
-// slab it stages the 10 x 18 halo of that patch ONCE (global loads, the fp32 -> hi/lo split and the LDS writes of the A
-// side drop 6.4x) and the nine taps read their MFMA A fragments from it at a wavefront-uniform row offset
-// (ky * 18 + kx); consecutive lanes still read consecutive 80-byte rows, so ds_read_b128 stays conflict-free.  The B
-// (weight) tile is double-buffered per tap exactly as in the generic kernel.  The halo of the next slab is prefetched
-// into registers a whole slab ahead and swapped in behind one extra barrier per nine taps.
-// GN: the input is GroupNorm(+swish)-ed on the fly from a per-(image, channel) scale/shift table while the halo is
-// staged — once per slab, not once per tap, so the normalisation costs 1/6 of what it does in a per-tap prologue and
-// the stand-alone normalise pass (a read and a write of the whole activation) disappears.  Padding pixels stay 0.
-// BM = 128: 8 x 16 patches (180 halo pixels); BM = 64: 8 x 8 patches (100 halo pixels) for the maps that would not
-// fill the chip with 128-pixel tiles.
-template <int BM, int BN, bool GN>
-__global__ __launch_bounds__(256) void conv3x3_f32x_halo_kernel(const XParams p) {
-    constexpr int WGM_ = 2;
-    constexpr int TH = 8, TW = BM / 8, TWS = (TW == 16) ? 4 : 3, HWID = TW + 2, HR = (TH + 2) * HWID;
-    static_assert(BM == 128 || BM == 64, "8 x 16 or 8 x 8 output patches");
-    constexpr int XBK = 32, XLD = XBK + 8;
-    constexpr int TM = BM / 64, TN = BN / 64;
-    constexpr int HPL = HR * XLD;                       // halfs per halo plane
-    constexpr int PLANE_B = BN * XLD;
-    constexpr int NH = (HR * 8 + 255) / 256;            // float4 halo loads per thread (6)
-    constexpr int OP_BYTES = (2 * HPL + 4 * PLANE_B) * 2;
-    constexpr int EPI_BYTES = 4 * (32 * TM) * (32 * TN + 4) * 4;
-    constexpr int SM_BYTES = OP_BYTES > EPI_BYTES ? OP_BYTES : EPI_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned short smem[SM_BYTES / 2];
-    unsigned short *halo = smem;                        // [2 planes][HR][XLD]
-    unsigned short *bsm = smem + 2 * HPL;               // [2 stages][2 planes][BN][XLD]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    int bx, by, bz;
-    xcd_block(p, bx, by, bz);
-    const int n0 = by * BN;
-    const int tiles_x = p.Wo / TW, tiles_img = tiles_x * (p.Ho / TH);
-    const int b = bx / tiles_img;
-    const int t_img = bx - b * tiles_img;
-    const int ty0 = (t_img / tiles_x) * TH, tx0 = (t_img % tiles_x) * TW;
-
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, (int)p.w_plane_bytes, 0x00020000);
-
-    const int it0 = bz * p.iters_per_split;
-    const int it1 = min(p.iters_total, it0 + p.iters_per_split);
-
-    // halo staging: float4 index tid + 256 j -> (halo pixel, float4 column); byte offset of channel 0, or out of range
-    unsigned h_off[NH];
-    int h_lds[NH];
-#pragma unroll
-    for (int j = 0; j < NH; ++j) {
-        const int idx = tid + 256 * j;
-        const int row = idx >> 3, col4 = idx & 7;
-        const int hy = row / HWID, hx = row - hy * HWID;
-        const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
-        const bool ok = row < HR && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-        h_off[j] = ok ? (unsigned)(((b * p.Hi + iy) * p.Wi + ix) * p.lda + col4 * 4) * 4u : 0xFFFFFFFFu;
-        h_lds[j] = row < HR ? row * XLD + col4 * 4 : -1;
-    }
-    constexpr int NPB = BN / 32;          // fragment-ordered weights: thread t takes piece t of each 32-row tile
-    unsigned b_off[NPB];
-    int b_lds[NPB];
-    const unsigned slabs_per_row = (unsigned)p.ldb / 32u;
-#pragma unroll
-    for (int j = 0; j < NPB; ++j) {
-        const int plane = tid >> 7, kk = (tid >> 6) & 1, kh = (tid >> 5) & 1, row = tid & 31;
-        const int n = n0 + j * 32 + row;
-        b_off[j] = n < p.N ? (((unsigned)(n >> 5) * slabs_per_row * 256u + (unsigned)tid) * 16u) : 0xC0000000u;
-        b_lds[j] = plane * PLANE_B + (j * 32 + row) * XLD + kk * 16 + kh * 8;
-    }
-
-    f32x4 hreg[NH];
-    f32x4 gt0, gt1;          // GN: {scale, shift} of this thread's 4 channels (its float4 column is the same for every j)
-    u32x4 bp[NPB];
-    auto hload = [&](int ch) {
-        const unsigned coff = (unsigned)ch * (XBK * 4u);
-#pragma unroll
-        for (int j = 0; j < NH; ++j) {
-            const unsigned o = h_off[j] == 0xFFFFFFFFu ? p.x_bytes : h_off[j] + coff;
-            hreg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)o, 0, 0));
-        }
-        if constexpr (GN) {
-            gn_scale_shift(p, b, ch * XBK + (tid & 7) * 4, gt0, gt1);
-        }
-    };
-    // hprep: GroupNorm(+swish) and the hi/lo split, in registers ({hi0, hi1, lo0, lo1} replace the four floats) — issued
-    // during the LAST tap of the running slab so that it hides behind that tap's MFMAs; hstore then only writes LDS
-    auto hprep = [&]() {
-#pragma unroll
-        for (int j = 0; j < NH; ++j) {
-            u32x2 hi, lo;
-            f32x4 v = hreg[j];
-            if constexpr (GN) {
-                v[0] = v[0] * gt0[0] + gt0[1];
-                v[1] = v[1] * gt0[2] + gt0[3];
-                v[2] = v[2] * gt1[0] + gt1[1];
-                v[3] = v[3] * gt1[2] + gt1[3];
-                if (p.gn_swish) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = sgam_swish(v[e]);
-                }
-                if (h_off[j] == 0xFFFFFFFFu) v = f32x4{0.f, 0.f, 0.f, 0.f};     // zero padding is applied AFTER the norm
-            }
-            split4(v, hi, lo);
-            hreg[j] = __builtin_bit_cast(f32x4, u32x4{hi[0], hi[1], lo[0], lo[1]});
-        }
-    };
-    auto hstore = [&]() {
-#pragma unroll
-        for (int j = 0; j < NH; ++j) {
-            const u32x4 q = __builtin_bit_cast(u32x4, hreg[j]);
-            if (h_lds[j] >= 0) {
-                *reinterpret_cast<u32x2 *>(halo + h_lds[j]) = u32x2{q[0], q[1]};
-                *reinterpret_cast<u32x2 *>(halo + HPL + h_lds[j]) = u32x2{q[2], q[3]};
-            }
-        }
-    };
-    auto bload = [&](int tap, int ch, bool live) {
-        const unsigned koff = (unsigned)(tap * p.Cin + ch * XBK) * 128u;
-#pragma unroll
-        for (int j = 0; j < NPB; ++j)
-            bp[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)xsel(live, b_off[j] + koff, p.w_plane_bytes), 0, 0);
-    };
-    auto bstore = [&](int buf) {
-        unsigned short *bhp = bsm + buf * 2 * PLANE_B;
-#pragma unroll
-        for (int j = 0; j < NPB; ++j) *reinterpret_cast<u32x4 *>(bhp + b_lds[j]) = bp[j];
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const int frag_row = lane & 31;
-    const int frag_k = (lane >> 5) * 8;
-    int a_base[TM];          // halo row of this lane's fragment rows at tap (0, 0), in halfs
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int r = wm * (BM / 2) + i * 32 + frag_row;
-        a_base[i] = ((r >> TWS) * HWID + (r & (TW - 1))) * XLD + frag_k;
-    }
-
-    int ch = it0 / 9;
-    int tap = it0 - ch * 9;
-    hload(ch);
-    bload(tap, ch, it0 < it1);
-    hprep();
-    hstore();
-    bstore(0);
-    if ((ch + 1) * 9 < it1) hload(ch + 1);              // next slab's halo: in flight for the whole slab
-    __syncthreads();
-
-    for (int it = it0; it < it1; ++it) {
-        const int buf = (it - it0) & 1;
-        int ntap = tap + 1, nch = ch;
-        if (ntap == 9) {
-            ntap = 0;
-            ++nch;
-        }
-        if (SGAM_XABLATE != 11 && SGAM_XABLATE != 12) bload(ntap, nch, it + 1 < it1);
-#if SGAM_XSB
-        __builtin_amdgcn_sched_barrier(0);      // keep the prefetch HERE: the scheduler otherwise sinks the loads to their use
-#endif
-        if (ntap == 0 && it + 1 < it1) hprep();          // next slab's halo: normalise + split under this tap's MFMAs
-        const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
-        const unsigned short *ah = halo + (ky * HWID + kx) * XLD;
-        const unsigned short *bhp = bsm + buf * 2 * PLANE_B + (wn * (BN / 2) + frag_row) * XLD + frag_k;
-        // both k-steps' fragments are requested up front (16 ds_read_b128 in flight); the MFMA clusters run at raised
-        // priority so that the two workgroups sharing a SIMD fall out of phase (one multiplies while the other reads)
-        u32x4 fah[2][TM], fal[2][TM], fbh[2][TN], fbl[2][TN];
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                fah[kk][i] = *reinterpret_cast<const u32x4 *>(ah + a_base[i] + kk * 16);
-                fal[kk][i] = *reinterpret_cast<const u32x4 *>(ah + HPL + a_base[i] + kk * 16);
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                fbh[kk][j] = *reinterpret_cast<const u32x4 *>(bhp + j * 32 * XLD + kk * 16);
-                fbl[kk][j] = *reinterpret_cast<const u32x4 *>(bhp + PLANE_B + j * 32 * XLD + kk * 16);
-            }
-        }
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            if (kk == 1 && SGAM_XABLATE != 12) bstore(buf ^ 1);
-#if SGAM_XPRIO
-            __builtin_amdgcn_s_setprio(SGAM_XPRIO);
-#endif
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if (SGAM_XABLATE == 13) {
-                        acc[i][j][0] += __builtin_bit_cast(float, fal[kk][i][0] ^ fbh[kk][j][0] ^ fah[kk][i][1] ^ fbl[kk][j][1]);
-                        continue;
-                    }
-                    acc[i][j] = mfma16(fal[kk][i], fbh[kk][j], acc[i][j]);
-                    acc[i][j] = mfma16(fah[kk][i], fbl[kk][j], acc[i][j]);
-                    acc[i][j] = mfma16(fah[kk][i], fbh[kk][j], acc[i][j]);
-                }
-#if SGAM_XPRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
-        }
-        if (SGAM_XABLATE != 14) __syncthreads();
-        if (ntap == 0 && it + 1 < it1 && SGAM_XABLATE != 15) {                 // slab boundary: every wavefront is done with the old halo
-            hstore();
-            if ((nch + 1) * 9 < it1) hload(nch + 1);
-            __syncthreads();
-        }
-        tap = ntap;
-        ch = nch;
-    }
-
-    xepilogue<BM, BN, WGM_>(p, acc, reinterpret_cast<float *>(smem), wave, lane, bx, bz, n0, [&](int row) {
-        return (b * p.Ho + ty0 + (row >> TWS)) * p.Wo + tx0 + (row & (TW - 1));
-    });
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Halo kernel, second generation: the B (weight) fragments never touch LDS.  In the [N][K/32][hi 32 | lo 32] layout the
+// (almost) the same pixels for every 32-channel slab.  Here the workgroup owns an 8 x 16 (8 x 8) patch of output pixels;
+// per slab it stages the 10 x 18 (10 x 10) halo of that patch ONCE (global loads, the fp32 -> hi/lo split and the LDS
+// writes of the A side drop 6.4x) and the nine taps read their MFMA A fragments from it at a wavefront-uniform offset.
+// (A first generation of this kernel kept the weight tile in LDS, double-buffered per tap with one barrier per tap; it
+// is in the history — this second generation replaced it.)  The B (weight) fragments never touch LDS.  In the [N][K/32][hi 32 | lo 32] layout the
 // MFMA B operand of a lane (8 consecutive halfs of one output channel's K slab) is one aligned 16-byte piece of a
 // 128-byte line, so every wavefront pulls the fragments of its own 64 output channels for the next tap straight into
 // registers (8 x buffer_load_dwordx4, each 128-byte line consumed whole across the four (k-step, plane) pieces; the
@@ -1073,9 +843,7 @@ struct XPlan {
 static bool halo_shape(const sgam_conv_desc *d, int bm, int bn) {
     static const int halo_on = [] { const char *e = getenv("SGAM_F32X_HALO"); return (e && e[0] == '0') ? 0 : 1; }();
     const bool tile_ok = (bm == 128 && bn == 128 && d->Wo % 16 == 0) || (bm == 64 && bn == 128 && d->Wo % 8 == 0);
-    static const int gen1 = [] { const char *e = getenv("SGAM_F32X_HALO"); return (e && e[0] == '1') ? 1 : 0; }();
     const int up = d->upsample2x ? 2 : 1;
-    if (d->upsample2x && gen1) return false;            // the first-generation halo kernel has no upsampling form
     return halo_on && tile_ok && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 &&
            d->Ho == up * d->Hi && d->Wo == up * d->Wi && d->Ho % 8 == 0 && d->Cin % 32 == 0;
 }
@@ -1274,25 +1042,15 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
     const bool halo = halo_eligible(d, pl, a_scale);
     if (ex.gn_stats && !halo) return SGAM_EINVAL;
     if (halo) {
-        static const int dyn = [] { const char *e = getenv("SGAM_XDYN_LDS"); return e ? atoi(e) : 0; }();   // occupancy experiments
-        static const int halo_gen = [] { const char *e = getenv("SGAM_F32X_HALO"); return (e && e[0] == '1') ? 1 : 2; }();
-        if (halo_gen == 2 && p.ups) {
-            if (pl.bm == 128) hipLaunchKernelGGL((conv3x3_f32x_halo2_kernel<128, 128, false, true>), grid, dim3(256), dyn, s, p);
-            else hipLaunchKernelGGL((conv3x3_f32x_halo2_kernel<64, 128, false, true>), grid, dim3(256), dyn, s, p);
-        } else if (halo_gen == 2) {
-            if (pl.bm == 128) {
-                if (p.gn_stats) hipLaunchKernelGGL((conv3x3_f32x_halo2_kernel<128, 128, true>), grid, dim3(256), dyn, s, p);
-                else hipLaunchKernelGGL((conv3x3_f32x_halo2_kernel<128, 128, false>), grid, dim3(256), dyn, s, p);
-            } else {
-                if (p.gn_stats) hipLaunchKernelGGL((conv3x3_f32x_halo2_kernel<64, 128, true>), grid, dim3(256), dyn, s, p);
-                else hipLaunchKernelGGL((conv3x3_f32x_halo2_kernel<64, 128, false>), grid, dim3(256), dyn, s, p);
-            }
+        if (p.ups) {
+            if (pl.bm == 128) hipLaunchKernelGGL((conv3x3_f32x_halo2_kernel<128, 128, false, true>), grid, dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((conv3x3_f32x_halo2_kernel<64, 128, false, true>), grid, dim3(256), 0, s, p);
         } else if (pl.bm == 128) {
-            if (p.gn_stats) hipLaunchKernelGGL((conv3x3_f32x_halo_kernel<128, 128, true>), grid, dim3(256), dyn, s, p);
-            else hipLaunchKernelGGL((conv3x3_f32x_halo_kernel<128, 128, false>), grid, dim3(256), dyn, s, p);
+            if (p.gn_stats) hipLaunchKernelGGL((conv3x3_f32x_halo2_kernel<128, 128, true>), grid, dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((conv3x3_f32x_halo2_kernel<128, 128, false>), grid, dim3(256), 0, s, p);
         } else {
-            if (p.gn_stats) hipLaunchKernelGGL((conv3x3_f32x_halo_kernel<64, 128, true>), grid, dim3(256), dyn, s, p);
-            else hipLaunchKernelGGL((conv3x3_f32x_halo_kernel<64, 128, false>), grid, dim3(256), dyn, s, p);
+            if (p.gn_stats) hipLaunchKernelGGL((conv3x3_f32x_halo2_kernel<64, 128, true>), grid, dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((conv3x3_f32x_halo2_kernel<64, 128, false>), grid, dim3(256), 0, s, p);
         }
     } else if (pl.bm == 128 && pl.bn == 128) XLAUNCH(128, 128);
     else if (pl.bm == 64 && pl.bn == 128) XLAUNCH(64, 128);
