@@ -115,7 +115,7 @@ class TsdfOracle:
             rx, ry = F((F(u) - cx) / fx), F((F(v) - cy) / fy)
             o = [c2w[r, 3] for r in range(3)]
             d = [F(F(F(c2w[r, 0] * rx) + F(c2w[r, 1] * ry)) + c2w[r, 2]) for r in range(3)]
-            RS = 4
+            RS = 8
             seg_len = F(F(F(z_far) - F(z_near)) / F(RS))
             best = None
             for seg in range(RS):           # the device marches the RS segments on adjacent lanes; nearest hit wins

@@ -31,7 +31,7 @@ namespace {
 
 constexpr int UR = 16;                 // voxels per unit edge (Open3D volume_unit_resolution)
 constexpr int UV = UR * UR * UR;       // voxels per brick
-constexpr int RS = 4;                  // depth segments (lanes) per ray in the ray cast
+constexpr int RS = 8;                  // depth segments (lanes) per ray in the ray cast
 
 struct Pose {
     float m[16];                       // row-major 4x4, passed by value in the kernel arguments
