@@ -63,3 +63,53 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.SgamHipError, match="no CPU fallback"):
         _lib.load()
+
+
+def _desc(**kw):
+    base = dict(B=1, Hi=64, Wi=64, Cin=128, Ho=64, Wo=64, N=128, KH=3, KW=3, stride=1, pad_t=1, pad_l=1, upsample2x=0,
+                lda=128, ldb=1152, ldc=128, ldr=0, n_valid=128, bias_per_row=0)
+    base.update(kw)
+    return _lib.ConvDesc(**base)
+
+
+def test_split_fp32_plan_queries_without_gpu():
+    """the host-side planning logic of the split-fp32 family (no launch): which kernel a descriptor gets, where the
+    GroupNorm statistics of its output come from, how split-K ranges are aligned"""
+    lib = _lib.load()
+    ref = ctypes.byref
+    d = _desc(plan_bm=64, plan_bn=128, plan_ksplit=1)
+    assert lib.sgam_conv2d_f32x_uses_halo(ref(d)) == 1 and lib.sgam_conv2d_f32x_gn_fusable(ref(d)) == 1
+    assert lib.sgam_conv2d_f32x_stats_chunks(ref(d)) > 0 and lib.sgam_conv2d_f32x_stats_mode(ref(d)) == 1
+    # nearest-2x upsampling conv: halo kernel, but no GroupNorm precedes it
+    u = _desc(Hi=32, Wi=32, upsample2x=1, plan_bm=64, plan_bn=128, plan_ksplit=1)
+    assert lib.sgam_conv2d_f32x_uses_halo(ref(u)) == 1 and lib.sgam_conv2d_f32x_gn_fusable(ref(u)) == 0
+    # stride 2 / 1x1 / maps that do not tile into 8x8 patches: generic kernel
+    for g in (_desc(Ho=32, Wo=32, stride=2, pad_t=0, pad_l=0, plan_bm=64, plan_bn=128, plan_ksplit=1),
+              _desc(KH=1, KW=1, pad_t=0, pad_l=0, ldb=128, plan_bm=64, plan_bn=128, plan_ksplit=1),
+              _desc(Hi=20, Wi=20, Ho=20, Wo=20, plan_bm=64, plan_bn=128, plan_ksplit=1), _desc()):   # last: heuristic 64x64
+        assert lib.sgam_conv2d_f32x_uses_halo(ref(g)) == 0
+    # halo plans split K on whole channel slabs (9 taps): 4 slabs of 9 taps -> ranges of 9, 18 or 36
+    bm, bn, ks = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    s = _desc(plan_bm=64, plan_bn=128, plan_ksplit=3)
+    assert lib.sgam_conv2d_f32x_plan(ref(s), ref(bm), ref(bn), ref(ks)) == 0 and ks.value == 2      # 18 + 18
+    assert lib.sgam_conv2d_f32x_workspace_bytes(ref(s)) == 2 * 64 * 64 * 128 * 4
+    assert lib.sgam_conv2d_f32x_stats_chunks(ref(s)) == 64 * 64 * 128 // 1024                     # from the combine
+    # rejected descriptors: layout constraints of the fragment-ordered B operand and the 16-byte epilogue
+    assert lib.sgam_conv2d_f32x_workspace_bytes(ref(_desc(ldb=1150))) == -1
+    assert lib.sgam_conv2d_f32x_workspace_bytes(ref(_desc(Cin=100, lda=100, ldb=928))) == -1      # taps need whole slabs
+    assert lib.sgam_conv2d_f32x_workspace_bytes(ref(_desc(n_valid=126))) == -1
+    assert lib.sgam_conv2d_f32x_plan(ref(_desc(plan_bm=96, plan_bn=128)), ref(bm), ref(bn), ref(ks)) < 0
+    # entry points refuse NULL operands before any launch
+    assert lib.sgam_conv2d_nhwc_f32x(ref(d), None, 1.0, None, 1.0, None, None, None, None, 0, None) == -1
+    assert lib.sgam_conv2d_gn_nhwc_f32x(ref(d), None, None, None, None, 1, None, 1.0, None, None, None, None, None, 0, None) == -1
+
+
+def test_tsdf_argument_validation_without_gpu():
+    lib = _lib.load()
+    g = _lib.TsdfGrid(0.01, 0.03, (ctypes.c_int32 * 3)(0, 0, 0), (ctypes.c_int32 * 3)(4, 4, 4))
+    bad = _lib.TsdfGrid(0.0, 0.03, (ctypes.c_int32 * 3)(0, 0, 0), (ctypes.c_int32 * 3)(4, 4, 4))
+    args = (None, 8, 8, 10.0, 10.0, 4.0, 4.0, None, None, 20.0, 1, None, None, None, None, 16, None, None, None, 16, None)
+    assert lib.sgam_tsdf_integrate_f32(ctypes.byref(g), *args) == -1
+    assert lib.sgam_tsdf_integrate_f32(ctypes.byref(bad), *args) == -1
+    assert lib.sgam_tsdf_raycast_depth_f32(ctypes.byref(g), 8, 8, 10.0, 10.0, 4.0, 4.0, None, 0.1, 4.0, None, None, None, None,
+                                           None, None) == -1
