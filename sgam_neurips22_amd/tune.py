@@ -131,10 +131,74 @@ def tune_shape(key, verbose=True):
         gf = 2.0 * M * N * K / 1e9
         print(f"{key:70s} auto {t_auto * 1e3:7.1f} us -> best {best[0] * 1e3:7.1f} us {best[1:]}  "
               f"({gf / best[0] / 1e3:6.1f} TFLOP/s)", flush=True)
+    CANDIDATES[key] = results[:4]
     # keep the heuristic unless the tuned plan wins by >3% (run-to-run noise)
     if t_auto is not None and best[0] > 0.97 * t_auto:
         return None, t_auto, best
     return best[1:], t_auto, best
+
+
+CANDIDATES = {}      # key -> the four fastest (time, bm, bn, ks) of the isolated timing, for refine_in_frame
+
+
+def refine_in_frame(plans, dataset="google_earth", res=256, frames=12, verbose=True):
+    """Second pass: the isolated timing of tune_shape replays one layer back to back (its split-K workspace and
+    weights stay cache-hot, the clock settles for that kernel alone).  Here every shape's runner-up plans are tried
+    INSIDE the real frame — the whole scene loop is re-captured and timed with the candidate in place — and a
+    candidate is kept only if the frame gets faster.  Greedy, one shape at a time, most expensive shapes first."""
+    import time
+
+    from .config import default_params
+    from .generative_sensing_module.model import VQModel
+    from .inference_pipeline import InfiniteSceneGeneration, synthetic_seed_frame
+    m = VQModel(**default_params(dataset))
+    m.load_state_dict(testing.synthetic_state_dict(m.state_dict(), seed=0))
+    m = m.to("cuda").eval()
+    seed = synthetic_seed_frame(dataset, 0, res)
+
+    def frame_ms():
+        m.enable_hip_graph(False)
+        m.enable_hip_graph(True)                     # drop the captured graphs: plans are baked into them
+        sc = InfiniteSceneGeneration(m, dataset, output_dim=(frames + 6, 1), seed_frame=seed)
+        best = 1e9
+        for rep in range(2):
+            for _ in range(3 if rep == 0 else 0):
+                sc.one_step_prediction(sc.next_pose(sc.curr)); sc.curr += 1
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            n = frames // 2
+            for _ in range(n):
+                sc.one_step_prediction(sc.next_pose(sc.curr)); sc.curr += 1
+            torch.cuda.synchronize()
+            best = min(best, (time.perf_counter() - t) / n * 1e3)
+        return best
+
+    def install(p):
+        ops.PLAN_CACHE.clear()
+        ops.PLAN_CACHE.update({k: tuple(v) for k, v in p.items()})
+
+    plans = dict(plans)
+    install(plans)
+    cur = frame_ms()
+    if verbose:
+        print(f"in-frame refinement: start {cur:.3f} ms/frame", flush=True)
+    order = sorted(CANDIDATES, key=lambda k: -CANDIDATES[k][0][0])
+    for key in order:
+        for t, bm, bn, ks in CANDIDATES[key][:3]:
+            if plans.get(key) == [bm, bn, ks] or plans.get(key) == (bm, bn, ks):
+                continue
+            trial = dict(plans)
+            trial[key] = [bm, bn, ks]
+            install(trial)
+            ms = frame_ms()
+            if ms < cur * 0.995:
+                if verbose:
+                    print(f"  {key}: {plans.get(key)} -> {[bm, bn, ks]}  {cur:.3f} -> {ms:.3f} ms/frame", flush=True)
+                plans, cur = trial, ms
+    install(plans)
+    if verbose:
+        print(f"in-frame refinement: end {cur:.3f} ms/frame", flush=True)
+    return plans
 
 
 def collect_shapes(dtypes, dataset="google_earth", res=256):
@@ -160,6 +224,8 @@ def main():
     ap.add_argument("--dtypes", default="f32,fp16,bf16", help="f32 tunes the current ops.F32_MODE (split by default)")
     ap.add_argument("--merge", action="store_true", help="keep the plans already in the output file for other dtypes")
     ap.add_argument("--out", default=ops._PLAN_FILE)
+    ap.add_argument("--refine", action="store_true", help="after the isolated timing, re-judge the runner-up plans inside the "
+                                                          "real frame (f32 only)")
     a = ap.parse_args()
     os.environ["SGAM_NO_TUNED_PLANS"] = "1"
     ops.load_plans()
@@ -172,6 +238,9 @@ def main():
             plans[k] = list(pl)
             saved += (t_auto - best[0])
     print(f"tuned {len(plans)} of {len(keys)} shapes; sum of per-shape savings {saved * 1e3:.0f} us (one launch each)")
+    if a.refine:
+        os.environ.pop("SGAM_NO_TUNED_PLANS", None)
+        plans = refine_in_frame(plans)
     if a.merge and os.path.exists(ops._PLAN_FILE):
         old = json.load(open(ops._PLAN_FILE)).get("plans", {})
         for k in keys:                 # every shape just examined: the new verdict (plan or heuristic) replaces the old one
