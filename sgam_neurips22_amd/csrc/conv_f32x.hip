@@ -8,8 +8,10 @@
 // Products of fp16 values are exact in fp32, so the only errors are the 2^-22-class representation residue and the
 // usual fp32 accumulation round-off: the result is as accurate as an fp32 GEMM with a different summation order
 // (and is held to the same acceptance tests: bit-exact codebook indices on the margin-guarded fixtures, RGB-D within
-// 1e-4 of the reference) at 3/16 of the fp32-MFMA issue time — the kernel then sits on the LDS / L1 data path
-// instead of the matrix pipe.
+// 1e-4 of the reference) at 3/16 of the fp32-MFMA issue time.  Three kernels share the arithmetic: the generic
+// implicit-GEMM kernel (any conv / GEMM shape; A and B tiles through LDS per (tap, slab)), and the halo-staged 3x3
+// kernel with its nearest-2x upsampling form (the bulk of the FLOPs; A halo staged once per channel slab, weight
+// fragments straight from L2 to registers).
 //
 //   * weights are split OFFLINE (sgam_pack_conv_weight_f32x) after multiplying by a power of two `w_scale` that
 //     lifts max|w| to (512, 1024]: both pieces stay in fp16's normal range; the accumulator is multiplied by the
@@ -18,9 +20,10 @@
 //     conv_gemm.hip: same descriptor, same addressing, same bounds-checked buffer loads).  |x| must stay below
 //     65504 (GroupNorm keeps the VQGAN's activations within a few hundred); pieces below fp16's normal range lose
 //     relative, not absolute, accuracy (<= 3e-8 per element).
-//   * LDS: per K slab of 32, four fp16 planes A_hi, A_lo [BM][40], B_hi, B_lo [BN][40] (80-byte rows: 16-byte aligned
-//     and conflict-free for the 16-lane ds_read_b128 groups), double buffered = 80 KiB for 128x128 (two workgroups
-//     per CU).  One ds_read_b128 = the 8 halfs a lane feeds to one 32x32x16 MFMA.
+//   * weights live in HBM in MFMA-fragment order (frag_index): the B operand of one MFMA is one contiguous kilobyte;
+//   * generic kernel LDS: per K slab of 32, four fp16 planes A_hi, A_lo [BM][40], B_hi, B_lo [BN][40] (80-byte rows:
+//     16-byte aligned and conflict-free for the 16-lane ds_read_b128 groups), double buffered = 80 KiB for 128x128
+//     (two workgroups per CU).  One ds_read_b128 = the 8 halfs a lane feeds to one 32x32x16 MFMA.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -36,7 +39,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 struct XParams {
     const float *x, *bias, *res;
-    const unsigned short *w;   // [2][N][ldb] : hi plane then lo plane
+    const unsigned short *w;   // hi / lo fp16 halves of scale * w in MFMA-fragment order (see frag_index)
     float *out, *ws;
     int B, Hi, Wi, Cin, Ho, Wo, N, KH, KW, stride, pad_t, pad_l, ups;
     int lda, ldb, ldc, ldr, n_valid, bias_per_row;
