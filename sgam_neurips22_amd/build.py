@@ -18,8 +18,8 @@ SOURCES = {
     "norm_softmax.hip": [],
     "groupnorm.hip": [],
     "h16.hip": [],
-    "conv_f32x.hip": [f"-DSGAM_XPF_BIG={os.environ.get('SGAM_XPF_BIG', '2')}",
-                      f"-DSGAM_XPF_SMALL={os.environ.get('SGAM_XPF_SMALL', '4')}",
+    "conv_f32x.hip": [f"-DSGAM_XPF_BIG={os.environ.get('SGAM_XPF_BIG', '1')}",
+                      f"-DSGAM_XPF_SMALL={os.environ.get('SGAM_XPF_SMALL', '2')}",
                       f"-DSGAM_XABLATE={os.environ.get('SGAM_XABLATE', '0')}",
                       f"-DSGAM_XSB={os.environ.get('SGAM_XSB', '1')}"],
     "vq.hip": ["-ffp-contract=off"],
