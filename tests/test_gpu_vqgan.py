@@ -305,3 +305,41 @@ def test_topk_sampler_batched_equals_sequential():
         near = q.quantize_nhwc(z)[1].view(3, 1, h, w).expand(-1, 2, -1, -1)
         em = F.interpolate(mask.float(), size=(h, w)).bool().expand(-1, 2, -1, -1)
         assert torch.equal(idx_b[~em], near[~em])
+
+
+def test_concurrent_scenes_reproduce_their_solo_frames():
+    """Two trajectories on two HIP streams of one GPU (graphs, private model instances) generate exactly the frames each
+    generates alone: no state leaks between scenes, no ordering dependence."""
+    from sgam_neurips22_amd.distributed import ConcurrentScenes
+    from sgam_neurips22_amd.inference_pipeline import synthetic_seed_frame
+
+    def model():
+        p = default_params("google_earth")
+        m = VQModel(**p)
+        sd = testing.synthetic_state_dict(m.state_dict(), seed=0)
+        sd["quantize.embedding.weight"] = testing.codebook_from_stats(0.0, 0.5, p["n_embed"], 256, 1)
+        m.load_state_dict(sd)
+        return m.to(DEV).eval().enable_hip_graph(True)
+
+    def scene(i, m):
+        return InfiniteSceneGeneration(m, "google_earth", seed_index=i, output_dim=(5, 1),
+                                       seed_frame=synthetic_seed_frame("google_earth", i, 256))
+
+    solo = []
+    for i in range(2):
+        sc = scene(i, model())
+        for _ in range(3):
+            sc.one_step_prediction(sc.next_pose(sc.curr))
+            sc.curr += 1
+        torch.cuda.synchronize()
+        solo.append({k: (v["rgb_u8"].clone(), v["depth"].clone()) for k, v in sc.frames.items()})
+    cs = ConcurrentScenes(lambda i: scene(i, model()), 2)
+    for _ in range(3):
+        cs.step()
+    cs.synchronize()
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert set(cs.scenes[i].frames) == set(solo[i])
+        for k, (u8, d) in solo[i].items():
+            assert torch.equal(cs.scenes[i].frames[k]["rgb_u8"], u8), (i, k)
+            assert torch.equal(cs.scenes[i].frames[k]["depth"], d), (i, k)
