@@ -295,11 +295,11 @@ int sgam_frame_feedback_f32(const float *dec, const float *lut256, int32_t datas
  * Integration is Open3D's published rule (16^3-voxel units, stride-4 unit opening, running weighted mean of
  * min(1, sdf / sdf_trunc)); the depth render is a direct ray cast of the fused surface (first +/- zero crossing of the
  * trilinear TSDF, view-space z, 0 = nothing hit).  Colour is not fused: the path only consumes the depth.
- *   unit_table [dims.z][dims.y][dims.x] int32, -1 = closed; unit_stamp same shape, 0-initialised;
+ *   unit_table [dims.z][dims.y][dims.x] int32, -1 = closed, else brick index | 0x40000000 once the brick holds part of
+ *   the truncation band (the ray cast only marches those); unit_stamp same shape, 0-initialised;
  *   counters int32[4] = {bricks allocated, length of this frame's brick list, samples outside the box, pool overflows};
- *   brick_tsdf / brick_weight [max_bricks][16*16*16] fp32, 0-initialised; brick_near int32[max_bricks], 0-initialised
- *   (set once a brick holds an observed value inside the truncation band: the ray cast only marches those);
- *   brick_list int32[max_list] scratch.
+ *   brick_tsdf [max_bricks][16*16*16] fp32 initialised to 2.0 (= unobserved: observed values are <= 1, so the ray cast
+ *   needs no weight loads), brick_weight same shape, 0-initialised; brick_list int32[max_list] scratch.
  *   cam2world / world2cam: row-major 4x4 HOST pointers (16 floats each, copied into the kernel arguments: no upload,
  *   no device allocation per frame); intrinsics by value.  frame_id > 0, distinct per call.
  * All state is caller-owned; nothing is synchronised or read back.
@@ -312,11 +312,10 @@ typedef struct sgam_tsdf_grid {
 int sgam_tsdf_integrate_f32(const sgam_tsdf_grid *grid, const float *depth, int32_t H, int32_t W, float fx, float fy, float cx,
                             float cy, const float *cam2world, const float *world2cam, float depth_trunc, int32_t frame_id,
                             int32_t *unit_table, int32_t *unit_stamp, int32_t *counters, int32_t *brick_list, int32_t max_list,
-                            float *brick_tsdf, float *brick_weight, int32_t *brick_near, int32_t max_bricks, void *stream);
+                            float *brick_tsdf, float *brick_weight, int32_t max_bricks, void *stream);
 int sgam_tsdf_raycast_depth_f32(const sgam_tsdf_grid *grid, int32_t H, int32_t W, float fx, float fy, float cx, float cy,
                                 const float *cam2world, float z_near, float z_far, const int32_t *unit_table,
-                                const float *brick_tsdf, const float *brick_weight, const int32_t *brick_near,
-                                float *depth_out, void *stream);
+                                const float *brick_tsdf, float *depth_out, void *stream);
 
 #ifdef __cplusplus
 }

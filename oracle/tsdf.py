@@ -46,7 +46,7 @@ class TsdfOracle:
         for key in touched:
             ux, uy, uz = key
             if key not in self.units:
-                self.units[key] = [np.zeros((UR, UR, UR), F), np.zeros((UR, UR, UR), F)]
+                self.units[key] = [np.full((UR, UR, UR), F(2.0), F), np.zeros((UR, UR, UR), F)]   # 2 = unobserved
             t, w = self.units[key]
             px = (F(ux) * self.unit_len + ii)[None, None, :]
             py = (F(uy) * self.unit_len + ii)[None, :, None]
@@ -77,7 +77,7 @@ class TsdfOracle:
         if u is None:
             return None
         x, y, z = ix & 15, iy & 15, iz & 15
-        if not u[1][z, y, x] > 0:
+        if not u[0][z, y, x] <= 1:
             return None
         return u[0][z, y, x]
 

@@ -31,6 +31,9 @@ namespace {
 
 constexpr int UR = 16;                 // voxels per unit edge (Open3D volume_unit_resolution)
 constexpr int UV = UR * UR * UR;       // voxels per brick
+constexpr int NEAR_BIT = 0x40000000;   // unit table entry = brick index | NEAR_BIT once the brick holds part of the band
+constexpr int BRICK_MASK = 0x3FFFFFFF;
+// (bricks start at 2.0 = unobserved: observed TSDF values are <= 1, so the ray cast tells the two apart in the one load)
 constexpr int RS = 8;                  // depth segments (lanes) per ray in the ray cast
 
 struct Pose {
@@ -84,7 +87,7 @@ __global__ void tsdf_touch_kernel(const float *__restrict__ depth, int H, int W,
                     continue;
                 }
                 if (atomicExch(&stamp[s], frame_id) == frame_id) continue;       // already listed for this frame
-                int brick = table[s];
+                int brick = table[s];          // (the NEAR bit, if set, rides along: entries are only ever extended)
                 if (brick < 0) {
                     // first touch ever: allocate.  The exchange above makes this thread the only one handling slot s
                     // in this frame, so no CAS loop is needed.
@@ -103,10 +106,9 @@ __global__ void tsdf_touch_kernel(const float *__restrict__ depth, int H, int W,
 // pass 2: one workgroup per listed brick (grid-stride over the device-side list), 256 lanes x 16 voxels.
 __global__ __launch_bounds__(256) void tsdf_integrate_kernel(const float *__restrict__ depth, int H, int W, float fx, float fy,
                                                              float cx, float cy, const Pose w2c_, TsdfGrid g,
-                                                             float depth_trunc, const int *__restrict__ table, const int *__restrict__ counters,
+                                                             float depth_trunc, int *__restrict__ table, const int *__restrict__ counters,
                                                              const int *__restrict__ list, int max_list,
-                                                             float *__restrict__ tsdf, float *__restrict__ weight,
-                                                             int *__restrict__ near_flag) {
+                                                             float *__restrict__ tsdf, float *__restrict__ weight) {
     const float *w2c = w2c_.m;
     int n = counters[1];
     if (n > max_list) n = max_list;
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(const float *__rest
     const float safe_w = __fsub_rn((float)W, 0.0001f), safe_h = __fsub_rn((float)H, 0.0001f);
     for (int li = blockIdx.x; li < n; li += gridDim.x) {
         const int s = list[li];
-        const int brick = table[s];
+        const int brick = table[s] & BRICK_MASK;
         const int ux = s % g.dims[0] + g.base[0];
         const int uy = (s / g.dims[0]) % g.dims[1] + g.base[1];
         const int uz = s / (g.dims[0] * g.dims[1]) + g.base[2];
@@ -152,27 +154,25 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(const float *__rest
             }
         }
         // a weighted mean of values <= 1 that is < 1 once stays < 1: the flag is monotone, a plain store suffices
-        if (__syncthreads_or(near) && threadIdx.x == 0) near_flag[brick] = 1;
+        if (__syncthreads_or(near) && threadIdx.x == 0) atomicOr(&table[s], NEAR_BIT);
     }
 }
 
 // TSDF at voxel lattice point (ix, iy, iz) (global voxel indices, centres at (i + 0.5) * voxel); false when unobserved
-__device__ __forceinline__ bool lattice(const TsdfGrid &g, const int *table, const float *tsdf, const float *weight, int ix, int iy,
-                                        int iz, float &val) {
+__device__ __forceinline__ bool lattice(const TsdfGrid &g, const int *table, const float *tsdf, int ix, int iy, int iz, float &val) {
     const int64_t s = unit_slot(g, ix >> 4, iy >> 4, iz >> 4);        // arithmetic shift = floor division by 16
     if (s < 0) return false;
     const int brick = table[s];
     if (brick < 0) return false;
     const int q = ((iz & 15) << 8) | ((iy & 15) << 4) | (ix & 15);
-    if (!(weight[(int64_t)brick * UV + q] > 0.f)) return false;
-    val = tsdf[(int64_t)brick * UV + q];
-    return true;
+    val = tsdf[(int64_t)(brick & BRICK_MASK) * UV + q];
+    return val <= 1.0f;
 }
 
 // TSDF at world point p: trilinear when all eight surrounding lattice points are observed, else the nearest lattice
 // point's value, else false
-__device__ __forceinline__ bool sample(const TsdfGrid &g, const int *table, const float *tsdf, const float *weight, const float *p,
-                                       float inv_voxel, float &val) {
+__device__ __forceinline__ bool sample(const TsdfGrid &g, const int *table, const float *tsdf, const float *p, float inv_voxel,
+                                       float &val) {
     float f[3];
     int i0[3];
 #pragma unroll
@@ -190,22 +190,21 @@ __device__ __forceinline__ bool sample(const TsdfGrid &g, const int *table, cons
         const int brick = s >= 0 ? table[s] : -1;
         if (brick < 0) return false;
         const int q0 = ((i0[2] & 15) << 8) | ((i0[1] & 15) << 4) | (i0[0] & 15);
-        const float *bw = weight + (int64_t)brick * UV + q0, *bt = tsdf + (int64_t)brick * UV + q0;
+        const float *bt = tsdf + (int64_t)(brick & BRICK_MASK) * UV + q0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int o = (k & 1) + ((k >> 1) & 1) * 16 + (k >> 2) * 256;
-            all = all && bw[o] > 0.f;
-            c[k] = bt[o];
+            c[k] = bt[(k & 1) + ((k >> 1) & 1) * 16 + (k >> 2) * 256];
+            all = all && c[k] <= 1.0f;
         }
     } else {
 #pragma unroll
         for (int k = 0; k < 8; ++k)
-            all = lattice(g, table, tsdf, weight, i0[0] + (k & 1), i0[1] + ((k >> 1) & 1), i0[2] + (k >> 2), c[k]) && all;
+            all = lattice(g, table, tsdf, i0[0] + (k & 1), i0[1] + ((k >> 1) & 1), i0[2] + (k >> 2), c[k]) && all;
     }
     if (!all) {
         // a cell with an unobserved corner (typically just behind an obliquely seen surface, where the truncation band
         // is thinner than a voxel diagonal): fall back to the nearest lattice point, if that one was observed
-        return lattice(g, table, tsdf, weight, i0[0] + (f[0] >= 0.5f ? 1 : 0), i0[1] + (f[1] >= 0.5f ? 1 : 0),
+        return lattice(g, table, tsdf, i0[0] + (f[0] >= 0.5f ? 1 : 0), i0[1] + (f[1] >= 0.5f ? 1 : 0),
                        i0[2] + (f[2] >= 0.5f ? 1 : 0), val);
     }
     // x, then y, then z
@@ -224,7 +223,7 @@ __device__ __forceinline__ bool sample(const TsdfGrid &g, const int *table, cons
 // space, 0.8 x the distance the TSDF value guarantees.
 __global__ void tsdf_raycast_kernel(int H, int W, float fx, float fy, float cx, float cy, const Pose c2w_, TsdfGrid g,
                                     float z_near, float z_far, const int *__restrict__ table, const float *__restrict__ tsdf,
-                                    const float *__restrict__ weight, const int *__restrict__ near_flag, float *__restrict__ out) {
+                                    float *__restrict__ out) {
     // The march is a chain of dependent loads (unit table -> brick -> values), i.e. latency-bound, and a 256 x 256 view is
     // only one wavefront per SIMD: every ray is cut into RS depth segments marched by RS adjacent lanes (each starts with
     // no history and runs two voxels into the next segment so that a crossing on a boundary is seen by the earlier one);
@@ -264,7 +263,7 @@ __global__ void tsdf_raycast_kernel(int H, int W, float fx, float fy, float cx, 
         // only bricks that hold part of the truncation band can contain the surface: everything else (unopened units,
         // bricks of observed free space, bricks with nothing observed) is crossed like empty space
         const int brick_here = s >= 0 ? table[s] : -1;
-        const bool open = brick_here >= 0 && near_flag[brick_here] != 0;
+        const bool open = brick_here >= 0 && (brick_here & NEAR_BIT) != 0;
         // such a unit is left in ONE step: distance (in t) to the nearest of its faces the ray is heading for
         float coarse = z_far;
 #pragma unroll
@@ -274,7 +273,7 @@ __global__ void tsdf_raycast_kernel(int H, int W, float fx, float fy, float cx, 
         }
         coarse = __fadd_rn(fmaxf(coarse, 0.f), eps);
         float val = 0.f;
-        const bool ok = open && sample(g, table, tsdf, weight, p, inv_voxel, val);
+        const bool ok = open && sample(g, table, tsdf, p, inv_voxel, val);
         if (ok && prev_ok && prev_val > 0.f && val <= 0.f) {
             // linear zero crossing between the two samples
             depth = __fadd_rn(prev_t, __fmul_rn(__fsub_rn(t, prev_t), __fdiv_rn(prev_val, __fsub_rn(prev_val, val))));
@@ -328,10 +327,11 @@ extern "C" int sgam_tsdf_integrate_f32(const sgam_tsdf_grid *grid, const float *
                                        float cx, float cy, const float *cam2world, const float *world2cam, float depth_trunc,
                                        int32_t frame_id,
                                        int32_t *unit_table, int32_t *unit_stamp, int32_t *counters, int32_t *brick_list,
-                                       int32_t max_list, float *brick_tsdf, float *brick_weight, int32_t *brick_near,
-                                       int32_t max_bricks, void *stream) {
+                                       int32_t max_list, float *brick_tsdf, float *brick_weight, int32_t max_bricks,
+                                       void *stream) {
     if (!grid_ok(grid) || !depth || !(fx > 0.f) || !(fy > 0.f) || !cam2world || !world2cam || !unit_table || !unit_stamp || !counters || !brick_list ||
-        !brick_tsdf || !brick_weight || !brick_near || H <= 0 || W <= 0 || max_list <= 0 || max_bricks <= 0 || frame_id <= 0)
+        !brick_tsdf || !brick_weight || H <= 0 || W <= 0 || max_list <= 0 || max_bricks <= 0 || max_bricks > BRICK_MASK ||
+        frame_id <= 0)
         return SGAM_EINVAL;
     const TsdfGrid g = to_dev(grid);
     hipStream_t s = sgam_stream(stream);
@@ -349,24 +349,22 @@ extern "C" int sgam_tsdf_integrate_f32(const sgam_tsdf_grid *grid, const float *
                        max_list);
     SGAM_LAUNCH_CHECK();
     hipLaunchKernelGGL(tsdf_integrate_kernel, dim3(2048), dim3(256), 0, s, depth, H, W, fx, fy, cx, cy, w2c, g,
-                       depth_trunc, unit_table, counters, brick_list, max_list, brick_tsdf, brick_weight, brick_near);
+                       depth_trunc, unit_table, counters, brick_list, max_list, brick_tsdf, brick_weight);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
 }
 
 extern "C" int sgam_tsdf_raycast_depth_f32(const sgam_tsdf_grid *grid, int32_t H, int32_t W, float fx, float fy, float cx,
                                            float cy, const float *cam2world, float z_near, float z_far, const int32_t *unit_table, const float *brick_tsdf,
-                                           const float *brick_weight, const int32_t *brick_near, float *depth_out,
-                                           void *stream) {
-    if (!grid_ok(grid) || !(fx > 0.f) || !(fy > 0.f) || !cam2world || !unit_table || !brick_tsdf || !brick_weight || !brick_near ||
-        !depth_out || H <= 0 || W <= 0 ||
+                                           float *depth_out, void *stream) {
+    if (!grid_ok(grid) || !(fx > 0.f) || !(fy > 0.f) || !cam2world || !unit_table || !brick_tsdf || !depth_out || H <= 0 || W <= 0 ||
         !(z_near > 0.f) || !(z_far > z_near))
         return SGAM_EINVAL;
     const TsdfGrid g = to_dev(grid);
     Pose c2w;
     for (int i = 0; i < 16; ++i) c2w.m[i] = cam2world[i];
     hipLaunchKernelGGL(tsdf_raycast_kernel, dim3(sgam_cdiv((int64_t)H * W * RS, 256)), dim3(256), 0, sgam_stream(stream), H, W, fx, fy,
-                       cx, cy, c2w, g, z_near, z_far, unit_table, brick_tsdf, brick_weight, brick_near, depth_out);
+                       cx, cy, c2w, g, z_near, z_far, unit_table, brick_tsdf, depth_out);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
 }

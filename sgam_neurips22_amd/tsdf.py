@@ -53,9 +53,8 @@ class TsdfVolume:
         self.unit_table = torch.full((n_units,), -1, dtype=torch.int32, device=device)
         self.unit_stamp = torch.zeros((n_units,), dtype=torch.int32, device=device)
         self.counters = torch.zeros((4,), dtype=torch.int32, device=device)
-        self.brick_tsdf = torch.zeros((self.max_bricks, UNIT ** 3), dtype=torch.float32, device=device)
+        self.brick_tsdf = torch.full((self.max_bricks, UNIT ** 3), 2.0, dtype=torch.float32, device=device)   # 2 = unobserved
         self.brick_weight = torch.zeros((self.max_bricks, UNIT ** 3), dtype=torch.float32, device=device)
-        self.brick_near = torch.zeros((self.max_bricks,), dtype=torch.int32, device=device)
         self.max_list = int(min(n_units, 1 << 22))
         self.brick_list = torch.empty((self.max_list,), dtype=torch.int32, device=device)
         self.frame_id = 0
@@ -78,7 +77,7 @@ class TsdfVolume:
         check(_lib.load().sgam_tsdf_integrate_f32(
             ctypes.byref(self.grid), ops._p(d), H, W, fx, fy, cx, cy, c2w.ctypes.data, w2c.ctypes.data, DEPTH_TRUNC, self.frame_id,
             ops._p(self.unit_table), ops._p(self.unit_stamp), ops._p(self.counters), ops._p(self.brick_list), self.max_list,
-            ops._p(self.brick_tsdf), ops._p(self.brick_weight), ops._p(self.brick_near), self.max_bricks, ops._stream()),
+            ops._p(self.brick_tsdf), ops._p(self.brick_weight), self.max_bricks, ops._stream()),
             "sgam_tsdf_integrate_f32")
 
     def render_depth(self, K, T_w2c, H, W, z_near, z_far):
@@ -89,7 +88,7 @@ class TsdfVolume:
         fx, fy, cx, cy = self._k4(K)
         check(_lib.load().sgam_tsdf_raycast_depth_f32(
             ctypes.byref(self.grid), H, W, fx, fy, cx, cy, c2w.ctypes.data, float(z_near), float(z_far), ops._p(self.unit_table),
-            ops._p(self.brick_tsdf), ops._p(self.brick_weight), ops._p(self.brick_near), ops._p(out), ops._stream()),
+            ops._p(self.brick_tsdf), ops._p(out), ops._stream()),
             "sgam_tsdf_raycast_depth_f32")
         return out
 

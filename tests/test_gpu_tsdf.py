@@ -43,6 +43,8 @@ def _scene(voxel, trunc, H, W, K, poses, depth_fn):
 
 def _bricks(vol):
     table = vol.unit_table.cpu().numpy().reshape(int(vol.dims[2]), int(vol.dims[1]), int(vol.dims[0]))
+    near = (table >= 0) & ((table & 0x40000000) != 0)
+    table = np.where(table >= 0, table & 0x3FFFFFFF, table)
     t, w = vol.brick_tsdf.cpu().numpy(), vol.brick_weight.cpu().numpy()
     out = {}
     for z, y, x in zip(*np.nonzero(table >= 0)):
