@@ -4,3 +4,4 @@ for ab in 0 1 24 21 25; do
   echo "== ablate $ab"
   python scripts/shape_time.py "$K3" 64,128,1 128,128,1 2>&1 | grep plan
 done
+python -m sgam_neurips22_amd.build 2>&1 | grep -E "error"

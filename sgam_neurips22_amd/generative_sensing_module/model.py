@@ -207,19 +207,22 @@ class VQModel(nn.Module):
                     batch[k] = batch[k].to(device=dev)
         if dataset not in ops.DATASET_NORM:
             raise NotImplementedError
-        x_dst = self.get_input("dst_img", batch)
-        x_depth = self.get_input("dst_depth", batch)
         if 'warped_tgt_features' in batch:
             x_rgb = batch['warped_tgt_features']
-            wd, em = ops.depth_normalise(batch['warped_tgt_depth'][:, None], dataset, compute_mask=True)
+            wd, extrapolation_mask = ops.depth_normalise(batch['warped_tgt_depth'][:, None], dataset, compute_mask=True,
+                                                         mask_bool=True)
             x = torch.cat([x_rgb, wd], 1)
-            extrapolation_mask = em.bool()
             warped_depth = wd
         else:
             x, extrapolation_mask, warped_depth = splat_to_model_input(
                 batch, dataset, depth_range=None if no_depth_range else self.depth_range)
-        x_scaled_inverse_depth, _ = ops.depth_normalise(x_depth, dataset, compute_mask=False)
-        x_dst = torch.cat([x_dst, x_scaled_inverse_depth], 1)
+        if "_x_dst" in batch:         # the scene loop's target is a constant (zeros): it assembles x_dst once
+            x_dst = batch["_x_dst"]
+        else:
+            x_dst = self.get_input("dst_img", batch)
+            x_depth = self.get_input("dst_depth", batch)
+            x_scaled_inverse_depth, _ = ops.depth_normalise(x_depth, dataset, compute_mask=False)
+            x_dst = torch.cat([x_dst, x_scaled_inverse_depth], 1)
         if return_extrapolation_mask:
             return x, x_dst, extrapolation_mask, warped_depth
         return x, x_dst

@@ -133,6 +133,17 @@ class InfiniteSceneGeneration:
         # host-side fp32 inverse like the reference (warp.py:210 / inference_pipeline.py:694), done once
         self._K_dev = K32.to(self.device)
         self._Kinv_dev = torch.inverse(K32).to(self.device)
+        self._Kinv_n = {}        # n sources -> (n,3,3) contiguous copy of the inverse intrinsics
+        # pinned staging ring for the per-step pose upload (see _upload)
+        self._stage = [torch.empty(256, dtype=torch.float32).pin_memory() for _ in range(8)] \
+            if self.device.type == "cuda" else None
+        self._stage_done = [None] * 8
+        self._stage_i = 0
+        H, W = self.image_resolution
+        # the target view is unknown at inference: the reference feeds zeros (:560-561); constant, so made once
+        self._dst_img = torch.zeros((1, H, W, 3), device=self.device)
+        self._dst_depth = torch.zeros((1, H, W), device=self.device)
+        self._x_dst = None       # get_x's x_dst of that constant target, kept after the first step
 
     # ---------------------------------------------------------------- TSDF fusion (reference :119-133, 745-838)
     # view-space z range of valid depths per dataset: the inverse-depth codec's bounds (model.py:210-229)
@@ -245,6 +256,30 @@ class InfiniteSceneGeneration:
             t_rels.append(T_rel[:3, 3])
         return np.stack(R_rels), np.stack(t_rels), np.stack(T_tgt2srcs)
 
+    def _upload(self, *arrays):
+        """Host fp32 arrays -> device tensors through ONE asynchronous copy out of a pinned staging slot.  A pageable
+        `.to(device)` makes the host wait for everything queued on the stream — i.e. for the previous frame — and the
+        GPU then idles while the host enqueues the next frame's conditioning launches."""
+        flat = np.concatenate([np.asarray(a, dtype=np.float32).ravel() for a in arrays])
+        if self._stage is None or flat.size > self._stage[0].numel():
+            devt = torch.from_numpy(flat).to(self.device)
+        else:
+            i = self._stage_i
+            self._stage_i = (i + 1) % len(self._stage)
+            if self._stage_done[i] is not None:
+                self._stage_done[i].synchronize()        # only ever waits when the host is a whole ring ahead
+            self._stage[i][:flat.size].copy_(torch.from_numpy(flat))
+            devt = torch.empty(flat.size, dtype=torch.float32, device=self.device)
+            devt.copy_(self._stage[i][:flat.size], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._stage_done[i] = ev
+        outs, o = [], 0
+        for a in arrays:
+            outs.append(devt[o:o + a.size].view(a.shape))
+            o += a.size
+        return outs
+
     def prepare_batch_data(self, tgt_node, src_nodes, num_src):
         dev = self.device
         coords = [s["grid_coord"] for s in src_nodes]
@@ -253,12 +288,17 @@ class InfiniteSceneGeneration:
         R_rels, t_rels, T_tgt2srcs = self.relative_poses(tgt_node, src_nodes)
         src_imgs = torch.stack([self.frames[c]["rgb_f"] for c in coords])[None]          # (1,N,H,W,3)
         src_depths = torch.stack([self._src_depth(c) for c in coords])[None]              # (1,N,H,W)
-        f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)  # noqa: E731
+        # T_src2tgt = [R | t; 0 0 0 1] (model.py:190-194): the same fp32 values the device-side assembly would hold
+        T = np.zeros((n, 4, 4), dtype=np.float32)
+        T[:, :3, :3], T[:, :3, 3], T[:, 3, 3] = R_rels, t_rels, 1.0
+        T_dev, T_t2s_dev, R_dev, t_dev = self._upload(T, T_tgt2srcs, R_rels, t_rels)
+        if n not in self._Kinv_n:
+            self._Kinv_n[n] = self._Kinv_dev.expand(n, 3, 3).contiguous()
         batch = {
             "Ks": self._K_dev.expand(1, n, 3, 3),
-            "_src_Kinv": self._Kinv_dev.expand(n, 3, 3).contiguous(),
-            "R_rels": f32(R_rels)[None], "t_rels": f32(t_rels)[None],
-            "dst_img": torch.zeros((1, H, W, 3), device=dev), "dst_depth": torch.zeros((1, H, W), device=dev),
+            "_src_Kinv": self._Kinv_n[n], "_T_src2tgt": T_dev,
+            "R_rels": R_dev[None], "t_rels": t_dev[None],
+            "dst_img": self._dst_img, "dst_depth": self._dst_depth,
             "src_imgs": src_imgs, "src_depths": src_depths,
         }
         if self.use_rgbd_integration:
@@ -267,7 +307,7 @@ class InfiniteSceneGeneration:
             else:
                 tgt_depth = self.rgbd_integration(src_nodes, tgt_node)
             warped = self.inverse_warping(src_imgs.permute(0, 1, 4, 2, 3).contiguous(), src_depths, tgt_depth[None],
-                                          batch["Ks"], self._K_dev[None], f32(T_tgt2srcs)[None], as_numpy=False,
+                                          batch["Ks"], self._K_dev[None], T_t2s_dev[None], as_numpy=False,
                                           tgt_Kinv=self._Kinv_dev[None])
             batch["warped_tgt_features"] = warped[None]
             batch["warped_tgt_depth"] = tgt_depth[None]
@@ -295,8 +335,11 @@ class InfiniteSceneGeneration:
         src_metas = [self.transform_grid[c[0]][c[1]] for c in src_coords]
         batch = self.prepare_batch_data(tgt_meta, src_metas, self.num_src)
         batch['src_depths'] = batch['src_depths'][..., None]
+        if self._x_dst is not None:
+            batch["_x_dst"] = self._x_dst
         x, x_dst, extrapolation_mask, warped_depth = self.dynamic_model.get_x(
             batch, self.data, return_extrapolation_mask=True, no_depth_range=True, parallel=True)
+        self._x_dst = x_dst
         x_sample_dets, _, pre_q, quant = self.dynamic_model(
             x, topk=self.topk, extrapolation_mask=extrapolation_mask, get_pre_quantized_feature=True,
             get_quantized_feature=True, sample_number=1)

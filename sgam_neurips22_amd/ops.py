@@ -531,11 +531,11 @@ def vq_topk(dist, k):
 # warps and frame feedback
 # ------------------------------------------------------------------------------------------------
 def forward_splat(src_feats, src_depths, tgt_K, src_Kinv, T, *, channels_last=False, depth_range=None,
-                  dataset=None, want=("merge_depths", "merge_feats", "extrap")):
+                  dataset=None, want=("merge_depths", "merge_feats", "extrap"), extrap_bool=False):
     """Forward splat + median fill + mask (+ normalised x).  src_feats (B,N,3,H,W) or, with
     channels_last, (B,N,H,W,3); src_depths (B,N,H,W); tgt_K (B,3,3); src_Kinv (B*N,3,3); T (B*N,4,4).
     Returns a dict with the tensors named in `want` (any of merge_depths, merge_feats, extrap, x,
-    proj_feats, proj_depth, inb_mask, pix_xy)."""
+    proj_feats, proj_depth, inb_mask, pix_xy).  extrap is uint8 0/1, or torch.bool (same bytes) with extrap_bool."""
     _need_cuda(src_feats, src_depths, tgt_K, src_Kinv, T)
     f = _f32c(src_feats)
     d = _f32c(src_depths)
@@ -547,7 +547,7 @@ def forward_splat(src_feats, src_depths, tgt_K, src_Kinv, T, *, channels_last=Fa
     mk = lambda shape, dt=torch.float32: torch.empty(shape, device=dev, dtype=dt)  # noqa: E731
     if "merge_depths" in want: o["merge_depths"] = mk((B, 1, H, W))
     if "merge_feats" in want: o["merge_feats"] = mk((B, 3, H, W))
-    if "extrap" in want: o["extrap"] = mk((B, 1, H, W), torch.uint8)
+    if "extrap" in want: o["extrap"] = mk((B, 1, H, W), torch.bool if extrap_bool else torch.uint8)
     if "x" in want: o["x"] = mk((B, 4, H, W))
     if "proj_feats" in want: o["proj_feats"] = mk((B, 3, H, W))
     if "proj_depth" in want: o["proj_depth"] = mk((B, 1, H, W))
@@ -572,12 +572,13 @@ def forward_splat(src_feats, src_depths, tgt_K, src_Kinv, T, *, channels_last=Fa
     return o
 
 
-def depth_normalise(depth, dataset, compute_mask=True):
-    """depth (any shape) -> (normalised inverse depth, extrap mask uint8 or None)  [model.py:196-229]"""
+def depth_normalise(depth, dataset, compute_mask=True, mask_bool=False):
+    """depth (any shape) -> (normalised inverse depth, extrap mask uint8 (torch.bool with mask_bool: the same 0/1
+    bytes) or None)  [model.py:196-229]"""
     _need_cuda(depth)
     d = _f32c(depth)
     out = torch.empty_like(d)
-    em = torch.empty(d.shape, device=d.device, dtype=torch.uint8) if compute_mask else None
+    em = torch.empty(d.shape, device=d.device, dtype=torch.bool if mask_bool else torch.uint8) if compute_mask else None
     if dataset not in DATASET_NORM:
         raise NotImplementedError(f"dataset {dataset!r}")
     check(_lib.load().sgam_depth_normalise_f32(_p(d), int(compute_mask), _p(em), _p(out), DATASET_NORM[dataset],

@@ -69,11 +69,14 @@ def splat_to_model_input(batch, dataset, depth_range=None):
     Ks = batch["Ks"]
     Kinv = batch["_src_Kinv"] if "_src_Kinv" in batch else _kinv_on(dev, Ks)
     # T_src2tgt = [R | t; 0 0 0 1]  (model.py:190-194) — data movement only
-    T = torch.zeros((B * N, 4, 4), device=dev, dtype=torch.float32)
-    T[:, :3, :3] = batch["R_rels"].reshape(B * N, 3, 3)
-    T[:, :3, 3] = batch["t_rels"].reshape(B * N, 3)
-    T[:, 3, 3] = 1.0
+    if "_T_src2tgt" in batch:          # the scene loop assembles it on the host and uploads it with the poses
+        T = batch["_T_src2tgt"].reshape(B * N, 4, 4)
+    else:
+        T = torch.zeros((B * N, 4, 4), device=dev, dtype=torch.float32)
+        T[:, :3, :3] = batch["R_rels"].reshape(B * N, 3, 3)
+        T[:, :3, 3] = batch["t_rels"].reshape(B * N, 3)
+        T[:, 3, 3] = 1.0
     o = ops.forward_splat(src, dep, Ks[:, 0].to(dev), Kinv.to(dev), T, channels_last=True, depth_range=depth_range,
-                          dataset=dataset, want=("x", "extrap"))
+                          dataset=dataset, want=("x", "extrap"), extrap_bool=True)
     x = o["x"]
-    return x, o["extrap"].bool(), x[:, 3:4]
+    return x, o["extrap"], x[:, 3:4]
