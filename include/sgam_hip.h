@@ -197,6 +197,21 @@ int sgam_groupnorm_stats_nhwc_f32(const float *x, const float *gamma, const floa
 int sgam_softmax_rows_f32(float *s, int32_t rows, int32_t cols, int32_t ld, float scale, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * K4-K6 fused — single-head self-attention of the AttnBlock in one pass over the keys (attention.hip):
+ *   out[i][:] = sum_j softmax_j(scale * q_i . k_j) v_j,   q, k, v : [n][C] fp32 with row stride ld (the column
+ *   slices of the fused q|k|v projection), out : [n][C] with row stride ldo.
+ * Replaces torch.bmm(q, k) / `w_ * c**-0.5` / softmax(dim=2) / torch.bmm(v, w_) of AttnBlock.forward
+ * (modules/diffusionmodules/model.py:176-187) without materialising the n x n scores.  Split-fp32 arithmetic as
+ * sgam_conv2d_nhwc_f32x (three fp16 MFMAs per product, fp32 accumulation), fp32 online soft-max.
+ * Supported: C == 256, n % 256 == 0, scale an exact power of two (C^-1/2 = 1/16); anything else -> SGAM_EINVAL and
+ * the caller keeps the GEMM / softmax / GEMM chain.  workspace: sgam_attention_f32x_workspace_bytes(n, C) bytes,
+ * 16-byte aligned (-1 = unsupported shape).
+ * ------------------------------------------------------------------------------------------ */
+int64_t sgam_attention_f32x_workspace_bytes(int32_t n, int32_t C);
+int sgam_attention_f32x(const float *q, const float *k, const float *v, int32_t ld, int32_t n, int32_t C, float scale,
+                        float *out, int32_t ldo, void *workspace, int64_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * K7/K8 — nearest-codeword quantiser.  Replaces VectorQuantizer2.forward
  * (modules/vqvae/quantize.py:285-307): d = (|z|^2 + |e|^2) - 2 z.e (that expression order, fp32),
  * arg-min with first-index-of-ties, embedding gather, straight-through value z + (e - z).

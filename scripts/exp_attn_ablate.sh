@@ -1,0 +1,5 @@
+for ab in 0 1 2 3 4 5; do
+  SGAM_ATTN_ABLATE=$ab python -m sgam_neurips22_amd.build 2>&1 | grep -E "error"
+  echo "== ablate $ab: $(python scripts/attn_time.py 4096 fused 2>&1 | grep fused)"
+done
+python -m sgam_neurips22_amd.build 2>&1 | grep -E "error"

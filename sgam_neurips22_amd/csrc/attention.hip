@@ -1,0 +1,348 @@
+// Fused single-head spatial self-attention of the VQGAN AttnBlock on the default fp32 path (gfx950 only).
+//
+//   o = softmax(q k^T * C^-1/2) v        q, k, v : [n tokens][C = 256] fp32 column slices of the fused q|k|v projection
+//
+// replaces `torch.bmm(q, k)`, `w_ * c**-0.5`, `softmax(dim=2)`, `torch.bmm(v, w_)` of the reference
+// (modules/diffusionmodules/model.py:176-187) in ONE pass over the keys: the n x n score matrix (64 MB at n = 4096,
+// written and read four times by the GEMM -> softmax -> GEMM chain) never exists.  Arithmetic as everywhere on this
+// path: every fp32 operand is split exactly into fp16 hi + lo, a product is three v_mfma_f32_32x32x16_f16 with fp32
+// accumulation; the soft-max runs in fp32 with a running maximum (the textbook online form: the result is the same
+// quotient sum_j e^{s_j - m} v_j / sum_j e^{s_j - m}, rounded in a different order).
+//
+// Orientation.  A wavefront owns 32 queries and computes the TRANSPOSED score tile S^T = K Q^T (keys are MFMA rows,
+// queries are MFMA columns): in the 32x32 accumulator layout a lane then holds 16 keys of ONE query, so the row
+// statistics of the soft-max are per-lane register reductions plus one exchange with lane ^ 32, and the probabilities
+// are already where the B operand of the second product O^T = V^T P^T wants them (lane = query column, 8 consecutive
+// k slots) — no cross-lane traffic between the two products.  The k-slot <-> key permutation this implies,
+//     key(t, h, s) = 4h + 8 (2t + s/4) + s%4        (k-step t of 16 keys, lane half h, slot s of 8),
+// is baked into the V^T fragments by attn_split_kv_kernel.
+//
+// Work split.  Workgroup = 4 wavefronts = 128 queries sharing every K / V block through LDS (double buffered, 32 keys per
+// block: 32 KB of K fragments + 32 KB of V^T fragments, already in MFMA-fragment order, so staging is a linear copy and
+// every ds_read_b128 of a fragment is one conflict-free kilobyte).  Per wavefront: the 32 x 256 query panel in
+// registers as B fragments (128 VGPRs), the 256 x 32 output accumulators (128), three score accumulators (one per
+// product term, so that consecutive MFMAs never chain on one accumulator) — a 512-register kernel, one wavefront per
+// SIMD.  n / 128 query blocks do not fill 256 CUs, so the keys are cut into `nsplit` ranges (flash-decoding style):
+// grid = nsplit x n/128, split s on XCD s (its K / V slice stays in that XCD's L2), each workgroup leaves its
+// un-normalised O, running maximum and sum; attn_combine_kernel merges the splits.
+#include "sgam_common.h"
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int AD = 256;            // head dimension (= channels of the AttnBlock)
+constexpr int KB = 32;             // keys per LDS block
+constexpr int BLK_BYTES = KB * AD * 4;   // one block of K (or V^T) fragments: hi + lo halves = 32 KB
+constexpr float P_SCALE = 1024.0f; // probabilities are lifted by 2^10 before the fp16 split (keeps the lo half normal)
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// exact hi / lo fp16 split of 8 fp32 values -> one MFMA operand register quad each
+__device__ __forceinline__ void split8(const float *v, u32x4 &hi, u32x4 &lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const _Float16 h0 = (_Float16)v[2 * e], h1 = (_Float16)v[2 * e + 1];
+        const _Float16 l0 = (_Float16)(v[2 * e] - (float)h0), l1 = (_Float16)(v[2 * e + 1] - (float)h1);
+        hi[e] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+        lo[e] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k, v slices -> MFMA-fragment order.  Both outputs are [key block of 32][8 tiles][256 pieces][8 halfs] with
+// piece = ((plane * 2 + k-step) * 2 + lane half) * 32 + row:
+//   K fragments (A operand of S^T = K Q^T): row = key in the block, tile = 32-wide slab of d, the 8 halfs of (k-step t,
+//     half h) are d = 32 tile + 16 t + 8 h + 0..7 — the layout sgam_split_rows_f32x produces;
+//   V^T fragments (A operand of O^T = V^T P^T): row = d in the tile, the 8 halfs of (t, h) are the keys key(t, h, 0..7).
+// One thread per (key block, tile, k-step, half, row): 8 values, hi and lo pieces, of both tensors.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_split_kv_kernel(const float *__restrict__ k, const float *__restrict__ v, int ld,
+                                                            int n, unsigned short *__restrict__ kf,
+                                                            unsigned short *__restrict__ vf) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;            // (key block, tile) * 128 + (t * 2 + h) * 32 + row
+    const int row = gid & 31, h = (gid >> 5) & 1, t = (gid >> 6) & 1, tile = (gid >> 7) & 7, kb = gid >> 10;
+    if (kb * KB >= n) return;
+    float kv[8], vv[8];
+    const float *kp = k + (int64_t)(kb * KB + row) * ld + tile * 32 + t * 16 + h * 8;
+    const f32x4 k0 = *reinterpret_cast<const f32x4 *>(kp), k1 = *reinterpret_cast<const f32x4 *>(kp + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        kv[e] = k0[e];
+        kv[4 + e] = k1[e];
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int key = 4 * h + 8 * (2 * t + (s >> 2)) + (s & 3);
+        vv[s] = v[(int64_t)(kb * KB + key) * ld + tile * 32 + row];
+    }
+    u32x4 hi, lo;
+    const int64_t piece = ((int64_t)(kb * 8 + tile) * 256 + (t * 2 + h) * 32 + row) * 8;      // halfs; lo plane: +128 pieces
+    split8(kv, hi, lo);
+    *reinterpret_cast<u32x4 *>(kf + piece) = hi;
+    *reinterpret_cast<u32x4 *>(kf + piece + 128 * 8) = lo;
+    split8(vv, hi, lo);
+    *reinterpret_cast<u32x4 *>(vf + piece) = hi;
+    *reinterpret_cast<u32x4 *>(vf + piece + 128 * 8) = lo;
+}
+
+struct AttnParams {
+    const float *q;                 // [n][ld] fp32, AD columns
+    const unsigned short *kf, *vf;  // fragment-ordered K and V^T
+    float *ws_o;                    // [NSPLIT][n / 32][AD][32]   un-normalised O^T per (split, 32-query tile)
+    float *ws_ml;                   // [NSPLIT][n][2]             running maximum (log2 domain), sum
+    int ld, n, blocks_per_split;
+    float qscale;                   // C^-1/2 (a power of two for C = 256: folding it into q is exact)
+};
+
+constexpr int NSPLIT = 8;          // key ranges = XCDs
+#ifndef SGAM_ATTN_SACC
+#define SGAM_ATTN_SACC 2           // score accumulators the 48 S MFMAs rotate over
+#endif
+#ifndef SGAM_ATTN_DMA_SPREAD
+#define SGAM_ATTN_DMA_SPREAD 1     // issue the next block's LDS-DMA pieces between the MFMA steps instead of in one burst
+#endif
+#ifndef SGAM_ATTN_ABLATE
+#define SGAM_ATTN_ABLATE 0         // timing experiments only (results are wrong when != 0): 1 no staging in the loop,
+#endif                             // 2 no soft-max arithmetic, 3 no S MFMAs, 4 no PV MFMAs, 5 no loop at all
+
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+__global__ __launch_bounds__(256) void attn_flash_f32x_kernel(const AttnParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * BLK_BYTES];   // K buffers 0, 1 | V^T buffers 0, 1
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sp = blockIdx.x % NSPLIT, qb = blockIdx.x / NSPLIT;
+    const int q0 = qb * 128 + wave * 32;
+    const int lq = lane & 31, lh = lane >> 5;
+    const int kb0 = sp * p.blocks_per_split, kb1 = kb0 + p.blocks_per_split;
+    const unsigned char *kg = reinterpret_cast<const unsigned char *>(p.kf), *vg = reinterpret_cast<const unsigned char *>(p.vf);
+
+    // a block is already in fragment order: staging = a linear 32 KB copy, done by the LDS-DMA path (global -> LDS without
+    // a register stop): each wavefront moves 8 KB as eight 1 KB pieces (lane l -> piece base + 16 l)
+    auto dma1 = [&](const unsigned char *g, int kb, int slot, const int i) {
+        const unsigned char *src = g + (int64_t)kb * BLK_BYTES + wave * 8192 + lane * 16;
+        unsigned char *dst = smem + slot * BLK_BYTES + wave * 8192;
+        __builtin_amdgcn_global_load_lds((gptr_t *)(src + i * 1024), (lptr_t *)(dst + i * 1024), 16, 0, 0);
+    };
+    auto dma = [&](const unsigned char *g, int kb, int slot) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dma1(g, kb, slot, i);
+    };
+    dma(kg, kb0, 0);
+    dma(vg, kb0, 2);
+
+    // ---- query panel -> B fragments (registers): k-step t covers d = 16 t + 8 h + 0..7 of query q0 + lq
+    u32x4 qh[16], ql[16];
+    {
+        const float *qp = p.q + (int64_t)(q0 + lq) * p.ld + lh * 8;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(qp + t * 16), b = *reinterpret_cast<const f32x4 *>(qp + t * 16 + 4);
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = a[e] * p.qscale;
+                v[4 + e] = b[e] * p.qscale;
+            }
+            split8(v, qh[t], ql[t]);
+        }
+    }
+
+    f32x16 o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;      // per lane: maximum of the whole query (both halves agree), sum of OWN keys
+    __syncthreads();
+
+    for (int kb = kb0; kb < (SGAM_ATTN_ABLATE == 5 ? kb0 : kb1); ++kb) {
+        const int buf = (kb - kb0) & 1;
+        const unsigned char *lk = smem + buf * BLK_BYTES + lane * 16, *lv = lk + 2 * BLK_BYTES;
+        const bool more = kb + 1 < kb1 && SGAM_ATTN_ABLATE != 1;
+#if SGAM_ATTN_DMA_SPREAD == 0
+        if (more) {
+            dma(kg, kb + 1, buf ^ 1);
+            dma(vg, kb + 1, 2 + (buf ^ 1));
+        }
+#endif
+        // ---- S^T = K Q^T: 16 k-steps over d; fragments are read two steps ahead (three rotating register sets), the
+        // 48 MFMAs alternate strictly between two accumulators so that none waits for its predecessor
+        u32x4 fh[3], fl[3];
+        auto kfrag = [&](const int set, const int t) {
+            fh[set] = *reinterpret_cast<const u32x4 *>(lk + (t >> 1) * 4096 + (t & 1) * 1024);
+            fl[set] = *reinterpret_cast<const u32x4 *>(lk + (t >> 1) * 4096 + (2 + (t & 1)) * 1024);
+        };
+        auto vfrag = [&](const int set, const int u) {
+            fh[set] = *reinterpret_cast<const u32x4 *>(lv + (u >> 1) * 4096 + (u & 1) * 1024);
+            fl[set] = *reinterpret_cast<const u32x4 *>(lv + (u >> 1) * 4096 + (2 + (u & 1)) * 1024);
+        };
+        f32x16 sacc[2];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sacc[0][e] = sacc[1][e] = 0.f;
+        kfrag(0, 0);
+        kfrag(1, 1);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            if (t + 2 < 16) kfrag((t + 2) % 3, t + 2);
+#if SGAM_ATTN_DMA_SPREAD
+            if (more && (t & 1)) dma1(kg, kb + 1, buf ^ 1, t >> 1);       // next K block: one piece every other step
+#endif
+            __builtin_amdgcn_sched_barrier(0);        // keep the reads two steps ahead of their MFMAs
+            if (SGAM_ATTN_ABLATE == 3) continue;
+            constexpr int NA = SGAM_ATTN_SACC;
+            sacc[(3 * t) % NA] = mfma16(fh[t % 3], qh[t], sacc[(3 * t) % NA]);
+            sacc[(3 * t + 1) % NA] = mfma16(fh[t % 3], ql[t], sacc[(3 * t + 1) % NA]);
+            sacc[(3 * t + 2) % NA] = mfma16(fl[t % 3], qh[t], sacc[(3 * t + 2) % NA]);
+        }
+        vfrag(0, 0);           // the first V^T fragments travel while the soft-max runs
+        vfrag(1, 1);
+        // ---- online soft-max of the 16 keys this lane holds (base-2 exponent domain)
+        float s[16], mloc = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            s[e] = (sacc[0][e] + sacc[1][e]) * LOG2E;
+            mloc = fmaxf(mloc, s[e]);
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        if (SGAM_ATTN_ABLATE != 2 && __any(m_new > m_run)) {                       // wavefront-uniform: the maximum settles after a few blocks
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+            // the output accumulators live in AccVGPRs (MFMA C/D); scale them in place, register by register, so that
+            // the allocator keeps them there instead of shuttling all 128 through VGPRs on every trip of the loop
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float x = o[i][e], tmp;
+                    asm volatile("v_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\tv_accvgpr_write_b32 %0, %1"
+                                 : "+a"(x), "=&v"(tmp)
+                                 : "v"(alpha));
+                    o[i][e] = x;
+                }
+            m_run = m_new;
+        }
+        float pv[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            if (SGAM_ATTN_ABLATE == 2) {
+                pv[e] = sacc[0][e];
+                continue;
+            }
+            pv[e] = __builtin_amdgcn_exp2f(s[e] - m_run);
+            l_run += pv[e];
+            pv[e] *= P_SCALE;
+        }
+        u32x4 ph[2], pl[2];
+        split8(pv, ph[0], pl[0]);
+        split8(pv + 8, ph[1], pl[1]);
+        // ---- O^T += V^T P^T: 8 tiles of d x 2 k-steps over the 32 keys
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            if (u + 2 < 16) vfrag((u + 2) % 3, u + 2);
+#if SGAM_ATTN_DMA_SPREAD
+            if (more && (u & 1)) dma1(vg, kb + 1, 2 + (buf ^ 1), u >> 1);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            if (SGAM_ATTN_ABLATE == 4) continue;
+            const int i = u >> 1, t = u & 1;
+            o[i] = mfma16(fh[u % 3], ph[t], o[i]);
+            o[i] = mfma16(fh[u % 3], pl[t], o[i]);
+            o[i] = mfma16(fl[u % 3], ph[t], o[i]);
+        }
+        __syncthreads();          // next block landed (the barrier drains the DMA queue); this one may be overwritten
+    }
+
+    // ---- partial result of this key range
+    l_run += __shfl_xor(l_run, 32, 64);
+    if (lh == 0) {
+        float *ml = p.ws_ml + ((int64_t)sp * p.n + q0 + lq) * 2;
+        ml[0] = m_run;
+        ml[1] = l_run;
+    }
+    float *wo = p.ws_o + ((int64_t)sp * (p.n / 32) + (q0 >> 5)) * (AD * 32) + lq;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) wo[(32 * i + 8 * (e >> 2) + 4 * lh + (e & 3)) * 32] = o[i][e];
+}
+
+// merge the key ranges: o[q][d] = sum_s w_s O_s[d][q] / (P_SCALE * sum_s w_s l_s),  w_s = 2^(m_s - max_s m_s).
+// Workgroup = (32-query tile, 32 columns of d); thread = (query, 4 d): 32 independent loads in flight per thread; the
+// 32 x 32 result goes through LDS so that rows leave as 128-byte pieces.
+__global__ __launch_bounds__(256) void attn_combine_kernel(const float *__restrict__ ws_o, const float *__restrict__ ws_ml,
+                                                           float *__restrict__ out, int ldo, int n) {
+    __shared__ float tile[32][33];
+    const int qt = blockIdx.x >> 3, dg = blockIdx.x & 7;
+    const int q = threadIdx.x & 31, dsub = threadIdx.x >> 5;
+    float w[NSPLIT], M = -INFINITY, L = 0.f;
+#pragma unroll
+    for (int s = 0; s < NSPLIT; ++s) {
+        const float *ml = ws_ml + ((int64_t)s * n + qt * 32 + q) * 2;
+        w[s] = ml[0];
+        M = fmaxf(M, w[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < NSPLIT; ++s) {
+        w[s] = __builtin_amdgcn_exp2f(w[s] - M);
+        L += w[s] * ws_ml[((int64_t)s * n + qt * 32 + q) * 2 + 1];
+    }
+    const float inv = 1.0f / (L * P_SCALE);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NSPLIT; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc[j] += w[s] * ws_o[(((int64_t)s * (n / 32) + qt) * AD + dg * 32 + dsub * 4 + j) * 32 + q];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tile[q][dsub * 4 + j] = acc[j] * inv;
+    __syncthreads();
+    const int r = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
+    const f32x4 v = {tile[r][c4], tile[r][c4 + 1], tile[r][c4 + 2], tile[r][c4 + 3]};
+    *reinterpret_cast<f32x4 *>(out + (int64_t)(qt * 32 + r) * ldo + dg * 32 + c4) = v;
+}
+
+}  // namespace
+
+extern "C" int64_t sgam_attention_f32x_workspace_bytes(int32_t n, int32_t C) {
+    if (C != AD || n < 256 || n % 256 != 0) return -1;
+    const int64_t nsplit = NSPLIT;
+    // K and V^T fragments (hi + lo fp16 = 4 bytes per element each), then the per-split partial O^T and {max, sum}
+    return 2 * (int64_t)n * AD * 4 + nsplit * (int64_t)n * AD * 4 + nsplit * (int64_t)n * 2 * 4;
+}
+
+extern "C" int sgam_attention_f32x(const float *q, const float *k, const float *v, int32_t ld, int32_t n, int32_t C,
+                                   float scale, float *out, int32_t ldo, void *workspace, int64_t workspace_bytes,
+                                   void *stream) {
+    if (!q || !k || !v || !out || !workspace) return SGAM_EINVAL;
+    const int64_t need = sgam_attention_f32x_workspace_bytes(n, C);
+    if (need < 0 || ld < C || ld % 4 != 0 || ldo < C) return SGAM_EINVAL;
+    int ex;
+    if (!(scale > 0.f) || frexpf(scale, &ex) != 0.5f) return SGAM_EINVAL;   // folded into q: must be an exact power of two
+    if (workspace_bytes < need) return SGAM_EWORKSPACE;
+    if (!sgam_aligned16(q) || !sgam_aligned16(k) || !sgam_aligned16(v) || !sgam_aligned16(workspace)) return SGAM_EALIGN;
+    const int nsplit = NSPLIT;
+    if ((n / KB) % nsplit != 0 || ldo % 4 != 0 || !sgam_aligned16(out)) return SGAM_EINVAL;
+    hipStream_t s = sgam_stream(stream);
+    unsigned short *kf = (unsigned short *)workspace;
+    unsigned short *vf = kf + (int64_t)n * AD * 2;
+    float *ws_o = (float *)(vf + (int64_t)n * AD * 2);
+    float *ws_ml = ws_o + (int64_t)nsplit * n * AD;
+    hipLaunchKernelGGL(attn_split_kv_kernel, dim3(n / KB * 8 * 128 / 256), dim3(256), 0, s, k, v, ld, n, kf, vf);
+    SGAM_LAUNCH_CHECK();
+    AttnParams p;
+    p.q = q; p.kf = kf; p.vf = vf; p.ws_o = ws_o; p.ws_ml = ws_ml;
+    p.ld = ld; p.n = n; p.blocks_per_split = n / KB / nsplit; p.qscale = scale;
+    hipLaunchKernelGGL(attn_flash_f32x_kernel, dim3(n / 128 * nsplit), dim3(256), 0, s, p);
+    SGAM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(attn_combine_kernel, dim3(n / 32 * 8), dim3(256), 0, s, ws_o, ws_ml, out, ldo, n);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}

@@ -199,10 +199,13 @@ class AttnBlock(_NHWCModule):
             xb = x[b].reshape(n, C)
             qkv = ops.gemm_nt(h[b].reshape(n, C), wqkv, bias=bqkv,
                               gn=None if table is None else (table[b:b + 1], False))   # (n, 3C)
-            vt = ops.nhwc_to_nchw(qkv[:, 2 * C:].unsqueeze(0).unsqueeze(0), c=C).view(C, n)   # (C, n) = v^T
-            s = ops.gemm_nt(qkv[:, :C], qkv[:, C:2 * C])                   # (n, n) scores
-            ops.softmax_rows_(s, scale)
-            o = ops.gemm_nt(s, vt, a_scale=1024.0)                         # (n, C); probabilities lifted before the split
+            if ops.F32_MODE == "split" and ops.attention_fusable(n, C):
+                o = ops.attention(qkv, C, scale)                           # one pass over the keys, no (n, n) scores
+            else:
+                vt = ops.nhwc_to_nchw(qkv[:, 2 * C:].unsqueeze(0).unsqueeze(0), c=C).view(C, n)   # (C, n) = v^T
+                s = ops.gemm_nt(qkv[:, :C], qkv[:, C:2 * C])               # (n, n) scores
+                ops.softmax_rows_(s, scale)
+                o = ops.gemm_nt(s, vt, a_scale=1024.0)                     # (n, C); probabilities lifted before the split
             ob = ops.gemm_nt(o, wp, bias=bp, residual=xb, out=out[b].reshape(n, C))
             if B == 1 and hasattr(ob, "_gn_partials"):
                 out._gn_partials = ob._gn_partials   # statistics of the block output for the next GroupNorm

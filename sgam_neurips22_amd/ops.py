@@ -425,6 +425,32 @@ def transpose_h16(x2d):
     return y
 
 
+FUSED_ATTENTION = os.environ.get("SGAM_FUSED_ATTN", "1") != "0"
+
+
+def attention_fusable(n, C):
+    """True when sgam_attention_f32x takes the shape (C = 256, n a multiple of 256)."""
+    return FUSED_ATTENTION and _lib.load().sgam_attention_f32x_workspace_bytes(int(n), int(C)) > 0 and n % 256 == 0
+
+
+def attention(qkv, C, scale, out=None):
+    """softmax(q k^T * scale) v for the fused projection qkv = [q | k | v] (n, 3C) fp32, in one pass over the keys
+    (csrc/attention.hip): the (n, n) score matrix is never written."""
+    _need_cuda(qkv)
+    n = qkv.shape[0]
+    assert qkv.dtype == torch.float32 and qkv.shape[1] == 3 * C and qkv.stride(1) == 1
+    lib = _lib.load()
+    ws_bytes = lib.sgam_attention_f32x_workspace_bytes(n, C)
+    if ws_bytes < 0:
+        raise SgamHipError(f"sgam_attention_f32x: unsupported shape n={n} C={C}")
+    ws = torch.empty((ws_bytes,), device=qkv.device, dtype=torch.uint8)
+    if out is None:
+        out = torch.empty((n, C), device=qkv.device, dtype=torch.float32)
+    check(lib.sgam_attention_f32x(_p(qkv), _p(qkv[:, C:]), _p(qkv[:, 2 * C:]), qkv.stride(0), n, C, float(scale), _p(out),
+                                  out.stride(0), _p(ws), ws_bytes, _stream()), "sgam_attention_f32x")
+    return out
+
+
 def softmax_rows_(s, scale):
     _need_cuda(s)
     rows, cols = s.shape

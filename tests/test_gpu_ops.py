@@ -353,3 +353,25 @@ def test_splitk_combine_delivers_groupnorm_statistics(C, H, W):
             ops.PLAN_CACHE[key] = old
     scale = plain.abs().max().item()
     assert (fused - plain).abs().max().item() <= 3e-6 * scale
+
+
+@pytest.mark.parametrize("n,spread", [(1024, 1.0), (4096, 1.0), (4096, 6.0), (256, 1.0)])
+def test_fused_attention_matches_fp64_and_the_gemm_chain(n, spread):
+    """sgam_attention_f32x (one pass over the keys, online soft-max) against softmax(q k^T / 16) v in fp64 and against
+    the GEMM -> softmax -> GEMM chain it replaces; `spread` widens the logits so that the running maximum moves and a few
+    keys dominate (the regime where the rescaling and the fp16 split of tiny probabilities matter)."""
+    C = 256
+    qkv = testing.seeded_tensor(f"attn.{n}", (n, 3 * C)).to(DEV)
+    qkv[:, :2 * C] *= spread
+    scale = C ** -0.5
+    o = ops.attention(qkv, C, scale)
+    q, k, v = (qkv[:, i * C:(i + 1) * C].double() for i in range(3))
+    ref = torch.softmax(q @ k.t() * scale, dim=1) @ v
+    _close(o, ref, 2e-5, "fused attention vs fp64")
+    s = ops.gemm_nt(qkv[:, :C], qkv[:, C:2 * C])
+    ops.softmax_rows_(s, scale)
+    vt = qkv[:, 2 * C:].t().contiguous()
+    chain = ops.gemm_nt(s, vt, a_scale=1024.0)
+    _close(o, chain, 2e-5, "fused attention vs GEMM chain")
+    assert torch.equal(o, ops.attention(qkv, C, scale))          # run-to-run deterministic
+    assert not ops.attention_fusable(n, 512) and not ops.attention_fusable(n + 32, C)
