@@ -22,8 +22,7 @@ SOURCES = {
                       f"-DSGAM_XPF_SMALL={os.environ.get('SGAM_XPF_SMALL', '2')}",
                       f"-DSGAM_XABLATE={os.environ.get('SGAM_XABLATE', '0')}",
                       f"-DSGAM_XSB={os.environ.get('SGAM_XSB', '1')}"],
-    "attention.hip": [f"-DSGAM_ATTN_ABLATE={os.environ.get('SGAM_ATTN_ABLATE', '0')}"] +
-                     [f"-D{k}={os.environ[k]}" for k in ("SGAM_ATTN_SACC", "SGAM_ATTN_DMA_SPREAD") if k in os.environ],
+    "attention.hip": [f"-DSGAM_ATTN_ABLATE={os.environ.get('SGAM_ATTN_ABLATE', '0')}"],
     "vq.hip": ["-ffp-contract=off"],
     "layout.hip": ["-ffp-contract=off"],
     "warp.hip": ["-ffp-contract=off"],

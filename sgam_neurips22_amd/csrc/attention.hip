@@ -18,13 +18,17 @@
 // is baked into the V^T fragments by attn_split_kv_kernel.
 //
 // Work split.  Workgroup = 4 wavefronts = 128 queries sharing every K / V block through LDS (double buffered, 32 keys per
-// block: 32 KB of K fragments + 32 KB of V^T fragments, already in MFMA-fragment order, so staging is a linear copy and
-// every ds_read_b128 of a fragment is one conflict-free kilobyte).  Per wavefront: the 32 x 256 query panel in
-// registers as B fragments (128 VGPRs), the 256 x 32 output accumulators (128), three score accumulators (one per
-// product term, so that consecutive MFMAs never chain on one accumulator) — a 512-register kernel, one wavefront per
-// SIMD.  n / 128 query blocks do not fill 256 CUs, so the keys are cut into `nsplit` ranges (flash-decoding style):
-// grid = nsplit x n/128, split s on XCD s (its K / V slice stays in that XCD's L2), each workgroup leaves its
-// un-normalised O, running maximum and sum; attn_combine_kernel merges the splits.
+// block: 32 KB of K fragments + 32 KB of V^T fragments, already in MFMA-fragment order, so staging is a linear copy —
+// done by LDS-DMA, global -> LDS without a register stop — and every ds_read_b128 of a fragment is one conflict-free
+// kilobyte).  Per wavefront: the 32 x 256 query panel in registers as B fragments (128 VGPRs), the 256 x 32 output
+// accumulators (128 AccVGPRs), two score accumulators the 48 S MFMAs alternate between — 372 registers, one wavefront
+// per SIMD.  n / 128 query blocks do not fill 256 CUs, so the keys are cut into NSPLIT = 8 ranges (flash-decoding
+// style): grid = 8 x n/128, range s on XCD s (its K / V slice stays in that XCD's L2), each workgroup leaves its
+// un-normalised O, running maximum and sum; attn_combine_kernel merges the ranges.
+//
+// Measured (n = 4096, one MI355X): split 6 us + this kernel 64 us + combine 7 us = 77 us against 141 us for the
+// GEMM / softmax / GEMM chain.  Of the 64 us, 24 are the 1536 MFMAs per wavefront at full rate; LDS-DMA issue (~16 us:
+// a piece costs the issuing wavefront ~100 cycles) and the prologue / epilogue (~13 us: 32 MB of partial O) are the rest.
 #include "sgam_common.h"
 
 namespace {
@@ -36,7 +40,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr int AD = 256;            // head dimension (= channels of the AttnBlock)
 constexpr int KB = 32;             // keys per LDS block
 constexpr int BLK_BYTES = KB * AD * 4;   // one block of K (or V^T) fragments: hi + lo halves = 32 KB
-constexpr float P_SCALE = 1024.0f; // probabilities are lifted by 2^10 before the fp16 split (keeps the lo half normal)
+constexpr float P_LIFT = 10.0f;    // probabilities are lifted by 2^10 before the fp16 split (keeps the lo half normal)
 constexpr float LOG2E = 1.4426950408889634f;
 
 __device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
@@ -101,15 +105,9 @@ struct AttnParams {
 };
 
 constexpr int NSPLIT = 8;          // key ranges = XCDs
-#ifndef SGAM_ATTN_SACC
-#define SGAM_ATTN_SACC 2           // score accumulators the 48 S MFMAs rotate over
-#endif
-#ifndef SGAM_ATTN_DMA_SPREAD
-#define SGAM_ATTN_DMA_SPREAD 1     // issue the next block's LDS-DMA pieces between the MFMA steps instead of in one burst
-#endif
 #ifndef SGAM_ATTN_ABLATE
-#define SGAM_ATTN_ABLATE 0         // timing experiments only (results are wrong when != 0): 1 no staging in the loop,
-#endif                             // 2 no soft-max arithmetic, 3 no S MFMAs, 4 no PV MFMAs, 5 no loop at all
+#define SGAM_ATTN_ABLATE 0         // timing experiments only (results are wrong when != 0), bit mask: 1 no staging in the
+#endif                             // loop, 2 no soft-max arithmetic, 4 no S MFMAs, 8 no PV MFMAs, 16 no loop at all
 
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
@@ -125,18 +123,23 @@ __global__ __launch_bounds__(256) void attn_flash_f32x_kernel(const AttnParams p
 
     // a block is already in fragment order: staging = a linear 32 KB copy, done by the LDS-DMA path (global -> LDS without
     // a register stop): each wavefront moves 8 KB as eight 1 KB pieces (lane l -> piece base + 16 l)
+    // piece i of a wavefront's 8 KB share: the instruction offset moves the global address and the LDS address alike, so
+    // one (address, M0) setup serves four pieces; the wavefront index is made scalar so that the LDS base stays in SGPRs
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
     auto dma1 = [&](const unsigned char *g, int kb, int slot, const int i) {
-        const unsigned char *src = g + (int64_t)kb * BLK_BYTES + wave * 8192 + lane * 16;
-        unsigned char *dst = smem + slot * BLK_BYTES + wave * 8192;
-        __builtin_amdgcn_global_load_lds((gptr_t *)(src + i * 1024), (lptr_t *)(dst + i * 1024), 16, 0, 0);
+        const unsigned char *src = g + (int64_t)kb * BLK_BYTES + wave_s * 8192 + (i >> 2) * 4096 + lane * 16;
+        unsigned char *dst = smem + slot * BLK_BYTES + wave_s * 8192 + (i >> 2) * 4096;
+        switch (i & 3) {
+        case 0: __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)dst, 16, 0, 0); break;
+        case 1: __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)dst, 16, 1024, 0); break;
+        case 2: __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)dst, 16, 2048, 0); break;
+        default: __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)dst, 16, 3072, 0); break;
+        }
     };
     auto dma = [&](const unsigned char *g, int kb, int slot) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) dma1(g, kb, slot, i);
     };
-    dma(kg, kb0, 0);
-    dma(vg, kb0, 2);
-
     // ---- query panel -> B fragments (registers): k-step t covers d = 16 t + 8 h + 0..7 of query q0 + lq
     u32x4 qh[16], ql[16];
     {
@@ -160,105 +163,157 @@ __global__ __launch_bounds__(256) void attn_flash_f32x_kernel(const AttnParams p
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;      // per lane: maximum of the whole query (both halves agree), sum of OWN keys
+
+    // Software pipeline over the key blocks (one wavefront per SIMD: nothing else hides the soft-max arithmetic, so it is
+    // threaded through the MFMA stream by hand).  Trip j of the loop runs
+    //     S(j+1) MFMAs   with   exp / sum / fp16 split of block j        (VALU in the shadow of the matrix pipe)
+    //     PV(j)  MFMAs   with   scores -> log2 domain + maximum of block j+1
+    // and ends with the (rare) rescale of O when the running maximum moved.  K therefore runs one block ahead of V^T:
+    // K(j+1) and V(j) are resident during trip j while K(j+2) and V(j+1) arrive (two LDS buffers each).
+    const int nb = kb1 - kb0;
+    auto blk = [&](int j) { return kb0 + (j < nb ? j : nb - 1); };       // past the end: a valid block, result unused
+    dma(kg, blk(0), 0);
+    dma(vg, blk(0), 2);
+    dma(kg, blk(1), 1);
+
+    // MFMA A fragments come out of LDS through explicit ds_read_b128 statements: three rotating register sets, issued
+    // two steps ahead and retired by counted waits.  (Left to the compiler the reads are cloned and hoisted until half of
+    // the query panel is pushed out to AccVGPRs and copied back before every MFMA.)
+    u32x4 fh[3], fl[3];
+    f32x16 sacc[2];
+    float s[16], pe[2];          // s: log2-domain scores of the block whose soft-max comes next
+    u32x4 ph[2], pl[2];
+    auto lds_off = [](const unsigned char *ptr) {
+        return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char *)ptr;
+    };
+#define ATTN_DS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+    // reads retired so far = all but the newest `n`; ties the fragment registers to the wait so that no MFMA moves above it
+#define ATTN_DS_WAIT(n, set) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(fh[set]), "+v"(fl[set]))
+    auto smfma = [&](const int t) {            // the three product terms of k-step t, alternating accumulators
+        sacc[(3 * t) & 1] = mfma16(fh[t % 3], qh[t], sacc[(3 * t) & 1]);
+        sacc[(3 * t + 1) & 1] = mfma16(fh[t % 3], ql[t], sacc[(3 * t + 1) & 1]);
+        sacc[(3 * t + 2) & 1] = mfma16(fl[t % 3], qh[t], sacc[(3 * t + 2) & 1]);
+    };
+    // fragment (hi, lo) of step `t` inside a 32 KB block -> register set: step t sits at (t / 2) * 4096 + (t % 2) * 1024,
+    // its lo plane 2048 bytes further (same formula for the K block's k-steps and the V^T block's (tile, k-step) pairs)
+#define ATTN_FRAG(set, base, t)                                              \
+    do {                                                                      \
+        ATTN_DS_READ(fh[set], base, ((t) >> 1) * 4096 + ((t) & 1) * 1024);        \
+        ATTN_DS_READ(fl[set], base, ((t) >> 1) * 4096 + (2 + ((t) & 1)) * 1024);  \
+    } while (0)
     __syncthreads();
 
-    for (int kb = kb0; kb < (SGAM_ATTN_ABLATE == 5 ? kb0 : kb1); ++kb) {
-        const int buf = (kb - kb0) & 1;
-        const unsigned char *lk = smem + buf * BLK_BYTES + lane * 16, *lv = lk + 2 * BLK_BYTES;
-        const bool more = kb + 1 < kb1 && SGAM_ATTN_ABLATE != 1;
-#if SGAM_ATTN_DMA_SPREAD == 0
-        if (more) {
-            dma(kg, kb + 1, buf ^ 1);
-            dma(vg, kb + 1, 2 + (buf ^ 1));
-        }
-#endif
-        // ---- S^T = K Q^T: 16 k-steps over d; fragments are read two steps ahead (three rotating register sets), the
-        // 48 MFMAs alternate strictly between two accumulators so that none waits for its predecessor
-        u32x4 fh[3], fl[3];
-        auto kfrag = [&](const int set, const int t) {
-            fh[set] = *reinterpret_cast<const u32x4 *>(lk + (t >> 1) * 4096 + (t & 1) * 1024);
-            fl[set] = *reinterpret_cast<const u32x4 *>(lk + (t >> 1) * 4096 + (2 + (t & 1)) * 1024);
-        };
-        auto vfrag = [&](const int set, const int u) {
-            fh[set] = *reinterpret_cast<const u32x4 *>(lv + (u >> 1) * 4096 + (u & 1) * 1024);
-            fl[set] = *reinterpret_cast<const u32x4 *>(lv + (u >> 1) * 4096 + (2 + (u & 1)) * 1024);
-        };
-        f32x16 sacc[2];
+    // ---- prologue: scores of the first block, their maximum
+    {
+        const unsigned lk = lds_off(smem + lane * 16);
 #pragma unroll
         for (int e = 0; e < 16; ++e) sacc[0][e] = sacc[1][e] = 0.f;
-        kfrag(0, 0);
-        kfrag(1, 1);
+        ATTN_FRAG(0, lk, 0);
+        ATTN_FRAG(1, lk, 1);
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            if (t + 2 < 16) kfrag((t + 2) % 3, t + 2);
-#if SGAM_ATTN_DMA_SPREAD
-            if (more && (t & 1)) dma1(kg, kb + 1, buf ^ 1, t >> 1);       // next K block: one piece every other step
-#endif
-            __builtin_amdgcn_sched_barrier(0);        // keep the reads two steps ahead of their MFMAs
-            if (SGAM_ATTN_ABLATE == 3) continue;
-            constexpr int NA = SGAM_ATTN_SACC;
-            sacc[(3 * t) % NA] = mfma16(fh[t % 3], qh[t], sacc[(3 * t) % NA]);
-            sacc[(3 * t + 1) % NA] = mfma16(fh[t % 3], ql[t], sacc[(3 * t + 1) % NA]);
-            sacc[(3 * t + 2) % NA] = mfma16(fl[t % 3], qh[t], sacc[(3 * t + 2) % NA]);
+            if (t + 2 < 16) ATTN_FRAG((t + 2) % 3, lk, t + 2);
+            if (t + 2 < 16) ATTN_DS_WAIT(4, t % 3);
+            else if (t + 1 < 16) ATTN_DS_WAIT(2, t % 3);
+            else ATTN_DS_WAIT(0, t % 3);
+            smfma(t);
         }
-        vfrag(0, 0);           // the first V^T fragments travel while the soft-max runs
-        vfrag(1, 1);
-        // ---- online soft-max of the 16 keys this lane holds (base-2 exponent domain)
-        float s[16], mloc = -INFINITY;
+        float mloc = -INFINITY;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             s[e] = (sacc[0][e] + sacc[1][e]) * LOG2E;
             mloc = fmaxf(mloc, s[e]);
         }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float m_new = fmaxf(m_run, mloc);
-        if (SGAM_ATTN_ABLATE != 2 && __any(m_new > m_run)) {                       // wavefront-uniform: the maximum settles after a few blocks
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            l_run *= alpha;
-            // the output accumulators live in AccVGPRs (MFMA C/D); scale them in place, register by register, so that
-            // the allocator keeps them there instead of shuttling all 128 through VGPRs on every trip of the loop
+        m_run = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    }
+
+    for (int j = 0; j < ((SGAM_ATTN_ABLATE & 16) ? 0 : nb); ++j) {
+        const int buf = j & 1;
+        const unsigned lk = lds_off(smem + (buf ^ 1) * BLK_BYTES + lane * 16);       // K(j+1)
+        const unsigned lv = lds_off(smem + (2 + buf) * BLK_BYTES + lane * 16);       // V^T(j)
+        const int kb_k = blk(j + 2), kb_v = blk(j + 1);
+        // ---- S(j+1) MFMAs + soft-max arithmetic of block j
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+        for (int e = 0; e < 16; ++e) sacc[0][e] = sacc[1][e] = 0.f;
+        ATTN_FRAG(0, lk, 0);
+        ATTN_FRAG(1, lk, 1);
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    float x = o[i][e], tmp;
-                    asm volatile("v_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\tv_accvgpr_write_b32 %0, %1"
-                                 : "+a"(x), "=&v"(tmp)
-                                 : "v"(alpha));
-                    o[i][e] = x;
-                }
-            m_run = m_new;
-        }
-        float pv[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            if (SGAM_ATTN_ABLATE == 2) {
-                pv[e] = sacc[0][e];
-                continue;
+        for (int t = 0; t < 16; ++t) {
+            // two reads leave at every step of the trip: K steps 2..15, then the first two V^T fragments
+            if (t + 2 < 16) ATTN_FRAG((t + 2) % 3, lk, t + 2);
+            else ATTN_FRAG((t + 2) % 3, lv, t + 2 - 16);
+            // K(j+2) into the buffer K(j) left, V^T(j+1) into V^T(j-1)'s: all sixteen pieces leave during the S steps so
+            // that they have the whole PV phase to land before the barrier drains the queue
+            if (!(SGAM_ATTN_ABLATE & 1)) {
+                if (t < 8) dma1(kg, kb_k, buf, t);
+                else dma1(vg, kb_v, 2 + (buf ^ 1), t - 8);
             }
-            pv[e] = __builtin_amdgcn_exp2f(s[e] - m_run);
-            l_run += pv[e];
-            pv[e] *= P_SCALE;
+            ATTN_DS_WAIT(4, t % 3);
+            if (!(SGAM_ATTN_ABLATE & 4)) smfma(t);
+            if (!(SGAM_ATTN_ABLATE & 2)) {
+                // p = 2^(s - m + 10): the lift by 2^10 rides in the exponent (l_run carries it too); the fp16 split
+                // truncates the hi half (v_cvt_pkrtz: two values per instruction) — hi + lo still holds 21 bits of p
+                pe[t & 1] = __builtin_amdgcn_exp2f(s[t] - m_run + P_LIFT);
+                l_run += pe[t & 1];
+                if (t & 1) {
+                    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+                    const f16x2 h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(pe[0], pe[1]));
+                    const f16x2 l = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(pe[0] - (float)h[0], pe[1] - (float)h[1]));
+                    ph[t >> 3][(t & 7) >> 1] = __builtin_bit_cast(unsigned, h);
+                    pl[t >> 3][(t & 7) >> 1] = __builtin_bit_cast(unsigned, l);
+                }
+            } else if (t & 1) {
+                ph[t >> 3][(t & 7) >> 1] = pl[t >> 3][(t & 7) >> 1] = __builtin_bit_cast(unsigned, s[t]);
+            }
         }
-        u32x4 ph[2], pl[2];
-        split8(pv, ph[0], pl[0]);
-        split8(pv + 8, ph[1], pl[1]);
-        // ---- O^T += V^T P^T: 8 tiles of d x 2 k-steps over the 32 keys
+        // ---- PV(j) MFMAs + log2-domain scores and maximum of block j+1.  V^T step u uses set (16 + u) % 3.
+        float mloc = -INFINITY;
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-            if (u + 2 < 16) vfrag((u + 2) % 3, u + 2);
-#if SGAM_ATTN_DMA_SPREAD
-            if (more && (u & 1)) dma1(vg, kb + 1, 2 + (buf ^ 1), u >> 1);
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-            if (SGAM_ATTN_ABLATE == 4) continue;
-            const int i = u >> 1, t = u & 1;
-            o[i] = mfma16(fh[u % 3], ph[t], o[i]);
-            o[i] = mfma16(fh[u % 3], pl[t], o[i]);
-            o[i] = mfma16(fl[u % 3], ph[t], o[i]);
+            if (u + 2 < 16) ATTN_FRAG((16 + u + 2) % 3, lv, u + 2);
+            if (u + 2 < 16) ATTN_DS_WAIT(4, (16 + u) % 3);
+            else if (u + 1 < 16) ATTN_DS_WAIT(2, (16 + u) % 3);
+            else ATTN_DS_WAIT(0, (16 + u) % 3);
+            const int i = u >> 1, t = u & 1, set = (16 + u) % 3;
+            if (!(SGAM_ATTN_ABLATE & 8)) {
+                o[i] = mfma16(fh[set], ph[t], o[i]);
+                o[i] = mfma16(fh[set], pl[t], o[i]);
+                o[i] = mfma16(fl[set], ph[t], o[i]);
+            }
+            if (u >= 4) {                              // (the last S MFMAs have left the pipe by now)
+#pragma unroll
+                for (int e = (u - 4) * 4 / 3; e < (u - 3) * 4 / 3; ++e) {
+                    s[e] = (sacc[0][e] + sacc[1][e]) * LOG2E;          // (slot e was consumed in S step e of this trip)
+                    mloc = fmaxf(mloc, s[e]);
+                }
+            }
         }
-        __syncthreads();          // next block landed (the barrier drains the DMA queue); this one may be overwritten
+        if (j + 1 < nb && !(SGAM_ATTN_ABLATE & 2)) {
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            const float m_new = fmaxf(m_run, mloc);
+            if (__any(m_new > m_run)) {                   // wavefront-uniform: the maximum settles after a few blocks
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                l_run *= alpha;
+                // the output accumulators live in AccVGPRs (MFMA C/D); scale them in place, register by register, so
+                // that the allocator keeps them there instead of shuttling all 128 through VGPRs on every trip
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float x = o[i][e], tmp;
+                        asm volatile("v_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\tv_accvgpr_write_b32 %0, %1"
+                                     : "+a"(x), "=&v"(tmp)
+                                     : "v"(alpha));
+                        o[i][e] = x;
+                    }
+                m_run = m_new;
+            }
+        }
+        __syncthreads();          // the arriving blocks have landed (the barrier drains the DMA queue); old ones are free
     }
+#undef ATTN_FRAG
+#undef ATTN_DS_WAIT
+#undef ATTN_DS_READ
 
     // ---- partial result of this key range
     l_run += __shfl_xor(l_run, 32, 64);
@@ -274,7 +329,7 @@ __global__ __launch_bounds__(256) void attn_flash_f32x_kernel(const AttnParams p
         for (int e = 0; e < 16; ++e) wo[(32 * i + 8 * (e >> 2) + 4 * lh + (e & 3)) * 32] = o[i][e];
 }
 
-// merge the key ranges: o[q][d] = sum_s w_s O_s[d][q] / (P_SCALE * sum_s w_s l_s),  w_s = 2^(m_s - max_s m_s).
+// merge the key ranges: o[q][d] = sum_s w_s O_s[d][q] / sum_s w_s l_s,  w_s = 2^(m_s - max_s m_s).
 // Workgroup = (32-query tile, 32 columns of d); thread = (query, 4 d): 32 independent loads in flight per thread; the
 // 32 x 32 result goes through LDS so that rows leave as 128-byte pieces.
 __global__ __launch_bounds__(256) void attn_combine_kernel(const float *__restrict__ ws_o, const float *__restrict__ ws_ml,
@@ -294,7 +349,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float *__restri
         w[s] = __builtin_amdgcn_exp2f(w[s] - M);
         L += w[s] * ws_ml[((int64_t)s * n + qt * 32 + q) * 2 + 1];
     }
-    const float inv = 1.0f / (L * P_SCALE);
+    const float inv = 1.0f / L;            // O and l both carry the 2^10 lift of the probabilities
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < NSPLIT; ++s)
