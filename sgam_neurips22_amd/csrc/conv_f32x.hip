@@ -753,14 +753,34 @@ __global__ __launch_bounds__(256) void splitk_reduce_f32x_kernel(const XParams p
     const int n = live ? (int)(q - (int64_t)m * nq) * 4 : 0;
     float gs = 0.f, gss = 0.f;
     if (live) {
-        f32x4 s = *reinterpret_cast<const f32x4 *>(p.ws + (int64_t)m * p.N + n);
-        for (int z = 1; z < p.ksplit; ++z) s += *reinterpret_cast<const f32x4 *>(p.ws + ((int64_t)z * p.M + m) * p.N + n);
+        // the partial slabs are summed in the order z = 0, 1, 2, ... with four loads in flight at a time (a plain loop
+        // compiles to load -> wait -> add: one L2 round trip per slab); bias / residual are fetched before they are used
+        const float *w0 = p.ws + (int64_t)m * p.N + n;
+        const int64_t zs = (int64_t)p.M * p.N;
+        float bv[4], rv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool ok = n + e < p.n_valid;
+            bv[e] = (ok && p.bias) ? (p.bias_per_row ? p.bias[m] : p.bias[n + e]) : 0.f;
+            rv[e] = (ok && p.res) ? p.res[(int64_t)m * p.ldr + n + e] : 0.f;
+        }
+        f32x4 s = *reinterpret_cast<const f32x4 *>(w0);
+        int z = 1;
+        for (; z + 4 <= p.ksplit; z += 4) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(w0 + z * zs), b = *reinterpret_cast<const f32x4 *>(w0 + (z + 1) * zs);
+            const f32x4 c = *reinterpret_cast<const f32x4 *>(w0 + (z + 2) * zs), d = *reinterpret_cast<const f32x4 *>(w0 + (z + 3) * zs);
+            s += a;
+            s += b;
+            s += c;
+            s += d;
+        }
+        for (; z < p.ksplit; ++z) s += *reinterpret_cast<const f32x4 *>(w0 + z * zs);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             if (n + e >= p.n_valid) continue;
             float v = s[e] * p.inv_w_scale;
-            if (p.bias) v += p.bias_per_row ? p.bias[m] : p.bias[n + e];
-            if (p.res) v += p.res[(int64_t)m * p.ldr + n + e];
+            if (p.bias) v += bv[e];
+            if (p.res) v += rv[e];
             p.out[(int64_t)m * p.ldc + n + e] = v;
             gs += v;
             gss += v * v;

@@ -260,6 +260,28 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const typename E<T>::S *_
     }
 }
 
+// lane-strided sum of the chunk partials {sum, sumsq}: four loads are in flight before the first add (a plain loop is
+// compiled to load -> wait -> add, one memory round trip per chunk), the adds keep the order k, k + 256, k + 512, ...
+__device__ __forceinline__ void gn_fold_chunks(const double *base, int groups, int nchunk, double &s, double &ss) {
+    const int64_t st = (int64_t)groups * 2;
+    int k = threadIdx.x;
+    for (; k + 768 < nchunk; k += 1024) {
+        const double2 a = *reinterpret_cast<const double2 *>(base + k * st);
+        const double2 b = *reinterpret_cast<const double2 *>(base + (k + 256) * st);
+        const double2 c = *reinterpret_cast<const double2 *>(base + (k + 512) * st);
+        const double2 d = *reinterpret_cast<const double2 *>(base + (k + 768) * st);
+        s += a.x; ss += a.y;
+        s += b.x; ss += b.y;
+        s += c.x; ss += c.y;
+        s += d.x; ss += d.y;
+    }
+    for (; k < nchunk; k += 256) {
+        const double2 v = *reinterpret_cast<const double2 *>(base + k * st);
+        s += v.x;
+        ss += v.y;
+    }
+}
+
 // finalize: one workgroup per (group, image) folds the chunk partials (lane-strided, then a fixed shuffle / LDS tree:
 // deterministic) and writes the per-channel scale / shift of its channels
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const double *__restrict__ partial, const float *__restrict__ gamma,
@@ -269,11 +291,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double *__restri
     const int g = blockIdx.x, b = blockIdx.y;
     const double *base = partial + ((int64_t)b * nchunk * groups + g) * 2;
     double s = 0.0, ss = 0.0;
-    for (int k = threadIdx.x; k < nchunk; k += 256) {
-        const double2 v = *reinterpret_cast<const double2 *>(base + (int64_t)k * groups * 2);
-        s += v.x;
-        ss += v.y;
-    }
+    gn_fold_chunks(base, groups, nchunk, s, ss);
     s = sgam_wave_sum_f64(s);
     ss = sgam_wave_sum_f64(ss);
     if ((threadIdx.x & 63) == 0) {
@@ -304,11 +322,7 @@ __global__ __launch_bounds__(256) void gn_finalize_stats_kernel(const double *__
     const int g = blockIdx.x, b = blockIdx.y;
     const double *base = partial + ((int64_t)b * nchunk * groups + g) * 2;
     double s = 0.0, ss = 0.0;
-    for (int k = threadIdx.x; k < nchunk; k += 256) {
-        const double2 v = *reinterpret_cast<const double2 *>(base + (int64_t)k * groups * 2);
-        s += v.x;
-        ss += v.y;
-    }
+    gn_fold_chunks(base, groups, nchunk, s, ss);
     s = sgam_wave_sum_f64(s);
     ss = sgam_wave_sum_f64(ss);
     if ((threadIdx.x & 63) == 0) {

@@ -26,10 +26,28 @@ __device__ __forceinline__ float sgam_wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// fp64 sum over the 64 lanes on the DPP data path (row shifts, then the two row broadcasts of wave64): six dependent
+// steps of a few cycles each, where the butterfly of ds_bpermute exchanges costs 24 LDS round trips.  Fixed order:
+// inclusive scan inside each row of 16, rows 0+1 / 2+3 joined by row_bcast:15, the halves by row_bcast:31; the total
+// (lane 63) is returned to every lane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double sgam_dpp_add_f64(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, true);
+    const double o = __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+    return v + o;            // lanes outside the row mask / without a source read 0.0
+}
 __device__ __forceinline__ double sgam_wave_sum_f64(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v = sgam_dpp_add_f64<0x111, 0xf>(v);      // row_shr:1
+    v = sgam_dpp_add_f64<0x112, 0xf>(v);      // row_shr:2
+    v = sgam_dpp_add_f64<0x114, 0xf>(v);      // row_shr:4
+    v = sgam_dpp_add_f64<0x118, 0xf>(v);      // row_shr:8   -> lane 15 of every row holds the row total
+    v = sgam_dpp_add_f64<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+    v = sgam_dpp_add_f64<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3
+    const long long t = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)t, 63), hi = __builtin_amdgcn_readlane((int)(t >> 32), 63);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
 }
 __device__ __forceinline__ float sgam_wave_max(float v) {
 #pragma unroll
