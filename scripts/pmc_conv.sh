@@ -7,7 +7,7 @@ cd /tmp
 SHAPE=${SHAPE:-1,128,128,256,256,3}
 run() { # name, counters...
   name=$1; shift
-  timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- python $GRAFT_REPO_ROOT/scripts/conv_micro.py --shape $SHAPE --reps 10 > $OUT/$name.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- ${CMD:-python $GRAFT_REPO_ROOT/scripts/conv_micro.py --shape $SHAPE --reps 10} > $OUT/$name.log 2>&1
   echo "$name rc=$?"
 }
 run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY
