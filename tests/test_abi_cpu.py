@@ -56,6 +56,11 @@ def test_argument_validation_without_gpu():
     assert lib.sgam_vq_workspace_bytes(16, 256, 4096) >= 0
     assert lib.sgam_vq_workspace_bytes(16, 250, 4096) == -1
     assert lib.sgam_softmax_rows_f32(None, 4, 4, 4, 1.0, None) == -1    # NULL pointer -> SGAM_EINVAL, no launch
+    # fused attention: C = 256 and n a multiple of 256 only; workspace = K / V^T fragments + 8 key ranges of partial O
+    assert lib.sgam_attention_f32x_workspace_bytes(4096, 256) == 2 * 4096 * 256 * 4 + 8 * 4096 * 256 * 4 + 8 * 4096 * 8
+    assert lib.sgam_attention_f32x_workspace_bytes(4096, 512) == -1
+    assert lib.sgam_attention_f32x_workspace_bytes(4000, 256) == -1
+    assert lib.sgam_attention_f32x(None, None, None, 768, 4096, 256, 0.0625, None, 256, None, 0, None) == -1
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
