@@ -320,6 +320,30 @@ def main():
                              "2e-3 on the golden 256x256 input (tests/test_gpu_h16.py)"}
         model.set_compute_dtype("f32")
 
+    stress = None
+    if rank == 0 and world == 1 and args.dtype == "f32" and not args.no_secondary:
+        # BASELINE config 5 (a parity-test case, timed here as a side note): 512x512 input, batch of 4 warp candidates
+        # through the VQGAN forward (32x32 latent, attention over 16 384 tokens) in both arithmetic modes
+        xs, ms = zip(*[testing.rect_hole_input(1, 512, 512, seed=40 + i) for i in range(4)])
+        x5, m5 = torch.cat(xs).to(dev), torch.cat(ms).to(dev)
+        stress = {"workload": "VQGAN forward, 512x512, batch of 4 candidates (attention over 16384 tokens)",
+                  "note": "f32 = split-fp32 with the fused attention kernel; fp16 = throughput mode, whose attention still "
+                          "materialises the 1 GB score matrix per image"}
+        for dtn in ("f32", "fp16"):
+            model.set_compute_dtype(dtn)
+            with torch.no_grad():
+                for _ in range(2):
+                    model(x5, extrapolation_mask=m5)
+                torch.cuda.synchronize()
+                t5 = time.perf_counter()
+                for _ in range(4):
+                    model(x5, extrapolation_mask=m5)
+                torch.cuda.synchronize()
+                d5 = (time.perf_counter() - t5) / 4
+            stress[dtn] = {"ms_per_batch": round(1e3 * d5, 2), "candidates_per_s": round(4 / d5, 1)}
+        model.set_compute_dtype("f32")
+        del x5, m5
+
     cpu = None
     if rank == 0 and world == 1 and args.cpu_frames > 0:
         cpu = cpu_baseline({k: v.cpu() for k, v in sd.items()}, p, seed_frame, args.cpu_frames)
@@ -338,7 +362,7 @@ def main():
                        "f32_products": ("exact hi/lo fp16 split on the fp16 matrix cores, fp32 accumulate (fp32-class accuracy)"
                                         if ops.F32_MODE == "split" else "fp32-in MFMA") if args.dtype == "f32" else None},
             "vqgan_tflops_wallclock": round(GFLOP_PER_FRAME * g["total_frames"] / t_max / 1e3 / world, 2),
-            "roofline": roofline, "cpu_baseline": cpu, "rgbd_integration_branch": rgbd_leg, "concurrent_scenes": conc_leg, "throughput_mode": secondary, "frame_checksums": [r[2] for r in g["per_rank"]],
+            "roofline": roofline, "cpu_baseline": cpu, "rgbd_integration_branch": rgbd_leg, "concurrent_scenes": conc_leg, "throughput_mode": secondary, "config5_512sq_batch4": stress, "frame_checksums": [r[2] for r in g["per_rank"]],
         }
         print(json.dumps(out), flush=True)
     if torch.distributed.is_available() and torch.distributed.is_initialized():
