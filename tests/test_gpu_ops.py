@@ -373,5 +373,6 @@ def test_fused_attention_matches_fp64_and_the_gemm_chain(n, spread):
     vt = qkv[:, 2 * C:].t().contiguous()
     chain = ops.gemm_nt(s, vt, a_scale=1024.0)
     _close(o, chain, 2e-5, "fused attention vs GEMM chain")
-    assert torch.equal(o, ops.attention(qkv, C, scale))          # run-to-run deterministic
+    for _ in range(10):                                          # run-to-run deterministic (LDS-DMA staging, counted waits)
+        assert torch.equal(o, ops.attention(qkv, C, scale))
     assert not ops.attention_fusable(n, 512) and not ops.attention_fusable(n + 32, C)
