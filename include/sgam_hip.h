@@ -211,6 +211,12 @@ int64_t sgam_attention_f32x_workspace_bytes(int32_t n, int32_t C);
 int sgam_attention_f32x(const float *q, const float *k, const float *v, int32_t ld, int32_t n, int32_t C, float scale,
                         float *out, int32_t ldo, void *workspace, int64_t workspace_bytes, void *stream);
 
+/* 16-bit throughput variant of the fused attention (`ht` = 0 bf16 / 1 fp16; q, k, v, out 16-bit with strides in elements;
+ * one MFMA per product, fp32 scores / statistics / accumulation; same shape limits; scale need not be a power of two) */
+int64_t sgam_attention_h16_workspace_bytes(int32_t n, int32_t C);
+int sgam_attention_h16(const void *q, const void *k, const void *v, int32_t ht, int32_t ld, int32_t n, int32_t C, float scale,
+                       void *out, int32_t ldo, void *workspace, int64_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * K7/K8 — nearest-codeword quantiser.  Replaces VectorQuantizer2.forward
  * (modules/vqvae/quantize.py:285-307): d = (|z|^2 + |e|^2) - 2 z.e (that expression order, fp32),

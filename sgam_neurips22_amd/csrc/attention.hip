@@ -364,6 +364,206 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float *__restri
     *reinterpret_cast<f32x4 *>(out + (int64_t)(qt * 32 + r) * ldo + dg * 32 + c4) = v;
 }
 
+// =====================================================================================================================
+// 16-bit throughput variant (bf16 `HT` = 0 / fp16 `HT` = 1 activations, the h16.hip mode): the same pass over the keys with
+// ONE MFMA per product and single-plane fragments — half the LDS block (16 KB of K + 16 KB of V^T per 32 keys), a 64-VGPR
+// query panel, probabilities rounded once to 16 bits (RNE) after the exponential.  Scores, soft-max statistics and the
+// output accumulation stay in fp32, as in the GEMM / softmax / GEMM chain of that mode.
+// =====================================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <int HT> struct HM;
+template <> struct HM<0> {
+    __device__ static __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ unsigned pack2(float a, float b) {
+        return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)a) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)b) << 16);
+    }
+    __device__ static __forceinline__ unsigned short from_f(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+};
+template <> struct HM<1> {
+    __device__ static __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ unsigned pack2(float a, float b) {
+        return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)a) | ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)b) << 16);
+    }
+    __device__ static __forceinline__ unsigned short from_f(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
+};
+
+constexpr int HBLK_BYTES = KB * AD * 2;     // one 32-key block of 16-bit K (or V^T) fragments = 16 KB
+
+// k, v (16-bit, row stride ld elements) -> [key block][8 tiles][(k-step * 2 + half) * 32 + row][8 halfs]; the K piece is a
+// straight 16-byte copy, the V^T piece gathers the keys key(t, h, 0..7) of one d
+__global__ __launch_bounds__(256) void attn_split_kv_h16_kernel(const unsigned short *__restrict__ k, const unsigned short *__restrict__ v,
+                                                                int ld, int n, unsigned short *__restrict__ kf,
+                                                                unsigned short *__restrict__ vf) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int row = gid & 31, h = (gid >> 5) & 1, t = (gid >> 6) & 1, tile = (gid >> 7) & 7, kb = gid >> 10;
+    if (kb * KB >= n) return;
+    const int64_t piece = ((int64_t)(kb * 8 + tile) * 128 + (t * 2 + h) * 32 + row) * 8;
+    *reinterpret_cast<u32x4 *>(kf + piece) =
+        *reinterpret_cast<const u32x4 *>(k + (int64_t)(kb * KB + row) * ld + tile * 32 + t * 16 + h * 8);
+    unsigned short vv[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) vv[s] = v[(int64_t)(kb * KB + 4 * h + 8 * (2 * t + (s >> 2)) + (s & 3)) * ld + tile * 32 + row];
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (unsigned)vv[2 * e] | ((unsigned)vv[2 * e + 1] << 16);
+    *reinterpret_cast<u32x4 *>(vf + piece) = o;
+}
+
+struct AttnHParams {
+    const unsigned short *q, *kf, *vf;
+    float *ws_o, *ws_ml;
+    int ld, n, blocks_per_split;
+    float qscale_log2e;             // C^-1/2 * log2(e): applied to the fp32 scores
+};
+
+template <int HT>
+__global__ __launch_bounds__(256, 2) void attn_flash_h16_kernel(const AttnHParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * HBLK_BYTES];   // K buffers 0, 1 | V^T buffers 0, 1
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sp = blockIdx.x % NSPLIT, qb = blockIdx.x / NSPLIT;
+    const int q0 = qb * 128 + wave * 32;
+    const int lq = lane & 31, lh = lane >> 5;
+    const int kb0 = sp * p.blocks_per_split, nb = p.blocks_per_split;
+    const unsigned char *kg = reinterpret_cast<const unsigned char *>(p.kf), *vg = reinterpret_cast<const unsigned char *>(p.vf);
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    // a wavefront moves 4 KB of every 16 KB block: four 1 KB LDS-DMA pieces behind one (address, M0) setup
+    auto dma = [&](const unsigned char *g, int kb, int slot) {
+        const unsigned char *src = g + (int64_t)kb * HBLK_BYTES + wave_s * 4096 + lane * 16;
+        unsigned char *dst = smem + slot * HBLK_BYTES + wave_s * 4096;
+        __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)dst, 16, 1024, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)dst, 16, 2048, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)dst, 16, 3072, 0);
+    };
+    auto blk = [&](int j) { return kb0 + (j < nb ? j : nb - 1); };
+    dma(kg, blk(0), 0);
+    dma(vg, blk(0), 2);
+
+    u32x4 qf[16];                      // query panel: k-step t = d 16 t + 8 h + 0..7 of query q0 + lq
+    {
+        const unsigned short *qp = p.q + (int64_t)(q0 + lq) * p.ld + lh * 8;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) qf[t] = *reinterpret_cast<const u32x4 *>(qp + t * 16);
+    }
+    f32x16 o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    __syncthreads();
+
+    // two wavefronts per SIMD here (half the registers of the split-fp32 kernel): the neighbour covers the soft-max
+    // arithmetic and the LDS round trips, so the loop is the plain S -> soft-max -> PV order, fragments read by the compiler
+    for (int j = 0; j < nb; ++j) {
+        const int buf = j & 1;
+        const unsigned char *lk = smem + buf * HBLK_BYTES + lane * 16, *lv = lk + 2 * HBLK_BYTES;
+        if (j + 1 < nb) {
+            dma(kg, kb0 + j + 1, buf ^ 1);
+            dma(vg, kb0 + j + 1, 2 + (buf ^ 1));
+        }
+        f32x16 sa, sb;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sa[e] = sb[e] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; t += 2) {        // fragment (tile t / 2, k-step t % 2) at (t / 2) * 2048 + (t % 2) * 1024
+            sa = HM<HT>::mfma(*reinterpret_cast<const u32x4 *>(lk + (t >> 1) * 2048), qf[t], sa);
+            sb = HM<HT>::mfma(*reinterpret_cast<const u32x4 *>(lk + (t >> 1) * 2048 + 1024), qf[t + 1], sb);
+        }
+        float s[16], mloc = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            s[e] = (sa[e] + sb[e]) * p.qscale_log2e;
+            mloc = fmaxf(mloc, s[e]);
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        if (__any(m_new > m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float x = o[i][e], tmp;
+                    asm volatile("v_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\tv_accvgpr_write_b32 %0, %1"
+                                 : "+a"(x), "=&v"(tmp)
+                                 : "v"(alpha));
+                    o[i][e] = x;
+                }
+            m_run = m_new;
+        }
+        u32x4 pf[2];
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+            const float p0 = __builtin_amdgcn_exp2f(s[e] - m_run), p1 = __builtin_amdgcn_exp2f(s[e + 1] - m_run);
+            // the sum runs over the ROUNDED probabilities, so numerator and denominator see the same values
+            const unsigned pk = HM<HT>::pack2(p0, p1);
+            pf[e >> 3][(e & 7) >> 1] = pk;
+            if (HT == 0) l_run += __builtin_bit_cast(float, pk << 16) + __builtin_bit_cast(float, pk & 0xffff0000u);
+            else l_run += (float)__builtin_bit_cast(_Float16, (unsigned short)(pk & 0xffffu)) + (float)__builtin_bit_cast(_Float16, (unsigned short)(pk >> 16));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                o[i] = HM<HT>::mfma(*reinterpret_cast<const u32x4 *>(lv + i * 2048 + t * 1024), pf[t], o[i]);
+        __syncthreads();
+    }
+
+    l_run += __shfl_xor(l_run, 32, 64);
+    if (lh == 0) {
+        float *ml = p.ws_ml + ((int64_t)sp * p.n + q0 + lq) * 2;
+        ml[0] = m_run;
+        ml[1] = l_run;
+    }
+    float *wo = p.ws_o + ((int64_t)sp * (p.n / 32) + (q0 >> 5)) * (AD * 32) + lq;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) wo[(32 * i + 8 * (e >> 2) + 4 * lh + (e & 3)) * 32] = o[i][e];
+}
+
+// merge of the key ranges for the 16-bit variant: as attn_combine_kernel, output rounded to 16 bits
+template <int HT>
+__global__ __launch_bounds__(256) void attn_combine_h16_kernel(const float *__restrict__ ws_o, const float *__restrict__ ws_ml,
+                                                               unsigned short *__restrict__ out, int ldo, int n) {
+    __shared__ float tile[32][33];
+    const int qt = blockIdx.x >> 3, dg = blockIdx.x & 7;
+    const int q = threadIdx.x & 31, dsub = threadIdx.x >> 5;
+    float w[NSPLIT], M = -INFINITY, L = 0.f;
+#pragma unroll
+    for (int s = 0; s < NSPLIT; ++s) {
+        w[s] = ws_ml[((int64_t)s * n + qt * 32 + q) * 2];
+        M = fmaxf(M, w[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < NSPLIT; ++s) {
+        w[s] = __builtin_amdgcn_exp2f(w[s] - M);
+        L += w[s] * ws_ml[((int64_t)s * n + qt * 32 + q) * 2 + 1];
+    }
+    const float inv = 1.0f / L;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NSPLIT; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc[j] += w[s] * ws_o[(((int64_t)s * (n / 32) + qt) * AD + dg * 32 + dsub * 4 + j) * 32 + q];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tile[q][dsub * 4 + j] = acc[j] * inv;
+    __syncthreads();
+    const int r = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
+    unsigned short *dst = out + (int64_t)(qt * 32 + r) * ldo + dg * 32 + c4;
+    u32x2 pk;
+    pk[0] = (unsigned)HM<HT>::from_f(tile[r][c4]) | ((unsigned)HM<HT>::from_f(tile[r][c4 + 1]) << 16);
+    pk[1] = (unsigned)HM<HT>::from_f(tile[r][c4 + 2]) | ((unsigned)HM<HT>::from_f(tile[r][c4 + 3]) << 16);
+    *reinterpret_cast<u32x2 *>(dst) = pk;
+}
+
 }  // namespace
 
 extern "C" int64_t sgam_attention_f32x_workspace_bytes(int32_t n, int32_t C) {
@@ -398,6 +598,45 @@ extern "C" int sgam_attention_f32x(const float *q, const float *k, const float *
     hipLaunchKernelGGL(attn_flash_f32x_kernel, dim3(n / 128 * nsplit), dim3(256), 0, s, p);
     SGAM_LAUNCH_CHECK();
     hipLaunchKernelGGL(attn_combine_kernel, dim3(n / 32 * 8), dim3(256), 0, s, ws_o, ws_ml, out, ldo, n);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+extern "C" int64_t sgam_attention_h16_workspace_bytes(int32_t n, int32_t C) {
+    if (C != AD || n < 256 || n % 256 != 0) return -1;
+    return 2 * (int64_t)n * AD * 2 + (int64_t)NSPLIT * n * AD * 4 + (int64_t)NSPLIT * n * 2 * 4;
+}
+
+extern "C" int sgam_attention_h16(const void *q, const void *k, const void *v, int32_t ht, int32_t ld, int32_t n, int32_t C,
+                                  float scale, void *out, int32_t ldo, void *workspace, int64_t workspace_bytes, void *stream) {
+    if (!q || !k || !v || !out || !workspace || (ht != 0 && ht != 1)) return SGAM_EINVAL;
+    const int64_t need = sgam_attention_h16_workspace_bytes(n, C);
+    if (need < 0 || ld < C || ld % 8 != 0 || ldo < C || ldo % 4 != 0 || !(scale > 0.f) || (n / KB) % NSPLIT != 0) return SGAM_EINVAL;
+    if (workspace_bytes < need) return SGAM_EWORKSPACE;
+    if (!sgam_aligned16(q) || !sgam_aligned16(k) || !sgam_aligned16(v) || !sgam_aligned16(workspace) ||
+        (((uintptr_t)out) & 7u) != 0)
+        return SGAM_EALIGN;
+    hipStream_t s = sgam_stream(stream);
+    unsigned short *kf = (unsigned short *)workspace;
+    unsigned short *vf = kf + (int64_t)n * AD;
+    float *ws_o = (float *)(vf + (int64_t)n * AD);
+    float *ws_ml = ws_o + (int64_t)NSPLIT * n * AD;
+    hipLaunchKernelGGL(attn_split_kv_h16_kernel, dim3(n / 8), dim3(256), 0, s, (const unsigned short *)k,
+                       (const unsigned short *)v, ld, n, kf, vf);
+    SGAM_LAUNCH_CHECK();
+    AttnHParams p;
+    p.q = (const unsigned short *)q; p.kf = kf; p.vf = vf; p.ws_o = ws_o; p.ws_ml = ws_ml;
+    p.ld = ld; p.n = n; p.blocks_per_split = n / KB / NSPLIT; p.qscale_log2e = scale * LOG2E;
+    const dim3 grid(n / 128 * NSPLIT), cgrid(n / 32 * 8);
+    if (ht == 0) {
+        hipLaunchKernelGGL(attn_flash_h16_kernel<0>, grid, dim3(256), 0, s, p);
+        SGAM_LAUNCH_CHECK();
+        hipLaunchKernelGGL(attn_combine_h16_kernel<0>, cgrid, dim3(256), 0, s, ws_o, ws_ml, (unsigned short *)out, ldo, n);
+    } else {
+        hipLaunchKernelGGL(attn_flash_h16_kernel<1>, grid, dim3(256), 0, s, p);
+        SGAM_LAUNCH_CHECK();
+        hipLaunchKernelGGL(attn_combine_h16_kernel<1>, cgrid, dim3(256), 0, s, ws_o, ws_ml, (unsigned short *)out, ldo, n);
+    }
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
 }

@@ -221,10 +221,13 @@ def _attn_h16(self, x, wqkv, bqkv, wp, bp):
     scale = int(C) ** (-0.5)
     for b in range(B):
         qkv = ops.gemm_nt(h[b].reshape(n, C), wqkv, bias=bqkv)                     # (n, 3C) 16-bit
-        vt = ops.transpose_h16(qkv[:, 2 * C:])                                     # (C, n)
-        s = ops.gemm_nt(qkv[:, :C], qkv[:, C:2 * C], out_dtype=torch.float32)      # (n, n) fp32 scores
-        p = ops.softmax_rows_h16(s, scale, x.dtype)                                # (n, n) 16-bit probabilities
-        o = ops.gemm_nt(p, vt)                                                     # (n, C)
+        if ops.attention_fusable(n, C):
+            o = ops.attention_h16(qkv, C, scale)                                   # one pass over the keys
+        else:
+            vt = ops.transpose_h16(qkv[:, 2 * C:])                                 # (C, n)
+            s = ops.gemm_nt(qkv[:, :C], qkv[:, C:2 * C], out_dtype=torch.float32)  # (n, n) fp32 scores
+            p = ops.softmax_rows_h16(s, scale, x.dtype)                            # (n, n) 16-bit probabilities
+            o = ops.gemm_nt(p, vt)                                                 # (n, C)
         ops.gemm_nt(o, wp, bias=bp, residual=x[b].reshape(n, C), out=out[b].reshape(n, C))
     return out
 

@@ -451,6 +451,23 @@ def attention(qkv, C, scale, out=None):
     return out
 
 
+def attention_h16(qkv, C, scale, out=None):
+    """16-bit throughput variant of `attention` (qkv bf16 / fp16, result in the same dtype)."""
+    _need_cuda(qkv)
+    n = qkv.shape[0]
+    assert qkv.dtype in H16 and qkv.shape[1] == 3 * C and qkv.stride(1) == 1
+    lib = _lib.load()
+    ws_bytes = lib.sgam_attention_h16_workspace_bytes(n, C)
+    if ws_bytes < 0:
+        raise SgamHipError(f"sgam_attention_h16: unsupported shape n={n} C={C}")
+    ws = torch.empty((ws_bytes,), device=qkv.device, dtype=torch.uint8)
+    if out is None:
+        out = torch.empty((n, C), device=qkv.device, dtype=qkv.dtype)
+    check(lib.sgam_attention_h16(_p(qkv), _p(qkv[:, C:]), _p(qkv[:, 2 * C:]), H16[qkv.dtype], qkv.stride(0), n, C, float(scale),
+                                 _p(out), out.stride(0), _p(ws), ws_bytes, _stream()), "sgam_attention_h16")
+    return out
+
+
 def softmax_rows_(s, scale):
     _need_cuda(s)
     rows, cols = s.shape

@@ -61,6 +61,9 @@ def test_argument_validation_without_gpu():
     assert lib.sgam_attention_f32x_workspace_bytes(4096, 512) == -1
     assert lib.sgam_attention_f32x_workspace_bytes(4000, 256) == -1
     assert lib.sgam_attention_f32x(None, None, None, 768, 4096, 256, 0.0625, None, 256, None, 0, None) == -1
+    assert lib.sgam_attention_h16_workspace_bytes(4096, 256) == 2 * 4096 * 256 * 2 + 8 * 4096 * 256 * 4 + 8 * 4096 * 8
+    assert lib.sgam_attention_h16_workspace_bytes(4096, 128) == -1
+    assert lib.sgam_attention_h16(None, None, None, 1, 768, 4096, 256, 0.0625, None, 256, None, 0, None) == -1
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

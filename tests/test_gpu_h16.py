@@ -99,3 +99,24 @@ def test_full_model_h16_vs_fp32(golden, dt):
     assert agree >= (0.80 if dt == "bf16" else 0.93)
     assert err_pre <= (8e-2 if dt == "bf16" else 1.5e-2)
     assert err_dec_same <= (8e-2 if dt == "bf16" else 1.5e-2)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("n", [1024, 4096])
+def test_fused_attention_h16(dt, n):
+    """sgam_attention_h16 against softmax(q k^T / 16) v in fp64 on the 16-bit inputs, and against the 16-bit GEMM / softmax /
+    GEMM chain it replaces (16-bit probabilities either way: the two agree to the rounding of P)."""
+    C = 256
+    qkv = testing.seeded_tensor(f"attn16.{n}", (n, 3 * C)).to(DEV).to(dt)
+    scale = C ** -0.5
+    o = ops.attention_h16(qkv, C, scale)
+    assert o.dtype == dt and torch.equal(o, ops.attention_h16(qkv, C, scale))
+    q, k, v = (qkv[:, i * C:(i + 1) * C].double() for i in range(3))
+    ref = torch.softmax(q @ k.t() * scale, dim=1) @ v
+    tol = 2e-2 if dt == torch.bfloat16 else 3e-3
+    err = (o.double() - ref).abs().max().item()
+    assert err <= tol * max(1.0, ref.abs().max().item()), err
+    vt = ops.transpose_h16(qkv[:, 2 * C:])
+    s = ops.gemm_nt(qkv[:, :C], qkv[:, C:2 * C], out_dtype=torch.float32)
+    chain = ops.gemm_nt(ops.softmax_rows_h16(s, scale, dt), vt)
+    assert (o.double() - chain.double()).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
