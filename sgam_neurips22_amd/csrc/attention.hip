@@ -295,7 +295,10 @@ __global__ __launch_bounds__(256) void attn_flash_f32x_kernel(const AttnParams p
                 const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
                 l_run *= alpha;
                 // the output accumulators live in AccVGPRs (MFMA C/D); scale them in place, register by register, so
-                // that the allocator keeps them there instead of shuttling all 128 through VGPRs on every trip
+                // that the allocator keeps them there instead of shuttling all 128 through VGPRs on every trip.
+                // (Hazards the compiler cannot see inside the asm: the statements run in tile order, so the tile the
+                // last PV MFMA wrote is read > 300 instructions after that MFMA issued, and the next MFMA that takes one
+                // of these registers as SrcC is a whole S phase away.)
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
 #pragma unroll
