@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void frame_feedback_kernel(const float *__rest
 }  // namespace
 
 extern "C" int sgam_abi_version(void) { return 2; }
-extern "C" const char *sgam_build_info(void) { return "libsgam_hip gfx950 (CDNA4) fp32-MFMA path, built " __DATE__; }
+extern "C" const char *sgam_build_info(void) { return "libsgam_hip gfx950 (CDNA4): split-fp32 / fp32-in / 16-bit MFMA paths, built " __DATE__; }
 
 extern "C" int sgam_nchw_to_nhwc_f32(const float *x, float *y, int32_t B, int32_t C, int32_t HW, int32_t ldy,
                                      void *stream) {
