@@ -22,8 +22,10 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # one hardware queue per concurrent scene (see distributed.py)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -160,7 +162,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the fp16 throughput-mode leg")
     ap.add_argument("--f32-mode", default=None, choices=["split", "mfma"],
                     help="fp32 products: fp16-split MFMA (default) or fp32-in MFMA")
-    ap.add_argument("--concurrent-scenes", type=int, default=3, help="secondary leg: this many independent trajectories "
+    ap.add_argument("--concurrent-scenes", type=int, default=4, help="secondary leg: this many independent trajectories "
                                                                       "on one GPU, one stream each (0/1 = skip)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying HIP graphs")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "fp16"],

@@ -4,8 +4,14 @@ per-rank (frames, seconds, checksum) record at the end — RCCL over xGMI on the
 gloo in the CPU tests."""
 import os
 
-import torch
-import torch.distributed as dist
+# HIP streams are dealt onto hardware queues (4 by default): with fewer queues than concurrent scenes — or an unlucky
+# deal — two scenes share a queue and run back to back instead of side by side (measured on one box: two scenes 319
+# frames/s with the default, 447 with 8 queues; three scenes 392 vs 503).  Must be in the environment before the HIP
+# runtime starts, i.e. before the first CUDA call of the process.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 
 def env_world():
