@@ -376,3 +376,16 @@ def test_fused_attention_matches_fp64_and_the_gemm_chain(n, spread):
     for _ in range(10):                                          # run-to-run deterministic (LDS-DMA staging, counted waits)
         assert torch.equal(o, ops.attention(qkv, C, scale))
     assert not ops.attention_fusable(n, 512) and not ops.attention_fusable(n + 32, C)
+
+
+def test_fused_attention_at_the_512sq_size():
+    """n = 16384 tokens (the 512x512 configuration: 1024 workgroups, 64 key blocks per range): a sample of query rows
+    against fp64."""
+    n, C = 16384, 256
+    qkv = testing.seeded_tensor("attn.16k", (n, 3 * C)).to(DEV)
+    scale = C ** -0.5
+    o = ops.attention(qkv, C, scale)
+    rows = torch.arange(0, n, 67, device=DEV)
+    q, k, v = qkv[rows, :C].double(), qkv[:, C:2 * C].double(), qkv[:, 2 * C:].double()
+    ref = torch.softmax(q @ k.t() * scale, dim=1) @ v
+    _close(o[rows], ref, 2e-5, "fused attention, n = 16384")
