@@ -33,6 +33,11 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert sorted(_lib.PROTOTYPES.keys()) == declared, "ctypes prototypes and the header disagree"
 
 
+def test_every_declared_symbol_is_documented_for_the_reference_side():
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert [s for s in _declared_symbols() if s not in doc] == []
+
+
 def test_conv_desc_layout_matches_header():
     text = open(os.path.join(ROOT, "include", "sgam_hip.h")).read()
     body = re.search(r"typedef struct sgam_conv_desc \{(.*?)\} sgam_conv_desc;", text, flags=re.S).group(1)
