@@ -34,6 +34,19 @@ int sgam_abi_version(void);
 const char *sgam_build_info(void);
 
 /* ------------------------------------------------------------------------------------------
+ * Kernel timeline (measurement; no reference counterpart — the reference has no profiling).  While
+ * enabled, every kernel launch of the library is bracketed by two HIP events recorded on the launch stream.  Not usable
+ * inside stream capture; the caller synchronises the device before reading.  sgam_prof_get(i): kernel name as written at
+ * the launch site, the enclosing function's signature (resolves symbolic template arguments), elapsed ms, and the
+ * algorithmic FLOP / bytes the launch site announced (0 when it announced none).  sgam_prof_mark_empty records a
+ * bracket around nothing (the cost of the bracket itself, to be subtracted).
+ * ------------------------------------------------------------------------------------------ */
+int sgam_prof_enable(int32_t on);
+int sgam_prof_mark_empty(void *stream);
+int32_t sgam_prof_count(void);
+int sgam_prof_get(int32_t i, const char **kernel, const char **where, float *ms, double *flops, double *bytes);
+
+/* ------------------------------------------------------------------------------------------
  * K1/K2/K3/K6 — convolution as implicit GEMM on the matrix cores (fp32-in/fp32-acc MFMA).
  * Replaces torch.nn.Conv2d in ResnetBlock/Upsample/Downsample/AttnBlock/VQModel:
  *   sgam/generative_sensing_module/modules/diffusionmodules/model.py:43-53 (nearest x2 + 3x3),
@@ -233,6 +246,11 @@ int sgam_vq_nearest_f32(const float *z, const float *codebook, const float *e_sq
                         int64_t *idx_out, float *zq_out, float *dist_out, int32_t T, int32_t D,
                         int32_t n_e, int32_t straight_through, void *workspace, int64_t workspace_bytes,
                         void *stream);
+/* commitment loss of VectorQuantizer2.forward (quantize.py:296-301, legacy = True):
+ *   loss = mean((e[idx] - z)^2) + beta * mean((e[idx] - z)^2)   — the scalar VQModel.forward returns as `diff`
+ * (model.py:144-147).  partial [T] doubles (scratch: per-token sums, folded in a fixed order); loss [1] float. */
+int sgam_vq_commit_loss_f32(const float *z, const float *codebook, const int64_t *idx, double *partial, float *loss,
+                            int32_t T, int32_t D, int32_t n_e, float beta, void *stream);
 /* pure gather (quantize.py:368, get_codebook_entry :321-335): out[t][:] = codebook[idx[t]][:] */
 int sgam_vq_gather_f32(const float *codebook, const int64_t *idx, float *out, int32_t T, int32_t D,
                        int32_t n_e, void *stream);
@@ -282,6 +300,16 @@ int sgam_forward_splat_f32(const float *src_feats, int64_t feat_cs, int64_t feat
                            float *merge_depths, float *merge_feats, uint8_t *extrap, float *x_out,
                            float *proj_feats, float *proj_depth, uint8_t *inb_mask, int32_t *pix_xy,
                            void *stream);
+/* Same splat with the sources addressed through a table of device pointers instead of one stacked tensor: the scene
+ * loop (prepare_batch_data, inference_pipeline.py:534-537) keeps every generated frame as its own HBM allocation and
+ * the warp reads them in place.  src_feat_ptrs / src_depth_ptrs: HOST arrays of B*N device pointers (entry b*N+n: the
+ * [HW] x 3 features of that source, strides feat_cs / feat_ps, and its [HW] depth map); B*N <= 16 (the table travels by
+ * value in the kernel arguments: no upload).  Everything else as sgam_forward_splat_f32. */
+int sgam_forward_splat_srcs_f32(const float *const *src_feat_ptrs, const float *const *src_depth_ptrs, int64_t feat_cs,
+                                int64_t feat_ps, const float *tgt_K, const float *src_Kinv, const float *T, int32_t B,
+                                int32_t N, int32_t H, int32_t W, const float *depth_range, int32_t dataset_norm,
+                                int32_t *winner, float *merge_depths, float *merge_feats, uint8_t *extrap, float *x_out,
+                                float *proj_feats, float *proj_depth, uint8_t *inb_mask, int32_t *pix_xy, void *stream);
 
 /* K12 standalone (VQModel.get_x, model.py:196-199 + 210-229, when the warped view is supplied by the
  * caller): compute_mask=1: extrap = depth <= 0, out = normalised inverse depth with holes = -2;
@@ -298,6 +326,12 @@ int sgam_depth_normalise_f32(const float *depth, int32_t compute_mask, uint8_t *
 int sgam_inverse_warp_f32(const float *src_imgs, const float *src_depths, const float *tgt_depth,
                           const float *src_K, const float *tgt_Kinv, const float *T_tgt2src, int32_t B,
                           int32_t N, int32_t H, int32_t W, float *warped, float *zbuf, void *stream);
+/* Same with a pointer table (HOST arrays of B*N <= 16 device pointers) and free channel / pixel strides of the source
+ * images: (3,H,W) planes: img_cs = HW, img_ps = 1; the frame store's (H,W,3): img_cs = 1, img_ps = 3. */
+int sgam_inverse_warp_srcs_f32(const float *const *src_img_ptrs, const float *const *src_depth_ptrs, int64_t img_cs,
+                               int64_t img_ps, const float *tgt_depth, const float *src_K, const float *tgt_Kinv,
+                               const float *T_tgt2src, int32_t B, int32_t N, int32_t H, int32_t W, float *warped,
+                               float *zbuf, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Frame feedback codec (inference_pipeline.py:898-911 then :534-537): decoder output (B,4,HW)
@@ -308,6 +342,8 @@ int sgam_inverse_warp_f32(const float *src_imgs, const float *src_depths, const 
  * ------------------------------------------------------------------------------------------ */
 int sgam_frame_feedback_f32(const float *dec, const float *lut256, int32_t dataset_norm, uint8_t *rgb_u8,
                             float *rgb_f, float *depth, int32_t B, int32_t HW, void *stream);
+/* the re-read half alone, for frames that arrive as uint8 (the seed frame): rgb_f[i] = lut256[rgb_u8[i]], n values */
+int sgam_rgb_u8_to_f32(const uint8_t *rgb_u8, const float *lut256, float *rgb_f, int64_t n, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * f1 — TSDF fusion of the generated RGB-D frames + depth render at the target pose.  Replaces

@@ -106,15 +106,16 @@ def distances(sd, z_flat):
 
 def quantize(sd, z):
     """VectorQuantizer2.forward at inference (quantize.py:275-319): returns z_q (NCHW, incl.
-    the straight-through expression z + (z_q - z)), indices (B,h,w) int64, distance matrix."""
+    the straight-through expression z + (z_q - z)), indices (B,h,w) int64, distance matrix, commitment loss."""
     e = sd["quantize.embedding.weight"]
     zp = z.permute(0, 2, 3, 1).contiguous()
     zf = zp.view(-1, e.shape[1])
     d = distances(sd, zf)
     idx = torch.argmin(d, dim=1)
     z_q = F.embedding(idx, e).view(zp.shape)
+    loss = torch.mean((z_q - zp) ** 2) + 0.25 * torch.mean((z_q - zp) ** 2)   # :296-301, legacy, beta = 0.25
     z_q = zp + (z_q - zp)
-    return z_q.permute(0, 3, 1, 2).contiguous(), idx.view(zp.shape[:-1]), d
+    return z_q.permute(0, 3, 1, 2).contiguous(), idx.view(zp.shape[:-1]), d, loss
 
 
 def get_multiple_codewords(sd, z, topk, sample_number, extrapolation_mask):
@@ -159,8 +160,8 @@ def forward(sd, dd, x, extrapolation_mask=None, topk=None, sample_number=1):
     """VQModel.forward (model.py:141-167) -> dict(dec, indices, pre_quant, quant)."""
     pre = encode_features(sd, dd, x, extrapolation_mask)
     if topk is None:
-        quant, idx, _ = quantize(sd, pre)
-        return {"dec": decode(sd, dd, quant), "indices": idx, "pre_quant": pre, "quant": quant}
+        quant, idx, _, loss = quantize(sd, pre)
+        return {"dec": decode(sd, dd, quant), "indices": idx, "pre_quant": pre, "quant": quant, "emb_loss": loss}
     quants, idx = get_multiple_codewords(sd, pre, topk, sample_number, extrapolation_mask)
     decs = [decode(sd, dd, quants[:, i])[None] for i in range(sample_number)]
     return {"dec": decs, "indices": idx, "pre_quant": pre, "quant": quants}

@@ -25,6 +25,11 @@ class TsdfGrid(ctypes.Structure):
 PROTOTYPES = {
     "sgam_abi_version": (c_i32, []),
     "sgam_build_info": (ctypes.c_char_p, []),
+    "sgam_prof_enable": (c_i32, [c_i32]),
+    "sgam_prof_mark_empty": (c_i32, [c_vp]),
+    "sgam_prof_count": (c_i32, []),
+    "sgam_prof_get": (c_i32, [c_i32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_char_p),
+                              ctypes.POINTER(c_f32), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "sgam_conv2d_workspace_bytes": (c_i64, [ctypes.POINTER(ConvDesc)]),
     "sgam_conv2d_plan": (c_i32, [ctypes.POINTER(ConvDesc), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32),
                                  ctypes.POINTER(c_i32)]),
@@ -83,6 +88,7 @@ PROTOTYPES = {
     "sgam_vq_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
     "sgam_vq_nearest_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp,
                                     c_i64, c_vp]),
+    "sgam_vq_commit_loss_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_vp]),
     "sgam_vq_gather_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "sgam_vq_topk_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "sgam_nchw_to_nhwc_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
@@ -91,9 +97,15 @@ PROTOTYPES = {
     "sgam_forward_splat_f32": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,
                                        ctypes.POINTER(c_f32), c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                        c_vp, c_vp, c_vp]),
+    "sgam_forward_splat_srcs_f32": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,
+                                            ctypes.POINTER(c_f32), c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                            c_vp, c_vp, c_vp]),
     "sgam_depth_normalise_f32": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_i32, c_i64, c_vp]),
     "sgam_inverse_warp_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp,
                                       c_vp]),
+    "sgam_inverse_warp_srcs_f32": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,
+                                           c_vp, c_vp, c_vp]),
+    "sgam_rgb_u8_to_f32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "sgam_frame_feedback_f32": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
 }
 

@@ -593,14 +593,15 @@ extern "C" int sgam_attention_f32x(const float *q, const float *k, const float *
     unsigned short *vf = kf + (int64_t)n * AD * 2;
     float *ws_o = (float *)(vf + (int64_t)n * AD * 2);
     float *ws_ml = ws_o + (int64_t)nsplit * n * AD;
-    hipLaunchKernelGGL(attn_split_kv_kernel, dim3(n / KB * 8 * 128 / 256), dim3(256), 0, s, k, v, ld, n, kf, vf);
+    SGAM_KLAUNCH(attn_split_kv_kernel, dim3(n / KB * 8 * 128 / 256), dim3(256), 0, s, k, v, ld, n, kf, vf);
     SGAM_LAUNCH_CHECK();
     AttnParams p;
     p.q = q; p.kf = kf; p.vf = vf; p.ws_o = ws_o; p.ws_ml = ws_ml;
     p.ld = ld; p.n = n; p.blocks_per_split = n / KB / nsplit; p.qscale = scale;
-    hipLaunchKernelGGL(attn_flash_f32x_kernel, dim3(n / 128 * nsplit), dim3(256), 0, s, p);
+    if (sgam_i_prof_on) sgam_i_prof_work(4.0 * n * (double)n * AD, 4.0 * 4.0 * n * AD);   // q k^T + P v; q, k, v, o once
+    SGAM_KLAUNCH(attn_flash_f32x_kernel, dim3(n / 128 * nsplit), dim3(256), 0, s, p);
     SGAM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(attn_combine_kernel, dim3(n / 32 * 8), dim3(256), 0, s, ws_o, ws_ml, out, ldo, n);
+    SGAM_KLAUNCH(attn_combine_kernel, dim3(n / 32 * 8), dim3(256), 0, s, ws_o, ws_ml, out, ldo, n);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
 }
@@ -624,21 +625,22 @@ extern "C" int sgam_attention_h16(const void *q, const void *k, const void *v, i
     unsigned short *vf = kf + (int64_t)n * AD;
     float *ws_o = (float *)(vf + (int64_t)n * AD);
     float *ws_ml = ws_o + (int64_t)NSPLIT * n * AD;
-    hipLaunchKernelGGL(attn_split_kv_h16_kernel, dim3(n / 8), dim3(256), 0, s, (const unsigned short *)k,
+    SGAM_KLAUNCH(attn_split_kv_h16_kernel, dim3(n / 8), dim3(256), 0, s, (const unsigned short *)k,
                        (const unsigned short *)v, ld, n, kf, vf);
     SGAM_LAUNCH_CHECK();
     AttnHParams p;
     p.q = (const unsigned short *)q; p.kf = kf; p.vf = vf; p.ws_o = ws_o; p.ws_ml = ws_ml;
     p.ld = ld; p.n = n; p.blocks_per_split = n / KB / NSPLIT; p.qscale_log2e = scale * LOG2E;
     const dim3 grid(n / 128 * NSPLIT), cgrid(n / 32 * 8);
+    if (sgam_i_prof_on) sgam_i_prof_work(4.0 * n * (double)n * AD, 4.0 * 2.0 * n * AD);
     if (ht == 0) {
-        hipLaunchKernelGGL(attn_flash_h16_kernel<0>, grid, dim3(256), 0, s, p);
+        SGAM_KLAUNCH(attn_flash_h16_kernel<0>, grid, dim3(256), 0, s, p);
         SGAM_LAUNCH_CHECK();
-        hipLaunchKernelGGL(attn_combine_h16_kernel<0>, cgrid, dim3(256), 0, s, ws_o, ws_ml, (unsigned short *)out, ldo, n);
+        SGAM_KLAUNCH(attn_combine_h16_kernel<0>, cgrid, dim3(256), 0, s, ws_o, ws_ml, (unsigned short *)out, ldo, n);
     } else {
-        hipLaunchKernelGGL(attn_flash_h16_kernel<1>, grid, dim3(256), 0, s, p);
+        SGAM_KLAUNCH(attn_flash_h16_kernel<1>, grid, dim3(256), 0, s, p);
         SGAM_LAUNCH_CHECK();
-        hipLaunchKernelGGL(attn_combine_h16_kernel<1>, cgrid, dim3(256), 0, s, ws_o, ws_ml, (unsigned short *)out, ldo, n);
+        SGAM_KLAUNCH(attn_combine_h16_kernel<1>, cgrid, dim3(256), 0, s, ws_o, ws_ml, (unsigned short *)out, ldo, n);
     }
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;

@@ -1056,24 +1056,29 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
 #define XLAUNCH(BM_, BN_)                                                                                                   \
     do {                                                                                                                    \
         const dim3 blk(256 * wk_of(BM_, BN_));                                                                              \
-        if (p.ups) hipLaunchKernelGGL((conv_gemm_f32x_kernel<BM_, BN_, true, false>), grid, blk, 0, s, p);                  \
-        else if (a_scale != 1.0f) hipLaunchKernelGGL((conv_gemm_f32x_kernel<BM_, BN_, false, true>), grid, blk, 0, s, p);   \
-        else hipLaunchKernelGGL((conv_gemm_f32x_kernel<BM_, BN_, false, false>), grid, blk, 0, s, p);                       \
+        if (p.ups) SGAM_KLAUNCH((conv_gemm_f32x_kernel<BM_, BN_, true, false>), grid, blk, 0, s, p);                  \
+        else if (a_scale != 1.0f) SGAM_KLAUNCH((conv_gemm_f32x_kernel<BM_, BN_, false, true>), grid, blk, 0, s, p);   \
+        else SGAM_KLAUNCH((conv_gemm_f32x_kernel<BM_, BN_, false, false>), grid, blk, 0, s, p);                       \
     } while (0)
     if (p.ups && a_scale != 1.0f) return SGAM_EINVAL;
     if (d->KH * d->KW > 32) return SGAM_EINVAL;   // tap validity mask is 32 bits
     const bool halo = halo_eligible(d, pl, a_scale);
     if (ex.gn_stats && !halo) return SGAM_EINVAL;
+    // algorithmic work of this launch: 2 M N K fp32 FLOP; bytes = input + weights + output once
+    if (sgam_i_prof_on)
+        sgam_i_prof_work(2.0 * p.M * d->n_valid * (double)(d->KH * d->KW * d->Cin),
+                         4.0 * ((double)d->B * d->Hi * d->Wi * d->Cin + (double)d->n_valid * d->KH * d->KW * d->Cin +
+                                (double)p.M * d->n_valid * (residual ? 2 : 1)));
     if (halo) {
         if (p.ups) {
-            if (pl.bm == 128) hipLaunchKernelGGL((conv3x3_f32x_halo2_kernel<128, 128, false, true>), grid, dim3(256), 0, s, p);
-            else hipLaunchKernelGGL((conv3x3_f32x_halo2_kernel<64, 128, false, true>), grid, dim3(256), 0, s, p);
+            if (pl.bm == 128) SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<128, 128, false, true>), grid, dim3(256), 0, s, p);
+            else SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<64, 128, false, true>), grid, dim3(256), 0, s, p);
         } else if (pl.bm == 128) {
-            if (p.gn_stats) hipLaunchKernelGGL((conv3x3_f32x_halo2_kernel<128, 128, true>), grid, dim3(256), 0, s, p);
-            else hipLaunchKernelGGL((conv3x3_f32x_halo2_kernel<128, 128, false>), grid, dim3(256), 0, s, p);
+            if (p.gn_stats) SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<128, 128, true>), grid, dim3(256), 0, s, p);
+            else SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<128, 128, false>), grid, dim3(256), 0, s, p);
         } else {
-            if (p.gn_stats) hipLaunchKernelGGL((conv3x3_f32x_halo2_kernel<64, 128, true>), grid, dim3(256), 0, s, p);
-            else hipLaunchKernelGGL((conv3x3_f32x_halo2_kernel<64, 128, false>), grid, dim3(256), 0, s, p);
+            if (p.gn_stats) SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<64, 128, true>), grid, dim3(256), 0, s, p);
+            else SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<64, 128, false>), grid, dim3(256), 0, s, p);
         }
     } else if (pl.bm == 128 && pl.bn == 128) XLAUNCH(128, 128);
     else if (pl.bm == 64 && pl.bn == 128) XLAUNCH(64, 128);
@@ -1082,7 +1087,7 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
     SGAM_LAUNCH_CHECK();
     if (pl.ksplit > 1) {
         const int64_t q = (int64_t)p.M * (p.N / 4);
-        hipLaunchKernelGGL(splitk_reduce_f32x_kernel, dim3(sgam_cdiv(q, 256)), dim3(256), 0, s, p);
+        SGAM_KLAUNCH(splitk_reduce_f32x_kernel, dim3(sgam_cdiv(q, 256)), dim3(256), 0, s, p);
         SGAM_LAUNCH_CHECK();
     }
     return SGAM_OK;
@@ -1092,7 +1097,7 @@ extern "C" int sgam_pack_conv_weight_f32x(const float *w_oihw, void *w_planes, f
                                           int32_t KH, int32_t KW, int32_t Cout_pad, int32_t Cin_pad, void *stream) {
     if (!w_oihw || !w_planes || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 || Cout_pad < Cout || Cin_pad < Cin || Cin_pad % 32 || Cout_pad % 32) return SGAM_EINVAL;
     const int64_t total = (int64_t)Cout_pad * KH * KW * Cin_pad;
-    hipLaunchKernelGGL(pack_weight_f32x_kernel, dim3(sgam_cdiv(total, 256)), dim3(256), 0, sgam_stream(stream), w_oihw,
+    SGAM_KLAUNCH(pack_weight_f32x_kernel, dim3(sgam_cdiv(total, 256)), dim3(256), 0, sgam_stream(stream), w_oihw,
                        (unsigned short *)w_planes, Cout, Cin, KH, KW, Cout_pad, Cin_pad, w_scale);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
@@ -1102,7 +1107,7 @@ extern "C" int sgam_split_rows_f32x(const float *x, void *planes, float scale, i
     if (!x || !planes || N <= 0 || K <= 0 || ld < K) return SGAM_EINVAL;
     const int Kp = (K + 31) / 32 * 32, Np = (N + 31) / 32 * 32;
     const int64_t total = (int64_t)Np * Kp;
-    hipLaunchKernelGGL(split_rows_f32x_kernel, dim3(sgam_cdiv(total, 256)), dim3(256), 0, sgam_stream(stream), x,
+    SGAM_KLAUNCH(split_rows_f32x_kernel, dim3(sgam_cdiv(total, 256)), dim3(256), 0, sgam_stream(stream), x,
                        (unsigned short *)planes, N, Np, K, Kp, ld, scale);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;

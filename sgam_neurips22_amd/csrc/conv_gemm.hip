@@ -827,24 +827,24 @@ static int conv_variant() {  // 2 = single-role v2 (default), 3 = producer/consu
 template <bool GN>
 static void launch_v3(const Plan &pl, const dim3 &grid, hipStream_t s, const ConvKernelParams &p) {
     if (pl.bm == 128 && pl.bn == 128) {
-        hipLaunchKernelGGL((conv_gemm_f32_v3_kernel<128, 128, GN>), grid, dim3(512), 0, s, p);
+        SGAM_KLAUNCH((conv_gemm_f32_v3_kernel<128, 128, GN>), grid, dim3(512), 0, s, p);
     } else if (pl.bm == 64 && pl.bn == 128) {
-        hipLaunchKernelGGL((conv_gemm_f32_v3_kernel<64, 128, GN>), grid, dim3(512), 0, s, p);
+        SGAM_KLAUNCH((conv_gemm_f32_v3_kernel<64, 128, GN>), grid, dim3(512), 0, s, p);
     } else {
-        hipLaunchKernelGGL((conv_gemm_f32_v3_kernel<64, 64, GN>), grid, dim3(512), 0, s, p);
+        SGAM_KLAUNCH((conv_gemm_f32_v3_kernel<64, 64, GN>), grid, dim3(512), 0, s, p);
     }
 }
 
 template <bool GN>
 static void launch_v2(const Plan &pl, const dim3 &grid, hipStream_t s, const ConvKernelParams &p) {
     if (pl.bm == 128 && pl.bn == 128 && pl.bk == 64) {
-        hipLaunchKernelGGL((conv_gemm_f32_v2_kernel<128, 128, GN, 64>), grid, dim3(256), 0, s, p);
+        SGAM_KLAUNCH((conv_gemm_f32_v2_kernel<128, 128, GN, 64>), grid, dim3(256), 0, s, p);
     } else if (pl.bm == 128 && pl.bn == 128) {
-        hipLaunchKernelGGL((conv_gemm_f32_v2_kernel<128, 128, GN, 32>), grid, dim3(256), 0, s, p);
+        SGAM_KLAUNCH((conv_gemm_f32_v2_kernel<128, 128, GN, 32>), grid, dim3(256), 0, s, p);
     } else if (pl.bm == 64 && pl.bn == 128) {
-        hipLaunchKernelGGL((conv_gemm_f32_v2_kernel<64, 128, GN, 32>), grid, dim3(256), 0, s, p);
+        SGAM_KLAUNCH((conv_gemm_f32_v2_kernel<64, 128, GN, 32>), grid, dim3(256), 0, s, p);
     } else {
-        hipLaunchKernelGGL((conv_gemm_f32_v2_kernel<64, 64, GN, 32>), grid, dim3(256), 0, s, p);
+        SGAM_KLAUNCH((conv_gemm_f32_v2_kernel<64, 64, GN, 32>), grid, dim3(256), 0, s, p);
     }
 }
 
@@ -879,13 +879,17 @@ extern "C" int sgam_conv2d_gn_nhwc_f32(const sgam_conv_desc *d, const float *x, 
     }
     const dim3 grid(sgam_cdiv(p.M, pl.bm), sgam_cdiv(p.N, pl.bn), pl.ksplit);
     hipStream_t s = sgam_stream(stream);
+    if (sgam_i_prof_on)
+        sgam_i_prof_work(2.0 * p.M * d->n_valid * (double)(d->KH * d->KW * d->Cin),
+                         4.0 * ((double)d->B * d->Hi * d->Wi * d->Cin + (double)d->n_valid * d->KH * d->KW * d->Cin +
+                                (double)p.M * d->n_valid));
     if (use_v1() && !gn_scale_shift) {
         if (pl.bm == 128 && pl.bn == 128) {
-            hipLaunchKernelGGL((conv_gemm_f32_kernel<128, 128>), grid, dim3(256), 0, s, p);
+            SGAM_KLAUNCH((conv_gemm_f32_kernel<128, 128>), grid, dim3(256), 0, s, p);
         } else if (pl.bm == 64 && pl.bn == 128) {
-            hipLaunchKernelGGL((conv_gemm_f32_kernel<64, 128>), grid, dim3(256), 0, s, p);
+            SGAM_KLAUNCH((conv_gemm_f32_kernel<64, 128>), grid, dim3(256), 0, s, p);
         } else {
-            hipLaunchKernelGGL((conv_gemm_f32_kernel<64, 64>), grid, dim3(256), 0, s, p);
+            SGAM_KLAUNCH((conv_gemm_f32_kernel<64, 64>), grid, dim3(256), 0, s, p);
         }
     } else if (gn_scale_shift) {
         if (conv_variant() == 3) launch_v3<true>(pl, grid, s, p); else launch_v2<true>(pl, grid, s, p);
@@ -895,7 +899,7 @@ extern "C" int sgam_conv2d_gn_nhwc_f32(const sgam_conv_desc *d, const float *x, 
     SGAM_LAUNCH_CHECK();
     if (pl.ksplit > 1) {
         const int64_t q = (int64_t)p.M * (p.N / 4);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(sgam_cdiv(q, 256)), dim3(256), 0, s, p);
+        SGAM_KLAUNCH(splitk_reduce_kernel, dim3(sgam_cdiv(q, 256)), dim3(256), 0, s, p);
         SGAM_LAUNCH_CHECK();
     }
     return SGAM_OK;
@@ -912,7 +916,7 @@ extern "C" int sgam_pack_conv_weight(const float *w_oihw, float *w_packed, int32
     if (!w_oihw || !w_packed || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 || Cout_pad < Cout || Cin_pad < Cin)
         return SGAM_EINVAL;
     const int64_t total = (int64_t)Cout_pad * KH * KW * Cin_pad;
-    hipLaunchKernelGGL(pack_weight_kernel, dim3(sgam_cdiv(total, 256)), dim3(256), 0, sgam_stream(stream), w_oihw,
+    SGAM_KLAUNCH(pack_weight_kernel, dim3(sgam_cdiv(total, 256)), dim3(256), 0, sgam_stream(stream), w_oihw,
                        w_packed, Cout, Cin, KH, KW, Cout_pad, Cin_pad);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;

@@ -363,7 +363,7 @@ int gn_launch(const void *x, const float *gamma, const float *beta, void *y, int
               int swish, void *workspace, hipStream_t s) {
     typedef typename E<T>::S S;
     if (HW <= GN_SMALL_HW) {
-        hipLaunchKernelGGL(gn_small_kernel<T>, dim3(groups, B), dim3(256), 0, s, (const S *)x, gamma, beta, (S *)y, HW, C,
+        SGAM_KLAUNCH(gn_small_kernel<T>, dim3(groups, B), dim3(256), 0, s, (const S *)x, gamma, beta, (S *)y, HW, C,
                            groups, eps, swish);
         SGAM_LAUNCH_CHECK();
         return SGAM_OK;
@@ -371,16 +371,16 @@ int gn_launch(const void *x, const float *gamma, const float *beta, void *y, int
     const int nchunk = gn_nchunk(HW, C, E<T>::VEC);
     const int ppc = sgam_cdiv(HW, nchunk);
     double *partial = (double *)workspace;
-    hipLaunchKernelGGL(gn_partial_kernel<T>, dim3(nchunk, B), dim3(GT), 0, s, (const S *)x, partial, HW, C, groups, ppc);
+    SGAM_KLAUNCH(gn_partial_kernel<T>, dim3(nchunk, B), dim3(GT), 0, s, (const S *)x, partial, HW, C, groups, ppc);
     SGAM_LAUNCH_CHECK();
     float *table = (float *)((char *)workspace + (int64_t)B * 256 * 64 * 2 * sizeof(double));
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(256), 0, s, partial, gamma, beta, table, HW, C, groups, nchunk, eps);
+    SGAM_KLAUNCH(gn_finalize_kernel, dim3(groups, B), dim3(256), 0, s, partial, gamma, beta, table, HW, C, groups, nchunk, eps);
     SGAM_LAUNCH_CHECK();
     const int cv = C / E<T>::VEC;
     int bpb = sgam_cdiv((int64_t)HW * cv, 256 * 4);   // ~4 vectors per lane
     if (bpb > 4096) bpb = 4096;
     if (bpb < 1) bpb = 1;
-    hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(bpb * B), dim3(256), 0, s, (const S *)x, table, (S *)y, HW, C, swish, bpb);
+    SGAM_KLAUNCH(gn_apply_kernel<T>, dim3(bpb * B), dim3(256), 0, s, (const S *)x, table, (S *)y, HW, C, swish, bpb);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
 }
@@ -428,13 +428,13 @@ extern "C" int sgam_groupnorm_from_partials_f32(const float *x, const double *pa
     if (!workspace || workspace_bytes < (int64_t)B * C * 2 * (int64_t)sizeof(float)) return SGAM_EWORKSPACE;
     hipStream_t s = sgam_stream(stream);
     float *table = (float *)workspace;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(256), 0, s, partial, gamma, beta, table, HW, C, groups, nchunk, eps);
+    SGAM_KLAUNCH(gn_finalize_kernel, dim3(groups, B), dim3(256), 0, s, partial, gamma, beta, table, HW, C, groups, nchunk, eps);
     SGAM_LAUNCH_CHECK();
     const int cv = C / 4;
     int bpb = sgam_cdiv((int64_t)HW * cv, 256 * 4);
     if (bpb > 4096) bpb = 4096;
     if (bpb < 1) bpb = 1;
-    hipLaunchKernelGGL(gn_apply_kernel<2>, dim3(bpb * B), dim3(256), 0, s, x, table, y, HW, C, fuse_swish, bpb);
+    SGAM_KLAUNCH(gn_apply_kernel<2>, dim3(bpb * B), dim3(256), 0, s, x, table, y, HW, C, fuse_swish, bpb);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
 }
@@ -445,7 +445,7 @@ extern "C" int sgam_groupnorm_stats_from_partials_f32(const double *partial, int
                                                       int32_t HW, int32_t C, int32_t groups, float eps, void *stream) {
     if (!partial || nchunk <= 0 || !mean_rstd || !gn_shape_ok(B, HW, C, groups)) return SGAM_EINVAL;
     if (!sgam_aligned16(partial)) return SGAM_EALIGN;
-    hipLaunchKernelGGL(gn_finalize_stats_kernel, dim3(groups, B), dim3(256), 0, sgam_stream(stream), partial, mean_rstd, HW, C,
+    SGAM_KLAUNCH(gn_finalize_stats_kernel, dim3(groups, B), dim3(256), 0, sgam_stream(stream), partial, mean_rstd, HW, C,
                        groups, nchunk, eps);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
@@ -461,9 +461,9 @@ extern "C" int sgam_groupnorm_meanrstd_nhwc_f32(const float *x, float *mean_rstd
     hipStream_t s = sgam_stream(stream);
     const int nchunk = gn_nchunk(HW, C, 4);
     double *partial = (double *)workspace;
-    hipLaunchKernelGGL(gn_partial_kernel<2>, dim3(nchunk, B), dim3(GT), 0, s, x, partial, HW, C, groups, sgam_cdiv(HW, nchunk));
+    SGAM_KLAUNCH(gn_partial_kernel<2>, dim3(nchunk, B), dim3(GT), 0, s, x, partial, HW, C, groups, sgam_cdiv(HW, nchunk));
     SGAM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gn_finalize_stats_kernel, dim3(groups, B), dim3(256), 0, s, partial, mean_rstd, HW, C, groups, nchunk, eps);
+    SGAM_KLAUNCH(gn_finalize_stats_kernel, dim3(groups, B), dim3(256), 0, s, partial, mean_rstd, HW, C, groups, nchunk, eps);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
 }
@@ -477,9 +477,9 @@ extern "C" int sgam_groupnorm_stats_nhwc_f32(const float *x, const float *gamma,
     hipStream_t s = sgam_stream(stream);
     const int nchunk = gn_nchunk(HW, C, 4);
     double *partial = (double *)workspace;
-    hipLaunchKernelGGL(gn_partial_kernel<2>, dim3(nchunk, B), dim3(GT), 0, s, x, partial, HW, C, groups, sgam_cdiv(HW, nchunk));
+    SGAM_KLAUNCH(gn_partial_kernel<2>, dim3(nchunk, B), dim3(GT), 0, s, x, partial, HW, C, groups, sgam_cdiv(HW, nchunk));
     SGAM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(256), 0, s, partial, gamma, beta, scale_shift, HW, C, groups, nchunk, eps);
+    SGAM_KLAUNCH(gn_finalize_kernel, dim3(groups, B), dim3(256), 0, s, partial, gamma, beta, scale_shift, HW, C, groups, nchunk, eps);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
 }

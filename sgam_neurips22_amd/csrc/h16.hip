@@ -468,13 +468,17 @@ int conv_h16_launch(const sgam_conv_desc *d, const void *x, const void *w, const
         p.ws = (float *)workspace;
     }
     const dim3 grid(sgam_cdiv(p.M, pl.bm), sgam_cdiv(p.N, pl.bn), pl.ksplit);
-    if (pl.bm == 128 && pl.bn == 128) hipLaunchKernelGGL((conv_gemm_h16_kernel<128, 128, HT>), grid, dim3(256), 0, s, p);
-    else if (pl.bm == 64 && pl.bn == 128) hipLaunchKernelGGL((conv_gemm_h16_kernel<64, 128, HT>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((conv_gemm_h16_kernel<64, 64, HT>), grid, dim3(256), 0, s, p);
+    if (sgam_i_prof_on)
+        sgam_i_prof_work(2.0 * p.M * d->n_valid * (double)(d->KH * d->KW * d->Cin),
+                         2.0 * ((double)d->B * d->Hi * d->Wi * d->Cin + (double)d->n_valid * d->KH * d->KW * d->Cin +
+                                (double)p.M * d->n_valid));
+    if (pl.bm == 128 && pl.bn == 128) SGAM_KLAUNCH((conv_gemm_h16_kernel<128, 128, HT>), grid, dim3(256), 0, s, p);
+    else if (pl.bm == 64 && pl.bn == 128) SGAM_KLAUNCH((conv_gemm_h16_kernel<64, 128, HT>), grid, dim3(256), 0, s, p);
+    else SGAM_KLAUNCH((conv_gemm_h16_kernel<64, 64, HT>), grid, dim3(256), 0, s, p);
     SGAM_LAUNCH_CHECK();
     if (pl.ksplit > 1) {
         const int64_t q = (int64_t)p.M * (p.N / 4);
-        hipLaunchKernelGGL(splitk_reduce_h16_kernel<HT>, dim3(sgam_cdiv(q, 256)), dim3(256), 0, s, p);
+        SGAM_KLAUNCH(splitk_reduce_h16_kernel<HT>, dim3(sgam_cdiv(q, 256)), dim3(256), 0, s, p);
         SGAM_LAUNCH_CHECK();
     }
     return SGAM_OK;
@@ -525,8 +529,8 @@ extern "C" int sgam_pack_conv_weight_h16(const float *w_oihw, void *w_packed, in
     const int64_t total = (int64_t)Cout_pad * KH * KW * Cin_pad;
     const dim3 g(sgam_cdiv(total, 256));
     hipStream_t s = sgam_stream(stream);
-    HT_DISPATCH(ht, hipLaunchKernelGGL(pack_weight_h16_kernel<0>, g, dim3(256), 0, s, w_oihw, (unsigned short *)w_packed, Cout, Cin, KH, KW, Cout_pad, Cin_pad),
-                hipLaunchKernelGGL(pack_weight_h16_kernel<1>, g, dim3(256), 0, s, w_oihw, (unsigned short *)w_packed, Cout, Cin, KH, KW, Cout_pad, Cin_pad));
+    HT_DISPATCH(ht, SGAM_KLAUNCH(pack_weight_h16_kernel<0>, g, dim3(256), 0, s, w_oihw, (unsigned short *)w_packed, Cout, Cin, KH, KW, Cout_pad, Cin_pad),
+                SGAM_KLAUNCH(pack_weight_h16_kernel<1>, g, dim3(256), 0, s, w_oihw, (unsigned short *)w_packed, Cout, Cin, KH, KW, Cout_pad, Cin_pad));
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
 }
@@ -534,8 +538,8 @@ extern "C" int sgam_pack_conv_weight_h16(const float *w_oihw, void *w_packed, in
 extern "C" int sgam_cast_f32_h16(const float *x, void *y, int32_t ht, int64_t n, void *stream) {
     if (!x || !y || n <= 0) return SGAM_EINVAL;
     hipStream_t s = sgam_stream(stream);
-    HT_DISPATCH(ht, hipLaunchKernelGGL(cast_f32_to_h16_kernel<0>, dim3(sgam_cdiv(n, 256)), dim3(256), 0, s, x, (unsigned short *)y, n),
-                hipLaunchKernelGGL(cast_f32_to_h16_kernel<1>, dim3(sgam_cdiv(n, 256)), dim3(256), 0, s, x, (unsigned short *)y, n));
+    HT_DISPATCH(ht, SGAM_KLAUNCH(cast_f32_to_h16_kernel<0>, dim3(sgam_cdiv(n, 256)), dim3(256), 0, s, x, (unsigned short *)y, n),
+                SGAM_KLAUNCH(cast_f32_to_h16_kernel<1>, dim3(sgam_cdiv(n, 256)), dim3(256), 0, s, x, (unsigned short *)y, n));
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
 }
@@ -543,8 +547,8 @@ extern "C" int sgam_cast_f32_h16(const float *x, void *y, int32_t ht, int64_t n,
 extern "C" int sgam_cast_h16_f32(const void *x, float *y, int32_t ht, int64_t n, void *stream) {
     if (!x || !y || n <= 0) return SGAM_EINVAL;
     hipStream_t s = sgam_stream(stream);
-    HT_DISPATCH(ht, hipLaunchKernelGGL(cast_h16_to_f32_kernel<0>, dim3(sgam_cdiv(n, 256)), dim3(256), 0, s, (const unsigned short *)x, y, n),
-                hipLaunchKernelGGL(cast_h16_to_f32_kernel<1>, dim3(sgam_cdiv(n, 256)), dim3(256), 0, s, (const unsigned short *)x, y, n));
+    HT_DISPATCH(ht, SGAM_KLAUNCH(cast_h16_to_f32_kernel<0>, dim3(sgam_cdiv(n, 256)), dim3(256), 0, s, (const unsigned short *)x, y, n),
+                SGAM_KLAUNCH(cast_h16_to_f32_kernel<1>, dim3(sgam_cdiv(n, 256)), dim3(256), 0, s, (const unsigned short *)x, y, n));
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
 }
@@ -555,7 +559,7 @@ extern "C" int sgam_softmax_rows_h16(const float *s_in, void *p_out, int32_t ht,
         return SGAM_EINVAL;
     hipStream_t s = sgam_stream(stream);
     unsigned short *po = (unsigned short *)p_out;
-#define SM_LAUNCH(HTV, MV) hipLaunchKernelGGL((softmax_rows_h16_kernel<HTV, MV>), dim3(rows), dim3(256), 0, s, s_in, po, cols, lds, ldp, scale)
+#define SM_LAUNCH(HTV, MV) SGAM_KLAUNCH((softmax_rows_h16_kernel<HTV, MV>), dim3(rows), dim3(256), 0, s, s_in, po, cols, lds, ldp, scale)
     if (cols <= 1024) HT_DISPATCH(ht, SM_LAUNCH(0, 1), SM_LAUNCH(1, 1));
     else if (cols <= 4096) HT_DISPATCH(ht, SM_LAUNCH(0, 4), SM_LAUNCH(1, 4));
     else if (cols <= 16384) HT_DISPATCH(ht, SM_LAUNCH(0, 16), SM_LAUNCH(1, 16));
@@ -569,8 +573,8 @@ extern "C" int sgam_encode_head_h16(const float *x, const uint8_t *mask, const f
                                     int32_t B, int32_t HW, int32_t ldy, void *stream) {
     if (!x || !w || !bias || !y || B <= 0 || HW <= 0 || ldy < 4 || ldy % 8 != 0) return SGAM_EINVAL;
     hipStream_t s = sgam_stream(stream);
-    HT_DISPATCH(ht, hipLaunchKernelGGL(encode_head_h16_kernel<0>, dim3(sgam_cdiv(HW, 256), B), dim3(256), 0, s, x, mask, w, bias, (unsigned short *)y, HW, ldy),
-                hipLaunchKernelGGL(encode_head_h16_kernel<1>, dim3(sgam_cdiv(HW, 256), B), dim3(256), 0, s, x, mask, w, bias, (unsigned short *)y, HW, ldy));
+    HT_DISPATCH(ht, SGAM_KLAUNCH(encode_head_h16_kernel<0>, dim3(sgam_cdiv(HW, 256), B), dim3(256), 0, s, x, mask, w, bias, (unsigned short *)y, HW, ldy),
+                SGAM_KLAUNCH(encode_head_h16_kernel<1>, dim3(sgam_cdiv(HW, 256), B), dim3(256), 0, s, x, mask, w, bias, (unsigned short *)y, HW, ldy));
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
 }
@@ -579,8 +583,8 @@ extern "C" int sgam_transpose_h16(const void *x, void *y, int32_t ht, int32_t C,
     if (!x || !y || C <= 0 || HW <= 0 || ldx < C) return SGAM_EINVAL;
     hipStream_t s = sgam_stream(stream);
     const dim3 g(sgam_cdiv(HW, 32), sgam_cdiv(C, 32));
-    HT_DISPATCH(ht, hipLaunchKernelGGL(transpose_h16_kernel<0>, g, dim3(256), 0, s, (const unsigned short *)x, (unsigned short *)y, C, HW, ldx),
-                hipLaunchKernelGGL(transpose_h16_kernel<1>, g, dim3(256), 0, s, (const unsigned short *)x, (unsigned short *)y, C, HW, ldx));
+    HT_DISPATCH(ht, SGAM_KLAUNCH(transpose_h16_kernel<0>, g, dim3(256), 0, s, (const unsigned short *)x, (unsigned short *)y, C, HW, ldx),
+                SGAM_KLAUNCH(transpose_h16_kernel<1>, g, dim3(256), 0, s, (const unsigned short *)x, (unsigned short *)y, C, HW, ldx));
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
 }

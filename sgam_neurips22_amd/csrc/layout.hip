@@ -110,15 +110,90 @@ __global__ __launch_bounds__(256) void frame_feedback_kernel(const float *__rest
     }
 }
 
+// the PNG re-read of prepare_batch_data (inference_pipeline.py:534): uint8 -> lut[u] = float32(u / 127.5 - 1.0)
+__global__ __launch_bounds__(256) void rgb_lut_kernel(const uint8_t *__restrict__ u8, const float *__restrict__ lut,
+                                                      float *__restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = lut[u8[i]];
+}
+
 }  // namespace
 
-extern "C" int sgam_abi_version(void) { return 2; }
+extern "C" int sgam_rgb_u8_to_f32(const uint8_t *rgb_u8, const float *lut256, float *rgb_f, int64_t n, void *stream) {
+    if (!rgb_u8 || !lut256 || !rgb_f || n <= 0) return SGAM_EINVAL;
+    SGAM_KLAUNCH(rgb_lut_kernel, dim3(sgam_cdiv(n, 256)), dim3(256), 0, sgam_stream(stream), rgb_u8, lut256, rgb_f, n);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+// ---- kernel timeline (see SGAM_KLAUNCH in sgam_common.h) ----
+namespace {
+struct ProfRec {
+    const char *kernel, *where;
+    hipEvent_t e0, e1;
+    double flops, bytes;
+};
+constexpr int PROF_MAX = 16384;
+ProfRec *g_prof = nullptr;
+int g_prof_n = 0, g_prof_events = 0;
+double g_work_flops = 0.0, g_work_bytes = 0.0;
+}  // namespace
+extern "C" int sgam_i_prof_on = 0;
+extern "C" void sgam_i_prof_work(double flops, double bytes) {
+    g_work_flops = flops;
+    g_work_bytes = bytes;
+}
+extern "C" void sgam_i_prof_begin(const char *kernel, const char *where, hipStream_t s) {
+    if (!g_prof || g_prof_n >= PROF_MAX) return;
+    ProfRec &r = g_prof[g_prof_n];
+    if (g_prof_n >= g_prof_events) {
+        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+        g_prof_events = g_prof_n + 1;
+    }
+    r.kernel = kernel;
+    r.where = where;
+    r.flops = g_work_flops;
+    r.bytes = g_work_bytes;
+    g_work_flops = g_work_bytes = 0.0;
+    (void)hipEventRecord(r.e0, s);
+}
+extern "C" void sgam_i_prof_end(hipStream_t s) {
+    if (!g_prof || g_prof_n >= PROF_MAX || g_prof_n >= g_prof_events) return;
+    (void)hipEventRecord(g_prof[g_prof_n].e1, s);
+    ++g_prof_n;
+}
+extern "C" int sgam_prof_enable(int32_t on) {
+    if (on && !g_prof) g_prof = new ProfRec[PROF_MAX]();
+    if (on) g_prof_n = 0;
+    sgam_i_prof_on = on ? 1 : 0;
+    return SGAM_OK;
+}
+extern "C" int sgam_prof_mark_empty(void *stream) {   // an event pair around nothing: what a bracket costs by itself
+    if (!sgam_i_prof_on) return SGAM_EINVAL;
+    sgam_i_prof_begin("(empty)", "", sgam_stream(stream));
+    sgam_i_prof_end(sgam_stream(stream));
+    return SGAM_OK;
+}
+extern "C" int32_t sgam_prof_count(void) { return g_prof_n; }
+extern "C" int sgam_prof_get(int32_t i, const char **kernel, const char **where, float *ms, double *flops, double *bytes) {
+    if (i < 0 || i >= g_prof_n || !kernel || !where || !ms || !flops || !bytes) return SGAM_EINVAL;
+    const ProfRec &r = g_prof[i];
+    hipError_t e = hipEventElapsedTime(ms, r.e0, r.e1);
+    if (e != hipSuccess) return (int)e;
+    *kernel = r.kernel;
+    *where = r.where;
+    *flops = r.flops;
+    *bytes = r.bytes;
+    return SGAM_OK;
+}
+
+extern "C" int sgam_abi_version(void) { return 3; }
 extern "C" const char *sgam_build_info(void) { return "libsgam_hip gfx950 (CDNA4): split-fp32 / fp32-in / 16-bit MFMA paths, built " __DATE__; }
 
 extern "C" int sgam_nchw_to_nhwc_f32(const float *x, float *y, int32_t B, int32_t C, int32_t HW, int32_t ldy,
                                      void *stream) {
     if (!x || !y || B <= 0 || C <= 0 || HW <= 0 || ldy < C) return SGAM_EINVAL;
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(sgam_cdiv(HW, 32), sgam_cdiv(C, 32), B), dim3(256), 0,
+    SGAM_KLAUNCH(nchw_to_nhwc_kernel, dim3(sgam_cdiv(HW, 32), sgam_cdiv(C, 32), B), dim3(256), 0,
                        sgam_stream(stream), x, y, C, HW, ldy);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
@@ -127,7 +202,7 @@ extern "C" int sgam_nchw_to_nhwc_f32(const float *x, float *y, int32_t B, int32_
 extern "C" int sgam_nhwc_to_nchw_f32(const float *x, float *y, int32_t B, int32_t C, int32_t HW, int32_t ldx,
                                      void *stream) {
     if (!x || !y || B <= 0 || C <= 0 || HW <= 0 || ldx < C) return SGAM_EINVAL;
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(sgam_cdiv(HW, 32), sgam_cdiv(C, 32), B), dim3(256), 0,
+    SGAM_KLAUNCH(nhwc_to_nchw_kernel, dim3(sgam_cdiv(HW, 32), sgam_cdiv(C, 32), B), dim3(256), 0,
                        sgam_stream(stream), x, y, C, HW, ldx);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
@@ -137,7 +212,7 @@ extern "C" int sgam_encode_head_f32(const float *x, const uint8_t *mask, const f
                                     int32_t B, int32_t HW, int32_t ldy, void *stream) {
     if (!x || !w || !bias || !y || B <= 0 || HW <= 0 || ldy < 4 || ldy % 4 != 0) return SGAM_EINVAL;
     if (!sgam_aligned16(y)) return SGAM_EALIGN;
-    hipLaunchKernelGGL(encode_head_kernel, dim3(sgam_cdiv(HW, 256), B), dim3(256), 0, sgam_stream(stream), x, mask, w,
+    SGAM_KLAUNCH(encode_head_kernel, dim3(sgam_cdiv(HW, 256), B), dim3(256), 0, sgam_stream(stream), x, mask, w,
                        bias, y, HW, ldy);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
@@ -146,7 +221,7 @@ extern "C" int sgam_encode_head_f32(const float *x, const uint8_t *mask, const f
 extern "C" int sgam_frame_feedback_f32(const float *dec, const float *lut256, int32_t dataset_norm, uint8_t *rgb_u8,
                                        float *rgb_f, float *depth, int32_t B, int32_t HW, void *stream) {
     if (!dec || !lut256 || B <= 0 || HW <= 0 || (dataset_norm != 1 && dataset_norm != 2)) return SGAM_EINVAL;
-    hipLaunchKernelGGL(frame_feedback_kernel, dim3(sgam_cdiv(HW, 256), B), dim3(256), 0, sgam_stream(stream), dec,
+    SGAM_KLAUNCH(frame_feedback_kernel, dim3(sgam_cdiv(HW, 256), B), dim3(256), 0, sgam_stream(stream), dec,
                        lut256, dataset_norm, rgb_u8, rgb_f, depth, HW);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;

@@ -72,11 +72,11 @@ extern "C" int sgam_softmax_rows_f32(float *sp, int32_t rows, int32_t cols, int3
     if (!sgam_aligned16(sp)) return SGAM_EALIGN;
     hipStream_t s = sgam_stream(stream);
     if (cols <= 1024) {
-        hipLaunchKernelGGL((softmax_rows_kernel<1>), dim3(rows), dim3(256), 0, s, sp, cols, ld, scale);
+        SGAM_KLAUNCH((softmax_rows_kernel<1>), dim3(rows), dim3(256), 0, s, sp, cols, ld, scale);
     } else if (cols <= 4096) {
-        hipLaunchKernelGGL((softmax_rows_kernel<4>), dim3(rows), dim3(256), 0, s, sp, cols, ld, scale);
+        SGAM_KLAUNCH((softmax_rows_kernel<4>), dim3(rows), dim3(256), 0, s, sp, cols, ld, scale);
     } else if (cols <= 16384) {
-        hipLaunchKernelGGL((softmax_rows_kernel<16>), dim3(rows), dim3(256), 0, s, sp, cols, ld, scale);
+        SGAM_KLAUNCH((softmax_rows_kernel<16>), dim3(rows), dim3(256), 0, s, sp, cols, ld, scale);
     } else {
         return SGAM_EINVAL;
     }

@@ -12,6 +12,22 @@
     } while (0)
 
 static inline hipStream_t sgam_stream(void *s) { return (hipStream_t)s; }
+
+// ---- in-library kernel timeline (sgam_prof_* in include/sgam_hip.h; implemented in layout.hip) ----
+// Every kernel launch of the library goes through SGAM_KLAUNCH.  When profiling is enabled (bench.py's untimed
+// roofline pass, never inside a captured graph) the launch is bracketed by two HIP events recorded on the launch
+// stream, tagged with the kernel's name as written at the launch site (+ the enclosing function's signature, which
+// resolves symbolic template arguments) and the algorithmic work announced through sgam_i_prof_work().
+extern "C" int sgam_i_prof_on;
+extern "C" void sgam_i_prof_begin(const char *kernel, const char *where, hipStream_t s);
+extern "C" void sgam_i_prof_end(hipStream_t s);
+extern "C" void sgam_i_prof_work(double flops, double bytes);
+#define SGAM_KLAUNCH(kern, grid, blk, shm, st, ...)                            \
+    do {                                                                       \
+        if (sgam_i_prof_on) sgam_i_prof_begin(#kern, __PRETTY_FUNCTION__, st); \
+        hipLaunchKernelGGL(kern, grid, blk, shm, st, __VA_ARGS__);             \
+        if (sgam_i_prof_on) sgam_i_prof_end(st);                               \
+    } while (0)
 static inline int sgam_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline bool sgam_aligned16(const void *p) { return (((uintptr_t)p) & 15u) == 0; }
 

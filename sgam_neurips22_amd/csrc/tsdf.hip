@@ -344,11 +344,11 @@ extern "C" int sgam_tsdf_integrate_f32(const sgam_tsdf_grid *grid, const float *
         c2w.m[i] = cam2world[i];
         w2c.m[i] = world2cam[i];
     }
-    hipLaunchKernelGGL(tsdf_touch_kernel, dim3(sgam_cdiv(ns, 256)), dim3(256), 0, s, depth, H, W, fx, fy, cx, cy,
+    SGAM_KLAUNCH(tsdf_touch_kernel, dim3(sgam_cdiv(ns, 256)), dim3(256), 0, s, depth, H, W, fx, fy, cx, cy,
                        c2w, g, depth_trunc, stride, unit_table, unit_stamp, frame_id, counters, max_bricks, brick_list,
                        max_list);
     SGAM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(tsdf_integrate_kernel, dim3(2048), dim3(256), 0, s, depth, H, W, fx, fy, cx, cy, w2c, g,
+    SGAM_KLAUNCH(tsdf_integrate_kernel, dim3(2048), dim3(256), 0, s, depth, H, W, fx, fy, cx, cy, w2c, g,
                        depth_trunc, unit_table, counters, brick_list, max_list, brick_tsdf, brick_weight);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
@@ -363,7 +363,7 @@ extern "C" int sgam_tsdf_raycast_depth_f32(const sgam_tsdf_grid *grid, int32_t H
     const TsdfGrid g = to_dev(grid);
     Pose c2w;
     for (int i = 0; i < 16; ++i) c2w.m[i] = cam2world[i];
-    hipLaunchKernelGGL(tsdf_raycast_kernel, dim3(sgam_cdiv((int64_t)H * W * RS, 256)), dim3(256), 0, sgam_stream(stream), H, W, fx, fy,
+    SGAM_KLAUNCH(tsdf_raycast_kernel, dim3(sgam_cdiv((int64_t)H * W * RS, 256)), dim3(256), 0, sgam_stream(stream), H, W, fx, fy,
                        cx, cy, c2w, g, z_near, z_far, unit_table, brick_tsdf, depth_out);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;

@@ -158,11 +158,60 @@ __global__ __launch_bounds__(256) void vq_topk_kernel(const float *__restrict__ 
     }
 }
 
+// commitment loss (quantize.py:296-301, legacy=True): mean((z_q - z)^2) + beta * mean((z_q - z)^2).  One wavefront per
+// token sums its D squared differences in fp64 (fixed lane order); a single workgroup then folds the T token sums in a
+// fixed order, so the scalar is run-to-run reproducible.
+__global__ __launch_bounds__(256) void vq_commit_partial_kernel(const float *__restrict__ z, const float *__restrict__ codebook,
+                                                                const int64_t *__restrict__ idx, double *__restrict__ partial,
+                                                                int T, int D, int n_e) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    const int lane = threadIdx.x & 63;
+    int64_t j = idx[t];
+    j = j < 0 ? 0 : (j >= n_e ? n_e - 1 : j);
+    double s = 0.0;
+    for (int c = lane; c < D; c += 64) {
+        const float d = __fsub_rn(codebook[j * D + c], z[(int64_t)t * D + c]);
+        s += (double)d * (double)d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) partial[t] = s;
+}
+
+__global__ __launch_bounds__(256) void vq_commit_fold_kernel(const double *__restrict__ partial, float *__restrict__ loss,
+                                                             int T, int D, float beta) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int t = threadIdx.x; t < T; t += 256) s += partial[t];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float m = (float)(red[0] / ((double)T * (double)D));
+        loss[0] = __fadd_rn(m, __fmul_rn(beta, m));
+    }
+}
+
 }  // namespace
+
+extern "C" int sgam_vq_commit_loss_f32(const float *z, const float *codebook, const int64_t *idx, double *partial,
+                                       float *loss, int32_t T, int32_t D, int32_t n_e, float beta, void *stream) {
+    if (!z || !codebook || !idx || !partial || !loss || T <= 0 || D <= 0 || n_e <= 0) return SGAM_EINVAL;
+    SGAM_KLAUNCH(vq_commit_partial_kernel, dim3(sgam_cdiv(T, 4)), dim3(256), 0, sgam_stream(stream), z, codebook, idx,
+                       partial, T, D, n_e);
+    SGAM_LAUNCH_CHECK();
+    SGAM_KLAUNCH(vq_commit_fold_kernel, dim3(1), dim3(256), 0, sgam_stream(stream), partial, loss, T, D, beta);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
 
 extern "C" int sgam_row_sumsq_f32(const float *x, float *out, int32_t rows, int32_t cols, void *stream) {
     if (!x || !out || rows <= 0 || cols <= 0) return SGAM_EINVAL;
-    hipLaunchKernelGGL(row_sumsq_kernel, dim3(sgam_cdiv(rows, 4)), dim3(256), 0, sgam_stream(stream), x, out, rows, cols);
+    SGAM_KLAUNCH(row_sumsq_kernel, dim3(sgam_cdiv(rows, 4)), dim3(256), 0, sgam_stream(stream), x, out, rows, cols);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
 }
@@ -191,7 +240,7 @@ extern "C" int sgam_vq_nearest_f32(const float *z, const float *codebook, const 
     const sgam_conv_desc d = vq_dot_desc(T, D, n_e);
     int rc = sgam_conv2d_nhwc_f32(&d, z, codebook, nullptr, nullptr, dots, workspace, workspace_bytes, stream);
     if (rc != SGAM_OK) return rc;
-    hipLaunchKernelGGL(vq_argmin_kernel, dim3(T), dim3(256), 0, sgam_stream(stream), z, codebook, e_sq, dots, idx_out,
+    SGAM_KLAUNCH(vq_argmin_kernel, dim3(T), dim3(256), 0, sgam_stream(stream), z, codebook, e_sq, dots, idx_out,
                        zq_out, dist_out, D, n_e, straight_through);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
@@ -201,7 +250,7 @@ extern "C" int sgam_vq_gather_f32(const float *codebook, const int64_t *idx, flo
                                   int32_t n_e, void *stream) {
     if (!codebook || !idx || !out || T <= 0 || D <= 0 || D % 4 != 0 || n_e <= 0) return SGAM_EINVAL;
     const int64_t total = (int64_t)T * (D / 4);
-    hipLaunchKernelGGL(vq_gather_kernel, dim3(sgam_cdiv(total, 256)), dim3(256), 0, sgam_stream(stream), codebook, idx,
+    SGAM_KLAUNCH(vq_gather_kernel, dim3(sgam_cdiv(total, 256)), dim3(256), 0, sgam_stream(stream), codebook, idx,
                        out, T, D, n_e);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
@@ -210,7 +259,7 @@ extern "C" int sgam_vq_gather_f32(const float *codebook, const int64_t *idx, flo
 extern "C" int sgam_vq_topk_f32(const float *dist, float *vals, int64_t *inds, int32_t T, int32_t n_e, int32_t k,
                                 void *stream) {
     if (!dist || !vals || !inds || T <= 0 || n_e <= 0 || k <= 0 || k > 64 || k > n_e) return SGAM_EINVAL;
-    hipLaunchKernelGGL(vq_topk_kernel, dim3(T), dim3(256), 0, sgam_stream(stream), dist, vals, inds, n_e, k);
+    SGAM_KLAUNCH(vq_topk_kernel, dim3(T), dim3(256), 0, sgam_stream(stream), dist, vals, inds, n_e, k);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
 }

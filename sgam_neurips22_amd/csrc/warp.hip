@@ -35,6 +35,14 @@ struct Cam {
     float Kinv[9], T[12], Kt[9];
 };
 
+// Sources addressed through a by-value table of device pointers (one per (batch item, source)): the scene loop keeps
+// every generated frame as its own HBM allocation, and the warps read them in place — no stacked copy per step.
+constexpr int SGAM_MAX_SRCS = 16;
+struct SrcTable {
+    const float *feat[SGAM_MAX_SRCS];
+    const float *depth[SGAM_MAX_SRCS];
+};
+
 __device__ __forceinline__ void load_cam(Cam &c, const float *Kinv, const float *T, const float *Kt) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) c.Kinv[i] = Kinv[i];
@@ -70,7 +78,8 @@ __device__ __forceinline__ bool project_pixel(const Cam &c, float X, float Y, fl
     return px >= 0 && px < W && py >= 0 && py < H;
 }
 
-__global__ __launch_bounds__(256) void splat_winner_kernel(const float *__restrict__ src_depths,
+template <bool TAB>
+__global__ __launch_bounds__(256) void splat_winner_kernel(const float *__restrict__ src_depths, SrcTable tab,
                                                            const float *__restrict__ tgt_K,
                                                            const float *__restrict__ src_Kinv, const float *__restrict__ T,
                                                            int N, int H, int W, int *__restrict__ winner,
@@ -86,7 +95,8 @@ __global__ __launch_bounds__(256) void splat_winner_kernel(const float *__restri
     load_cam(c, src_Kinv + 9 * bn, T + 16 * bn, tgt_K + 9 * b);
     const int i = pix / W, j = pix - i * W;
     float X, Y, Z;
-    to_target_cam(c, (float)j, (float)i, src_depths[(int64_t)bn * HW + pix], X, Y, Z);
+    const float sd = TAB ? tab.depth[bn][pix] : src_depths[(int64_t)bn * HW + pix];
+    to_target_cam(c, (float)j, (float)i, sd, X, Y, Z);
     int px = 0, py = 0;
     const bool inb = project_pixel(c, X, Y, Z, H, W, px, py);
     const int p = pix * N + s;  // the reference's linear point index (warp.py:217-218)
@@ -141,8 +151,9 @@ __device__ __forceinline__ float normalise_depth(float md, bool hole, int datase
     return __fadd_rn(__fmul_rn(wd, nm), __fmul_rn(-2.0f, m));
 }
 
+template <bool TAB>
 __global__ __launch_bounds__(TS *TS) void splat_resolve_kernel(
-    const float *__restrict__ src_feats, int64_t feat_cs, int64_t feat_ps, const float *__restrict__ src_depths,
+    const float *__restrict__ src_feats, int64_t feat_cs, int64_t feat_ps, const float *__restrict__ src_depths, SrcTable tab,
     const float *__restrict__ src_Kinv, const float *__restrict__ T, const int *__restrict__ winner, int N, int H, int W,
     float r0, float r1, int use_range, int dataset_norm, float *__restrict__ merge_depths,
     float *__restrict__ merge_feats, uint8_t *__restrict__ extrap, float *__restrict__ x_out,
@@ -160,7 +171,7 @@ __global__ __launch_bounds__(TS *TS) void splat_resolve_kernel(
             if (wv >= 0) {
                 const int pix = wv / N, s = wv - pix * N;
                 const int bn = b * N + s;
-                const float *fp = src_feats + (int64_t)bn * 3 * HW + (int64_t)pix * feat_ps;
+                const float *fp = (TAB ? tab.feat[bn] : src_feats + (int64_t)bn * 3 * HW) + (int64_t)pix * feat_ps;
                 f0 = fp[0];
                 f1 = fp[feat_cs];
                 f2 = fp[2 * feat_cs];
@@ -168,7 +179,7 @@ __global__ __launch_bounds__(TS *TS) void splat_resolve_kernel(
                 load_cam(c, src_Kinv + 9 * bn, T + 16 * bn, src_Kinv);  // Kt unused here
                 const int i = pix / W, j = pix - i * W;
                 float X, Y;
-                to_target_cam(c, (float)j, (float)i, src_depths[(int64_t)bn * HW + pix], X, Y, z);
+                to_target_cam(c, (float)j, (float)i, TAB ? tab.depth[bn][pix] : src_depths[(int64_t)bn * HW + pix], X, Y, z);
             }
         }
         tile[0][hy][hx] = f0;
@@ -225,8 +236,9 @@ __global__ __launch_bounds__(TS *TS) void splat_resolve_kernel(
 // grid_sample(nearest, zeros, align_corners=False) as torch's vectorised CPU kernel evaluates it:
 // ix = (x+1)*(W/2) - 0.5, round-half-even.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void inverse_warp_kernel(const float *__restrict__ src_imgs,
-                                                           const float *__restrict__ src_depths,
+template <bool TAB>
+__global__ __launch_bounds__(256) void inverse_warp_kernel(const float *__restrict__ src_imgs, int64_t img_cs, int64_t img_ps,
+                                                           const float *__restrict__ src_depths, SrcTable tab,
                                                            const float *__restrict__ tgt_depth,
                                                            const float *__restrict__ src_K,
                                                            const float *__restrict__ tgt_Kinv, const float *__restrict__ T,
@@ -263,12 +275,13 @@ __global__ __launch_bounds__(256) void inverse_warp_kernel(const float *__restri
         const float rx = rintf(ix), ry = rintf(iy);
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
         if (rx >= 0.0f && rx <= (float)(W - 1) && ry >= 0.0f && ry <= (float)(H - 1)) {
-            const int64_t o = (int64_t)bn * 3 * HW + (int)ry * W + (int)rx;
-            s0 = __fadd_rn(src_imgs[o], 2.0f);
-            s1 = __fadd_rn(src_imgs[o + HW], 2.0f);
-            s2 = __fadd_rn(src_imgs[o + 2 * (int64_t)HW], 2.0f);
+            const float *ip = (TAB ? tab.feat[bn] : src_imgs + (int64_t)bn * 3 * HW) + (int64_t)((int)ry * W + (int)rx) * img_ps;
+            s0 = __fadd_rn(ip[0], 2.0f);
+            s1 = __fadd_rn(ip[img_cs], 2.0f);
+            s2 = __fadd_rn(ip[2 * img_cs], 2.0f);
         }
-        const float diff = fabsf(__fsub_rn(Z, src_depths[(int64_t)bn * HW + pix]));
+        const float sdep = TAB ? tab.depth[bn][pix] : src_depths[(int64_t)bn * HW + pix];
+        const float diff = fabsf(__fsub_rn(Z, sdep));
         const float sum = __fadd_rn(__fadd_rn(s0, s1), s2);
         const bool mk = (diff < zbuf) && (Z >= 0.0f) && (sum > 0.0f);
         const float fm = mk ? 1.0f : 0.0f, fn = mk ? 0.0f : 1.0f;
@@ -313,10 +326,54 @@ __global__ __launch_bounds__(256) void depth_normalise_kernel(const float *__res
 extern "C" int sgam_depth_normalise_f32(const float *depth, int32_t compute_mask, uint8_t *extrap, float *out,
                                         int32_t dataset_norm, int64_t n, void *stream) {
     if (!depth || !out || n <= 0 || (dataset_norm != 1 && dataset_norm != 2)) return SGAM_EINVAL;
-    hipLaunchKernelGGL(depth_normalise_kernel, dim3(sgam_cdiv(n, 256)), dim3(256), 0, sgam_stream(stream), depth,
+    SGAM_KLAUNCH(depth_normalise_kernel, dim3(sgam_cdiv(n, 256)), dim3(256), 0, sgam_stream(stream), depth,
                        compute_mask, extrap, out, dataset_norm, n);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
+}
+
+static int forward_splat_launch(const float *src_feats, const float *src_depths, const SrcTable *tab, int64_t feat_cs,
+                                int64_t feat_ps, const float *tgt_K, const float *src_Kinv, const float *T, int32_t B,
+                                int32_t N, int32_t H, int32_t W, const float *depth_range, int32_t dataset_norm,
+                                int32_t *winner, float *merge_depths, float *merge_feats, uint8_t *extrap, float *x_out,
+                                float *proj_feats, float *proj_depth, uint8_t *inb_mask, int32_t *pix_xy, void *stream) {
+    if (!tgt_K || !src_Kinv || !T || !winner) return SGAM_EINVAL;
+    if (B <= 0 || N <= 0 || H <= 0 || W <= 0 || (int64_t)H * W * N >= (1ll << 31)) return SGAM_EINVAL;
+    if (x_out && dataset_norm != 1 && dataset_norm != 2) return SGAM_EINVAL;
+    hipStream_t s = sgam_stream(stream);
+    const int HW = H * W;
+    hipError_t e = hipMemsetAsync(winner, 0xFF, (size_t)B * HW * sizeof(int32_t), s);  // -1 = empty
+    if (e != hipSuccess) return (int)e;
+    const dim3 g1(sgam_cdiv((int64_t)HW * N, 256), B), g2(sgam_cdiv(W, TS), sgam_cdiv(H, TS), B);
+    const float r0 = depth_range ? depth_range[0] : 0.f, r1 = depth_range ? depth_range[1] : 0.f;
+    SrcTable none = {};
+    if (tab) {
+        SGAM_KLAUNCH(splat_winner_kernel<true>, g1, dim3(256), 0, s, src_depths, *tab, tgt_K, src_Kinv, T, N, H, W,
+                           winner, inb_mask, pix_xy);
+        SGAM_LAUNCH_CHECK();
+        SGAM_KLAUNCH(splat_resolve_kernel<true>, g2, dim3(TS * TS), 0, s, src_feats, feat_cs, feat_ps, src_depths, *tab,
+                           src_Kinv, T, winner, N, H, W, r0, r1, depth_range ? 1 : 0, dataset_norm, merge_depths, merge_feats,
+                           extrap, x_out, proj_feats, proj_depth);
+    } else {
+        SGAM_KLAUNCH(splat_winner_kernel<false>, g1, dim3(256), 0, s, src_depths, none, tgt_K, src_Kinv, T, N, H, W,
+                           winner, inb_mask, pix_xy);
+        SGAM_LAUNCH_CHECK();
+        SGAM_KLAUNCH(splat_resolve_kernel<false>, g2, dim3(TS * TS), 0, s, src_feats, feat_cs, feat_ps, src_depths, none,
+                           src_Kinv, T, winner, N, H, W, r0, r1, depth_range ? 1 : 0, dataset_norm, merge_depths, merge_feats,
+                           extrap, x_out, proj_feats, proj_depth);
+    }
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+static bool fill_table(SrcTable &tab, const float *const *feat_ptrs, const float *const *depth_ptrs, int n) {
+    if (!feat_ptrs || !depth_ptrs || n <= 0 || n > SGAM_MAX_SRCS) return false;
+    for (int i = 0; i < SGAM_MAX_SRCS; ++i) {
+        tab.feat[i] = i < n ? feat_ptrs[i] : nullptr;
+        tab.depth[i] = i < n ? depth_ptrs[i] : nullptr;
+        if (i < n && (!tab.feat[i] || !tab.depth[i])) return false;
+    }
+    return true;
 }
 
 extern "C" int sgam_forward_splat_f32(const float *src_feats, int64_t feat_cs, int64_t feat_ps, const float *src_depths,
@@ -325,22 +382,24 @@ extern "C" int sgam_forward_splat_f32(const float *src_feats, int64_t feat_cs, i
                                       int32_t *winner, float *merge_depths, float *merge_feats, uint8_t *extrap,
                                       float *x_out, float *proj_feats, float *proj_depth, uint8_t *inb_mask,
                                       int32_t *pix_xy, void *stream) {
-    if (!src_feats || !src_depths || !tgt_K || !src_Kinv || !T || !winner) return SGAM_EINVAL;
-    if (B <= 0 || N <= 0 || H <= 0 || W <= 0 || (int64_t)H * W * N >= (1ll << 31)) return SGAM_EINVAL;
-    if (x_out && dataset_norm != 1 && dataset_norm != 2) return SGAM_EINVAL;
-    hipStream_t s = sgam_stream(stream);
-    const int HW = H * W;
-    hipError_t e = hipMemsetAsync(winner, 0xFF, (size_t)B * HW * sizeof(int32_t), s);  // -1 = empty
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(splat_winner_kernel, dim3(sgam_cdiv((int64_t)HW * N, 256), B), dim3(256), 0, s, src_depths, tgt_K,
-                       src_Kinv, T, N, H, W, winner, inb_mask, pix_xy);
-    SGAM_LAUNCH_CHECK();
-    const float r0 = depth_range ? depth_range[0] : 0.f, r1 = depth_range ? depth_range[1] : 0.f;
-    hipLaunchKernelGGL(splat_resolve_kernel, dim3(sgam_cdiv(W, TS), sgam_cdiv(H, TS), B), dim3(TS * TS), 0, s, src_feats,
-                       feat_cs, feat_ps, src_depths, src_Kinv, T, winner, N, H, W, r0, r1, depth_range ? 1 : 0,
-                       dataset_norm, merge_depths, merge_feats, extrap, x_out, proj_feats, proj_depth);
-    SGAM_LAUNCH_CHECK();
-    return SGAM_OK;
+    if (!src_feats || !src_depths) return SGAM_EINVAL;
+    return forward_splat_launch(src_feats, src_depths, nullptr, feat_cs, feat_ps, tgt_K, src_Kinv, T, B, N, H, W, depth_range,
+                                dataset_norm, winner, merge_depths, merge_feats, extrap, x_out, proj_feats, proj_depth,
+                                inb_mask, pix_xy, stream);
+}
+
+extern "C" int sgam_forward_splat_srcs_f32(const float *const *src_feat_ptrs, const float *const *src_depth_ptrs,
+                                           int64_t feat_cs, int64_t feat_ps, const float *tgt_K, const float *src_Kinv,
+                                           const float *T, int32_t B, int32_t N, int32_t H, int32_t W,
+                                           const float *depth_range, int32_t dataset_norm, int32_t *winner,
+                                           float *merge_depths, float *merge_feats, uint8_t *extrap, float *x_out,
+                                           float *proj_feats, float *proj_depth, uint8_t *inb_mask, int32_t *pix_xy,
+                                           void *stream) {
+    SrcTable tab;
+    if (B <= 0 || N <= 0 || !fill_table(tab, src_feat_ptrs, src_depth_ptrs, B * N)) return SGAM_EINVAL;
+    return forward_splat_launch(nullptr, nullptr, &tab, feat_cs, feat_ps, tgt_K, src_Kinv, T, B, N, H, W, depth_range,
+                                dataset_norm, winner, merge_depths, merge_feats, extrap, x_out, proj_feats, proj_depth,
+                                inb_mask, pix_xy, stream);
 }
 
 extern "C" int sgam_inverse_warp_f32(const float *src_imgs, const float *src_depths, const float *tgt_depth,
@@ -348,8 +407,23 @@ extern "C" int sgam_inverse_warp_f32(const float *src_imgs, const float *src_dep
                                      int32_t N, int32_t H, int32_t W, float *warped, float *zbuf, void *stream) {
     if (!src_imgs || !src_depths || !tgt_depth || !src_K || !tgt_Kinv || !T_tgt2src || !warped) return SGAM_EINVAL;
     if (B <= 0 || N <= 0 || H <= 1 || W <= 1) return SGAM_EINVAL;
-    hipLaunchKernelGGL(inverse_warp_kernel, dim3(sgam_cdiv((int64_t)H * W, 256), B), dim3(256), 0, sgam_stream(stream),
-                       src_imgs, src_depths, tgt_depth, src_K, tgt_Kinv, T_tgt2src, N, H, W, warped, zbuf);
+    SrcTable none = {};
+    SGAM_KLAUNCH(inverse_warp_kernel<false>, dim3(sgam_cdiv((int64_t)H * W, 256), B), dim3(256), 0, sgam_stream(stream),
+                       src_imgs, (int64_t)H * W, (int64_t)1, src_depths, none, tgt_depth, src_K, tgt_Kinv, T_tgt2src, N, H, W,
+                       warped, zbuf);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+extern "C" int sgam_inverse_warp_srcs_f32(const float *const *src_img_ptrs, const float *const *src_depth_ptrs, int64_t img_cs,
+                                          int64_t img_ps, const float *tgt_depth, const float *src_K, const float *tgt_Kinv,
+                                          const float *T_tgt2src, int32_t B, int32_t N, int32_t H, int32_t W, float *warped,
+                                          float *zbuf, void *stream) {
+    SrcTable tab;
+    if (B <= 0 || N <= 0 || !fill_table(tab, src_img_ptrs, src_depth_ptrs, B * N)) return SGAM_EINVAL;
+    if (!tgt_depth || !src_K || !tgt_Kinv || !T_tgt2src || !warped || H <= 1 || W <= 1) return SGAM_EINVAL;
+    SGAM_KLAUNCH(inverse_warp_kernel<true>, dim3(sgam_cdiv((int64_t)H * W, 256), B), dim3(256), 0, sgam_stream(stream),
+                       nullptr, img_cs, img_ps, nullptr, tab, tgt_depth, src_K, tgt_Kinv, T_tgt2src, N, H, W, warped, zbuf);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
 }

@@ -98,12 +98,17 @@ class VQModel(nn.Module):
         return self
 
     def _forward_graphed(self, input, topk, extrapolation_mask, sample_number, flags):
+        # inputs that live in persistent buffers of the caller (the scene loop's warp outputs, marked `_sgam_persistent`)
+        # are captured by address: the graph reads them in place and no copy is paid per replay
+        inplace = getattr(input, "_sgam_persistent", False) and (
+            extrapolation_mask is None or getattr(extrapolation_mask, "_sgam_persistent", False))
         key = (tuple(input.shape), None if extrapolation_mask is None else tuple(extrapolation_mask.shape), topk,
-               sample_number, flags, self.compute_dtype, str(input.device))
+               sample_number, flags, self.compute_dtype, str(input.device),
+               (input.data_ptr(), None if extrapolation_mask is None else extrapolation_mask.data_ptr()) if inplace else None)
         ent = self._graphs.get(key)
         if ent is None:
-            sx = input.detach().clone()
-            sm = None if extrapolation_mask is None else extrapolation_mask.detach().clone()
+            sx = input if inplace else input.detach().clone()
+            sm = None if extrapolation_mask is None else (extrapolation_mask if inplace else extrapolation_mask.detach().clone())
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):          # eager warm-up: weight packing, codebook norms, allocator pools
@@ -115,9 +120,10 @@ class VQModel(nn.Module):
                 out = self._forward_eager(sx, topk, sm, sample_number, *flags)
             ent = self._graphs[key] = (graph, sx, sm, out)
         graph, sx, sm, out = ent
-        sx.copy_(input)
-        if sm is not None:
-            sm.copy_(extrapolation_mask)
+        if not inplace:
+            sx.copy_(input)
+            if sm is not None:
+                sm.copy_(extrapolation_mask)
         graph.replay()
         return out
 
@@ -148,9 +154,10 @@ class VQModel(nn.Module):
                 B, h, w, D = pre.shape
                 idx = encoding_indices.reshape(B, h, w)
                 zq = ops.vq_gather(self.quantize._codebook()[0], idx).view(B, h, w, D)
-            return ops.nhwc_to_nchw(zq), None, (None, None, idx), ops.nhwc_to_nchw(pre)
+            return ops.nhwc_to_nchw(zq), self.quantize.commit_loss_nhwc(pre, idx), (None, None, idx), ops.nhwc_to_nchw(pre)
         zqs, idx = self.quantize.sample_nhwc(pre, topk, sample_number, extrapolation_mask)
-        quants = torch.stack([ops.nhwc_to_nchw(zqs[:, i]) for i in range(zqs.shape[1])], 1)
+        # zqs is (B,S,h,w,D): a sample's slice has batch stride S*h*w*D — the kernels take dense NHWC only
+        quants = torch.stack([ops.nhwc_to_nchw(zqs[:, i].contiguous()) for i in range(zqs.shape[1])], 1)
         return quants, None, (None, None, idx), ops.nhwc_to_nchw(pre)
 
     def decode(self, quant):
@@ -171,15 +178,18 @@ class VQModel(nn.Module):
             dec = ops.nhwc_to_nchw(self._decode_nhwc(pre))
             return dec, torch.tensor(0).to(dec.device), ops.nhwc_to_nchw(pre)
         want_q = get_quantized_feature
+        diff = None
         if topk is None:
             zq, idx, _ = self.quantize.quantize_nhwc(pre)
+            diff = self.quantize.commit_loss_nhwc(pre, idx)          # emb_loss (model.py:144-147, quantize.py:296-301)
             decs = ops.nhwc_to_nchw(self._decode_nhwc(zq))
             quants = ops.nhwc_to_nchw(zq) if want_q else None
         else:
             zqs, idx = self.quantize.sample_nhwc(pre, topk, sample_number, extrapolation_mask)
-            decs = [ops.nhwc_to_nchw(self._decode_nhwc(zqs[:, i]))[None] for i in range(sample_number)]
-            quants = torch.stack([ops.nhwc_to_nchw(zqs[:, i]) for i in range(sample_number)], 1) if want_q else None
-        res = [decs, None]
+            zs = [zqs[:, i].contiguous() for i in range(sample_number)]   # dense NHWC per sample (batch stride!)
+            decs = [ops.nhwc_to_nchw(self._decode_nhwc(z))[None] for z in zs]
+            quants = torch.stack([ops.nhwc_to_nchw(z) for z in zs], 1) if want_q else None
+        res = [decs, diff]
         if get_codebook_count:
             res.append(idx)
         if get_pre_quantized_feature:
@@ -209,10 +219,19 @@ class VQModel(nn.Module):
             raise NotImplementedError
         if 'warped_tgt_features' in batch:
             x_rgb = batch['warped_tgt_features']
-            wd, extrapolation_mask = ops.depth_normalise(batch['warped_tgt_depth'][:, None], dataset, compute_mask=True,
-                                                         mask_bool=True)
-            x = torch.cat([x_rgb, wd], 1)
-            warped_depth = wd
+            wo = batch.get("_warp_out") if hasattr(batch, "get") else None
+            if wo is not None and x_rgb.shape[0] == 1 and x_rgb.data_ptr() == wo["x"].data_ptr():
+                # the scene loop warped straight into its persistent model input: the normalised depth and the mask
+                # complete it in place (no cat, no copy)
+                x = wo["x"]
+                warped_depth, extrapolation_mask = ops.depth_normalise(
+                    batch['warped_tgt_depth'][:, None], dataset, compute_mask=True, mask_bool=True, out=x[:, 3:4],
+                    out_mask=wo["extrap"])
+            else:
+                wd, extrapolation_mask = ops.depth_normalise(batch['warped_tgt_depth'][:, None], dataset,
+                                                             compute_mask=True, mask_bool=True)
+                x = torch.cat([x_rgb, wd], 1)
+                warped_depth = wd
         else:
             x, extrapolation_mask, warped_depth = splat_to_model_input(
                 batch, dataset, depth_range=None if no_depth_range else self.depth_range)

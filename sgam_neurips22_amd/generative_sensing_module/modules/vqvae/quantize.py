@@ -4,8 +4,11 @@
 forward                : L2 nearest codeword (MFMA z.e^T + exact-order distance/arg-min kernel), embedding
                          gather, straight-through value z + (z_q - z)            (reference :275-319)
 get_multiple_codewords : top-k infill sampler (reference :344-381) — distances / top-k on the GPU, the
-                         softmax + multinomial draws on the host CPU RNG stream exactly like the reference
-                         (it samples every token from row 0's distribution, :358 — preserved).
+                         softmax + multinomial draws on the host CPU generator: draw for draw what the reference's
+                         CPU path does (the parity target of this backend; pinned by tests/golden/vqgan_topk4_s2.npz),
+                         including its quirk of sampling every token from row 0's distribution (:358).  A reference
+                         run with the model on a CUDA device draws from the device generator instead, so against
+                         such a run the parity is statistical only.
 """
 import numpy as np
 import torch
@@ -51,6 +54,11 @@ class VectorQuantizer2(nn.Module):
                                        want_dist=want_dist)
         return zq.view(B, h, w, D), idx.view(B, h, w), dist
 
+    def commit_loss_nhwc(self, z_nhwc, idx):
+        """the `loss` of reference forward (:296-301, legacy): mean((z_q-z)^2) + beta*mean((z_q-z)^2), 0-d fp32 tensor"""
+        D = z_nhwc.shape[-1]
+        return ops.vq_commit_loss(z_nhwc.reshape(-1, D), self._codebook()[0], idx, self.beta)
+
     def forward(self, z, temp=None, rescale_logits=False, return_logits=False, encoding_indices=None, valid_mask=None):
         assert temp is None or temp == 1.0, "Only for interface compatible with Gumbel"
         assert rescale_logits is False, "Only for interface compatible with Gumbel"
@@ -62,7 +70,7 @@ class VectorQuantizer2(nn.Module):
             B, h, w, D = zn.shape
             idx = encoding_indices.reshape(B, h, w)
             zq = ops.vq_gather(self._codebook()[0], idx).view(B, h, w, D)
-        loss = None  # commitment loss is a training quantity (reference :296-301); not computed at inference
+        loss = self.commit_loss_nhwc(zn, idx)
         if self.sane_index_shape:
             idx = idx.reshape(zq.shape[0], zq.shape[1], zq.shape[2])
         return ops.nhwc_to_nchw(zq), loss, (None, None, idx)
@@ -120,5 +128,5 @@ class VectorQuantizer2(nn.Module):
                                temp=1):
         zqs, idx = self.sample_nhwc(ops.nchw_to_nhwc(z), topk, sample_number, extrapolation_mask)
         S = zqs.shape[1]
-        out = torch.stack([ops.nhwc_to_nchw(zqs[:, i]) for i in range(S)], 1)  # (1,S,D,h,w)
+        out = torch.stack([ops.nhwc_to_nchw(zqs[:, i].contiguous()) for i in range(S)], 1)  # (B,S,D,h,w)
         return out, None, (None, None, idx)

@@ -89,10 +89,35 @@ def load_template_seed(data, seed_index, image_resolution, templates_root="templ
     rgb = np.array(Image.open(img_fn).convert("RGB").resize((image_resolution[1], image_resolution[0]),
                                                             resample=Image.LANCZOS))
     depth = np.load(dm_fn)
-    if data == "clevr-infinite":  # the reference rewrites the template depth at construction (:71-79)
+    if data == "clevr-infinite":  # the reference rewrites the template depth at construction (:71-79), in float64
         depth = ray_to_z_depth(depth, intrinsics(data))
     depth = F.interpolate(torch.from_numpy(depth[None, None]), size=image_resolution)[0][0].numpy().squeeze()
-    return rgb, depth.astype(np.float32)
+    # CLEVR: stays float64 — the reference keeps the seed depth in float64 through BOTH ray->z conversions (the .npy it
+    # rewrites at construction, :79, and the per-load re-conversion, :582-590) and rounds to fp32 once (:607)
+    return rgb, (depth if data == "clevr-infinite" else depth.astype(np.float32))
+
+
+class _Lazy(dict):
+    """dict whose listed keys are built on first access: the reference's batch / result dictionaries carry stacked
+    copies of the source frames (`src_imgs`, `src_depths`, ...) that the device path itself never reads — they are
+    materialised only for a caller that asks for them"""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self._makers = {}
+
+    def lazy(self, key, fn):
+        self._makers[key] = fn
+        return self
+
+    def __missing__(self, key):
+        if key in self._makers:
+            self[key] = v = self._makers.pop(key)()
+            return v
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._makers
 
 
 class InfiniteSceneGeneration:
@@ -134,6 +159,7 @@ class InfiniteSceneGeneration:
         self._K_dev = K32.to(self.device)
         self._Kinv_dev = torch.inverse(K32).to(self.device)
         self._Kinv_n = {}        # n sources -> (n,3,3) contiguous copy of the inverse intrinsics
+        self._K_n = {}           # n sources -> (n,3,3) contiguous copy of the intrinsics
         # pinned staging ring for the per-step pose upload (see _upload)
         self._stage = [torch.empty(256, dtype=torch.float32).pin_memory() for _ in range(8)] \
             if self.device.type == "cuda" else None
@@ -144,6 +170,13 @@ class InfiniteSceneGeneration:
         self._dst_img = torch.zeros((1, H, W, 3), device=self.device)
         self._dst_depth = torch.zeros((1, H, W), device=self.device)
         self._x_dst = None       # get_x's x_dst of that constant target, kept after the first step
+        # persistent outputs of the conditioning warp = the model's graph inputs (captured by address: no copy per step)
+        self._warp_out = {"x": torch.empty((1, 4, H, W), device=self.device),
+                          "extrap": torch.empty((1, 1, H, W), device=self.device, dtype=torch.bool),
+                          "winner": torch.empty((1, H * W), device=self.device, dtype=torch.int32)} \
+            if self.device.type == "cuda" else None
+        if self._warp_out is not None:
+            self._warp_out["x"]._sgam_persistent = self._warp_out["extrap"]._sgam_persistent = True
 
     # ---------------------------------------------------------------- TSDF fusion (reference :119-133, 745-838)
     # view-space z range of valid depths per dataset: the inverse-depth codec's bounds (model.py:210-229)
@@ -168,7 +201,9 @@ class InfiniteSceneGeneration:
         for s in src_nodes:
             T = np.eye(4)
             T[:3, :3], T[:3, 3] = s["R"], s["t"]
-            self.volume.integrate(self._src_depth(s["grid_coord"]), self.K, T)
+            # the reference fuses the depth as loaded (:570-574) — for the CLEVR seed that is the ONCE-converted map;
+            # its second ray->z conversion (:582-590) only touches batch['src_depths'], after the fusion
+            self.volume.integrate(self.frames[s["grid_coord"]]["depth"], self.K, T)
         T = np.eye(4)
         T[:3, :3], T[:3, 3] = tgt_node["R"], tgt_node["t"]
         H, W = self.image_resolution
@@ -225,22 +260,22 @@ class InfiniteSceneGeneration:
     def _store_seed(self, seed_frame):
         rgb_u8, depth = seed_frame
         u8 = torch.from_numpy(np.ascontiguousarray(rgb_u8)).to(self.device)
-        self.frames[(0, 0)] = {
-            "rgb_u8": u8, "rgb_f": ops.rgb_lut(self.device)[u8.long()],  # table lookup = the PNG re-read
-            "depth": torch.from_numpy(np.ascontiguousarray(depth, dtype=np.float32)).to(self.device),
-            "index": 0,
-        }
+        fr = {"rgb_u8": u8, "rgb_f": ops.rgb_u8_to_f32(u8),  # table lookup = the PNG re-read
+              "depth": torch.from_numpy(np.ascontiguousarray(depth, dtype=np.float32)).to(self.device), "index": 0}
+        if self.data == "clevr-infinite":
+            # the reference converts the seed's ray depth to z AGAIN on every load (:582-590), still in float64 (the
+            # once-converted map was saved as float64, :79) and rounds to fp32 only at :607.  Both fp32 maps are derived
+            # from the float64 once-converted depth: `depth` feeds rgbd_integration / inverse_warping (:570-580),
+            # `depth_reconv` the forward splat (batch['src_depths']).
+            d64 = np.asarray(depth, dtype=np.float64)
+            fr["depth_reconv"] = torch.from_numpy(ray_to_z_depth(d64, self.K).astype(np.float32)).to(self.device)
+        self.frames[(0, 0)] = fr
         self.transform_grid[0][0]["visited"] = True
 
     def _src_depth(self, coord):
+        """the depth map prepare_batch_data puts into batch['src_depths'] (the forward splat's source depth)"""
         fr = self.frames[coord]
-        if fr["index"] == 0 and self.data == "clevr-infinite":
-            # the reference converts the seed depth AGAIN on every load (:582-590); float64 host math
-            if "depth_reconv" not in fr:
-                d = ray_to_z_depth(fr["depth"].cpu().numpy(), self.K)
-                fr["depth_reconv"] = torch.from_numpy(d.astype(np.float32)).to(self.device)
-            return fr["depth_reconv"]
-        return fr["depth"]
+        return fr.get("depth_reconv", fr["depth"])
 
     # ---------------------------------------------------------------- batch assembly
     def relative_poses(self, tgt_node, src_nodes):
@@ -281,35 +316,40 @@ class InfiniteSceneGeneration:
         return outs
 
     def prepare_batch_data(self, tgt_node, src_nodes, num_src):
-        dev = self.device
         coords = [s["grid_coord"] for s in src_nodes]
         n = len(coords)
-        H, W = self.image_resolution
         R_rels, t_rels, T_tgt2srcs = self.relative_poses(tgt_node, src_nodes)
-        src_imgs = torch.stack([self.frames[c]["rgb_f"] for c in coords])[None]          # (1,N,H,W,3)
-        src_depths = torch.stack([self._src_depth(c) for c in coords])[None]              # (1,N,H,W)
+        # the sources stay where the frame store holds them: the warps read them through a pointer table
+        feats = [self.frames[c]["rgb_f"] for c in coords]                                  # N x (H,W,3)
+        depths = [self._src_depth(c) for c in coords]                                      # N x (H,W)
         # T_src2tgt = [R | t; 0 0 0 1] (model.py:190-194): the same fp32 values the device-side assembly would hold
         T = np.zeros((n, 4, 4), dtype=np.float32)
         T[:, :3, :3], T[:, :3, 3], T[:, 3, 3] = R_rels, t_rels, 1.0
         T_dev, T_t2s_dev, R_dev, t_dev = self._upload(T, T_tgt2srcs, R_rels, t_rels)
         if n not in self._Kinv_n:
             self._Kinv_n[n] = self._Kinv_dev.expand(n, 3, 3).contiguous()
-        batch = {
+        batch = _Lazy({
             "Ks": self._K_dev.expand(1, n, 3, 3),
             "_src_Kinv": self._Kinv_n[n], "_T_src2tgt": T_dev,
             "R_rels": R_dev[None], "t_rels": t_dev[None],
             "dst_img": self._dst_img, "dst_depth": self._dst_depth,
-            "src_imgs": src_imgs, "src_depths": src_depths,
-        }
+            "_src_list": (feats, depths), "_warp_out": self._warp_out,
+        })
+        batch.lazy("src_imgs", lambda: torch.stack(feats)[None])                           # (1,N,H,W,3)
+        batch.lazy("src_depths", lambda: torch.stack(depths)[None])                        # (1,N,H,W)
         if self.use_rgbd_integration:
             if self.tgt_depth_provider is not None:
                 tgt_depth = self.tgt_depth_provider(self, tgt_node, src_nodes, batch)      # (H,W) device fp32
             else:
                 tgt_depth = self.rgbd_integration(src_nodes, tgt_node)
-            warped = self.inverse_warping(src_imgs.permute(0, 1, 4, 2, 3).contiguous(), src_depths, tgt_depth[None],
-                                          batch["Ks"], self._K_dev[None], T_t2s_dev[None], as_numpy=False,
-                                          tgt_Kinv=self._Kinv_dev[None])
-            batch["warped_tgt_features"] = warped[None]
+            # inverse_warping sees the depths as loaded (:575-580) — for the CLEVR seed the once-converted map
+            if n not in self._K_n:
+                self._K_n[n] = self._K_dev.expand(n, 3, 3).contiguous()
+            # written straight into the rgb planes of the persistent model input (B = 1: a contiguous view)
+            dst = self._warp_out["x"][:, :3] if self._warp_out is not None else None
+            warped = ops.inverse_warp_srcs(feats, [self.frames[c]["depth"] for c in coords], tgt_depth[None],
+                                           self._K_n[n], self._Kinv_dev[None], T_t2s_dev, out=dst)
+            batch["warped_tgt_features"] = warped
             batch["warped_tgt_depth"] = tgt_depth[None]
         return batch
 
@@ -334,7 +374,8 @@ class InfiniteSceneGeneration:
         tgt_meta = self.transform_grid[tgt_pose_grid_coord[0]][tgt_pose_grid_coord[1]]
         src_metas = [self.transform_grid[c[0]][c[1]] for c in src_coords]
         batch = self.prepare_batch_data(tgt_meta, src_metas, self.num_src)
-        batch['src_depths'] = batch['src_depths'][..., None]
+        depths = batch["_src_list"][1]
+        batch.lazy("src_depths", lambda: torch.stack(depths)[None][..., None])             # (1,N,H,W,1) like :868
         if self._x_dst is not None:
             batch["_x_dst"] = self._x_dst
         x, x_dst, extrapolation_mask, warped_depth = self.dynamic_model.get_x(
@@ -347,13 +388,15 @@ class InfiniteSceneGeneration:
         rgb_f, depth, rgb_u8 = ops.frame_feedback(x_sample_det, self.data, want_u8=True)
         if save_res_to_disk:  # name kept from the reference; here "disk" is the in-HBM frame store
             self.save_to_store(tgt_pose_grid_coord, rgb_u8[0], rgb_f[0], depth[0])
-        return {
+        res = _Lazy({
             "rgbd": x_sample_dets[0].squeeze().detach(), "feature": quant.squeeze().detach(),
             "pre_quantized_features": pre_q.squeeze().detach(), "fixed": False, "x": x.detach(),
-            "batch_src_imgs": batch['src_imgs'], "batch_src_depths": batch['src_depths'],
             "batch_R_rels": batch['R_rels'], "batch_t_rels": batch['t_rels'], "warped_depth": warped_depth,
             "extrapolation_mask": extrapolation_mask, "src_coords": src_coords,
-        }
+        })
+        res.lazy("batch_src_imgs", lambda: batch['src_imgs'])          # stacked copies only if the caller reads them
+        res.lazy("batch_src_depths", lambda: batch['src_depths'])
+        return res
 
     def save_to_store(self, coord, rgb_u8, rgb_f, depth):
         self.frames[coord] = {"rgb_u8": rgb_u8, "rgb_f": rgb_f, "depth": depth, "index": self.curr}

@@ -39,6 +39,16 @@ def _f32c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _dense_nhwc(x, what):
+    """(B,H,W,C) with free channel pitch but dense pixel / row / image pitches — the only layout the kernels address"""
+    B, H, W, _ = x.shape
+    ld = x.stride(2)
+    if x.stride(3) != 1 or (W > 1 and ld < x.shape[3]) or (H > 1 and x.stride(1) != W * ld) or \
+            (B > 1 and x.stride(0) != H * W * ld):
+        raise SgamHipError(f"{what}: NHWC tensor with strides {tuple(x.stride())} is not pixel-dense "
+                           "(call .contiguous() on slices taken along a leading axis)")
+
+
 def round_up(v, m):
     return (v + m - 1) // m * m
 
@@ -127,6 +137,53 @@ def cast(x, dtype):
     else:
         raise SgamHipError(f"cast {x.dtype} -> {dtype} not supported")
     return y
+
+
+# ------------------------------------------------------------------------------------------------
+# kernel timeline (measurement only)
+# ------------------------------------------------------------------------------------------------
+def _kernel_name(kernel, where):
+    """launch-site spelling -> `name<args>` with symbolic template arguments resolved from the enclosing function"""
+    import re
+    name = kernel.strip().strip("()").replace(" ", "")
+    m = re.search(r"\[([^\]]*)\]\s*$", where or "")
+    if m and "<" in name:
+        sub = dict(kv.split(" = ") for kv in m.group(1).split(", ") if " = " in kv)
+        head, args = name.split("<", 1)
+        args = [sub.get(a, a) for a in args.rstrip(">").split(",")]
+        name = f"{head}<{','.join(args)}>"
+    return name
+
+
+def kernel_timeline(fn, empty_brackets=32):
+    """Run fn() with the library's per-kernel HIP-event brackets on (include/sgam_hip.h, sgam_prof_*): returns
+    (records, bracket_ms) — records = [(kernel name, ms, flops, bytes)] in launch order, elapsed times as measured (the
+    caller subtracts bracket_ms, the median cost of a bracket around nothing).  Eager launches only (no graph replay)."""
+    lib = _lib.load()
+    torch.cuda.synchronize()
+    check(lib.sgam_prof_enable(1), "sgam_prof_enable")
+    try:
+        # park the GPU behind a spin so that the host enqueues everything ahead of it: launches then run back to back
+        # and a bracket is the kernel's duration, not the host's launch gap
+        torch.cuda._sleep(int(1.0e8))
+        fn()
+        for _ in range(empty_brackets):
+            lib.sgam_prof_mark_empty(_stream())
+        torch.cuda.synchronize()
+    finally:
+        lib.sgam_prof_enable(0)
+    recs, empties = [], []
+    k, w = ctypes.c_char_p(), ctypes.c_char_p()
+    ms, fl, by = ctypes.c_float(), ctypes.c_double(), ctypes.c_double()
+    for i in range(lib.sgam_prof_count()):
+        check(lib.sgam_prof_get(i, ctypes.byref(k), ctypes.byref(w), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)),
+              "sgam_prof_get")
+        if k.value == b"(empty)":
+            empties.append(ms.value)
+        else:
+            recs.append((_kernel_name(k.value.decode(), (w.value or b"").decode()), ms.value, fl.value, by.value))
+    empties.sort()
+    return recs, (empties[len(empties) // 2] if empties else 0.0)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -299,6 +356,7 @@ def conv2d_nhwc(x, w_packed, bias, *, cout, kh, kw, stride=1, pad_t=0, pad_l=0, 
     """x (B,Hi,Wi,Cx) NHWC fp32 -> (B,Ho,Wo,cout).  w_packed from pack_conv_weight (rows padded to 64,
     Cin padded to 32).  `cin` = channels of x actually contracted (defaults to Cx, must be % 32)."""
     _need_cuda(x, w_packed)
+    _dense_nhwc(x, "conv2d_nhwc")
     B, Hi, Wi, Cx = x.shape
     cin = cin or Cx
     pad_b = pad_t if pad_b is None else pad_b
@@ -491,6 +549,7 @@ def nchw_to_nhwc(x, c_pad=None):
 
 def nhwc_to_nchw(x, c=None):
     _need_cuda(x)
+    _dense_nhwc(x, "nhwc_to_nchw")
     B, H, W, ld = x.shape
     c = c or ld
     y = torch.empty((B, c, H, W), device=x.device, dtype=torch.float32)
@@ -508,7 +567,10 @@ def encode_head(x_nchw, mask, w, bias, ld=32, dtype=torch.float32):
     m = None
     if mask is not None:
         m = mask.reshape(B, H * W)
-        m = (m != 0).to(torch.uint8).contiguous()
+        if m.dtype == torch.bool and m.is_contiguous():
+            m = m.view(torch.uint8)          # same 0/1 bytes: no conversion kernel inside the step
+        else:
+            m = (m != 0).to(torch.uint8).contiguous()
     y = torch.empty((B, H, W, ld), device=x.device, dtype=dtype)
     wf, bf = _f32c(w.detach().reshape(4, 5)), _f32c(bias.detach())
     if dtype == torch.float32:
@@ -549,6 +611,19 @@ def vq_nearest(z_tokens, codebook, e_sq, straight_through=True, want_dist=False,
     check(lib.sgam_vq_nearest_f32(_p(z), _p(codebook), _p(e_sq), _p(dots), _p(idx), _p(zq), _p(dist), T, D, n_e,
                                   int(straight_through), _p(ws), ws_bytes, _stream()), "sgam_vq_nearest_f32")
     return idx, zq, dist
+
+
+def vq_commit_loss(z_tokens, codebook, idx, beta):
+    """scalar commitment loss mean((e[idx]-z)^2) + beta*mean((e[idx]-z)^2) (quantize.py:296-301) as a 0-d tensor"""
+    _need_cuda(z_tokens, codebook, idx)
+    z = _f32c(z_tokens)
+    T, D = z.shape
+    partial = torch.empty((T,), device=z.device, dtype=torch.float64)
+    loss = torch.empty((1,), device=z.device, dtype=torch.float32)
+    idx = idx.reshape(-1)
+    check(_lib.load().sgam_vq_commit_loss_f32(_p(z), _p(codebook), _p(idx), _p(partial), _p(loss), T, D, codebook.shape[0],
+                                              float(beta), _stream()), "sgam_vq_commit_loss_f32")
+    return loss[0]
 
 
 def vq_gather(codebook, idx):
@@ -615,13 +690,80 @@ def forward_splat(src_feats, src_depths, tgt_K, src_Kinv, T, *, channels_last=Fa
     return o
 
 
-def depth_normalise(depth, dataset, compute_mask=True, mask_bool=False):
+def _ptr_table(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def forward_splat_srcs(src_feats, src_depths, tgt_K, src_Kinv, T, *, B=1, depth_range=None, dataset=None,
+                       want=("x", "extrap"), extrap_bool=False, out=None):
+    """`forward_splat` with the sources as a LIST of B*N per-frame tensors — features (H,W,3) channels-last fp32
+    contiguous and depths (H,W) — read in place through a pointer table (no stacked copy).  `out`: optional dict of
+    preallocated outputs (persistent buffers of the scene loop)."""
+    n_src = len(src_feats)
+    assert n_src == len(src_depths) and n_src % B == 0 and 0 < n_src <= 16
+    N = n_src // B
+    for f, d in zip(src_feats, src_depths):
+        _need_cuda(f, d)
+        if f.dtype != torch.float32 or d.dtype != torch.float32 or not f.is_contiguous() or not d.is_contiguous():
+            raise SgamHipError("forward_splat_srcs: sources must be contiguous fp32 (H,W,3) / (H,W) tensors")
+    H, W = src_depths[0].shape[-2:]
+    HW = H * W
+    dev = src_depths[0].device
+    out = out or {}
+    o = {}
+    mk = lambda name, shape, dt=torch.float32: out[name] if name in out else torch.empty(shape, device=dev, dtype=dt)  # noqa: E731
+    if "merge_depths" in want: o["merge_depths"] = mk("merge_depths", (B, 1, H, W))
+    if "merge_feats" in want: o["merge_feats"] = mk("merge_feats", (B, 3, H, W))
+    if "extrap" in want: o["extrap"] = mk("extrap", (B, 1, H, W), torch.bool if extrap_bool else torch.uint8)
+    if "x" in want: o["x"] = mk("x", (B, 4, H, W))
+    winner = mk("winner", (B, HW), torch.int32)
+    dr = None
+    if depth_range is not None:
+        dr = (ctypes.c_float * 2)(float(depth_range[0]), float(depth_range[1]))
+    norm = DATASET_NORM.get(dataset, 0) if dataset else 0
+    if "x" in want and norm == 0:
+        raise NotImplementedError(f"dataset {dataset!r}")
+    kt, kinv, tt = _f32c(tgt_K), _f32c(src_Kinv), _f32c(T)       # locals keep any contiguous copy alive until enqueued
+    check(_lib.load().sgam_forward_splat_srcs_f32(
+        _ptr_table(src_feats), _ptr_table(src_depths), 1, 3, _p(kt), _p(kinv), _p(tt), B, N, H, W, dr, norm, _p(winner),
+        _p(o.get("merge_depths")), _p(o.get("merge_feats")), _p(o.get("extrap")), _p(o.get("x")), None, None, None, None,
+        _stream()), "sgam_forward_splat_srcs_f32")
+    return o
+
+
+def inverse_warp_srcs(src_imgs, src_depths, tgt_depth, src_K, tgt_Kinv, T_tgt2src, B=1, out=None):
+    """`inverse_warp` over a LIST of B*N per-frame sources: images (H,W,3) channels-last, depths (H,W), in place.
+    `out`: optional contiguous (B,3,H,W) destination (e.g. the rgb planes of a persistent B = 1 model input)."""
+    n_src = len(src_imgs)
+    assert n_src == len(src_depths) and n_src % B == 0 and 0 < n_src <= 16
+    for f, d in zip(src_imgs, src_depths):
+        _need_cuda(f, d)
+        if f.dtype != torch.float32 or d.dtype != torch.float32 or not f.is_contiguous() or not d.is_contiguous():
+            raise SgamHipError("inverse_warp_srcs: sources must be contiguous fp32 (H,W,3) / (H,W) tensors")
+    H, W = src_depths[0].shape[-2:]
+    if out is None:
+        out = torch.empty((B, 3, H, W), device=src_depths[0].device, dtype=torch.float32)
+    assert out.shape == (B, 3, H, W) and out.is_contiguous() and out.dtype == torch.float32
+    td, sk, tk, tt = _f32c(tgt_depth), _f32c(src_K), _f32c(tgt_Kinv), _f32c(T_tgt2src)  # keep alive
+    check(_lib.load().sgam_inverse_warp_srcs_f32(_ptr_table(src_imgs), _ptr_table(src_depths), 1, 3, _p(td), _p(sk), _p(tk),
+                                                 _p(tt), B, n_src // B, H, W, _p(out), None, _stream()),
+          "sgam_inverse_warp_srcs_f32")
+    return out
+
+
+def depth_normalise(depth, dataset, compute_mask=True, mask_bool=False, out=None, out_mask=None):
     """depth (any shape) -> (normalised inverse depth, extrap mask uint8 (torch.bool with mask_bool: the same 0/1
-    bytes) or None)  [model.py:196-229]"""
+    bytes) or None)  [model.py:196-229].  `out` / `out_mask`: optional contiguous destinations of the same size."""
     _need_cuda(depth)
     d = _f32c(depth)
-    out = torch.empty_like(d)
-    em = torch.empty(d.shape, device=d.device, dtype=torch.bool if mask_bool else torch.uint8) if compute_mask else None
+    if out is None:
+        out = torch.empty_like(d)
+    assert out.numel() == d.numel() and out.is_contiguous() and out.dtype == torch.float32
+    em = None
+    if compute_mask:
+        em = out_mask if out_mask is not None else torch.empty(d.shape, device=d.device,
+                                                               dtype=torch.bool if mask_bool else torch.uint8)
+        assert em.numel() == d.numel() and em.is_contiguous() and em.element_size() == 1
     if dataset not in DATASET_NORM:
         raise NotImplementedError(f"dataset {dataset!r}")
     check(_lib.load().sgam_depth_normalise_f32(_p(d), int(compute_mask), _p(em), _p(out), DATASET_NORM[dataset],
@@ -653,6 +795,17 @@ def rgb_lut(device):
         lut = (np.arange(256, dtype=np.float64) / 127.5 - 1.0).astype(np.float32)
         _LUT[key] = torch.from_numpy(lut).to(device)
     return _LUT[key]
+
+
+def rgb_u8_to_f32(u8):
+    """uint8 image -> fp32 lut[u8] (the PNG re-read of prepare_batch_data, inference_pipeline.py:534)"""
+    _need_cuda(u8)
+    u8 = _c(u8)
+    assert u8.dtype == torch.uint8
+    out = torch.empty(u8.shape, device=u8.device, dtype=torch.float32)
+    check(_lib.load().sgam_rgb_u8_to_f32(_p(u8), _p(rgb_lut(u8.device)), _p(out), u8.numel(), _stream()),
+          "sgam_rgb_u8_to_f32")
+    return out
 
 
 def frame_feedback(dec, dataset, want_u8=False):

@@ -60,6 +60,13 @@ def render_projection_from_srcs_fast(src_features, src_depths, tgt_intrinsic, sr
 def splat_to_model_input(batch, dataset, depth_range=None):
     """The get_x hot path (model.py:184-229 without the by-products): batch -> (x (B,4,H,W) =
     cat(warped rgb, normalised inverse depth with holes=-2), extrapolation mask bool, normalised depth)."""
+    if "_src_list" in batch:           # the scene loop: per-frame tensors read in place through a pointer table
+        feats, depths = batch["_src_list"]
+        B = batch["R_rels"].shape[0]
+        T = batch["_T_src2tgt"].reshape(len(feats), 4, 4)
+        o = ops.forward_splat_srcs(feats, depths, batch["Ks"][:, 0], batch["_src_Kinv"], T, B=B, depth_range=depth_range,
+                                   dataset=dataset, want=("x", "extrap"), extrap_bool=True, out=batch.get("_warp_out"))
+        return o["x"], o["extrap"], o["x"][:, 3:4]
     src = batch["src_imgs"]            # (B,N,H,W,3) channels-last, read in place by the kernel
     dep = batch["src_depths"]          # (B,N,H,W,1) or (B,N,H,W)
     if dep.dim() == 5:

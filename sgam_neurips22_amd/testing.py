@@ -139,3 +139,82 @@ OP_CASES = [("res128", "ResnetBlock", dict(in_channels=128, out_channels=128), (
             ("attn512", "AttnBlock", dict(in_channels=512), (2, 512, 8, 8)),
             ("down128", "Downsample", dict(in_channels=128, with_conv=True), (1, 128, 16, 20)),
             ("up256", "Upsample", dict(in_channels=256, with_conv=True), (1, 256, 8, 12))]
+
+
+def sha256(t):
+    """digest of a tensor's / array's raw bytes: bit-exact outputs are pinned by hash where the data would be large"""
+    import hashlib
+    a = t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest()
+
+
+def _fresh_row(zmean, zstd, dim, row, k):
+    g = torch.Generator().manual_seed(99991 + 31 * int(row) + 7 * int(k))
+    return (torch.randn((dim,), generator=g) * float(zstd) + float(zmean)).float()
+
+
+def apply_codebook_repairs(cb, repairs, zmean, zstd):
+    """replay the (row, k) replacements recorded by `repaired_codebook`"""
+    cb = cb.clone()
+    for row, k in np.asarray(repairs).reshape(-1, 2).tolist():
+        cb[row] = _fresh_row(zmean, zstd, cb.shape[1], row, k)
+    return cb
+
+
+def repaired_codebook(z_tokens, zmean, zstd, n_e, dim, seed=0, min_gap=1e-4, max_rounds=200):
+    """`codebook_from_stats`, then every token whose nearest / second-nearest codeword are closer than `min_gap`
+    (relative) gets its SECOND-nearest row replaced by a fresh seeded row, until the arg-min of every token is well
+    conditioned.  Seed search alone cannot reach that for thousands of tokens (P(gap < 1e-4) is ~5e-3 per token).
+    Returns (codebook, [(row, k), ...]) — the list replays through `apply_codebook_repairs`."""
+    cb = codebook_from_stats(zmean, zstd, n_e, dim, seed)
+    z = z_tokens.detach().double().cpu()
+    repairs, count = [], {}
+    for _ in range(max_rounds):
+        c = cb.double()
+        d = (z ** 2).sum(1, keepdim=True) + (c ** 2).sum(1) - 2 * z @ c.t()
+        top2 = torch.topk(d, 2, dim=1, largest=False)
+        gap = (top2.values[:, 1] - top2.values[:, 0]) / top2.values[:, 0].abs().clamp_min(1e-12)
+        bad = torch.nonzero(gap < min_gap).reshape(-1).tolist()
+        if not bad:
+            return cb, repairs
+        for t in bad:
+            row = int(top2.indices[t, 1])
+            k = count.get(row, 0)
+            count[row] = k + 1
+            cb[row] = _fresh_row(zmean, zstd, dim, row, k)
+            repairs.append((row, k))
+    raise RuntimeError("repaired_codebook did not converge")
+
+
+def config5_batch(src0_rgb_u8, src0_depth, res=512):
+    """BASELINE config 5 inputs (numpy fp32, keys / shapes of the reference's get_x batch, model.py:179-209): a batch
+    of FOUR candidate target poses, each conditioned on the same TWO 512x512 source frames — the reference's
+    GoogleEarth seed0 template at grid cell (0,0) and a synthetic seeded frame at cell (1,0) — with the pipeline's own
+    pose geometry (inference_pipeline.py:157-204: start pose, half grid steps, OpenGL->CV flip, T_rel = T_tgt T_src^-1)."""
+    from .inference_pipeline import _GL2CV, _START, intrinsics, synthetic_seed_frame
+    start, step_i, _ = _START["google_earth"]
+    K = intrinsics("google_earth", (res, res))
+
+    def w2c(k, yaw=0.0):
+        c2w = np.eye(4)
+        c, s = np.cos(yaw), np.sin(yaw)
+        c2w[:3, :3] = start[:3, :3] @ np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+        c2w[:3, 3] = start[:3, 3] + step_i / 2 * k
+        return np.linalg.inv(c2w @ _GL2CV)
+
+    T_srcs = [w2c(0.0), w2c(1.0)]
+    T_tgts = [w2c(2.0), w2c(1.5, 0.02), w2c(0.5, -0.03), w2c(3.0)]
+    rgb1, d1 = synthetic_seed_frame("google_earth", 1, res)
+    lut = (np.arange(256, dtype=np.float64) / 127.5 - 1.0).astype(np.float32)
+    imgs = np.stack([lut[src0_rgb_u8], lut[rgb1]])                      # (2,H,W,3)
+    deps = np.stack([np.asarray(src0_depth, np.float32), d1])           # (2,H,W)
+    R = np.zeros((4, 2, 3, 3))
+    t = np.zeros((4, 2, 3))
+    for b, Tt in enumerate(T_tgts):
+        for n, Ts in enumerate(T_srcs):
+            Trel = Tt @ np.linalg.inv(Ts)
+            R[b, n], t[b, n] = Trel[:3, :3], Trel[:3, 3]
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)  # noqa: E731
+    return {"Ks": f32(np.tile(K, (4, 2, 1, 1))), "R_rels": f32(R), "t_rels": f32(t),
+            "src_imgs": f32(np.tile(imgs[None], (4, 1, 1, 1, 1))), "src_depths": f32(np.tile(deps[None], (4, 1, 1, 1))),
+            "dst_img": np.zeros((4, res, res, 3), np.float32), "dst_depth": np.zeros((4, res, res), np.float32)}

@@ -10,6 +10,10 @@ Fixtures
   vqgan_ops.npz    ResnetBlock / AttnBlock / Downsample / Upsample / GroupNorm+swish / VectorQuantizer2
   vqgan_full_*.npz VQModel.forward on seeded synthetic weights + margin-guarded codebook
   trajectory_ge.npz 3 steps of InfiniteSceneGeneration.one_step_prediction (GoogleEarth seed0)
+  vqgan_topk4_s2.npz        VQModel.forward(topk=4, sample_number=2): get_multiple_codewords' sampling branch (CPU RNG)
+  config5_ge512_b4.npz      BASELINE config 5: 512x512, four warp candidates (two real template sources) -> get_x -> forward
+  trajectory_ge_free32.npz  32 FREE-RUNNING steps of the GoogleEarth loop (no teacher forcing; BASELINE config 3)
+  trajectory_clevr.npz      3 steps of the CLEVR-Infinite loop (seed depth converted twice in float64, num_src 5)
 """
 import os
 import sys
@@ -128,7 +132,8 @@ def gen_full(dataset, res, tag, topk=None):
             dec = decs[0][0]
     wsum = np.array([float(sd[k].double().abs().sum()) for k in sorted(sd.keys())[:8]])
     step = 1 if res <= 64 else 2
-    save(f"vqgan_full_{tag}.npz", dataset=dataset, res=res, zmean=zmean, zstd=zstd, cb_seed=cb_seed,
+    extra = {} if diff is None else {"emb_loss": float(diff)}
+    save(f"vqgan_full_{tag}.npz", dataset=dataset, res=res, zmean=zmean, zstd=zstd, cb_seed=cb_seed, **extra,
          weight_abs_sums=wsum, dec_sub=dec[..., ::step, ::step], dec_step=step, dec_sum=float(dec.double().sum()),
          dec_abs_sum=float(dec.double().abs().sum()), indices=idx, pre_quant=pre, quant=quant,
          topk=-1 if topk is None else topk)
@@ -188,6 +193,158 @@ def gen_trajectory(rgb0, dm0):
         os.chdir(cwd)
 
 
+def _ge_model(cb=None):
+    """GoogleEarth reference VQModel on the seeded synthetic weights (+ the ge256 fixture's margin-guarded codebook)."""
+    p = R.load_params("google_earth")
+    torch.manual_seed(0)
+    model = VQModel(**p).eval()
+    sd = testing.synthetic_state_dict(model.state_dict(), seed=0)
+    full = np.load(os.path.join(HERE, "vqgan_full_ge256.npz"))
+    sd["quantize.embedding.weight"] = cb if cb is not None else testing.codebook_from_stats(
+        float(full["zmean"]), float(full["zstd"]), 4096, 256, int(full["cb_seed"]))
+    model.load_state_dict(sd)
+    return model, sd, p, full
+
+
+def gen_topk4():
+    """get_multiple_codewords' sampling branch (quantize.py:344-381) through VQModel.forward: topk=4, 2 samples.  The
+    reference is run on the CPU, so the multinomial draws come from the CPU generator seeded right before the call."""
+    print("top-k = 4, sample_number = 2 (GoogleEarth 256x256)")
+    model, sd, p, full = _ge_model()
+    x, mask = testing.rect_hole_input(1, 256, 256, seed=3)
+    torch.manual_seed(3)
+    with torch.no_grad():
+        decs, diff, idx, pre, quants = model(x, topk=4, extrapolation_mask=mask, sample_number=2, get_codebook_count=True,
+                                             get_pre_quantized_feature=True, get_quantized_feature=True)
+    assert diff is None and len(decs) == 2 and idx.shape == (1, 2, 16, 16) and quants.shape == (1, 2, 256, 16, 16)
+    n_sampled = int((idx[0, 0] != idx[0, 1]).sum())
+    print(f"  tokens whose two samples differ: {n_sampled} / 256")
+    save("vqgan_topk4_s2.npz", indices=idx, quant_sha=np.frombuffer(testing.sha256(quants), np.uint8),
+         dec_sub=torch.stack([d[0, 0][..., ::2, ::2] for d in decs]), dec_sum=[float(d.double().sum()) for d in decs],
+         n_sampled=n_sampled)
+
+
+def gen_config5():
+    """BASELINE config 5: GoogleEarth 512x512, a batch of four warp candidates per step.  Sources (N = 2): the reference's
+    seed0 template at its native 512x512 and a synthetic seeded frame; candidates: four target poses in the pipeline's
+    own grid geometry (testing.config5_batch).  Reference get_x (forward splat at B = 4) -> forward (arg-min path) item by item
+    (B = 1 calls: the 16384 x 16384 fp32 score matrix is 1 GiB per item)."""
+    print("config 5: 512x512, four warp candidates")
+    from PIL import Image
+    d = f"{R.REF}/templates/google_earth/seed0"
+    src0_rgb = np.array(Image.open(f"{d}/im_00000.png").convert("RGB"))
+    src0_depth = np.load(f"{d}/dm_00000.npy").astype(np.float32)
+    batch_np = testing.config5_batch(src0_rgb, src0_depth)
+    model, sd, p, full = _ge_model()
+    batch = {k: torch.from_numpy(v) for k, v in batch_np.items()}
+    batch["src_depths"] = batch["src_depths"][..., None]
+    with torch.no_grad():
+        x, x_dst, mask, wd = model.get_x(batch, "google_earth", return_extrapolation_mask=True, no_depth_range=True,
+                                         parallel=True)
+        pres = torch.cat([model.encode(x[b:b + 1], extrapolation_mask=mask[b:b + 1])[3] for b in range(4)])
+    z = pres.permute(0, 2, 3, 1).reshape(-1, 256)
+    zmean, zstd = float(z.mean()), float(z.std())
+    cb, repairs = testing.repaired_codebook(z, zmean, zstd, 4096, 256, seed=0, min_gap=1e-4)
+    gap = float(testing.top2_relative_gap(z, cb).min())
+    print(f"  codebook N({zmean:.4f}, {zstd:.4f}), {len(repairs)} repaired rows: min relative top-2 gap {gap:.3e}")
+    assert gap >= 1e-4
+    sd["quantize.embedding.weight"] = cb
+    model.load_state_dict(sd)
+    decs, idxs, losses = [], [], []
+    with torch.no_grad():
+        for b in range(4):
+            dec, diff, idx, pre = model(x[b:b + 1], extrapolation_mask=mask[b:b + 1], get_codebook_count=True,
+                                        get_pre_quantized_feature=True)
+            assert torch.equal(pre, pres[b:b + 1])
+            decs.append(dec); idxs.append(idx); losses.append(float(diff))
+    dec, idx = torch.cat(decs), torch.cat(idxs)
+    save("config5_ge512_b4.npz", src0_rgb=src0_rgb, src0_depth=src0_depth, zmean=zmean, zstd=zstd, repairs=np.array(repairs, np.int64).reshape(-1, 2), min_gap=gap,
+         x_sha=np.frombuffer(testing.sha256(x), np.uint8), mask=np.packbits(mask.numpy()), x_sum=float(x.double().sum()),
+         x_sub=x[..., ::8, ::8], indices=idx.to(torch.int16), pre_quant0=pres[0], pre_quant_sub=pres[:, ::8],
+         dec_sub=dec[..., ::4, ::4], dec_sum=[float(d.double().sum()) for d in decs], emb_loss=losses)
+
+
+def _quant_to_idx(quant, cb):
+    """indices of a pure-gather quantised latent (256,16,16): exact row match against the codebook"""
+    q = quant.reshape(256, -1).t()
+    d = torch.cdist(q.double(), cb.double())
+    idx = d.argmin(1)
+    assert torch.equal(cb[idx], q)
+    return idx.reshape(16, 16)
+
+
+def _run_trajectory(dataset, model, cb, steps, output_dim):
+    import random
+    import tempfile
+    from PIL import Image
+    cwd, tmp = os.getcwd(), tempfile.mkdtemp()
+    os.symlink(f"{R.REF}/templates", os.path.join(tmp, "templates"))
+    os.chdir(tmp)
+    out = {}
+    try:
+        random.seed(10); np.random.seed(29); torch.random.manual_seed(3)
+        fw = InfiniteSceneGeneration(model, dataset, seed_index=0, use_rgbd_integration=False, output_dim=output_dim)
+        for step in range(steps):
+            with torch.no_grad():
+                tgt = fw.next_pose(fw.curr)
+                srcs, _ = fw.get_src_grid_coords(tgt)
+                res = fw.one_step_prediction(tgt)
+            node = fw.transform_grid[tgt[0]][tgt[1]]
+            out[f"s{step}.tgt"], out[f"s{step}.srcs"] = np.array(tgt), np.array(srcs)
+            out[f"s{step}.indices"] = _quant_to_idx(res["feature"], cb).to(torch.int16)
+            out[f"s{step}.mask"] = np.packbits((res["x"][0, 3] == -2).numpy())
+            out[f"s{step}.x_sum"] = float(res["x"].double().sum())
+            # how well conditioned each token's arg-min was in the reference's own run (SURVEY D4): relative top-2 gap
+            out[f"s{step}.gap"] = testing.top2_relative_gap(res["pre_quantized_features"].reshape(256, -1).t(), cb).float()
+            yield step, fw, res, node, out, Image
+            fw.curr += 1
+    finally:
+        os.chdir(cwd)
+
+
+def gen_trajectory_free(steps=32):
+    """BASELINE config 3: the GoogleEarth loop FREE-RUNNING for 32 generated frames (every frame conditions on the
+    reference's own earlier outputs through its PNG / NPY round trip)."""
+    print(f"GoogleEarth free-running trajectory, {steps} frames")
+    model, sd, p, full = _ge_model()
+    cb = sd["quantize.embedding.weight"]
+    final = None
+    for step, fw, res, node, out, Image in _run_trajectory("google_earth", model, cb, steps, (steps + 1, 1)):
+        u8 = np.array(Image.open(node["rgb_path"]))
+        out[f"s{step}.rgb_u8_sub"] = u8[::4, ::4]
+        out[f"s{step}.rgb_u8_sum"] = int(u8.astype(np.int64).sum())
+        out[f"s{step}.depth_sub"] = np.load(node["depth_path"])[::4, ::4]
+        final = out
+        print(f"  step {step}: srcs {out[f's{step}.srcs'].tolist()} holes {int((res['x'][0, 3] == -2).sum())}")
+    save("trajectory_ge_free32.npz", steps=steps, **final)
+
+
+def gen_trajectory_clevr():
+    """CLEVR-Infinite loop, 3 steps on a 2x2 grid: 16384 codes, num_src 5, the seed depth's ray->z conversion applied at
+    construction (:71-79) AND again at every load (:582-590), both in float64."""
+    print("CLEVR 3-step trajectory")
+    p = R.load_params("clevr-infinite")
+    torch.manual_seed(0)
+    model = VQModel(**p).eval()
+    sd = testing.synthetic_state_dict(model.state_dict(), seed=0)
+    full = np.load(os.path.join(HERE, "vqgan_full_clevr256_topk1.npz"))
+    cb = testing.codebook_from_stats(float(full["zmean"]), float(full["zstd"]), 16384, 256, int(full["cb_seed"]))
+    sd["quantize.embedding.weight"] = cb
+    model.load_state_dict(sd)
+    final = None
+    for step, fw, res, node, out, Image in _run_trajectory("clevr-infinite", model, cb, 3, (2, 2)):
+        if step == 0:
+            out["seed_rgb"] = np.array(Image.open(fw.transform_grid[0][0]["rgb_path"]).convert("RGB"))
+            out["seed_depth_once"] = np.load(fw.transform_grid[0][0]["depth_path"])          # float64, converted once
+            out["seed_src_depth"] = res["batch_src_depths"][0, 0, ..., 0]                     # fp32 after both conversions
+        out[f"s{step}.rgb_u8"] = np.array(Image.open(node["rgb_path"]))
+        out[f"s{step}.depth"] = np.load(node["depth_path"])
+        out[f"s{step}.R_rels"], out[f"s{step}.t_rels"] = res["batch_R_rels"], res["batch_t_rels"]
+        out[f"s{step}.rgbd_sub"] = res["rgbd"][:, ::4, ::4]
+        final = out
+    save("trajectory_clevr.npz", zmean=full["zmean"], zstd=full["zstd"], cb_seed=full["cb_seed"], **final)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     rgb0, dm0 = gen_splat() if (not only or "splat" in only or "traj" in only) else (None, None)
@@ -201,3 +358,11 @@ if __name__ == "__main__":
         gen_full("clevr-infinite", 256, "clevr256_topk1", topk=1)
     if not only or "traj" in only:
         gen_trajectory(rgb0, dm0)
+    if not only or "topk4" in only:
+        gen_topk4()
+    if not only or "config5" in only:
+        gen_config5()
+    if not only or "free" in only:
+        gen_trajectory_free()
+    if not only or "clevr" in only:
+        gen_trajectory_clevr()

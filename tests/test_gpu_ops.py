@@ -187,7 +187,7 @@ def test_vq_nearest_bit_exact_indices(T, n_e):
         seed += 1
     sd = {"quantize.embedding.weight": cb}
     side = int(T ** 0.5)
-    zq_ref, idx_ref, d_ref = OV.quantize(sd, z.view(1, side, T // side, 256).permute(0, 3, 1, 2))
+    zq_ref, idx_ref, d_ref, _ = OV.quantize(sd, z.view(1, side, T // side, 256).permute(0, 3, 1, 2))
     cbd = cb.to(DEV)
     idx, zq, dist = ops.vq_nearest(z.to(DEV), cbd, ops.row_sumsq(cbd), straight_through=True, want_dist=True)
     assert torch.equal(idx.cpu(), idx_ref.reshape(-1)), "codebook indices must be bit-exact on margin-guarded inputs"

@@ -90,3 +90,72 @@ def test_depth_codec_expressions():
     assert torch.allclose(back, d[~em], atol=2e-4)
     x = torch.tensor([-1.0, -0.999, 0.0, 0.5, 0.999999, 1.0, 1.5]).view(1, 7, 1).expand(3, 7, 1)
     assert OW.rgb_to_uint8(x)[:, 0, 0].tolist() == [0, 0, 127, 191, 254, 255, 255]
+
+
+def _ge_sd(golden):
+    g = golden("vqgan_full_ge256.npz")
+    sd = testing.synthetic_state_dict(_ref_like_sd("google_earth"), seed=0)
+    sd["quantize.embedding.weight"] = testing.codebook_from_stats(float(g["zmean"]), float(g["zstd"]), 4096, 256, int(g["cb_seed"]))
+    return sd, default_params("google_earth")
+
+
+def test_commitment_loss_matches_reference(golden):
+    """`diff` of VQModel.forward (emb_loss, quantize.py:296-301) as the reference returned it"""
+    g = golden("vqgan_full_ge64.npz")
+    sd = testing.synthetic_state_dict(_ref_like_sd("google_earth"), seed=0)
+    sd["quantize.embedding.weight"] = testing.codebook_from_stats(float(g["zmean"]), float(g["zstd"]), 4096, 256, int(g["cb_seed"]))
+    x, mask = testing.rect_hole_input(1, 64, 64, seed=3)
+    o = OV.forward(sd, default_params("google_earth")["ddconfig"], x, mask)
+    assert abs(float(o["emb_loss"]) - float(g["emb_loss"])) <= 1e-6 * abs(float(g["emb_loss"]))
+
+
+def test_topk4_sampler_oracle_matches_reference(golden):
+    """get_multiple_codewords' sampling branch (topk = 4, two samples; quantize.py:344-381 incl. the row-0 quirk at
+    :358) pinned to the reference's own CPU-RNG draws"""
+    g = golden("vqgan_topk4_s2.npz")
+    sd, p = _ge_sd(golden)
+    x, mask = testing.rect_hole_input(1, 256, 256, seed=3)
+    torch.manual_seed(3)
+    o = OV.forward(sd, p["ddconfig"], x, mask, topk=4, sample_number=2)
+    assert int(g["n_sampled"]) > 0, "the fixture must exercise real sampling"
+    assert torch.equal(o["indices"], torch.from_numpy(g["indices"]))
+    assert testing.sha256(o["quant"]) == g["quant_sha"].tobytes()
+    for s in range(2):
+        assert np.abs(o["dec"][s][0, 0][..., ::2, ::2].numpy() - g["dec_sub"][s]).max() <= 2e-5
+
+
+def test_config5_oracle_matches_reference(golden):
+    """BASELINE config 5 (512x512, four warp candidates): the C splat restatement reproduces the reference's model input
+    bit for bit at full size (hash), and the VQGAN restatement reproduces candidate 0 (indices exact, margin asserted)."""
+    g = golden("config5_ge512_b4.npz")
+    b = testing.config5_batch(g["src0_rgb"], g["src0_depth"])
+    T = np.zeros((4, 2, 4, 4), np.float32)
+    T[:, :, :3, :3], T[:, :, :3, 3], T[:, :, 3, 3] = b["R_rels"], b["t_rels"], 1.0
+    w = OW.forward_splat(np.ascontiguousarray(b["src_imgs"].transpose(0, 1, 4, 2, 3)), b["src_depths"], b["Ks"][:, 0], b["Ks"], T)
+    em = torch.from_numpy(w["extrapolation_mask"])
+    x = torch.cat([torch.from_numpy(w["merge_feats"]), OW.normalise_depth(torch.from_numpy(w["merge_depths"]), em, "google_earth")], 1)
+    assert np.array_equal(np.packbits(em.numpy()), g["mask"])
+    assert testing.sha256(x) == g["x_sha"].tobytes()
+    sd, p = _ge_sd(golden)
+    cb = testing.codebook_from_stats(float(g["zmean"]), float(g["zstd"]), 4096, 256, 0)
+    sd["quantize.embedding.weight"] = testing.apply_codebook_repairs(cb, g["repairs"], float(g["zmean"]), float(g["zstd"]))
+    assert float(g["min_gap"]) >= 1e-4
+    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    o = OV.forward(sd, p["ddconfig"], x[:1], em[:1])
+    assert np.abs(o["pre_quant"][0].numpy() - g["pre_quant0"]).max() <= 2e-5
+    assert torch.equal(o["indices"][0].to(torch.int16), torch.from_numpy(g["indices"][0]))
+    assert np.abs(o["dec"][..., ::4, ::4].numpy() - g["dec_sub"][:1]).max() <= 5e-5
+    assert abs(float(o["emb_loss"]) - float(g["emb_loss"][0])) <= 1e-6 * float(g["emb_loss"][0])
+    gap = testing.top2_relative_gap(o["pre_quant"].permute(0, 2, 3, 1).reshape(-1, 256), sd["quantize.embedding.weight"])
+    assert float(gap.min()) >= 1e-4
+
+
+def test_clevr_seed_depth_double_conversion(golden):
+    """CLEVR seed depth: ray->z at construction and AGAIN at every load, both in float64, one rounding to fp32
+    (inference_pipeline.py:71-79, 582-590, 607)"""
+    from sgam_neurips22_amd.inference_pipeline import intrinsics, ray_to_z_depth
+    g = golden("trajectory_clevr.npz")
+    once = g["seed_depth_once"]
+    assert once.dtype == np.float64
+    twice = ray_to_z_depth(once, intrinsics("clevr-infinite")).astype(np.float32)
+    assert np.array_equal(twice, g["seed_src_depth"])
