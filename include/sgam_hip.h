@@ -110,6 +110,14 @@ int sgam_pack_conv_weight(const float *w_oihw, float *w_packed, int32_t Cout, in
  * ldb = K elements per row, % 32 == 0 (the buffer holds 2 * ldb halfs per row of the 32-row-padded matrix); Cin % 8 == 0, and % 32 == 0 when
  * KH * KW > 1; |a_scale * x| must stay below 65504.
  * ------------------------------------------------------------------------------------------ */
+/* Range guard of the split path.  An activation with |a_scale * x| >= 65520 becomes inf in its fp16 hi half, and the
+ * output it feeds becomes inf / NaN.  Every split-fp32 kernel that produces final outputs (conv / GEMM epilogue, split-K
+ * combine, fused-attention combine) ORs 1 into *device_flag when it writes a non-finite value.  The caller owns the int32
+ * (zero it, read it at a synchronisation point); on 1 the results since the last check are invalid in this mode and
+ * must be recomputed on the fp32-in MFMA path (sgam_conv2d_nhwc_f32), which has no range precondition — the Python
+ * side does exactly that (VQModel.forward, InfiniteSceneGeneration.scene_expansion).  NULL (default) disables the
+ * reporting.  This pointer is the library's only mutable global: one flag per process (= per GPU). */
+int sgam_f32x_set_range_flag(int32_t *device_flag);
 int64_t sgam_conv2d_f32x_workspace_bytes(const sgam_conv_desc *d);
 int sgam_conv2d_f32x_plan(const sgam_conv_desc *d, int32_t *bm, int32_t *bn, int32_t *ksplit);
 int sgam_conv2d_nhwc_f32x(const sgam_conv_desc *d, const float *x, float a_scale, const void *w_planes,

@@ -37,6 +37,7 @@ PROTOTYPES = {
     "sgam_conv2d_gn_nhwc_f32": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64,
                                         c_vp]),
     "sgam_pack_conv_weight": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "sgam_f32x_set_range_flag": (c_i32, [c_vp]),
     "sgam_conv2d_f32x_workspace_bytes": (c_i64, [ctypes.POINTER(ConvDesc)]),
     "sgam_conv2d_f32x_plan": (c_i32, [ctypes.POINTER(ConvDesc), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32),
                                       ctypes.POINTER(c_i32)]),

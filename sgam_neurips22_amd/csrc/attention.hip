@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void attn_flash_f32x_kernel(const AttnParams p
 // Workgroup = (32-query tile, 32 columns of d); thread = (query, 4 d): 32 independent loads in flight per thread; the
 // 32 x 32 result goes through LDS so that rows leave as 128-byte pieces.
 __global__ __launch_bounds__(256) void attn_combine_kernel(const float *__restrict__ ws_o, const float *__restrict__ ws_ml,
-                                                           float *__restrict__ out, int ldo, int n) {
+                                                           float *__restrict__ out, int ldo, int n, int32_t *range_flag) {
     __shared__ float tile[32][33];
     const int qt = blockIdx.x >> 3, dg = blockIdx.x & 7;
     const int q = threadIdx.x & 31, dsub = threadIdx.x >> 5;
@@ -365,6 +365,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float *__restri
     const int r = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
     const f32x4 v = {tile[r][c4], tile[r][c4 + 1], tile[r][c4 + 2], tile[r][c4 + 3]};
     *reinterpret_cast<f32x4 *>(out + (int64_t)(qt * 32 + r) * ldo + dg * 32 + c4) = v;
+    if (range_flag && sgam_not_finite((v[0] + v[1]) + (v[2] + v[3]))) atomicOr(range_flag, 1);   // q, k or v left fp16's range
 }
 
 // =====================================================================================================================
@@ -601,7 +602,7 @@ extern "C" int sgam_attention_f32x(const float *q, const float *k, const float *
     if (sgam_i_prof_on) sgam_i_prof_work(4.0 * n * (double)n * AD, 4.0 * 4.0 * n * AD);   // q k^T + P v; q, k, v, o once
     SGAM_KLAUNCH(attn_flash_f32x_kernel, dim3(n / 128 * nsplit), dim3(256), 0, s, p);
     SGAM_LAUNCH_CHECK();
-    SGAM_KLAUNCH(attn_combine_kernel, dim3(n / 32 * 8), dim3(256), 0, s, ws_o, ws_ml, out, ldo, n);
+    SGAM_KLAUNCH(attn_combine_kernel, dim3(n / 32 * 8), dim3(256), 0, s, ws_o, ws_ml, out, ldo, n, sgam_i_range_flag);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
 }

@@ -53,6 +53,7 @@ struct XParams {
 
     double *gn_partial;  // optional: per-(row-half of the tile, group) {sum, sumsq} of the OUTPUT for the next GroupNorm
     int gn_cpg;          // channels per group of that GroupNorm (N / 32)
+    int32_t *range_flag; // optional: set to 1 when an output is not finite (an operand left fp16's range, see sgam_hip.h)
     float inv_w_scale;   // 1 / (a_scale * w_scale), an exact power of two
     float a_scale;       // power of two applied to the A operand before the split (e.g. 1024 for softmax probabilities)
 };
@@ -191,6 +192,7 @@ __device__ __forceinline__ void xepilogue(const XParams &p, f32x16 (&acc)[BM / (
     const int n4 = wn0 + c4 * 4;
     const bool n_ok = n4 < n_lim;       // n_valid is a multiple of 4
     float gs = 0.f, gss = 0.f;   // this lane's share of the output statistics (4 channels x WM/RPP pixels)
+    bool bad = false;            // a non-finite output: an operand overflowed the fp16 hi half (or fp32 itself overflowed)
 #pragma unroll
     for (int pass = 0; pass < WM / RPP; ++pass) {
         const int row = rr0 + pass * RPP;
@@ -208,10 +210,13 @@ __device__ __forceinline__ void xepilogue(const XParams &p, f32x16 (&acc)[BM / (
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro,
                                                (int)xsel(ok, (unsigned)(m * ldo + n4) * 4u, OOB), 0, 0);
         if (ok) {
-            gs += (v[0] + v[1]) + (v[2] + v[3]);
+            const float t4 = (v[0] + v[1]) + (v[2] + v[3]);
+            gs += t4;
             gss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            bad |= sgam_not_finite(t4);
         }
     }
+    if (bad && !to_ws && p.range_flag) atomicOr(p.range_flag, 1);      // rare path; partial sums are checked by the combine
     if (p.gn_partial && !to_ws) {
         // GroupNorm statistics of the tensor just written, for free: a float4 never straddles a group (cpg is a
         // multiple of 4).  Lanes -> LDS, then one lane per group of this wavefront's column range folds, in a fixed
@@ -785,6 +790,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_f32x_kernel(const XParams p
             gs += v;
             gss += v * v;
         }
+        if (p.range_flag && sgam_not_finite(gs)) atomicOr(p.range_flag, 1);
     }
     if (!p.gn_partial) return;
     // host guarantees: n_valid == N, 1024 % N == 0, whole workgroups inside one image
@@ -1032,6 +1038,7 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
     p.M = d->B * d->Ho * d->Wo;
     p.ksplit = pl.ksplit; p.iters_total = pl.iters_total; p.iters_per_split = pl.iters_per_split;
     p.inv_w_scale = 1.0f / (w_scale * a_scale);
+    p.range_flag = sgam_i_range_flag;
     p.a_scale = a_scale;
     p.gn_partial = ex.gn_partial;
     p.gn_cpg = d->N / 32;

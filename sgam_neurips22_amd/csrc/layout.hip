@@ -126,6 +126,13 @@ extern "C" int sgam_rgb_u8_to_f32(const uint8_t *rgb_u8, const float *lut256, fl
     return SGAM_OK;
 }
 
+// ---- split-fp32 range guard ----
+extern "C" int32_t *sgam_i_range_flag = nullptr;
+extern "C" int sgam_f32x_set_range_flag(int32_t *device_flag) {
+    sgam_i_range_flag = device_flag;
+    return SGAM_OK;
+}
+
 // ---- kernel timeline (see SGAM_KLAUNCH in sgam_common.h) ----
 namespace {
 struct ProfRec {

@@ -31,6 +31,11 @@ extern "C" void sgam_i_prof_work(double flops, double bytes);
 static inline int sgam_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline bool sgam_aligned16(const void *p) { return (((uintptr_t)p) & 15u) == 0; }
 
+// ---- split-fp32 range guard (sgam_f32x_set_range_flag): a device int32 the split-fp32 kernels OR 1 into when a result
+// is not finite — which is what an activation beyond fp16's range (|x| >= 65520 -> inf in the hi half) turns into.
+extern "C" int32_t *sgam_i_range_flag;
+__device__ __forceinline__ bool sgam_not_finite(float t) { return !(__builtin_fabsf(t) <= 3.4028234663852886e38f); }
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -32,6 +32,47 @@ def init(backend=None):
     return rank, local_rank, world
 
 
+def self_launch(script, argv, n):
+    """`python bench.py --gpus N` without a launcher: re-run `script argv` as N ranks of one node through
+    torch.distributed.run (the same command line the driver uses), rendezvous on 127.0.0.1 and a free port.  Returns the
+    launcher's exit code."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this host driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def pin_to_gpu_numa_node(local_rank):
+    """Bind this rank's host threads to the CPUs of the NUMA node its GPU hangs off (PCI bus id -> sysfs numa_node ->
+    cpulist), so that the pinned staging buffer and the launch thread are local to the GPU.  Best effort: returns the
+    node number, or None when the topology cannot be read (containers without sysfs, single-node hosts)."""
+    try:
+        prop = torch.cuda.get_device_properties(local_rank)
+        bdf = f"{getattr(prop, 'pci_domain_id', 0):04x}:{prop.pci_bus_id:02x}:{prop.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return None
+        with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+            cpus = set()
+            for part in f.read().strip().split(","):
+                lo, _, hi = part.partition("-")
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+        if cpus:
+            os.sched_setaffinity(0, cpus & os.sched_getaffinity(0) or cpus)
+        return node
+    except Exception:
+        return None
+
+
 def shard_scenes(num_scenes, rank, world):
     """rank r owns scenes {s : s mod world == r} (round-robin)."""
     return [s for s in range(num_scenes) if s % world == rank]

@@ -97,6 +97,19 @@ class VQModel(nn.Module):
             self._graphs = {}
         return self
 
+    def eager(self):
+        """context manager: launch every kernel of `forward` eagerly even when graphs are enabled (profiling passes)"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def _cm():
+            old, self._graph_bypass = getattr(self, "_graph_bypass", False), True
+            try:
+                yield self
+            finally:
+                self._graph_bypass = old
+        return _cm()
+
     def _forward_graphed(self, input, topk, extrapolation_mask, sample_number, flags):
         # inputs that live in persistent buffers of the caller (the scene loop's warp outputs, marked `_sgam_persistent`)
         # are captured by address: the graph reads them in place and no copy is paid per replay
@@ -112,8 +125,8 @@ class VQModel(nn.Module):
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):          # eager warm-up: weight packing, codebook norms, allocator pools
-                for _ in range(2):
-                    self._forward_eager(sx, topk, sm, sample_number, *flags)
+                for _ in range(2):                 # (guarded: a range overflow switches to the fp32-in MFMA before capture)
+                    self._forward_guarded(sx, topk, sm, sample_number, flags)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
@@ -167,9 +180,36 @@ class VQModel(nn.Module):
                 get_pre_quantized_feature=False, get_quantized_feature=False):
         flags = (bool(get_codebook_count), bool(get_pre_quantized_feature), bool(get_quantized_feature))
         replay_safe = topk is None or (topk == 1 and not self.quantize.consume_host_rng)   # no host RNG in the graph
-        if self.use_hip_graph and ops.CONV_TRACE is None and replay_safe and input.is_cuda and not torch.is_grad_enabled():
+        if self.use_hip_graph and not getattr(self, "_graph_bypass", False) and replay_safe and input.is_cuda \
+                and not torch.is_grad_enabled():
             return self._forward_graphed(input, topk, extrapolation_mask, sample_number, flags)
-        return self._forward_eager(input, topk, extrapolation_mask, sample_number, *flags)
+        return self._forward_guarded(input, topk, extrapolation_mask, sample_number, flags)
+
+    # ---- range guard of the split-fp32 arithmetic (include/sgam_hip.h, sgam_f32x_set_range_flag) ----
+    range_check = "sync"     # "sync": eager forwards verify the flag (one device sync) and recompute; "off": caller checks
+
+    def _guard_active(self, input):
+        return (self.range_check == "sync" and input.is_cuda and self.compute_dtype == torch.float32
+                and ops.F32_MODE == "split" and not torch.cuda.is_current_stream_capturing())
+
+    def _forward_guarded(self, input, topk, extrapolation_mask, sample_number, flags):
+        """eager forward; if a split-fp32 kernel reported a non-finite output (an activation beyond fp16's range), the
+        forward is recomputed on the fp32-in MFMA path, which has no range precondition, and the process stays there"""
+        guard = self._guard_active(input)
+        if guard:
+            ops.range_flag(input.device)
+            rng = torch.get_rng_state() if (topk is not None and topk > 1) else None
+        out = self._forward_eager(input, topk, extrapolation_mask, sample_number, *flags)
+        if guard and ops.f32x_range_tripped():
+            import warnings
+            warnings.warn("sgam split-fp32 path: an activation left fp16's range (|x| >= 65520) and produced a non-finite "
+                          "value; recomputing on the fp32-in MFMA path and switching SGAM_F32_MODE to 'mfma'", RuntimeWarning)
+            ops.set_f32_mode("mfma")
+            self._graphs = {}
+            if rng is not None:
+                torch.set_rng_state(rng)
+            out = self._forward_eager(input, topk, extrapolation_mask, sample_number, *flags)
+        return out
 
     def _forward_eager(self, input, topk=None, extrapolation_mask=None, sample_number=1, get_codebook_count=False,
                        get_pre_quantized_feature=False, get_quantized_feature=False):

@@ -402,10 +402,35 @@ class InfiniteSceneGeneration:
         self.frames[coord] = {"rgb_u8": rgb_u8, "rgb_f": rgb_f, "depth": depth, "index": self.curr}
         self.transform_grid[coord[0]][coord[1]]["visited"] = True
 
-    def scene_expansion(self, return_hs=False):
-        for _ in range(self.output_dim[0] * self.output_dim[1] - 1):
+    def _range_checkpoint(self, verified_curr):
+        """split-fp32 range guard at a synchronisation point of the loop: when a kernel reported a non-finite output since
+        the last checkpoint, the frames generated since then are dropped, the process switches to the fp32-in MFMA path
+        (no range precondition) and the loop resumes from the last verified frame.  Returns the new `curr`."""
+        if not (self.device.type == "cuda" and ops.F32_MODE == "split" and ops.f32x_range_tripped()):
+            return self.curr
+        import warnings
+        warnings.warn(f"sgam split-fp32 path: an activation left fp16's range; regenerating frames {verified_curr}.."
+                      f"{self.curr - 1} on the fp32-in MFMA path (SGAM_F32_MODE -> 'mfma')", RuntimeWarning)
+        ops.set_f32_mode("mfma")
+        self.dynamic_model._graphs = {}
+        for c in self._ordered_grid_coords[verified_curr:self.curr]:
+            self.frames.pop(c, None)
+            self.transform_grid[c[0]][c[1]]["visited"] = False
+        if self.volume is not None:            # the fused volume saw the invalid frames: start it again (every step
+            self.volume = self._make_volume()  # re-integrates its own sources, :757-790)
+        return verified_curr
+
+    def scene_expansion(self, return_hs=False, range_check_every=8):
+        total = self.output_dim[0] * self.output_dim[1]
+        if self.device.type == "cuda":
+            ops.range_flag(self.device)
+        verified = self.curr
+        while self.curr < total:
             self.one_step_prediction(self.next_pose(self.curr))
             self.curr += 1
+            if self.curr == total or (self.curr - verified) >= range_check_every:
+                self.curr = self._range_checkpoint(verified)
+                verified = self.curr
         return self.frames
 
     # ---------------------------------------------------------------- export (after the run)

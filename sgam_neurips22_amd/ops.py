@@ -65,6 +65,28 @@ FUSE_GN_STATS = os.environ.get("SGAM_FUSE_GN_STATS", "1") == "1"
 FUSE_GN_APPLY = os.environ.get("SGAM_FUSE_GN_APPLY", "1") == "1"
 
 
+_RANGE_FLAG = None
+
+
+def range_flag(device):
+    """the split path's range flag (one int32 per process = per GPU), registered with the library on first use"""
+    global _RANGE_FLAG
+    if _RANGE_FLAG is None or _RANGE_FLAG.device != torch.device(device):
+        _RANGE_FLAG = torch.zeros((1,), device=device, dtype=torch.int32)
+        check(_lib.load().sgam_f32x_set_range_flag(_p(_RANGE_FLAG)), "sgam_f32x_set_range_flag")
+    return _RANGE_FLAG
+
+
+def f32x_range_tripped(reset=True):
+    """True when a split-fp32 kernel wrote a non-finite output since the last reset (synchronises the device)"""
+    if _RANGE_FLAG is None:
+        return False
+    hit = bool(_RANGE_FLAG.item())
+    if hit and reset:
+        _RANGE_FLAG.zero_()
+    return hit
+
+
 def set_f32_mode(mode):
     global F32_MODE
     if mode not in ("split", "mfma"):
@@ -218,8 +240,6 @@ def pack_conv_weight(w_oihw, cout_pad=None, cin_pad=None, dtype=torch.float32):
 # ------------------------------------------------------------------------------------------------
 # conv / GEMM (MFMA implicit GEMM)
 # ------------------------------------------------------------------------------------------------
-CONV_TRACE = None  # set to a list by bench.py's profiling pass: (desc copy, flops, start event, end event)
-
 # ---- autotuned launch plans (sgam_neurips22_amd/tune.py): shape key -> (bm, bn, ksplit) ----
 PLAN_CACHE = {}
 PLAN_RECORD = None  # set to a dict by the tuner to collect the distinct shapes of a model run
@@ -275,22 +295,6 @@ def _run_conv(desc, x, w, bias, residual, out, gn=None, a_scale=1.0, norm=None):
             gn = (groupnorm_meanrstd(x, eps), gamma, beta, swish)
         else:
             x = groupnorm_nhwc(x, gamma, beta, swish, groups, eps)
-    if CONV_TRACE is not None:
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-        _run_conv_inner(lib, desc, x, w, bias, residual, out, gn, a_scale)
-        ev1.record()
-        flops = 2.0 * desc.B * desc.Ho * desc.Wo * desc.n_valid * desc.KH * desc.KW * desc.Cin
-        plan = conv_plan(desc, x.dtype in H16, split)
-        if split:
-            halo = a_scale == 1.0 and lib.sgam_conv2d_f32x_uses_halo(ctypes.byref(desc)) == 1
-            kernel = f"{'conv3x3_f32x_halo2_kernel' if halo else 'conv_gemm_f32x_kernel'}<{plan[0]},{plan[1]}>"
-        else:
-            kernel = f"{'conv_gemm_h16_kernel' if x.dtype in H16 else 'conv_gemm_f32_v2_kernel'}<{plan[0]},{plan[1]}>"
-        CONV_TRACE.append((plan + ("f32x" if split else str(x.dtype).replace("torch.", ""), kernel,
-                                   plan_key(desc, "f32x" if split else x.dtype)),
-                           (desc.B * desc.Ho * desc.Wo, desc.n_valid, desc.KH * desc.KW * desc.Cin), flops, ev0, ev1))
-        return out
     return _run_conv_inner(lib, desc, x, w, bias, residual, out, gn, a_scale)
 
 

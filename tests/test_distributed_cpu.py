@@ -53,3 +53,28 @@ def test_single_process_gather_is_identity():
     from sgam_neurips22_amd.distributed import gather_metrics
     g = gather_metrics(31, 0.5, 7, "cpu")
     assert g["total_frames"] == 31 and g["frames_per_s"] == 62.0 and g["per_rank"] == [(31.0, 0.5, 7.0)]
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus2_self_launches_two_ranks():
+    """`python bench.py --gpus 2` (no torchrun environment) must start 2 ranks by itself; --dry-run takes them through
+    scene sharding and the metric all-gather over gloo without touching a GPU."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1",
+                        "--dry-run"], capture_output=True, text=True, env=env, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1, r.stdout
+    out = json.loads(line[0])
+    assert out["n_gpus"] == 2 and out["dry_run"] is True and out["scenes_per_rank"] == [0.0, 1.0]
+    assert abs(out["value"] - 10 / 1.01) < 1e-9          # 2 ranks x 5 frames / max(1.00, 1.01) s
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    import subprocess
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True,
+                       text=True, env=env, timeout=120)
+    assert r.returncode != 0 and "--gpus 2" in (r.stderr + r.stdout)
