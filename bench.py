@@ -79,8 +79,12 @@ def frame_timeline(scene):
 
     one()                                        # eager warm-up (allocator pools, first-use paths)
     recs, bracket = ops.kernel_timeline(one)
+    if os.environ.get("SGAM_DUMP_TIMELINE"):      # every launch of the frame, in order: kernel, us (net), GEMM view
+        with open(os.environ["SGAM_DUMP_TIMELINE"], "w") as f:
+            for name, ms, flops, nbytes, shp in recs:
+                f.write(f"{name}\t{1e3 * max(ms - bracket, 0):.2f}\t{flops / 1e9:.3f}\t{shp[0]}x{shp[1]}x{shp[2]}/{shp[3]}\n")
     agg = {}
-    for name, ms, flops, nbytes in recs:
+    for name, ms, flops, nbytes, _shp in recs:
         a = agg.setdefault(name, {"calls": 0, "ms": 0.0, "gflop": 0.0, "gbyte": 0.0})
         a["calls"] += 1
         a["ms"] += max(ms - bracket, 0.0)

@@ -45,6 +45,8 @@ int sgam_prof_enable(int32_t on);
 int sgam_prof_mark_empty(void *stream);
 int32_t sgam_prof_count(void);
 int sgam_prof_get(int32_t i, const char **kernel, const char **where, float *ms, double *flops, double *bytes);
+/* GEMM view of record i where the launch site announced one: mnks[4] = {M, N, K, split-K factor}, zeros otherwise */
+int sgam_prof_get_shape(int32_t i, int32_t *mnks);
 
 /* ------------------------------------------------------------------------------------------
  * K1/K2/K3/K6 — convolution as implicit GEMM on the matrix cores (fp32-in/fp32-acc MFMA).

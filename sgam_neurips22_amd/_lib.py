@@ -30,6 +30,7 @@ PROTOTYPES = {
     "sgam_prof_count": (c_i32, []),
     "sgam_prof_get": (c_i32, [c_i32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_char_p),
                               ctypes.POINTER(c_f32), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "sgam_prof_get_shape": (c_i32, [c_i32, ctypes.POINTER(c_i32)]),
     "sgam_conv2d_workspace_bytes": (c_i64, [ctypes.POINTER(ConvDesc)]),
     "sgam_conv2d_plan": (c_i32, [ctypes.POINTER(ConvDesc), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32),
                                  ctypes.POINTER(c_i32)]),

@@ -1072,6 +1072,7 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
     const bool halo = halo_eligible(d, pl, a_scale);
     if (ex.gn_stats && !halo) return SGAM_EINVAL;
     // algorithmic work of this launch: 2 M N K fp32 FLOP; bytes = input + weights + output once
+    if (sgam_i_prof_on) sgam_i_prof_shape(p.M, d->n_valid, d->KH * d->KW * d->Cin, pl.ksplit);
     if (sgam_i_prof_on)
         sgam_i_prof_work(2.0 * p.M * d->n_valid * (double)(d->KH * d->KW * d->Cin),
                          4.0 * ((double)d->B * d->Hi * d->Wi * d->Cin + (double)d->n_valid * d->KH * d->KW * d->Cin +

@@ -879,6 +879,7 @@ extern "C" int sgam_conv2d_gn_nhwc_f32(const sgam_conv_desc *d, const float *x, 
     }
     const dim3 grid(sgam_cdiv(p.M, pl.bm), sgam_cdiv(p.N, pl.bn), pl.ksplit);
     hipStream_t s = sgam_stream(stream);
+    if (sgam_i_prof_on) sgam_i_prof_shape(p.M, d->n_valid, d->KH * d->KW * d->Cin, pl.ksplit);
     if (sgam_i_prof_on)
         sgam_i_prof_work(2.0 * p.M * d->n_valid * (double)(d->KH * d->KW * d->Cin),
                          4.0 * ((double)d->B * d->Hi * d->Wi * d->Cin + (double)d->n_valid * d->KH * d->KW * d->Cin +

@@ -139,12 +139,17 @@ struct ProfRec {
     const char *kernel, *where;
     hipEvent_t e0, e1;
     double flops, bytes;
+    int shape[4];
 };
 constexpr int PROF_MAX = 16384;
 ProfRec *g_prof = nullptr;
 int g_prof_n = 0, g_prof_events = 0;
 double g_work_flops = 0.0, g_work_bytes = 0.0;
+int g_shape[4] = {0, 0, 0, 0};
 }  // namespace
+extern "C" void sgam_i_prof_shape(int m, int n, int k, int ksplit) {
+    g_shape[0] = m; g_shape[1] = n; g_shape[2] = k; g_shape[3] = ksplit;
+}
 extern "C" int sgam_i_prof_on = 0;
 extern "C" void sgam_i_prof_work(double flops, double bytes) {
     g_work_flops = flops;
@@ -162,6 +167,7 @@ extern "C" void sgam_i_prof_begin(const char *kernel, const char *where, hipStre
     r.flops = g_work_flops;
     r.bytes = g_work_bytes;
     g_work_flops = g_work_bytes = 0.0;
+    for (int i = 0; i < 4; ++i) { r.shape[i] = g_shape[i]; g_shape[i] = 0; }
     (void)hipEventRecord(r.e0, s);
 }
 extern "C" void sgam_i_prof_end(hipStream_t s) {
@@ -182,6 +188,11 @@ extern "C" int sgam_prof_mark_empty(void *stream) {   // an event pair around no
     return SGAM_OK;
 }
 extern "C" int32_t sgam_prof_count(void) { return g_prof_n; }
+extern "C" int sgam_prof_get_shape(int32_t i, int32_t *mnks) {   // GEMM view of the launch: M, N, K, split-K factor (0: n/a)
+    if (i < 0 || i >= g_prof_n || !mnks) return SGAM_EINVAL;
+    for (int j = 0; j < 4; ++j) mnks[j] = g_prof[i].shape[j];
+    return SGAM_OK;
+}
 extern "C" int sgam_prof_get(int32_t i, const char **kernel, const char **where, float *ms, double *flops, double *bytes) {
     if (i < 0 || i >= g_prof_n || !kernel || !where || !ms || !flops || !bytes) return SGAM_EINVAL;
     const ProfRec &r = g_prof[i];

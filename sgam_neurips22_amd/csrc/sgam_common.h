@@ -22,6 +22,7 @@ extern "C" int sgam_i_prof_on;
 extern "C" void sgam_i_prof_begin(const char *kernel, const char *where, hipStream_t s);
 extern "C" void sgam_i_prof_end(hipStream_t s);
 extern "C" void sgam_i_prof_work(double flops, double bytes);
+extern "C" void sgam_i_prof_shape(int m, int n, int k, int ksplit);
 #define SGAM_KLAUNCH(kern, grid, blk, shm, st, ...)                            \
     do {                                                                       \
         if (sgam_i_prof_on) sgam_i_prof_begin(#kern, __PRETTY_FUNCTION__, st); \

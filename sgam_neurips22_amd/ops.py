@@ -179,7 +179,7 @@ def _kernel_name(kernel, where):
 
 def kernel_timeline(fn, empty_brackets=32):
     """Run fn() with the library's per-kernel HIP-event brackets on (include/sgam_hip.h, sgam_prof_*): returns
-    (records, bracket_ms) — records = [(kernel name, ms, flops, bytes)] in launch order, elapsed times as measured (the
+    (records, bracket_ms) — records = [(kernel name, ms, flops, bytes, (M, N, K, ksplit))] in launch order, elapsed times as measured (the
     caller subtracts bracket_ms, the median cost of a bracket around nothing).  Eager launches only (no graph replay)."""
     lib = _lib.load()
     torch.cuda.synchronize()
@@ -197,13 +197,15 @@ def kernel_timeline(fn, empty_brackets=32):
     recs, empties = [], []
     k, w = ctypes.c_char_p(), ctypes.c_char_p()
     ms, fl, by = ctypes.c_float(), ctypes.c_double(), ctypes.c_double()
+    shp = (ctypes.c_int32 * 4)()
     for i in range(lib.sgam_prof_count()):
         check(lib.sgam_prof_get(i, ctypes.byref(k), ctypes.byref(w), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)),
               "sgam_prof_get")
         if k.value == b"(empty)":
             empties.append(ms.value)
         else:
-            recs.append((_kernel_name(k.value.decode(), (w.value or b"").decode()), ms.value, fl.value, by.value))
+            lib.sgam_prof_get_shape(i, shp)
+            recs.append((_kernel_name(k.value.decode(), (w.value or b"").decode()), ms.value, fl.value, by.value, tuple(shp)))
     empties.sort()
     return recs, (empties[len(empties) // 2] if empties else 0.0)
 
