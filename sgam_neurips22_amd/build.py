@@ -21,7 +21,8 @@ SOURCES = {
     "conv_f32x.hip": [f"-DSGAM_XPF_BIG={os.environ.get('SGAM_XPF_BIG', '1')}",
                       f"-DSGAM_XPF_SMALL={os.environ.get('SGAM_XPF_SMALL', '2')}",
                       f"-DSGAM_XABLATE={os.environ.get('SGAM_XABLATE', '0')}",
-                      f"-DSGAM_XSB={os.environ.get('SGAM_XSB', '1')}"],
+                      f"-DSGAM_XSB={os.environ.get('SGAM_XSB', '1')}",
+                      f"-DSGAM_XWGM={os.environ.get('SGAM_XWGM', '1')}"],
     "attention.hip": [f"-DSGAM_ATTN_ABLATE={os.environ.get('SGAM_ATTN_ABLATE', '0')}"],
     "vq.hip": ["-ffp-contract=off"],
     "layout.hip": ["-ffp-contract=off"],

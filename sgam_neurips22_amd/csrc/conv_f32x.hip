@@ -537,13 +537,19 @@ __global__ __launch_bounds__(256 * wk_of(BM, BN)) void conv_gemm_f32x_kernel(con
 // ((p + k - 1) >> 1) + 1 per axis.
 template <int BM, int BN, bool GN, bool UPS = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParams p) {
-    constexpr int WGM_ = 1;          // four wavefronts side by side along N: each owns all BM rows x BN / 4 channels
+#ifndef SGAM_XWGM
+#define SGAM_XWGM 1
+#endif
+    // wavefront layout: 1 = four wavefronts side by side along N (each owns all BM rows x BN / 4 channels: every A fragment
+    // is read from LDS by all four), 2 = a 2 x 2 grid (each owns BM / 2 rows x BN / 2 channels: half the LDS reads of A,
+    // twice the weight-fragment loads, which two wavefronts share in the vector L1)
+    constexpr int WGM_ = SGAM_XWGM, WGN_ = 4 / WGM_;
     constexpr int TH = 8, TW = BM / 8, TWS = (TW == 16) ? 4 : 3;
     constexpr int HROWS = UPS ? TH / 2 + 2 : TH + 2, HWID = UPS ? TW / 2 + 2 : TW + 2, HR = HROWS * HWID;
     static_assert(!(UPS && GN), "no GroupNorm precedes an upsampling conv");
     static_assert(BM == 128 || BM == 64, "8 x 16 or 8 x 8 output patches");
     constexpr int XBK = 32, XLD = XBK + 8;
-    constexpr int TM = BM / 32, TN = BN / 128;
+    constexpr int TM = BM / (32 * WGM_), TN = BN / (32 * WGN_);
     // halo pixel (hy, hx) sits at hy * LP + hx * XLD halfs; the line pitch LP is padded (720 -> 768, 400 -> 448) so that
     // the 16-lane groups of ds_read_b128, which straddle two or more patch rows, land on 16 distinct bank quads for
     // every tap offset (found by enumeration over the hardware's lane groups)
@@ -559,7 +565,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wn = wave;
+    const int wm = WGM_ == 2 ? wave >> 1 : 0, wn = WGM_ == 2 ? (wave & 1) : wave;
     int bx, by, bz;
     xcd_block(p, bx, by, bz);
     const int n0 = by * BN;
@@ -591,7 +597,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         // fragment-ordered weights: lane l reads piece (plane, k-step) * 64 + l of its 32-row tile: one contiguous KB
-        const int nt = (n0 + wn * (BN / 4) + j * 32) >> 5;
+        const int nt = (n0 + wn * (BN / WGN_) + j * 32) >> 5;
         bf_off[j] = ((unsigned)nt * ((unsigned)p.ldb / 32u) * 256u + (unsigned)lane) * 16u;
     }
 
@@ -672,7 +678,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
     int a_base[TM], a_py[TM], a_px[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int r = i * 32 + frag_row;
+        const int r = wm * (BM / WGM_) + i * 32 + frag_row;
         a_py[i] = r >> TWS;
         a_px[i] = r & (TW - 1);
         a_base[i] = a_py[i] * LP + a_px[i] * XLD + frag_k;
@@ -705,9 +711,47 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
             fa[set][i][1] = *reinterpret_cast<const u32x4 *>(ah + HPL + kk * 16);
         }
     };
+    // The A fragments of the plain (non-upsampling) kernel come out of LDS through EXPLICIT ds_read_b128 statements, one
+    // step (12 or 6 MFMAs) ahead of their use, retired by a counted wait: left to the compiler the reads are sunk next to
+    // the MFMA that consumes them (one register quad re-used for all of them), and every MFMA then waits out an LDS round
+    // trip (rocprof: matrix pipe 47 % busy).  Address = per-row base register + compile-time (tap, k-step, plane) offset.
+#define XDS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+    unsigned a_lds[TM];                    // LDS byte address of (this lane's row of m tile i, tap (0,0), k-step 0, hi plane)
+    auto afrag_asm = [&](const int set, const int tap, const int kk) {
+        const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            XDS_READ(fa[set][i][0], a_lds[i], 2 * (ky * LP + kx * XLD + kk * 16));
+            XDS_READ(fa[set][i][1], a_lds[i], 2 * (ky * LP + kx * XLD + kk * 16 + HPL));
+        }
+    };
+    // all reads but the newest 2 * TM (= the set issued for the NEXT step) have landed; the fragment registers are tied to
+    // the wait so that no MFMA moves above it
+    auto await = [&](const int set, const bool next_in_flight) {
+        if constexpr (TM == 4) {
+            if (next_in_flight)
+                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(fa[set][0][0]), "+v"(fa[set][0][1]), "+v"(fa[set][1][0]), "+v"(fa[set][1][1]),
+                             "+v"(fa[set][2][0]), "+v"(fa[set][2][1]), "+v"(fa[set][3][0]), "+v"(fa[set][3][1]));
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[set][0][0]), "+v"(fa[set][0][1]), "+v"(fa[set][1][0]), "+v"(fa[set][1][1]),
+                             "+v"(fa[set][2][0]), "+v"(fa[set][2][1]), "+v"(fa[set][3][0]), "+v"(fa[set][3][1]));
+        } else {
+            static_assert(TM == 2 || TM == 4, "wait counts are spelled for 2 or 4 row tiles");
+            if (next_in_flight)
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[set][0][0]), "+v"(fa[set][0][1]), "+v"(fa[set][1][0]), "+v"(fa[set][1][1]));
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[set][0][0]), "+v"(fa[set][0][1]), "+v"(fa[set][1][0]), "+v"(fa[set][1][1]));
+        }
+    };
+    constexpr bool XASM = !UPS && (SGAM_XABLATE != 30);
     for (int sl = s0; sl < s1; ++sl) {
         const bool has_next = sl + 1 < s1;
         hb = smem + hcur * HBUF;
+        if constexpr (XASM) {
+            const unsigned hb_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short *)hb;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a_lds[i] = hb_lds + 2u * (unsigned)a_base[i];
+        }
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int set = tap % 3;
@@ -725,8 +769,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
             for (int kk = 0; kk < 2; ++kk) {
                 const int q = tap * 2 + kk;                 // step inside the slab: 0 .. 17
                 // A fragments are read one step ahead (register double buffer fa[q & 1]); step 0 reads its own
-                if (q == 0) afrag(0, 0, 0);
-                if (q < 17) afrag((q + 1) & 1, (q + 1) >> 1, (q + 1) & 1);
+                if constexpr (XASM) {
+                    if (q == 0) afrag_asm(0, 0, 0);
+                    if (q < 17) afrag_asm((q + 1) & 1, (q + 1) >> 1, (q + 1) & 1);
+                    await(q & 1, q < 17);
+                } else {
+                    if (q == 0) afrag(0, 0, 0);
+                    if (q < 17) afrag((q + 1) & 1, (q + 1) >> 1, (q + 1) & 1);
+                }
                 // term-major order: the three MFMAs of one accumulator are TM * TN instructions apart
 #pragma unroll
                 for (int term = 0; term < 3; ++term)
