@@ -18,6 +18,7 @@ SOURCES = {
     "norm_softmax.hip": [],
     "groupnorm.hip": [],
     "h16.hip": [],
+    "h16_halo.hip": [],
     "conv_f32x.hip": [f"-DSGAM_XPF_BIG={os.environ.get('SGAM_XPF_BIG', '1')}",
                       f"-DSGAM_XPF_SMALL={os.environ.get('SGAM_XPF_SMALL', '2')}",
                       f"-DSGAM_XABLATE={os.environ.get('SGAM_XABLATE', '0')}",

@@ -468,6 +468,55 @@ extern "C" int sgam_groupnorm_meanrstd_nhwc_f32(const float *x, float *mean_rstd
     return SGAM_OK;
 }
 
+// 16-bit tensors (bf16 ht = 0 / fp16 ht = 1) whose producer — the 16-bit halo conv (h16_halo.hip) — left partial statistics:
+// finalize + apply only, and {mean, rstd} for consumers that normalise while staging
+extern "C" int sgam_groupnorm_from_partials_h16(const void *x, const double *partial, int32_t nchunk, const float *gamma,
+                                                const float *beta, void *y, int32_t ht, int32_t B, int32_t HW, int32_t C,
+                                                int32_t groups, float eps, int32_t fuse_swish, void *workspace,
+                                                int64_t workspace_bytes, void *stream) {
+    if (!x || !y || !partial || nchunk <= 0 || !gamma || !beta || !gn_shape_ok(B, HW, C, groups) || (ht != 0 && ht != 1))
+        return SGAM_EINVAL;
+    if (!sgam_aligned16(x) || !sgam_aligned16(y) || !sgam_aligned16(workspace) || !sgam_aligned16(partial)) return SGAM_EALIGN;
+    if (!workspace || workspace_bytes < (int64_t)B * C * 2 * (int64_t)sizeof(float)) return SGAM_EWORKSPACE;
+    hipStream_t s = sgam_stream(stream);
+    float *table = (float *)workspace;
+    SGAM_KLAUNCH(gn_finalize_kernel, dim3(groups, B), dim3(256), 0, s, partial, gamma, beta, table, HW, C, groups, nchunk, eps);
+    SGAM_LAUNCH_CHECK();
+    const int cv = C / 8;
+    int bpb = sgam_cdiv((int64_t)HW * cv, 256 * 4);
+    if (bpb > 4096) bpb = 4096;
+    if (bpb < 1) bpb = 1;
+    if (ht == 0)
+        SGAM_KLAUNCH(gn_apply_kernel<0>, dim3(bpb * B), dim3(256), 0, s, (const unsigned short *)x, table, (unsigned short *)y, HW, C,
+                     fuse_swish, bpb);
+    else
+        SGAM_KLAUNCH(gn_apply_kernel<1>, dim3(bpb * B), dim3(256), 0, s, (const unsigned short *)x, table, (unsigned short *)y, HW, C,
+                     fuse_swish, bpb);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+extern "C" int sgam_groupnorm_meanrstd_nhwc_h16(const void *x, float *mean_rstd, int32_t ht, int32_t B, int32_t HW, int32_t C,
+                                                int32_t groups, float eps, void *workspace, int64_t workspace_bytes,
+                                                void *stream) {
+    if (!x || !mean_rstd || !gn_shape_ok(B, HW, C, groups) || (ht != 0 && ht != 1)) return SGAM_EINVAL;
+    if (!sgam_aligned16(x) || !sgam_aligned16(workspace)) return SGAM_EALIGN;
+    if (!workspace || workspace_bytes < sgam_groupnorm_workspace_bytes(B, HW, C)) return SGAM_EWORKSPACE;
+    hipStream_t s = sgam_stream(stream);
+    const int nchunk = gn_nchunk(HW, C, 8);
+    double *partial = (double *)workspace;
+    if (ht == 0)
+        SGAM_KLAUNCH(gn_partial_kernel<0>, dim3(nchunk, B), dim3(GT), 0, s, (const unsigned short *)x, partial, HW, C, groups,
+                     sgam_cdiv(HW, nchunk));
+    else
+        SGAM_KLAUNCH(gn_partial_kernel<1>, dim3(nchunk, B), dim3(GT), 0, s, (const unsigned short *)x, partial, HW, C, groups,
+                     sgam_cdiv(HW, nchunk));
+    SGAM_LAUNCH_CHECK();
+    SGAM_KLAUNCH(gn_finalize_stats_kernel, dim3(groups, B), dim3(256), 0, s, partial, mean_rstd, HW, C, groups, nchunk, eps);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
 extern "C" int sgam_groupnorm_stats_nhwc_f32(const float *x, const float *gamma, const float *beta,
                                              float *scale_shift, int32_t B, int32_t HW, int32_t C, int32_t groups,
                                              float eps, void *workspace, int64_t workspace_bytes, void *stream) {

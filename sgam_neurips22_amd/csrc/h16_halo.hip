@@ -1,0 +1,493 @@
+// h16_halo.hip — the 3x3 / stride 1 / pad 1 convolutions of the 16-bit throughput mode (bf16 or fp16 activations and
+// weights, fp32 accumulation) on the design of the split-fp32 halo kernel (conv_f32x.hip), re-balanced for ONE MFMA per
+// product instead of three:
+//   * a workgroup owns an 8 x 16 (8 x 8) patch of output pixels and stages the 10 x 18 (10 x 10) halo of the patch ONCE
+//     per 32-channel slab (16-bit: 64 bytes per halo pixel, one LDS plane); the nine taps read their MFMA A fragments from
+//     it at a wavefront-uniform offset, through explicit ds_read_b128 statements one step ahead;
+//   * GroupNorm(+swish) of the input is applied while the halo is staged (fp32 arithmetic, one rounding to 16 bits), from
+//     {mean, rstd} per (image, group): the stand-alone normalise pass (statistics + finalize + apply: three launches and two
+//     trips over the activation in this mode) disappears; the statistics of the OUTPUT leave the epilogue as per-chunk
+//     partial sums exactly like the split-fp32 kernel's, so ResnetBlock = conv -> fold -> conv -> fold here too;
+//   * weights are stored in MFMA-fragment order (one plane): per (32-row tile, 32-element K slab) 128 pieces of 16 bytes,
+//     piece = (k-step * 2 + k-half) * 32 + row — the B operand of one v_mfma_f32_32x32x16 is one contiguous kilobyte that
+//     goes straight from L2 / L1 to registers, two taps ahead;
+//   * with a third of the MFMA time per fragment, the wavefronts form a 2 x 2 grid (each owns BM / 2 rows x BN / 2 = 64
+//     channels): every A fragment read from LDS and every B fragment fetched feeds TWO MFMAs (the 1 x 4 layout of the
+//     split-fp32 kernel would need one 1 KB LDS read per MFMA — the LDS port's whole bandwidth);
+//   * epilogue: accumulators -> wave-private LDS transpose -> 8-byte row-contiguous stores of four 16-bit channels (or 16
+//     bytes of fp32), bias / residual fused (the generic 16-bit kernel stores 2 bytes per instruction).
+// Split-K plans are not taken here (the small maps keep the generic kernel of h16.hip).
+#include <stdlib.h>
+
+#include "sgam_common.h"
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <int HT> struct HH;
+template <> struct HH<0> {
+    __device__ static __forceinline__ float to_f(unsigned short u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
+    __device__ static __forceinline__ unsigned short from_f(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+    __device__ static __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct HH<1> {
+    __device__ static __forceinline__ float to_f(unsigned short u) { return (float)__builtin_bit_cast(_Float16, u); }
+    __device__ static __forceinline__ unsigned short from_f(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
+    __device__ static __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+
+struct HHParams {
+    const unsigned short *x, *w, *res;
+    const float *bias;
+    void *out;                    // 16-bit or fp32 (out_f32)
+    int B, Hi, Wi, Cin, Ho, Wo, N, ups;
+    int lda, ldb, ldc, ldr, n_valid, out_f32;
+    int M, slabs;
+    int gx, gy, xcd_swizzle;
+    unsigned x_bytes, w_bytes;
+    const float *gn_stats, *gn_gamma, *gn_beta;   // GroupNorm(+swish) of the input: {mean, rstd} [B][32][2] + affine [Cin]
+    int gn_swish;
+    double *gn_partial;           // optional: per-(tile row half, group) {sum, sumsq} of the output
+    int gn_cpg;
+};
+
+__device__ __forceinline__ unsigned hsel(bool c, unsigned a, unsigned b) {
+    const unsigned m = 0u - (unsigned)c;
+    return (a & m) | (b & ~m);
+}
+
+__device__ __forceinline__ void hxcd_block(const HHParams &p, int &bx, int &by) {
+    const unsigned L = blockIdx.x, T = gridDim.x;
+    unsigned Lp = L;
+    if (p.xcd_swizzle) {
+        const unsigned q = T >> 3, r = T & 7u, xcd = L & 7u, idx = L >> 3;
+        Lp = xcd * q + (xcd < r ? xcd : r) + idx;
+    }
+    bx = (int)(Lp % (unsigned)p.gx);
+    by = (int)(Lp / (unsigned)p.gx);
+}
+
+template <int BM, int BN, int HT, bool GN, bool UPS>
+__global__ __launch_bounds__(256, 2) void conv3x3_h16_halo_kernel(const HHParams p) {
+    constexpr int TH = 8, TW = BM / 8, TWS = (TW == 16) ? 4 : 3;
+    constexpr int HROWS = UPS ? TH / 2 + 2 : TH + 2, HWID = UPS ? TW / 2 + 2 : TW + 2, HR = HROWS * HWID;
+    static_assert(!(UPS && GN), "no GroupNorm precedes an upsampling conv");
+    static_assert(BM == 128 || BM == 64, "8 x 16 or 8 x 8 output patches");
+    static_assert(BN == 128, "2 x 2 wavefronts of 64 channels");
+    constexpr int XBK = 32, XLD = XBK + 8;
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int LP = UPS ? ((TW == 16) ? 408 : 240) : ((TW == 16) ? 768 : 448);   // line pitch (halfs), see conv_f32x.hip
+    constexpr int HPL = HROWS * LP;                     // halfs per halo buffer (one plane)
+    constexpr int NH = (HR * 4 + 255) / 256;            // 16-byte halo pieces (8 channels) per thread
+    constexpr int OP_BYTES = 2 * HPL * 2;
+    constexpr int WM = 32 * TM, WN = 32 * TN, LDR = WN + 4;
+    constexpr int EPI_BYTES = 4 * WM * LDR * 4;
+    constexpr int SM_BYTES = OP_BYTES > EPI_BYTES ? OP_BYTES : EPI_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned short smem[SM_BYTES / 2];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int bx, by;
+    hxcd_block(p, bx, by);
+    const int n0 = by * BN;
+    const int tiles_x = p.Wo / TW, tiles_img = tiles_x * (p.Ho / TH);
+    const int b = bx / tiles_img;
+    const int t_img = bx - b * tiles_img;
+    const int ty0 = (t_img / tiles_x) * TH, tx0 = (t_img % tiles_x) * TW;
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, (int)p.w_bytes, 0x00020000);
+
+    unsigned h_off[NH];
+    int h_lds[NH];
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+        const int idx = tid + 256 * j;
+        const int row = idx >> 2, c8 = idx & 3;
+        const int hy = row / HWID, hx = row - hy * HWID;
+        const int iy = (UPS ? ty0 / 2 : ty0) + hy - 1, ix = (UPS ? tx0 / 2 : tx0) + hx - 1;
+        const bool ok = row < HR && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        h_off[j] = ok ? (unsigned)(((b * p.Hi + iy) * p.Wi + ix) * p.lda + c8 * 8) * 2u : 0xFFFFFFFFu;
+        h_lds[j] = row < HR ? hy * LP + hx * XLD + c8 * 8 : -1;
+    }
+    unsigned bf_off[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nt = (n0 + wn * (BN / 2) + j * 32) >> 5;
+        bf_off[j] = ((unsigned)nt * ((unsigned)p.ldb / 32u) * 128u + (unsigned)lane) * 16u;
+    }
+
+    u32x4 hreg[NH];
+    float gsc[8], gsh[8];                  // GroupNorm scale / shift of this thread's 8 channels of the slab in flight
+    auto hload = [&](int ch, bool live) {
+        const unsigned coff = (unsigned)ch * (XBK * 2u);
+#pragma unroll
+        for (int j = 0; j < NH; ++j) {
+            const unsigned o = hsel(live && h_off[j] != 0xFFFFFFFFu, h_off[j] + coff, p.x_bytes);
+            hreg[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)o, 0, 0);
+        }
+        if constexpr (GN) {
+            const int c = (live ? ch : 0) * XBK + (tid & 3) * 8;
+            const int cpg = p.Cin / 32;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {            // two float4 halves: a 4-channel group never straddles one
+                const int g = (c + 4 * h) / cpg;
+                const float mean = p.gn_stats[(b * 32 + g) * 2], rstd = p.gn_stats[(b * 32 + g) * 2 + 1];
+                const f32x4 ga = *reinterpret_cast<const f32x4 *>(p.gn_gamma + c + 4 * h);
+                const f32x4 be = *reinterpret_cast<const f32x4 *>(p.gn_beta + c + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    gsc[4 * h + e] = rstd * ga[e];
+                    gsh[4 * h + e] = be[e] - mean * gsc[4 * h + e];
+                }
+            }
+        }
+    };
+    auto hprep_piece = [&](const int j) {
+        if constexpr (GN) {
+            u32x4 q = hreg[j];
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2) {
+                float v0 = HH<HT>::to_f((unsigned short)(q[w2] & 0xFFFFu)), v1 = HH<HT>::to_f((unsigned short)(q[w2] >> 16));
+                v0 = v0 * gsc[2 * w2] + gsh[2 * w2];
+                v1 = v1 * gsc[2 * w2 + 1] + gsh[2 * w2 + 1];
+                if (p.gn_swish) {
+                    v0 = sgam_swish(v0);
+                    v1 = sgam_swish(v1);
+                }
+                q[w2] = (unsigned)HH<HT>::from_f(v0) | ((unsigned)HH<HT>::from_f(v1) << 16);
+            }
+            if (h_off[j] == 0xFFFFFFFFu) q = u32x4{0u, 0u, 0u, 0u};       // zero padding applies to the normalised tensor
+            hreg[j] = q;
+        }
+    };
+    auto hstore = [&](int hb) {
+        unsigned short *halo = smem + hb * HPL;
+#pragma unroll
+        for (int j = 0; j < NH; ++j)
+            if (h_lds[j] >= 0) *reinterpret_cast<u32x4 *>(halo + h_lds[j]) = hreg[j];
+    };
+
+    u32x4 bq[3][TN][2];                    // [tap % 3][n tile][k-step]
+    auto bload = [&](const int set, int tap, int ch, bool live) {
+        const unsigned koff = (unsigned)(tap * p.Cin + ch * XBK) * 64u;   // 2048 bytes per (row tile, slab)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                bq[set][j][kk] = __builtin_amdgcn_raw_buffer_load_b128(
+                    rw, (int)hsel(live, bf_off[j] + koff + (unsigned)(kk * 1024), p.w_bytes), 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int frag_row = lane & 31;
+    const int frag_k = (lane >> 5) * 8;
+    int a_base[TM], a_py[TM], a_px[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = wm * (BM / 2) + i * 32 + frag_row;
+        a_py[i] = r >> TWS;
+        a_px[i] = r & (TW - 1);
+        a_base[i] = a_py[i] * LP + a_px[i] * XLD + frag_k;
+    }
+
+    const int s1 = p.slabs;
+    int hcur = 0;
+    hload(0, true);
+    bload(0, 0, 0, true);
+    bload(1, 1, 0, true);
+#pragma unroll
+    for (int j = 0; j < NH; ++j) hprep_piece(j);
+    hstore(0);
+    hload(1, 1 < s1);
+    __syncthreads();
+
+    u32x4 fa[2][TM];
+    const unsigned short *hb = smem;
+    auto afrag = [&](const int set, const int tap, const int kk) {          // upsampling form: per-lane source pixel
+        const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const unsigned short *ah = hb + (((a_py[i] + ky - 1) >> 1) + 1) * LP + (((a_px[i] + kx - 1) >> 1) + 1) * XLD + frag_k;
+            fa[set][i] = *reinterpret_cast<const u32x4 *>(ah + kk * 16);
+        }
+    };
+#define HDS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+    unsigned a_lds[TM];
+    auto afrag_asm = [&](const int set, const int tap, const int kk) {
+        const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) HDS_READ(fa[set][i], a_lds[i], 2 * (ky * LP + kx * XLD + kk * 16));
+    };
+    auto await = [&](const int set, const bool next_in_flight) {      // all reads but the newest TM have landed
+        if constexpr (TM == 2) {
+            if (next_in_flight) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[set][0]), "+v"(fa[set][1]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[set][0]), "+v"(fa[set][1]));
+        } else {
+            static_assert(TM == 1 || TM == 2, "wait counts are spelled for 1 or 2 row tiles");
+            if (next_in_flight) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(fa[set][0]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[set][0]));
+        }
+    };
+    for (int sl = 0; sl < s1; ++sl) {
+        const bool has_next = sl + 1 < s1;
+        hb = smem + hcur * HPL;
+        if constexpr (!UPS) {
+            const unsigned hb_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short *)hb;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a_lds[i] = hb_lds + 2u * (unsigned)a_base[i];
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int set = tap % 3;
+            if (tap < 7) bload((tap + 2) % 3, tap + 2, sl, true);
+            else bload((tap + 2) % 3, tap - 7, sl + 1, has_next);
+            if (tap >= 1 && tap <= NH) hprep_piece(tap - 1);            // next slab's halo, one piece per tap
+            if (tap == NH + 1) {
+                hstore(hcur ^ 1);
+                hload(sl + 2, sl + 2 < s1);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int q = tap * 2 + kk;
+                if constexpr (!UPS) {
+                    if (q == 0) afrag_asm(0, 0, 0);
+                    if (q < 17) afrag_asm((q + 1) & 1, (q + 1) >> 1, (q + 1) & 1);
+                    await(q & 1, q < 17);
+                } else {
+                    if (q == 0) afrag(0, 0, 0);
+                    if (q < 17) afrag((q + 1) & 1, (q + 1) >> 1, (q + 1) & 1);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = HH<HT>::mfma(fa[q & 1][i], bq[set][j][kk], acc[i][j]);
+            }
+        }
+        __syncthreads();
+        hcur ^= 1;
+    }
+    __syncthreads();
+
+    // ---- epilogue: wave-private LDS transpose, then every lane owns 4 consecutive channels of one pixel
+    float *region = reinterpret_cast<float *>(smem) + wave * (WM * LDR);
+    const int n_lim = p.n_valid;
+    const unsigned osz = p.out_f32 ? 4u : 2u;
+    const unsigned o_bytes = (unsigned)(((int64_t)(p.M - 1) * p.ldc + n_lim) * osz);
+    const unsigned r_bytes = p.res ? (unsigned)(((int64_t)(p.M - 1) * p.ldr + p.n_valid) * 2) : 0u;
+    const unsigned bias_bytes = p.bias ? (unsigned)(p.N * 4) : 0u;
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)o_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void *)p.res, 0, (int)r_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)p.bias, 0, (int)bias_bytes, 0x00020000);
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    const int col_l = lane & 31, row_h = 4 * (lane >> 5);
+    const int wn0 = n0 + wn * (BN / 2);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = wn0 + j * 32 + col_l;
+            const float bias_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                              rb, (int)hsel(n < n_lim, (unsigned)n * 4u, OOB), 0, 0));
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                region[(i * 32 + (e & 3) + 8 * (e >> 2) + row_h) * LDR + j * 32 + col_l] = acc[i][j][e] + bias_n;
+        }
+    constexpr int C4 = WN / 4;          // float4 chunks per row: 16
+    constexpr int RPP = 64 / C4;        // rows per pass: 4
+    const int c4 = lane % C4, rr0 = lane / C4;
+    const int n4 = wn0 + c4 * 4;
+    const bool n_ok = n4 < n_lim;
+    float gs = 0.f, gss = 0.f;
+#pragma unroll
+    for (int pass = 0; pass < WM / RPP; ++pass) {
+        const int row = rr0 + pass * RPP;
+        const int trow = wm * (BM / 2) + row;
+        const int m = (b * p.Ho + ty0 + (trow >> TWS)) * p.Wo + tx0 + (trow & (TW - 1));
+        const bool ok = n_ok && m < p.M;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(region + row * LDR + c4 * 4);
+        const u32x2 rq = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
+                                                       rr, (int)hsel(ok, (unsigned)(m * p.ldr + n4) * 2u, OOB), 0, 0));
+        v[0] += HH<HT>::to_f((unsigned short)(rq[0] & 0xFFFFu));
+        v[1] += HH<HT>::to_f((unsigned short)(rq[0] >> 16));
+        v[2] += HH<HT>::to_f((unsigned short)(rq[1] & 0xFFFFu));
+        v[3] += HH<HT>::to_f((unsigned short)(rq[1] >> 16));
+        if (p.out_f32) {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, (int)hsel(ok, (unsigned)(m * p.ldc + n4) * 4u, OOB),
+                                                   0, 0);
+        } else {
+            u32x2 o;
+            unsigned short h0 = HH<HT>::from_f(v[0]), h1 = HH<HT>::from_f(v[1]), h2 = HH<HT>::from_f(v[2]), h3 = HH<HT>::from_f(v[3]);
+            o[0] = (unsigned)h0 | ((unsigned)h1 << 16);
+            o[1] = (unsigned)h2 | ((unsigned)h3 << 16);
+            __builtin_amdgcn_raw_buffer_store_b64(o, ro, (int)hsel(ok, (unsigned)(m * p.ldc + n4) * 2u, OOB), 0, 0);
+            // the statistics describe the STORED (rounded) tensor: that is what the next GroupNorm normalises
+            v = f32x4{HH<HT>::to_f(h0), HH<HT>::to_f(h1), HH<HT>::to_f(h2), HH<HT>::to_f(h3)};
+        }
+        if (ok) {
+            gs += (v[0] + v[1]) + (v[2] + v[3]);
+            gss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
+    }
+    if (p.gn_partial) {
+        float *sl = region;                   // wave-private: [64 lanes][2]
+        sl[lane * 2] = gs;
+        sl[lane * 2 + 1] = gss;
+        const int c4_per_group = p.gn_cpg / 4;
+        const int groups_here = C4 / c4_per_group;
+        if (lane < groups_here) {
+            double ds = 0.0, dss = 0.0;
+            for (int r = 0; r < RPP; ++r)
+                for (int k = 0; k < c4_per_group; ++k) {
+                    const int l = r * C4 + lane * c4_per_group + k;
+                    ds += (double)sl[l * 2];
+                    dss += (double)sl[l * 2 + 1];
+                }
+            const int g = (wn0 / p.gn_cpg) + lane;
+            const int groups = p.N / p.gn_cpg;
+            if (g < groups) {
+                // chunk = (tile, row half, column half): two wavefronts share a row half but own different channels, so
+                // each (chunk = tile * 2 + wm, group) is written by exactly one lane of one wavefront
+                const int chunks_per_b = tiles_img * 2;
+                double *o = p.gn_partial + (((int64_t)b * chunks_per_b + t_img * 2 + wm) * groups + g) * 2;
+                o[0] = ds;
+                o[1] = dss;
+            }
+        }
+    }
+}
+
+template <int HT>
+__global__ void pack_weight_h16_frag_kernel(const float *w, unsigned short *o, int Cout, int Cin, int KH, int KW, int Cout_pad,
+                                            int Cin_pad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int taps = KH * KW;
+    const int64_t total = (int64_t)Cout_pad * taps * Cin_pad;
+    if (i >= total) return;
+    const int c = (int)(i % Cin_pad);
+    const int t = (int)((i / Cin_pad) % taps);
+    const int n = (int)(i / ((int64_t)Cin_pad * taps));
+    float v = 0.f;
+    if (n < Cout && c < Cin) v = w[((int64_t)n * Cin + c) * taps + t];
+    const int64_t k = (int64_t)t * Cin_pad + c, slabs = (int64_t)taps * Cin_pad / 32;
+    const int64_t slab = k >> 5, kin = k & 31;
+    const int64_t piece = (((kin >> 4) * 2) + ((kin >> 3) & 1)) * 32 + (n & 31);
+    o[((((int64_t)(n >> 5)) * slabs + slab) * 128 + piece) * 8 + (kin & 7)] = HH<HT>::from_f(v);
+}
+
+bool hh_shape(const sgam_conv_desc *d, int bm) {
+    const int up = d->upsample2x ? 2 : 1;
+    const bool tile_ok = (bm == 128 && d->Wo % 16 == 0) || (bm == 64 && d->Wo % 8 == 0);
+    return tile_ok && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 && d->Ho == up * d->Hi &&
+           d->Wo == up * d->Wi && d->Ho % 8 == 0 && d->Cin % 32 == 0 && d->N % 128 == 0 && d->lda % 8 == 0 && d->ldb % 32 == 0 &&
+           d->ldb >= 9 * d->Cin && d->n_valid % 4 == 0 && d->ldc % 4 == 0 && d->ldr % 4 == 0 && d->bias_per_row == 0;
+}
+
+// tile rows for this descriptor: 128 when that still fills the chip (or the caller's plan asks for it), else 64; 0 = not a
+// halo shape
+int hh_bm(const sgam_conv_desc *d) {
+    if (!d || d->B <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->N <= 0 || d->Cin <= 0) return 0;
+    if (d->plan_ksplit > 1) return 0;                                    // the tuner wants split-K: generic kernel
+    const int64_t M = (int64_t)d->B * d->Ho * d->Wo;
+    int bm = (M / 128) * (d->N / 128) >= 224 ? 128 : 64;
+    if (d->plan_bm == 128 || d->plan_bm == 64) bm = d->plan_bm;
+    if (bm == 128 && !hh_shape(d, 128)) bm = 64;
+    if (!hh_shape(d, bm)) return 0;
+    // no split-K here: maps too small to fill the chip with whole-K workgroups keep the generic kernel and its split-K plan
+    return (M / bm) * (d->N / 128) >= 128 ? bm : 0;
+}
+
+}  // namespace
+
+extern "C" int32_t sgam_conv2d_h16_uses_halo(const sgam_conv_desc *d) { return hh_bm(d) ? 1 : 0; }
+
+// chunks of output statistics per image the halo kernel leaves (sgam_conv2d_halo_nhwc_h16 with gn_partial), 0 = none
+extern "C" int32_t sgam_conv2d_h16_stats_chunks(const sgam_conv_desc *d) {
+    const int bm = hh_bm(d);
+    if (!bm || d->n_valid != d->N) return 0;
+    return (d->Ho * d->Wo / bm) * 2;
+}
+
+extern "C" int sgam_pack_conv_weight_h16_frag(const float *w_oihw, void *w_frag, int32_t ht, int32_t Cout, int32_t Cin, int32_t KH,
+                                              int32_t KW, int32_t Cout_pad, int32_t Cin_pad, void *stream) {
+    if (!w_oihw || !w_frag || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 || Cout_pad < Cout || Cin_pad < Cin || Cin_pad % 32 ||
+        Cout_pad % 32 || (ht != 0 && ht != 1))
+        return SGAM_EINVAL;
+    const int64_t total = (int64_t)Cout_pad * KH * KW * Cin_pad;
+    const dim3 g(sgam_cdiv(total, 256));
+    if (ht == 0)
+        SGAM_KLAUNCH(pack_weight_h16_frag_kernel<0>, g, dim3(256), 0, sgam_stream(stream), w_oihw, (unsigned short *)w_frag, Cout,
+                     Cin, KH, KW, Cout_pad, Cin_pad);
+    else
+        SGAM_KLAUNCH(pack_weight_h16_frag_kernel<1>, g, dim3(256), 0, sgam_stream(stream), w_oihw, (unsigned short *)w_frag, Cout,
+                     Cin, KH, KW, Cout_pad, Cin_pad);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+extern "C" int sgam_conv2d_halo_nhwc_h16(const sgam_conv_desc *d, int32_t ht, const void *x, const float *gn_mean_rstd,
+                                         const float *gn_gamma, const float *gn_beta, int32_t gn_swish, const void *w_frag,
+                                         const float *bias, const void *residual, void *out, int32_t out_f32, double *gn_partial,
+                                         void *stream) {
+    const int bm = hh_bm(d);
+    if (!bm || !x || !w_frag || !out || (ht != 0 && ht != 1)) return SGAM_EINVAL;
+    if (!sgam_aligned16(x) || !sgam_aligned16(w_frag) || (((uintptr_t)out) & 7u) || (residual && (((uintptr_t)residual) & 7u)))
+        return SGAM_EALIGN;
+    const bool gn = gn_mean_rstd != nullptr;
+    if (gn && (!gn_gamma || !gn_beta || !sgam_aligned16(gn_gamma) || !sgam_aligned16(gn_beta) || d->upsample2x || d->Cin % 128))
+        return SGAM_EINVAL;
+    if (gn_partial && sgam_conv2d_h16_stats_chunks(d) <= 0) return SGAM_EINVAL;
+    HHParams p;
+    p.x = (const unsigned short *)x; p.w = (const unsigned short *)w_frag; p.res = (const unsigned short *)residual;
+    p.bias = bias; p.out = out;
+    p.B = d->B; p.Hi = d->Hi; p.Wi = d->Wi; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.N = d->N; p.ups = d->upsample2x ? 1 : 0;
+    p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldr = d->ldr; p.n_valid = d->n_valid; p.out_f32 = out_f32 ? 1 : 0;
+    p.M = d->B * d->Ho * d->Wo;
+    p.slabs = d->Cin / 32;
+    const int64_t xb = (((int64_t)d->B * d->Hi * d->Wi - 1) * d->lda + d->Cin) * 2;
+    const int64_t wb = (int64_t)d->N * d->ldb * 2;
+    if (xb >= (1ll << 32) - 64 || wb >= (1ll << 32) - 256) return SGAM_EINVAL;
+    p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
+    p.gn_stats = gn_mean_rstd; p.gn_gamma = gn_gamma; p.gn_beta = gn_beta; p.gn_swish = gn_swish ? 1 : 0;
+    p.gn_partial = gn_partial; p.gn_cpg = d->N / 32;
+    p.gx = p.M / bm; p.gy = d->N / 128;
+    static const int swz = [] { const char *e = getenv("SGAM_XCD_SWIZZLE"); return (e && e[0] == '0') ? 0 : 1; }();
+    p.xcd_swizzle = swz;
+    const dim3 grid((unsigned)((int64_t)p.gx * p.gy));
+    hipStream_t s = sgam_stream(stream);
+    if (sgam_i_prof_on) sgam_i_prof_shape(p.M, d->n_valid, 9 * d->Cin, 1);
+    if (sgam_i_prof_on)
+        sgam_i_prof_work(2.0 * p.M * d->n_valid * (double)(9 * d->Cin),
+                         2.0 * ((double)d->B * d->Hi * d->Wi * d->Cin + (double)d->n_valid * 9 * d->Cin + (double)p.M * d->n_valid));
+#define HH_LAUNCH(BM_, HT_)                                                                                                      \
+    do {                                                                                                                         \
+        if (p.ups) SGAM_KLAUNCH((conv3x3_h16_halo_kernel<BM_, 128, HT_, false, true>), grid, dim3(256), 0, s, p);                \
+        else if (gn) SGAM_KLAUNCH((conv3x3_h16_halo_kernel<BM_, 128, HT_, true, false>), grid, dim3(256), 0, s, p);              \
+        else SGAM_KLAUNCH((conv3x3_h16_halo_kernel<BM_, 128, HT_, false, false>), grid, dim3(256), 0, s, p);                     \
+    } while (0)
+    if (bm == 128) {
+        if (ht == 0) HH_LAUNCH(128, 0); else HH_LAUNCH(128, 1);
+    } else {
+        if (ht == 0) HH_LAUNCH(64, 0); else HH_LAUNCH(64, 1);
+    }
+#undef HH_LAUNCH
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}

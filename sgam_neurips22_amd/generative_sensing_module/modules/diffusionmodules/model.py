@@ -32,6 +32,9 @@ class Conv2d(nn.Conv2d):
             dtype = "f32x"      # fp32 activations, weights pre-split into fp16 hi/lo planes (conv_f32x.hip)
         if dtype not in self._packs:
             self._packs[dtype] = ops.pack_conv_weight(w, dtype=dtype)
+            if dtype in ops.H16 and self.kernel_size == (3, 3) and self.stride == (1, 1):
+                # the 16-bit halo kernel reads a fragment-ordered copy (packed on first use, csrc/h16_halo.hip)
+                self._packs[dtype]._sgam_frag_src = w
         return self._packs[dtype], self._pack_bias
 
     def forward_nhwc(self, x, residual=None, upsample2x=False, pad=None, gn=None, out_dtype=None, norm=None):
@@ -75,7 +78,7 @@ def _norm_conv(norm, swish, conv, x, **kw):
     """GroupNorm(+swish) followed by a convolution."""
     if FUSE_GROUPNORM_INTO_CONV:
         return conv.forward_nhwc(x, gn=(norm.stats_nhwc(x), swish), **kw)
-    if x.dtype == torch.float32 and ops.F32_MODE == "split":
+    if (x.dtype == torch.float32 and ops.F32_MODE == "split") or x.dtype in ops.H16:
         # ops decides per launch: normalise inside the halo-staged 3x3 kernel where that kernel runs, else a separate pass
         return conv.forward_nhwc(x, norm=(norm.weight.detach(), norm.bias.detach(), swish, norm.num_groups, norm.eps), **kw)
     return conv.forward_nhwc(norm.forward_nhwc(x, swish=swish), **kw)

@@ -116,6 +116,33 @@ class SplitWeight:
         return self.planes.is_cuda
 
 
+class FragWeightH16:
+    """16-bit conv weight in MFMA-fragment order [Np/32][K/32][128 pieces][8 halfs] (csrc/h16_halo.hip)"""
+    __slots__ = ("planes", "shape")
+
+    def __init__(self, planes):
+        self.planes, self.shape = planes, (planes.shape[0] * 32, planes.shape[1] * 32)
+
+    def stride(self, dim):
+        return self.shape[1] if dim == 0 else 1
+
+    @property
+    def dtype(self):
+        return self.planes.dtype
+
+
+def pack_conv_weight_h16_frag(w_oihw, dtype):
+    """torch Conv2d.weight (Cout,Cin,3,3) -> FragWeightH16 (rows padded to 128, Cin to 32)"""
+    _need_cuda(w_oihw)
+    w = _f32c(w_oihw.detach())
+    cout, cin, kh, kw = w.shape
+    cout_pad, cin_pad = round_up(cout, 128), round_up(cin, 32)
+    planes = torch.empty((cout_pad // 32, kh * kw * cin_pad // 32, 128, 8), device=w.device, dtype=dtype)
+    check(_lib.load().sgam_pack_conv_weight_h16_frag(_p(w), _p(planes), H16[dtype], cout, cin, kh, kw, cout_pad, cin_pad, _stream()),
+          "sgam_pack_conv_weight_h16_frag")
+    return FragWeightH16(planes)
+
+
 def _pow2_scale(maxabs):
     """power of two lifting max|w| into (512, 1024]"""
     import math
@@ -221,7 +248,7 @@ def pack_conv_weight(w_oihw, cout_pad=None, cin_pad=None, dtype=torch.float32):
     # split-fp32 3x3 weights are padded to whole 128-channel tiles so that narrow convs (conv_out: 128 -> 4) run on the
     # halo-staged kernel too (one tile of mostly-zero columns costs less than the generic kernel's per-tap staging, and
     # the preceding GroupNorm fuses into it)
-    cout_pad = cout_pad or round_up(cout, 128 if (dtype == "f32x" and kh * kw == 9) else 64)
+    cout_pad = cout_pad or round_up(cout, 128 if ((dtype == "f32x" or dtype in H16) and kh * kw == 9) else 64)
     cin_pad = cin_pad or round_up(cin, 32)
     if dtype == "f32x":
         planes = torch.empty((cout_pad // 32, kh * kw * cin_pad // 32, 256, 8), device=w.device, dtype=torch.float16)
@@ -293,11 +320,26 @@ def _run_conv(desc, x, w, bias, residual, out, gn=None, a_scale=1.0, norm=None):
         # 32-workgroup launch; computing them is two launches, so a map of <= 1024 pixels without them is cheaper through
         # the one-launch statistics+apply kernel
         have = getattr(x, "_gn_partials", None) is not None
+        h16_fusable = (x.dtype in H16 and FUSE_GN_APPLY and x.dim() == 4 and groups == 32 and eps == 1e-6
+                       and x.shape[3] % 128 == 0 and not desc.upsample2x and _h16_frag(w, desc) is not None)
         if fusable and (have or x.shape[1] * x.shape[2] > 1024):
             gn = (groupnorm_meanrstd(x, eps), gamma, beta, swish)
+        elif h16_fusable:
+            gn = (groupnorm_meanrstd(x, eps), _f32c(gamma), _f32c(beta), swish)
         else:
             x = groupnorm_nhwc(x, gamma, beta, swish, groups, eps)
     return _run_conv_inner(lib, desc, x, w, bias, residual, out, gn, a_scale)
+
+
+def _h16_frag(w, desc):
+    """the fragment-ordered copy of a 16-bit 3x3 weight when this descriptor runs on the 16-bit halo kernel, else None"""
+    src = getattr(w, "_sgam_frag_src", None)
+    if src is None or _lib.load().sgam_conv2d_h16_uses_halo(ctypes.byref(desc)) != 1:
+        return None
+    fw = getattr(w, "_sgam_frag", None)
+    if fw is None:
+        fw = w._sgam_frag = pack_conv_weight_h16_frag(src, w.dtype)
+    return fw
 
 
 def _run_conv_inner(lib, desc, x, w, bias, residual, out, gn=None, a_scale=1.0):
@@ -337,8 +379,23 @@ def _run_conv_inner(lib, desc, x, w, bias, residual, out, gn=None, a_scale=1.0):
                                         _p(residual), _p(out), _p(ws), ws_bytes, _stream()), "sgam_conv2d_nhwc_f32x")
         return out
     if x.dtype in H16:
-        if gn is not None or w.dtype != x.dtype or (residual is not None and residual.dtype != x.dtype):
-            raise SgamHipError("16-bit conv: operands must share one 16-bit dtype; no fused GroupNorm prologue")
+        if w.dtype != x.dtype or (residual is not None and residual.dtype != x.dtype):
+            raise SgamHipError("16-bit conv: operands must share one 16-bit dtype")
+        fw = _h16_frag(w, desc)
+        if fw is not None:
+            # halo-staged 3x3 kernel of the 16-bit mode (csrc/h16_halo.hip): optional GroupNorm(+swish) of x while staging,
+            # statistics of `out` from the epilogue
+            chunks = lib.sgam_conv2d_h16_stats_chunks(ctypes.byref(desc)) if (FUSE_GN_STATS and out.dtype in H16) else 0
+            partial = torch.empty((desc.B * chunks * 32 * 2,), device=x.device, dtype=torch.float64) if chunks > 0 else None
+            mr, gamma, beta, swish = gn if gn is not None else (None, None, None, False)
+            check(lib.sgam_conv2d_halo_nhwc_h16(ctypes.byref(desc), H16[x.dtype], _p(x), _p(mr), _p(gamma), _p(beta), int(swish),
+                                                _p(fw.planes), _p(bias), _p(residual), _p(out), int(out.dtype == torch.float32),
+                                                _p(partial), _stream()), "sgam_conv2d_halo_nhwc_h16")
+            if partial is not None:
+                out._gn_partials = (partial, chunks)
+            return out
+        if gn is not None:
+            raise SgamHipError("16-bit conv: fused GroupNorm needs the halo-staged 3x3 kernel (sgam_conv2d_h16_uses_halo)")
         ws_bytes = lib.sgam_conv2d_h16_workspace_bytes(ctypes.byref(desc))
         if ws_bytes < 0:
             raise SgamHipError(f"sgam_conv2d_h16: unsupported shape {[(f, getattr(desc, f)) for f, _ in desc._fields_]}")
@@ -410,6 +467,14 @@ def groupnorm_nhwc(x, gamma, beta, swish, groups=32, eps=1e-6):
             raise SgamHipError(f"sgam_groupnorm_h16: unsupported shape B={B} HW={H * W} C={C}")
         ws = torch.empty((ws_bytes,), device=x.device, dtype=torch.uint8)
         y = torch.empty_like(x)
+        pre = getattr(x, "_gn_partials", None)
+        if pre is not None and H * W > 1024 and groups == 32:
+            partial, chunks = pre     # statistics came with the tensor (16-bit halo conv epilogue): finalize + apply only
+            gamma, beta = _f32c(gamma), _f32c(beta)
+            check(lib.sgam_groupnorm_from_partials_h16(_p(x), _p(partial), chunks, _p(gamma), _p(beta), _p(y), H16[x.dtype], B,
+                                                       H * W, C, groups, eps, int(swish), _p(ws), ws_bytes, _stream()),
+                  "sgam_groupnorm_from_partials_h16")
+            return y
         check(lib.sgam_groupnorm_nhwc_h16(_p(x), _p(gamma), _p(beta), _p(y), H16[x.dtype], B, H * W, C, groups, eps,
                                           int(swish), _p(ws), ws_bytes, _stream()), "sgam_groupnorm_nhwc_h16")
         return y
@@ -464,6 +529,10 @@ def groupnorm_meanrstd(x, eps=1e-6):
     if ws_bytes < 0:
         raise SgamHipError(f"sgam_groupnorm: unsupported shape B={B} HW={H * W} C={C}")
     ws = torch.empty((ws_bytes,), device=x.device, dtype=torch.uint8)
+    if x.dtype in H16:
+        check(lib.sgam_groupnorm_meanrstd_nhwc_h16(_p(x), _p(out), H16[x.dtype], B, H * W, C, 32, eps, _p(ws), ws_bytes, _stream()),
+              "sgam_groupnorm_meanrstd_nhwc_h16")
+        return out
     check(lib.sgam_groupnorm_meanrstd_nhwc_f32(_p(x), _p(out), B, H * W, C, 32, eps, _p(ws), ws_bytes, _stream()),
           "sgam_groupnorm_meanrstd_nhwc_f32")
     return out

@@ -120,3 +120,55 @@ def test_fused_attention_h16(dt, n):
     s = ops.gemm_nt(qkv[:, :C], qkv[:, C:2 * C], out_dtype=torch.float32)
     chain = ops.gemm_nt(ops.softmax_rows_h16(s, scale, dt), vt)
     assert (o.double() - chain.double()).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dt", DT, ids=["bf16", "fp16"])
+@pytest.mark.parametrize("case", [("h128", 1, 128, 128, 128, 128, False, True, True), ("h64", 2, 128, 256, 64, 64, False, True, False),
+                                  ("hups", 1, 256, 256, 32, 32, True, False, False), ("hout", 1, 128, 4, 128, 128, False, True, False),
+                                  ("h256", 1, 128, 128, 256, 256, False, True, True)], ids=lambda c: c[0])
+def test_conv_h16_halo_kernel(dt, case):
+    """the 16-bit halo-staged 3x3 kernel (csrc/h16_halo.hip): plain, nearest-2x upsampled, and with GroupNorm(+swish) of
+    the input applied while staging — against the fp32 operator on the same 16-bit-rounded operands; the statistics of
+    the output that leave its epilogue against the tensor itself."""
+    tag, B, Cin, Cout, H, W, ups, gn, with_res = case
+    x = testing.seeded_tensor(tag + ".x", (B, Cin, H, W), 1.3, 0.4).to(dt)
+    w = testing.seeded_tensor(tag + ".w", (Cout, Cin, 3, 3), scale=(1.0 / (Cin * 9)) ** 0.5)
+    b = testing.seeded_tensor(tag + ".b", (Cout,), scale=0.1)
+    g = 1 + 0.1 * testing.seeded_tensor(tag + ".g", (Cin,))
+    bt = 0.1 * testing.seeded_tensor(tag + ".bt", (Cin,))
+    wp = ops.pack_conv_weight(w.to(DEV), dtype=dt)
+    wp._sgam_frag_src = w.to(DEV)
+    xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if ups else x.float()
+    Ho, Wo = xin.shape[2:]
+    res = testing.seeded_tensor(tag + ".r", (B, Cout, Ho, Wo)).to(dt) if with_res else None
+    kw = dict(cout=Cout, kh=3, kw=3, pad_t=1, pad_l=1, upsample2x=ups, residual=None if res is None else _nhwc(res).to(DEV))
+    xd = _nhwc(x).to(DEV)
+    from sgam_neurips22_amd._lib import ConvDesc, load
+    d = ConvDesc(B=B, Hi=H, Wi=W, Cin=Cin, Ho=Ho, Wo=Wo, N=wp.shape[0], KH=3, KW=3, stride=1, pad_t=1, pad_l=1,
+                 upsample2x=int(ups), lda=Cin, ldb=wp.stride(0), ldc=Cout, ldr=Cout if with_res else 0, n_valid=Cout, bias_per_row=0)
+    import ctypes
+    assert load().sgam_conv2d_h16_uses_halo(ctypes.byref(d)) == 1
+    # plain
+    out = ops.conv2d_nhwc(xd, wp, b.to(DEV), **kw)
+    ref = F.conv2d(xin, w.to(dt).float(), b, padding=1) + (0 if res is None else res.float())
+    assert out.dtype == dt and _rel(out.permute(0, 3, 1, 2), ref) <= 1.5 * EPS[dt], "plain"
+    if Cout % 128 == 0:
+        assert hasattr(out, "_gn_partials")
+        st = ops.groupnorm_meanrstd(out).cpu()
+        og = out.float().permute(0, 3, 1, 2).cpu().double().reshape(B, 32, -1)
+        assert torch.allclose(st[:, :, 0].double(), og.mean(-1), rtol=0, atol=1e-5)
+        assert torch.allclose(st[:, :, 1].double(), (og.var(-1, unbiased=False) + 1e-6).rsqrt(), rtol=1e-5, atol=0)
+        y = ops.groupnorm_nhwc(out, g[:Cout].to(DEV) if Cout <= Cin else torch.ones(Cout, device=DEV),
+                               bt[:Cout].to(DEV) if Cout <= Cin else torch.zeros(Cout, device=DEV), True)
+        y2 = ops.groupnorm_nhwc(out.clone(), g[:Cout].to(DEV) if Cout <= Cin else torch.ones(Cout, device=DEV),
+                                bt[:Cout].to(DEV) if Cout <= Cin else torch.zeros(Cout, device=DEV), True)
+        assert _rel(y, y2.float()) <= 2 * EPS[dt], "GroupNorm from the epilogue's statistics"
+    # fp32 output variant (conv_out)
+    out32 = ops.conv2d_nhwc(xd, wp, b.to(DEV), out_dtype=torch.float32, **kw)
+    assert out32.dtype == torch.float32 and _rel(out32.permute(0, 3, 1, 2), ref) <= 2e-5 + (1.5 * EPS[dt] if with_res else 0)
+    if gn:
+        fused = ops.conv2d_nhwc(xd, wp, b.to(DEV), norm=(g.to(DEV), bt.to(DEV), True, 32, 1e-6), **kw)
+        xn = F.group_norm(x.float(), 32, g, bt, eps=1e-6)
+        xn = (xn * torch.sigmoid(xn)).to(dt).float()             # the staged operand is rounded once to 16 bits
+        refn = F.conv2d(xn, w.to(dt).float(), b, padding=1) + (0 if res is None else res.float())
+        assert fused.dtype == dt and _rel(fused.permute(0, 3, 1, 2), refn) <= 4 * EPS[dt], "GroupNorm fused into the staging"
