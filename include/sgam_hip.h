@@ -383,7 +383,11 @@ int sgam_rgb_u8_to_f32(const uint8_t *rgb_u8, const float *lut256, float *rgb_f,
  * ScalableTSDFVolume.integrate / extract_triangle_mesh / OffscreenRenderer.render_to_depth_image).
  * Integration is Open3D's published rule (16^3-voxel units, stride-4 unit opening, running weighted mean of
  * min(1, sdf / sdf_trunc)); the depth render is a direct ray cast of the fused surface (first +/- zero crossing of the
- * trilinear TSDF, view-space z, 0 = nothing hit).  Colour is not fused: the path only consumes the depth.
+ * trilinear TSDF, view-space z, 0 = nothing hit).  Colour (TSDFVolumeColorType::RGB8, :123-131, 777-790) is fused
+ * with the same running mean — color <- (color * w + rgb(u, v)) / (w + 1) per channel, 0..255 — when rgb_u8 [H][W][3] and
+ * brick_color [max_bricks][16*16*16][3] fp32 (0-initialised) are given (both or neither), and the ray cast can return the
+ * colour of the nearest voxel at the hit (color_out [H][W][3] fp32, 0 = nothing hit); the conditioning path itself only
+ * consumes the depth.
  *   unit_table [dims.z][dims.y][dims.x] int32, -1 = closed, else brick index | 0x40000000 once the brick holds part of
  *   the truncation band (the ray cast only marches those); unit_stamp same shape, 0-initialised;
  *   counters int32[4] = {bricks allocated, length of this frame's brick list, samples outside the box, pool overflows};
@@ -401,10 +405,12 @@ typedef struct sgam_tsdf_grid {
 int sgam_tsdf_integrate_f32(const sgam_tsdf_grid *grid, const float *depth, int32_t H, int32_t W, float fx, float fy, float cx,
                             float cy, const float *cam2world, const float *world2cam, float depth_trunc, int32_t frame_id,
                             int32_t *unit_table, int32_t *unit_stamp, int32_t *counters, int32_t *brick_list, int32_t max_list,
-                            float *brick_tsdf, float *brick_weight, int32_t max_bricks, void *stream);
+                            float *brick_tsdf, float *brick_weight, int32_t max_bricks, const uint8_t *rgb_u8,
+                            float *brick_color, void *stream);
 int sgam_tsdf_raycast_depth_f32(const sgam_tsdf_grid *grid, int32_t H, int32_t W, float fx, float fy, float cx, float cy,
                                 const float *cam2world, float z_near, float z_far, const int32_t *unit_table,
-                                const float *brick_tsdf, float *depth_out, void *stream);
+                                const float *brick_tsdf, float *depth_out, const float *brick_color, float *color_out,
+                                void *stream);
 
 #ifdef __cplusplus
 }

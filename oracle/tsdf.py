@@ -19,7 +19,9 @@ class TsdfOracle:
         self.units = {}          # (ux, uy, uz) -> [tsdf (16,16,16) indexed [z][y][x], weight]
         self.near = set()        # units the ray cast marches (everything else is crossed like empty space)
 
-    def integrate(self, depth, K, T_w2c, depth_trunc=20.0, stride=4):
+    def integrate(self, depth, K, T_w2c, depth_trunc=20.0, stride=4, rgb_u8=None):
+        """rgb_u8 (H,W,3): also fuse colour, color <- (color * w + rgb) / (w + 1) (TSDFVolumeColorType::RGB8); the colour
+        brick is the third entry of self.units[key]"""
         depth = np.asarray(depth, dtype=F)
         H, W = depth.shape
         fx, fy, cx, cy = F(K[0][0]), F(K[1][1]), F(K[0][2]), F(K[1][2])
@@ -46,8 +48,9 @@ class TsdfOracle:
         for key in touched:
             ux, uy, uz = key
             if key not in self.units:
-                self.units[key] = [np.full((UR, UR, UR), F(2.0), F), np.zeros((UR, UR, UR), F)]   # 2 = unobserved
-            t, w = self.units[key]
+                self.units[key] = [np.full((UR, UR, UR), F(2.0), F), np.zeros((UR, UR, UR), F),    # 2 = unobserved
+                                   np.zeros((UR, UR, UR, 3), F)]
+            t, w, col = self.units[key]
             px = (F(ux) * self.unit_len + ii)[None, None, :]
             py = (F(uy) * self.unit_len + ii)[None, :, None]
             pz = (F(uz) * self.unit_len + ii)[:, None, None]
@@ -67,6 +70,10 @@ class TsdfOracle:
             m &= sdf > -self.trunc
             tv = np.minimum(F(1.0), (sdf * inv_trunc).astype(F))
             new_t = ((t * w + tv) / (w + F(1.0))).astype(F)
+            if rgb_u8 is not None:
+                px = np.asarray(rgb_u8)[v, u].astype(F)                                       # (16,16,16,3)
+                new_c = ((col * w[..., None] + px) / (w[..., None] + F(1.0))).astype(F)
+                col[m] = new_c[m]
             t[m] = new_t[m]
             w[m] = (w + F(1.0))[m]
             if (new_t[m] < F(1.0)).any():

@@ -57,9 +57,9 @@ PROTOTYPES = {
     "sgam_groupnorm_stats_from_partials_f32": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp]),
     "sgam_groupnorm_meanrstd_nhwc_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_i64, c_vp]),
     "sgam_tsdf_integrate_f32": (c_i32, [ctypes.POINTER(TsdfGrid), c_vp, c_i32, c_i32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp,
-                                        c_f32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp]),
+                                        c_f32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "sgam_tsdf_raycast_depth_f32": (c_i32, [ctypes.POINTER(TsdfGrid), c_i32, c_i32, c_f32, c_f32, c_f32, c_f32, c_vp, c_f32,
-                                            c_f32, c_vp, c_vp, c_vp, c_vp]),
+                                            c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "sgam_pack_conv_weight_f32x": (c_i32, [c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "sgam_split_rows_f32x": (c_i32, [c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_vp]),
     "sgam_conv2d_h16_workspace_bytes": (c_i64, [ctypes.POINTER(ConvDesc)]),

@@ -14,7 +14,9 @@
 // The depth render is NOT Open3D's (marching-cubes mesh + rasteriser): the fused surface is ray-cast directly — per
 // target pixel the ray is marched through the opened units and the first +/- zero crossing of the trilinearly
 // interpolated TSDF (nearest-voxel value where a cell has unobserved corners) is refined linearly; the result is the view-space z
-// of that point, 0 where nothing is hit, like the reference's depth image with inf -> 0.  Parity for this branch is
+// of that point, 0 where nothing is hit, like the reference's depth image with inf -> 0.  Colour (TSDFVolumeColorType::RGB8,
+// :123-131, 777-790) is fused with the same running mean per voxel and can be rendered alongside the depth (nearest voxel
+// at the hit) — the conditioning path itself only consumes the depth; the colour serves the final coloured export.  Parity for this branch is
 // therefore pinned against oracle/tsdf.py (the same rule in numpy) and analytic scenes, not against Open3D: "parity
 // unpinned" at the Open3D boundary, as SURVEY.md §8c anticipates.
 //
@@ -108,7 +110,8 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(const float *__rest
                                                              float cx, float cy, const Pose w2c_, TsdfGrid g,
                                                              float depth_trunc, int *__restrict__ table, const int *__restrict__ counters,
                                                              const int *__restrict__ list, int max_list,
-                                                             float *__restrict__ tsdf, float *__restrict__ weight) {
+                                                             float *__restrict__ tsdf, float *__restrict__ weight,
+                                                             const uint8_t *__restrict__ rgb, float *__restrict__ color) {
     const float *w2c = w2c_.m;
     int n = counters[1];
     if (n > max_list) n = max_list;
@@ -149,6 +152,14 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(const float *__rest
                 const float w = bw[q];
                 const float nt = __fdiv_rn(__fadd_rn(__fmul_rn(bt[q], w), t), __fadd_rn(w, 1.0f));
                 bt[q] = nt;
+                if (color) {
+                    // TSDFVolumeColorType::RGB8: color <- (color * w + rgb(u, v)) / (w + 1), per channel, 0..255
+                    float *bc = color + ((int64_t)brick * UV + q) * 3;
+                    const uint8_t *px3 = rgb + ((int64_t)v * W + u) * 3;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch)
+                        bc[ch] = __fdiv_rn(__fadd_rn(__fmul_rn(bc[ch], w), (float)px3[ch]), __fadd_rn(w, 1.0f));
+                }
                 bw[q] = __fadd_rn(w, 1.0f);
                 near |= nt < 1.0f;
             }
@@ -223,7 +234,7 @@ __device__ __forceinline__ bool sample(const TsdfGrid &g, const int *table, cons
 // space, 0.8 x the distance the TSDF value guarantees.
 __global__ void tsdf_raycast_kernel(int H, int W, float fx, float fy, float cx, float cy, const Pose c2w_, TsdfGrid g,
                                     float z_near, float z_far, const int *__restrict__ table, const float *__restrict__ tsdf,
-                                    float *__restrict__ out) {
+                                    float *__restrict__ out, const float *__restrict__ color, float *__restrict__ color_out) {
     // The march is a chain of dependent loads (unit table -> brick -> values), i.e. latency-bound, and a 256 x 256 view is
     // only one wavefront per SIMD: every ray is cut into RS depth segments marched by RS adjacent lanes (each starts with
     // no history and runs two voxels into the next segment so that a crossing on a boundary is seen by the earlier one);
@@ -300,6 +311,25 @@ __global__ void tsdf_raycast_kernel(int H, int W, float fx, float fy, float cx, 
 #pragma unroll
     for (int o = 1; o < RS; o <<= 1) best = fminf(best, __shfl_xor(best, o, 64));
     if (live && seg == 0) out[i] = best < 3.0e38f ? best : 0.f;
+    if (color_out && live) {
+        // colour of the fused surface at the hit: the nearest voxel's running mean (0 where nothing is hit).  The lane that
+        // found the winning crossing writes it (equal depths on two lanes: both write the same voxel's colour).
+        if (seg == 0 && !(best < 3.0e38f)) color_out[i * 3] = color_out[i * 3 + 1] = color_out[i * 3 + 2] = 0.f;
+        if (depth > 0.f && depth == best) {
+            int vi[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) vi[r] = (int)floorf(__fmul_rn(__fadd_rn(o[r], __fmul_rn(dir[r], depth)), inv_voxel));
+            const int64_t s = unit_slot(g, vi[0] >> 4, vi[1] >> 4, vi[2] >> 4);
+            const int brick = s >= 0 ? table[s] : -1;
+            float c3[3] = {0.f, 0.f, 0.f};
+            if (brick >= 0) {
+                const int q = ((vi[2] & 15) << 8) | ((vi[1] & 15) << 4) | (vi[0] & 15);
+                const float *bc = color + ((int64_t)(brick & BRICK_MASK) * UV + q) * 3;
+                c3[0] = bc[0]; c3[1] = bc[1]; c3[2] = bc[2];
+            }
+            color_out[i * 3] = c3[0]; color_out[i * 3 + 1] = c3[1]; color_out[i * 3 + 2] = c3[2];
+        }
+    }
 }
 
 int grid_ok(const sgam_tsdf_grid *g) {
@@ -328,7 +358,8 @@ extern "C" int sgam_tsdf_integrate_f32(const sgam_tsdf_grid *grid, const float *
                                        int32_t frame_id,
                                        int32_t *unit_table, int32_t *unit_stamp, int32_t *counters, int32_t *brick_list,
                                        int32_t max_list, float *brick_tsdf, float *brick_weight, int32_t max_bricks,
-                                       void *stream) {
+                                       const uint8_t *rgb_u8, float *brick_color, void *stream) {
+    if ((rgb_u8 == nullptr) != (brick_color == nullptr)) return SGAM_EINVAL;     // colour fusion needs both or neither
     if (!grid_ok(grid) || !depth || !(fx > 0.f) || !(fy > 0.f) || !cam2world || !world2cam || !unit_table || !unit_stamp || !counters || !brick_list ||
         !brick_tsdf || !brick_weight || H <= 0 || W <= 0 || max_list <= 0 || max_bricks <= 0 || max_bricks > BRICK_MASK ||
         frame_id <= 0)
@@ -349,14 +380,15 @@ extern "C" int sgam_tsdf_integrate_f32(const sgam_tsdf_grid *grid, const float *
                        max_list);
     SGAM_LAUNCH_CHECK();
     SGAM_KLAUNCH(tsdf_integrate_kernel, dim3(2048), dim3(256), 0, s, depth, H, W, fx, fy, cx, cy, w2c, g,
-                       depth_trunc, unit_table, counters, brick_list, max_list, brick_tsdf, brick_weight);
+                       depth_trunc, unit_table, counters, brick_list, max_list, brick_tsdf, brick_weight, rgb_u8, brick_color);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
 }
 
 extern "C" int sgam_tsdf_raycast_depth_f32(const sgam_tsdf_grid *grid, int32_t H, int32_t W, float fx, float fy, float cx,
                                            float cy, const float *cam2world, float z_near, float z_far, const int32_t *unit_table, const float *brick_tsdf,
-                                           float *depth_out, void *stream) {
+                                           float *depth_out, const float *brick_color, float *color_out, void *stream) {
+    if ((brick_color == nullptr) != (color_out == nullptr)) return SGAM_EINVAL;
     if (!grid_ok(grid) || !(fx > 0.f) || !(fy > 0.f) || !cam2world || !unit_table || !brick_tsdf || !depth_out || H <= 0 || W <= 0 ||
         !(z_near > 0.f) || !(z_far > z_near))
         return SGAM_EINVAL;
@@ -364,7 +396,7 @@ extern "C" int sgam_tsdf_raycast_depth_f32(const sgam_tsdf_grid *grid, int32_t H
     Pose c2w;
     for (int i = 0; i < 16; ++i) c2w.m[i] = cam2world[i];
     SGAM_KLAUNCH(tsdf_raycast_kernel, dim3(sgam_cdiv((int64_t)H * W * RS, 256)), dim3(256), 0, sgam_stream(stream), H, W, fx, fy,
-                       cx, cy, c2w, g, z_near, z_far, unit_table, brick_tsdf, depth_out);
+                       cx, cy, c2w, g, z_near, z_far, unit_table, brick_tsdf, depth_out, brick_color, color_out);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
 }

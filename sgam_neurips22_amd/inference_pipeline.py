@@ -59,7 +59,7 @@ def ray_to_z_depth(depth, K):
 def synthetic_seed_frame(data, seed_index=0, res=256):
     """Seeded smooth RGB-D seed frame for boxes without the reference's templates/ (bench, GPU tests):
     RGB uint8, depth fp32 in the template range ([1.4,3.4] GoogleEarth, [10.3,15.5] CLEVR)."""
-    rs = np.random.RandomState(1000 + seed_index)
+    rs = np.random.RandomState(1000 + int(seed_index))        # main_scene_generation passes seed_index through argparse
     yy, xx = np.meshgrid(np.linspace(0, 1, res), np.linspace(0, 1, res), indexing="ij")
     acc = np.zeros((res, res, 4))
     for _ in range(12):
@@ -145,6 +145,9 @@ class InfiniteSceneGeneration:
             if os.path.isdir(os.path.join(templates_root, data)):
                 seed_frame = load_template_seed(data, seed_index, self.image_resolution, templates_root)
             else:
+                import warnings
+                warnings.warn(f"{templates_root}/{data} not found: starting from a SYNTHETIC seed frame, not the reference's "
+                              "template", RuntimeWarning)
                 seed_frame = synthetic_seed_frame(data, seed_index, self.image_resolution[0])
         self.frames = {}        # grid coord -> dict(rgb_f (H,W,3) fp32, depth (H,W) fp32, rgb_u8, index)
         self.prepare_grid(self.output_dim)
@@ -193,7 +196,8 @@ class InfiniteSceneGeneration:
                 poses.append(T)
         H, W = self.image_resolution
         lo, hi = frustum_bounds(self.K, poses, H, W, self._Z_RANGE[self.data][1], margin=trunc + voxel * UNIT)
-        return TsdfVolume(voxel, trunc, lo, hi, self.device, memory_budget_bytes=16 << 30)
+        # RGB8 colour is fused alongside the depth like the reference's volume (:123-131); pool sized from the free memory
+        return TsdfVolume(voxel, trunc, lo, hi, self.device, color=True)
 
     def rgbd_integration(self, src_nodes, tgt_node):
         """reference :745-838: integrate every source frame of this step (again — the volume is cumulative, like the
@@ -203,7 +207,8 @@ class InfiniteSceneGeneration:
             T[:3, :3], T[:3, 3] = s["R"], s["t"]
             # the reference fuses the depth as loaded (:570-574) — for the CLEVR seed that is the ONCE-converted map;
             # its second ray->z conversion (:582-590) only touches batch['src_depths'], after the fusion
-            self.volume.integrate(self.frames[s["grid_coord"]]["depth"], self.K, T)
+            fr = self.frames[s["grid_coord"]]
+            self.volume.integrate(fr["depth"], self.K, T, rgb_u8=fr["rgb_u8"])
         T = np.eye(4)
         T[:3, :3], T[:3, 3] = tgt_node["R"], tgt_node["t"]
         H, W = self.image_resolution
@@ -431,6 +436,8 @@ class InfiniteSceneGeneration:
             if self.curr == total or (self.curr - verified) >= range_check_every:
                 self.curr = self._range_checkpoint(verified)
                 verified = self.curr
+                if self.volume is not None:
+                    self.volume.check()            # pool overflow / samples outside the box: do not lose geometry silently
         return self.frames
 
     # ---------------------------------------------------------------- export (after the run)

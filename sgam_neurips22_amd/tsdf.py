@@ -34,9 +34,11 @@ def frustum_bounds(K, poses_w2c, H, W, z_far, margin):
 
 
 class TsdfVolume:
-    def __init__(self, voxel_length, sdf_trunc, lo, hi, device, max_bricks=None, memory_budget_bytes=48 << 30):
+    def __init__(self, voxel_length, sdf_trunc, lo, hi, device, max_bricks=None, memory_budget_bytes=None, color=False):
         """lo / hi: world-space box the scene can occupy (see frustum_bounds).  max_bricks defaults to what
-        `memory_budget_bytes` of brick pool holds (32 KB per brick), capped at the number of units in the box."""
+        `memory_budget_bytes` of brick pool holds (32 KB per brick, 80 KB with colour), capped at the number of units in
+        the box; the budget defaults to a quarter of the device memory that is free right now (not more than 48 GiB).
+        color: also fuse RGB8 colour (TSDFVolumeColorType.RGB8, reference :123-131)."""
         self.voxel_length, self.sdf_trunc = float(voxel_length), float(sdf_trunc)
         unit_len = np.float32(voxel_length) * np.float32(UNIT)
         base = np.floor(np.asarray(lo, dtype=np.float64) / float(unit_len)).astype(np.int64)
@@ -45,8 +47,11 @@ class TsdfVolume:
         n_units = int(dims.prod())
         if n_units >= 2 ** 31:
             raise ops.SgamHipError(f"TSDF box of {tuple(dims)} units does not fit the int32 unit table; shrink the scene box")
+        if memory_budget_bytes is None:
+            free = torch.cuda.mem_get_info(device)[0] if torch.device(device).type == "cuda" else 1 << 30
+            memory_budget_bytes = min(48 << 30, free // 4)
         if max_bricks is None:
-            max_bricks = max(1, min(n_units, memory_budget_bytes // (UNIT ** 3 * 8)))
+            max_bricks = max(1, min(n_units, memory_budget_bytes // (UNIT ** 3 * (20 if color else 8))))
         self.base, self.dims, self.max_bricks, self.device = base, dims, int(max_bricks), device
         self.grid = TsdfGrid(np.float32(voxel_length), np.float32(sdf_trunc), (ctypes.c_int32 * 3)(*map(int, base)),
                              (ctypes.c_int32 * 3)(*map(int, dims)))
@@ -55,6 +60,7 @@ class TsdfVolume:
         self.counters = torch.zeros((4,), dtype=torch.int32, device=device)
         self.brick_tsdf = torch.full((self.max_bricks, UNIT ** 3), 2.0, dtype=torch.float32, device=device)   # 2 = unobserved
         self.brick_weight = torch.zeros((self.max_bricks, UNIT ** 3), dtype=torch.float32, device=device)
+        self.brick_color = torch.zeros((self.max_bricks, UNIT ** 3, 3), dtype=torch.float32, device=device) if color else None
         self.max_list = int(min(n_units, 1 << 22))
         self.brick_list = torch.empty((self.max_list,), dtype=torch.int32, device=device)
         self.frame_id = 0
@@ -64,9 +70,15 @@ class TsdfVolume:
         K = np.asarray(K, dtype=np.float32)
         return float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2])
 
-    def integrate(self, depth, K, T_w2c):
-        """depth (H,W) fp32 device tensor, K 3x3, T_w2c 4x4 world->camera (the reference's extrinsic [R|t])."""
+    def integrate(self, depth, K, T_w2c, rgb_u8=None):
+        """depth (H,W) fp32 device tensor, K 3x3, T_w2c 4x4 world->camera (the reference's extrinsic [R|t]); rgb_u8 (H,W,3)
+        uint8 device tensor: the frame's colour, fused when the volume was built with color=True."""
         ops._need_cuda(depth)
+        rgb = None
+        if self.brick_color is not None:
+            if rgb_u8 is None or rgb_u8.dtype != torch.uint8 or tuple(rgb_u8.shape) != (*depth.shape, 3):
+                raise ops.SgamHipError("TsdfVolume(color=True).integrate needs the frame's (H,W,3) uint8 colour")
+            rgb = rgb_u8.contiguous()
         H, W = depth.shape
         T = np.asarray(T_w2c, dtype=np.float64)
         w2c = np.ascontiguousarray(T, dtype=np.float32)                      # host 4x4s: passed by value to the kernels
@@ -77,21 +89,37 @@ class TsdfVolume:
         check(_lib.load().sgam_tsdf_integrate_f32(
             ctypes.byref(self.grid), ops._p(d), H, W, fx, fy, cx, cy, c2w.ctypes.data, w2c.ctypes.data, DEPTH_TRUNC, self.frame_id,
             ops._p(self.unit_table), ops._p(self.unit_stamp), ops._p(self.counters), ops._p(self.brick_list), self.max_list,
-            ops._p(self.brick_tsdf), ops._p(self.brick_weight), self.max_bricks, ops._stream()),
+            ops._p(self.brick_tsdf), ops._p(self.brick_weight), self.max_bricks, ops._p(rgb),
+            ops._p(self.brick_color if rgb is not None else None), ops._stream()),
             "sgam_tsdf_integrate_f32")
 
-    def render_depth(self, K, T_w2c, H, W, z_near, z_far):
-        """View-space z of the fused surface at the pose, (H,W) fp32, 0 where nothing is hit."""
+    def render_depth(self, K, T_w2c, H, W, z_near, z_far, want_color=False):
+        """View-space z of the fused surface at the pose, (H,W) fp32, 0 where nothing is hit; with want_color also the
+        fused colour at the hit, (H,W,3) fp32 in 0..255."""
         T = np.asarray(T_w2c, dtype=np.float64)
         c2w = np.ascontiguousarray(np.linalg.inv(T), dtype=np.float32)
         out = torch.empty((H, W), dtype=torch.float32, device=self.device)
         fx, fy, cx, cy = self._k4(K)
         check(_lib.load().sgam_tsdf_raycast_depth_f32(
             ctypes.byref(self.grid), H, W, fx, fy, cx, cy, c2w.ctypes.data, float(z_near), float(z_far), ops._p(self.unit_table),
-            ops._p(self.brick_tsdf), ops._p(out), ops._stream()),
+            ops._p(self.brick_tsdf), ops._p(out), ops._p(self.brick_color if want_color else None),
+            ops._p(col := (torch.empty((H, W, 3), dtype=torch.float32, device=self.device) if want_color else None)), ops._stream()),
             "sgam_tsdf_raycast_depth_f32")
-        return out
+        return (out, col) if want_color else out
 
     def stats(self):
         """(bricks allocated, last frame's brick count, samples outside the box, pool overflows) — host sync."""
         return tuple(int(v) for v in self.counters.cpu())
+
+    def check(self):
+        """Raise when the fusion silently lost geometry: units that could not be opened because the brick pool was
+        exhausted, or depth samples that fell outside the scene box (the rendered target depth then has holes there).
+        One host sync: call at checkpoints of the loop, not per frame."""
+        bricks, _, outside, overflow = self.stats()
+        if overflow > 0:
+            raise ops.SgamHipError(f"TSDF brick pool exhausted: {overflow} unit openings dropped (pool of {self.max_bricks} "
+                                   f"bricks, {min(bricks, self.max_bricks)} used); raise memory_budget_bytes / max_bricks")
+        if outside > 0:
+            import warnings
+            warnings.warn(f"TSDF: {outside} depth samples fell outside the scene box and were not fused", RuntimeWarning)
+        return bricks

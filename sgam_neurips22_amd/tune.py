@@ -39,6 +39,10 @@ def _time(desc, x, w, out, reps=20):
     nb0 = (lib.sgam_conv2d_f32x_workspace_bytes if split else
            (lib.sgam_conv2d_h16_workspace_bytes if h16 else lib.sgam_conv2d_workspace_bytes))(ctypes.byref(desc))
     ws0 = torch.empty((max(nb0, 16),), device=x.device, dtype=torch.uint8) if nb0 >= 0 else None
+    # 16-bit 3x3 convs run on the halo-staged kernel when the plan allows it (no split-K): time what would actually run
+    wfrag = None
+    if h16 and lib.sgam_conv2d_h16_uses_halo(ctypes.byref(desc)) == 1:
+        wfrag = (torch.randn((desc.N // 32, desc.ldb // 32, 128, 8), device=x.device) * 0.03).to(x.dtype)
 
     def run():
         nb, ws = nb0, ws0
@@ -47,6 +51,9 @@ def _time(desc, x, w, out, reps=20):
         if split:
             rc = lib.sgam_conv2d_nhwc_f32x(ctypes.byref(desc), ops._p(x), 1.0, ops._p(w.planes), float(w.scale), None, None,
                                            ops._p(out), ops._p(ws), nb, ops._stream())
+        elif h16 and wfrag is not None:
+            rc = lib.sgam_conv2d_halo_nhwc_h16(ctypes.byref(desc), ops.H16[x.dtype], ops._p(x), None, None, None, 0, ops._p(wfrag),
+                                               None, None, ops._p(out), 0, None, ops._stream())
         elif h16:
             rc = lib.sgam_conv2d_nhwc_h16(ctypes.byref(desc), ops.H16[x.dtype], ops._p(x), ops._p(w), None, None, ops._p(out),
                                           0, ops._p(ws), nb, ops._stream())
@@ -201,19 +208,19 @@ def refine_in_frame(plans, dataset="google_earth", res=256, frames=12, verbose=T
     return plans
 
 
-def collect_shapes(dtypes, dataset="google_earth", res=256):
+def collect_shapes(dtypes, dataset="google_earth", res=256, batch=1):
     from .config import default_params
     from .generative_sensing_module.model import VQModel
     keys = {}
     m = VQModel(**default_params(dataset))
     m.load_state_dict(testing.synthetic_state_dict(m.state_dict(), seed=0))
     m = m.to("cuda").eval()
-    x, mask = testing.rect_hole_input(1, res, res)
+    x, mask = testing.rect_hole_input(batch, res, res)
     for dt in dtypes:
         m.set_compute_dtype(dt)
         ops.PLAN_RECORD = {}
         with torch.no_grad():
-            m(x.cuda(), topk=1, extrapolation_mask=mask.cuda())
+            m(x.cuda(), topk=1 if batch == 1 else None, extrapolation_mask=mask.cuda())
         keys.update(ops.PLAN_RECORD)
         ops.PLAN_RECORD = None
     return sorted(keys)
@@ -224,12 +231,15 @@ def main():
     ap.add_argument("--dtypes", default="f32,fp16,bf16", help="f32 tunes the current ops.F32_MODE (split by default)")
     ap.add_argument("--merge", action="store_true", help="keep the plans already in the output file for other dtypes")
     ap.add_argument("--out", default=ops._PLAN_FILE)
+    ap.add_argument("--configs", default="256x1", help="comma list of <resolution>x<batch> model inputs whose layer shapes are "
+                                                       "tuned: 256x1 = BASELINE configs 1-4, 512x4 = config 5")
     ap.add_argument("--refine", action="store_true", help="after the isolated timing, re-judge the runner-up plans inside the "
                                                           "real frame (f32 only)")
     a = ap.parse_args()
     os.environ["SGAM_NO_TUNED_PLANS"] = "1"
     ops.load_plans()
-    keys = collect_shapes(a.dtypes.split(","))
+    keys = sorted({k for cfg in a.configs.split(",")
+                   for k in collect_shapes(a.dtypes.split(","), res=int(cfg.split("x")[0]), batch=int(cfg.split("x")[1]))})
     print(f"{len(keys)} distinct conv/GEMM shapes", flush=True)
     plans, saved = {}, 0.0
     for k in keys:

@@ -121,8 +121,8 @@ def test_tsdf_argument_validation_without_gpu():
     lib = _lib.load()
     g = _lib.TsdfGrid(0.01, 0.03, (ctypes.c_int32 * 3)(0, 0, 0), (ctypes.c_int32 * 3)(4, 4, 4))
     bad = _lib.TsdfGrid(0.0, 0.03, (ctypes.c_int32 * 3)(0, 0, 0), (ctypes.c_int32 * 3)(4, 4, 4))
-    args = (None, 8, 8, 10.0, 10.0, 4.0, 4.0, None, None, 20.0, 1, None, None, None, None, 16, None, None, 16, None)
+    args = (None, 8, 8, 10.0, 10.0, 4.0, 4.0, None, None, 20.0, 1, None, None, None, None, 16, None, None, 16, None, None, None)
     assert lib.sgam_tsdf_integrate_f32(ctypes.byref(g), *args) == -1
     assert lib.sgam_tsdf_integrate_f32(ctypes.byref(bad), *args) == -1
     assert lib.sgam_tsdf_raycast_depth_f32(ctypes.byref(g), 8, 8, 10.0, 10.0, 4.0, 4.0, None, 0.1, 4.0, None, None, None,
-                                           None) == -1
+                                           None, None, None) == -1

@@ -122,3 +122,106 @@ def test_scene_loop_with_rgbd_integration():
         assert cover > 0.4, cover
     st = scene.volume.stats()
     assert st[0] > 100 and st[3] == 0, st           # bricks were allocated, the pool did not overflow
+
+
+def _textured(H, W, seed):
+    rs = np.random.RandomState(seed)
+    yy, xx = np.meshgrid(np.linspace(0, 1, H), np.linspace(0, 1, W), indexing="ij")
+    img = np.stack([127 + 120 * np.sin(2 * np.pi * (rs.uniform(1, 3) * xx + rs.uniform(1, 3) * yy + rs.uniform())) for _ in range(3)], -1)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def test_colour_fusion_matches_the_oracle_bit_for_bit():
+    """TSDFVolumeColorType::RGB8 (reference :123-131, 777-790): colour bricks equal the restated rule bit for bit"""
+    H = W = 64
+    K = _K(120.0, 31.5)
+    poses = [_pose(), _pose(tx=0.21, yaw=0.07), _pose(tx=-0.13, ty=0.05, yaw=-0.05)]
+    lo, hi = frustum_bounds(K, poses, H, W, 4.8, margin=0.03 + 16 * 0.01)
+    vol = TsdfVolume(0.01, 0.03, lo, hi, DEV, memory_budget_bytes=2 << 30, color=True)
+    ora = TsdfOracle(0.01, 0.03)
+    for i, T in enumerate(poses):
+        d = plane_depth(K, T, H, W, 2.2)
+        rgb = _textured(H, W, i)
+        vol.integrate(torch.from_numpy(d).to(DEV), K, T, rgb_u8=torch.from_numpy(rgb).to(DEV))
+        ora.integrate(d, K, T, rgb_u8=rgb)
+    table = vol.unit_table.cpu().numpy().reshape(int(vol.dims[2]), int(vol.dims[1]), int(vol.dims[0]))
+    col = vol.brick_color.cpu().numpy()
+    n = 0
+    for z, y, x in zip(*np.nonzero(table >= 0)):
+        key = (int(x + vol.base[0]), int(y + vol.base[1]), int(z + vol.base[2]))
+        got = col[table[z, y, x] & 0x3FFFFFFF].reshape(16, 16, 16, 3)
+        assert np.array_equal(got.view(np.uint32), ora.units[key][2].view(np.uint32)), key
+        n += 1
+    assert n == len(ora.units) > 10
+    with pytest.raises(Exception):
+        vol.integrate(torch.from_numpy(plane_depth(K, poses[0], H, W, 2.2)).to(DEV), K, poses[0])     # colour volume needs rgb
+    assert vol.check() == n
+
+
+@pytest.mark.parametrize("voxel,trunc,zc,radius", [(0.05, 0.5, 9.0, 1.5), (0.01, 0.03, 2.4, 0.5)])
+def test_against_the_independent_dense_float64_reference(voxel, trunc, zc, radius):
+    """oracle/tsdf_dense.py: dense float64 grid, no units / bricks / stride-4 opening, fine march + bisection.  Stated
+    tolerances: fused TSDF values max(1e-5, 4 fp32 ulps of the depth / sdf_trunc) on the in-band voxels both volumes observed equally often (>= 98 % of the band; every
+    in-band voxel the dense rule observes is present in the brick pool); rendered depth within 0.15 voxel on average and 0.6 voxel
+    at worst away from the silhouette; fused colour within 1 level of 255 where both hit."""
+    from oracle.tsdf_dense import DenseTsdf
+    H = W = 96
+    K = _K(150.0, 47.5)
+    centre = (0.05 * zc / 9, -0.03 * zc / 9, zc)
+    sc = zc / 9.0
+    poses = [_pose(), _pose(tx=0.4 * sc, yaw=0.05), _pose(tx=-0.35 * sc, ty=0.2 * sc, yaw=-0.04)]
+    lo = np.array(centre) - radius - 3 * trunc - 20 * voxel
+    hi = np.array(centre) + radius + 3 * trunc + 20 * voxel
+    flo, fhi = frustum_bounds(K, poses, H, W, zc + 2 * radius, margin=trunc + 16 * voxel)
+    vol = TsdfVolume(voxel, trunc, flo, fhi, DEV, memory_budget_bytes=4 << 30, color=True)
+    dense = DenseTsdf(voxel, trunc, lo, hi)
+    for i, T in enumerate(poses):
+        d = sphere_depth(K, T, H, W, centre, radius)
+        rgb = _textured(H, W, 10 + i)
+        vol.integrate(torch.from_numpy(d).to(DEV), K, T, rgb_u8=torch.from_numpy(rgb).to(DEV))
+        dense.integrate(d, K, T, rgb_u8=rgb)
+    assert vol.check() > 0
+    # --- voxel values: every brick against the dense grid
+    table = vol.unit_table.cpu().numpy().reshape(int(vol.dims[2]), int(vol.dims[1]), int(vol.dims[0]))
+    bt, bw = vol.brick_tsdf.cpu().numpy(), vol.brick_weight.cpu().numpy()
+    seen = np.zeros(dense.tsdf.shape, bool)
+    worst, n_band, n_same = 0.0, 0, 0
+    for z, y, x in zip(*np.nonzero(table >= 0)):
+        b = table[z, y, x] & 0x3FFFFFFF
+        g0 = (np.array([x + vol.base[0], y + vol.base[1], z + vol.base[2]]) * 16 - dense.i0)      # first voxel of the unit
+        if np.any(g0 + 16 <= 0) or np.any(g0 >= dense.n):
+            continue
+        a0, a1 = np.maximum(g0, 0), np.minimum(g0 + 16, dense.n)
+        sl_d = (slice(a0[2], a1[2]), slice(a0[1], a1[1]), slice(a0[0], a1[0]))
+        sl_b = (slice(a0[2] - g0[2], a1[2] - g0[2]), slice(a0[1] - g0[1], a1[1] - g0[1]), slice(a0[0] - g0[0], a1[0] - g0[0]))
+        t, w = bt[b].reshape(16, 16, 16)[sl_b], bw[b].reshape(16, 16, 16)[sl_b]
+        # comparable voxels: inside the truncation band of the dense field (the unit-based volume, like Open3D's, only opens
+        # units within sdf_trunc of the surface and therefore never counts the free-space observations the dense rule
+        # records in front of it), observed by both, with the same number of observations (a unit is only updated in
+        # the frames that touch it: a voxel at the rim of the band can have missed one)
+        band = (w > 0) & (dense.weight[sl_d] > 0) & (np.abs(dense.tsdf[sl_d]) < 0.9)
+        same = band & (w == dense.weight[sl_d])
+        n_band += int(band.sum())
+        n_same += int(same.sum())
+        if same.any():
+            worst = max(worst, float(np.abs(t[same] - dense.tsdf[sl_d][same]).max()))
+        seen[sl_d] |= w > 0
+    assert n_band > 1000 and n_same >= 0.98 * n_band, (n_same, n_band)
+    # the kernel evaluates (d - z) / trunc in fp32: a few ulps of a depth of ~zc, divided by the truncation distance
+    tol = max(1e-5, 4 * 2.0 ** -23 * (zc + radius) / trunc)
+    assert worst <= tol, (worst, tol)
+    inband = (dense.weight > 0) & (np.abs(dense.tsdf) < 0.9)        # the band around the surface must be in the pool
+    assert (seen[inband]).mean() > 0.999
+    # --- rendered depth and colour at a new pose
+    T_new = _pose(tx=0.15 * sc, ty=0.1 * sc, yaw=0.02)
+    got_d, got_c = vol.render_depth(K, T_new, H, W, max(0.05, zc - 3 * radius), zc + 2 * radius, want_color=True)
+    got_d, got_c = got_d.cpu().numpy(), got_c.cpu().numpy()
+    ref_d, ref_c = dense.render(K, T_new, H, W, max(0.05, zc - 3 * radius), zc + 2 * radius)
+    inner = sphere_depth(K, T_new, H, W, centre, radius * 0.85) > 0
+    both = inner & (got_d > 0) & (ref_d > 0)
+    assert both.sum() > 0.97 * inner.sum()
+    err = np.abs(got_d - ref_d)[both] / voxel
+    assert err.mean() <= 0.15 and err.max() <= 0.6, (err.mean(), err.max())
+    same_voxel = both & (np.abs(got_d - ref_d) < 0.02 * voxel)
+    cerr = np.abs(got_c - ref_c)[same_voxel]
+    assert same_voxel.sum() > 100 and np.percentile(cerr, 99) <= 1.0, (same_voxel.sum(), np.percentile(cerr, 99))

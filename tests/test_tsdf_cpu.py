@@ -56,5 +56,5 @@ def test_unobserved_space_renders_zero_and_truncation_is_respected():
     vol.integrate(d, K, _pose())
     out = vol.render_depth(K, _pose(), H, W, 1.0, 16.5, pixels=[(16, 4), (16, 28)])
     assert out[16, 4] == 0.0 and abs(out[16, 28] - 8.0) < 0.025
-    for t, w in vol.units.values():
+    for t, w, _col in vol.units.values():
         assert (t[w == 0] == 2.0).all() and (not (w > 0).any() or (t[w > 0].max() <= 1.0 and t[w > 0].min() > -1.0))
