@@ -797,6 +797,218 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
     });
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolution for the SMALL maps (16^2, 32^2: M = 256 .. 1024 output pixels, 256 .. 512 channels):
+// K split across the four wavefronts of a workgroup instead of across workgroups.
+// On these maps the halo kernel above needs split-K plans of 8 - 16 to fill the chip: a workgroup then multiplies ONE
+// channel slab between a prologue and an epilogue, a second launch sums the partial slabs, and the layer takes 11 + 3 us
+// (+ a launch gap) for 1.2 GFLOP.  Here a workgroup owns a 4 x 8 patch of output pixels x 32 output channels over the WHOLE
+// K range: the 6 x 10 halo of 128 input channels (four slabs) is staged per step, wavefront w multiplies slab w of the step
+// — same A rows, its own weight fragments straight from L2 (distinct K ranges: no fragment is fetched twice inside a
+// workgroup) — and the four partial tiles are summed through LDS in the fixed order w = 0, 1, 2, 3 before the epilogue
+// (bias, residual, 16-byte stores, GroupNorm statistics of the output).  128 (16^2 x 512) / 256 (32^2 x 256) workgroups of
+// 216 / 108 MFMAs per wavefront, no workspace, no combine launch, and the result does not depend on a split-K plan.
+template <bool GN>
+__global__ __launch_bounds__(256) void conv3x3_f32x_k4_kernel(const XParams p) {
+    constexpr int TH = 4, TW = 8, BM = 32, BN = 32;
+    constexpr int HROWS = TH + 2, HWID = TW + 2, HR = HROWS * HWID;       // 6 x 10 halo pixels
+    constexpr int XBK = 32, XLD = XBK + 8, LP = 448;                       // pixel / line pitch in halfs (as the 8 x 8 patch)
+    constexpr int HPL = HROWS * LP;                                        // halfs per plane of one slab
+    constexpr int SLAB_H = 2 * HPL;                                        // hi plane, lo plane
+    constexpr int STAGE_H = 4 * SLAB_H;                                    // four slabs = 128 channels
+    constexpr int NH = (HR * 32 + 255) / 256;                              // float4 pieces per thread and stage (8)
+    constexpr int LDR = BN + 4;
+    static_assert(4 * BM * LDR * 4 <= 2 * STAGE_H * 2, "the partial tiles must fit the operand LDS");
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * STAGE_H];
+    __shared__ float gstat_unused[2];
+    (void)gstat_unused;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    int bx, by, bz;
+    xcd_block(p, bx, by, bz);
+    const int n0 = by * BN;
+    const int tiles_x = p.Wo / TW, tiles_img = tiles_x * (p.Ho / TH);
+    const int b = bx / tiles_img;
+    const int t_img = bx - b * tiles_img;
+    const int ty0 = (t_img / tiles_x) * TH, tx0 = (t_img % tiles_x) * TW;
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, (int)p.w_plane_bytes, 0x00020000);
+
+    // staging map: piece = (halo pixel, float4 column of the 128 channels); 256 % 32 == 0, so a thread keeps ONE column
+    const int c4 = tid & 31, my_slab = c4 >> 3, col4 = c4 & 7;
+    unsigned h_off[NH];
+    int h_lds[NH];
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+        const int row = (tid >> 5) + 8 * j;                    // halo pixel 0 .. 63 (60 valid)
+        const int hy = row / HWID, hx = row - hy * HWID;
+        const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
+        const bool ok = row < HR && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        h_off[j] = ok ? (unsigned)(((b * p.Hi + iy) * p.Wi + ix) * p.lda + c4 * 4) * 4u : 0xFFFFFFFFu;
+        h_lds[j] = row < HR ? my_slab * SLAB_H + hy * LP + hx * XLD + col4 * 4 : -1;
+    }
+    const int stages = p.Cin / 128;
+    const unsigned bf_off = ((unsigned)(n0 >> 5) * ((unsigned)p.ldb / 32u) * 256u + (unsigned)lane) * 16u;
+
+    f32x4 hreg[NH];
+    f32x4 gt0, gt1;
+    auto hload = [&](int g, bool live) {
+        const unsigned coff = (unsigned)g * (128u * 4u);
+#pragma unroll
+        for (int j = 0; j < NH; ++j) {
+            const unsigned o = xsel(live && h_off[j] != 0xFFFFFFFFu, h_off[j] + coff, p.x_bytes);
+            hreg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)o, 0, 0));
+        }
+        if constexpr (GN) gn_scale_shift(p, b, (live ? g : 0) * 128 + c4 * 4, gt0, gt1);
+    };
+    auto hprep_piece = [&](const int j) {
+        u32x2 hi, lo;
+        f32x4 v = hreg[j];
+        if constexpr (GN) {
+            v[0] = v[0] * gt0[0] + gt0[1];
+            v[1] = v[1] * gt0[2] + gt0[3];
+            v[2] = v[2] * gt1[0] + gt1[1];
+            v[3] = v[3] * gt1[2] + gt1[3];
+            if (p.gn_swish) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = sgam_swish(v[e]);
+            }
+            if (h_off[j] == 0xFFFFFFFFu) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        split4(v, hi, lo);
+        hreg[j] = __builtin_bit_cast(f32x4, u32x4{hi[0], hi[1], lo[0], lo[1]});
+    };
+    auto hstore = [&](int hb) {
+        unsigned short *halo = smem + hb * STAGE_H;
+#pragma unroll
+        for (int j = 0; j < NH; ++j) {
+            const u32x4 q = __builtin_bit_cast(u32x4, hreg[j]);
+            if (h_lds[j] >= 0) {
+                *reinterpret_cast<u32x2 *>(halo + h_lds[j]) = u32x2{q[0], q[1]};
+                *reinterpret_cast<u32x2 *>(halo + HPL + h_lds[j]) = u32x2{q[2], q[3]};
+            }
+        }
+    };
+    // weight fragments of THIS wavefront's slab of the stage: channel slab 4 g + wave, two taps ahead, three register sets
+    u32x4 bq[3][2][2];                     // [tap % 3][k-step][hi, lo]
+    auto bload = [&](const int set, int tap, int g, bool live) {
+        const unsigned koff = (unsigned)(tap * p.Cin + (4 * g + wave) * XBK) * 128u;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+                bq[set][kk][pl] = __builtin_amdgcn_raw_buffer_load_b128(
+                    rw, (int)xsel(live, bf_off + koff + (unsigned)((pl * 2 + kk) * 1024), p.w_plane_bytes), 0, 0);
+    };
+
+    // one accumulator per product term: three independent MFMA chains
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    const int frag_row = lane & 31, frag_k = (lane >> 5) * 8;
+    const int a_base = (frag_row >> 3) * LP + (frag_row & 7) * XLD + frag_k + wave * SLAB_H;
+
+    int hcur = 0;
+    hload(0, true);
+    bload(0, 0, 0, true);
+    bload(1, 1, 0, true);
+#pragma unroll
+    for (int j = 0; j < NH; ++j) hprep_piece(j);
+    hstore(0);
+    hload(1, 1 < stages);
+    __syncthreads();
+
+    u32x4 fa[2][2];                        // [step parity][hi, lo]
+#define K4_DS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+    for (int g = 0; g < stages; ++g) {
+        const bool has_next = g + 1 < stages;
+        const unsigned a_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short *)(smem + hcur * STAGE_H) +
+                               2u * (unsigned)a_base;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int set = tap % 3;
+            if (tap < 7) bload((tap + 2) % 3, tap + 2, g, true);
+            else bload((tap + 2) % 3, tap - 7, g + 1, has_next);
+            if (tap < NH) hprep_piece(tap);                     // next stage's halo: one piece per tap (NH = 8)
+            if (tap == NH) {
+                hstore(hcur ^ 1);                               // idle buffer: nobody reads it during this stage
+                hload(g + 2, g + 2 < stages);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int q = tap * 2 + kk;
+                auto rd = [&](const int st, const int tp, const int k2) {
+                    const int ky = tp / 3, kx = tp - 3 * ky;
+                    K4_DS_READ(fa[st][0], a_lds, 2 * (ky * LP + kx * XLD + k2 * 16));
+                    K4_DS_READ(fa[st][1], a_lds, 2 * (ky * LP + kx * XLD + k2 * 16 + HPL));
+                };
+                if (q == 0) rd(0, 0, 0);
+                if (q < 17) rd((q + 1) & 1, (q + 1) >> 1, (q + 1) & 1);
+                if (q < 17) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[q & 1][0]), "+v"(fa[q & 1][1]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[q & 1][0]), "+v"(fa[q & 1][1]));
+                acc[0] = mfma16(fa[q & 1][1], bq[set][kk][0], acc[0]);       // a_lo b_hi
+                acc[1] = mfma16(fa[q & 1][0], bq[set][kk][1], acc[1]);       // a_hi b_lo
+                acc[2] = mfma16(fa[q & 1][0], bq[set][kk][0], acc[2]);       // a_hi b_hi
+            }
+        }
+        __syncthreads();
+        hcur ^= 1;
+    }
+    __syncthreads();
+
+    // ---- the four wavefronts' partial tiles meet in LDS; small terms first, then the fixed order w = 0, 1, 2, 3
+    float *xr = reinterpret_cast<float *>(smem);
+    {
+        const int col_l = lane & 31, row_h = 4 * (lane >> 5);
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            xr[(wave * BM + (e & 3) + 8 * (e >> 2) + row_h) * LDR + col_l] = (acc[0][e] + acc[1][e]) + acc[2][e];
+    }
+    __syncthreads();
+    const int row = tid >> 3, c4o = tid & 7;                   // 32 rows x 8 float4 columns = 256 threads
+    f32x4 v = *reinterpret_cast<const f32x4 *>(xr + (0 * BM + row) * LDR + c4o * 4);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4 *>(xr + (w * BM + row) * LDR + c4o * 4);
+    const int m = (b * p.Ho + ty0 + (row >> 3)) * p.Wo + tx0 + (row & 7);
+    const int n4 = n0 + c4o * 4;
+    const bool ok = n4 < p.n_valid;                            // n_valid is a multiple of 4
+    v = v * p.inv_w_scale;
+    if (p.bias && ok) v += p.bias_per_row ? f32x4{p.bias[m], p.bias[m], p.bias[m], p.bias[m]} : *reinterpret_cast<const f32x4 *>(p.bias + n4);
+    if (p.res && ok) v += *reinterpret_cast<const f32x4 *>(p.res + (int64_t)m * p.ldr + n4);
+    if (ok) *reinterpret_cast<f32x4 *>(p.out + (int64_t)m * p.ldc + n4) = v;
+    const float t4 = (v[0] + v[1]) + (v[2] + v[3]);
+    if (ok && p.range_flag && sgam_not_finite(t4)) atomicOr(p.range_flag, 1);
+    if (p.gn_partial) {
+        // GroupNorm statistics of the 32 x 32 output tile: chunk = this patch, groups = the tile's 32 / cpg groups
+        __syncthreads();                                       // everybody is done reading the partial tiles
+        float *sl = xr;                                        // [32 rows][8 columns][2]
+        sl[(row * 8 + c4o) * 2] = t4;
+        sl[(row * 8 + c4o) * 2 + 1] = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        __syncthreads();
+        const int c4_per_group = p.gn_cpg / 4, groups_here = 8 / c4_per_group;
+        if (tid < groups_here) {
+            double ds = 0.0, dss = 0.0;
+            for (int r = 0; r < BM; ++r)
+                for (int k = 0; k < c4_per_group; ++k) {
+                    const int l = r * 8 + tid * c4_per_group + k;
+                    ds += (double)sl[l * 2];
+                    dss += (double)sl[l * 2 + 1];
+                }
+            const int g = n0 / p.gn_cpg + tid, groups = p.N / p.gn_cpg;
+            double *o = p.gn_partial + (((int64_t)b * tiles_img + t_img) * groups + g) * 2;
+            o[0] = ds;
+            o[1] = dss;
+        }
+    }
+}
+
 // fixed-order split-K reduction (partials are still weight-scaled) + un-scale + bias + residual; optionally the GroupNorm
 // statistics of what it writes: a workgroup covers 1024 / N whole output rows (N in {128, 256, 512, 1024}), lanes of one
 // (row, group) are neighbours -> shuffle fold, rows -> LDS fold, one {sum, sumsq} pair per (workgroup = chunk, group).
@@ -919,7 +1131,16 @@ struct XPlan {
 
 // shapes the halo-staged 3x3 kernels take: 3x3 / stride 1 / pad 1, no upsampling, 8 x 16 (8 x 8) output patches, whole
 // 32-channel slabs
+// shapes the K-in-workgroup kernel takes (plan tile (32, 32)): 3x3 / s1 / p1, no upsampling, 4 x 8 patches, 128-channel steps
+static bool k4_shape(const sgam_conv_desc *d) {
+    static const int k4_on = [] { const char *e = getenv("SGAM_F32X_K4"); return (e && e[0] == '0') ? 0 : 1; }();
+    return k4_on && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 && !d->upsample2x &&
+           d->Ho == d->Hi && d->Wo == d->Wi && d->Ho % 4 == 0 && d->Wo % 8 == 0 && d->Cin % 128 == 0 && d->N % 32 == 0 &&
+           d->bias_per_row == 0;
+}
+
 static bool halo_shape(const sgam_conv_desc *d, int bm, int bn) {
+    if (bm == 32 && bn == 32) return k4_shape(d);
     static const int halo_on = [] { const char *e = getenv("SGAM_F32X_HALO"); return (e && e[0] == '0') ? 0 : 1; }();
     const bool tile_ok = (bm == 128 && bn == 128 && d->Wo % 16 == 0) || (bm == 64 && bn == 128 && d->Wo % 8 == 0);
     const int up = d->upsample2x ? 2 : 1;
@@ -934,7 +1155,14 @@ XPlan make_xplan(const sgam_conv_desc *d) {
     if (d->N % 128 == 0 && blocks(128, 128) >= 224) { pl.bm = 128; pl.bn = 128; }
     else if (d->N % 128 == 0 && blocks(64, 128) >= 224) { pl.bm = 64; pl.bn = 128; }
     else { pl.bm = 64; pl.bn = 64; }
+    // small maps with deep K (the 16^2 / 32^2 levels): K inside the workgroup instead of a split-K plan
+    if (d->plan_bm == 0 && M <= 1024 && d->Cin >= 256 && k4_shape(d)) { pl.bm = 32; pl.bn = 32; }
     if (d->plan_bm > 0 && d->plan_bn > 0) { pl.bm = d->plan_bm; pl.bn = d->plan_bn; }
+    if (pl.bm == 32 && pl.bn == 32) {
+        pl.iters_total = pl.iters_per_split = 9 * (d->Cin / 32);
+        pl.ksplit = 1;
+        return pl;
+    }
     const int xbk = xbk_of(pl.bm, pl.bn);
     pl.iters_total = d->KH * d->KW * ((d->Cin + xbk - 1) / xbk);
     const int64_t nb = blocks(pl.bm, pl.bn);
@@ -967,7 +1195,7 @@ int xvalidate(const sgam_conv_desc *d) {
     if (d->n_valid % 4 != 0 || d->ldc % 4 != 0 || d->ldr % 4 != 0) return SGAM_EALIGN;   // 16-byte epilogue accesses
     if (d->plan_bm != 0 || d->plan_bn != 0) {
         const bool ok = (d->plan_bm == 128 && d->plan_bn == 128) || (d->plan_bm == 64 && d->plan_bn == 128) ||
-                        (d->plan_bm == 64 && d->plan_bn == 64);
+                        (d->plan_bm == 64 && d->plan_bn == 64) || (d->plan_bm == 32 && d->plan_bn == 32 && k4_shape(d));
         if (!ok || (d->plan_bn == 128 && d->N % 128 != 0)) return SGAM_EINVAL;
     }
     if (d->plan_ksplit < 0 || d->plan_ksplit > 64) return SGAM_EINVAL;
@@ -1023,6 +1251,7 @@ extern "C" int32_t sgam_conv2d_f32x_stats_chunks(const sgam_conv_desc *d) {
     const XPlan pl = make_xplan(d);
     const int hw = d->Ho * d->Wo;
     if (d->N % 128 != 0 || d->n_valid != d->N) return 0;                           // 32 groups of >= 4 channels, complete rows
+    if (pl.bm == 32) return (d->B > 1 && hw % 32 != 0) ? 0 : hw / 32;               // K-in-workgroup kernel: one chunk per patch
     if (pl.ksplit == 1) {
         // from the conv epilogue: one chunk per (tile, wavefront row)
         if (d->B > 1 && hw % pl.bm != 0) return 0;                                 // a tile must not straddle two images
@@ -1127,7 +1356,11 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
         sgam_i_prof_work(2.0 * p.M * d->n_valid * (double)(d->KH * d->KW * d->Cin),
                          4.0 * ((double)d->B * d->Hi * d->Wi * d->Cin + (double)d->n_valid * d->KH * d->KW * d->Cin +
                                 (double)p.M * d->n_valid * (residual ? 2 : 1)));
-    if (halo) {
+    if (halo && pl.bm == 32) {
+        if (a_scale != 1.0f) return SGAM_EINVAL;
+        if (p.gn_stats) SGAM_KLAUNCH((conv3x3_f32x_k4_kernel<true>), grid, dim3(256), 0, s, p);
+        else SGAM_KLAUNCH((conv3x3_f32x_k4_kernel<false>), grid, dim3(256), 0, s, p);
+    } else if (halo) {
         if (p.ups) {
             if (pl.bm == 128) SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<128, 128, false, true>), grid, dim3(256), 0, s, p);
             else SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<64, 128, false, true>), grid, dim3(256), 0, s, p);

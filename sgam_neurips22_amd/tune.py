@@ -19,7 +19,7 @@ import torch
 from . import _lib, ops, testing
 from ._lib import ConvDesc
 
-TILES = [(128, 128), (64, 128), (64, 64)]
+TILES = [(128, 128), (64, 128), (64, 64), (32, 32)]
 
 
 def _parse(key):

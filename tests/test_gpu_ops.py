@@ -389,3 +389,52 @@ def test_fused_attention_at_the_512sq_size():
     q, k, v = qkv[rows, :C].double(), qkv[:, C:2 * C].double(), qkv[:, 2 * C:].double()
     ref = torch.softmax(q @ k.t() * scale, dim=1) @ v
     _close(o[rows], ref, 2e-5, "fused attention, n = 16384")
+
+
+@pytest.mark.parametrize("B,C,Cout,H,W,gn,with_res", [(1, 512, 512, 16, 16, True, True), (1, 256, 256, 32, 32, True, False),
+                                                     (2, 256, 512, 16, 24, False, True), (1, 128, 160, 8, 16, False, False)])
+def test_small_map_k_in_workgroup_kernel(B, C, Cout, H, W, gn, with_res):
+    """conv3x3_f32x_k4_kernel (plan tile (32, 32)): K split across the wavefronts of a workgroup, no split-K launch —
+    against fp64, with GroupNorm(+swish) fused into the staging, and the GroupNorm statistics of its output."""
+    ops.set_f32_mode("split")
+    x = _nhwc(testing.seeded_tensor("k4.x", (B, C, H, W), 1.2, 0.3)).to(DEV)
+    w = testing.seeded_tensor("k4.w", (Cout, C, 3, 3), scale=(1.0 / (C * 9)) ** 0.5)
+    bias = testing.seeded_tensor("k4.b", (Cout,), 0.1).to(DEV)
+    res = _nhwc(testing.seeded_tensor("k4.r", (B, Cout, H, W))).to(DEV) if with_res else None
+    g = (1 + 0.1 * testing.seeded_tensor("k4.g", (C,))).to(DEV)
+    bt = (0.1 * testing.seeded_tensor("k4.bt", (C,))).to(DEV)
+    wp = ops.pack_conv_weight(w.to(DEV), dtype="f32x")
+    key = f"f32x|B{B}|{H}x{W}x{C}|{H}x{W}|N{wp.shape[0]}|k3x3s1u0"
+    old = ops.PLAN_CACHE.get(key)
+    ops.PLAN_CACHE[key] = (32, 32, 1)
+    try:
+        kw = dict(cout=Cout, kh=3, kw=3, pad_t=1, pad_l=1, residual=res)
+        out = ops.conv2d_nhwc(x, wp, bias, norm=(g, bt, True, 32, 1e-6) if gn else None, **kw)
+    finally:
+        if old is None:
+            ops.PLAN_CACHE.pop(key, None)
+        else:
+            ops.PLAN_CACHE[key] = old
+    xin = x.permute(0, 3, 1, 2).cpu()
+    if gn:
+        xin = F.group_norm(xin, 32, g.cpu(), bt.cpu(), eps=1e-6)
+        xin = xin * torch.sigmoid(xin)
+    ref = F.conv2d(xin.double(), w.double(), bias.cpu().double(), padding=1).float()
+    if with_res:
+        ref = ref + res.permute(0, 3, 1, 2).cpu()
+    _close(out.permute(0, 3, 1, 2), ref, 2e-5, "K-in-workgroup conv")
+    if Cout % 128 == 0:
+        assert hasattr(out, "_gn_partials")
+        st = ops.groupnorm_meanrstd(out).cpu()
+        og = out.permute(0, 3, 1, 2).cpu().double().reshape(B, 32, -1)
+        assert torch.allclose(st[:, :, 0].double(), og.mean(-1), rtol=0, atol=2e-6)
+        assert torch.allclose(st[:, :, 1].double(), (og.var(-1, unbiased=False) + 1e-6).rsqrt(), rtol=2e-6, atol=0)
+    for _ in range(3):      # run-to-run deterministic
+        ops.PLAN_CACHE[key] = (32, 32, 1)
+        try:
+            again = ops.conv2d_nhwc(x, wp, bias, norm=(g, bt, True, 32, 1e-6) if gn else None, **kw)
+        finally:
+            ops.PLAN_CACHE.pop(key, None)
+            if old is not None:
+                ops.PLAN_CACHE[key] = old
+        assert torch.equal(out, again)
