@@ -4,7 +4,8 @@ import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libsgam_hip.so")
+# SGAM_HIP_LIB: an alternative build of the same library (kernel A/B experiments, scripts/exp_*.sh); default = the in-tree build
+LIB_PATH = os.environ.get("SGAM_HIP_LIB") or os.path.join(_PKG, "lib", "libsgam_hip.so")
 
 c_i32, c_i64, c_f32, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 

@@ -8,7 +8,7 @@ import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
-LIBDIR = os.path.join(PKG, "lib")
+LIBDIR = os.environ.get("SGAM_LIB_DIR") or os.path.join(PKG, "lib")     # SGAM_LIB_DIR: variant builds for A/B experiments
 LIB = os.path.join(LIBDIR, "libsgam_hip.so")
 ARCH = "gfx950"
 
@@ -23,7 +23,8 @@ SOURCES = {
                       f"-DSGAM_XPF_SMALL={os.environ.get('SGAM_XPF_SMALL', '2')}",
                       f"-DSGAM_XABLATE={os.environ.get('SGAM_XABLATE', '0')}",
                       f"-DSGAM_XSB={os.environ.get('SGAM_XSB', '1')}",
-                      f"-DSGAM_XWGM={os.environ.get('SGAM_XWGM', '1')}"],
+                      f"-DSGAM_XWGM={os.environ.get('SGAM_XWGM', '1')}",
+                      f"-DSGAM_XSOFF={os.environ.get('SGAM_XSOFF', '1')}"],
     "attention.hip": [f"-DSGAM_ATTN_ABLATE={os.environ.get('SGAM_ATTN_ABLATE', '0')}"],
     "vq.hip": ["-ffp-contract=off"],
     "layout.hip": ["-ffp-contract=off"],

@@ -852,18 +852,47 @@ __global__ __launch_bounds__(256) void conv3x3_f32x_k4_kernel(const XParams p) {
         h_lds[j] = row < HR ? my_slab * SLAB_H + hy * LP + hx * XLD + col4 * 4 : -1;
     }
     const int stages = p.Cin / 128;
+    // The workgroups of one channel tile (8 .. 32 patches) all stream the SAME weights.  Started in step they would request
+    // the same lines at the same time: one miss in flight per line however many workgroups wait for it, i.e. the layer would
+    // run at the latency of a single cold stream (measured: 20 us inside a frame against 9 - 11 us back to back, weights
+    // hot).  Patch i therefore walks the 128-channel steps in the rotated order i, i + 1, ... (mod steps): the patches of a
+    // tile pull different parts of the weight panel concurrently and find the others' parts in L2 afterwards.  The order
+    // is a fixed function of the patch: results stay bit-reproducible.
+    const int phase = t_img % stages;
+    auto rot = [&](int g) { const int r = g + phase; return r >= stages ? r - stages : r; };
+    // ... and the three filter ROWS of a step in the rotated order row_rot, row_rot + 1, ... (mod 3): stages x 3 distinct
+    // walks, so the eight patches of a 16 x 16 map never ask for the same fragment at the same time
+    const int row_rot = (t_img / stages) % 3;
     const unsigned bf_off = ((unsigned)(n0 >> 5) * ((unsigned)p.ldb / 32u) * 256u + (unsigned)lane) * 16u;
 
     f32x4 hreg[NH];
+    // GroupNorm scale / shift of this thread's four channels for EVERY step, formed once (the column is fixed per thread):
+    // a load inside the loop would be the newest entry of the in-order VMEM queue right when it is needed, i.e. every step
+    // would wait for all the weight fragments requested ahead (vmcnt(0)) and the deep prefetch below would be void
+    constexpr int MAXST = 8;               // Cin <= 1024
+    f32x4 gts[MAXST][2];
+    if constexpr (GN) {
+#pragma unroll
+        for (int g = 0; g < MAXST; ++g)
+            if (g < stages) gn_scale_shift(p, b, g * 128 + c4 * 4, gts[g][0], gts[g][1]);
+    }
     f32x4 gt0, gt1;
-    auto hload = [&](int g, bool live) {
+    auto hload = [&](int g_seq, bool live) {
+        const int g = live ? rot(g_seq) : 0;
         const unsigned coff = (unsigned)g * (128u * 4u);
 #pragma unroll
         for (int j = 0; j < NH; ++j) {
             const unsigned o = xsel(live && h_off[j] != 0xFFFFFFFFu, h_off[j] + coff, p.x_bytes);
             hreg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)o, 0, 0));
         }
-        if constexpr (GN) gn_scale_shift(p, b, (live ? g : 0) * 128 + c4 * 4, gt0, gt1);
+        if constexpr (GN) {
+#pragma unroll
+            for (int k = 0; k < MAXST; ++k)
+                if (k == g) {
+                    gt0 = gts[k][0];
+                    gt1 = gts[k][1];
+                }
+        }
     };
     auto hprep_piece = [&](const int j) {
         u32x2 hi, lo;
@@ -894,8 +923,11 @@ __global__ __launch_bounds__(256) void conv3x3_f32x_k4_kernel(const XParams p) {
         }
     };
     // weight fragments of THIS wavefront's slab of the stage: channel slab 4 g + wave, two taps ahead, three register sets
-    u32x4 bq[3][2][2];                     // [tap % 3][k-step][hi, lo]
-    auto bload = [&](const int set, int tap, int g, bool live) {
+    u32x4 bq[9][2][2];                     // [tap][k-step][hi, lo]
+    auto bload = [&](const int set, int tap_seq, int g_seq, bool live) {
+        const int g = live ? rot(g_seq) : 0;
+        int tap = tap_seq + 3 * row_rot;           // the filter tap this position of the walk multiplies
+        tap = tap >= 9 ? tap - 9 : tap;
         const unsigned koff = (unsigned)(tap * p.Cin + (4 * g + wave) * XBK) * 128u;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
@@ -917,8 +949,8 @@ __global__ __launch_bounds__(256) void conv3x3_f32x_k4_kernel(const XParams p) {
 
     int hcur = 0;
     hload(0, true);
-    bload(0, 0, 0, true);
-    bload(1, 1, 0, true);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) bload(t, t, 0, true);
 #pragma unroll
     for (int j = 0; j < NH; ++j) hprep_piece(j);
     hstore(0);
@@ -929,13 +961,17 @@ __global__ __launch_bounds__(256) void conv3x3_f32x_k4_kernel(const XParams p) {
 #define K4_DS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
     for (int g = 0; g < stages; ++g) {
         const bool has_next = g + 1 < stages;
-        const unsigned a_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short *)(smem + hcur * STAGE_H) +
-                               2u * (unsigned)a_base;
+        const unsigned a_lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short *)(smem + hcur * STAGE_H) +
+                                2u * (unsigned)a_base;
+        unsigned a_row[3];                     // halo line of filter row (j + row_rot) % 3, j = position in the walk
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int ky = j + row_rot >= 3 ? j + row_rot - 3 : j + row_rot;
+            a_row[j] = a_lds0 + 2u * (unsigned)(ky * LP);
+        }
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int set = tap % 3;
-            if (tap < 7) bload((tap + 2) % 3, tap + 2, g, true);
-            else bload((tap + 2) % 3, tap - 7, g + 1, has_next);
+            const int set = tap;
             if (tap < NH) hprep_piece(tap);                     // next stage's halo: one piece per tap (NH = 8)
             if (tap == NH) {
                 hstore(hcur ^ 1);                               // idle buffer: nobody reads it during this stage
@@ -945,9 +981,9 @@ __global__ __launch_bounds__(256) void conv3x3_f32x_k4_kernel(const XParams p) {
             for (int kk = 0; kk < 2; ++kk) {
                 const int q = tap * 2 + kk;
                 auto rd = [&](const int st, const int tp, const int k2) {
-                    const int ky = tp / 3, kx = tp - 3 * ky;
-                    K4_DS_READ(fa[st][0], a_lds, 2 * (ky * LP + kx * XLD + k2 * 16));
-                    K4_DS_READ(fa[st][1], a_lds, 2 * (ky * LP + kx * XLD + k2 * 16 + HPL));
+                    const int kyj = tp / 3, kx = tp - 3 * kyj;
+                    K4_DS_READ(fa[st][0], a_row[kyj], 2 * (kx * XLD + k2 * 16));
+                    K4_DS_READ(fa[st][1], a_row[kyj], 2 * (kx * XLD + k2 * 16 + HPL));
                 };
                 if (q == 0) rd(0, 0, 0);
                 if (q < 17) rd((q + 1) & 1, (q + 1) >> 1, (q + 1) & 1);
@@ -957,6 +993,7 @@ __global__ __launch_bounds__(256) void conv3x3_f32x_k4_kernel(const XParams p) {
                 acc[1] = mfma16(fa[q & 1][0], bq[set][kk][1], acc[1]);       // a_hi b_lo
                 acc[2] = mfma16(fa[q & 1][0], bq[set][kk][0], acc[2]);       // a_hi b_hi
             }
+            bload(tap, tap, g + 1, has_next);                   // this tap's registers are free: the next stage's fragments
         }
         __syncthreads();
         hcur ^= 1;
@@ -1133,8 +1170,7 @@ struct XPlan {
 // 32-channel slabs
 // shapes the K-in-workgroup kernel takes (plan tile (32, 32)): 3x3 / s1 / p1, no upsampling, 4 x 8 patches, 128-channel steps
 static bool k4_shape(const sgam_conv_desc *d) {
-    static const int k4_on = [] { const char *e = getenv("SGAM_F32X_K4"); return (e && e[0] == '0') ? 0 : 1; }();
-    return k4_on && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 && !d->upsample2x &&
+    return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 && !d->upsample2x &&
            d->Ho == d->Hi && d->Wo == d->Wi && d->Ho % 4 == 0 && d->Wo % 8 == 0 && d->Cin % 128 == 0 && d->N % 32 == 0 &&
            d->bias_per_row == 0;
 }
@@ -1155,8 +1191,13 @@ XPlan make_xplan(const sgam_conv_desc *d) {
     if (d->N % 128 == 0 && blocks(128, 128) >= 224) { pl.bm = 128; pl.bn = 128; }
     else if (d->N % 128 == 0 && blocks(64, 128) >= 224) { pl.bm = 64; pl.bn = 128; }
     else { pl.bm = 64; pl.bn = 64; }
-    // small maps with deep K (the 16^2 / 32^2 levels): K inside the workgroup instead of a split-K plan
-    if (d->plan_bm == 0 && M <= 1024 && d->Cin >= 256 && k4_shape(d)) { pl.bm = 32; pl.bn = 32; }
+    // small maps with deep K (the 16^2 / 32^2 levels): K inside the workgroup instead of a split-K plan — opt-in
+    // (SGAM_F32X_K4=1 or an explicit (32, 32) plan).  Measured on MI355X: back to back the kernel beats the split-K plan by
+    // 4 - 7 us per layer (no combine launch), but inside a frame, with GroupNorm(+swish) fused into the staging, it loses:
+    // 32 x 32 tiles mean 16 channel tiles per patch, each re-normalising the whole 512-channel halo (4x the staging VALU
+    // work of the 128-wide tiles), and a workgroup streams its 590 KB of cold weights alone.
+    static const int k4_default = [] { const char *e = getenv("SGAM_F32X_K4"); return (e && e[0] == '1') ? 1 : 0; }();
+    if (k4_default && d->plan_bm == 0 && M <= 1024 && d->Cin >= 256 && k4_shape(d)) { pl.bm = 32; pl.bn = 32; }
     if (d->plan_bm > 0 && d->plan_bn > 0) { pl.bm = d->plan_bm; pl.bn = d->plan_bn; }
     if (pl.bm == 32 && pl.bn == 32) {
         pl.iters_total = pl.iters_per_split = 9 * (d->Cin / 32);

@@ -272,7 +272,7 @@ def pack_conv_weight(w_oihw, cout_pad=None, cin_pad=None, dtype=torch.float32):
 # ---- autotuned launch plans (sgam_neurips22_amd/tune.py): shape key -> (bm, bn, ksplit) ----
 PLAN_CACHE = {}
 PLAN_RECORD = None  # set to a dict by the tuner to collect the distinct shapes of a model run
-_PLAN_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_plans_gfx950.json")
+_PLAN_FILE = os.environ.get("SGAM_PLAN_FILE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_plans_gfx950.json")
 
 
 def plan_key(desc, dtype):
