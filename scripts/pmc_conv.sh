@@ -1,13 +1,13 @@
 #!/bin/bash
 # PMC passes for the dominant conv kernel (separate passes: SQ counters; FETCH_SIZE; WRITE_SIZE), kernel-trace only.
 export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc
+OUT=$GRAFT_REPO_ROOT/gpurun_out/${PMC_DIR:-pmc}
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp
 SHAPE=${SHAPE:-1,128,128,256,256,3}
 run() { # name, counters...
   name=$1; shift
-  timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- ${CMD:-python $GRAFT_REPO_ROOT/scripts/conv_micro.py --shape $SHAPE --reps 10} > $OUT/$name.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- ${CMD:-python $GRAFT_REPO_ROOT/scripts/conv_micro.py --shape $SHAPE --reps 10 $MICRO_ARGS} > $OUT/$name.log 2>&1
   echo "$name rc=$?"
 }
 run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY
@@ -20,7 +20,7 @@ run sq4 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM SQ_LDS_
 find $OUT -name "*.csv" | head -20
 python3 - <<'PY'
 import csv,glob,os,collections
-out=os.environ.get("GRAFT_REPO_ROOT",".")+"/gpurun_out/pmc"
+out=os.environ.get("GRAFT_REPO_ROOT",".")+"/gpurun_out/"+os.environ.get("PMC_DIR","pmc")
 for f in sorted(glob.glob(out+"/*/**/*counter_collection.csv", recursive=True)):
     rows=list(csv.DictReader(open(f)))
     agg=collections.defaultdict(lambda: collections.defaultdict(list))

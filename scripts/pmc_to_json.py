@@ -9,6 +9,11 @@ import shutil
 import sys
 
 src, kname, dst, us = sys.argv[1], sys.argv[2], sys.argv[3], float(sys.argv[4])
+# optional: B,Cin,Cout,H,W,k of the layer (default: the 128 -> 128 3x3 layer on the 256 x 256 map), element bytes of the
+# activations (4 = fp32 split path, 2 = 16-bit), and the timeline name under which bench.py looks the entry up
+shape = [int(v) for v in (sys.argv[5] if len(sys.argv) > 5 else "1,128,128,256,256,3").split(",")]
+ebytes = int(sys.argv[6]) if len(sys.argv) > 6 else 4
+tl_name = sys.argv[7] if len(sys.argv) > 7 else None
 counters, n = {}, 0
 for f in sorted(glob.glob(src + "/*/**/*counter_collection.csv", recursive=True)):
     group = f.split(src.rstrip("/") + "/")[1].split("/")[0]
@@ -25,14 +30,16 @@ for f in sorted(glob.glob(src + "/*/**/*counter_collection.csv", recursive=True)
             w = csv.DictWriter(o, fieldnames=list(keep[0].keys()))
             w.writeheader()
             w.writerows(keep)
-M, N, K = 65536, 128, 1152
+Bs, Cin_, Cout_, H_, W_, k_ = shape
+M, N, K = Bs * H_ * W_, Cout_, k_ * k_ * Cin_
 fetch = counters.get("FETCH_SIZE", 0) * 1024      # FETCH_SIZE / WRITE_SIZE are reported in KiB
 write = counters.get("WRITE_SIZE", 0) * 1024
-alg = M * 128 * 4 + M * N * 4 + N * K * 2 * 2     # input + output + the hi / lo fp16 weight halves
+alg = M * Cin_ * ebytes + M * N * ebytes + N * K * (4 if ebytes == 4 else 2)     # input + output + weights (hi / lo fp16 halves = 4 B)
 xcd_cycles = counters.get("GRBM_GUI_ACTIVE", 0) / 8.0
-d = {"kernel": f"{kname} (128 x 128 tile) on the dominant layer shape (B=1, 128->128, 3x3, 256x256: M=65536 N=128 K=1152)",
+d = {"kernel": f"{kname} on the layer B={Bs}, {Cin_}->{Cout_}, {k_}x{k_}, {H_}x{W_}: M={M} N={N} K={K}",
+     "timeline_name": tl_name,
      "command": "scripts/pmc_conv.sh (rocprofv3 --kernel-trace --pmc <group> -- python scripts/conv_micro.py "
-                "--shape 1,128,128,256,256,3 --reps 10; one pass per counter group)",
+                f"--shape {','.join(map(str, shape))} --reps 10 [--norm]; one pass per counter group)",
      "counters": counters, "launches_averaged": n,
      "derived": {"fetch_bytes_raw": fetch, "fetch_bytes_gfx950_corrected_x2": 2 * fetch, "write_bytes": write,
                  "hbm_traffic_bytes_per_launch": 2 * fetch + write, "algorithmic_bytes_per_launch": alg,
@@ -46,4 +53,14 @@ d = {"kernel": f"{kname} (128 x 128 tile) on the dominant layer shape (B=1, 128-
                  "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B for "
                          "16-B/lane loads)."}}
 json.dump(d, open(dst + ".json", "w"), indent=1)
+if tl_name:     # bench.py's roofline.traffic comes from this index, keyed by the kernel name of its timeline
+    import os
+    idx_path = os.path.join(os.path.dirname(dst), "pmc_index.json")
+    idx = json.load(open(idx_path)) if os.path.exists(idx_path) else {}
+    idx[tl_name] = {"hbm_traffic_bytes_per_launch": round(2 * fetch + write), "algorithmic_bytes_per_launch": alg,
+                    "mfma_busy_frac": d["derived"]["mfma_busy_frac"], "us_per_launch": us, "file": os.path.basename(dst) + ".json",
+                    "note": f"bytes/launch on {d['kernel']}: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE from separate rocprofv3 "
+                            f"--pmc passes; algorithmic {alg} B; in-kernel MFMA pipe busy "
+                            f"{d['derived']['mfma_busy_frac']:.3f}"}
+    json.dump(idx, open(idx_path, "w"), indent=1, sort_keys=True)
 print(json.dumps(d["derived"], indent=1))

@@ -23,6 +23,7 @@ SOURCES = {
                       f"-DSGAM_XPF_SMALL={os.environ.get('SGAM_XPF_SMALL', '2')}",
                       f"-DSGAM_XABLATE={os.environ.get('SGAM_XABLATE', '0')}",
                       f"-DSGAM_XSB={os.environ.get('SGAM_XSB', '1')}",
+                      f"-DSGAM_XNT={os.environ.get('SGAM_XNT', '0')}",
                       f"-DSGAM_XWGM={os.environ.get('SGAM_XWGM', '1')}",
                       f"-DSGAM_XSOFF={os.environ.get('SGAM_XSOFF', '1')}"],
     "attention.hip": [f"-DSGAM_ATTN_ABLATE={os.environ.get('SGAM_ATTN_ABLATE', '0')}"],

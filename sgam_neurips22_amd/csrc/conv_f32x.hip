@@ -58,6 +58,11 @@ struct XParams {
     float a_scale;       // power of two applied to the A operand before the split (e.g. 1024 for softmax probabilities)
 };
 
+// cache policy of the STREAMED operands (activation patches in, residual in, outputs out): 2 = non-temporal.  The weight
+// panel of a layer (0.6 - 9 MB) is re-read by every workgroup and should own the L2s; the activations pass through once.
+#ifndef SGAM_XNT
+#define SGAM_XNT 0
+#endif
 #ifndef SGAM_XPF_BIG
 #define SGAM_XPF_BIG 1
 #endif
@@ -200,7 +205,7 @@ __device__ __forceinline__ void xepilogue(const XParams &p, f32x16 (&acc)[BM / (
         const bool ok = n_ok && m < p.M;
         f32x4 v = *reinterpret_cast<const f32x4 *>(region + row * LDR + c4 * 4);
         const f32x4 rv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                       rr, (int)xsel(ok, (unsigned)(m * p.ldr + n4) * 4u, OOB), 0, 0));
+                                                       rr, (int)xsel(ok, (unsigned)(m * p.ldr + n4) * 4u, OOB), 0, SGAM_XNT));
         if (p.bias_per_row) {
             const float bm = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                                            rb, (int)xsel(ok, (unsigned)m * 4u, OOB), 0, 0));
@@ -208,7 +213,7 @@ __device__ __forceinline__ void xepilogue(const XParams &p, f32x16 (&acc)[BM / (
         }
         v += rv;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro,
-                                               (int)xsel(ok, (unsigned)(m * ldo + n4) * 4u, OOB), 0, 0);
+                                               (int)xsel(ok, (unsigned)(m * ldo + n4) * 4u, OOB), 0, SGAM_XNT);
         if (ok) {
             const float t4 = (v[0] + v[1]) + (v[2] + v[3]);
             gs += t4;
@@ -604,12 +609,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
     f32x4 hreg[NH];
     f32x4 gt0, gt1;
     auto hload = [&](int ch, bool live) {            // !live: out-of-range offsets (zeros come back, no memory traffic)
+        // the slab's channel offset is wave-uniform: it rides in the load's scalar offset (no VALU per load); the bounds
+        // check only sees the vector offset, so a dead load / a padding pixel (h_off = ~0) stays out of range
         const unsigned coff = (unsigned)ch * (XBK * 4u);
 #pragma unroll
-        for (int j = 0; j < NH; ++j) {
-            const unsigned o = xsel(live && h_off[j] != 0xFFFFFFFFu, h_off[j] + coff, p.x_bytes);
-            hreg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)o, 0, 0));
-        }
+        for (int j = 0; j < NH; ++j)
+            hreg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(live ? h_off[j] : 0xFFFFFFFFu), (int)coff, SGAM_XNT));
         if constexpr (GN) {
             gn_scale_shift(p, b, (live ? ch : 0) * XBK + (tid & 7) * 4, gt0, gt1);
         }
@@ -654,15 +659,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
     // round trip when a SIMD holds a single wavefront
     u32x4 bq[3][TN][2][2];                 // [tap % 3][n tile][k-step][hi, lo]
     auto bload = [&](const int set, int tap, int ch, bool live) {
-        const unsigned koff = (unsigned)(tap * p.Cin + ch * XBK) * 128u;   // 4096 bytes per (row tile, slab)
+        const unsigned koff = (unsigned)(tap * p.Cin + ch * XBK) * 128u;   // 4096 bytes per (row tile, slab); scalar offset
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TN; ++j) {
+            const unsigned vo = live ? bf_off[j] : 0xFFFFFFF0u;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl)
-                    bq[set][j][kk][pl] = __builtin_amdgcn_raw_buffer_load_b128(
-                        rw, (int)xsel(live, bf_off[j] + koff + (unsigned)((pl * 2 + kk) * 1024), p.w_plane_bytes), 0, 0);
+                    bq[set][j][kk][pl] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)vo, (int)(koff + (unsigned)((pl * 2 + kk) * 1024)), 0);
+        }
     };
 
     f32x16 acc[TM][TN];
