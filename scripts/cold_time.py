@@ -30,15 +30,32 @@ for plan in sys.argv[2:]:
     nb = lib.sgam_conv2d_f32x_workspace_bytes(ctypes.byref(d))
     ws = torch.empty((max(nb, 16),), device="cuda", dtype=torch.uint8)
 
-    def one():
+    def run():
+        lib.sgam_conv2d_nhwc_f32x(ctypes.byref(d), ops._p(x), 1.0, ops._p(w.planes), float(w.scale), None, None, ops._p(out),
+                                  ops._p(ws), nb, ops._stream())
+
+    def med(fn):
+        fn()
+        recs, br = ops.kernel_timeline(fn)
+        per = {}
+        for name, ms, *_ in recs:
+            per.setdefault(name, []).append(ms - br)
+        return {k: sorted(v)[len(v) // 2] * 1e3 for k, v in per.items()}
+
+    def cold():
         for _ in range(12):
             flush.fill_(1.0)
-            lib.sgam_conv2d_nhwc_f32x(ctypes.byref(d), ops._p(x), 1.0, ops._p(w.planes), float(w.scale), None, None, ops._p(out),
-                                      ops._p(ws), nb, ops._stream())
-    one()
-    recs, br = ops.kernel_timeline(one)
-    per = {}
-    for name, ms, *_ in recs:
-        per.setdefault(name, []).append(ms - br)
-    tot = sum(sorted(v)[len(v) // 2] for v in per.values())
-    print(f"{key} plan {plan}: COLD {tot * 1e3:6.1f} us  " + "  ".join(f"{k.split('<')[0][-22:]} {sorted(v)[len(v) // 2] * 1e3:.1f}" for k, v in per.items()))
+            run()
+
+    def warm_w():                     # weights touched after the flush (memory-side cache / some L2s), activations cold
+        for _ in range(12):
+            flush.fill_(1.0)
+            w.planes.view(torch.int32).sum()
+            run()
+
+    def hot():
+        for _ in range(12):
+            run()
+    res = {n: med(f) for n, f in (("COLD", cold), ("WARMW", warm_w), ("HOT", hot))}
+    print(f"{key} plan {plan}: " + "   ".join(
+        f"{n} {sum(v.values()):6.1f} us (" + " ".join(f"{k.split('<')[0][-14:]} {t:.1f}" for k, t in v.items()) + ")" for n, v in res.items()))

@@ -18,7 +18,6 @@ SOURCES = {
     "norm_softmax.hip": [],
     "groupnorm.hip": [],
     "h16.hip": [],
-    "h16_halo.hip": [],
     "conv_f32x.hip": [f"-DSGAM_XPF_BIG={os.environ.get('SGAM_XPF_BIG', '1')}",
                       f"-DSGAM_XPF_SMALL={os.environ.get('SGAM_XPF_SMALL', '2')}",
                       f"-DSGAM_XABLATE={os.environ.get('SGAM_XABLATE', '0')}",
@@ -26,7 +25,10 @@ SOURCES = {
                       f"-DSGAM_XNT={os.environ.get('SGAM_XNT', '0')}",
                       f"-DSGAM_XWGM={os.environ.get('SGAM_XWGM', '1')}",
                       f"-DSGAM_XSOFF={os.environ.get('SGAM_XSOFF', '1')}"],
-    "attention.hip": [f"-DSGAM_ATTN_ABLATE={os.environ.get('SGAM_ATTN_ABLATE', '0')}"],
+    "h16_halo.hip": [f"-DSGAM_HABLATE={os.environ.get('SGAM_HABLATE', '0')}",
+                     f"-DSGAM_HDIRECT={os.environ.get('SGAM_HDIRECT', '1')}"],
+    "attention.hip": [f"-DSGAM_ATTN_ABLATE={os.environ.get('SGAM_ATTN_ABLATE', '0')}",
+                      f"-DSGAM_ATTN_STAGE={os.environ.get('SGAM_ATTN_STAGE', '0')}"],
     "vq.hip": ["-ffp-contract=off"],
     "layout.hip": ["-ffp-contract=off"],
     "warp.hip": ["-ffp-contract=off"],

@@ -105,6 +105,9 @@ struct AttnParams {
 };
 
 constexpr int NSPLIT = 8;          // key ranges = XCDs
+#ifndef SGAM_ATTN_STAGE
+#define SGAM_ATTN_STAGE 0          // 1: K / V^T blocks reach LDS through registers (global_load -> ds_write), 0: by LDS-DMA
+#endif
 #ifndef SGAM_ATTN_ABLATE
 #define SGAM_ATTN_ABLATE 0         // timing experiments only (results are wrong when != 0), bit mask: 1 no staging in the
 #endif                             // loop, 2 no soft-max arithmetic, 4 no S MFMAs, 8 no PV MFMAs, 16 no loop at all
@@ -201,6 +204,14 @@ __global__ __launch_bounds__(256) void attn_flash_f32x_kernel(const AttnParams p
         ATTN_DS_READ(fh[set], base, ((t) >> 1) * 4096 + ((t) & 1) * 1024);        \
         ATTN_DS_READ(fl[set], base, ((t) >> 1) * 4096 + (2 + ((t) & 1)) * 1024);  \
     } while (0)
+#if SGAM_ATTN_STAGE
+    u32x4 st[16];
+    const unsigned goff0 = lane * 16, goff1 = lane * 16 + 4096;
+#define ATTN_GLOAD(dst, voff, base, off) \
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=a"(dst) : "v"(voff), "s"(base), "n"(off))
+#define ATTN_STAGE(src, ldsaddr, off, cnt) \
+    asm volatile("s_waitcnt vmcnt(%2)\n\tds_write_b128 %1, %0 offset:%3" : : "a"(src), "v"(ldsaddr), "n"(cnt), "n"(off))
+#endif
     __syncthreads();
 
     // ---- prologue: scores of the first block, their maximum
@@ -232,6 +243,15 @@ __global__ __launch_bounds__(256) void attn_flash_f32x_kernel(const AttnParams p
         const unsigned lk = lds_off(smem + (buf ^ 1) * BLK_BYTES + lane * 16);       // K(j+1)
         const unsigned lv = lds_off(smem + (2 + buf) * BLK_BYTES + lane * 16);       // V^T(j)
         const int kb_k = blk(j + 2), kb_v = blk(j + 1);
+#if SGAM_ATTN_STAGE
+        // K(j+2) / V^T(j+1): this wavefront's 16 KB share leaves as sixteen 1 KB loads during the S steps (one per step,
+        // into AccVGPRs: the 208 arch VGPRs are taken) and is written to LDS during the PV steps, one piece per step behind
+        // a counted vmcnt — both destination buffers are free for the whole trip
+        const unsigned char *kbase = kg + (int64_t)kb_k * BLK_BYTES + wave_s * 8192;
+        const unsigned char *vbase = vg + (int64_t)kb_v * BLK_BYTES + wave_s * 8192;
+        const unsigned lkw = lds_off(smem + buf * BLK_BYTES + wave_s * 8192 + lane * 16);
+        const unsigned lvw = lds_off(smem + (2 + (buf ^ 1)) * BLK_BYTES + wave_s * 8192 + lane * 16);
+#endif
         // ---- S(j+1) MFMAs + soft-max arithmetic of block j
 #pragma unroll
         for (int e = 0; e < 16; ++e) sacc[0][e] = sacc[1][e] = 0.f;
@@ -245,8 +265,13 @@ __global__ __launch_bounds__(256) void attn_flash_f32x_kernel(const AttnParams p
             // K(j+2) into the buffer K(j) left, V^T(j+1) into V^T(j-1)'s: all sixteen pieces leave during the S steps so
             // that they have the whole PV phase to land before the barrier drains the queue
             if (!(SGAM_ATTN_ABLATE & 1)) {
+#if SGAM_ATTN_STAGE
+                if (t < 8) ATTN_GLOAD(st[t], (t & 4) ? goff1 : goff0, kbase, (t & 3) * 1024);
+                else ATTN_GLOAD(st[t], (t & 4) ? goff1 : goff0, vbase, (t & 3) * 1024);
+#else
                 if (t < 8) dma1(kg, kb_k, buf, t);
                 else dma1(vg, kb_v, 2 + (buf ^ 1), t - 8);
+#endif
             }
             ATTN_DS_WAIT(4, t % 3);
             if (!(SGAM_ATTN_ABLATE & 4)) smfma(t);
@@ -275,6 +300,12 @@ __global__ __launch_bounds__(256) void attn_flash_f32x_kernel(const AttnParams p
             else if (u + 1 < 16) ATTN_DS_WAIT(2, (16 + u) % 3);
             else ATTN_DS_WAIT(0, (16 + u) % 3);
             const int i = u >> 1, t = u & 1, set = (16 + u) % 3;
+#if SGAM_ATTN_STAGE
+            if (!(SGAM_ATTN_ABLATE & 1)) {
+                if (u < 8) ATTN_STAGE(st[u], lkw, u * 1024, 15 - u);
+                else ATTN_STAGE(st[u], lvw, (u - 8) * 1024, 15 - u);
+            }
+#endif
             if (!(SGAM_ATTN_ABLATE & 8)) {
                 o[i] = mfma16(fh[set], ph[t], o[i]);
                 o[i] = mfma16(fh[set], pl[t], o[i]);
@@ -312,6 +343,9 @@ __global__ __launch_bounds__(256) void attn_flash_f32x_kernel(const AttnParams p
                 m_run = m_new;
             }
         }
+#if SGAM_ATTN_STAGE
+        asm volatile("s_waitcnt lgkmcnt(0)");      // the staging writes above are invisible to the compiler's own counting
+#endif
         __syncthreads();          // the arriving blocks have landed (the barrier drains the DMA queue); old ones are free
     }
 #undef ATTN_FRAG

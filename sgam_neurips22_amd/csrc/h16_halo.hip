@@ -21,6 +21,14 @@
 
 #include "sgam_common.h"
 
+#ifndef SGAM_HDIRECT
+#define SGAM_HDIRECT 1     // 1: the product is computed TRANSPOSED (weights = MFMA rows, pixels = columns) and leaves the
+#endif                     //    accumulators straight for memory; 0: pixels = rows, LDS transpose in the epilogue
+#ifndef SGAM_HABLATE
+#define SGAM_HABLATE 0     // timing experiments only (results are wrong when != 0): 1 no MFMAs, 2 no epilogue, 4 no main loop,
+                           // 8 no weight-fragment loads in the loop, 16 no halo staging in the loop, 32 stores dropped
+#endif
+
 namespace {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -75,12 +83,18 @@ __device__ __forceinline__ void hxcd_block(const HHParams &p, int &bx, int &by) 
     by = (int)(Lp / (unsigned)p.gx);
 }
 
-template <int BM, int BN, int HT, bool GN, bool UPS>
-__global__ __launch_bounds__(256, 2) void conv3x3_h16_halo_kernel(const HHParams p) {
-    constexpr int TH = 8, TW = BM / 8, TWS = (TW == 16) ? 4 : 3;
+// `SW`: the fused GroupNorm is followed by swish (a template parameter, not a flag: a run-time test per staged piece cuts the
+// main loop into a dozen basic blocks and the MFMA / VALU interleaving stops at each of their borders)
+template <int BM, int BN, int HT, bool GN, bool UPS, bool SW = true>
+__global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kernel(const HHParams p) {
+    // BM = 256 (a 16 x 16 patch, every wavefront 128 rows x 64 channels, TM = 4: a weight fragment fetched feeds four MFMAs,
+    // one workgroup per CU with the 128 accumulators in AccVGPRs) compiles and passes the tests but is not dispatched:
+    // measured 27-29 us against 25 for BM = 128 on the 256 x 256 x 128 layer (one wavefront per SIMD hides less than the
+    // halved fragment stream saves).
+    constexpr int TH = BM == 256 ? 16 : 8, TW = BM / TH, TWS = (TW == 16) ? 4 : 3;
     constexpr int HROWS = UPS ? TH / 2 + 2 : TH + 2, HWID = UPS ? TW / 2 + 2 : TW + 2, HR = HROWS * HWID;
     static_assert(!(UPS && GN), "no GroupNorm precedes an upsampling conv");
-    static_assert(BM == 128 || BM == 64, "8 x 16 or 8 x 8 output patches");
+    static_assert(BM == 256 || BM == 128 || BM == 64, "16 x 16, 8 x 16 or 8 x 8 output patches");
     static_assert(BN == 128, "2 x 2 wavefronts of 64 channels");
     constexpr int XBK = 32, XLD = XBK + 8;
     constexpr int TM = BM / 64, TN = BN / 64;
@@ -89,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h16_halo_kernel(const HHParams
     constexpr int NH = (HR * 4 + 255) / 256;            // 16-byte halo pieces (8 channels) per thread
     constexpr int OP_BYTES = 2 * HPL * 2;
     constexpr int WM = 32 * TM, WN = 32 * TN, LDR = WN + 4;
-    constexpr int EPI_BYTES = 4 * WM * LDR * 4;
+    constexpr int EPI_BYTES = SGAM_HDIRECT ? 4 * 2 * TN * 8 * 4 : 4 * WM * LDR * 4;
     constexpr int SM_BYTES = OP_BYTES > EPI_BYTES ? OP_BYTES : EPI_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned short smem[SM_BYTES / 2];
 
@@ -112,13 +126,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h16_halo_kernel(const HHParams
     int h_lds[NH];
 #pragma unroll
     for (int j = 0; j < NH; ++j) {
-        const int idx = tid + 256 * j;
+        // a thread past the end of the halo stages an earlier piece a second time (same bytes to the same place):
+        // every store is unconditional and the loop keeps one basic block
+        int idx = tid + 256 * j;
+        if (idx >= HR * 4) idx -= (NH > 1 ? 256 : HR * 4);        // (NH == 1: another thread's piece, same bytes again)
         const int row = idx >> 2, c8 = idx & 3;
         const int hy = row / HWID, hx = row - hy * HWID;
         const int iy = (UPS ? ty0 / 2 : ty0) + hy - 1, ix = (UPS ? tx0 / 2 : tx0) + hx - 1;
-        const bool ok = row < HR && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
         h_off[j] = ok ? (unsigned)(((b * p.Hi + iy) * p.Wi + ix) * p.lda + c8 * 8) * 2u : 0xFFFFFFFFu;
-        h_lds[j] = row < HR ? hy * LP + hx * XLD + c8 * 8 : -1;
+        h_lds[j] = hy * LP + hx * XLD + c8 * 8;
     }
     unsigned bf_off[TN];
 #pragma unroll
@@ -130,12 +147,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h16_halo_kernel(const HHParams
     u32x4 hreg[NH];
     float gsc[8], gsh[8];                  // GroupNorm scale / shift of this thread's 8 channels of the slab in flight
     auto hload = [&](int ch, bool live) {
-        const unsigned coff = (unsigned)ch * (XBK * 2u);
+        const unsigned coff = (unsigned)ch * (XBK * 2u);       // wave-uniform: the load's scalar offset (no VALU per load)
 #pragma unroll
-        for (int j = 0; j < NH; ++j) {
-            const unsigned o = hsel(live && h_off[j] != 0xFFFFFFFFu, h_off[j] + coff, p.x_bytes);
-            hreg[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)o, 0, 0);
-        }
+        for (int j = 0; j < NH; ++j)
+            hreg[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(live ? h_off[j] : 0xFFFFFFFFu), (int)coff, 0);
         if constexpr (GN) {
             const int c = (live ? ch : 0) * XBK + (tid & 3) * 8;
             const int cpg = p.Cin / 32;
@@ -161,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h16_halo_kernel(const HHParams
                 float v0 = HH<HT>::to_f((unsigned short)(q[w2] & 0xFFFFu)), v1 = HH<HT>::to_f((unsigned short)(q[w2] >> 16));
                 v0 = v0 * gsc[2 * w2] + gsh[2 * w2];
                 v1 = v1 * gsc[2 * w2 + 1] + gsh[2 * w2 + 1];
-                if (p.gn_swish) {
+                if constexpr (SW) {
                     v0 = sgam_swish(v0);
                     v1 = sgam_swish(v1);
                 }
@@ -175,18 +190,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h16_halo_kernel(const HHParams
         unsigned short *halo = smem + hb * HPL;
 #pragma unroll
         for (int j = 0; j < NH; ++j)
-            if (h_lds[j] >= 0) *reinterpret_cast<u32x4 *>(halo + h_lds[j]) = hreg[j];
+            *reinterpret_cast<u32x4 *>(halo + h_lds[j]) = hreg[j];
     };
 
     u32x4 bq[3][TN][2];                    // [tap % 3][n tile][k-step]
     auto bload = [&](const int set, int tap, int ch, bool live) {
-        const unsigned koff = (unsigned)(tap * p.Cin + ch * XBK) * 64u;   // 2048 bytes per (row tile, slab)
+        const unsigned koff = (unsigned)(tap * p.Cin + ch * XBK) * 64u;   // 2048 bytes per (row tile, slab); scalar offset
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TN; ++j) {
+            const unsigned vo = live ? bf_off[j] : 0xFFFFFFF0u;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
-                bq[set][j][kk] = __builtin_amdgcn_raw_buffer_load_b128(
-                    rw, (int)hsel(live, bf_off[j] + koff + (unsigned)(kk * 1024), p.w_bytes), 0, 0);
+                bq[set][j][kk] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)vo, (int)(koff + (unsigned)(kk * 1024)), 0);
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -237,16 +253,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h16_halo_kernel(const HHParams
         for (int i = 0; i < TM; ++i) HDS_READ(fa[set][i], a_lds[i], 2 * (ky * LP + kx * XLD + kk * 16));
     };
     auto await = [&](const int set, const bool next_in_flight) {      // all reads but the newest TM have landed
-        if constexpr (TM == 2) {
+        if constexpr (TM == 4) {
+            if (next_in_flight)
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[set][0]), "+v"(fa[set][1]), "+v"(fa[set][2]), "+v"(fa[set][3]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[set][0]), "+v"(fa[set][1]), "+v"(fa[set][2]), "+v"(fa[set][3]));
+        } else if constexpr (TM == 2) {
             if (next_in_flight) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[set][0]), "+v"(fa[set][1]));
             else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[set][0]), "+v"(fa[set][1]));
         } else {
-            static_assert(TM == 1 || TM == 2, "wait counts are spelled for 1 or 2 row tiles");
+            static_assert(TM == 1 || TM == 2 || TM == 4, "wait counts are spelled for 1, 2 or 4 row tiles");
             if (next_in_flight) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(fa[set][0]));
             else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[set][0]));
         }
     };
-    for (int sl = 0; sl < s1; ++sl) {
+    for (int sl = 0; sl < ((SGAM_HABLATE & 4) ? 0 : s1); ++sl) {
         const bool has_next = sl + 1 < s1;
         hb = smem + hcur * HPL;
         if constexpr (!UPS) {
@@ -257,12 +277,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h16_halo_kernel(const HHParams
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int set = tap % 3;
-            if (tap < 7) bload((tap + 2) % 3, tap + 2, sl, true);
-            else bload((tap + 2) % 3, tap - 7, sl + 1, has_next);
-            if (tap >= 1 && tap <= NH) hprep_piece(tap - 1);            // next slab's halo, one piece per tap
-            if (tap == NH + 1) {
-                hstore(hcur ^ 1);
-                hload(sl + 2, sl + 2 < s1);
+            if constexpr (!(SGAM_HABLATE & 8)) {
+                if (tap < 7) bload((tap + 2) % 3, tap + 2, sl, true);
+                else bload((tap + 2) % 3, tap - 7, sl + 1, has_next);
+            }
+            if constexpr (!(SGAM_HABLATE & 16)) {
+                if (tap >= 1 && tap <= NH) hprep_piece(tap - 1);            // next slab's halo, one piece per tap
+                if (tap == NH + 1) {
+                    hstore(hcur ^ 1);
+                    hload(sl + 2, sl + 2 < s1);
+                }
             }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
@@ -278,7 +302,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h16_halo_kernel(const HHParams
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = HH<HT>::mfma(fa[q & 1][i], bq[set][j][kk], acc[i][j]);
+                    for (int j = 0; j < TN; ++j) {
+                        if constexpr (SGAM_HABLATE & 1) acc[i][j][0] += __builtin_bit_cast(float, fa[q & 1][i][0] ^ bq[set][j][kk][0]);
+                        else if constexpr (SGAM_HDIRECT) acc[i][j] = HH<HT>::mfma(bq[set][j][kk], fa[q & 1][i], acc[i][j]);
+                        else acc[i][j] = HH<HT>::mfma(fa[q & 1][i], bq[set][j][kk], acc[i][j]);
+                    }
             }
         }
         __syncthreads();
@@ -286,8 +314,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h16_halo_kernel(const HHParams
     }
     __syncthreads();
 
-    // ---- epilogue: wave-private LDS transpose, then every lane owns 4 consecutive channels of one pixel
-    float *region = reinterpret_cast<float *>(smem) + wave * (WM * LDR);
+    if constexpr (SGAM_HABLATE & 2) {          // keep the accumulators alive through one store that never happens
+        float keep = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) keep += acc[i][j][e];
+        if (keep == 12345.678f) reinterpret_cast<float *>(p.out)[tid] = keep;
+        return;
+    }
     const int n_lim = p.n_valid;
     const unsigned osz = p.out_f32 ? 4u : 2u;
     const unsigned o_bytes = (unsigned)(((int64_t)(p.M - 1) * p.ldc + n_lim) * osz);
@@ -297,8 +334,136 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h16_halo_kernel(const HHParams
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void *)p.res, 0, (int)r_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)p.bias, 0, (int)bias_bytes, 0x00020000);
     constexpr unsigned OOB = 0xFFFFFFF0u;
-    const int col_l = lane & 31, row_h = 4 * (lane >> 5);
     const int wn0 = n0 + wn * (BN / 2);
+#if SGAM_HDIRECT
+    // ---- epilogue, transposed product: in the 32 x 32 accumulator layout lane (pixel = lane & 31, half = lane >> 5) holds
+    // MFMA rows 8 (e / 4) + 4 half + e % 4, e = 0..15; the weight rows were packed in the order that makes those the
+    // channels 16 half + e of the 32-channel tile (pack_weight_h16_frag_kernel): SIXTEEN CONSECUTIVE CHANNELS OF ONE PIXEL
+    // per lane and accumulator tile — 32 bytes of a 16-bit row (64 of an fp32 one) go out as 16-byte stores, and bias,
+    // residual and the GroupNorm statistics of the output are applied in registers: no trip through LDS.
+    const int pl = lane & 31, hh = lane >> 5;
+    int mrow[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int trow = wm * (BM / 2) + i * 32 + pl;
+        mrow[i] = (b * p.Ho + ty0 + (trow >> TWS)) * p.Wo + tx0 + (trow & (TW - 1));
+    }
+    u32x2 rq[TM][TN][4];                      // residual: four 4-channel units per (row tile, channel tile)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int n4 = wn0 + j * 32 + hh * 16 + k * 4;
+                rq[i][j][k] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
+                                                            rr, (int)hsel(n4 < n_lim, (unsigned)(mrow[i] * p.ldr + n4) * 2u, OOB), 0, 0));
+            }
+    float us[TN][4], uss[TN][4];              // per 4-channel unit: sum, sum of squares over this lane's pixels
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nb = wn0 + j * 32 + hh * 16;
+        f32x4 bv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            bv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                  rb, (int)hsel(nb + 4 * k < n_lim, (unsigned)(nb + 4 * k) * 4u, OOB), 0, 0));
+            us[j][k] = uss[j][k] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            u32x4 o16[2];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int n4 = nb + 4 * k;
+                const bool ok = n4 < n_lim;
+                const bool st_ok = ok && !(SGAM_HABLATE & 32);        // (32: every store lands out of range and is dropped)
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * k + e] + bv[k][e];
+                v[0] += HH<HT>::to_f((unsigned short)(rq[i][j][k][0] & 0xFFFFu));
+                v[1] += HH<HT>::to_f((unsigned short)(rq[i][j][k][0] >> 16));
+                v[2] += HH<HT>::to_f((unsigned short)(rq[i][j][k][1] & 0xFFFFu));
+                v[3] += HH<HT>::to_f((unsigned short)(rq[i][j][k][1] >> 16));
+                if (p.out_f32) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro,
+                                                           (int)hsel(st_ok, (unsigned)(mrow[i] * p.ldc + n4) * 4u, OOB), 0, 0);
+                } else {
+                    const unsigned short h0 = HH<HT>::from_f(v[0]), h1 = HH<HT>::from_f(v[1]), h2 = HH<HT>::from_f(v[2]),
+                                         h3 = HH<HT>::from_f(v[3]);
+                    o16[k >> 1][(k & 1) * 2] = (unsigned)h0 | ((unsigned)h1 << 16);
+                    o16[k >> 1][(k & 1) * 2 + 1] = (unsigned)h2 | ((unsigned)h3 << 16);
+                    // the statistics describe the STORED (rounded) tensor: that is what the next GroupNorm normalises
+                    v = f32x4{HH<HT>::to_f(h0), HH<HT>::to_f(h1), HH<HT>::to_f(h2), HH<HT>::to_f(h3)};
+                }
+                if (ok) {
+                    us[j][k] += (v[0] + v[1]) + (v[2] + v[3]);
+                    uss[j][k] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                }
+            }
+            if (!p.out_f32) {
+                if (nb + 16 <= n_lim) {               // the usual case: two 16-byte stores
+#pragma unroll
+                    for (int q2 = 0; q2 < 2; ++q2)
+                        __builtin_amdgcn_raw_buffer_store_b128(
+                            o16[q2], ro, (int)hsel(!(SGAM_HABLATE & 32), (unsigned)(mrow[i] * p.ldc + nb + 8 * q2) * 2u, OOB), 0, 0);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const u32x2 o8 = {o16[k >> 1][(k & 1) * 2], o16[k >> 1][(k & 1) * 2 + 1]};
+                        __builtin_amdgcn_raw_buffer_store_b64(
+                            o8, ro, (int)hsel(nb + 4 * k < n_lim && !(SGAM_HABLATE & 32), (unsigned)(mrow[i] * p.ldc + nb + 4 * k) * 2u, OOB),
+                            0, 0);
+                    }
+                }
+            }
+        }
+    }
+    if (p.gn_partial) {
+        // over the 32 pixels of a lane half (xor shuffles stay inside it), then lane 0 of each half leaves its 4 x TN units
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int off = 16; off >= 1; off >>= 1) {
+                    us[j][k] += __shfl_xor(us[j][k], off, 64);
+                    uss[j][k] += __shfl_xor(uss[j][k], off, 64);
+                }
+        float *sl = reinterpret_cast<float *>(smem) + wave * (2 * TN * 8);      // wave-private: [unit = 8 j + 4 half + k][2]
+        if (pl == 0) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    sl[(j * 8 + hh * 4 + k) * 2] = us[j][k];
+                    sl[(j * 8 + hh * 4 + k) * 2 + 1] = uss[j][k];
+                }
+        }
+        const int c4_per_group = p.gn_cpg / 4;
+        const int groups_here = (TN * 8) / c4_per_group;
+        if (lane < groups_here) {
+            double ds = 0.0, dss = 0.0;
+            for (int k = 0; k < c4_per_group; ++k) {
+                ds += (double)sl[(lane * c4_per_group + k) * 2];
+                dss += (double)sl[(lane * c4_per_group + k) * 2 + 1];
+            }
+            const int g = (wn0 / p.gn_cpg) + lane;
+            const int groups = p.N / p.gn_cpg;
+            if (g < groups) {
+                // chunk = (tile, row half, column half): two wavefronts share a row half but own different channels, so
+                // each (chunk = tile * 2 + wm, group) is written by exactly one lane of one wavefront
+                const int chunks_per_b = tiles_img * 2;
+                double *o = p.gn_partial + (((int64_t)b * chunks_per_b + t_img * 2 + wm) * groups + g) * 2;
+                o[0] = ds;
+                o[1] = dss;
+            }
+        }
+    }
+#else
+    // ---- epilogue: wave-private LDS transpose, then every lane owns 4 consecutive channels of one pixel
+    float *region = reinterpret_cast<float *>(smem) + wave * (WM * LDR);
+    const int col_l = lane & 31, row_h = 4 * (lane >> 5);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -322,6 +487,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h16_halo_kernel(const HHParams
         const int trow = wm * (BM / 2) + row;
         const int m = (b * p.Ho + ty0 + (trow >> TWS)) * p.Wo + tx0 + (trow & (TW - 1));
         const bool ok = n_ok && m < p.M;
+        const bool st_ok = ok && !(SGAM_HABLATE & 32);        // (32: every store lands out of range and is dropped)
         f32x4 v = *reinterpret_cast<const f32x4 *>(region + row * LDR + c4 * 4);
         const u32x2 rq = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
                                                        rr, (int)hsel(ok, (unsigned)(m * p.ldr + n4) * 2u, OOB), 0, 0));
@@ -330,14 +496,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h16_halo_kernel(const HHParams
         v[2] += HH<HT>::to_f((unsigned short)(rq[1] & 0xFFFFu));
         v[3] += HH<HT>::to_f((unsigned short)(rq[1] >> 16));
         if (p.out_f32) {
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, (int)hsel(ok, (unsigned)(m * p.ldc + n4) * 4u, OOB),
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, (int)hsel(st_ok, (unsigned)(m * p.ldc + n4) * 4u, OOB),
                                                    0, 0);
         } else {
             u32x2 o;
             unsigned short h0 = HH<HT>::from_f(v[0]), h1 = HH<HT>::from_f(v[1]), h2 = HH<HT>::from_f(v[2]), h3 = HH<HT>::from_f(v[3]);
             o[0] = (unsigned)h0 | ((unsigned)h1 << 16);
             o[1] = (unsigned)h2 | ((unsigned)h3 << 16);
-            __builtin_amdgcn_raw_buffer_store_b64(o, ro, (int)hsel(ok, (unsigned)(m * p.ldc + n4) * 2u, OOB), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(o, ro, (int)hsel(st_ok, (unsigned)(m * p.ldc + n4) * 2u, OOB), 0, 0);
             // the statistics describe the STORED (rounded) tensor: that is what the next GroupNorm normalises
             v = f32x4{HH<HT>::to_f(h0), HH<HT>::to_f(h1), HH<HT>::to_f(h2), HH<HT>::to_f(h3)};
         }
@@ -372,6 +538,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h16_halo_kernel(const HHParams
             }
         }
     }
+#endif
 }
 
 template <int HT>
@@ -388,7 +555,11 @@ __global__ void pack_weight_h16_frag_kernel(const float *w, unsigned short *o, i
     if (n < Cout && c < Cin) v = w[((int64_t)n * Cin + c) * taps + t];
     const int64_t k = (int64_t)t * Cin_pad + c, slabs = (int64_t)taps * Cin_pad / 32;
     const int64_t slab = k >> 5, kin = k & 31;
-    const int64_t piece = (((kin >> 4) * 2) + ((kin >> 3) & 1)) * 32 + (n & 31);
+    // row of the 32-row tile: plain (pixels = MFMA rows) or, for the transposed product, the MFMA row whose accumulator slot
+    // makes channel c = 16 half + e slot e of lane half `half`: row = 8 (e / 4) + 4 half + e % 4
+    const int c32 = n & 31;
+    const int r32 = SGAM_HDIRECT ? 8 * ((c32 & 15) >> 2) + 4 * (c32 >> 4) + (c32 & 3) : c32;
+    const int64_t piece = (((kin >> 4) * 2) + ((kin >> 3) & 1)) * 32 + r32;
     o[((((int64_t)(n >> 5)) * slabs + slab) * 128 + piece) * 8 + (kin & 7)] = HH<HT>::from_f(v);
 }
 
@@ -479,7 +650,8 @@ extern "C" int sgam_conv2d_halo_nhwc_h16(const sgam_conv_desc *d, int32_t ht, co
 #define HH_LAUNCH(BM_, HT_)                                                                                                      \
     do {                                                                                                                         \
         if (p.ups) SGAM_KLAUNCH((conv3x3_h16_halo_kernel<BM_, 128, HT_, false, true>), grid, dim3(256), 0, s, p);                \
-        else if (gn) SGAM_KLAUNCH((conv3x3_h16_halo_kernel<BM_, 128, HT_, true, false>), grid, dim3(256), 0, s, p);              \
+        else if (gn && p.gn_swish) SGAM_KLAUNCH((conv3x3_h16_halo_kernel<BM_, 128, HT_, true, false>), grid, dim3(256), 0, s, p); \
+        else if (gn) SGAM_KLAUNCH((conv3x3_h16_halo_kernel<BM_, 128, HT_, true, false, false>), grid, dim3(256), 0, s, p);        \
         else SGAM_KLAUNCH((conv3x3_h16_halo_kernel<BM_, 128, HT_, false, false>), grid, dim3(256), 0, s, p);                     \
     } while (0)
     if (bm == 128) {

@@ -125,7 +125,8 @@ def test_fused_attention_h16(dt, n):
 @pytest.mark.parametrize("dt", DT, ids=["bf16", "fp16"])
 @pytest.mark.parametrize("case", [("h128", 1, 128, 128, 128, 128, False, True, True), ("h64", 2, 128, 256, 64, 64, False, True, False),
                                   ("hups", 1, 256, 256, 32, 32, True, False, False), ("hout", 1, 128, 4, 128, 128, False, True, False),
-                                  ("h256", 1, 128, 128, 256, 256, False, True, True)], ids=lambda c: c[0])
+                                  ("h256", 1, 128, 128, 256, 256, False, True, True),
+                                  ("hups256", 1, 128, 128, 128, 128, True, False, False)], ids=lambda c: c[0])
 def test_conv_h16_halo_kernel(dt, case):
     """the 16-bit halo-staged 3x3 kernel (csrc/h16_halo.hip): plain, nearest-2x upsampled, and with GroupNorm(+swish) of
     the input applied while staging — against the fp32 operator on the same 16-bit-rounded operands; the statistics of
@@ -172,3 +173,7 @@ def test_conv_h16_halo_kernel(dt, case):
         xn = (xn * torch.sigmoid(xn)).to(dt).float()             # the staged operand is rounded once to 16 bits
         refn = F.conv2d(xn, w.to(dt).float(), b, padding=1) + (0 if res is None else res.float())
         assert fused.dtype == dt and _rel(fused.permute(0, 3, 1, 2), refn) <= 4 * EPS[dt], "GroupNorm fused into the staging"
+        plain_gn = ops.conv2d_nhwc(xd, wp, b.to(DEV), norm=(g.to(DEV), bt.to(DEV), False, 32, 1e-6), **kw)    # no swish
+        refp = F.conv2d(F.group_norm(x.float(), 32, g, bt, eps=1e-6).to(dt).float(), w.to(dt).float(), b, padding=1)
+        refp = refp + (0 if res is None else res.float())
+        assert _rel(plain_gn.permute(0, 3, 1, 2), refp) <= 4 * EPS[dt], "GroupNorm without swish fused into the staging"
