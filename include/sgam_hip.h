@@ -180,19 +180,24 @@ int sgam_conv2d_nhwc_h16(const sgam_conv_desc *d, int32_t ht, const void *x, con
 /* The 3x3 / stride 1 / pad 1 convolutions of the 16-bit mode on a halo-staged kernel (csrc/h16_halo.hip; ResnetBlock
  * conv1 / conv2, Upsample.conv, conv_out: diffusionmodules/model.py:43-53, 88-102, 117-137): input patch staged once per
  * 32-channel slab, weights in MFMA-fragment order straight to registers, optional GroupNorm(+swish) of the INPUT applied
- * while staging (gn_mean_rstd [B][32][2] or NULL, gn_gamma / gn_beta [Cin]), 8-byte row-contiguous stores, optional
- * statistics of the OUTPUT as per-chunk partial sums (gn_partial [B][sgam_conv2d_h16_stats_chunks(d)][32][2] doubles or
- * NULL).  Available when sgam_conv2d_h16_uses_halo(d) == 1 (3x3 s1 p1 on the input or its nearest-2x upsampling, Ho % 8 == 0,
- * Wo % 8 == 0, Cin % 32 == 0, N % 128 == 0, no split-K plan).  w_frag from sgam_pack_conv_weight_h16_frag:
- * [Cout_pad / 32][KH*KW*Cin_pad / 32][128 pieces][8 halfs], piece = (k-step * 2 + k-half) * 32 + row. */
+ * while staging (gn_mean_rstd [B][32][2] or NULL, gn_gamma / gn_beta [Cin]), the product computed transposed so that a lane
+ * stores 16 consecutive channels of one pixel, optional statistics of the OUTPUT as per-chunk partial sums (gn_partial
+ * [B][sgam_conv2d_h16_stats_chunks(d)][32][2] doubles or NULL).  Available when sgam_conv2d_h16_uses_halo(d) == 1 (3x3 s1 p1
+ * on the input or its nearest-2x upsampling, Ho % 8 == 0, Wo % 8 == 0, Cin % 32 == 0, N % 128 == 0).  Maps too small to fill
+ * the chip split the K slabs over grid.y (plan_ksplit, or chosen by the library): fp32 partial tiles go to `workspace`
+ * (sgam_conv2d_halo_h16_workspace_bytes(d) bytes, 0 without split-K) and a combine launch adds them in a fixed order, applies
+ * bias / residual, rounds and leaves the statistics.  w_frag from sgam_pack_conv_weight_h16_frag:
+ * [Cout_pad / 32][KH*KW*Cin_pad / 32][128 pieces][8 halfs], piece = (k-step * 2 + k-half) * 32 + row', where row' = 8 (e / 4)
+ * + 4 half + e % 4 for channel 16 half + e of the 32-channel tile (the accumulator slot order of the transposed product). */
 int32_t sgam_conv2d_h16_uses_halo(const sgam_conv_desc *d);
 int32_t sgam_conv2d_h16_stats_chunks(const sgam_conv_desc *d);
+int64_t sgam_conv2d_halo_h16_workspace_bytes(const sgam_conv_desc *d);
 int sgam_pack_conv_weight_h16_frag(const float *w_oihw, void *w_frag, int32_t ht, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW,
                                    int32_t Cout_pad, int32_t Cin_pad, void *stream);
 int sgam_conv2d_halo_nhwc_h16(const sgam_conv_desc *d, int32_t ht, const void *x, const float *gn_mean_rstd,
                               const float *gn_gamma, const float *gn_beta, int32_t gn_swish, const void *w_frag,
                               const float *bias, const void *residual, void *out, int32_t out_f32, double *gn_partial,
-                              void *stream);
+                              void *workspace, int64_t workspace_bytes, void *stream);
 /* GroupNorm of 16-bit tensors from the partial statistics the halo kernel left / {mean, rstd} of any 16-bit tensor */
 int sgam_groupnorm_from_partials_h16(const void *x, const double *partial, int32_t nchunk, const float *gamma, const float *beta,
                                      void *y, int32_t ht, int32_t B, int32_t HW, int32_t C, int32_t groups, float eps,

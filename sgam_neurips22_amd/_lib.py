@@ -71,8 +71,9 @@ PROTOTYPES = {
     "sgam_conv2d_h16_uses_halo": (c_i32, [ctypes.POINTER(ConvDesc)]),
     "sgam_conv2d_h16_stats_chunks": (c_i32, [ctypes.POINTER(ConvDesc)]),
     "sgam_pack_conv_weight_h16_frag": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "sgam_conv2d_halo_h16_workspace_bytes": (c_i64, [ctypes.POINTER(ConvDesc)]),
     "sgam_conv2d_halo_nhwc_h16": (c_i32, [ctypes.POINTER(ConvDesc), c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp,
-                                          c_i32, c_vp, c_vp]),
+                                          c_i32, c_vp, c_vp, c_i64, c_vp]),
     "sgam_groupnorm_from_partials_h16": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32,
                                                  c_i32, c_vp, c_i64, c_vp]),
     "sgam_groupnorm_meanrstd_nhwc_h16": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_i64, c_vp]),

@@ -59,6 +59,8 @@ struct HHParams {
     int B, Hi, Wi, Cin, Ho, Wo, N, ups;
     int lda, ldb, ldc, ldr, n_valid, out_f32;
     int M, slabs;
+    int ksplit, slabs_per_split;  // split-K: grid.y = ksplit ranges of the K slabs, fp32 partial tiles to `ws`
+    float *ws;                    // [ksplit][M][N] (ksplit > 1)
     int gx, gy, xcd_swizzle;
     unsigned x_bytes, w_bytes;
     const float *gn_stats, *gn_gamma, *gn_beta;   // GroupNorm(+swish) of the input: {mean, rstd} [B][32][2] + affine [Cin]
@@ -224,15 +226,16 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
         a_base[i] = a_py[i] * LP + a_px[i] * XLD + frag_k;
     }
 
-    const int s1 = p.slabs;
+    const int s0 = (int)blockIdx.y * p.slabs_per_split;            // this workgroup's range of K slabs (split-K: grid.y)
+    const int s1 = min(p.slabs, s0 + p.slabs_per_split);
     int hcur = 0;
-    hload(0, true);
-    bload(0, 0, 0, true);
-    bload(1, 1, 0, true);
+    hload(s0, true);
+    bload(0, 0, s0, true);
+    bload(1, 1, s0, true);
 #pragma unroll
     for (int j = 0; j < NH; ++j) hprep_piece(j);
     hstore(0);
-    hload(1, 1 < s1);
+    hload(s0 + 1, s0 + 1 < s1);
     __syncthreads();
 
     u32x4 fa[2][TM];
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
             else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[set][0]));
         }
     };
-    for (int sl = 0; sl < ((SGAM_HABLATE & 4) ? 0 : s1); ++sl) {
+    for (int sl = s0; sl < ((SGAM_HABLATE & 4) ? s0 : s1); ++sl) {
         const bool has_next = sl + 1 < s1;
         hb = smem + hcur * HPL;
         if constexpr (!UPS) {
@@ -347,6 +350,21 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
     for (int i = 0; i < TM; ++i) {
         const int trow = wm * (BM / 2) + i * 32 + pl;
         mrow[i] = (b * p.Ho + ty0 + (trow >> TWS)) * p.Wo + tx0 + (trow & (TW - 1));
+    }
+    if (p.ksplit > 1) {
+        // split-K: the raw fp32 partial tile of this K range; bias, residual, rounding and the statistics belong to the
+        // combine (h16_splitk_reduce_kernel), which adds the ranges in a fixed order
+        float *wsz = p.ws + (int64_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const f32x4 v = {acc[i][j][4 * k], acc[i][j][4 * k + 1], acc[i][j][4 * k + 2], acc[i][j][4 * k + 3]};
+                    *reinterpret_cast<f32x4 *>(wsz + (int64_t)mrow[i] * p.N + wn0 + j * 32 + hh * 16 + k * 4) = v;
+                }
+        return;
     }
     u32x2 rq[TM][TN][4];                      // residual: four 4-channel units per (row tile, channel tile)
 #pragma unroll
@@ -541,6 +559,79 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
 #endif
 }
 
+// split-K combine: out = round16(sum_z ws[z] + bias + residual), ranges added in the order z = 0, 1, 2, ...; thread = 4
+// channels of one pixel, workgroup = 1024 outputs = 1024 / N whole rows = one chunk of output statistics (the scheme of
+// splitk_reduce_f32x_kernel, conv_f32x.hip)
+template <int HT>
+__global__ __launch_bounds__(256) void h16_splitk_reduce_kernel(const HHParams p) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nq = p.N / 4;
+    const bool live = q < (int64_t)p.M * nq;
+    const int m = live ? (int)(q / nq) : 0;
+    const int n = live ? (int)(q - (int64_t)m * nq) * 4 : 0;
+    float gs = 0.f, gss = 0.f;
+    if (live && n < p.n_valid) {
+        const float *w0 = p.ws + (int64_t)m * p.N + n;
+        const int64_t zs = (int64_t)p.M * p.N;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bv = *reinterpret_cast<const f32x4 *>(p.bias + n);
+        u32x2 rq = {0u, 0u};
+        if (p.res) rq = *reinterpret_cast<const u32x2 *>(p.res + (int64_t)m * p.ldr + n);
+        f32x4 sum = *reinterpret_cast<const f32x4 *>(w0);
+        int z = 1;
+        for (; z + 4 <= p.ksplit; z += 4) {              // four loads in flight (a plain loop is load -> wait -> add)
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(w0 + z * zs), b2 = *reinterpret_cast<const f32x4 *>(w0 + (z + 1) * zs);
+            const f32x4 c = *reinterpret_cast<const f32x4 *>(w0 + (z + 2) * zs), d = *reinterpret_cast<const f32x4 *>(w0 + (z + 3) * zs);
+            sum += a;
+            sum += b2;
+            sum += c;
+            sum += d;
+        }
+        for (; z < p.ksplit; ++z) sum += *reinterpret_cast<const f32x4 *>(w0 + z * zs);
+        f32x4 v = sum + bv;
+        if (p.res) {
+            v[0] += HH<HT>::to_f((unsigned short)(rq[0] & 0xFFFFu));
+            v[1] += HH<HT>::to_f((unsigned short)(rq[0] >> 16));
+            v[2] += HH<HT>::to_f((unsigned short)(rq[1] & 0xFFFFu));
+            v[3] += HH<HT>::to_f((unsigned short)(rq[1] >> 16));
+        }
+        if (p.out_f32) {
+            *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(p.out) + (int64_t)m * p.ldc + n) = v;
+        } else {
+            const unsigned short h0 = HH<HT>::from_f(v[0]), h1 = HH<HT>::from_f(v[1]), h2 = HH<HT>::from_f(v[2]), h3 = HH<HT>::from_f(v[3]);
+            const u32x2 o = {(unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16)};
+            *reinterpret_cast<u32x2 *>(reinterpret_cast<unsigned short *>(p.out) + (int64_t)m * p.ldc + n) = o;
+            v = f32x4{HH<HT>::to_f(h0), HH<HT>::to_f(h1), HH<HT>::to_f(h2), HH<HT>::to_f(h3)};     // statistics of the STORED tensor
+        }
+        gs = (v[0] + v[1]) + (v[2] + v[3]);
+        gss = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+    if (!p.gn_partial) return;
+    // host guarantees: n_valid == N, 1024 % N == 0, whole workgroups inside one image
+    const int c4n = p.gn_cpg / 4;                      // lanes per (row, group): 1, 2, 4 or 8 neighbours
+    for (int o = 1; o < c4n; o <<= 1) {
+        gs += __shfl_xor(gs, o, 64);
+        gss += __shfl_xor(gss, o, 64);
+    }
+    __shared__ float sh[8][32][2];                     // [row in workgroup][group]
+    const int rows = 1024 / p.N, row = threadIdx.x / nq, g = (threadIdx.x - row * nq) / c4n;
+    if ((threadIdx.x % c4n) == 0) {
+        sh[row][g][0] = gs;
+        sh[row][g][1] = gss;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        double ds = 0.0, dss = 0.0;
+        for (int r = 0; r < rows; ++r) {
+            ds += (double)sh[r][threadIdx.x][0];
+            dss += (double)sh[r][threadIdx.x][1];
+        }
+        double *o = p.gn_partial + ((int64_t)blockIdx.x * 32 + threadIdx.x) * 2;     // chunk = workgroup (image-major)
+        o[0] = ds;
+        o[1] = dss;
+    }
+}
+
 template <int HT>
 __global__ void pack_weight_h16_frag_kernel(const float *w, unsigned short *o, int Cout, int Cin, int KH, int KW, int Cout_pad,
                                             int Cin_pad) {
@@ -571,29 +662,60 @@ bool hh_shape(const sgam_conv_desc *d, int bm) {
            d->ldb >= 9 * d->Cin && d->n_valid % 4 == 0 && d->ldc % 4 == 0 && d->ldr % 4 == 0 && d->bias_per_row == 0;
 }
 
-// tile rows for this descriptor: 128 when that still fills the chip (or the caller's plan asks for it), else 64; 0 = not a
-// halo shape
-int hh_bm(const sgam_conv_desc *d) {
-    if (!d || d->B <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->N <= 0 || d->Cin <= 0) return 0;
-    if (d->plan_ksplit > 1) return 0;                                    // the tuner wants split-K: generic kernel
+// plan for this descriptor: tile rows (128 when that still fills the chip or the caller's plan asks for it, else 64) and
+// the split of the K slabs over grid.y for maps too small to fill the chip with whole-K workgroups; bm = 0: not a halo shape
+struct HHPlan {
+    int bm = 0, ksplit = 1, slabs_per_split = 0;
+};
+
+HHPlan hh_plan(const sgam_conv_desc *d) {
+    HHPlan pl;
+    if (!d || d->B <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->N <= 0 || d->Cin <= 0) return pl;
     const int64_t M = (int64_t)d->B * d->Ho * d->Wo;
     int bm = (M / 128) * (d->N / 128) >= 224 ? 128 : 64;
     if (d->plan_bm == 128 || d->plan_bm == 64) bm = d->plan_bm;
     if (bm == 128 && !hh_shape(d, 128)) bm = 64;
-    if (!hh_shape(d, bm)) return 0;
-    // no split-K here: maps too small to fill the chip with whole-K workgroups keep the generic kernel and its split-K plan
-    return (M / bm) * (d->N / 128) >= 128 ? bm : 0;
+    if (!hh_shape(d, bm)) return pl;
+    const int slabs = d->Cin / 32;
+    const int64_t tiles = (M / bm) * (d->N / 128);
+    int ks = 1;
+    if (SGAM_HDIRECT) {
+        if (d->plan_ksplit > 0) ks = d->plan_ksplit;
+        else if (tiles < 128) ks = (int)((256 + tiles - 1) / tiles);
+        if (ks > slabs) ks = slabs;
+        if (ks > 32) ks = 32;
+    } else if (d->plan_ksplit > 1 || tiles < 128) {
+        return pl;                                  // (the LDS-transpose build has no split-K epilogue)
+    }
+    pl.bm = bm;
+    pl.slabs_per_split = (slabs + ks - 1) / ks;
+    pl.ksplit = (slabs + pl.slabs_per_split - 1) / pl.slabs_per_split;
+    return pl;
 }
+
+int hh_bm(const sgam_conv_desc *d) { return hh_plan(d).bm; }
 
 }  // namespace
 
 extern "C" int32_t sgam_conv2d_h16_uses_halo(const sgam_conv_desc *d) { return hh_bm(d) ? 1 : 0; }
 
-// chunks of output statistics per image the halo kernel leaves (sgam_conv2d_halo_nhwc_h16 with gn_partial), 0 = none
+// bytes of fp32 split-K partials sgam_conv2d_halo_nhwc_h16 needs for this descriptor (0: whole-K workgroups), -1: not a
+// halo shape
+extern "C" int64_t sgam_conv2d_halo_h16_workspace_bytes(const sgam_conv_desc *d) {
+    const HHPlan pl = hh_plan(d);
+    if (!pl.bm) return -1;
+    return pl.ksplit > 1 ? (int64_t)pl.ksplit * d->B * d->Ho * d->Wo * d->N * 4 : 0;
+}
+
+// chunks of output statistics per image the halo kernel leaves (sgam_conv2d_halo_nhwc_h16 with gn_partial), 0 = none:
+// one per (tile, wavefront row) from the epilogue, one per 1024 outputs (1024 / N whole rows) from the split-K combine
 extern "C" int32_t sgam_conv2d_h16_stats_chunks(const sgam_conv_desc *d) {
-    const int bm = hh_bm(d);
-    if (!bm || d->n_valid != d->N) return 0;
-    return (d->Ho * d->Wo / bm) * 2;
+    const HHPlan pl = hh_plan(d);
+    if (!pl.bm || d->n_valid != d->N) return 0;
+    const int hw = d->Ho * d->Wo;
+    if (pl.ksplit == 1) return (hw / pl.bm) * 2;
+    if (d->N > 1024 || 1024 % d->N != 0 || ((int64_t)hw * d->N) % 1024 != 0) return 0;
+    return (int32_t)((int64_t)hw * d->N / 1024);
 }
 
 extern "C" int sgam_pack_conv_weight_h16_frag(const float *w_oihw, void *w_frag, int32_t ht, int32_t Cout, int32_t Cin, int32_t KH,
@@ -616,8 +738,9 @@ extern "C" int sgam_pack_conv_weight_h16_frag(const float *w_oihw, void *w_frag,
 extern "C" int sgam_conv2d_halo_nhwc_h16(const sgam_conv_desc *d, int32_t ht, const void *x, const float *gn_mean_rstd,
                                          const float *gn_gamma, const float *gn_beta, int32_t gn_swish, const void *w_frag,
                                          const float *bias, const void *residual, void *out, int32_t out_f32, double *gn_partial,
-                                         void *stream) {
-    const int bm = hh_bm(d);
+                                         void *workspace, int64_t workspace_bytes, void *stream) {
+    const HHPlan pl = hh_plan(d);
+    const int bm = pl.bm;
     if (!bm || !x || !w_frag || !out || (ht != 0 && ht != 1)) return SGAM_EINVAL;
     if (!sgam_aligned16(x) || !sgam_aligned16(w_frag) || (((uintptr_t)out) & 7u) || (residual && (((uintptr_t)residual) & 7u)))
         return SGAM_EALIGN;
@@ -625,6 +748,9 @@ extern "C" int sgam_conv2d_halo_nhwc_h16(const sgam_conv_desc *d, int32_t ht, co
     if (gn && (!gn_gamma || !gn_beta || !sgam_aligned16(gn_gamma) || !sgam_aligned16(gn_beta) || d->upsample2x || d->Cin % 128))
         return SGAM_EINVAL;
     if (gn_partial && sgam_conv2d_h16_stats_chunks(d) <= 0) return SGAM_EINVAL;
+    if (pl.ksplit > 1 && (!workspace || workspace_bytes < sgam_conv2d_halo_h16_workspace_bytes(d) || !sgam_aligned16(workspace) ||
+                          (bias && !sgam_aligned16(bias))))
+        return SGAM_EINVAL;
     HHParams p;
     p.x = (const unsigned short *)x; p.w = (const unsigned short *)w_frag; p.res = (const unsigned short *)residual;
     p.bias = bias; p.out = out;
@@ -632,6 +758,7 @@ extern "C" int sgam_conv2d_halo_nhwc_h16(const sgam_conv_desc *d, int32_t ht, co
     p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldr = d->ldr; p.n_valid = d->n_valid; p.out_f32 = out_f32 ? 1 : 0;
     p.M = d->B * d->Ho * d->Wo;
     p.slabs = d->Cin / 32;
+    p.ksplit = pl.ksplit; p.slabs_per_split = pl.slabs_per_split; p.ws = (float *)workspace;
     const int64_t xb = (((int64_t)d->B * d->Hi * d->Wi - 1) * d->lda + d->Cin) * 2;
     const int64_t wb = (int64_t)d->N * d->ldb * 2;
     if (xb >= (1ll << 32) - 64 || wb >= (1ll << 32) - 256) return SGAM_EINVAL;
@@ -641,7 +768,7 @@ extern "C" int sgam_conv2d_halo_nhwc_h16(const sgam_conv_desc *d, int32_t ht, co
     p.gx = p.M / bm; p.gy = d->N / 128;
     static const int swz = [] { const char *e = getenv("SGAM_XCD_SWIZZLE"); return (e && e[0] == '0') ? 0 : 1; }();
     p.xcd_swizzle = swz;
-    const dim3 grid((unsigned)((int64_t)p.gx * p.gy));
+    const dim3 grid((unsigned)((int64_t)p.gx * p.gy), (unsigned)pl.ksplit);
     hipStream_t s = sgam_stream(stream);
     if (sgam_i_prof_on) sgam_i_prof_shape(p.M, d->n_valid, 9 * d->Cin, 1);
     if (sgam_i_prof_on)
@@ -661,5 +788,12 @@ extern "C" int sgam_conv2d_halo_nhwc_h16(const sgam_conv_desc *d, int32_t ht, co
     }
 #undef HH_LAUNCH
     SGAM_LAUNCH_CHECK();
+    if (pl.ksplit > 1) {
+        const int64_t q = (int64_t)p.M * (d->N / 4);
+        if (sgam_i_prof_on) sgam_i_prof_work(0.0, (double)pl.ksplit * p.M * d->N * 4.0 + 2.0 * p.M * d->n_valid);
+        if (ht == 0) SGAM_KLAUNCH(h16_splitk_reduce_kernel<0>, dim3(sgam_cdiv(q, 256)), dim3(256), 0, s, p);
+        else SGAM_KLAUNCH(h16_splitk_reduce_kernel<1>, dim3(sgam_cdiv(q, 256)), dim3(256), 0, s, p);
+        SGAM_LAUNCH_CHECK();
+    }
     return SGAM_OK;
 }

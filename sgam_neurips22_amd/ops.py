@@ -388,9 +388,11 @@ def _run_conv_inner(lib, desc, x, w, bias, residual, out, gn=None, a_scale=1.0):
             chunks = lib.sgam_conv2d_h16_stats_chunks(ctypes.byref(desc)) if (FUSE_GN_STATS and out.dtype in H16) else 0
             partial = torch.empty((desc.B * chunks * 32 * 2,), device=x.device, dtype=torch.float64) if chunks > 0 else None
             mr, gamma, beta, swish = gn if gn is not None else (None, None, None, False)
+            ws_bytes = lib.sgam_conv2d_halo_h16_workspace_bytes(ctypes.byref(desc))
+            ws = torch.empty((ws_bytes,), device=x.device, dtype=torch.uint8) if ws_bytes > 0 else None
             check(lib.sgam_conv2d_halo_nhwc_h16(ctypes.byref(desc), H16[x.dtype], _p(x), _p(mr), _p(gamma), _p(beta), int(swish),
                                                 _p(fw.planes), _p(bias), _p(residual), _p(out), int(out.dtype == torch.float32),
-                                                _p(partial), _stream()), "sgam_conv2d_halo_nhwc_h16")
+                                                _p(partial), _p(ws), max(ws_bytes, 0), _stream()), "sgam_conv2d_halo_nhwc_h16")
             if partial is not None:
                 out._gn_partials = (partial, chunks)
             return out

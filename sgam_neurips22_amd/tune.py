@@ -40,9 +40,12 @@ def _time(desc, x, w, out, reps=20):
            (lib.sgam_conv2d_h16_workspace_bytes if h16 else lib.sgam_conv2d_workspace_bytes))(ctypes.byref(desc))
     ws0 = torch.empty((max(nb0, 16),), device=x.device, dtype=torch.uint8) if nb0 >= 0 else None
     # 16-bit 3x3 convs run on the halo-staged kernel when the plan allows it (no split-K): time what would actually run
-    wfrag = None
+    wfrag = hws = None
+    hnb = 0
     if h16 and lib.sgam_conv2d_h16_uses_halo(ctypes.byref(desc)) == 1:
         wfrag = (torch.randn((desc.N // 32, desc.ldb // 32, 128, 8), device=x.device) * 0.03).to(x.dtype)
+        hnb = lib.sgam_conv2d_halo_h16_workspace_bytes(ctypes.byref(desc))
+        hws = torch.empty((max(hnb, 16),), device=x.device, dtype=torch.uint8)
 
     def run():
         nb, ws = nb0, ws0
@@ -53,7 +56,7 @@ def _time(desc, x, w, out, reps=20):
                                            ops._p(out), ops._p(ws), nb, ops._stream())
         elif h16 and wfrag is not None:
             rc = lib.sgam_conv2d_halo_nhwc_h16(ctypes.byref(desc), ops.H16[x.dtype], ops._p(x), None, None, None, 0, ops._p(wfrag),
-                                               None, None, ops._p(out), 0, None, ops._stream())
+                                               None, None, ops._p(out), 0, None, ops._p(hws), hnb, ops._stream())
         elif h16:
             rc = lib.sgam_conv2d_nhwc_h16(ctypes.byref(desc), ops.H16[x.dtype], ops._p(x), ops._p(w), None, None, ops._p(out),
                                           0, ops._p(ws), nb, ops._stream())

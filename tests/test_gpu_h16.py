@@ -126,7 +126,10 @@ def test_fused_attention_h16(dt, n):
 @pytest.mark.parametrize("case", [("h128", 1, 128, 128, 128, 128, False, True, True), ("h64", 2, 128, 256, 64, 64, False, True, False),
                                   ("hups", 1, 256, 256, 32, 32, True, False, False), ("hout", 1, 128, 4, 128, 128, False, True, False),
                                   ("h256", 1, 128, 128, 256, 256, False, True, True),
-                                  ("hups256", 1, 128, 128, 128, 128, True, False, False)], ids=lambda c: c[0])
+                                  ("hups256", 1, 128, 128, 128, 128, True, False, False),
+                                  # maps too small to fill the chip: K slabs split over grid.y + the combine launch
+                                  ("hsk16", 1, 512, 512, 16, 16, False, True, True), ("hsk32", 2, 256, 256, 32, 32, False, True, True),
+                                  ("hskups", 1, 512, 512, 16, 16, True, False, False)], ids=lambda c: c[0])
 def test_conv_h16_halo_kernel(dt, case):
     """the 16-bit halo-staged 3x3 kernel (csrc/h16_halo.hip): plain, nearest-2x upsampled, and with GroupNorm(+swish) of
     the input applied while staging — against the fp32 operator on the same 16-bit-rounded operands; the statistics of
