@@ -108,3 +108,67 @@ def test_product_path_refuses_cpu_tensors(model):
     with pytest.raises(ops.SgamHipError):
         ops.forward_splat(torch.zeros(1, 1, 3, 8, 8), torch.ones(1, 1, 8, 8), torch.eye(3)[None], torch.eye(3)[None],
                           torch.eye(4)[None])
+
+
+# ---- host codec boundary: the seed frame as the reference reads it, the frame store as it writes it --------
+def _write_template(root, data, seed_index, rgb, depth):
+    from PIL import Image
+    d = root / ("google_earth/seed%d" % seed_index if data == "google_earth" else "clevr-infinite")
+    d.mkdir(parents=True)
+    stem = "00000_00_00"
+    Image.fromarray(rgb).save(d / f"im_{stem}.png")
+    np.save(d / f"dm_{stem}.npy", depth)
+
+
+def test_load_template_seed_google_earth(tmp_path):
+    """inference_pipeline.py:534-537 of the reference: PIL LANCZOS resize of the PNG, nearest resize of the depth map"""
+    from PIL import Image
+    from sgam_neurips22_amd.inference_pipeline import load_template_seed
+    rs = np.random.RandomState(3)
+    rgb = rs.randint(0, 256, (512, 512, 3), dtype=np.uint8)
+    depth = rs.uniform(1.4, 3.4, (512, 512)).astype(np.float32)
+    _write_template(tmp_path, "google_earth", 2, rgb, depth)
+    got_rgb, got_d = load_template_seed("google_earth", 2, (256, 256), templates_root=str(tmp_path))
+    assert got_rgb.dtype == np.uint8 and got_rgb.shape == (256, 256, 3)
+    assert np.array_equal(got_rgb, np.array(Image.fromarray(rgb).resize((256, 256), resample=Image.LANCZOS)))
+    assert got_d.dtype == np.float32 and got_d.shape == (256, 256)
+    assert np.array_equal(got_d, depth[::2, ::2])          # F.interpolate default = nearest, source index floor(i * 2)
+
+
+def test_load_template_seed_clevr_keeps_float64(tmp_path):
+    """the CLEVR template is ray length: converted to z-depth ONCE in float64 at load (reference :71-79) and kept in
+    float64 — the second conversion and the only rounding to fp32 happen in the loop (:582-590, :607)"""
+    from sgam_neurips22_amd.inference_pipeline import intrinsics, load_template_seed, ray_to_z_depth
+    rs = np.random.RandomState(4)
+    rgb = rs.randint(0, 256, (256, 256, 3), dtype=np.uint8)
+    ray = rs.uniform(10.3, 15.5, (256, 256))               # float64 on disk, like the reference's .npy
+    _write_template(tmp_path, "clevr-infinite", 0, rgb, ray)
+    got_rgb, got_d = load_template_seed("clevr-infinite", 0, (256, 256), templates_root=str(tmp_path))
+    assert np.array_equal(got_rgb, rgb)                     # same size: LANCZOS resize is the identity
+    assert got_d.dtype == np.float64
+    assert np.array_equal(got_d, ray_to_z_depth(ray, intrinsics("clevr-infinite")))
+    assert (got_d < ray).all() or np.isclose(got_d, ray).any()      # z-depth <= ray length, equal only on the axis
+
+
+def test_export_to_disk_writes_the_reference_layout(tmp_path):
+    """save_to_disk of the reference (:928-942): im_XXXXX_ii_jj.png (lossless), dm_ / R_ / t_ .npy per visited cell; what
+    is written reads back bit for bit (the codec the in-HBM frame store replaces inside the loop)"""
+    from PIL import Image
+    from sgam_neurips22_amd.inference_pipeline import InfiniteSceneGeneration
+    rs = np.random.RandomState(5)
+    sc = object.__new__(InfiniteSceneGeneration)            # no device: the method only walks the frame store
+    sc.frames, sc.transform_grid = {}, [[None] * 3 for _ in range(2)]
+    for n, (i, j) in enumerate([(0, 0), (0, 1), (1, 2)]):
+        sc.frames[(i, j)] = {"index": n, "rgb_u8": torch.from_numpy(rs.randint(0, 256, (64, 64, 3), dtype=np.uint8)),
+                             "depth": torch.from_numpy(rs.uniform(1, 4, (64, 64)).astype(np.float32))}
+        sc.transform_grid[i][j] = {"R": rs.randn(3, 3), "t": rs.randn(3)}
+    sc.export_to_disk(str(tmp_path / "out"))
+    names = sorted(p.name for p in (tmp_path / "out").iterdir())
+    assert names == sorted(f"{k}_{n:05d}_{i:02d}_{j:02d}.{e}" for n, (i, j) in enumerate([(0, 0), (0, 1), (1, 2)])
+                           for k, e in (("im", "png"), ("dm", "npy"), ("R", "npy"), ("t", "npy")))
+    for (i, j), fr in sc.frames.items():
+        sfx = f"{fr['index']:05d}_{i:02d}_{j:02d}"
+        assert np.array_equal(np.array(Image.open(tmp_path / "out" / f"im_{sfx}.png")), fr["rgb_u8"].numpy())
+        assert np.array_equal(np.load(tmp_path / "out" / f"dm_{sfx}.npy"), fr["depth"].numpy())
+        assert np.array_equal(np.load(tmp_path / "out" / f"R_{sfx}.npy"), sc.transform_grid[i][j]["R"])
+        assert np.array_equal(np.load(tmp_path / "out" / f"t_{sfx}.npy"), sc.transform_grid[i][j]["t"])
