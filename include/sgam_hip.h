@@ -417,6 +417,50 @@ int sgam_tsdf_raycast_depth_f32(const sgam_tsdf_grid *grid, int32_t H, int32_t W
                                 const float *brick_tsdf, float *depth_out, const float *brick_color, float *color_out,
                                 void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * f4 (partial) — backward / optimiser kernels of the VQGAN autoencoder update: VQModel.training_step
+ * (sgam/generative_sensing_module/model.py:271-345) with VQLPIPSWithDiscriminator.forward(optimizer_idx = 0)
+ * (modules/losses/vqperceptual.py:77-110) at perceptual_weight = 0 and global_step < disc_start, i.e.
+ * loss = mean|x - xrec| + codebook_weight * qloss, torch.optim.Adam(betas = (0.5, 0.9)) (model.py:414-428).
+ * Every product of the backward pass runs on the forward's MFMA GEMM (sgam_conv2d_gn_nhwc_f32, fp32-in mode):
+ *   data gradient    dcol[M][KH*KW*cin_pad] = dy[M][Cout] . W[Cout][KH*KW*cin_pad],   dx = sgam_col2im_gather_f32(dcol)
+ *   weight gradient  dW[Cout][KH*KW*cin_pad] = dy^T[Cout][M] . col^T[KH*KW*cin_pad][M]^T,   col^T = sgam_im2col_t_f32(x)
+ * for every convolution of the model through ONE pair of index kernels driven by the forward's descriptor (3x3 / 1x1,
+ * stride 1, Downsample's stride 2 with (0,1,0,1) padding, Upsample's nearest-2x folded into the conv); k = tap * cin_pad
+ * + channel as in sgam_pack_conv_weight.  LPIPS, the PatchGAN and its optimiser are not built.
+ * ------------------------------------------------------------------------------------------ */
+int sgam_im2col_t_f32(const sgam_conv_desc *d, const float *x, float *col_t, int32_t cin_pad, void *stream);
+int sgam_col2im_gather_f32(const sgam_conv_desc *d, const float *dcol, float *dx, int32_t cin_pad, void *stream);
+int sgam_unpack_conv_weight_grad_f32(const float *grad_packed, int32_t ld, float *grad_oihw, int32_t Cout, int32_t Cin,
+                                     int32_t KH, int32_t KW, int32_t Cin_pad, void *stream);
+/* bias gradient: out[N] = column sums of a[M][N] (two launches, fixed order) */
+int64_t sgam_colsum_workspace_bytes(int32_t M, int32_t N);
+int sgam_colsum_f32(const float *a, int32_t lda, float *out, int32_t M, int32_t N, void *workspace, int64_t workspace_bytes,
+                    void *stream);
+/* GroupNorm(32, eps)(+swish) backward (Normalize + nonlinearity, diffusionmodules/model.py:30-40): x = the layer's input,
+ * dy = gradient of its output, mean_rstd [B][groups][2] from sgam_groupnorm_stats_*; dx like x; dgamma_b / dbeta_b [B][C]
+ * per-image sums (the caller adds the images); group_means [B][groups][2] scratch */
+int sgam_groupnorm_bwd_nhwc_f32(const float *x, const float *dy, const float *mean_rstd, const float *gamma, const float *beta,
+                                int32_t swish, float *dx, float *dgamma_b, float *dbeta_b, float *group_means, int32_t B,
+                                int32_t HW, int32_t C, int32_t groups, void *stream);
+/* p = softmax(scale * s) over rows (AttnBlock, model.py:176-181): ds = scale * p * (dp - sum_j dp_j p_j) */
+int sgam_softmax_bwd_rows_f32(const float *p, const float *dp, float *ds, int32_t rows, int32_t cols, int32_t ld, float scale,
+                              void *stream);
+/* rec_loss = |inputs - reconstructions| (vqperceptual.py:79): grad[rows][ld_grad] = sign(rec - target) * grad_scale on the C
+ * real columns (0 on the padding), partial[ceil(rows * ld_grad / 256)] doubles = sums of |rec - target| */
+int sgam_l1_loss_grad_f32(const float *rec, const float *target, float *grad, double *partial, int64_t rows, int32_t C,
+                          int32_t ld_rec, int32_t ld_grad, float grad_scale, void *stream);
+/* VectorQuantizer2 backward (quantize.py:296-304, legacy form): dz = dzq + two_c * (z - zq) with two_c = 2 * codebook_weight /
+ * numel; d_codebook[k] = two_c_beta * sum_{t: indices[t] = k} (zq_t - z_t) */
+int sgam_vq_bwd_f32(const float *dzq, const float *z, const float *zq, float *dz, int64_t n, float two_c, void *stream);
+int sgam_vq_codebook_grad_f32(const int64_t *indices, const float *z, const float *zq, float *d_codebook, int32_t T, int32_t n_e,
+                              int32_t D, float two_c_beta, void *stream);
+/* out = alpha * a + beta * b (b may be NULL): gradient fan-in of the residual connections */
+int sgam_axpby_f32(const float *a, const float *b, float *out, int64_t n, float alpha, float beta, void *stream);
+/* torch.optim.Adam step (no weight decay / amsgrad) on one tensor; step = 1, 2, ... */
+int sgam_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
+                       float beta2, float eps, int32_t step, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -113,8 +113,10 @@ def quantize(sd, z):
     d = distances(sd, zf)
     idx = torch.argmin(d, dim=1)
     z_q = F.embedding(idx, e).view(zp.shape)
-    loss = torch.mean((z_q - zp) ** 2) + 0.25 * torch.mean((z_q - zp) ** 2)   # :296-301, legacy, beta = 0.25
-    z_q = zp + (z_q - zp)
+    # :296-304, legacy form, beta = 0.25 (the detach()es only matter to autograd: tests/test_gpu_training.py differentiates
+    # this restatement to check the HIP backward pass)
+    loss = torch.mean((z_q.detach() - zp) ** 2) + 0.25 * torch.mean((z_q - zp.detach()) ** 2)
+    z_q = zp + (z_q - zp).detach()
     return z_q.permute(0, 3, 1, 2).contiguous(), idx.view(zp.shape[:-1]), d, loss
 
 

@@ -61,6 +61,19 @@ PROTOTYPES = {
                                         c_f32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "sgam_tsdf_raycast_depth_f32": (c_i32, [ctypes.POINTER(TsdfGrid), c_i32, c_i32, c_f32, c_f32, c_f32, c_f32, c_vp, c_f32,
                                             c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "sgam_im2col_t_f32": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_i32, c_vp]),
+    "sgam_col2im_gather_f32": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_i32, c_vp]),
+    "sgam_unpack_conv_weight_grad_f32": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "sgam_colsum_workspace_bytes": (c_i64, [c_i32, c_i32]),
+    "sgam_colsum_f32": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp]),
+    "sgam_groupnorm_bwd_nhwc_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,
+                                            c_vp]),
+    "sgam_softmax_bwd_rows_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_vp]),
+    "sgam_l1_loss_grad_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_f32, c_vp]),
+    "sgam_vq_bwd_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_vp]),
+    "sgam_vq_codebook_grad_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_vp]),
+    "sgam_axpby_f32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_vp]),
+    "sgam_adam_step_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp]),
     "sgam_pack_conv_weight_f32x": (c_i32, [c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "sgam_split_rows_f32x": (c_i32, [c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_vp]),
     "sgam_conv2d_h16_workspace_bytes": (c_i64, [ctypes.POINTER(ConvDesc)]),

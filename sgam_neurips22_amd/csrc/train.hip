@@ -1,0 +1,388 @@
+// train.hip — backward / optimiser kernels of the VQGAN autoencoder update (partial: the
+// pre-discriminator phase of the reference's training_step, sgam/generative_sensing_module/model.py:271-345 with
+// modules/losses/vqperceptual.py:77-110 at perceptual_weight = 0, global_step < disc_start).  gfx950 only.
+//
+// Every product of the backward pass is a GEMM on the existing MFMA kernels (fp32-in MFMA mode: gradients are far below
+// fp16's normal range, so the split-fp32 trick of the inference path does not apply):
+//   data gradient    dcol[M][taps*Cin] = dy[M][Cout] . W[Cout][taps*Cin]          then col2im_gather (below)
+//   weight gradient  dW[Cout][taps*Cin] = dy^T[Cout][M] . col^T[taps*Cin][M]^T     with col^T from im2col_t (below)
+// which makes one pair of index kernels serve every convolution of the model: 3x3 / 1x1, stride 1, stride 2 with the
+// (0,1,0,1) padding of Downsample (model.py:62-75) and the nearest-2x upsampling folded into Upsample.conv (:43-53).
+// This file holds those index kernels and the element-wise / reduction kernels around the GEMMs: GroupNorm(+swish)
+// backward, soft-max backward, the L1 reconstruction loss and its gradient, the quantiser's straight-through +
+// commitment gradient, bias gradients, Adam.  Not on the inference hot path; written for correctness and coalesced
+// access, not tuned.
+#include "sgam_common.h"
+
+namespace {
+
+struct ConvGeo {
+    int B, Hi, Wi, Cin, Cin_pad, Ho, Wo, KH, KW, stride, pad_t, pad_l, ups;
+};
+
+// source pixel of (output pixel, tap) in the conv's input; false = zero padding.  `ups`: the conv runs on the nearest-2x
+// upsampling of the stored tensor (virtual size 2 Hi x 2 Wi).
+__device__ __forceinline__ bool src_of(const ConvGeo &g, int oy, int ox, int ky, int kx, int &iy, int &ix) {
+    const int vy = oy * g.stride + ky - g.pad_t, vx = ox * g.stride + kx - g.pad_l;
+    const int Hv = g.ups ? 2 * g.Hi : g.Hi, Wv = g.ups ? 2 * g.Wi : g.Wi;
+    if ((unsigned)vy >= (unsigned)Hv || (unsigned)vx >= (unsigned)Wv) return false;
+    iy = g.ups ? vy >> 1 : vy;
+    ix = g.ups ? vx >> 1 : vx;
+    return true;
+}
+
+// col^T[k = tap * Cin_pad + c][m = (b, oy, ox)] of the NHWC input x (row stride ld)
+__global__ __launch_bounds__(256) void im2col_t_kernel(const float *__restrict__ x, int ld, float *__restrict__ out, ConvGeo g) {
+    const int64_t M = (int64_t)g.B * g.Ho * g.Wo;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)g.KH * g.KW * g.Cin_pad * M;
+    if (i >= total) return;
+    const int64_t m = i % M;
+    const int k = (int)(i / M);
+    const int c = k % g.Cin_pad, tap = k / g.Cin_pad;
+    const int ky = tap / g.KW, kx = tap - ky * g.KW;
+    const int ox = (int)(m % g.Wo), oy = (int)((m / g.Wo) % g.Ho), b = (int)(m / ((int64_t)g.Wo * g.Ho));
+    int iy, ix;
+    float v = 0.f;
+    if (c < g.Cin && src_of(g, oy, ox, ky, kx, iy, ix)) v = x[((int64_t)(b * g.Hi + iy) * g.Wi + ix) * ld + c];
+    out[i] = v;
+}
+
+// dx[b][iy][ix][c] = sum over (output pixel, tap) pairs that read this input pixel of dcol[m][tap * Cin_pad + c]; a gather
+// in a fixed order (taps ascending, then the 2 x 2 virtual pixels of an upsampled source), so it is deterministic
+__global__ __launch_bounds__(256) void col2im_gather_kernel(const float *__restrict__ dcol, float *__restrict__ dx, int ldx, ConvGeo g) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)g.B * g.Hi * g.Wi * g.Cin;
+    if (i >= total) return;
+    const int c = (int)(i % g.Cin);
+    const int64_t p = i / g.Cin;
+    const int ix = (int)(p % g.Wi), iy = (int)((p / g.Wi) % g.Hi), b = (int)(p / ((int64_t)g.Wi * g.Hi));
+    const int K = g.KH * g.KW * g.Cin_pad;
+    const int nv = g.ups ? 2 : 1;
+    float acc = 0.f;
+    for (int ky = 0; ky < g.KH; ++ky)
+        for (int kx = 0; kx < g.KW; ++kx)
+            for (int a = 0; a < nv; ++a)
+                for (int e = 0; e < nv; ++e) {
+                    // virtual input pixel (vy, vx) = output position * stride + tap - pad
+                    const int vy = (g.ups ? 2 * iy + a : iy) + g.pad_t - ky, vx = (g.ups ? 2 * ix + e : ix) + g.pad_l - kx;
+                    if (vy < 0 || vx < 0 || vy % g.stride || vx % g.stride) continue;
+                    const int oy = vy / g.stride, ox = vx / g.stride;
+                    if (oy >= g.Ho || ox >= g.Wo) continue;
+                    const int64_t m = ((int64_t)b * g.Ho + oy) * g.Wo + ox;
+                    acc += dcol[m * K + (ky * g.KW + kx) * g.Cin_pad + c];
+                }
+    dx[p * ldx + c] = acc;
+}
+
+// packed weight gradient [Cout_pad][taps][Cin_pad] -> torch layout [Cout][Cin][KH][KW]
+__global__ void unpack_weight_grad_kernel(const float *__restrict__ gp, int ldg, float *__restrict__ g, int Cout, int Cin, int taps,
+                                          int Cin_pad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)Cout * Cin * taps) return;
+    const int t = (int)(i % taps), c = (int)((i / taps) % Cin), n = (int)(i / ((int64_t)taps * Cin));
+    g[i] = gp[(int64_t)n * ldg + t * Cin_pad + c];
+}
+
+// ---- column sums of a [M][N] matrix (bias gradients): partial sums over row chunks, then the same kernel over the partials
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ a, int lda, float *__restrict__ out, int M, int N,
+                                                     int rows_per_chunk) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += a[(int64_t)r * lda + n];
+    out[(int64_t)blockIdx.y * N + n] = s;
+}
+
+// ---- GroupNorm(+swish) backward.  Forward: xh = (x - mean) rstd, n = gamma xh + beta, y = swish ? n sigmoid(n) : n.
+// With g = dL/dn:  dgamma_c = sum g xh,  dbeta_c = sum g,
+//                  dx = rstd (g gamma - mean_grp(g gamma) - xh mean_grp(g gamma xh))       (means over the group's elements)
+// Pass 1: one workgroup per (image, group) leaves the per-channel sums of this image and the two group means.
+__device__ __forceinline__ float dswish(float n) {
+    const float s = 1.0f / (1.0f + __expf(-n));
+    return s * (1.0f + n * (1.0f - s));
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                            const float *__restrict__ mean_rstd, const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, int swish, float *__restrict__ dgamma_b,
+                                                            float *__restrict__ dbeta_b, float *__restrict__ gmeans, int HW, int C,
+                                                            int groups) {
+    const int b = blockIdx.x / groups, grp = blockIdx.x % groups, cpg = C / groups;
+    const float mean = mean_rstd[(b * groups + grp) * 2], rstd = mean_rstd[(b * groups + grp) * 2 + 1];
+    __shared__ double sh[256][2];
+    __shared__ double tot[2];
+    if (threadIdx.x < 2) tot[threadIdx.x] = 0.0;
+    // channel by channel: the 256 threads stride over the pixels (fixed assignment -> fixed summation order)
+    for (int cc = 0; cc < cpg; ++cc) {
+        const int c = grp * cpg + cc;
+        const float ga = gamma[c], be = beta[c];
+        double s_g = 0.0, s_gx = 0.0;
+        for (int p = threadIdx.x; p < HW; p += 256) {
+            const int64_t o = ((int64_t)b * HW + p) * C + c;
+            const float xh = (x[o] - mean) * rstd;
+            float g = dy[o];
+            if (swish) g *= dswish(ga * xh + be);
+            s_g += (double)g;
+            s_gx += (double)g * (double)xh;
+        }
+        sh[threadIdx.x][0] = s_g;
+        sh[threadIdx.x][1] = s_gx;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (threadIdx.x < o) {
+                sh[threadIdx.x][0] += sh[threadIdx.x + o][0];
+                sh[threadIdx.x][1] += sh[threadIdx.x + o][1];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            dbeta_b[b * C + c] = (float)sh[0][0];
+            dgamma_b[b * C + c] = (float)sh[0][1];
+            tot[0] += (double)ga * sh[0][0];
+            tot[1] += (double)ga * sh[0][1];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double n = (double)cpg * HW;
+        gmeans[(b * groups + grp) * 2] = (float)(tot[0] / n);
+        gmeans[(b * groups + grp) * 2 + 1] = (float)(tot[1] / n);
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                           const float *__restrict__ mean_rstd, const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta, int swish, const float *__restrict__ gmeans,
+                                                           float *__restrict__ dx, int64_t total, int HW, int C, int groups) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const int b = (int)(i / ((int64_t)HW * C));
+    const int grp = c / (C / groups);
+    const float mean = mean_rstd[(b * groups + grp) * 2], rstd = mean_rstd[(b * groups + grp) * 2 + 1];
+    const float xh = (x[i] - mean) * rstd;
+    float g = dy[i];
+    if (swish) g *= dswish(gamma[c] * xh + beta[c]);
+    dx[i] = rstd * (g * gamma[c] - gmeans[(b * groups + grp) * 2] - xh * gmeans[(b * groups + grp) * 2 + 1]);
+}
+
+// ---- soft-max backward over rows: p = softmax(scale * s) -> ds = scale * p (dp - sum_j dp_j p_j); one workgroup per row
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float *__restrict__ p, const float *__restrict__ dp,
+                                                               float *__restrict__ ds, int cols, int ld, float scale) {
+    const int64_t r = blockIdx.x;
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (int j = threadIdx.x; j < cols; j += 256) s += (double)dp[r * ld + j] * (double)p[r * ld + j];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    const float dot = (float)sh[0];
+    for (int j = threadIdx.x; j < cols; j += 256) ds[r * ld + j] = scale * p[r * ld + j] * (dp[r * ld + j] - dot);
+}
+
+// ---- L1 reconstruction loss over n_valid of ld columns: grad = sign(rec - target) * gscale (0 on the padding columns) and
+// per-workgroup partial sums of |rec - target| (doubles; the host adds the few hundred partials)
+__global__ __launch_bounds__(256) void l1_loss_grad_kernel(const float *__restrict__ rec, const float *__restrict__ target,
+                                                           float *__restrict__ grad, double *__restrict__ partial, int64_t rows, int C,
+                                                           int ld_rec, int ld_grad, float gscale) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double a = 0.0;
+    if (i < rows * ld_grad) {
+        const int64_t r = i / ld_grad;
+        const int c = (int)(i - r * ld_grad);
+        float gv = 0.f;
+        if (c < C) {
+            const float d = rec[r * ld_rec + c] - target[r * C + c];
+            a = (double)fabsf(d);
+            gv = d > 0.f ? gscale : (d < 0.f ? -gscale : 0.f);
+        }
+        grad[i] = gv;
+    }
+    __shared__ double sh[256];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+
+// ---- quantiser backward (quantize.py:296-304, legacy form): loss_q = mean((zq.detach - z)^2) + beta mean((zq - z.detach)^2),
+// z_q = z + (zq - z).detach  =>  dL/dz = dzq + 2 c_commit (z - zq),   c_commit = codebook_weight / numel
+__global__ void vq_bwd_kernel(const float *__restrict__ dzq, const float *__restrict__ z, const float *__restrict__ zq,
+                              float *__restrict__ dz, int64_t n, float c2) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dz[i] = dzq[i] + c2 * (z[i] - zq[i]);
+}
+
+// codebook gradient of the same loss: dE[k] = 2 beta c sum_{t: idx_t = k} (zq_t - z_t); thread = (code, 4 channels), scanning
+// the tokens in order (T is a few hundred on this path; deterministic, no atomics)
+__global__ void vq_codebook_grad_kernel(const int64_t *__restrict__ idx, const float *__restrict__ z, const float *__restrict__ zq,
+                                        float *__restrict__ dE, int T, int n_e, int D, float c2b) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n_e * D) return;
+    const int k = (int)(i / D), d = (int)(i - (int64_t)k * D);
+    float s = 0.f;
+    for (int t = 0; t < T; ++t)
+        if (idx[t] == k) s += zq[(int64_t)t * D + d] - z[(int64_t)t * D + d];
+    dE[i] = c2b * s;
+}
+
+__global__ void axpby_kernel(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, int64_t n,
+                             float alpha, float beta) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = alpha * a[i] + (b ? beta * b[i] : 0.f);
+}
+
+// torch.optim.Adam (no weight decay, no amsgrad), one launch per parameter tensor:
+//   m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+__global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
+                            int64_t n, float b1, float b2, float step_size, float inv_sqrt_bc2, float eps) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+}
+
+ConvGeo geo_of(const sgam_conv_desc *d, int cin_pad) {
+    ConvGeo g;
+    g.B = d->B; g.Hi = d->Hi; g.Wi = d->Wi; g.Cin = d->Cin; g.Cin_pad = cin_pad; g.Ho = d->Ho; g.Wo = d->Wo; g.KH = d->KH; g.KW = d->KW;
+    g.stride = d->stride; g.pad_t = d->pad_t; g.pad_l = d->pad_l; g.ups = d->upsample2x ? 1 : 0;
+    return g;
+}
+
+bool geo_ok(const sgam_conv_desc *d, int cin_pad) {
+    return d && d->B > 0 && d->Hi > 0 && d->Wi > 0 && d->Cin > 0 && cin_pad >= d->Cin && d->Ho > 0 && d->Wo > 0 && d->KH > 0 && d->KW > 0 &&
+           d->stride > 0 && d->pad_t >= 0 && d->pad_l >= 0;
+}
+
+}  // namespace
+
+extern "C" int sgam_im2col_t_f32(const sgam_conv_desc *d, const float *x, float *col_t, int32_t cin_pad, void *stream) {
+    if (!geo_ok(d, cin_pad) || !x || !col_t || d->lda < d->Cin) return SGAM_EINVAL;
+    const ConvGeo g = geo_of(d, cin_pad);
+    const int64_t total = (int64_t)g.KH * g.KW * g.Cin_pad * g.B * g.Ho * g.Wo;
+    if (total >= ((int64_t)1 << 31) * 256) return SGAM_EINVAL;
+    SGAM_KLAUNCH(im2col_t_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, sgam_stream(stream), x, d->lda, col_t, g);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+extern "C" int sgam_col2im_gather_f32(const sgam_conv_desc *d, const float *dcol, float *dx, int32_t cin_pad, void *stream) {
+    if (!geo_ok(d, cin_pad) || !dcol || !dx || d->lda < d->Cin) return SGAM_EINVAL;
+    const ConvGeo g = geo_of(d, cin_pad);
+    const int64_t total = (int64_t)g.B * g.Hi * g.Wi * g.Cin;
+    SGAM_KLAUNCH(col2im_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, sgam_stream(stream), dcol, dx, d->lda, g);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+extern "C" int sgam_unpack_conv_weight_grad_f32(const float *grad_packed, int32_t ld, float *grad_oihw, int32_t Cout, int32_t Cin,
+                                                int32_t KH, int32_t KW, int32_t Cin_pad, void *stream) {
+    if (!grad_packed || !grad_oihw || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 || Cin_pad < Cin || ld < KH * KW * Cin_pad)
+        return SGAM_EINVAL;
+    const int64_t total = (int64_t)Cout * Cin * KH * KW;
+    SGAM_KLAUNCH(unpack_weight_grad_kernel, dim3(sgam_cdiv(total, 256)), dim3(256), 0, sgam_stream(stream), grad_packed, ld, grad_oihw,
+                 Cout, Cin, KH * KW, Cin_pad);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+// out[N] = column sums of a[M][N]; workspace >= sgam_colsum_workspace_bytes(M, N)
+extern "C" int64_t sgam_colsum_workspace_bytes(int32_t M, int32_t N) {
+    if (M <= 0 || N <= 0) return -1;
+    return (int64_t)sgam_cdiv(M, 256) * N * 4;
+}
+
+extern "C" int sgam_colsum_f32(const float *a, int32_t lda, float *out, int32_t M, int32_t N, void *workspace, int64_t workspace_bytes,
+                               void *stream) {
+    if (!a || !out || M <= 0 || N <= 0 || lda < N || !workspace || workspace_bytes < sgam_colsum_workspace_bytes(M, N)) return SGAM_EINVAL;
+    const int chunks = sgam_cdiv(M, 256);
+    hipStream_t s = sgam_stream(stream);
+    SGAM_KLAUNCH(colsum_kernel, dim3(sgam_cdiv(N, 256), chunks), dim3(256), 0, s, a, lda, (float *)workspace, M, N, 256);
+    SGAM_LAUNCH_CHECK();
+    SGAM_KLAUNCH(colsum_kernel, dim3(sgam_cdiv(N, 256), 1), dim3(256), 0, s, (const float *)workspace, N, out, chunks, N, chunks);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+extern "C" int sgam_groupnorm_bwd_nhwc_f32(const float *x, const float *dy, const float *mean_rstd, const float *gamma, const float *beta,
+                                           int32_t swish, float *dx, float *dgamma_b, float *dbeta_b, float *group_means, int32_t B,
+                                           int32_t HW, int32_t C, int32_t groups, void *stream) {
+    if (!x || !dy || !mean_rstd || !gamma || !beta || !dx || !dgamma_b || !dbeta_b || !group_means || B <= 0 || HW <= 0 || C <= 0 ||
+        groups <= 0 || C % groups)
+        return SGAM_EINVAL;
+    hipStream_t s = sgam_stream(stream);
+    SGAM_KLAUNCH(gn_bwd_reduce_kernel, dim3(B * groups), dim3(256), 0, s, x, dy, mean_rstd, gamma, beta, swish ? 1 : 0, dgamma_b, dbeta_b,
+                 group_means, HW, C, groups);
+    SGAM_LAUNCH_CHECK();
+    const int64_t total = (int64_t)B * HW * C;
+    SGAM_KLAUNCH(gn_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, dy, mean_rstd, gamma, beta, swish ? 1 : 0,
+                 group_means, dx, total, HW, C, groups);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+extern "C" int sgam_softmax_bwd_rows_f32(const float *p, const float *dp, float *ds, int32_t rows, int32_t cols, int32_t ld, float scale,
+                                         void *stream) {
+    if (!p || !dp || !ds || rows <= 0 || cols <= 0 || ld < cols) return SGAM_EINVAL;
+    SGAM_KLAUNCH(softmax_bwd_rows_kernel, dim3(rows), dim3(256), 0, sgam_stream(stream), p, dp, ds, cols, ld, scale);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+// partial: sgam_cdiv(rows * ld_grad, 256) doubles
+extern "C" int sgam_l1_loss_grad_f32(const float *rec, const float *target, float *grad, double *partial, int64_t rows, int32_t C,
+                                     int32_t ld_rec, int32_t ld_grad, float grad_scale, void *stream) {
+    if (!rec || !target || !grad || !partial || rows <= 0 || C <= 0 || ld_rec < C || ld_grad < C) return SGAM_EINVAL;
+    const int64_t total = rows * ld_grad;
+    SGAM_KLAUNCH(l1_loss_grad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, sgam_stream(stream), rec, target, grad, partial,
+                 rows, C, ld_rec, ld_grad, grad_scale);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+extern "C" int sgam_vq_bwd_f32(const float *dzq, const float *z, const float *zq, float *dz, int64_t n, float two_c, void *stream) {
+    if (!dzq || !z || !zq || !dz || n <= 0) return SGAM_EINVAL;
+    SGAM_KLAUNCH(vq_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sgam_stream(stream), dzq, z, zq, dz, n, two_c);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+extern "C" int sgam_vq_codebook_grad_f32(const int64_t *indices, const float *z, const float *zq, float *d_codebook, int32_t T,
+                                         int32_t n_e, int32_t D, float two_c_beta, void *stream) {
+    if (!indices || !z || !zq || !d_codebook || T <= 0 || n_e <= 0 || D <= 0) return SGAM_EINVAL;
+    const int64_t total = (int64_t)n_e * D;
+    SGAM_KLAUNCH(vq_codebook_grad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, sgam_stream(stream), indices, z, zq,
+                 d_codebook, T, n_e, D, two_c_beta);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+// out = alpha a + beta b (b may be NULL)
+extern "C" int sgam_axpby_f32(const float *a, const float *b, float *out, int64_t n, float alpha, float beta, void *stream) {
+    if (!a || !out || n <= 0) return SGAM_EINVAL;
+    SGAM_KLAUNCH(axpby_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sgam_stream(stream), a, b, out, n, alpha, beta);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+extern "C" int sgam_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
+                                  float beta2, float eps, int32_t step, void *stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step <= 0) return SGAM_EINVAL;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    SGAM_KLAUNCH(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sgam_stream(stream), param, grad, exp_avg, exp_avg_sq, n,
+                 beta1, beta2, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), eps);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}

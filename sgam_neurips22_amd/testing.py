@@ -218,3 +218,21 @@ def config5_batch(src0_rgb_u8, src0_depth, res=512):
     return {"Ks": f32(np.tile(K, (4, 2, 1, 1))), "R_rels": f32(R), "t_rels": f32(t),
             "src_imgs": f32(np.tile(imgs[None], (4, 1, 1, 1, 1))), "src_depths": f32(np.tile(deps[None], (4, 1, 1, 1))),
             "dst_img": np.zeros((4, res, res, 3), np.float32), "dst_depth": np.zeros((4, res, res), np.float32)}
+
+
+def small_train_params(params):
+    """the small conditional VQGAN of the training-step tests and of tests/golden/train_step_small.npz: 64 x 64 input, widths
+    128 / 256 (the GroupNorm kernels of the forward path take multiples of 128 channels), one Downsample, 32 x 32 latent of 32
+    channels, 64 codes, attention at 32 and in the middle (applied to a copy of a full params dict)"""
+    import copy
+    p = copy.deepcopy(params)
+    p["embed_dim"], p["n_embed"] = 32, 64
+    p["ddconfig"].update(ch=128, ch_mult=[1, 2], num_res_blocks=1, attn_resolutions=[32], resolution=64, z_channels=32)
+    return p
+
+
+def train_batch():
+    """(x, mask, x_dst) of that fixture: B = 2, 64 x 64"""
+    x, mask = rect_hole_input(2, 64, 64, seed=5)
+    x_dst = (seeded_tensor("train.dst", (2, 4, 64, 64), scale=0.5)).clamp(-1, 1)
+    return x, mask, x_dst

@@ -319,6 +319,44 @@ def gen_trajectory_free(steps=32):
     save("trajectory_ge_free32.npz", steps=steps, **final)
 
 
+def gen_train():
+    """one autoencoder update of the REFERENCE on the small model of the training tests: VQModel.forward + VQLPIPSWithDiscriminator
+    (optimizer_idx 0, perceptual_weight 0, global_step 0 < disc_start) + backward — loss terms and a few gradients"""
+    from sgam.generative_sensing_module.modules.losses.vqperceptual import VQLPIPSWithDiscriminator
+    print("training step (small model)")
+    p = testing.small_train_params(R.load_params("google_earth"))
+    p["phase"] = "codebook"
+    torch.manual_seed(0)
+    model = VQModel(**p).train()
+    sd = testing.synthetic_state_dict(model.state_dict(), seed=11)
+    model.load_state_dict(sd)
+    x, mask, x_dst = testing.train_batch()
+    with torch.no_grad():
+        pre = model.encode(x, extrapolation_mask=mask)[3]
+    z = pre.permute(0, 2, 3, 1).reshape(-1, pre.shape[1])
+    zmean, zstd = float(z.mean()), float(z.std())
+    cb_seed = 0
+    while float(testing.top2_relative_gap(z, testing.codebook_from_stats(zmean, zstd, 64, 32, cb_seed)).min()) < 1e-4:
+        cb_seed += 1
+    sd["quantize.embedding.weight"] = testing.codebook_from_stats(zmean, zstd, 64, 32, cb_seed)
+    model.load_state_dict(sd)
+    loss_fn = VQLPIPSWithDiscriminator(disc_start=10 ** 9, codebook_weight=1.0, perceptual_weight=0.0, disc_in_channels=4,
+                                       disc_weight=0.8, disc_num_layers=2, use_discriminative_loss=True)
+    torch.manual_seed(1)
+    xrec, qloss, idx, pre = model(x, extrapolation_mask=mask, get_codebook_count=True, get_pre_quantized_feature=True)
+    aeloss, log = loss_fn(qloss, x_dst, xrec, 0, 0, last_layer=model.get_last_layer(), split="train", extrapolation_mask=mask)
+    model.zero_grad()
+    aeloss.backward()
+    named = dict(model.named_parameters())
+    keep = ["encoder.conv_in.weight", "decoder.conv_out.weight", "quantize.embedding.weight", "encoder.mid.attn_1.q.weight",
+            "conv_in.weight", "encoder.down.0.downsample.conv.weight", "decoder.up.1.upsample.conv.bias", "encoder.norm_out.weight"]
+    gn = {k: float(v.grad.double().norm()) for k, v in named.items() if v.grad is not None}
+    save("train_step_small.npz", zmean=zmean, zstd=zstd, cb_seed=cb_seed, loss=float(aeloss), quant_loss=float(qloss),
+         rec_loss=float(log["train/rec_loss"]), d_weight=float(log["train/d_weight"]), indices=idx[2] if isinstance(idx, tuple) else idx,
+         grad_norm_names=np.array(sorted(gn)), grad_norms=np.array([gn[k] for k in sorted(gn)]),
+         **{"grad." + k: named[k].grad for k in keep})
+
+
 def gen_trajectory_clevr():
     """CLEVR-Infinite loop, 3 steps on a 2x2 grid: 16384 codes, num_src 5, the seed depth's ray->z conversion applied at
     construction (:71-79) AND again at every load (:582-590), both in float64."""
@@ -366,3 +404,5 @@ if __name__ == "__main__":
         gen_trajectory_free()
     if not only or "clevr" in only:
         gen_trajectory_clevr()
+    if not only or "train" in only:
+        gen_train()
