@@ -78,3 +78,34 @@ def test_bench_refuses_a_world_that_is_not_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True,
                        text=True, env=env, timeout=120)
     assert r.returncode != 0 and "--gpus 2" in (r.stderr + r.stdout)
+
+
+def _grad_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from sgam_neurips22_amd import distributed as sdist
+    from sgam_neurips22_amd import testing, training
+    from sgam_neurips22_amd.config import default_params
+    from sgam_neurips22_amd.generative_sensing_module.model import VQModel
+    sdist.init(backend="gloo")
+    m = VQModel(**testing.small_train_params(default_params("google_earth")))
+    tr = training.AutoencoderTrainer(m, phase="conditional_generation", lr=1e-4)
+    ps = tr.parameters()
+    for i, p in enumerate(ps):                       # rank-dependent stand-in gradients: (rank + 1) * (i + 1)
+        tr.grads[p] = torch.full(p.shape, float((rank + 1) * (i + 1)))
+    nbytes = tr.allreduce_grads()
+    ok = all(torch.equal(tr.grads[p], torch.full(p.shape, 1.5 * (i + 1))) for i, p in enumerate(ps))
+    torch.save({"ok": ok, "bytes": nbytes, "n": sum(p.numel() for p in ps)}, os.path.join(out_dir, f"g{rank}.pt"))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_training_gradient_bucket_allreduce_world2_gloo(tmp_path):
+    """the trainer averages the phase's gradients over the ranks through ONE flat bucket (what DDP does
+    for the reference's LightningModule); world 2 over gloo, stand-in gradients"""
+    port = _free_port()
+    mp.spawn(_grad_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        res = torch.load(tmp_path / f"g{r}.pt")
+        assert res["ok"] and res["bytes"] == 4 * res["n"] > 0
