@@ -370,15 +370,19 @@ def main():
 
     train_leg = None
     if rank == 0 and world == 1 and args.dtype == "f32" and not args.no_secondary:
-        # SURVEY §8 f4 (partial, a side note like the other legs): the autoencoder update of the reference's training step on the
-        # same 256x256 model — forward with tape, L1 + codebook loss, backward, Adam on the encoder (the phase that trains the
-        # hot-path model); a second instance of the model, so the inference legs are not disturbed
+        # SURVEY §8 f4 (a side note like the other legs): the reference's training step on the same 256x256 model, past
+        # disc_start — forward with tape, L1 + codebook + adaptive-weighted generator loss, backward, Adam on the encoder (the
+        # phase that trains the hot-path model), then the PatchGAN's hinge loss, backward and Adam; perceptual_weight 0 (no
+        # LPIPS); a second instance of the model, so the inference legs are not disturbed
         from sgam_neurips22_amd import training
         mt = build_model(dev)[0]
         xt, mk = testing.rect_hole_input(1, 256, 256, seed=9)
         xd = testing.seeded_tensor("bench.train.dst", (1, 4, 256, 256), scale=0.5).clamp(-1, 1).to(dev)
         xt, mk = xt.to(dev), mk.to(dev)
-        tr = training.AutoencoderTrainer(mt, phase="conditional_generation", lr=4.5e-6)
+        from sgam_neurips22_amd.generative_sensing_module.modules.losses.vqperceptual import VQLPIPSWithDiscriminator
+        lcfg = VQLPIPSWithDiscriminator(disc_start=0, perceptual_weight=0.0, disc_in_channels=4, disc_weight=0.8,
+                                        use_discriminative_loss=True).to(dev).train()      # trained_models/*/config.yaml lossconfig
+        tr = training.VQGANTrainer(mt, lcfg, phase="conditional_generation", lr=4.5e-6)
         l0 = tr.step(xt, xd, mk)[0]
         torch.cuda.synchronize()
         tt = time.perf_counter()
@@ -388,8 +392,8 @@ def main():
         dt_ = (time.perf_counter() - tt) / 3
         train_leg = {"ms_per_update": round(1e3 * dt_, 1), "updates_per_s": round(1 / dt_, 2), "batch": 1,
                      "loss_first": round(float(l0), 6), "loss_after_4": round(float(l1), 6),
-                     "note": "partial f4: L1 + codebook loss (VQLPIPSWithDiscriminator before disc_start, perceptual_weight 0), "
-                             "encoder parameter set, fp32-in MFMA GEMMs + csrc/train.hip; no LPIPS / PatchGAN; untuned"}
+                     "note": "f4 without LPIPS: autoencoder (encoder parameter set) + PatchGAN discriminator updates of training_step "
+                             "past disc_start, perceptual_weight 0; fp32-in MFMA GEMMs + csrc/train.hip; untuned"}
         del mt, tr
 
     cpu = None
@@ -411,7 +415,7 @@ def main():
                                         if ops.F32_MODE == "split" else "fp32-in MFMA") if args.dtype == "f32" else None},
             "vqgan_tflops_wallclock": round(GFLOP_PER_FRAME * g["total_frames"] / t_max / 1e3 / world, 2),
             "roofline": roofline, "cpu_baseline": cpu, "f32_mfma_mode": f32_mfma_leg, "numa_node": numa, "f32x_range_flag": int(range_tripped),
-            "rgbd_integration_branch": rgbd_leg, "concurrent_scenes": conc_leg, "throughput_mode": secondary, "config5_512sq_batch4": stress, "training_step_partial": train_leg, "frame_checksums": [r[2] for r in g["per_rank"]],
+            "rgbd_integration_branch": rgbd_leg, "concurrent_scenes": conc_leg, "throughput_mode": secondary, "config5_512sq_batch4": stress, "training_step": train_leg, "frame_checksums": [r[2] for r in g["per_rank"]],
         }
         print(json.dumps(out), flush=True)
     if torch.distributed.is_available() and torch.distributed.is_initialized():

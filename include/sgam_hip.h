@@ -425,11 +425,12 @@ int sgam_tsdf_raycast_depth_f32(const sgam_tsdf_grid *grid, int32_t H, int32_t W
  * Every product of the backward pass runs on the forward's MFMA GEMM (sgam_conv2d_gn_nhwc_f32, fp32-in mode):
  *   data gradient    dcol[M][KH*KW*cin_pad] = dy[M][Cout] . W[Cout][KH*KW*cin_pad],   dx = sgam_col2im_gather_f32(dcol)
  *   weight gradient  dW[Cout][KH*KW*cin_pad] = dy^T[Cout][M] . col^T[KH*KW*cin_pad][M]^T,   col^T = sgam_im2col_t_f32(x)
+ *                    (rows ld_m >= M apart: M is rounded up to the GEMM's K granule with a zero tail)
  * for every convolution of the model through ONE pair of index kernels driven by the forward's descriptor (3x3 / 1x1,
  * stride 1, Downsample's stride 2 with (0,1,0,1) padding, Upsample's nearest-2x folded into the conv); k = tap * cin_pad
  * + channel as in sgam_pack_conv_weight.  LPIPS, the PatchGAN and its optimiser are not built.
  * ------------------------------------------------------------------------------------------ */
-int sgam_im2col_t_f32(const sgam_conv_desc *d, const float *x, float *col_t, int32_t cin_pad, void *stream);
+int sgam_im2col_t_f32(const sgam_conv_desc *d, const float *x, float *col_t, int32_t cin_pad, int64_t ld_m, void *stream);
 int sgam_col2im_gather_f32(const sgam_conv_desc *d, const float *dcol, float *dx, int32_t cin_pad, void *stream);
 int sgam_unpack_conv_weight_grad_f32(const float *grad_packed, int32_t ld, float *grad_oihw, int32_t Cout, int32_t Cin,
                                      int32_t KH, int32_t KW, int32_t Cin_pad, void *stream);
@@ -460,6 +461,22 @@ int sgam_axpby_f32(const float *a, const float *b, float *out, int64_t n, float 
 /* torch.optim.Adam step (no weight decay / amsgrad) on one tensor; step = 1, 2, ... */
 int sgam_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
                        float beta2, float eps, int32_t step, void *stream);
+
+/* PatchGAN discriminator pieces (modules/discriminator/model.py:17-67; hinge loss and adaptive weight,
+ * modules/losses/vqperceptual.py:17-21, 63-75): nn.BatchNorm2d in training mode over [rows = B*H*W][C] NHWC matrices
+ * (mean_rstd [C][2] from the batch, biased variance; running_mean / running_var updated with the unbiased one), fused with
+ * LeakyReLU; mean_rstd = NULL: LeakyReLU alone (the first layer).  Workspace: sgam_batchnorm_workspace_bytes. */
+int64_t sgam_batchnorm_workspace_bytes(int32_t rows, int32_t C);
+int sgam_batchnorm_stats_f32(const float *x, float *mean_rstd, float *running_mean, float *running_var, int32_t rows, int32_t C,
+                             float eps, float momentum, void *workspace, int64_t workspace_bytes, void *stream);
+int sgam_bn_lrelu_fwd_f32(const float *x, const float *mean_rstd, const float *gamma, const float *beta, float *y, int32_t rows,
+                          int32_t C, float slope, void *stream);
+int sgam_bn_lrelu_bwd_f32(const float *x, const float *dy, const float *mean_rstd, const float *gamma, const float *beta, float *dx,
+                          float *dgamma, float *dbeta, float *gbuf, float *means, int32_t rows, int32_t C, float slope,
+                          void *workspace, int64_t workspace_bytes, void *stream);
+/* mode +1: relu(1 + l), -1: relu(1 - l), 0: l; grad = d(term)/dl * grad_scale, partial[ceil(n / 256)] = sums of the terms */
+int sgam_hinge_terms_f32(const float *logits, float *grad, double *partial, int64_t n, int32_t mode, float grad_scale, void *stream);
+int sgam_sumsq_partial_f32(const float *a, double *partial, int64_t n, void *stream);
 
 #ifdef __cplusplus
 }

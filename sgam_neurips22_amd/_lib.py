@@ -61,7 +61,7 @@ PROTOTYPES = {
                                         c_f32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "sgam_tsdf_raycast_depth_f32": (c_i32, [ctypes.POINTER(TsdfGrid), c_i32, c_i32, c_f32, c_f32, c_f32, c_f32, c_vp, c_f32,
                                             c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "sgam_im2col_t_f32": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_i32, c_vp]),
+    "sgam_im2col_t_f32": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_i32, c_i64, c_vp]),
     "sgam_col2im_gather_f32": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_i32, c_vp]),
     "sgam_unpack_conv_weight_grad_f32": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "sgam_colsum_workspace_bytes": (c_i64, [c_i32, c_i32]),
@@ -74,6 +74,13 @@ PROTOTYPES = {
     "sgam_vq_codebook_grad_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_vp]),
     "sgam_axpby_f32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_vp]),
     "sgam_adam_step_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp]),
+    "sgam_batchnorm_workspace_bytes": (c_i64, [c_i32, c_i32]),
+    "sgam_batchnorm_stats_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_vp, c_i64, c_vp]),
+    "sgam_bn_lrelu_fwd_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp]),
+    "sgam_bn_lrelu_bwd_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp, c_i64,
+                                      c_vp]),
+    "sgam_hinge_terms_f32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_vp]),
+    "sgam_sumsq_partial_f32": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
     "sgam_pack_conv_weight_f32x": (c_i32, [c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "sgam_split_rows_f32x": (c_i32, [c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_vp]),
     "sgam_conv2d_h16_workspace_bytes": (c_i64, [ctypes.POINTER(ConvDesc)]),

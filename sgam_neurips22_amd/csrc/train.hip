@@ -31,8 +31,9 @@ __device__ __forceinline__ bool src_of(const ConvGeo &g, int oy, int ox, int ky,
     return true;
 }
 
-// col^T[k = tap * Cin_pad + c][m = (b, oy, ox)] of the NHWC input x (row stride ld)
-__global__ __launch_bounds__(256) void im2col_t_kernel(const float *__restrict__ x, int ld, float *__restrict__ out, ConvGeo g) {
+// col^T[k = tap * Cin_pad + c][m = (b, oy, ox)] of the NHWC input x (row stride ld); rows of col^T are ldm apart (>= M: the
+// caller zero-fills the tail when it rounds the GEMM's K = M up)
+__global__ __launch_bounds__(256) void im2col_t_kernel(const float *__restrict__ x, int ld, float *__restrict__ out, int64_t ldm, ConvGeo g) {
     const int64_t M = (int64_t)g.B * g.Ho * g.Wo;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t total = (int64_t)g.KH * g.KW * g.Cin_pad * M;
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(256) void im2col_t_kernel(const float *__restrict__
     int iy, ix;
     float v = 0.f;
     if (c < g.Cin && src_of(g, oy, ox, ky, kx, iy, ix)) v = x[((int64_t)(b * g.Hi + iy) * g.Wi + ix) * ld + c];
-    out[i] = v;
+    out[(int64_t)k * ldm + m] = v;
 }
 
 // dx[b][iy][ix][c] = sum over (output pixel, tap) pairs that read this input pixel of dcol[m][tap * Cin_pad + c]; a gather
@@ -254,6 +255,149 @@ __global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, 
     p[i] -= step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
 }
 
+// ---- PatchGAN discriminator pieces (modules/discriminator/model.py: Conv 4x4 -> [BatchNorm2d] -> LeakyReLU(0.2)) ----
+// BatchNorm2d in training mode over the rows (= batch x pixels) of an NHWC matrix [rows][C]: per-channel partial sums of x and
+// x^2 over row chunks (fp64), folded by bn_fold_kernel into {mean, rstd} (biased variance, as F.batch_norm normalises) and
+// the running statistics (momentum update with the UNBIASED variance, like nn.BatchNorm2d)
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict__ x, int ld, double *__restrict__ part, int rows, int C,
+                                                         int rows_per_chunk) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+    double s = 0.0, ss = 0.0;
+    for (int r = r0; r < r1; ++r) {
+        const double v = (double)x[(int64_t)r * ld + c];
+        s += v;
+        ss += v * v;
+    }
+    part[((int64_t)blockIdx.y * C + c) * 2] = s;
+    part[((int64_t)blockIdx.y * C + c) * 2 + 1] = ss;
+}
+
+__global__ void bn_fold_kernel(const double *__restrict__ part, int chunks, float *__restrict__ mean_rstd, float *__restrict__ run_mean,
+                               float *__restrict__ run_var, int rows, int C, float eps, float momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < chunks; ++k) {
+        s += part[((int64_t)k * C + c) * 2];
+        ss += part[((int64_t)k * C + c) * 2 + 1];
+    }
+    const double mean = s / rows;
+    double var = ss / rows - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mean_rstd[c * 2] = (float)mean;
+    mean_rstd[c * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    if (run_mean) {
+        const double unb = rows > 1 ? var * rows / (rows - 1.0) : var;
+        run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * (float)mean;
+        run_var[c] = (1.0f - momentum) * run_var[c] + momentum * (float)unb;
+    }
+}
+
+// y = lrelu(n), n = has_bn ? gamma (x - mean) rstd + beta : x
+__global__ void bn_lrelu_fwd_kernel(const float *__restrict__ x, const float *__restrict__ mean_rstd, const float *__restrict__ gamma,
+                                    const float *__restrict__ beta, float *__restrict__ y, int64_t total, int C, float slope) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    float n = x[i];
+    if (mean_rstd) n = gamma[c] * ((n - mean_rstd[c * 2]) * mean_rstd[c * 2 + 1]) + beta[c];
+    y[i] = n > 0.f ? n : slope * n;
+}
+
+// g = dy * lrelu'(n); partial column sums of g and g * xh over row chunks (xh = 1 without BatchNorm); g is written to `gbuf`
+__global__ __launch_bounds__(256) void bn_lrelu_bwd_partial_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                                   const float *__restrict__ mean_rstd, const float *__restrict__ gamma,
+                                                                   const float *__restrict__ beta, float *__restrict__ gbuf,
+                                                                   double *__restrict__ part, int rows, int C, int rows_per_chunk,
+                                                                   float slope) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+    const float mean = mean_rstd ? mean_rstd[c * 2] : 0.f, rstd = mean_rstd ? mean_rstd[c * 2 + 1] : 1.f;
+    const float ga = mean_rstd ? gamma[c] : 1.f, be = mean_rstd ? beta[c] : 0.f;
+    double s = 0.0, sx = 0.0;
+    for (int r = r0; r < r1; ++r) {
+        const int64_t o = (int64_t)r * C + c;
+        const float xh = mean_rstd ? (x[o] - mean) * rstd : x[o];
+        const float n = mean_rstd ? ga * xh + be : xh;
+        const float g = dy[o] * (n > 0.f ? 1.f : slope);
+        gbuf[o] = g;
+        s += (double)g;
+        sx += (double)g * (double)xh;
+    }
+    part[((int64_t)blockIdx.y * C + c) * 2] = s;
+    part[((int64_t)blockIdx.y * C + c) * 2 + 1] = sx;
+}
+
+__global__ void bn_bwd_fold_kernel(const double *__restrict__ part, int chunks, float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                   float *__restrict__ means, int rows, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, sx = 0.0;
+    for (int k = 0; k < chunks; ++k) {
+        s += part[((int64_t)k * C + c) * 2];
+        sx += part[((int64_t)k * C + c) * 2 + 1];
+    }
+    dbeta[c] = (float)s;
+    dgamma[c] = (float)sx;
+    means[c * 2] = (float)(s / rows);
+    means[c * 2 + 1] = (float)(sx / rows);
+}
+
+// dx = gamma rstd (g - mean(g) - xh mean(g xh)) with BatchNorm, else dx = g (already in gbuf)
+__global__ void bn_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ gbuf, const float *__restrict__ mean_rstd,
+                                    const float *__restrict__ gamma, const float *__restrict__ means, float *__restrict__ dx,
+                                    int64_t total, int C) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const float xh = (x[i] - mean_rstd[c * 2]) * mean_rstd[c * 2 + 1];
+    dx[i] = gamma[c] * mean_rstd[c * 2 + 1] * (gbuf[i] - means[c * 2] - xh * means[c * 2 + 1]);
+}
+
+// hinge terms over a logit map (vqperceptual.py:17-21, 98): mode +1: relu(1 + l) (fake, discriminator step), -1: relu(1 - l)
+// (real), 0: l itself (generator step: g_loss = -mean(l), grad = gscale everywhere).  grad[i] = d(term)/dl * gscale,
+// partial[workgroup] = sum of the terms
+__global__ __launch_bounds__(256) void hinge_kernel(const float *__restrict__ l, float *__restrict__ grad, double *__restrict__ partial,
+                                                    int64_t n, int mode, float gscale) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double a = 0.0;
+    if (i < n) {
+        const float v = l[i];
+        if (mode == 0) {
+            a = (double)v;
+            grad[i] = gscale;
+        } else {
+            const float t = 1.0f + (float)mode * v;
+            a = t > 0.f ? (double)t : 0.0;
+            grad[i] = t > 0.f ? (float)mode * gscale : 0.f;
+        }
+    }
+    __shared__ double sh[256];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+
+// partial sums of squares (the two gradient norms of calculate_adaptive_weight, vqperceptual.py:63-75)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float *__restrict__ a, double *__restrict__ partial, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    __shared__ double sh[256];
+    sh[threadIdx.x] = i < n ? (double)a[i] * (double)a[i] : 0.0;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+
 ConvGeo geo_of(const sgam_conv_desc *d, int cin_pad) {
     ConvGeo g;
     g.B = d->B; g.Hi = d->Hi; g.Wi = d->Wi; g.Cin = d->Cin; g.Cin_pad = cin_pad; g.Ho = d->Ho; g.Wo = d->Wo; g.KH = d->KH; g.KW = d->KW;
@@ -268,12 +412,12 @@ bool geo_ok(const sgam_conv_desc *d, int cin_pad) {
 
 }  // namespace
 
-extern "C" int sgam_im2col_t_f32(const sgam_conv_desc *d, const float *x, float *col_t, int32_t cin_pad, void *stream) {
-    if (!geo_ok(d, cin_pad) || !x || !col_t || d->lda < d->Cin) return SGAM_EINVAL;
+extern "C" int sgam_im2col_t_f32(const sgam_conv_desc *d, const float *x, float *col_t, int32_t cin_pad, int64_t ld_m, void *stream) {
+    if (!geo_ok(d, cin_pad) || !x || !col_t || d->lda < d->Cin || ld_m < (int64_t)d->B * d->Ho * d->Wo) return SGAM_EINVAL;
     const ConvGeo g = geo_of(d, cin_pad);
     const int64_t total = (int64_t)g.KH * g.KW * g.Cin_pad * g.B * g.Ho * g.Wo;
     if (total >= ((int64_t)1 << 31) * 256) return SGAM_EINVAL;
-    SGAM_KLAUNCH(im2col_t_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, sgam_stream(stream), x, d->lda, col_t, g);
+    SGAM_KLAUNCH(im2col_t_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, sgam_stream(stream), x, d->lda, col_t, ld_m, g);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
 }
@@ -383,6 +527,80 @@ extern "C" int sgam_adam_step_f32(float *param, const float *grad, float *exp_av
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     SGAM_KLAUNCH(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sgam_stream(stream), param, grad, exp_avg, exp_avg_sq, n,
                  beta1, beta2, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), eps);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+// ---- BatchNorm2d (training mode) + LeakyReLU of the PatchGAN discriminator, on [rows = B*H*W][C] NHWC matrices ----
+// workspace: sgam_cdiv(rows, 256) * C * 2 doubles
+extern "C" int64_t sgam_batchnorm_workspace_bytes(int32_t rows, int32_t C) {
+    if (rows <= 0 || C <= 0) return -1;
+    return (int64_t)sgam_cdiv(rows, 256) * C * 2 * 8;
+}
+
+// mean_rstd [C][2] out; running_mean / running_var updated in place when given (momentum 0.1 in the reference)
+extern "C" int sgam_batchnorm_stats_f32(const float *x, float *mean_rstd, float *running_mean, float *running_var, int32_t rows, int32_t C,
+                                        float eps, float momentum, void *workspace, int64_t workspace_bytes, void *stream) {
+    if (!x || !mean_rstd || rows <= 0 || C <= 0 || (running_mean == nullptr) != (running_var == nullptr) || !workspace ||
+        workspace_bytes < sgam_batchnorm_workspace_bytes(rows, C))
+        return SGAM_EINVAL;
+    const int chunks = sgam_cdiv(rows, 256);
+    hipStream_t s = sgam_stream(stream);
+    SGAM_KLAUNCH(bn_partial_kernel, dim3(sgam_cdiv(C, 256), chunks), dim3(256), 0, s, x, C, (double *)workspace, rows, C, 256);
+    SGAM_LAUNCH_CHECK();
+    SGAM_KLAUNCH(bn_fold_kernel, dim3(sgam_cdiv(C, 256)), dim3(256), 0, s, (const double *)workspace, chunks, mean_rstd, running_mean,
+                 running_var, rows, C, eps, momentum);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+// y = leaky_relu(mean_rstd ? gamma * (x - mean) * rstd + beta : x, slope)
+extern "C" int sgam_bn_lrelu_fwd_f32(const float *x, const float *mean_rstd, const float *gamma, const float *beta, float *y, int32_t rows,
+                                     int32_t C, float slope, void *stream) {
+    if (!x || !y || rows <= 0 || C <= 0 || (mean_rstd && (!gamma || !beta))) return SGAM_EINVAL;
+    const int64_t total = (int64_t)rows * C;
+    SGAM_KLAUNCH(bn_lrelu_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, sgam_stream(stream), x, mean_rstd, gamma, beta, y,
+                 total, C, slope);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+// backward of the same: dx [rows][C]; dgamma / dbeta [C] (BatchNorm only); scratch: gbuf [rows][C] floats (may alias dx),
+// means [C][2] floats, workspace as for the statistics
+extern "C" int sgam_bn_lrelu_bwd_f32(const float *x, const float *dy, const float *mean_rstd, const float *gamma, const float *beta,
+                                     float *dx, float *dgamma, float *dbeta, float *gbuf, float *means, int32_t rows, int32_t C,
+                                     float slope, void *workspace, int64_t workspace_bytes, void *stream) {
+    if (!x || !dy || !dx || !gbuf || rows <= 0 || C <= 0 || !workspace || workspace_bytes < sgam_batchnorm_workspace_bytes(rows, C))
+        return SGAM_EINVAL;
+    if (mean_rstd && (!gamma || !beta || !dgamma || !dbeta || !means || gbuf == dx)) return SGAM_EINVAL;
+    if (!mean_rstd && gbuf != dx) return SGAM_EINVAL;          // without BatchNorm the masked gradient IS dx
+    const int chunks = sgam_cdiv(rows, 256);
+    hipStream_t s = sgam_stream(stream);
+    SGAM_KLAUNCH(bn_lrelu_bwd_partial_kernel, dim3(sgam_cdiv(C, 256), chunks), dim3(256), 0, s, x, dy, mean_rstd, gamma, beta, gbuf,
+                 (double *)workspace, rows, C, 256, slope);
+    SGAM_LAUNCH_CHECK();
+    if (!mean_rstd) return SGAM_OK;
+    SGAM_KLAUNCH(bn_bwd_fold_kernel, dim3(sgam_cdiv(C, 256)), dim3(256), 0, s, (const double *)workspace, chunks, dgamma, dbeta, means, rows,
+                 C);
+    SGAM_LAUNCH_CHECK();
+    const int64_t total = (int64_t)rows * C;
+    SGAM_KLAUNCH(bn_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, gbuf, mean_rstd, gamma, means, dx, total, C);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+// partial: sgam_cdiv(n, 256) doubles
+extern "C" int sgam_hinge_terms_f32(const float *logits, float *grad, double *partial, int64_t n, int32_t mode, float grad_scale,
+                                    void *stream) {
+    if (!logits || !grad || !partial || n <= 0 || mode < -1 || mode > 1) return SGAM_EINVAL;
+    SGAM_KLAUNCH(hinge_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sgam_stream(stream), logits, grad, partial, n, mode, grad_scale);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+extern "C" int sgam_sumsq_partial_f32(const float *a, double *partial, int64_t n, void *stream) {
+    if (!a || !partial || n <= 0) return SGAM_EINVAL;
+    SGAM_KLAUNCH(sumsq_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sgam_stream(stream), a, partial, n);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
 }

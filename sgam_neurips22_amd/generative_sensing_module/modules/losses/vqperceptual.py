@@ -1,0 +1,23 @@
+"""Hyper-parameter / parameter container of the reference's VQLPIPSWithDiscriminator
+(sgam/generative_sensing_module/modules/losses/vqperceptual.py:34-137), consumed by sgam_neurips22_amd.training.VQGANTrainer.
+LPIPS is NOT built (it needs torchvision's pretrained VGG16, absent offline): perceptual_weight must be 0."""
+import torch.nn as nn
+
+from ..discriminator.model import NLayerDiscriminator, weights_init
+
+
+class VQLPIPSWithDiscriminator(nn.Module):
+    def __init__(self, disc_start, codebook_weight=1.0, pixelloss_weight=1.0, disc_num_layers=3, disc_in_channels=3, disc_factor=1.0,
+                 disc_weight=1.0, perceptual_weight=1.0, use_actnorm=False, disc_conditional=False, disc_ndf=64, disc_loss="hinge",
+                 use_discriminative_loss=False, disp_loss_weight=None, disc_update_every_n_step=None, kernel_width=4):
+        super().__init__()
+        if disc_loss != "hinge":
+            raise NotImplementedError("only the hinge discriminator loss of the shipped configs is built")
+        if disc_conditional:
+            raise NotImplementedError("disc_conditional")
+        self.codebook_weight, self.pixel_weight, self.perceptual_weight = codebook_weight, pixelloss_weight, perceptual_weight
+        self.use_discriminative_loss = use_discriminative_loss
+        self.discriminator = NLayerDiscriminator(input_nc=disc_in_channels, n_layers=disc_num_layers, use_actnorm=use_actnorm,
+                                                 ndf=disc_ndf, kernel_width=kernel_width).apply(weights_init)
+        self.discriminator_iter_start = disc_start
+        self.disc_factor, self.discriminator_weight, self.disc_conditional = disc_factor, disc_weight, disc_conditional

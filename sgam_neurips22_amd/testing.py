@@ -236,3 +236,26 @@ def train_batch():
     x, mask = rect_hole_input(2, 64, 64, seed=5)
     x_dst = (seeded_tensor("train.dst", (2, 4, 64, 64), scale=0.5)).clamp(-1, 1)
     return x, mask, x_dst
+
+
+def synthetic_disc_state_dict(reference_state_dict, seed=0):
+    """deterministic PatchGAN weights in the spirit of its weights_init (Conv ~ N(0, 0.02), BatchNorm weight ~ N(1, 0.02), bias 0)
+    — scaled up 5x so that the logits are not all near zero — with fresh running statistics"""
+    out = {}
+    for name in sorted(reference_state_dict.keys()):
+        ref = reference_state_dict[name]
+        g = torch.Generator().manual_seed((zlib.crc32(("disc." + name).encode()) + 7919 * seed) % (2 ** 31))
+        if name.endswith("num_batches_tracked"):
+            t = torch.zeros((), dtype=torch.int64)
+        elif name.endswith("running_mean"):
+            t = torch.zeros(tuple(ref.shape))
+        elif name.endswith("running_var"):
+            t = torch.ones(tuple(ref.shape))
+        elif ref.dim() == 4:
+            t = torch.randn(tuple(ref.shape), generator=g) * 0.1
+        elif name.endswith("weight"):
+            t = 1.0 + 0.02 * torch.randn(tuple(ref.shape), generator=g)
+        else:
+            t = 0.05 * torch.randn(tuple(ref.shape), generator=g)
+        out[name] = t
+    return out

@@ -1,22 +1,27 @@
-"""Autoencoder update of the reference's training step on the HIP kernels (SURVEY.md §8 row f4 — PARTIAL).
+"""The reference's training step on the HIP kernels (LPIPS and the online k-means refresh not built).
 
 What the reference does per batch (sgam/generative_sensing_module/model.py:271-345): forward of the conditional VQGAN,
 `VQLPIPSWithDiscriminator.forward(qloss, x_dst, xrec, optimizer_idx=0, global_step, ...)`
-(modules/losses/vqperceptual.py:77-110), `opt_ae.zero_grad(); aeloss.backward(); opt_ae.step()`, then the same for the
-discriminator.  Built here: that autoencoder half while the loss is in its pre-discriminator phase — `perceptual_weight = 0`
-and `global_step < disc_start`, where `d_weight * disc_factor * g_loss` is identically zero — i.e.
+(modules/losses/vqperceptual.py:77-110), `opt_ae.zero_grad(); aeloss.backward(); opt_ae.step()`, then the same with
+`optimizer_idx=1` for the PatchGAN discriminator.  Built here, at `perceptual_weight = 0`:
 
-    loss = mean|x_dst - xrec| + codebook_weight * qloss,          Adam(lr, betas=(0.5, 0.9))   (model.py:414-428)
+  `AutoencoderTrainer`   loss = mean|x_dst - xrec| + codebook_weight * qloss   (what the reference's loss reduces to before
+                          `disc_start`), Adam(lr, betas=(0.5, 0.9)) over the phase's parameter set (model.py:414-428:
+                          `conditional_generation`: encoder + conv_in; `codebook`: the whole autoencoder incl. the embedding)
+  `VQGANTrainer`          the whole step: + g_loss = -mean D(xrec) weighted by the adaptive `d_weight` = ||d nll / d W_last|| /
+                          (||d g_loss / d W_last|| + 1e-4) * disc_weight and by `disc_factor` (0 before `disc_start`), then the
+                          discriminator update with the hinge loss on D(x_dst), D(xrec.detach()) and its own Adam; the three
+                          discriminator forwards per step update its BatchNorm running statistics like the reference's
 
-over the parameter set of the phase (`conditional_generation`: encoder (+ conv_in with the extrapolation mask);
-`codebook`: encoder, decoder, quantiser, quant_conv, post_quant_conv (+ conv_in)).  NOT built: LPIPS, the PatchGAN
-discriminator, its hinge loss and optimiser, the adaptive generator weight, the online k-means codebook refresh.
+NOT built: LPIPS (torchvision's pretrained VGG16 is not available offline, so neither the reference's perceptual term nor a
+fixture for it can be produced here) and the online k-means codebook refresh.
 
 Arithmetic: every product (forward convolutions, data / weight gradients, attention) runs on the MFMA GEMM of csrc/conv_gemm.hip
 in its fp32-in mode (`ops.set_f32_mode("mfma")` for the duration of a step: gradients sit far below fp16's normal range, so the
 exact hi / lo fp16 split of the inference path does not apply); the index, reduction and element-wise kernels are
-csrc/train.hip.  torch is used for memory, views and `torch.distributed` only (and `torch.cat` / `zeros` to lay out the 5-channel
-input), never for arithmetic.  Activations NHWC fp32, one tape entry per layer.
+csrc/train.hip.  torch is used for memory, views, zero-padded copies and `torch.distributed` only, never for arithmetic
+(the few hundred per-workgroup partial sums behind a logged scalar or a gradient norm are added on the host, where the
+reference calls `.item()`).  Activations NHWC fp32, one tape entry per layer.
 """
 import contextlib
 import ctypes
@@ -39,6 +44,29 @@ def _transpose2d(a):
     """(R, C) dense fp32 -> (C, R) dense (the layout-hop kernel of the forward path)"""
     R, C = a.shape
     return ops.nhwc_to_nchw(a.reshape(1, R, 1, C)).reshape(C, R)
+
+
+def _pad_rows(a2d, rows):
+    """(R, C) -> (rows, C) with a zero tail (a copy; no arithmetic)"""
+    if a2d.shape[0] == rows:
+        return a2d
+    out = torch.zeros((rows, a2d.shape[1]), device=a2d.device, dtype=a2d.dtype)
+    out[:a2d.shape[0]] = a2d
+    return out
+
+
+def _pad_channels(x, c):
+    """(..., C) -> (..., c) dense with zero channels appended (a copy; no arithmetic)"""
+    if x.shape[-1] == c:
+        return x if x.is_contiguous() else x.contiguous()
+    out = torch.zeros(x.shape[:-1] + (c,), device=x.device, dtype=x.dtype)
+    out[..., :x.shape[-1]] = x
+    return out
+
+
+def _host_sum(partial):
+    """fold of a few hundred per-workgroup partial sums (logging values and the two norms of the adaptive weight)"""
+    return float(partial.cpu().numpy().sum())
 
 
 def _axpby(a, b=None, alpha=1.0, beta=1.0):
@@ -90,15 +118,16 @@ class _Conv:
         M = d.B * d.Ho * d.Wo
         K = self.kh * self.kw * self.cin_pad
         dy2 = dy.reshape(M, dy.shape[-1])
-        assert dy2.shape[1] == self.cout_k and M % 32 == 0, (dy2.shape, self.cout_k, M)
+        assert dy2.shape[1] == self.cout_k, (dy2.shape, self.cout_k)
         pointwise = self.kh == 1 and self.kw == 1 and self.stride == 1 and not self.ups
         if self.need_wgrad:
-            dyT = _transpose2d(dy2)                                        # [cout_k][M]
+            Mp = _round_up(M, 32)                                          # the weight-gradient GEMM contracts over M: zero tail
+            dyT = _transpose2d(_pad_rows(dy2, Mp))                         # [cout_k][Mp]
             if pointwise:
-                colT = _transpose2d(x.reshape(M, self.cin_pad))
+                colT = _transpose2d(_pad_rows(x.reshape(M, self.cin_pad), Mp))
             else:
-                colT = torch.empty((K, M), device=x.device, dtype=torch.float32)
-                check(lib.sgam_im2col_t_f32(ctypes.byref(d), _p(x), _p(colT), self.cin_pad, _stream()), "sgam_im2col_t_f32")
+                colT = (torch.empty if Mp == M else torch.zeros)((K, Mp), device=x.device, dtype=torch.float32)
+                check(lib.sgam_im2col_t_f32(ctypes.byref(d), _p(x), _p(colT), self.cin_pad, Mp, _stream()), "sgam_im2col_t_f32")
             gwp = ops.gemm_nt(dyT, colT)                                   # [cout_k][K]
             gw = torch.empty_like(self.conv.weight)
             check(lib.sgam_unpack_conv_weight_grad_f32(_p(gwp), gwp.stride(0), _p(gw), self.cout, self.cin, self.kh, self.kw,
@@ -303,48 +332,53 @@ class AutoencoderTrainer:
         out[..., :4] = h
         return out
 
-    def forward_backward(self, x, x_dst, extrapolation_mask=None):
-        """-> (loss tensors dict); fills self.grads for every parameter of the phase"""
+    def _forward(self, x, x_dst, extrapolation_mask):
+        """forward with tape + the reconstruction loss and its gradient (call inside _mfma_mode())"""
         m, lib = self.model, _lib.load()
         self.grads.clear()
+        xin = self._input_nhwc(x, extrapolation_mask)
+        z = self.quant_conv.fwd(self.enc.fwd(xin))                               # (B,h,w,D)
+        zq_st, idx, _ = m.quantize.quantize_nhwc(z)                               # straight-through value, indices
+        e = ops.vq_gather(m.quantize._codebook()[0], idx).view(z.shape)           # the codebook rows themselves
+        qloss = float(m.quantize.commit_loss_nhwc(z, idx))
+        rec = self.dec.fwd(self.post_quant_conv.fwd(zq_st))                       # (B,H,W,out_ch)
+        C = rec.shape[3]
+        rows = rec.numel() // C
+        tgt = ops.nchw_to_nhwc(x_dst)                                             # (B,H,W,C)
+        ldg = _round_up(C, 32)
+        drec = torch.empty(rec.shape[:3] + (ldg,), device=rec.device, dtype=torch.float32)
+        part = torch.empty(((rows * ldg + 255) // 256,), device=rec.device, dtype=torch.float64)
+        check(lib.sgam_l1_loss_grad_f32(_p(rec), _p(tgt), _p(drec), _p(part), rows, C, C, ldg, 1.0 / (rows * C), _stream()),
+              "sgam_l1_loss_grad_f32")
+        # logging values are folded on the host like the reference's `.item()`s (the backward pass does not depend on them)
+        return {"z": z, "e": e, "idx": idx, "rec": rec, "drec": drec, "nll": _host_sum(part) / (rows * C), "qloss": qloss}
+
+    def _backward(self, fw, drec):
+        """drec (B,H,W,32) = dL/d(reconstruction) -> self.grads for every parameter of the phase"""
+        m, lib = self.model, _lib.load()
+        z, e, idx = fw["z"], fw["e"], fw["idx"]
+        B, h, w, D = z.shape
+        dzq = self.post_quant_conv.bwd(self.dec.bwd(drec))
+        two_c = 2.0 * self.codebook_weight / z.numel()
+        dz = torch.empty_like(z)
+        check(lib.sgam_vq_bwd_f32(_p(dzq), _p(z), _p(e), _p(dz), z.numel(), two_c, _stream()), "sgam_vq_bwd_f32")
+        if self.phase == "codebook":
+            emb = m.quantize.embedding.weight
+            ge = torch.empty_like(emb)
+            check(lib.sgam_vq_codebook_grad_f32(_p(idx.reshape(-1)), _p(z), _p(e), _p(ge), B * h * w, emb.shape[0], D,
+                                                two_c * m.quantize.beta, _stream()), "sgam_vq_codebook_grad_f32")
+            self.grads[emb] = ge
+        dxin = self.enc.bwd(self.quant_conv.bwd(dz))
+        if self.head is not None:
+            self.head.bwd(_pad_channels(dxin[..., :4], 32), need_dx=False)
+
+    def forward_backward(self, x, x_dst, extrapolation_mask=None):
+        """-> dict of loss terms / outputs; fills self.grads for every parameter of the phase"""
         with _mfma_mode():
-            xin = self._input_nhwc(x, extrapolation_mask)
-            z = self.quant_conv.fwd(self.enc.fwd(xin))                               # (B,h,w,D)
-            B, h, w, D = z.shape
-            zq_st, idx, _ = m.quantize.quantize_nhwc(z)                               # straight-through value, indices
-            e = ops.vq_gather(m.quantize._codebook()[0], idx).view(B, h, w, D)        # the codebook rows themselves
-            qloss = m.quantize.commit_loss_nhwc(z, idx)
-            rec = self.dec.fwd(self.post_quant_conv.fwd(zq_st))                       # (B,H,W,out_ch)
-            # ---- loss and its gradient
-            C = rec.shape[3]
-            rows = rec.numel() // C
-            tgt = ops.nchw_to_nhwc(x_dst)                                             # (B,H,W,C)
-            ldg = _round_up(C, 32)
-            drec = torch.empty((rec.shape[0], rec.shape[1], rec.shape[2], ldg), device=rec.device, dtype=torch.float32)
-            nblk = (rows * ldg + 255) // 256
-            part = torch.empty((nblk,), device=rec.device, dtype=torch.float64)
-            check(lib.sgam_l1_loss_grad_f32(_p(rec), _p(tgt), _p(drec), _p(part), rows, C, C, ldg, 1.0 / (rows * C), _stream()),
-                  "sgam_l1_loss_grad_f32")
-            # ---- backward
-            dzq = self.post_quant_conv.bwd(self.dec.bwd(drec))
-            two_c = 2.0 * self.codebook_weight / z.numel()
-            dz = torch.empty_like(z)
-            check(lib.sgam_vq_bwd_f32(_p(dzq), _p(z), _p(e), _p(dz), z.numel(), two_c, _stream()), "sgam_vq_bwd_f32")
-            if self.phase == "codebook":
-                emb = m.quantize.embedding.weight
-                ge = torch.empty_like(emb)
-                check(lib.sgam_vq_codebook_grad_f32(_p(idx.reshape(-1)), _p(z), _p(e), _p(ge), B * h * w, emb.shape[0], D,
-                                                    two_c * m.quantize.beta, _stream()), "sgam_vq_codebook_grad_f32")
-                self.grads[emb] = ge
-            dxin = self.enc.bwd(self.quant_conv.bwd(dz))
-            if self.head is not None:
-                d4 = torch.zeros(dxin.shape[:3] + (32,), device=dxin.device, dtype=torch.float32)
-                d4[..., :4] = dxin[..., :4]
-                self.head.bwd(d4, need_dx=False)
-        # logging values, folded on the host like the reference's `.item()`s (the backward pass does not depend on them)
-        nll = float(part.cpu().numpy().sum()) / (rows * C)
-        ql = float(qloss)
-        return {"nll_loss": nll, "quant_loss": ql, "loss": nll + self.codebook_weight * ql, "rec": rec, "indices": idx}
+            fw = self._forward(x, x_dst, extrapolation_mask)
+            self._backward(fw, fw["drec"])
+        return {"nll_loss": fw["nll"], "quant_loss": fw["qloss"], "loss": fw["nll"] + self.codebook_weight * fw["qloss"],
+                "rec": fw["rec"], "indices": fw["idx"]}
 
     def allreduce_grads(self):
         """what DDP does for the reference's LightningModule: average the gradients over the ranks — one flat bucket, one
@@ -363,18 +397,21 @@ class AutoencoderTrainer:
             o += n
         return flat.numel() * 4
 
-    def adam_step(self):
+    def _adam(self, params, grads, state):
         lib = _lib.load()
-        self.global_step += 1
-        for p in self.parameters():
-            g = self.grads.get(p)
+        for p in params:
+            g = grads.get(p)
             if g is None:
                 continue
-            st = self.state.get(p)
+            st = state.get(p)
             if st is None:
-                st = self.state[p] = (torch.zeros_like(p.data), torch.zeros_like(p.data))
+                st = state[p] = (torch.zeros_like(p.data), torch.zeros_like(p.data))
             check(lib.sgam_adam_step_f32(_p(p.data), _p(ops._f32c(g)), _p(st[0]), _p(st[1]), p.numel(), self.lr, ADAM_BETAS[0],
                                          ADAM_BETAS[1], ADAM_EPS, self.global_step, _stream()), "sgam_adam_step_f32")
+
+    def adam_step(self):
+        self.global_step += 1
+        self._adam(self.parameters(), self.grads, self.state)
         _invalidate_packs(self.model)
 
     def step(self, x, x_dst, extrapolation_mask=None):
@@ -384,6 +421,176 @@ class AutoencoderTrainer:
         log = {"train/total_loss": out["loss"], "train/quant_loss": out["quant_loss"], "train/rec_loss": out["nll_loss"],
                "train/nll_loss": out["nll_loss"]}
         return out["loss"], log
+
+
+class _BNLReLU:
+    """[BatchNorm2d in training mode ->] LeakyReLU(0.2) of the PatchGAN (discriminator/model.py:40-60)"""
+
+    def __init__(self, bn, grads, slope=0.2):
+        self.bn, self.grads, self.slope = bn, grads, slope
+
+    def fwd(self, x):
+        lib = _lib.load()
+        B, H, W, C = x.shape
+        rows = B * H * W
+        self.x, self.mr = x, None
+        y = torch.empty_like(x)
+        if self.bn is not None:
+            bn = self.bn
+            nb = lib.sgam_batchnorm_workspace_bytes(rows, C)
+            ws = torch.empty((nb,), device=x.device, dtype=torch.uint8)
+            self.mr = torch.empty((C, 2), device=x.device, dtype=torch.float32)
+            track = bn.training and bn.track_running_stats
+            check(lib.sgam_batchnorm_stats_f32(_p(x), _p(self.mr), _p(bn.running_mean) if track else None,
+                                               _p(bn.running_var) if track else None, rows, C, bn.eps, bn.momentum, _p(ws), nb, _stream()),
+                  "sgam_batchnorm_stats_f32")
+            if track:
+                bn.num_batches_tracked += 1
+            check(lib.sgam_bn_lrelu_fwd_f32(_p(x), _p(self.mr), _p(bn.weight.data), _p(bn.bias.data), _p(y), rows, C, self.slope, _stream()),
+                  "sgam_bn_lrelu_fwd_f32")
+        else:
+            check(lib.sgam_bn_lrelu_fwd_f32(_p(x), None, None, None, _p(y), rows, C, self.slope, _stream()), "sgam_bn_lrelu_fwd_f32")
+        return y
+
+    def bwd(self, dy, need_pgrad=True):
+        lib = _lib.load()
+        x = self.x
+        B, H, W, C = x.shape
+        rows = B * H * W
+        nb = lib.sgam_batchnorm_workspace_bytes(rows, C)
+        ws = torch.empty((nb,), device=x.device, dtype=torch.uint8)
+        dx = torch.empty_like(x)
+        if self.bn is None:
+            check(lib.sgam_bn_lrelu_bwd_f32(_p(x), _p(dy), None, None, None, _p(dx), None, None, _p(dx), None, rows, C, self.slope, _p(ws),
+                                            nb, _stream()), "sgam_bn_lrelu_bwd_f32")
+            return dx
+        bn = self.bn
+        dg, db = torch.empty((C,), device=x.device), torch.empty((C,), device=x.device)
+        gbuf, means = torch.empty_like(x), torch.empty((C, 2), device=x.device)
+        check(lib.sgam_bn_lrelu_bwd_f32(_p(x), _p(dy), _p(self.mr), _p(bn.weight.data), _p(bn.bias.data), _p(dx), _p(dg), _p(db), _p(gbuf),
+                                        _p(means), rows, C, self.slope, _p(ws), nb, _stream()), "sgam_bn_lrelu_bwd_f32")
+        if need_pgrad:
+            _accumulate(self.grads, bn.weight, dg)
+            _accumulate(self.grads, bn.bias, db)
+        return dx
+
+
+def _accumulate(grads, p, g):
+    grads[p] = g if p not in grads else _axpby(grads[p], g)
+
+
+class _DiscTape:
+    """one forward of NLayerDiscriminator.main on an NHWC batch (channels padded to 32) with everything the backward needs"""
+
+    def __init__(self, disc, grads):
+        self.grads = grads
+        self.layers = []
+        mods = list(disc.main)
+        i = 0
+        while i < len(mods):
+            conv = mods[i]
+            bn = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], torch.nn.BatchNorm2d) else None
+            has_act = any(isinstance(m, torch.nn.LeakyReLU) for m in mods[i + 1:i + 3])
+            self.layers.append((_Conv(conv, {}), _BNLReLU(bn, grads) if has_act else None))
+            i += 1 + (1 if bn is not None else 0) + (1 if has_act else 0)
+
+    def fwd(self, x):
+        for conv, act in self.layers:
+            x = conv.fwd(x)
+            if act is not None:
+                x = act.fwd(x)
+        return x                                              # logits (B,h,w,1)
+
+    def bwd(self, dlogits, need_pgrad):
+        """dlogits (B,h,w,32) (column 0 real) -> gradient w.r.t. the input (B,H,W,32); parameter gradients ACCUMULATE into grads"""
+        dy = dlogits
+        for conv, act in reversed(self.layers):
+            if act is not None:
+                dy = act.bwd(dy, need_pgrad)
+            conv.need_wgrad = need_pgrad
+            conv.grads.clear()
+            dy = conv.bwd(_pad_channels(dy, conv.cout_k))
+            for p, g in conv.grads.items():
+                _accumulate(self.grads, p, g)
+        return dy
+
+
+class VQGANTrainer(AutoencoderTrainer):
+    """`VQModel.training_step` (model.py:271-345) with `VQLPIPSWithDiscriminator` (vqperceptual.py:34-137) at
+    perceptual_weight = 0: the autoencoder update with the adaptive-weighted generator term, then the discriminator update
+    (hinge loss, its own Adam).  `loss_cfg` = a modules.losses.vqperceptual.VQLPIPSWithDiscriminator container."""
+
+    def __init__(self, model, loss_cfg, phase=None, lr=None, process_group=None):
+        if loss_cfg.perceptual_weight != 0:
+            raise NotImplementedError("LPIPS is not built (needs torchvision's pretrained VGG16): perceptual_weight must be 0")
+        super().__init__(model, phase=phase, lr=lr, codebook_weight=loss_cfg.codebook_weight, process_group=process_group)
+        self.cfg, self.disc = loss_cfg, loss_cfg.discriminator
+        self.dgrads, self.dstate = {}, {}
+
+    def _disc_factor(self):
+        return self.cfg.disc_factor if self.global_step >= self.cfg.discriminator_iter_start else 0.0       # adopt_weight, :14-17
+
+    def _hinge(self, logits, mode, gscale):
+        lib = _lib.load()
+        n = logits.numel()
+        grad = torch.empty((n,), device=logits.device, dtype=torch.float32)
+        part = torch.empty(((n + 255) // 256,), device=logits.device, dtype=torch.float64)
+        check(lib.sgam_hinge_terms_f32(_p(logits), _p(grad), _p(part), n, mode, float(gscale), _stream()), "sgam_hinge_terms_f32")
+        return _host_sum(part) / n, _pad_channels(grad.reshape(logits.shape), 32)
+
+    def _norm(self, t):
+        part = torch.empty(((t.numel() + 255) // 256,), device=t.device, dtype=torch.float64)
+        check(_lib.load().sgam_sumsq_partial_f32(_p(t), _p(part), t.numel(), _stream()), "sgam_sumsq_partial_f32")
+        return _host_sum(part) ** 0.5
+
+    def step(self, x, x_dst, extrapolation_mask=None):
+        cfg, lib = self.cfg, _lib.load()
+        disc_factor = self._disc_factor()
+        with _mfma_mode():
+            # ---- optimizer_idx 0 (vqperceptual.py:77-110)
+            fw = self._forward(x, x_dst, extrapolation_mask)
+            rec, drec_nll = fw["rec"], fw["drec"]
+            tape_g = _DiscTape(self.disc, {})
+            logits_fake = tape_g.fwd(_pad_channels(rec, 32))
+            n_log = logits_fake.numel()
+            mean_fake, dlog = self._hinge(logits_fake, 0, -1.0 / n_log)                # g_loss = -mean(logits_fake)
+            g_loss = -mean_fake
+            drec_g = tape_g.bwd(dlog, need_pgrad=False)
+            # adaptive weight (:63-75): the two gradients w.r.t. the last layer's weight
+            last = self.dec.layers[-1]
+            keep = last.need_wgrad
+            last.need_wgrad, norms = True, []
+            for d in (drec_nll, drec_g):
+                last.bwd(d, need_dx=False)
+                norms.append(self._norm(self.grads[last.conv.weight]))
+            last.need_wgrad = keep
+            self.grads.clear()
+            d_weight = min(max(norms[0] / (norms[1] + 1e-4), 0.0), 1e4) * cfg.discriminator_weight
+            drec = _axpby(drec_nll, drec_g, 1.0, d_weight * disc_factor) if disc_factor != 0 else drec_nll
+            self._backward(fw, drec)
+            self.allreduce_grads()
+            # ---- optimizer_idx 1 (:112-129): the discriminator sees the reconstruction of BEFORE the autoencoder update
+            tape_r, tape_f = _DiscTape(self.disc, self.dgrads), _DiscTape(self.disc, self.dgrads)
+            self.dgrads.clear()
+            logits_real = tape_r.fwd(ops.nchw_to_nhwc(x_dst, c_pad=32))
+            logits_fake2 = tape_f.fwd(_pad_channels(rec, 32))
+            lr_mean, dl_real = self._hinge(logits_real, -1, 0.5 * disc_factor / logits_real.numel())
+            lf_mean, dl_fake = self._hinge(logits_fake2, +1, 0.5 * disc_factor / logits_fake2.numel())
+            d_loss = disc_factor * 0.5 * (lr_mean + lf_mean)
+            if disc_factor != 0:
+                tape_r.bwd(dl_real, need_pgrad=True)
+                tape_f.bwd(dl_fake, need_pgrad=True)
+        self.adam_step()                                        # opt_ae.step(); also advances global_step
+        self._adam(list(self.disc.parameters()), self.dgrads, self.dstate)       # opt_disc.step()
+        _invalidate_packs(self.disc)
+        ae = fw["nll"] + d_weight * disc_factor * g_loss + self.codebook_weight * fw["qloss"]
+        log = {"train/total_loss": ae, "train/quant_loss": fw["qloss"], "train/rec_loss": fw["nll"], "train/d_weight": d_weight,
+               "train/disc_factor": disc_factor, "train/g_loss": g_loss, "train/disc_loss": d_loss,
+               "train/logits_real": self._mean_logit(logits_real), "train/logits_fake": self._mean_logit(logits_fake2)}
+        return ae, log
+
+    def _mean_logit(self, logits):
+        return self._hinge(logits, 0, 0.0)[0]
 
 
 def _invalidate_packs(model):

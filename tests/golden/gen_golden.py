@@ -357,6 +357,48 @@ def gen_train():
          **{"grad." + k: named[k].grad for k in keep})
 
 
+def gen_train_gan():
+    """the reference's whole training_step AFTER disc_start (perceptual_weight 0) on the small model: autoencoder loss with the
+    adaptive-weighted generator term, its gradients, then the discriminator's hinge loss and gradients, BatchNorm running
+    statistics after the three discriminator forwards"""
+    from sgam.generative_sensing_module.modules.losses.vqperceptual import VQLPIPSWithDiscriminator
+    print("training step with the discriminator (small model)")
+    g0 = np.load(os.path.join(HERE, "train_step_small.npz"))
+    p = testing.small_train_params(R.load_params("google_earth"))
+    p["phase"] = "codebook"
+    torch.manual_seed(0)
+    model = VQModel(**p).train()
+    sd = testing.synthetic_state_dict(model.state_dict(), seed=11)
+    sd["quantize.embedding.weight"] = testing.codebook_from_stats(float(g0["zmean"]), float(g0["zstd"]), 64, 32, int(g0["cb_seed"]))
+    model.load_state_dict(sd)
+    x, mask, x_dst = testing.train_batch()
+    loss_fn = VQLPIPSWithDiscriminator(disc_start=0, codebook_weight=1.0, perceptual_weight=0.0, disc_in_channels=4, disc_weight=0.8,
+                                       use_discriminative_loss=True).train()
+    loss_fn.discriminator.load_state_dict(testing.synthetic_disc_state_dict(loss_fn.discriminator.state_dict(), seed=2))
+    xrec, qloss, idx, pre = model(x, extrapolation_mask=mask, get_codebook_count=True, get_pre_quantized_feature=True)
+    aeloss, log = loss_fn(qloss, x_dst, xrec, 0, 0, last_layer=model.get_last_layer(), split="train", extrapolation_mask=mask)
+    model.zero_grad()
+    aeloss.backward()
+    named = dict(model.named_parameters())
+    keep = ["encoder.conv_in.weight", "decoder.conv_out.weight", "quantize.embedding.weight", "decoder.up.1.upsample.conv.bias"]
+    gn = {k: float(v.grad.double().norm()) for k, v in named.items() if v.grad is not None}
+    ae_grads = {"grad." + k: named[k].grad.clone() for k in keep}
+    discloss, dlog = loss_fn(qloss, x_dst, xrec, 1, 0, last_layer=model.get_last_layer(), split="train", extrapolation_mask=mask)
+    loss_fn.discriminator.zero_grad()
+    discloss.backward()
+    dn = dict(loss_fn.discriminator.named_parameters())
+    dgn = {k: float(v.grad.double().norm()) for k, v in dn.items()}
+    dsd = loss_fn.discriminator.state_dict()
+    save("train_step_gan_small.npz", loss=float(aeloss), d_weight=float(log["train/d_weight"]), g_loss=float(log["train/g_loss"]),
+         rec_loss=float(log["train/rec_loss"]), quant_loss=float(qloss), disc_loss=float(discloss),
+         logits_real=float(dlog["train/logits_real"]), logits_fake=float(dlog["train/logits_fake"]),
+         grad_norm_names=np.array(sorted(gn)), grad_norms=np.array([gn[k] for k in sorted(gn)]),
+         dgrad_norm_names=np.array(sorted(dgn)), dgrad_norms=np.array([dgn[k] for k in sorted(dgn)]),
+         **ae_grads, **{"dgrad.main.0.weight": dn["main.0.weight"].grad, "dgrad.main.3.weight": dn["main.3.weight"].grad,
+                        "dgrad.main.11.bias": dn["main.11.bias"].grad, "dgrad.main.6.bias": dn["main.6.bias"].grad},
+         **{"bn." + k: v for k, v in dsd.items() if "running" in k or "num_batches" in k})
+
+
 def gen_trajectory_clevr():
     """CLEVR-Infinite loop, 3 steps on a 2x2 grid: 16384 codes, num_src 5, the seed depth's ray->z conversion applied at
     construction (:71-79) AND again at every load (:582-590), both in float64."""
@@ -406,3 +448,4 @@ if __name__ == "__main__":
         gen_trajectory_clevr()
     if not only or "train" in only:
         gen_train()
+        gen_train_gan()

