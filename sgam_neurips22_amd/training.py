@@ -1,4 +1,4 @@
-"""The reference's training step on the HIP kernels (LPIPS and the online k-means refresh not built).
+"""The reference's training step on the HIP kernels (LPIPS not built).
 
 What the reference does per batch (sgam/generative_sensing_module/model.py:271-345): forward of the conditional VQGAN,
 `VQLPIPSWithDiscriminator.forward(qloss, x_dst, xrec, optimizer_idx=0, global_step, ...)`
@@ -14,7 +14,8 @@ What the reference does per batch (sgam/generative_sensing_module/model.py:271-3
                           discriminator forwards per step update its BatchNorm running statistics like the reference's
 
 NOT built: LPIPS (torchvision's pretrained VGG16 is not available offline, so neither the reference's perceptual term nor a
-fixture for it can be produced here) and the online k-means codebook refresh.
+fixture for it can be produced here).  The online k-means codebook refresh (model.py:274-295, 313-323) is host logic in the
+reference and here (`OnlineCodebookRefresh`, scipy's kmeans2).
 
 Arithmetic: every product (forward convolutions, data / weight gradients, attention) runs on the MFMA GEMM of csrc/conv_gemm.hip
 in its fp32-in mode (`ops.set_f32_mode("mfma")` for the duration of a step: gradients sit far below fp16's normal range, so the
@@ -308,6 +309,11 @@ class AutoencoderTrainer:
         self.post_quant_conv = _Conv(model.post_quant_conv, self.grads, need_wgrad=full)
         self.dec = _Seq(_decoder_layers(model.decoder, self.grads, full))
         self.head = _Conv(model.conv_in, self.grads) if model.use_extrapolation_mask else None
+        self.refresh = None
+        kcfg = getattr(model, "online_kmeans_config", None)
+        if self.phase == "codebook" and kcfg and kcfg.get("do_online_kmeans_clustering"):
+            rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
+            self.refresh = OnlineCodebookRefresh(model, kcfg, rank)
 
     # ---- the parameter set of the phase, in the order of configure_optimizers (model.py:414-428)
     def parameters(self):
@@ -336,11 +342,15 @@ class AutoencoderTrainer:
         """forward with tape + the reconstruction loss and its gradient (call inside _mfma_mode())"""
         m, lib = self.model, _lib.load()
         self.grads.clear()
+        if self.refresh is not None:
+            self.refresh.before_step(self.global_step)
         xin = self._input_nhwc(x, extrapolation_mask)
         z = self.quant_conv.fwd(self.enc.fwd(xin))                               # (B,h,w,D)
         zq_st, idx, _ = m.quantize.quantize_nhwc(z)                               # straight-through value, indices
         e = ops.vq_gather(m.quantize._codebook()[0], idx).view(z.shape)           # the codebook rows themselves
         qloss = float(m.quantize.commit_loss_nhwc(z, idx))
+        if self.refresh is not None and self.refresh._started(self.global_step) and self.refresh.rank == 0:
+            self.refresh.after_forward(self.global_step, idx.cpu().numpy(), ops.nhwc_to_nchw(z[:1])[0].cpu().numpy())
         rec = self.dec.fwd(self.post_quant_conv.fwd(zq_st))                       # (B,H,W,out_ch)
         C = rec.shape[3]
         rows = rec.numel() // C
@@ -421,6 +431,57 @@ class AutoencoderTrainer:
         log = {"train/total_loss": out["loss"], "train/quant_loss": out["quant_loss"], "train/rec_loss": out["nll_loss"],
                "train/nll_loss": out["nll_loss"]}
         return out["loss"], log
+
+
+class OnlineCodebookRefresh:
+    """The online k-means codebook refresh of VQModel.training_step (model.py:274-295 before the forward, :313-323 after it;
+    phase `codebook`, rank 0): every codeword carries a countdown that is reset whenever the word is used by the first image
+    of a batch; when more than `inactive_threshold` of the words have run out, enough pre-quantisation feature maps are
+    buffered and the step is a multiple of `frequency`, the dead words are replaced by the k-means centres of the buffered
+    features (`scipy.cluster.vq.kmeans2(..., minit='points')`, the reference's own host call).  Host logic throughout, as in
+    the reference; the codebook rows are written through `VectorQuantizer2.update_codebook`."""
+
+    def __init__(self, model, config, rank=0):
+        self.model, self.cfg, self.rank = model, dict(config), rank
+        self.enabled = bool(self.cfg.get("do_online_kmeans_clustering", False))
+        n = model.quantize.embedding.weight.shape[0]
+        self.countdown = {i: self.cfg.get("online_kmeans_word_timeout", 10) for i in range(n)}            # train_codebook_map
+        self.features = []                                                                               # train_sampled_feature_maps
+
+    def _started(self, global_step):
+        return self.enabled and global_step >= self.cfg.get("start_global_step", 0)
+
+    def before_step(self, global_step):
+        """model.py:274-295; returns the number of codewords replaced (0 = none)"""
+        if not self._started(global_step) or self.rank != 0:
+            return 0
+        import numpy as np
+        from scipy.cluster.vq import kmeans2
+        dead = [k for k, v in self.countdown.items() if v <= 0]
+        if not (len(dead) / len(self.countdown) > self.cfg["inactive_threshold"]
+                and len(self.features) >= self.cfg["train_feature_buffer_size"] and global_step % self.cfg["frequency"] == 0):
+            return 0
+        f = np.stack(self.features).transpose(0, 2, 3, 1)
+        centres = kmeans2(f.reshape(-1, f.shape[-1]), len(dead), minit="points")[0]
+        self.model.quantize.update_codebook(centres.astype(np.float32), dead)
+        _invalidate_packs(self.model)
+        for k in dead:
+            self.countdown[k] = self.cfg["online_kmeans_word_timeout"]
+        return len(dead)
+
+    def after_forward(self, global_step, indices, pre_quant_nchw0):
+        """model.py:313-323: `indices` = codebook indices of the batch (first image is what the reference looks at),
+        `pre_quant_nchw0` = the first image's pre-quantisation features (D,h,w) as a host array"""
+        if not self._started(global_step) or self.rank != 0:
+            return
+        import numpy as np
+        for v in np.unique(np.asarray(indices[0]).reshape(-1)):
+            self.countdown[int(v)] = self.cfg["online_kmeans_word_timeout"]
+        if len(self.features) > self.cfg["train_feature_buffer_size"]:
+            self.features = self.features[-self.cfg["train_feature_buffer_size"]:]
+        self.features.append(np.asarray(pre_quant_nchw0))
+        for k in self.countdown:
+            self.countdown[k] -= 1
 
 
 class _BNLReLU:
