@@ -372,16 +372,18 @@ def main():
     if rank == 0 and world == 1 and args.dtype == "f32" and not args.no_secondary:
         # SURVEY §8 f4 (a side note like the other legs): the reference's training step on the same 256x256 model, past
         # disc_start — forward with tape, L1 + codebook + adaptive-weighted generator loss, backward, Adam on the encoder (the
-        # phase that trains the hot-path model), then the PatchGAN's hinge loss, backward and Adam; perceptual_weight 0 (no
-        # LPIPS); a second instance of the model, so the inference legs are not disturbed
+        # phase that trains the hot-path model) with the LPIPS term on (synthetic VGG16 trunk), then the PatchGAN's hinge loss,
+        # backward and Adam; a second instance of the model, so the inference legs are not disturbed
         from sgam_neurips22_amd import training
         mt = build_model(dev)[0]
         xt, mk = testing.rect_hole_input(1, 256, 256, seed=9)
         xd = testing.seeded_tensor("bench.train.dst", (1, 4, 256, 256), scale=0.5).clamp(-1, 1).to(dev)
         xt, mk = xt.to(dev), mk.to(dev)
         from sgam_neurips22_amd.generative_sensing_module.modules.losses.vqperceptual import VQLPIPSWithDiscriminator
-        lcfg = VQLPIPSWithDiscriminator(disc_start=0, perceptual_weight=0.0, disc_in_channels=4, disc_weight=0.8,
+        lcfg = VQLPIPSWithDiscriminator(disc_start=0, perceptual_weight=1.0, disc_in_channels=4, disc_weight=0.8,
                                         use_discriminative_loss=True).to(dev).train()      # trained_models/*/config.yaml lossconfig
+        lcfg.perceptual_loss.load_state_dict({k: v.to(dev) for k, v in testing.synthetic_vgg_state_dict(
+            lcfg.perceptual_loss.state_dict(), seed=4).items()})        # (the ImageNet trunk cannot be fetched: synthetic)
         tr = training.VQGANTrainer(mt, lcfg, phase="conditional_generation", lr=4.5e-6)
         l0 = tr.step(xt, xd, mk)[0]
         torch.cuda.synchronize()
@@ -392,8 +394,8 @@ def main():
         dt_ = (time.perf_counter() - tt) / 3
         train_leg = {"ms_per_update": round(1e3 * dt_, 1), "updates_per_s": round(1 / dt_, 2), "batch": 1,
                      "loss_first": round(float(l0), 6), "loss_after_4": round(float(l1), 6),
-                     "note": "f4 without LPIPS: autoencoder (encoder parameter set) + PatchGAN discriminator updates of training_step "
-                             "past disc_start, perceptual_weight 0; fp32-in MFMA GEMMs + csrc/train.hip; untuned"}
+                     "note": "f4: autoencoder (encoder parameter set) + PatchGAN discriminator updates of training_step past disc_start, "
+                             "LPIPS on (synthetic VGG16 trunk); fp32-in MFMA GEMMs + csrc/train.hip; untuned"}
         del mt, tr
 
     cpu = None

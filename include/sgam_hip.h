@@ -478,6 +478,17 @@ int sgam_bn_lrelu_bwd_f32(const float *x, const float *dy, const float *mean_rst
 int sgam_hinge_terms_f32(const float *logits, float *grad, double *partial, int64_t n, int32_t mode, float grad_scale, void *stream);
 int sgam_sumsq_partial_f32(const float *a, double *partial, int64_t n, void *stream);
 
+/* LPIPS pieces (modules/losses/lpips.py:10-123): MaxPool2d(2, 2) of the VGG16 trunk and its backward (gradient to the first
+ * maximum of the window), ScalingLayer ((x - shift) / scale on the RGB channels into a zero-padded NHWC tensor; with shift 0 the
+ * same kernel is its backward), and one feature level of the metric: val_b = mean_p sum_c w_c (f0/(|f0|+eps) - f1/(|f1|+eps))^2
+ * (normalize_tensor -> squared difference -> NetLinLayer -> spatial_average) with its gradient w.r.t. f0. */
+int sgam_maxpool2x2_f32(const float *x, float *y, int32_t B, int32_t H, int32_t W, int32_t C, void *stream);
+int sgam_maxpool2x2_bwd_f32(const float *x, const float *dy, float *dx, int32_t B, int32_t H, int32_t W, int32_t C, void *stream);
+int sgam_channel_affine_f32(const float *x, int32_t ldx, float *y, int32_t ldy, int64_t rows, int32_t n, const float *shift4,
+                            const float *inv_scale4, void *stream);
+int sgam_lpips_level_f32(const float *f0, const float *f1, const float *lin_w, double *partial, float *df0, int32_t B, int32_t HW,
+                         int32_t C, float eps, float grad_scale, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,6 +81,10 @@ PROTOTYPES = {
                                       c_vp]),
     "sgam_hinge_terms_f32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_vp]),
     "sgam_sumsq_partial_f32": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
+    "sgam_maxpool2x2_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "sgam_maxpool2x2_bwd_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "sgam_channel_affine_f32": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp]),
+    "sgam_lpips_level_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_f32, c_vp]),
     "sgam_pack_conv_weight_f32x": (c_i32, [c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "sgam_split_rows_f32x": (c_i32, [c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_vp]),
     "sgam_conv2d_h16_workspace_bytes": (c_i64, [ctypes.POINTER(ConvDesc)]),

@@ -398,6 +398,103 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float *__restrict__ a,
     if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
 }
 
+// ---- LPIPS pieces (modules/losses/lpips.py): MaxPool2d(2, 2), the input ScalingLayer, and per feature level
+//      val_b = mean_p sum_c w_c (f0 / (|f0| + eps) - f1 / (|f1| + eps))^2     (normalize_tensor, NetLinLayer, spatial_average)
+__global__ void maxpool2x2_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, int B, int H, int W, int C) {
+    const int Ho = H / 2, Wo = W / 2;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * Ho * Wo * C) return;
+    const int c = (int)(i % C);
+    const int ox = (int)((i / C) % Wo), oy = (int)((i / ((int64_t)C * Wo)) % Ho), b = (int)(i / ((int64_t)C * Wo * Ho));
+    const float *p = x + (((int64_t)b * H + 2 * oy) * W + 2 * ox) * C + c;
+    y[i] = fmaxf(fmaxf(p[0], p[C]), fmaxf(p[(int64_t)W * C], p[(int64_t)W * C + C]));
+}
+
+// the gradient goes to the first maximum of the window in row-major order (what torch's max_pool2d backward does)
+__global__ void maxpool2x2_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ dx, int B, int H,
+                                      int W, int C) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * H * W * C) return;
+    const int c = (int)(i % C);
+    const int ix = (int)((i / C) % W), iy = (int)((i / ((int64_t)C * W)) % H), b = (int)(i / ((int64_t)C * W * H));
+    const int Ho = H / 2, Wo = W / 2, oy = iy >> 1, ox = ix >> 1;
+    float g = 0.f;
+    if (oy < Ho && ox < Wo) {
+        const float *p = x + (((int64_t)b * H + 2 * oy) * W + 2 * ox) * C + c;
+        const float v[4] = {p[0], p[C], p[(int64_t)W * C], p[(int64_t)W * C + C]};
+        int best = 0;
+        for (int k = 1; k < 4; ++k)
+            if (v[k] > v[best]) best = k;
+        if (best == ((iy & 1) * 2 + (ix & 1))) g = dy[(((int64_t)b * Ho + oy) * Wo + ox) * C + c];
+    }
+    dx[i] = g;
+}
+
+// y[..., c] = (x[..., c] - shift[c]) * inv_scale[c] for c < Cv, 0 for the padding channels; backward: dx = dy * inv_scale
+__global__ void channel_affine_kernel(const float *__restrict__ x, int ldx, float *__restrict__ y, int ldy, int64_t rows, int Cv,
+                                      f32x4 shift, f32x4 inv_scale) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * ldy) return;
+    const int64_t r = i / ldy;
+    const int c = (int)(i - r * ldy);
+    y[i] = c < Cv ? (x[r * ldx + c] - shift[c]) * inv_scale[c] : 0.f;
+}
+
+// one thread per pixel: partial[workgroup] = sum over its pixels of sum_c w_c (a_c - b_c)^2
+__global__ __launch_bounds__(256) void lpips_level_fwd_kernel(const float *__restrict__ f0, const float *__restrict__ f1,
+                                                              const float *__restrict__ w, double *__restrict__ partial, int HW, int C,
+                                                              float eps) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    double v = 0.0;
+    if (p < HW) {
+        const float *a = f0 + ((int64_t)b * HW + p) * C, *q = f1 + ((int64_t)b * HW + p) * C;
+        float s0 = 0.f, s1 = 0.f;
+        for (int c = 0; c < C; ++c) {
+            s0 += a[c] * a[c];
+            s1 += q[c] * q[c];
+        }
+        const float i0 = 1.0f / (sqrtf(s0) + eps), i1 = 1.0f / (sqrtf(s1) + eps);
+        float acc = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float d = a[c] * i0 - q[c] * i1;
+            acc += w[c] * d * d;
+        }
+        v = (double)acc;
+    }
+    __shared__ double sh[256];
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[(int64_t)b * gridDim.x + blockIdx.x] = sh[0];
+}
+
+// d val_b / d f0 * gscale: with n = |f0|, a = f0 / (n + eps), u_c = 2 w_c (a_c - b_c):
+//   df0_k = gscale / HW * (u_k / (n + eps) - f0_k (sum_c u_c f0_c) / (n (n + eps)^2))
+__global__ __launch_bounds__(256) void lpips_level_bwd_kernel(const float *__restrict__ f0, const float *__restrict__ f1,
+                                                              const float *__restrict__ w, float *__restrict__ df0, int HW, int C,
+                                                              float eps, float gscale) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const float *a = f0 + ((int64_t)b * HW + p) * C, *q = f1 + ((int64_t)b * HW + p) * C;
+    float *o = df0 + ((int64_t)b * HW + p) * C;
+    float s0 = 0.f, s1 = 0.f;
+    for (int c = 0; c < C; ++c) {
+        s0 += a[c] * a[c];
+        s1 += q[c] * q[c];
+    }
+    const float n0 = sqrtf(s0), i0 = 1.0f / (n0 + eps), i1 = 1.0f / (sqrtf(s1) + eps);
+    float dot = 0.f;
+    for (int c = 0; c < C; ++c) dot += 2.0f * w[c] * (a[c] * i0 - q[c] * i1) * a[c];
+    const float k2 = n0 > 0.f ? dot * i0 * i0 / n0 : 0.f;
+    const float g = gscale / (float)HW;
+    for (int c = 0; c < C; ++c) o[c] = g * (2.0f * w[c] * (a[c] * i0 - q[c] * i1) * i0 - a[c] * k2);
+}
+
 ConvGeo geo_of(const sgam_conv_desc *d, int cin_pad) {
     ConvGeo g;
     g.B = d->B; g.Hi = d->Hi; g.Wi = d->Wi; g.Cin = d->Cin; g.Cin_pad = cin_pad; g.Ho = d->Ho; g.Wo = d->Wo; g.KH = d->KH; g.KW = d->KW;
@@ -602,5 +699,50 @@ extern "C" int sgam_sumsq_partial_f32(const float *a, double *partial, int64_t n
     if (!a || !partial || n <= 0) return SGAM_EINVAL;
     SGAM_KLAUNCH(sumsq_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sgam_stream(stream), a, partial, n);
     SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+// ---- LPIPS (modules/losses/lpips.py) ----
+extern "C" int sgam_maxpool2x2_f32(const float *x, float *y, int32_t B, int32_t H, int32_t W, int32_t C, void *stream) {
+    if (!x || !y || B <= 0 || H < 2 || W < 2 || C <= 0) return SGAM_EINVAL;
+    const int64_t total = (int64_t)B * (H / 2) * (W / 2) * C;
+    SGAM_KLAUNCH(maxpool2x2_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, sgam_stream(stream), x, y, B, H, W, C);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+extern "C" int sgam_maxpool2x2_bwd_f32(const float *x, const float *dy, float *dx, int32_t B, int32_t H, int32_t W, int32_t C, void *stream) {
+    if (!x || !dy || !dx || B <= 0 || H < 2 || W < 2 || C <= 0) return SGAM_EINVAL;
+    const int64_t total = (int64_t)B * H * W * C;
+    SGAM_KLAUNCH(maxpool2x2_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, sgam_stream(stream), x, dy, dx, B, H, W, C);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+// y[rows][ldy] = (x[rows][ldx][:n] - shift) * inv_scale on the first n <= 4 channels, 0 on the rest (ScalingLayer; with shift 0
+// also its backward)
+extern "C" int sgam_channel_affine_f32(const float *x, int32_t ldx, float *y, int32_t ldy, int64_t rows, int32_t n, const float *shift4,
+                                       const float *inv_scale4, void *stream) {
+    if (!x || !y || rows <= 0 || n <= 0 || n > 4 || ldx < n || ldy < n || !shift4 || !inv_scale4) return SGAM_EINVAL;
+    const f32x4 sh = {shift4[0], shift4[1], shift4[2], shift4[3]}, is = {inv_scale4[0], inv_scale4[1], inv_scale4[2], inv_scale4[3]};
+    const int64_t total = rows * ldy;
+    SGAM_KLAUNCH(channel_affine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, sgam_stream(stream), x, ldx, y, ldy, rows, n, sh,
+                 is);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+// one feature level: partial [B][ceil(HW / 256)] doubles (val_b = sum of row b / HW); df0 (optional) = gscale * d val_b / d f0
+extern "C" int sgam_lpips_level_f32(const float *f0, const float *f1, const float *lin_w, double *partial, float *df0, int32_t B, int32_t HW,
+                                    int32_t C, float eps, float grad_scale, void *stream) {
+    if (!f0 || !f1 || !lin_w || !partial || B <= 0 || HW <= 0 || C <= 0) return SGAM_EINVAL;
+    const dim3 grid(sgam_cdiv(HW, 256), B);
+    hipStream_t s = sgam_stream(stream);
+    SGAM_KLAUNCH(lpips_level_fwd_kernel, grid, dim3(256), 0, s, f0, f1, lin_w, partial, HW, C, eps);
+    SGAM_LAUNCH_CHECK();
+    if (df0) {
+        SGAM_KLAUNCH(lpips_level_bwd_kernel, grid, dim3(256), 0, s, f0, f1, lin_w, df0, HW, C, eps, grad_scale);
+        SGAM_LAUNCH_CHECK();
+    }
     return SGAM_OK;
 }

@@ -1,9 +1,11 @@
 """Hyper-parameter / parameter container of the reference's VQLPIPSWithDiscriminator
 (sgam/generative_sensing_module/modules/losses/vqperceptual.py:34-137), consumed by sgam_neurips22_amd.training.VQGANTrainer.
-LPIPS is NOT built (it needs torchvision's pretrained VGG16, absent offline): perceptual_weight must be 0."""
+`perceptual_loss` is the LPIPS container (modules/losses/lpips.py): its VGG16 trunk needs torchvision's ImageNet checkpoint, which
+cannot be fetched here — load one before training with perceptual_weight > 0."""
 import torch.nn as nn
 
 from ..discriminator.model import NLayerDiscriminator, weights_init
+from .lpips import LPIPS
 
 
 class VQLPIPSWithDiscriminator(nn.Module):
@@ -17,6 +19,7 @@ class VQLPIPSWithDiscriminator(nn.Module):
             raise NotImplementedError("disc_conditional")
         self.codebook_weight, self.pixel_weight, self.perceptual_weight = codebook_weight, pixelloss_weight, perceptual_weight
         self.use_discriminative_loss = use_discriminative_loss
+        self.perceptual_loss = LPIPS().eval()
         self.discriminator = NLayerDiscriminator(input_nc=disc_in_channels, n_layers=disc_num_layers, use_actnorm=use_actnorm,
                                                  ndf=disc_ndf, kernel_width=kernel_width).apply(weights_init)
         self.discriminator_iter_start = disc_start

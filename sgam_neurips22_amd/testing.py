@@ -259,3 +259,21 @@ def synthetic_disc_state_dict(reference_state_dict, seed=0):
             t = 0.05 * torch.randn(tuple(ref.shape), generator=g)
         out[name] = t
     return out
+
+
+def synthetic_vgg_state_dict(lpips_state_dict, seed=0):
+    """He-style deterministic weights for the VGG16 trunk of an LPIPS state_dict (keys net.slice<k>.<i>.weight / .bias) — a stand-in
+    for torchvision's ImageNet checkpoint, which cannot be fetched offline; every other key is passed through unchanged"""
+    out = {}
+    for name in sorted(lpips_state_dict.keys()):
+        ref = lpips_state_dict[name]
+        if not name.startswith("net."):
+            out[name] = ref.clone()
+            continue
+        g = torch.Generator().manual_seed((zlib.crc32(("vgg." + name).encode()) + 7919 * seed) % (2 ** 31))
+        if ref.dim() == 4:
+            fan_in = ref.shape[1] * ref.shape[2] * ref.shape[3]
+            out[name] = torch.randn(tuple(ref.shape), generator=g) * (2.0 / fan_in) ** 0.5
+        else:
+            out[name] = 0.05 * torch.randn(tuple(ref.shape), generator=g)
+    return out

@@ -1,9 +1,9 @@
-"""The reference's training step on the HIP kernels (LPIPS not built).
+"""The reference's training step on the HIP kernels.
 
 What the reference does per batch (sgam/generative_sensing_module/model.py:271-345): forward of the conditional VQGAN,
 `VQLPIPSWithDiscriminator.forward(qloss, x_dst, xrec, optimizer_idx=0, global_step, ...)`
 (modules/losses/vqperceptual.py:77-110), `opt_ae.zero_grad(); aeloss.backward(); opt_ae.step()`, then the same with
-`optimizer_idx=1` for the PatchGAN discriminator.  Built here, at `perceptual_weight = 0`:
+`optimizer_idx=1` for the PatchGAN discriminator.  Built here:
 
   `AutoencoderTrainer`   loss = mean|x_dst - xrec| + codebook_weight * qloss   (what the reference's loss reduces to before
                           `disc_start`), Adam(lr, betas=(0.5, 0.9)) over the phase's parameter set (model.py:414-428:
@@ -13,9 +13,13 @@ What the reference does per batch (sgam/generative_sensing_module/model.py:271-3
                           discriminator update with the hinge loss on D(x_dst), D(xrec.detach()) and its own Adam; the three
                           discriminator forwards per step update its BatchNorm running statistics like the reference's
 
-NOT built: LPIPS (torchvision's pretrained VGG16 is not available offline, so neither the reference's perceptual term nor a
-fixture for it can be produced here).  The online k-means codebook refresh (model.py:274-295, 313-323) is host logic in the
-reference and here (`OnlineCodebookRefresh`, scipy's kmeans2).
+  LPIPS (`_Lpips`)        rec_loss = |x - xrec| + perceptual_weight * LPIPS(x[:, :3], xrec[:, :3]) (vqperceptual.py:79-84): the
+                          ScalingLayer, the frozen VGG16 trunk on both images, per level normalise / squared difference / `lin` /
+                          spatial mean, and the backward pass to the reconstruction.  The trunk's ImageNet checkpoint is
+                          torchvision's and cannot be fetched here: tests run on synthetic trunk weights (the `lin` weights are the
+                          reference's shipped ones), so what is pinned is the computation, not the metric's pretrained values.
+  `OnlineCodebookRefresh` the online k-means refresh of dead codewords (model.py:274-295, 313-323): host logic with scipy's
+                          kmeans2 in the reference and here.
 
 Arithmetic: every product (forward convolutions, data / weight gradients, attention) runs on the MFMA GEMM of csrc/conv_gemm.hip
 in its fp32-in mode (`ops.set_f32_mode("mfma")` for the duration of a step: gradients sit far below fp16's normal range, so the
@@ -484,10 +488,91 @@ class OnlineCodebookRefresh:
             self.countdown[k] -= 1
 
 
+class _MaxPool:
+    def fwd(self, x):
+        self.x = x
+        B, H, W, C = x.shape
+        y = torch.empty((B, H // 2, W // 2, C), device=x.device, dtype=torch.float32)
+        check(_lib.load().sgam_maxpool2x2_f32(_p(x), _p(y), B, H, W, C, _stream()), "sgam_maxpool2x2_f32")
+        return y
+
+    def bwd(self, dy):
+        x = self.x
+        B, H, W, C = x.shape
+        dx = torch.empty_like(x)
+        check(_lib.load().sgam_maxpool2x2_bwd_f32(_p(x), _p(dy), _p(dx), B, H, W, C, _stream()), "sgam_maxpool2x2_bwd_f32")
+        return dx
+
+
+class _Lpips:
+    """LPIPS(input, target) of the reference (modules/losses/lpips.py:41-55) and its gradient w.r.t. `input`: ScalingLayer ->
+    VGG16 trunk (frozen; 13 convs + ReLU, 4 max-pools) on both images -> per level: unit-normalise over channels, squared
+    difference, 1x1 `lin`, spatial mean -> sum over the five levels.  Eval mode (the `lin` dropouts are identities)."""
+
+    def __init__(self, lp):
+        self.lp = lp
+        self.shift = (ctypes.c_float * 4)(*[float(v) for v in lp.scaling_layer.shift.reshape(-1)], 0.0)
+        self.zero = (ctypes.c_float * 4)(0.0, 0.0, 0.0, 0.0)
+        self.inv_scale = (ctypes.c_float * 4)(*[1.0 / float(v) for v in lp.scaling_layer.scale.reshape(-1)], 0.0)
+
+    def _trunk(self):
+        """fresh tape: [(layers of slice k)] for k = 0..4"""
+        out = []
+        for k in range(5):
+            ls = []
+            for mod in getattr(self.lp.net, f"slice{k + 1}"):
+                if isinstance(mod, torch.nn.MaxPool2d):
+                    ls.append(_MaxPool())
+                elif isinstance(mod, torch.nn.ReLU):
+                    ls.append(_BNLReLU(None, {}, slope=0.0))
+                else:
+                    ls.append(_Conv(mod, {}, need_wgrad=False))
+            out.append(_Seq(ls))
+        return out
+
+    def _scaled(self, x_nhwc):
+        B, H, W, ld = x_nhwc.shape
+        y = torch.empty((B, H, W, 32), device=x_nhwc.device, dtype=torch.float32)
+        check(_lib.load().sgam_channel_affine_f32(_p(x_nhwc), ld, _p(y), 32, B * H * W, 3, self.shift, self.inv_scale, _stream()),
+              "sgam_channel_affine_f32")
+        return y
+
+    def loss_and_grad(self, rec_nhwc, target_nhwc, grad_scale):
+        """rec / target (B,H,W,>=3) NHWC (RGB first) -> (values per image [B] host floats, grad_scale * d sum_b val_b / d rec
+        as (B,H,W,32) with the RGB channels filled)"""
+        lib = _lib.load()
+        B, H, W, _ = rec_nhwc.shape
+        t0, t1 = self._trunk(), self._trunk()
+        f0, f1 = self._scaled(rec_nhwc), self._scaled(target_nhwc)
+        vals = [0.0] * B
+        dfeat = []
+        for k in range(5):
+            f0, f1 = t0[k].fwd(f0), t1[k].fwd(f1)
+            Bk, Hk, Wk, Ck = f0.shape
+            nblk = (Hk * Wk + 255) // 256
+            part = torch.empty((Bk, nblk), device=f0.device, dtype=torch.float64)
+            df = torch.empty_like(f0)
+            check(lib.sgam_lpips_level_f32(_p(f0), _p(f1), _p(self.lp.lin_weight(k)), _p(part), _p(df), Bk, Hk * Wk, Ck, 1e-10,
+                                           float(grad_scale), _stream()), "sgam_lpips_level_f32")
+            ph = part.cpu().numpy().sum(axis=1) / (Hk * Wk)
+            vals = [v + float(a) for v, a in zip(vals, ph)]
+            dfeat.append(df)
+        # backward through the trunk of the reconstruction: the five level gradients enter at their depths
+        g = dfeat[4]
+        for k in (4, 3, 2, 1, 0):
+            g = t0[k].bwd(g)
+            if k > 0:
+                g = _axpby(g, dfeat[k - 1])
+        dx = torch.empty((B, H, W, 32), device=g.device, dtype=torch.float32)
+        check(lib.sgam_channel_affine_f32(_p(g), g.shape[3], _p(dx), 32, B * H * W, 3, self.zero, self.inv_scale, _stream()),
+              "sgam_channel_affine_f32")
+        return vals, dx
+
+
 class _BNLReLU:
     """[BatchNorm2d in training mode ->] LeakyReLU(0.2) of the PatchGAN (discriminator/model.py:40-60)"""
 
-    def __init__(self, bn, grads, slope=0.2):
+    def __init__(self, bn, grads, slope=0.2):            # slope 0: plain ReLU (the VGG16 trunk of LPIPS)
         self.bn, self.grads, self.slope = bn, grads, slope
 
     def fwd(self, x):
@@ -582,10 +667,9 @@ class VQGANTrainer(AutoencoderTrainer):
     (hinge loss, its own Adam).  `loss_cfg` = a modules.losses.vqperceptual.VQLPIPSWithDiscriminator container."""
 
     def __init__(self, model, loss_cfg, phase=None, lr=None, process_group=None):
-        if loss_cfg.perceptual_weight != 0:
-            raise NotImplementedError("LPIPS is not built (needs torchvision's pretrained VGG16): perceptual_weight must be 0")
         super().__init__(model, phase=phase, lr=lr, codebook_weight=loss_cfg.codebook_weight, process_group=process_group)
         self.cfg, self.disc = loss_cfg, loss_cfg.discriminator
+        self.lpips = _Lpips(loss_cfg.perceptual_loss) if loss_cfg.perceptual_weight > 0 else None
         self.dgrads, self.dstate = {}, {}
 
     def _disc_factor(self):
@@ -611,6 +695,15 @@ class VQGANTrainer(AutoencoderTrainer):
             # ---- optimizer_idx 0 (vqperceptual.py:77-110)
             fw = self._forward(x, x_dst, extrapolation_mask)
             rec, drec_nll = fw["rec"], fw["drec"]
+            p_loss = 0.0
+            if self.lpips is not None:
+                # rec_loss = |x - xrec| + perceptual_weight * p_loss (p_loss (B,1,1,1) broadcast), nll = its mean (:79-89):
+                # every image's LPIPS value enters the mean with weight 1 / B
+                B = rec.shape[0]
+                vals, dp = self.lpips.loss_and_grad(rec, ops.nchw_to_nhwc(x_dst), cfg.perceptual_weight / B)
+                p_loss = sum(vals) / B
+                fw["nll"] += cfg.perceptual_weight * p_loss
+                drec_nll = _axpby(drec_nll, dp)
             tape_g = _DiscTape(self.disc, {})
             logits_fake = tape_g.fwd(_pad_channels(rec, 32))
             n_log = logits_fake.numel()
@@ -645,7 +738,7 @@ class VQGANTrainer(AutoencoderTrainer):
         self._adam(list(self.disc.parameters()), self.dgrads, self.dstate)       # opt_disc.step()
         _invalidate_packs(self.disc)
         ae = fw["nll"] + d_weight * disc_factor * g_loss + self.codebook_weight * fw["qloss"]
-        log = {"train/total_loss": ae, "train/quant_loss": fw["qloss"], "train/rec_loss": fw["nll"], "train/d_weight": d_weight,
+        log = {"train/total_loss": ae, "train/quant_loss": fw["qloss"], "train/rec_loss": fw["nll"], "train/p_loss": p_loss, "train/d_weight": d_weight,
                "train/disc_factor": disc_factor, "train/g_loss": g_loss, "train/disc_loss": d_loss,
                "train/logits_real": self._mean_logit(logits_real), "train/logits_fake": self._mean_logit(logits_fake2)}
         return ae, log

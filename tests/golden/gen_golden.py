@@ -399,6 +399,60 @@ def gen_train_gan():
          **{"bn." + k: v for k, v in dsd.items() if "running" in k or "num_batches" in k})
 
 
+def gen_lpips():
+    """the REFERENCE's LPIPS class (modules/losses/lpips.py) on 64 x 64 images, with its shipped `lin` weights, over a stand-in for
+    `torchvision.models.vgg16`: torchvision is not installed and its ImageNet checkpoint cannot be fetched, so the trunk has the
+    standard configuration "D" with SYNTHETIC weights (testing.synthetic_vgg_state_dict).  What this pins is the reference's
+    slicing, scaling, normalisation, `lin` weighting and averaging — not the metric's pretrained values."""
+    import importlib
+    import types
+    import torch.nn as nn
+    print("LPIPS (reference class, stand-in VGG16 trunk)")
+
+    def vgg16(pretrained=False, **kw):
+        layers, cin = [], 3
+        for v in [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"]:
+            if v == "M":
+                layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+            else:
+                layers += [nn.Conv2d(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+                cin = v
+        m = nn.Module()
+        m.features = nn.Sequential(*layers)
+        return m
+
+    tv, tvm = types.ModuleType("torchvision"), types.ModuleType("torchvision.models")
+    tvm.vgg16 = vgg16
+    tv.models = tvm
+    sys.modules["torchvision"], sys.modules["torchvision.models"] = tv, tvm
+    for m in ("requests", "tqdm"):
+        if m not in sys.modules:
+            try:
+                importlib.import_module(m)
+            except Exception:
+                sys.modules[m] = types.ModuleType(m)
+    name = "sgam.generative_sensing_module.modules.losses.lpips"
+    stub = sys.modules.pop(name, None)
+    cwd = os.getcwd()
+    os.chdir(R.REF)                              # load_from_pretrained resolves the shipped lin weights relative to the cwd
+    try:
+        ref_lpips = importlib.import_module(name)
+        torch.manual_seed(0)
+        lp = ref_lpips.LPIPS().eval()
+    finally:
+        os.chdir(cwd)
+        if stub is not None:
+            sys.modules[name] = stub
+    sd = testing.synthetic_vgg_state_dict(lp.state_dict(), seed=4)
+    lp.load_state_dict(sd)
+    a = testing.seeded_tensor("lpips.a", (2, 3, 64, 64), scale=0.5).clamp(-1, 1).requires_grad_(True)
+    b = testing.seeded_tensor("lpips.b", (2, 3, 64, 64), scale=0.5).clamp(-1, 1)
+    val = lp(a, b)
+    val.sum().backward()
+    save("lpips_small.npz", value=val.detach().reshape(-1), grad_input=a.grad,
+         **{"lin." + k: v for k, v in sd.items() if k.startswith("lin")})
+
+
 def gen_trajectory_clevr():
     """CLEVR-Infinite loop, 3 steps on a 2x2 grid: 16384 codes, num_src 5, the seed depth's ray->z conversion applied at
     construction (:71-79) AND again at every load (:582-590), both in float64."""
@@ -449,3 +503,5 @@ if __name__ == "__main__":
     if not only or "train" in only:
         gen_train()
         gen_train_gan()
+    if not only or "lpips" in only:
+        gen_lpips()

@@ -361,3 +361,60 @@ def test_discriminator_is_idle_before_disc_start(golden):
     for n, q in cfg.discriminator.named_parameters():
         assert torch.equal(q.detach(), dbefore[n]), n
     assert int(cfg.discriminator.main[3].num_batches_tracked) == 3
+
+
+def test_lpips_value_and_gradient(golden):
+    """the LPIPS path of training.py (ScalingLayer, VGG16 trunk, max-pools, per-level normalise / lin / mean, and the backward
+    pass to the input) against the reference class's own output (lpips_small.npz) and the oracle; stand-in trunk weights"""
+    from test_oracle_golden import lpips_state_dict
+    from sgam_neurips22_amd.generative_sensing_module.modules.losses.lpips import LPIPS
+    g = golden("lpips_small.npz")
+    lp = LPIPS()
+    lp.load_state_dict(lpips_state_dict(golden))
+    lp = lp.to(DEV).eval()
+    a = testing.seeded_tensor("lpips.a", (2, 3, 64, 64), scale=0.5).clamp(-1, 1)
+    b = testing.seeded_tensor("lpips.b", (2, 3, 64, 64), scale=0.5).clamp(-1, 1)
+    with training._mfma_mode():
+        vals, dx = training._Lpips(lp).loss_and_grad(_nhwc(a).to(DEV), _nhwc(b).to(DEV), 1.0)
+    assert np.allclose(np.array(vals), g["value"], rtol=1e-4)
+    assert _rel(dx[..., :3].permute(0, 3, 1, 2), torch.from_numpy(g["grad_input"])) <= 1e-3
+    assert dx[..., 3:].abs().max().item() == 0
+
+
+def test_full_training_step_with_lpips_and_discriminator(golden):
+    """the shipped loss configuration (perceptual_weight 1, discriminator on) on the small model: loss terms, d_weight and every
+    gradient against the oracles (oracle/vqgan.py + lpips.py + patchgan.py under autograd)"""
+    from test_oracle_golden import lpips_state_dict, oracle_gan_step
+    from sgam_neurips22_amd.generative_sensing_module.modules.losses.vqperceptual import VQLPIPSWithDiscriminator
+    g0 = golden("train_step_small.npz")
+    p = small_params()
+    p["phase"] = "codebook"
+    m = VQModel(**p)
+    sd = small_state_dict(m, g0)
+    m.load_state_dict(sd)
+    cfg = VQLPIPSWithDiscriminator(disc_start=0, perceptual_weight=1.0, disc_in_channels=4, disc_weight=0.8, use_discriminative_loss=True)
+    dsd = testing.synthetic_disc_state_dict(cfg.discriminator.state_dict(), seed=2)
+    cfg.discriminator.load_state_dict(dsd)
+    lsd = lpips_state_dict(golden)
+    cfg.perceptual_loss.load_state_dict(lsd)
+    x, mask, x_dst = testing.train_batch()
+    names = [n for n, _ in m.named_parameters()]
+    r = oracle_gan_step(sd, {k: v.clone() for k, v in dsd.items()}, p["ddconfig"], x, mask, x_dst, train_names=names, lpips_sd=lsd,
+                        perceptual_weight=1.0)
+    m, cfg = m.to(DEV), cfg.to(DEV).train()
+    cfg.perceptual_loss.eval()
+    tr = training.VQGANTrainer(m, cfg, phase="codebook", lr=1e-4)
+    loss, log = tr.step(x.to(DEV), x_dst.to(DEV), mask.to(DEV))
+    for k, want in (("train/total_loss", "loss"), ("train/d_weight", "d_weight"), ("train/g_loss", "g_loss"), ("train/rec_loss", "nll"),
+                    ("train/p_loss", "p_loss"), ("train/quant_loss", "qloss"), ("train/disc_loss", "d_loss")):
+        assert abs(log[k] - r[want]) <= 2e-4 * max(abs(r[want]), 1e-3), (k, log[k], r[want])
+    worst = 0.0
+    for n, q in m.named_parameters():
+        if n.endswith(".k.bias"):
+            continue
+        e = _rel(tr.grads[q], r["ae_grads"][n])
+        worst = max(worst, e)
+        assert e <= 3e-3, (n, e)
+    for n, q in cfg.discriminator.named_parameters():
+        assert _rel(tr.dgrads[q], r["d_grads"][n]) <= 3e-3, n
+    print(f"[lpips + gan] worst relative autoencoder gradient error {worst:.2e}, p_loss {log['train/p_loss']:.5f}, d_weight {log['train/d_weight']:.5f}")

@@ -195,7 +195,36 @@ def test_training_step_autograd_matches_the_reference(golden):
         assert abs(float(ref[n].grad.double().norm()) - want) <= 1e-4 * want + 1e-12, n
 
 
-def oracle_gan_step(sd, dsd, dd, x, mask, x_dst, disc_weight=0.8, disc_factor=1.0, train_names=None):
+def lpips_state_dict(golden):
+    """LPIPS state for the tests: synthetic VGG16 trunk (the ImageNet checkpoint cannot be fetched), the reference's shipped `lin`
+    weights (carried by the fixture), the ScalingLayer constants"""
+    from sgam_neurips22_amd import testing
+    from sgam_neurips22_amd.generative_sensing_module.modules.losses.lpips import LPIPS
+    g = golden("lpips_small.npz")
+    sd = testing.synthetic_vgg_state_dict(LPIPS().state_dict(), seed=4)
+    for k in g.files:
+        if k.startswith("lin."):
+            sd[k[4:]] = torch.from_numpy(g[k])
+    return sd
+
+
+def test_lpips_oracle_matches_the_reference_class(golden):
+    """oracle/lpips.py against the reference's own LPIPS class (value per image and gradient w.r.t. the input) on the fixture's
+    stand-in trunk — see tests/golden/gen_golden.py gen_lpips for what that does and does not pin"""
+    from oracle import lpips as OL
+    from sgam_neurips22_amd import testing
+    g = golden("lpips_small.npz")
+    sd = lpips_state_dict(golden)
+    a = testing.seeded_tensor("lpips.a", (2, 3, 64, 64), scale=0.5).clamp(-1, 1).requires_grad_(True)
+    b = testing.seeded_tensor("lpips.b", (2, 3, 64, 64), scale=0.5).clamp(-1, 1)
+    val = OL.lpips(sd, a, b)
+    val.sum().backward()
+    assert np.allclose(val.detach().reshape(-1).numpy(), g["value"], rtol=2e-5)
+    assert (a.grad - torch.from_numpy(g["grad_input"])).abs().max().item() <= 2e-5 * float(np.abs(g["grad_input"]).max())
+
+
+def oracle_gan_step(sd, dsd, dd, x, mask, x_dst, disc_weight=0.8, disc_factor=1.0, train_names=None, lpips_sd=None,
+                    perceptual_weight=0.0):
     """the whole training_step after disc_start (perceptual_weight 0) through the oracles: returns the loss terms, the autoencoder
     gradients, the discriminator gradients; `dsd` (discriminator state) has its BatchNorm running statistics updated in place by
     the three discriminator forwards, like the reference"""
@@ -207,7 +236,14 @@ def oracle_gan_step(sd, dsd, dd, x, mask, x_dst, disc_weight=0.8, disc_factor=1.
     pre = OV.encode_features(ref, dd, x, mask.float())
     quant, idx, _, qloss = OV.quantize(ref, pre)
     dec = OV.decode(ref, dd, quant)
-    nll = (x_dst - dec).abs().mean()
+    rec_loss = (x_dst - dec).abs()
+    p_loss = torch.zeros(())
+    if perceptual_weight > 0:
+        from oracle import lpips as OL
+        p = OL.lpips(lpips_sd, x_dst[:, :3], dec[:, :3])          # vqperceptual.py:80-82
+        rec_loss = rec_loss + perceptual_weight * p
+        p_loss = p.mean()
+    nll = rec_loss.mean()
     logits_fake = OP.discriminator(dref, dec)
     g_loss = -logits_fake.mean()
     last = ref["decoder.conv_out.weight"]
@@ -224,7 +260,8 @@ def oracle_gan_step(sd, dsd, dd, x, mask, x_dst, disc_weight=0.8, disc_factor=1.
     for k, v in dref.items():           # hand the updated running statistics back
         if "running" in k or "num_batches" in k:
             dsd[k] = v
-    return {"loss": float(loss), "nll": float(nll), "qloss": float(qloss), "g_loss": float(g_loss), "d_weight": float(d_weight),
+    return {"loss": float(loss), "nll": float(nll), "p_loss": float(p_loss), "qloss": float(qloss), "g_loss": float(g_loss),
+            "d_weight": float(d_weight),
             "d_loss": float(d_loss), "logits_real": float(logits_real.mean()), "logits_fake": float(logits_fake2.mean()),
             "ae_grads": dict(zip(names, ae_grads)), "d_grads": dict(zip(dnames, d_grads)), "dec": dec.detach(), "idx": idx}
 
