@@ -385,15 +385,15 @@ def main():
         lcfg.perceptual_loss.load_state_dict({k: v.to(dev) for k, v in testing.synthetic_vgg_state_dict(
             lcfg.perceptual_loss.state_dict(), seed=4).items()})        # (the ImageNet trunk cannot be fetched: synthetic)
         tr = training.VQGANTrainer(mt, lcfg, phase="conditional_generation", lr=4.5e-6)
-        l0 = tr.step(xt, xd, mk)[0]
+        l0 = tr.step(xt, xd, mk)[1]["train/rec_loss"]
         torch.cuda.synchronize()
         tt = time.perf_counter()
         for _ in range(3):
-            l1 = tr.step(xt, xd, mk)[0]
+            l1 = tr.step(xt, xd, mk)[1]["train/rec_loss"]
         torch.cuda.synchronize()
         dt_ = (time.perf_counter() - tt) / 3
         train_leg = {"ms_per_update": round(1e3 * dt_, 1), "updates_per_s": round(1 / dt_, 2), "batch": 1,
-                     "loss_first": round(float(l0), 6), "loss_after_4": round(float(l1), 6),
+                     "rec_loss_first": round(float(l0), 6), "rec_loss_after_4": round(float(l1), 6),
                      "note": "f4: autoencoder (encoder parameter set) + PatchGAN discriminator updates of training_step past disc_start, "
                              "LPIPS on (synthetic VGG16 trunk); fp32-in MFMA GEMMs + csrc/train.hip; untuned"}
         del mt, tr
