@@ -418,7 +418,7 @@ int sgam_tsdf_raycast_depth_f32(const sgam_tsdf_grid *grid, int32_t H, int32_t W
                                 void *stream);
 
 /* ------------------------------------------------------------------------------------------
- * f4 (partial) — backward / optimiser kernels of the VQGAN autoencoder update: VQModel.training_step
+ * f4 — backward / optimiser kernels of the training step: VQModel.training_step
  * (sgam/generative_sensing_module/model.py:271-345) with VQLPIPSWithDiscriminator.forward(optimizer_idx = 0)
  * (modules/losses/vqperceptual.py:77-110) at perceptual_weight = 0 and global_step < disc_start, i.e.
  * loss = mean|x - xrec| + codebook_weight * qloss, torch.optim.Adam(betas = (0.5, 0.9)) (model.py:414-428).
@@ -428,7 +428,7 @@ int sgam_tsdf_raycast_depth_f32(const sgam_tsdf_grid *grid, int32_t H, int32_t W
  *                    (rows ld_m >= M apart: M is rounded up to the GEMM's K granule with a zero tail)
  * for every convolution of the model through ONE pair of index kernels driven by the forward's descriptor (3x3 / 1x1,
  * stride 1, Downsample's stride 2 with (0,1,0,1) padding, Upsample's nearest-2x folded into the conv); k = tap * cin_pad
- * + channel as in sgam_pack_conv_weight.  LPIPS, the PatchGAN and its optimiser are not built.
+ * + channel as in sgam_pack_conv_weight.  The PatchGAN and LPIPS pieces follow below.
  * ------------------------------------------------------------------------------------------ */
 int sgam_im2col_t_f32(const sgam_conv_desc *d, const float *x, float *col_t, int32_t cin_pad, int64_t ld_m, void *stream);
 int sgam_col2im_gather_f32(const sgam_conv_desc *d, const float *dcol, float *dx, int32_t cin_pad, void *stream);

@@ -1,17 +1,17 @@
-// train.hip — backward / optimiser kernels of the VQGAN autoencoder update (partial: the
-// pre-discriminator phase of the reference's training_step, sgam/generative_sensing_module/model.py:271-345 with
-// modules/losses/vqperceptual.py:77-110 at perceptual_weight = 0, global_step < disc_start).  gfx950 only.
+// train.hip — backward / optimiser kernels of the reference's training step: VQModel.training_step,
+// sgam/generative_sensing_module/model.py:271-345, with VQLPIPSWithDiscriminator (modules/losses/vqperceptual.py:34-137),
+// the PatchGAN discriminator (modules/discriminator/model.py) and LPIPS (modules/losses/lpips.py).  gfx950 only.
 //
 // Every product of the backward pass is a GEMM on the existing MFMA kernels (fp32-in MFMA mode: gradients are far below
 // fp16's normal range, so the split-fp32 trick of the inference path does not apply):
 //   data gradient    dcol[M][taps*Cin] = dy[M][Cout] . W[Cout][taps*Cin]          then col2im_gather (below)
 //   weight gradient  dW[Cout][taps*Cin] = dy^T[Cout][M] . col^T[taps*Cin][M]^T     with col^T from im2col_t (below)
-// which makes one pair of index kernels serve every convolution of the model: 3x3 / 1x1, stride 1, stride 2 with the
-// (0,1,0,1) padding of Downsample (model.py:62-75) and the nearest-2x upsampling folded into Upsample.conv (:43-53).
-// This file holds those index kernels and the element-wise / reduction kernels around the GEMMs: GroupNorm(+swish)
-// backward, soft-max backward, the L1 reconstruction loss and its gradient, the quantiser's straight-through +
-// commitment gradient, bias gradients, Adam.  Not on the inference hot path; written for correctness and coalesced
-// access, not tuned.
+// which makes one pair of index kernels serve every convolution: 3x3 / 1x1 / 4x4, stride 1 / 2, the (0,1,0,1) padding of
+// Downsample (model.py:62-75) and the nearest-2x upsampling folded into Upsample.conv (:43-53).  This file holds those index
+// kernels and the element-wise / reduction kernels around the GEMMs: GroupNorm(+swish) and BatchNorm(+LeakyReLU) backward,
+// soft-max backward, max-pool, the LPIPS feature-level kernel, the L1 reconstruction loss and the hinge terms with their
+// gradients, the quantiser's straight-through + commitment gradient, bias gradients, sums of squares, Adam.  Not on the
+// inference hot path; written for correctness, determinism (no atomics) and coalesced access, not tuned.
 #include "sgam_common.h"
 
 namespace {
