@@ -411,6 +411,7 @@ HPlan make_hplan(const sgam_conv_desc *d) {
     else if (d->N % 128 == 0 && blocks(64, 128) >= 224) { pl.bm = 64; pl.bn = 128; }
     else { pl.bm = 64; pl.bn = 64; }
     if (d->plan_bm > 0 && d->plan_bn > 0) { pl.bm = d->plan_bm; pl.bn = d->plan_bn; }   // autotuned override
+    if (pl.bm == 256) pl.bm = 128;            // (256 rows: a tile of the halo-staged kernel only, h16_halo.hip)
     const int64_t nb = blocks(pl.bm, pl.bn);
     int ks = 1;
     if (d->plan_ksplit > 0) {
@@ -437,8 +438,8 @@ int hvalidate(const sgam_conv_desc *d) {
     if (d->ldb < d->KH * d->KW * d->Cin || d->ldb % 8 != 0) return SGAM_EALIGN;
     if (d->n_valid <= 0 || d->n_valid > d->N || d->ldc < d->n_valid) return SGAM_EINVAL;
     if (d->plan_bm != 0 || d->plan_bn != 0) {
-        const bool ok = (d->plan_bm == 128 && d->plan_bn == 128) || (d->plan_bm == 64 && d->plan_bn == 128) ||
-                        (d->plan_bm == 64 && d->plan_bn == 64);
+        const bool ok = (d->plan_bm == 256 && d->plan_bn == 128) || (d->plan_bm == 128 && d->plan_bn == 128) ||
+                        (d->plan_bm == 64 && d->plan_bn == 128) || (d->plan_bm == 64 && d->plan_bn == 64);
         if (!ok || (d->plan_bn == 128 && d->N % 128 != 0)) return SGAM_EINVAL;
     }
     if (d->plan_ksplit < 0 || d->plan_ksplit > 64) return SGAM_EINVAL;

@@ -195,7 +195,11 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
             *reinterpret_cast<u32x4 *>(halo + h_lds[j]) = hreg[j];
     };
 
-    u32x4 bq[3][TN][2];                    // [tap % 3][n tile][k-step]
+    // weight-fragment ring: three sets, loaded two taps ahead (two workgroups per CU share the registers) — or, for the one-
+    // workgroup-per-CU 256-row tile, one set per tap, each refilled for the NEXT slab as soon as its tap is done (nine taps
+    // = 4 600 MFMA cycles ahead: an L2 round trip is ~0.7 us, two taps of this kernel are 0.2)
+    constexpr int NBR = BM == 256 ? 9 : 3;
+    u32x4 bq[NBR][TN][2];                  // [tap % NBR][n tile][k-step]
     auto bload = [&](const int set, int tap, int ch, bool live) {
         const unsigned koff = (unsigned)(tap * p.Cin + ch * XBK) * 64u;   // 2048 bytes per (row tile, slab); scalar offset
 #pragma unroll
@@ -230,8 +234,13 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
     const int s1 = min(p.slabs, s0 + p.slabs_per_split);
     int hcur = 0;
     hload(s0, true);
-    bload(0, 0, s0, true);
-    bload(1, 1, s0, true);
+    if constexpr (NBR == 9) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) bload(t, t, s0, true);
+    } else {
+        bload(0, 0, s0, true);
+        bload(1, 1, s0, true);
+    }
 #pragma unroll
     for (int j = 0; j < NH; ++j) hprep_piece(j);
     hstore(0);
@@ -279,8 +288,8 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
         }
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int set = tap % 3;
-            if constexpr (!(SGAM_HABLATE & 8)) {
+            const int set = tap % NBR;
+            if constexpr (!(SGAM_HABLATE & 8) && NBR == 3) {
                 if (tap < 7) bload((tap + 2) % 3, tap + 2, sl, true);
                 else bload((tap + 2) % 3, tap - 7, sl + 1, has_next);
             }
@@ -311,6 +320,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
                         else acc[i][j] = HH<HT>::mfma(fa[q & 1][i], bq[set][j][kk], acc[i][j]);
                     }
             }
+            if constexpr (!(SGAM_HABLATE & 8) && NBR == 9) bload(tap, tap, sl + 1, has_next);      // this tap's set, next slab
         }
         __syncthreads();
         hcur ^= 1;
@@ -656,7 +666,7 @@ __global__ void pack_weight_h16_frag_kernel(const float *w, unsigned short *o, i
 
 bool hh_shape(const sgam_conv_desc *d, int bm) {
     const int up = d->upsample2x ? 2 : 1;
-    const bool tile_ok = (bm == 128 && d->Wo % 16 == 0) || (bm == 64 && d->Wo % 8 == 0);
+    const bool tile_ok = (bm == 256 && d->Wo % 16 == 0 && d->Ho % 16 == 0) || (bm == 128 && d->Wo % 16 == 0) || (bm == 64 && d->Wo % 8 == 0);
     return tile_ok && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 && d->Ho == up * d->Hi &&
            d->Wo == up * d->Wi && d->Ho % 8 == 0 && d->Cin % 32 == 0 && d->N % 128 == 0 && d->lda % 8 == 0 && d->ldb % 32 == 0 &&
            d->ldb >= 9 * d->Cin && d->n_valid % 4 == 0 && d->ldc % 4 == 0 && d->ldr % 4 == 0 && d->bias_per_row == 0;
@@ -673,7 +683,8 @@ HHPlan hh_plan(const sgam_conv_desc *d) {
     if (!d || d->B <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->N <= 0 || d->Cin <= 0) return pl;
     const int64_t M = (int64_t)d->B * d->Ho * d->Wo;
     int bm = (M / 128) * (d->N / 128) >= 224 ? 128 : 64;
-    if (d->plan_bm == 128 || d->plan_bm == 64) bm = d->plan_bm;
+    if (d->plan_bm == 256 || d->plan_bm == 128 || d->plan_bm == 64) bm = d->plan_bm;
+    if (bm == 256 && !hh_shape(d, 256)) bm = 128;
     if (bm == 128 && !hh_shape(d, 128)) bm = 64;
     if (!hh_shape(d, bm)) return pl;
     const int slabs = d->Cin / 32;
@@ -781,7 +792,9 @@ extern "C" int sgam_conv2d_halo_nhwc_h16(const sgam_conv_desc *d, int32_t ht, co
         else if (gn) SGAM_KLAUNCH((conv3x3_h16_halo_kernel<BM_, 128, HT_, true, false, false>), grid, dim3(256), 0, s, p);        \
         else SGAM_KLAUNCH((conv3x3_h16_halo_kernel<BM_, 128, HT_, false, false>), grid, dim3(256), 0, s, p);                     \
     } while (0)
-    if (bm == 128) {
+    if (bm == 256) {
+        if (ht == 0) HH_LAUNCH(256, 0); else HH_LAUNCH(256, 1);
+    } else if (bm == 128) {
         if (ht == 0) HH_LAUNCH(128, 0); else HH_LAUNCH(128, 1);
     } else {
         if (ht == 0) HH_LAUNCH(64, 0); else HH_LAUNCH(64, 1);
