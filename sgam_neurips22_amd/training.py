@@ -335,6 +335,8 @@ class AutoencoderTrainer:
         if self.head is None:
             return ops.nchw_to_nhwc(x, c_pad=32)
         # cat(x, mask) -> 1x1 conv (model.py:107-113): laid out as a 32-channel NHWC tensor with 5 real channels
+        if mask is None:
+            mask = torch.zeros((B, 1, H, W), device=x.device)
         m = mask.reshape(B, 1, H, W).to(torch.float32)
         x5 = ops.nchw_to_nhwc(torch.cat([x.to(torch.float32), m], 1), c_pad=32)
         h = self.head.fwd(x5)                                        # (B,H,W,4)
@@ -397,16 +399,21 @@ class AutoencoderTrainer:
     def allreduce_grads(self):
         """what DDP does for the reference's LightningModule: average the gradients over the ranks — one flat bucket, one
         RCCL all-reduce (111 MB for the encoder set, 276 MB for the whole autoencoder at fp32)"""
+        return self._allreduce(self.grads, self.parameters())
+
+    def _allreduce(self, grads, params):
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.pg) == 1:
             return 0
-        ps = [p for p in self.parameters() if p in self.grads]
-        flat = torch.cat([self.grads[p].reshape(-1) for p in ps])
+        ps = [p for p in params if p in grads]
+        if not ps:
+            return 0
+        flat = torch.cat([grads[p].reshape(-1) for p in ps])
         dist.all_reduce(flat, group=self.pg)
         ws, o = dist.get_world_size(self.pg), 0
         for p in ps:
             n = p.numel()
-            self.grads[p] = _axpby(flat[o:o + n].reshape(p.shape).contiguous(), None, 1.0 / ws) if flat.is_cuda else \
+            grads[p] = _axpby(flat[o:o + n].reshape(p.shape).contiguous(), None, 1.0 / ws) if flat.is_cuda else \
                 (flat[o:o + n] / ws).reshape(p.shape)
             o += n
         return flat.numel() * 4
@@ -734,6 +741,7 @@ class VQGANTrainer(AutoencoderTrainer):
             if disc_factor != 0:
                 tape_r.bwd(dl_real, need_pgrad=True)
                 tape_f.bwd(dl_fake, need_pgrad=True)
+            self._allreduce(self.dgrads, list(self.disc.parameters()))          # the discriminator sits inside the DDP module too
         self.adam_step()                                        # opt_ae.step(); also advances global_step
         self._adam(list(self.disc.parameters()), self.dgrads, self.dstate)       # opt_disc.step()
         _invalidate_packs(self.disc)

@@ -96,6 +96,9 @@ def _grad_worker(rank, world, port, out_dir):
         tr.grads[p] = torch.full(p.shape, float((rank + 1) * (i + 1)))
     nbytes = tr.allreduce_grads()
     ok = all(torch.equal(tr.grads[p], torch.full(p.shape, 1.5 * (i + 1))) for i, p in enumerate(ps))
+    extra = [torch.nn.Parameter(torch.zeros(3, 5)), torch.nn.Parameter(torch.zeros(7))]      # a second bucket (the discriminator's)
+    dg = {q: torch.full(q.shape, float(rank + 1)) for q in extra}
+    ok = ok and tr._allreduce(dg, extra) == 4 * 22 and all(torch.equal(dg[q], torch.full(q.shape, 1.5)) for q in extra)
     torch.save({"ok": ok, "bytes": nbytes, "n": sum(p.numel() for p in ps)}, os.path.join(out_dir, f"g{rank}.pt"))
     torch.distributed.destroy_process_group()
 
