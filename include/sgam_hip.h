@@ -441,9 +441,10 @@ int sgam_colsum_f32(const float *a, int32_t lda, float *out, int32_t M, int32_t 
 /* GroupNorm(32, eps)(+swish) backward (Normalize + nonlinearity, diffusionmodules/model.py:30-40): x = the layer's input,
  * dy = gradient of its output, mean_rstd [B][groups][2] from sgam_groupnorm_stats_*; dx like x; dgamma_b / dbeta_b [B][C]
  * per-image sums (the caller adds the images); group_means [B][groups][2] scratch */
+int64_t sgam_groupnorm_bwd_workspace_bytes(int32_t B, int32_t HW, int32_t C);
 int sgam_groupnorm_bwd_nhwc_f32(const float *x, const float *dy, const float *mean_rstd, const float *gamma, const float *beta,
                                 int32_t swish, float *dx, float *dgamma_b, float *dbeta_b, float *group_means, int32_t B,
-                                int32_t HW, int32_t C, int32_t groups, void *stream);
+                                int32_t HW, int32_t C, int32_t groups, void *workspace, int64_t workspace_bytes, void *stream);
 /* p = softmax(scale * s) over rows (AttnBlock, model.py:176-181): ds = scale * p * (dp - sum_j dp_j p_j) */
 int sgam_softmax_bwd_rows_f32(const float *p, const float *dp, float *ds, int32_t rows, int32_t cols, int32_t ld, float scale,
                               void *stream);

@@ -66,8 +66,9 @@ PROTOTYPES = {
     "sgam_unpack_conv_weight_grad_f32": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "sgam_colsum_workspace_bytes": (c_i64, [c_i32, c_i32]),
     "sgam_colsum_f32": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp]),
+    "sgam_groupnorm_bwd_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
     "sgam_groupnorm_bwd_nhwc_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,
-                                            c_vp]),
+                                            c_vp, c_i64, c_vp]),
     "sgam_softmax_bwd_rows_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_vp]),
     "sgam_l1_loss_grad_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_f32, c_vp]),
     "sgam_vq_bwd_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_vp]),

@@ -85,48 +85,91 @@ __global__ void unpack_weight_grad_kernel(const float *__restrict__ gp, int ldg,
     g[i] = gp[(int64_t)n * ldg + t * Cin_pad + c];
 }
 
-// ---- column sums of a [M][N] matrix (bias gradients): partial sums over row chunks, then the same kernel over the partials
+// ---- column sums of a [M][N] matrix (bias gradients): partial sums over row chunks, then the same kernel over the partials.
+// Thread layout of every column reduction in this file: 64 adjacent columns x 4 row lanes per workgroup (a row segment of
+// 256 bytes is one coalesced access), the row lanes joined through LDS in a fixed order.
+constexpr int CT = 64, RL = 4;
+template <typename T>
+__device__ __forceinline__ T join_row_lanes(T v, T (*sh)[CT]) {          // sum over the RL row lanes of a column; valid for rl == 0
+    const int cl = threadIdx.x % CT, rl = threadIdx.x / CT;
+    sh[rl][cl] = v;
+    __syncthreads();
+    T t = sh[0][cl];
+#pragma unroll
+    for (int k = 1; k < RL; ++k) t += sh[k][cl];
+    __syncthreads();
+    return t;
+}
+
 __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ a, int lda, float *__restrict__ out, int M, int N,
                                                      int rows_per_chunk) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+    __shared__ float sh[RL][CT];
+    const int cl = threadIdx.x % CT, rl = threadIdx.x / CT;
+    const int n = blockIdx.x * CT + cl;
     const int r0 = blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
     float s = 0.f;
-    for (int r = r0; r < r1; ++r) s += a[(int64_t)r * lda + n];
-    out[(int64_t)blockIdx.y * N + n] = s;
+    if (n < N)
+        for (int r = r0 + rl; r < r1; r += RL) s += a[(int64_t)r * lda + n];
+    s = join_row_lanes(s, sh);
+    if (rl == 0 && n < N) out[(int64_t)blockIdx.y * N + n] = s;
 }
 
 // ---- GroupNorm(+swish) backward.  Forward: xh = (x - mean) rstd, n = gamma xh + beta, y = swish ? n sigmoid(n) : n.
 // With g = dL/dn:  dgamma_c = sum g xh,  dbeta_c = sum g,
 //                  dx = rstd (g gamma - mean_grp(g gamma) - xh mean_grp(g gamma xh))       (means over the group's elements)
-// Pass 1: one workgroup per (image, group) leaves the per-channel sums of this image and the two group means.
 __device__ __forceinline__ float dswish(float n) {
     const float s = 1.0f / (1.0f + __expf(-n));
     return s * (1.0f + n * (1.0f - s));
 }
 
-__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float *__restrict__ x, const float *__restrict__ dy,
-                                                            const float *__restrict__ mean_rstd, const float *__restrict__ gamma,
-                                                            const float *__restrict__ beta, int swish, float *__restrict__ dgamma_b,
-                                                            float *__restrict__ dbeta_b, float *__restrict__ gmeans, int HW, int C,
-                                                            int groups) {
-    const int b = blockIdx.x / groups, grp = blockIdx.x % groups, cpg = C / groups;
-    const float mean = mean_rstd[(b * groups + grp) * 2], rstd = mean_rstd[(b * groups + grp) * 2 + 1];
-    __shared__ double sh[256][2];
-    __shared__ double tot[2];
-    if (threadIdx.x < 2) tot[threadIdx.x] = 0.0;
-    // channel by channel: the 256 threads stride over the pixels (fixed assignment -> fixed summation order)
-    for (int cc = 0; cc < cpg; ++cc) {
-        const int c = grp * cpg + cc;
+// Pass 1a: per (image, row chunk, channel) partial sums of g and g xh in fp64 (64 channels x 4 row lanes per workgroup).
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                             const float *__restrict__ mean_rstd, const float *__restrict__ gamma,
+                                                             const float *__restrict__ beta, int swish, double *__restrict__ part,
+                                                             int HW, int C, int groups, int rows_per_chunk) {
+    __shared__ double sh[RL][CT];
+    const int cl = threadIdx.x % CT, rl = threadIdx.x / CT;
+    const int c = blockIdx.x * CT + cl, chunk = blockIdx.y, b = blockIdx.z, nchunk = gridDim.y;
+    const int r0 = chunk * rows_per_chunk, r1 = min(HW, r0 + rows_per_chunk);
+    double s_g = 0.0, s_gx = 0.0;
+    if (c < C) {
+        const int grp = c / (C / groups);
+        const float mean = mean_rstd[(b * groups + grp) * 2], rstd = mean_rstd[(b * groups + grp) * 2 + 1];
         const float ga = gamma[c], be = beta[c];
-        double s_g = 0.0, s_gx = 0.0;
-        for (int p = threadIdx.x; p < HW; p += 256) {
+        for (int p = r0 + rl; p < r1; p += RL) {
             const int64_t o = ((int64_t)b * HW + p) * C + c;
             const float xh = (x[o] - mean) * rstd;
             float g = dy[o];
             if (swish) g *= dswish(ga * xh + be);
             s_g += (double)g;
             s_gx += (double)g * (double)xh;
+        }
+    }
+    s_g = join_row_lanes(s_g, sh);
+    s_gx = join_row_lanes(s_gx, sh);
+    if (rl == 0 && c < C) {
+        double *o = part + (((int64_t)b * nchunk + chunk) * C + c) * 2;
+        o[0] = s_g;
+        o[1] = s_gx;
+    }
+}
+
+// Pass 1b: one workgroup per (image, group): the chunks of its channels added in order -> dbeta_b, dgamma_b per channel and
+// the two group means
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const double *__restrict__ part, int nchunk, const float *__restrict__ gamma,
+                                                            float *__restrict__ dgamma_b, float *__restrict__ dbeta_b,
+                                                            float *__restrict__ gmeans, int HW, int C, int groups) {
+    const int b = blockIdx.x / groups, grp = blockIdx.x % groups, cpg = C / groups;
+    __shared__ double sh[256][2];
+    __shared__ double tot[2];
+    if (threadIdx.x < 2) tot[threadIdx.x] = 0.0;
+    for (int cc = 0; cc < cpg; ++cc) {
+        const int c = grp * cpg + cc;
+        double s_g = 0.0, s_gx = 0.0;
+        for (int k = threadIdx.x; k < nchunk; k += 256) {
+            const double *q = part + (((int64_t)b * nchunk + k) * C + c) * 2;
+            s_g += q[0];
+            s_gx += q[1];
         }
         sh[threadIdx.x][0] = s_g;
         sh[threadIdx.x][1] = s_gx;
@@ -141,8 +184,8 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float *__restr
         if (threadIdx.x == 0) {
             dbeta_b[b * C + c] = (float)sh[0][0];
             dgamma_b[b * C + c] = (float)sh[0][1];
-            tot[0] += (double)ga * sh[0][0];
-            tot[1] += (double)ga * sh[0][1];
+            tot[0] += (double)gamma[c] * sh[0][0];
+            tot[1] += (double)gamma[c] * sh[0][1];
         }
         __syncthreads();
     }
@@ -261,17 +304,23 @@ __global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, 
 // the running statistics (momentum update with the UNBIASED variance, like nn.BatchNorm2d)
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict__ x, int ld, double *__restrict__ part, int rows, int C,
                                                          int rows_per_chunk) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double sh[RL][CT];
+    const int cl = threadIdx.x % CT, rl = threadIdx.x / CT;
+    const int c = blockIdx.x * CT + cl;
     const int r0 = blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
     double s = 0.0, ss = 0.0;
-    for (int r = r0; r < r1; ++r) {
-        const double v = (double)x[(int64_t)r * ld + c];
-        s += v;
-        ss += v * v;
+    if (c < C)
+        for (int r = r0 + rl; r < r1; r += RL) {
+            const double v = (double)x[(int64_t)r * ld + c];
+            s += v;
+            ss += v * v;
+        }
+    s = join_row_lanes(s, sh);
+    ss = join_row_lanes(ss, sh);
+    if (rl == 0 && c < C) {
+        part[((int64_t)blockIdx.y * C + c) * 2] = s;
+        part[((int64_t)blockIdx.y * C + c) * 2 + 1] = ss;
     }
-    part[((int64_t)blockIdx.y * C + c) * 2] = s;
-    part[((int64_t)blockIdx.y * C + c) * 2 + 1] = ss;
 }
 
 __global__ void bn_fold_kernel(const double *__restrict__ part, int chunks, float *__restrict__ mean_rstd, float *__restrict__ run_mean,
@@ -312,23 +361,30 @@ __global__ __launch_bounds__(256) void bn_lrelu_bwd_partial_kernel(const float *
                                                                    const float *__restrict__ beta, float *__restrict__ gbuf,
                                                                    double *__restrict__ part, int rows, int C, int rows_per_chunk,
                                                                    float slope) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double sh[RL][CT];
+    const int cl = threadIdx.x % CT, rl = threadIdx.x / CT;
+    const int c = blockIdx.x * CT + cl;
     const int r0 = blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
-    const float mean = mean_rstd ? mean_rstd[c * 2] : 0.f, rstd = mean_rstd ? mean_rstd[c * 2 + 1] : 1.f;
-    const float ga = mean_rstd ? gamma[c] : 1.f, be = mean_rstd ? beta[c] : 0.f;
     double s = 0.0, sx = 0.0;
-    for (int r = r0; r < r1; ++r) {
-        const int64_t o = (int64_t)r * C + c;
-        const float xh = mean_rstd ? (x[o] - mean) * rstd : x[o];
-        const float n = mean_rstd ? ga * xh + be : xh;
-        const float g = dy[o] * (n > 0.f ? 1.f : slope);
-        gbuf[o] = g;
-        s += (double)g;
-        sx += (double)g * (double)xh;
+    if (c < C) {
+        const float mean = mean_rstd ? mean_rstd[c * 2] : 0.f, rstd = mean_rstd ? mean_rstd[c * 2 + 1] : 1.f;
+        const float ga = mean_rstd ? gamma[c] : 1.f, be = mean_rstd ? beta[c] : 0.f;
+        for (int r = r0 + rl; r < r1; r += RL) {
+            const int64_t o = (int64_t)r * C + c;
+            const float xh = mean_rstd ? (x[o] - mean) * rstd : x[o];
+            const float n = mean_rstd ? ga * xh + be : xh;
+            const float g = dy[o] * (n > 0.f ? 1.f : slope);
+            gbuf[o] = g;
+            s += (double)g;
+            sx += (double)g * (double)xh;
+        }
     }
-    part[((int64_t)blockIdx.y * C + c) * 2] = s;
-    part[((int64_t)blockIdx.y * C + c) * 2 + 1] = sx;
+    s = join_row_lanes(s, sh);
+    sx = join_row_lanes(sx, sh);
+    if (rl == 0 && c < C) {
+        part[((int64_t)blockIdx.y * C + c) * 2] = s;
+        part[((int64_t)blockIdx.y * C + c) * 2 + 1] = sx;
+    }
 }
 
 __global__ void bn_bwd_fold_kernel(const double *__restrict__ part, int chunks, float *__restrict__ dgamma, float *__restrict__ dbeta,
@@ -550,21 +606,32 @@ extern "C" int sgam_colsum_f32(const float *a, int32_t lda, float *out, int32_t 
     if (!a || !out || M <= 0 || N <= 0 || lda < N || !workspace || workspace_bytes < sgam_colsum_workspace_bytes(M, N)) return SGAM_EINVAL;
     const int chunks = sgam_cdiv(M, 256);
     hipStream_t s = sgam_stream(stream);
-    SGAM_KLAUNCH(colsum_kernel, dim3(sgam_cdiv(N, 256), chunks), dim3(256), 0, s, a, lda, (float *)workspace, M, N, 256);
+    SGAM_KLAUNCH(colsum_kernel, dim3(sgam_cdiv(N, CT), chunks), dim3(256), 0, s, a, lda, (float *)workspace, M, N, 256);
     SGAM_LAUNCH_CHECK();
-    SGAM_KLAUNCH(colsum_kernel, dim3(sgam_cdiv(N, 256), 1), dim3(256), 0, s, (const float *)workspace, N, out, chunks, N, chunks);
+    SGAM_KLAUNCH(colsum_kernel, dim3(sgam_cdiv(N, CT), 1), dim3(256), 0, s, (const float *)workspace, N, out, chunks, N, chunks);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
 }
 
+extern "C" int64_t sgam_groupnorm_bwd_workspace_bytes(int32_t B, int32_t HW, int32_t C) {
+    if (B <= 0 || HW <= 0 || C <= 0) return -1;
+    return (int64_t)B * sgam_cdiv(HW, 256) * C * 2 * 8;
+}
+
 extern "C" int sgam_groupnorm_bwd_nhwc_f32(const float *x, const float *dy, const float *mean_rstd, const float *gamma, const float *beta,
                                            int32_t swish, float *dx, float *dgamma_b, float *dbeta_b, float *group_means, int32_t B,
-                                           int32_t HW, int32_t C, int32_t groups, void *stream) {
+                                           int32_t HW, int32_t C, int32_t groups, void *workspace, int64_t workspace_bytes,
+                                           void *stream) {
     if (!x || !dy || !mean_rstd || !gamma || !beta || !dx || !dgamma_b || !dbeta_b || !group_means || B <= 0 || HW <= 0 || C <= 0 ||
         groups <= 0 || C % groups)
         return SGAM_EINVAL;
     hipStream_t s = sgam_stream(stream);
-    SGAM_KLAUNCH(gn_bwd_reduce_kernel, dim3(B * groups), dim3(256), 0, s, x, dy, mean_rstd, gamma, beta, swish ? 1 : 0, dgamma_b, dbeta_b,
+    const int nchunk = sgam_cdiv(HW, 256);
+    if (!workspace || workspace_bytes < sgam_groupnorm_bwd_workspace_bytes(B, HW, C)) return SGAM_EWORKSPACE;
+    SGAM_KLAUNCH(gn_bwd_partial_kernel, dim3(sgam_cdiv(C, CT), nchunk, B), dim3(256), 0, s, x, dy, mean_rstd, gamma, beta, swish ? 1 : 0,
+                 (double *)workspace, HW, C, groups, 256);
+    SGAM_LAUNCH_CHECK();
+    SGAM_KLAUNCH(gn_bwd_reduce_kernel, dim3(B * groups), dim3(256), 0, s, (const double *)workspace, nchunk, gamma, dgamma_b, dbeta_b,
                  group_means, HW, C, groups);
     SGAM_LAUNCH_CHECK();
     const int64_t total = (int64_t)B * HW * C;
@@ -643,7 +710,7 @@ extern "C" int sgam_batchnorm_stats_f32(const float *x, float *mean_rstd, float 
         return SGAM_EINVAL;
     const int chunks = sgam_cdiv(rows, 256);
     hipStream_t s = sgam_stream(stream);
-    SGAM_KLAUNCH(bn_partial_kernel, dim3(sgam_cdiv(C, 256), chunks), dim3(256), 0, s, x, C, (double *)workspace, rows, C, 256);
+    SGAM_KLAUNCH(bn_partial_kernel, dim3(sgam_cdiv(C, CT), chunks), dim3(256), 0, s, x, C, (double *)workspace, rows, C, 256);
     SGAM_LAUNCH_CHECK();
     SGAM_KLAUNCH(bn_fold_kernel, dim3(sgam_cdiv(C, 256)), dim3(256), 0, s, (const double *)workspace, chunks, mean_rstd, running_mean,
                  running_var, rows, C, eps, momentum);
@@ -673,7 +740,7 @@ extern "C" int sgam_bn_lrelu_bwd_f32(const float *x, const float *dy, const floa
     if (!mean_rstd && gbuf != dx) return SGAM_EINVAL;          // without BatchNorm the masked gradient IS dx
     const int chunks = sgam_cdiv(rows, 256);
     hipStream_t s = sgam_stream(stream);
-    SGAM_KLAUNCH(bn_lrelu_bwd_partial_kernel, dim3(sgam_cdiv(C, 256), chunks), dim3(256), 0, s, x, dy, mean_rstd, gamma, beta, gbuf,
+    SGAM_KLAUNCH(bn_lrelu_bwd_partial_kernel, dim3(sgam_cdiv(C, CT), chunks), dim3(256), 0, s, x, dy, mean_rstd, gamma, beta, gbuf,
                  (double *)workspace, rows, C, 256, slope);
     SGAM_LAUNCH_CHECK();
     if (!mean_rstd) return SGAM_OK;

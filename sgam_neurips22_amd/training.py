@@ -172,9 +172,12 @@ class _Norm:
         dg = torch.empty((B, C), device=x.device, dtype=torch.float32)
         db = torch.empty((B, C), device=x.device, dtype=torch.float32)
         gm = torch.empty((B, G, 2), device=x.device, dtype=torch.float32)
-        check(_lib.load().sgam_groupnorm_bwd_nhwc_f32(_p(x), _p(dy), _p(self.mr), _p(ops._f32c(self.norm.weight.detach())),
-                                                      _p(ops._f32c(self.norm.bias.detach())), int(self.swish), _p(dx), _p(dg), _p(db),
-                                                      _p(gm), B, H * W, C, G, _stream()), "sgam_groupnorm_bwd_nhwc_f32")
+        lib = _lib.load()
+        nb = lib.sgam_groupnorm_bwd_workspace_bytes(B, H * W, C)
+        ws = torch.empty((nb,), device=x.device, dtype=torch.uint8)
+        check(lib.sgam_groupnorm_bwd_nhwc_f32(_p(x), _p(dy), _p(self.mr), _p(ops._f32c(self.norm.weight.detach())),
+                                              _p(ops._f32c(self.norm.bias.detach())), int(self.swish), _p(dx), _p(dg), _p(db), _p(gm), B,
+                                              H * W, C, G, _p(ws), nb, _stream()), "sgam_groupnorm_bwd_nhwc_f32")
         if self.need_pgrad:
             self.grads[self.norm.weight] = _colsum(dg) if B > 1 else dg.reshape(C)
             self.grads[self.norm.bias] = _colsum(db) if B > 1 else db.reshape(C)
