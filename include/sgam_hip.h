@@ -382,6 +382,16 @@ int sgam_frame_feedback_f32(const float *dec, const float *lut256, int32_t datas
 /* the re-read half alone, for frames that arrive as uint8 (the seed frame): rgb_f[i] = lut256[rgb_u8[i]], n values */
 int sgam_rgb_u8_to_f32(const uint8_t *rgb_u8, const float *lut256, float *rgb_f, int64_t n, void *stream);
 
+/* Fused q | k | v projection of AttnBlock on the split-fp32 path (diffusionmodules/model.py:168-175: norm -> three 1x1
+ * convolutions): out[M][N] = GroupNorm(x)[M][K] . W[N][K]^T + bias with the normalisation applied while the 64 x 256 operand
+ * panel is staged (mean_rstd [B][32][2] from sgam_groupnorm_stats_*; no swish), w_planes / w_scale = a SplitWeight of the
+ * stacked weights (sgam_split_rows_f32x).  sgam_gemm_gn_f32x_fits: M % 64 == 0 inside whole images of HW rows, N % 128 == 0,
+ * K % 256 == 0. */
+int32_t sgam_gemm_gn_f32x_fits(int32_t M, int32_t N, int32_t K, int32_t HW);
+int sgam_gemm_gn_f32x(const float *x, int32_t lda, const float *mean_rstd, const float *gamma, const float *beta, const void *w_planes,
+                      float w_scale, const float *bias, float *out, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t HW,
+                      void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * f1 — TSDF fusion of the generated RGB-D frames + depth render at the target pose.  Replaces
  * InfiniteSceneGeneration.rgbd_integration (sgam/inference_pipeline.py:119-133, 745-838: Open3D 0.15.2

@@ -32,6 +32,7 @@ SOURCES = {
     "vq.hip": ["-ffp-contract=off"],
     "layout.hip": ["-ffp-contract=off"],
     "warp.hip": ["-ffp-contract=off"],
+    "gemm_gn_f32x.hip": [],
     "train.hip": [],
     "tsdf.hip": ["-ffp-contract=off"] + (["-DSGAM_TSDF_DEBUG_STEPS"] if os.environ.get("SGAM_TSDF_DEBUG_STEPS") else []),
 }

@@ -11,6 +11,8 @@ Activations stay NHWC between layers (``forward_nhwc``); the public ``forward`` 
 and returns NCHW like the reference and pays one layout hop on each side.
 """
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 
@@ -72,6 +74,8 @@ class GroupNorm(nn.GroupNorm):
 # costs more (+19 us on the 128->128 @256^2 layer) than the stand-alone HBM-bound normalise pass it removes
 # (~12 us).  The fused kernel stays available (and parity-tested) behind this switch.
 FUSE_GROUPNORM_INTO_CONV = False
+# AttnBlock on the split-fp32 path: normalise inside the q | k | v GEMM (measured)
+FUSE_NORM_INTO_QKV = os.environ.get("SGAM_FUSE_NORM_QKV", "1") != "0"
 
 
 def _norm_conv(norm, swish, conv, x, **kw):
@@ -192,7 +196,13 @@ class AttnBlock(_NHWCModule):
         wp, bp = self.proj_out._packed(x.dtype)
         if x.dtype in ops.H16:
             return self._forward_nhwc_h16(x, wqkv, bqkv, wp, bp)
-        if FUSE_GROUPNORM_INTO_CONV:
+        fused_qkv = wkey == "f32x" and FUSE_NORM_INTO_QKV and ops.gemm_gn_fits(B * n, 3 * C, C, n)
+        if fused_qkv:
+            # GroupNorm applied while the q | k | v GEMM stages its operand (csrc/gemm_gn_f32x.hip): no normalise pass
+            mr = ops.groupnorm_meanrstd(x, self.norm.eps)
+            qkv_all = ops.gemm_gn_f32x(x.reshape(B * n, C), mr, self.norm.weight.detach(), self.norm.bias.detach(), wqkv, bqkv, n)
+            table, h = None, None
+        elif FUSE_GROUPNORM_INTO_CONV:
             table, h = self.norm.stats_nhwc(x), x                         # (B, C, 2), no swish for attention
         else:
             table, h = None, self.norm.forward_nhwc(x, swish=False)
@@ -200,8 +210,8 @@ class AttnBlock(_NHWCModule):
         scale = int(C) ** (-0.5)
         for b in range(B):
             xb = x[b].reshape(n, C)
-            qkv = ops.gemm_nt(h[b].reshape(n, C), wqkv, bias=bqkv,
-                              gn=None if table is None else (table[b:b + 1], False))   # (n, 3C)
+            qkv = qkv_all[b * n:(b + 1) * n] if fused_qkv else ops.gemm_nt(
+                h[b].reshape(n, C), wqkv, bias=bqkv, gn=None if table is None else (table[b:b + 1], False))   # (n, 3C)
             if ops.F32_MODE == "split" and ops.attention_fusable(n, C):
                 o = ops.attention(qkv, C, scale)                           # one pass over the keys, no (n, n) scores
             else:

@@ -456,6 +456,23 @@ def gemm_nt(a, b, bias=None, residual=None, bias_per_row=False, out=None, gn=Non
     return _run_conv(d, a, b, bias, residual, out, gn, a_scale)
 
 
+def gemm_gn_fits(M, N, K, HW):
+    return F32_MODE == "split" and _lib.load().sgam_gemm_gn_f32x_fits(M, N, K, HW) == 1
+
+
+def gemm_gn_f32x(x2d, mean_rstd, gamma, beta, w, bias, hw):
+    """out[M][N] = GroupNorm(x)[M][K] @ W^T + bias with the normalisation fused into the operand staging (AttnBlock's q | k | v
+    projection on the split-fp32 path; csrc/gemm_gn_f32x.hip).  x2d (M, K) fp32 rows of NHWC pixels, `hw` rows per image,
+    mean_rstd (B, 32, 2), w a SplitWeight of the stacked (N, K) weights."""
+    _need_cuda(x2d, mean_rstd)
+    M, K = x2d.shape
+    N = w.shape[0]
+    out = torch.empty((M, N), device=x2d.device, dtype=torch.float32)
+    check(_lib.load().sgam_gemm_gn_f32x(_p(x2d), x2d.stride(0), _p(mean_rstd), _p(_f32c(gamma)), _p(_f32c(beta)), _p(w.planes),
+                                        float(w.scale), _p(bias), _p(out), N, M, N, K, hw, _stream()), "sgam_gemm_gn_f32x")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # GroupNorm(+swish), softmax
 # ------------------------------------------------------------------------------------------------

@@ -438,3 +438,32 @@ def test_small_map_k_in_workgroup_kernel(B, C, Cout, H, W, gn, with_res):
             if old is not None:
                 ops.PLAN_CACHE[key] = old
         assert torch.equal(out, again)
+
+
+@pytest.mark.parametrize("case", [(1, 4096, 256), (2, 256, 512), (3, 1024, 256)], ids=lambda c: f"B{c[0]}n{c[1]}C{c[2]}")
+def test_fused_groupnorm_qkv_gemm(case):
+    """csrc/gemm_gn_f32x.hip: GroupNorm(x) @ [Wq; Wk; Wv]^T + bias with the normalisation applied while the operand panel is
+    staged, against torch fp64 (AttnBlock, model.py:168-175) and against the two-launch path it replaces"""
+    B, n, C = case
+    x = testing.seeded_tensor(f"gnqkv.x{n}", (B * n, C), 1.4, 0.3).to(DEV)
+    g = (1 + 0.2 * testing.seeded_tensor("gnqkv.g", (C,))).to(DEV)
+    bt = (0.2 * testing.seeded_tensor("gnqkv.b", (C,))).to(DEV)
+    w = (testing.seeded_tensor("gnqkv.w", (3 * C, C)) * C ** -0.5).to(DEV)
+    bias = (0.1 * testing.seeded_tensor("gnqkv.bias", (3 * C,))).to(DEV)
+    old = ops.F32_MODE
+    ops.set_f32_mode("split")
+    try:
+        assert ops.gemm_gn_fits(B * n, 3 * C, C, n)
+        x4 = x.view(B, n, 1, C)
+        mr = ops.groupnorm_meanrstd(x4)
+        ws = ops.split_rows(w, ops._pow2_scale(float(w.abs().max())))
+        got = ops.gemm_gn_f32x(x, mr, g, bt, ws, bias, n)
+        assert torch.equal(got, ops.gemm_gn_f32x(x, mr, g, bt, ws, bias, n))
+        two = ops.gemm_nt(ops.groupnorm_nhwc(x4, g, bt, False).view(B * n, C), ws, bias=bias)
+    finally:
+        ops.set_f32_mode(old)
+    xn = F.group_norm(x.double().cpu().view(B, n, C).permute(0, 2, 1), 32, g.double().cpu(), bt.double().cpu(), eps=1e-6)
+    ref = xn.permute(0, 2, 1).reshape(B * n, C) @ w.double().cpu().t() + bias.double().cpu()
+    scale = ref.abs().max().item()
+    assert (got.double().cpu() - ref).abs().max().item() <= 2e-6 * scale
+    assert (got - two).abs().max().item() <= 4e-6 * scale
