@@ -386,8 +386,14 @@ int sgam_rgb_u8_to_f32(const uint8_t *rgb_u8, const float *lut256, float *rgb_f,
  * convolutions): out[M][N] = GroupNorm(x)[M][K] . W[N][K]^T + bias with the normalisation applied while the 64 x 256 operand
  * panel is staged (mean_rstd [B][32][2] from sgam_groupnorm_stats_*; no swish), w_planes / w_scale = a SplitWeight of the
  * stacked weights (sgam_split_rows_f32x).  sgam_gemm_gn_f32x_fits: M % 64 == 0 inside whole images of HW rows, N % 128 == 0,
- * K % 256 == 0. */
+ * K % 256 == 0 (K = 128 without normalisation). */
 int32_t sgam_gemm_gn_f32x_fits(int32_t M, int32_t N, int32_t K, int32_t HW);
+/* the same kernel for the other 1x1 convolutions / GEMMs that fit (proj_out, nin_shortcut, quant_conv): mean_rstd / gamma /
+ * beta NULL = no normalisation (then K = 128 is accepted too); optional residual [M][ldr]; optional gn_partial
+ * [B][HW / 64][32][2] fp64 = per-chunk statistics of `out` for the next GroupNorm (N / 32 a power of two <= 32) */
+int sgam_gemm_panel_f32x(const float *x, int32_t lda, const float *mean_rstd, const float *gamma, const float *beta,
+                         const void *w_planes, float w_scale, const float *bias, const float *residual, int32_t ldr, float *out,
+                         int32_t ldc, double *gn_partial, int32_t M, int32_t N, int32_t K, int32_t HW, void *stream);
 int sgam_gemm_gn_f32x(const float *x, int32_t lda, const float *mean_rstd, const float *gamma, const float *beta, const void *w_planes,
                       float w_scale, const float *bias, float *out, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t HW,
                       void *stream);

@@ -14,6 +14,12 @@
 // Tile: 64 rows x 128 columns, four wavefronts side by side (each 64 x 32: two row tiles share every weight fragment).  In
 // the 32 x 32 accumulator layout a lane holds one column and 16 rows, so the 32 lanes of a half-wave write 128 contiguous
 // bytes of an output row: stores go out directly (no LDS transpose).
+//
+// The same kernel without the normalisation (GN = false) serves the other 1x1 convolutions and plain GEMMs of the path whose
+// shapes fit — AttnBlock.proj_out (+ residual), ResnetBlock.nin_shortcut, quant_conv / post_quant_conv — with the bias /
+// residual epilogue and the per-chunk statistics of the output that the next GroupNorm consumes (one chunk per 64-row tile:
+// a lane sums its column over the 32 rows it holds, the cpg lanes of a group and the two lane halves are joined by xor
+// shuffles; same [B][chunk][32][2] fp64 layout as the conv kernels').  K_chunk = 128 for K = 128.
 #include "sgam_common.h"
 
 namespace {
@@ -21,13 +27,16 @@ namespace {
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int GBM = 64, GBN = 128, KC = 256, LDK = KC + 8;        // LDS row pitch in halfs: 528 B, rows 4 banks apart
+constexpr int GBM = 64, GBN = 128;
 
 struct GemmGnParams {
     const float *x;            // [M][lda]
     const unsigned short *w;   // fragment-ordered hi / lo planes: [N / 32][K / 32][256 pieces][8 halfs]
     const float *bias;         // [N] or NULL
+    const float *res;          // [M][ldr] or NULL
     float *out;                // [M][ldc]
+    double *gn_partial;        // [B][M / HW * HW / 64][32][2] or NULL: statistics of the output per 64-row chunk
+    int ldr;
     const float *mean_rstd;    // [B][32][2]
     const float *gamma, *beta; // [K]
     int M, N, K, lda, ldc, HW; // HW rows per image (GroupNorm statistics are per image)
@@ -39,12 +48,14 @@ __device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
+template <bool GN, int KC>
 __global__ __launch_bounds__(256, 2) void gemm_gn_f32x_kernel(const GemmGnParams p) {
+    constexpr int LDK = KC + 8;                                     // LDS row pitch in halfs: rows 4 banks apart
     __shared__ __attribute__((aligned(16))) unsigned short sA[2][GBM][LDK];         // hi plane, lo plane
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * GBM, n0 = blockIdx.y * GBN + wave * 32;
     const int b = m0 / p.HW;                                       // host guarantees HW % 64 == 0: a tile lies in one image
-    const int cpg = p.K / 32;                                      // channels per group (32 groups)
+    const int cpg = p.K / 32;                                      // channels per group of the INPUT's GroupNorm (32 groups)
     const int slabs = p.K / 32;
     const int lr = lane & 31, lh = lane >> 5;
 
@@ -69,17 +80,20 @@ __global__ __launch_bounds__(256, 2) void gemm_gn_f32x_kernel(const GemmGnParams
 #pragma unroll 4
         for (int it = 0; it < GBM * (KC / 4) / 256; ++it) {
             const int idx = it * 256 + tid;
-            const int row = idx >> 6, c4 = (idx & 63) * 4;
+            const int row = idx / (KC / 4), c4 = (idx % (KC / 4)) * 4;
             const int c = k0 + c4;
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(p.x + (int64_t)(m0 + row) * p.lda + c);
-            const int g = c / cpg;
-            const float mean = p.mean_rstd[(b * 32 + g) * 2], rstd = p.mean_rstd[(b * 32 + g) * 2 + 1];
-            const f32x4 ga = *reinterpret_cast<const f32x4 *>(p.gamma + c), be = *reinterpret_cast<const f32x4 *>(p.beta + c);
+            f32x4 v = *reinterpret_cast<const f32x4 *>(p.x + (int64_t)(m0 + row) * p.lda + c);
+            if constexpr (GN) {
+                const int g = c / cpg;
+                const float mean = p.mean_rstd[(b * 32 + g) * 2], rstd = p.mean_rstd[(b * 32 + g) * 2 + 1];
+                const f32x4 ga = *reinterpret_cast<const f32x4 *>(p.gamma + c), be = *reinterpret_cast<const f32x4 *>(p.beta + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (v[e] - mean) * rstd * ga[e] + be[e];
+            }
             unsigned hi[2], lo[2];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const float a0 = (v[2 * e] - mean) * rstd * ga[2 * e] + be[2 * e];
-                const float a1 = (v[2 * e + 1] - mean) * rstd * ga[2 * e + 1] + be[2 * e + 1];
+                const float a0 = v[2 * e], a1 = v[2 * e + 1];
                 const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
                 const _Float16 l0 = (_Float16)(a0 - (float)h0), l1 = (_Float16)(a1 - (float)h1);
                 hi[e] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
@@ -108,39 +122,78 @@ __global__ __launch_bounds__(256, 2) void gemm_gn_f32x_kernel(const GemmGnParams
     // ---- epilogue: lane = column n0 + lr, rows 8 (e / 4) + 4 lh + e % 4 of each 32-row tile; a half-wave writes 128 B of a row
     const int n = n0 + lr;
     const float bias = p.bias ? p.bias[n] : 0.f;
-    float chk = 0.f;
+    float gs = 0.f, gss = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int row = m0 + i * 32 + 8 * (e >> 2) + 4 * lh + (e & 3);
-            const float v = acc[i][e] * p.inv_w_scale + bias;
+            float v = acc[i][e] * p.inv_w_scale + bias;
+            if (p.res) v += p.res[(int64_t)row * p.ldr + n];
             p.out[(int64_t)row * p.ldc + n] = v;
-            chk += v;
+            gs += v;
+            gss += v * v;
         }
-    if (p.range_flag && sgam_not_finite(chk)) atomicOr(p.range_flag, 1);          // an operand left fp16's range
+    if (p.range_flag && sgam_not_finite(gs)) atomicOr(p.range_flag, 1);           // an operand left fp16's range
+    if (p.gn_partial) {
+        // statistics of the output for the next GroupNorm: groups of cpo = N / 32 adjacent columns (4, 8 or 16 lanes) x the
+        // two lane halves; one chunk per 64-row tile
+        const int cpo = p.N / 32;
+        double ds = (double)gs, dss = (double)gss;
+        for (int o = 1; o < cpo; o <<= 1) {
+            ds += __shfl_xor(ds, o, 64);
+            dss += __shfl_xor(dss, o, 64);
+        }
+        ds += __shfl_xor(ds, 32, 64);
+        dss += __shfl_xor(dss, 32, 64);
+        if (lh == 0 && (lr % cpo) == 0) {
+            const int chunks_per_b = p.HW / GBM, chunk = (m0 - b * p.HW) / GBM;
+            double *o = p.gn_partial + (((int64_t)b * chunks_per_b + chunk) * 32 + n / cpo) * 2;
+            o[0] = ds;
+            o[1] = dss;
+        }
+    }
 }
 
 }  // namespace
 
-// 1 when (M, N, K, HW) fit the kernel: whole 64-row tiles inside one image, whole 128-column tiles, K a multiple of 256
+// 1 when (M, N, K, HW) fit the kernel: whole 64-row tiles inside one image, whole 128-column tiles, K a multiple of 256 (or 128)
 extern "C" int32_t sgam_gemm_gn_f32x_fits(int32_t M, int32_t N, int32_t K, int32_t HW) {
-    return (M > 0 && N > 0 && K > 0 && HW > 0 && M % GBM == 0 && HW % GBM == 0 && M % HW == 0 && N % GBN == 0 && K % KC == 0) ? 1 : 0;
+    return (M > 0 && N > 0 && K > 0 && HW > 0 && M % GBM == 0 && HW % GBM == 0 && M % HW == 0 && N % GBN == 0 && (K % 256 == 0 || K == 128)) ? 1
+                                                                                                                                         : 0;
+}
+
+// out = [GroupNorm](x) . W^T (+ bias) (+ residual); mean_rstd / gamma / beta NULL = no normalisation; gn_partial (optional):
+// [B][HW / 64][32][2] fp64 partial statistics of `out` (needs N % 128 == 0 as always, N / 32 a power of two <= 32)
+extern "C" int sgam_gemm_panel_f32x(const float *x, int32_t lda, const float *mean_rstd, const float *gamma, const float *beta,
+                                    const void *w_planes, float w_scale, const float *bias, const float *residual, int32_t ldr, float *out,
+                                    int32_t ldc, double *gn_partial, int32_t M, int32_t N, int32_t K, int32_t HW, void *stream) {
+    const bool gn = mean_rstd != nullptr;
+    if (!x || !w_planes || !out || sgam_gemm_gn_f32x_fits(M, N, K, HW) != 1 || lda < K || ldc < N || !(w_scale > 0.f) ||
+        (gn && (!gamma || !beta || K % 256)) || (residual && ldr < N))
+        return SGAM_EINVAL;
+    const int cpo = N / 32;
+    if (gn_partial && (cpo > 32 || (cpo & (cpo - 1)))) return SGAM_EINVAL;
+    if (!sgam_aligned16(x) || (gn && (!sgam_aligned16(gamma) || !sgam_aligned16(beta))) || !sgam_aligned16(w_planes) || lda % 4)
+        return SGAM_EALIGN;
+    GemmGnParams p;
+    p.x = x; p.w = (const unsigned short *)w_planes; p.bias = bias; p.res = residual; p.ldr = ldr; p.out = out; p.gn_partial = gn_partial;
+    p.mean_rstd = mean_rstd; p.gamma = gamma; p.beta = beta;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldc = ldc; p.HW = HW; p.inv_w_scale = 1.0f / w_scale; p.range_flag = sgam_i_range_flag;
+    if (sgam_i_prof_on) sgam_i_prof_shape(M, N, K, 1);
+    if (sgam_i_prof_on) sgam_i_prof_work(2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+    const dim3 grid(M / GBM, N / GBN);
+    hipStream_t s = sgam_stream(stream);
+    if (gn) SGAM_KLAUNCH((gemm_gn_f32x_kernel<true, 256>), grid, dim3(256), 0, s, p);
+    else if (K == 128) SGAM_KLAUNCH((gemm_gn_f32x_kernel<false, 128>), grid, dim3(256), 0, s, p);
+    else SGAM_KLAUNCH((gemm_gn_f32x_kernel<false, 256>), grid, dim3(256), 0, s, p);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
 }
 
 extern "C" int sgam_gemm_gn_f32x(const float *x, int32_t lda, const float *mean_rstd, const float *gamma, const float *beta,
                                  const void *w_planes, float w_scale, const float *bias, float *out, int32_t ldc, int32_t M, int32_t N,
                                  int32_t K, int32_t HW, void *stream) {
-    if (!x || !mean_rstd || !gamma || !beta || !w_planes || !out || sgam_gemm_gn_f32x_fits(M, N, K, HW) != 1 || lda < K || ldc < N ||
-        !(w_scale > 0.f))
-        return SGAM_EINVAL;
-    if (!sgam_aligned16(x) || !sgam_aligned16(gamma) || !sgam_aligned16(beta) || !sgam_aligned16(w_planes) || lda % 4) return SGAM_EALIGN;
-    GemmGnParams p;
-    p.x = x; p.w = (const unsigned short *)w_planes; p.bias = bias; p.out = out; p.mean_rstd = mean_rstd; p.gamma = gamma; p.beta = beta;
-    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldc = ldc; p.HW = HW; p.inv_w_scale = 1.0f / w_scale; p.range_flag = sgam_i_range_flag;
-    if (sgam_i_prof_on) sgam_i_prof_shape(M, N, K, 1);
-    if (sgam_i_prof_on) sgam_i_prof_work(2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
-    SGAM_KLAUNCH(gemm_gn_f32x_kernel, dim3(M / GBM, N / GBN), dim3(256), 0, sgam_stream(stream), p);
-    SGAM_LAUNCH_CHECK();
-    return SGAM_OK;
+    if (!mean_rstd) return SGAM_EINVAL;
+    return sgam_gemm_panel_f32x(x, lda, mean_rstd, gamma, beta, w_planes, w_scale, bias, nullptr, 0, out, ldc, nullptr, M, N, K, HW, stream);
 }

@@ -59,6 +59,10 @@ def round_up(v, m):
 #   "mfma"  : fp32-in MFMA (conv_gemm.hip) — bit-for-bit an fp32 fmaf chain; the reference implementation of the
 #             parity path and the one the fused GroupNorm prologue / autotuned plans were built on
 F32_MODE = os.environ.get("SGAM_F32_MODE", "split")
+# the other 1x1 convs / GEMMs on the whole-K-panel kernel of csrc/gemm_gn_f32x.hip where they fit: measured 0.7 % SLOWER in the
+# frame than the generic kernel under its tuned plans (scripts/exp_panel.sh), so opt-in; the fused GroupNorm + q|k|v projection
+# (where the kernel removes a whole pass) is independent of this switch
+PANEL_GEMM = os.environ.get("SGAM_PANEL_GEMM", "0") == "1"
 # split-mode convolutions also emit the GroupNorm statistics of their output from the epilogue (no statistics pass)
 FUSE_GN_STATS = os.environ.get("SGAM_FUSE_GN_STATS", "1") == "1"
 # ... and normalise(+swish) their INPUT while staging it (halo-staged 3x3 kernel): no stand-alone normalise pass
@@ -346,6 +350,21 @@ def _run_conv_inner(lib, desc, x, w, bias, residual, out, gn=None, a_scale=1.0):
     if isinstance(w, SplitWeight):
         if x.dtype != torch.float32:
             raise SgamHipError("split fp32 conv: fp32 activations only")
+        # (opt-in, ops.PANEL_GEMM) 1x1 convolutions / plain GEMMs whose shape fits on the whole-K-panel kernel
+        # (csrc/gemm_gn_f32x.hip: one barrier per 256 of K instead of one per 32, direct row stores, statistics from registers)
+        M_, HW_ = desc.B * desc.Ho * desc.Wo, desc.Ho * desc.Wo
+        if (PANEL_GEMM and gn is None and a_scale == 1.0 and desc.KH == 1 and desc.KW == 1 and desc.stride == 1 and not desc.upsample2x
+                and desc.bias_per_row == 0 and desc.n_valid == desc.N and (M_ // 64) * (desc.N // 128) >= 64
+                and lib.sgam_gemm_gn_f32x_fits(M_, desc.N, desc.Cin, HW_) == 1):
+            cpo = desc.N // 32
+            chunks = HW_ // 64 if (FUSE_GN_STATS and cpo <= 32 and cpo & (cpo - 1) == 0) else 0
+            partial = torch.empty((desc.B * chunks * 32 * 2,), device=x.device, dtype=torch.float64) if chunks > 0 else None
+            check(lib.sgam_gemm_panel_f32x(_p(x), desc.lda, None, None, None, _p(w.planes), float(w.scale), _p(bias), _p(residual),
+                                           desc.ldr, _p(out), desc.ldc, _p(partial), M_, desc.N, desc.Cin, HW_, _stream()),
+                  "sgam_gemm_panel_f32x")
+            if partial is not None:
+                out._gn_partials = (partial, chunks)
+            return out
         ws_bytes = lib.sgam_conv2d_f32x_workspace_bytes(ctypes.byref(desc))
         if ws_bytes < 0:
             raise SgamHipError(f"sgam_conv2d_f32x: unsupported shape {[(f, getattr(desc, f)) for f, _ in desc._fields_]}")

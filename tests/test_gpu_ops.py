@@ -467,3 +467,34 @@ def test_fused_groupnorm_qkv_gemm(case):
     scale = ref.abs().max().item()
     assert (got.double().cpu() - ref).abs().max().item() <= 2e-6 * scale
     assert (got - two).abs().max().item() <= 4e-6 * scale
+
+
+@pytest.mark.parametrize("case", [(1, 64, 64, 256, 256, True), (1, 128, 128, 256, 128, False), (2, 64, 64, 128, 256, False)],
+                         ids=lambda c: f"B{c[0]}_{c[1]}x{c[2]}_{c[3]}to{c[4]}")
+def test_panel_gemm_1x1_conv_with_residual_and_statistics(case):
+    """the whole-K-panel kernel behind the 1x1 convolutions of the split-fp32 path (proj_out with its residual, nin_shortcut):
+    result against torch fp64, bit-identical repeats, and the statistics it leaves for the next GroupNorm"""
+    B, H, W, cin, cout, with_res = case
+    x = testing.seeded_tensor("panel.x", (B, cin, H, W), 1.1, 0.2)
+    w = testing.seeded_tensor("panel.w", (cout, cin, 1, 1), scale=cin ** -0.5)
+    b = testing.seeded_tensor("panel.b", (cout,), scale=0.1)
+    res = testing.seeded_tensor("panel.r", (B, cout, H, W)) if with_res else None
+    old, old_panel = ops.F32_MODE, ops.PANEL_GEMM
+    ops.set_f32_mode("split")
+    ops.PANEL_GEMM = True                         # opt-in path (measured slightly slower than the tuned generic kernel in the frame)
+    try:
+        wp = ops.pack_conv_weight(w.to(DEV), dtype="f32x")
+        xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+        rd = None if res is None else res.permute(0, 2, 3, 1).contiguous().to(DEV)
+        out = ops.conv2d_nhwc(xd, wp, b.to(DEV), cout=cout, kh=1, kw=1, residual=rd)
+        assert ops.PANEL_GEMM and hasattr(out, "_gn_partials") and out._gn_partials[1] == H * W // 64
+        assert torch.equal(out, ops.conv2d_nhwc(xd, wp, b.to(DEV), cout=cout, kh=1, kw=1, residual=rd))
+        st = ops.groupnorm_meanrstd(out).cpu()
+    finally:
+        ops.set_f32_mode(old)
+        ops.PANEL_GEMM = old_panel
+    ref = F.conv2d(x.double(), w.double(), b.double()) + (0 if res is None else res.double())
+    assert (out.permute(0, 3, 1, 2).cpu().double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    og = ref.reshape(B, 32, -1)
+    assert torch.allclose(st[:, :, 0].double(), og.mean(-1), rtol=0, atol=1e-5)
+    assert torch.allclose(st[:, :, 1].double(), (og.var(-1, unbiased=False) + 1e-6).rsqrt(), rtol=1e-5, atol=0)
