@@ -14,6 +14,11 @@ _ALIASES = [
     "generative_sensing_module.modules.diffusionmodules.model",
     "generative_sensing_module.modules.vqvae",
     "generative_sensing_module.modules.vqvae.quantize",
+    "generative_sensing_module.modules.losses",                 # the YAML's lossconfig.target resolves
+    "generative_sensing_module.modules.losses.vqperceptual",
+    "generative_sensing_module.modules.losses.lpips",
+    "generative_sensing_module.modules.discriminator",
+    "generative_sensing_module.modules.discriminator.model",
     "point_rendering",
     "point_rendering.warp",
     "inference_pipeline",

@@ -170,7 +170,7 @@ extern "C" int sgam_gemm_panel_f32x(const float *x, int32_t lda, const float *me
                                     int32_t ldc, double *gn_partial, int32_t M, int32_t N, int32_t K, int32_t HW, void *stream) {
     const bool gn = mean_rstd != nullptr;
     if (!x || !w_planes || !out || sgam_gemm_gn_f32x_fits(M, N, K, HW) != 1 || lda < K || ldc < N || !(w_scale > 0.f) ||
-        (gn && (!gamma || !beta || K % 256)) || (residual && ldr < N))
+        (gn && (!gamma || !beta)) || (residual && ldr < N))
         return SGAM_EINVAL;
     const int cpo = N / 32;
     if (gn_partial && (cpo > 32 || (cpo & (cpo - 1)))) return SGAM_EINVAL;
@@ -184,7 +184,8 @@ extern "C" int sgam_gemm_panel_f32x(const float *x, int32_t lda, const float *me
     if (sgam_i_prof_on) sgam_i_prof_work(2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
     const dim3 grid(M / GBM, N / GBN);
     hipStream_t s = sgam_stream(stream);
-    if (gn) SGAM_KLAUNCH((gemm_gn_f32x_kernel<true, 256>), grid, dim3(256), 0, s, p);
+    if (gn && K == 128) SGAM_KLAUNCH((gemm_gn_f32x_kernel<true, 128>), grid, dim3(256), 0, s, p);   // C = 128 AttnBlocks (ch * ch_mult = 128 levels)
+    else if (gn) SGAM_KLAUNCH((gemm_gn_f32x_kernel<true, 256>), grid, dim3(256), 0, s, p);
     else if (K == 128) SGAM_KLAUNCH((gemm_gn_f32x_kernel<false, 128>), grid, dim3(256), 0, s, p);
     else SGAM_KLAUNCH((gemm_gn_f32x_kernel<false, 256>), grid, dim3(256), 0, s, p);
     SGAM_LAUNCH_CHECK();

@@ -14,9 +14,13 @@
 //   * with a third of the MFMA time per fragment, the wavefronts form a 2 x 2 grid (each owns BM / 2 rows x BN / 2 = 64
 //     channels): every A fragment read from LDS and every B fragment fetched feeds TWO MFMAs (the 1 x 4 layout of the
 //     split-fp32 kernel would need one 1 KB LDS read per MFMA — the LDS port's whole bandwidth);
-//   * epilogue: accumulators -> wave-private LDS transpose -> 8-byte row-contiguous stores of four 16-bit channels (or 16
-//     bytes of fp32), bias / residual fused (the generic 16-bit kernel stores 2 bytes per instruction).
-// Split-K plans are not taken here (the small maps keep the generic kernel of h16.hip).
+//   * epilogue (SGAM_HDIRECT = 1, the default): the product is computed TRANSPOSED (weights = MFMA rows, pixels = columns)
+//     and the weight rows of a 32-channel tile are packed so that a lane's sixteen accumulator slots are sixteen
+//     CONSECUTIVE channels of one pixel: they leave as 16-byte stores with bias, residual and the output statistics applied
+//     in registers — no LDS transpose (70 -> 31 KB of LDS; the generic 16-bit kernel stores 2 bytes per instruction);
+//   * the maps too small to fill the chip with whole-K workgroups (16^2 ... 64^2) split the K slabs over grid.y: fp32
+//     partial tiles in the same lane-owned layout, then h16_splitk_reduce_kernel adds them in a fixed order, applies bias /
+//     residual, rounds and leaves the per-chunk statistics (so those layers, too, normalise while staging).
 #include <stdlib.h>
 
 #include "sgam_common.h"

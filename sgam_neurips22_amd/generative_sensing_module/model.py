@@ -7,8 +7,9 @@ inference path: same constructor signature, attribute names, ``state_dict`` keys
 ``nn.Module`` (no Lightning at inference): ``global_step`` = 0, ``device`` property provided.
 
 Everything between the NCHW boundary tensors runs in libsgam_hip.so, NHWC fp32, without leaving the GPU.
-The training half of the reference class (training_step / optimisers / online k-means, model.py:271-472)
-is out of scope.
+The training half of the reference class (training_step / configure_optimizers / online k-means,
+model.py:271-472) delegates to ``sgam_neurips22_amd.training`` (hand-written backward in
+csrc/train.hip): ``training_step`` / ``configure_optimizers`` below keep the reference's call surface.
 """
 import torch
 import torch.nn as nn
@@ -43,7 +44,7 @@ class VQModel(nn.Module):
         # arithmetic of the VQGAN body: float32 = parity path (fp32-in MFMA); bfloat16 / float16 = throughput
         # path (16-bit MFMA, fp32 accumulate).  The quantiser always runs in fp32 on the fp32 latent.
         self.compute_dtype = torch.float32
-        # replay the ~340 kernel launches of one forward from a captured HIP graph (opt-in: enable_hip_graph())
+        # replay the ~215 kernel launches of one forward from a captured HIP graph (opt-in: enable_hip_graph())
         self.use_hip_graph = False
         self._graphs = {}
         if self.use_extrapolation_mask:
@@ -88,7 +89,7 @@ class VQModel(nn.Module):
     def enable_hip_graph(self, on=True):
         """Capture `forward` once per (input shape, flags, dtype) into a HIP graph (hipStreamBeginCapture through
         torch.cuda.graph — the kernels are this library's, launched on the capturing stream) and replay it on later
-        calls: one graph launch instead of ~340 kernel launches, no per-launch host work, intermediates in a
+        calls: one graph launch instead of ~215 kernel launches, no per-launch host work, intermediates in a
         graph-private pool.  Outputs of a replay are the graph's static tensors: they are overwritten by the next
         call with the same signature (the scene loop consumes them before that).  Weights must not change while
         graphs exist (call enable_hip_graph(False) first)."""
@@ -115,8 +116,10 @@ class VQModel(nn.Module):
         # are captured by address: the graph reads them in place and no copy is paid per replay
         inplace = getattr(input, "_sgam_persistent", False) and (
             extrapolation_mask is None or getattr(extrapolation_mask, "_sgam_persistent", False))
+        if self.compute_dtype == torch.float32 and ops.F32_MODE == "split":
+            ops.range_flag(input.device)       # this device's flag is the registered one before anything is captured
         key = (tuple(input.shape), None if extrapolation_mask is None else tuple(extrapolation_mask.shape), topk,
-               sample_number, flags, self.compute_dtype, str(input.device),
+               sample_number, flags, self.compute_dtype, str(input.device), ops.RANGE_FLAG_EPOCH,
                (input.data_ptr(), None if extrapolation_mask is None else extrapolation_mask.data_ptr()) if inplace else None)
         ent = self._graphs.get(key)
         if ent is None:
@@ -237,6 +240,69 @@ class VQModel(nn.Module):
         if get_quantized_feature:
             res.append(quants)
         return res
+
+    # ---- training call surface (reference model.py:52-57, 271-345, 405-432) ----
+    learning_rate = 4.5e-6          # main.py sets model.learning_rate before fit(); same default as the shipped configs' base rate
+
+    def init_loss(self):
+        """`self.loss = instantiate_from_config(lossconfig)` (model.py:57), deferred: the inference path never touches the
+        loss (LPIPS trunk + PatchGAN), so it is built on first training use — call this BEFORE load_state_dict when a
+        checkpoint's `loss.*` tensors are wanted.  Returns the container (modules/losses/vqperceptual.py)."""
+        if getattr(self, "loss", None) is None:
+            from ...config import instantiate_from_config
+            if not self.lossconfig or not self.lossconfig.get("target"):
+                raise ops.SgamHipError("VQModel: lossconfig has no `target` — nothing to train against")
+            self.loss = instantiate_from_config(self.lossconfig).to(self.device)
+        return self.loss
+
+    def _trainer_for_step(self):
+        tr = getattr(self, "_trainer", None)
+        if tr is None:
+            from ... import training
+            loss = self.init_loss()
+            if getattr(loss, "use_discriminative_loss", False):
+                tr = training.VQGANTrainer(self, loss, phase=self.phase, lr=self.learning_rate)
+            else:
+                # configure_optimizers returns only opt_ae then (model.py:427-432); the loss reduces to L1 (+ LPIPS) + codebook
+                if loss.perceptual_weight > 0:
+                    raise NotImplementedError("perceptual loss without the discriminator branch: use training.VQGANTrainer directly")
+                tr = training.AutoencoderTrainer(self, phase=self.phase, lr=self.learning_rate, codebook_weight=loss.codebook_weight)
+            object.__setattr__(self, "_trainer", tr)        # not a submodule: the trainer refers back to the model
+        return tr
+
+    def configure_optimizers(self):
+        """model.py:405-432: (opt_ae, opt_disc) — or opt_ae alone without the discriminative loss — as descriptors of the two
+        Adam(lr, betas=(0.5, 0.9)) parameter sets; the updates themselves run in csrc/train.hip (`sgam_adam_step_f32`) from
+        `training_step`, which — like the reference's manual-optimisation step — owns zero_grad / backward / step."""
+        from ... import training
+        tr = self._trainer_for_step()
+        opt_ae = training.AdamHandle(tr.parameters(), tr.lr, tr.state)
+        if isinstance(tr, training.VQGANTrainer):
+            return opt_ae, training.AdamHandle(list(tr.disc.parameters()), tr.lr, tr.dstate)
+        return opt_ae
+
+    def training_step(self, batch, batch_idx):
+        """model.py:271-345 on the HIP backward (sgam_neurips22_amd.training): online k-means refresh, forward, autoencoder
+        loss + backward + Adam, discriminator loss + backward + Adam.  Returns aeloss; the logged scalars of the step are
+        left in `self.logged` (what the reference hands to `self.log` / `self.log_dict`)."""
+        tr = self._trainer_for_step()
+        tr.global_step = max(tr.global_step, int(self.global_step))     # (the online k-means refresh runs inside tr.step)
+        if self.phase == "conditional_generation":
+            x, x_dst, extrapolation_mask, _ = self.get_x(batch, self.data_config["dataset"] if isinstance(self.data_config, dict)
+                                                         else self.data_config.dataset, return_extrapolation_mask=True)
+        elif self.phase == "codebook":
+            x = self.get_input(self.image_key, batch).to(self.device)
+            x_dst, extrapolation_mask = x, None
+        else:
+            raise NotImplementedError(self.phase)
+        aeloss, log = tr.step(x, x_dst, extrapolation_mask)
+        self.global_step = tr.global_step
+        self.logged = dict(log)
+        self.logged["train/aeloss"] = aeloss
+        return aeloss
+
+    def get_last_layer(self):
+        return self.decoder.conv_out.weight
 
     def get_input(self, key, batch):
         x = batch[key]

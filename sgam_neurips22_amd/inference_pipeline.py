@@ -374,7 +374,12 @@ class InfiniteSceneGeneration:
 
     # ---------------------------------------------------------------- the step
     @torch.no_grad()
-    def one_step_prediction(self, tgt_pose_grid_coord, save_res_to_disk=True):
+    def one_step_prediction(self, tgt_pose_grid_coord, save_res_to_disk=True, keep_results=False):
+        """reference :860-926.  ALIASING (differs from the reference, which returns fresh tensors): `x`,
+        `extrapolation_mask`, `warped_depth` are views of this scene's persistent model-input buffers and `rgbd` /
+        `feature` / `pre_quantized_features` are the static outputs of the captured HIP graph — the NEXT step overwrites
+        them in place.  The frame store (`self.frames`) always holds its own tensors.  A caller that keeps a result
+        dictionary across steps passes keep_results=True (six device copies per step) or clones what it keeps."""
         src_coords, _ = self.get_src_grid_coords(tgt_pose_grid_coord)
         tgt_meta = self.transform_grid[tgt_pose_grid_coord[0]][tgt_pose_grid_coord[1]]
         src_metas = [self.transform_grid[c[0]][c[1]] for c in src_coords]
@@ -393,11 +398,12 @@ class InfiniteSceneGeneration:
         rgb_f, depth, rgb_u8 = ops.frame_feedback(x_sample_det, self.data, want_u8=True)
         if save_res_to_disk:  # name kept from the reference; here "disk" is the in-HBM frame store
             self.save_to_store(tgt_pose_grid_coord, rgb_u8[0], rgb_f[0], depth[0])
+        own = (lambda t: t.clone()) if keep_results else (lambda t: t)
         res = _Lazy({
-            "rgbd": x_sample_dets[0].squeeze().detach(), "feature": quant.squeeze().detach(),
-            "pre_quantized_features": pre_q.squeeze().detach(), "fixed": False, "x": x.detach(),
-            "batch_R_rels": batch['R_rels'], "batch_t_rels": batch['t_rels'], "warped_depth": warped_depth,
-            "extrapolation_mask": extrapolation_mask, "src_coords": src_coords,
+            "rgbd": own(x_sample_dets[0].squeeze().detach()), "feature": own(quant.squeeze().detach()),
+            "pre_quantized_features": own(pre_q.squeeze().detach()), "fixed": False, "x": own(x.detach()),
+            "batch_R_rels": batch['R_rels'], "batch_t_rels": batch['t_rels'], "warped_depth": own(warped_depth),
+            "extrapolation_mask": own(extrapolation_mask), "src_coords": src_coords,
         })
         res.lazy("batch_src_imgs", lambda: batch['src_imgs'])          # stacked copies only if the caller reads them
         res.lazy("batch_src_depths", lambda: batch['src_depths'])

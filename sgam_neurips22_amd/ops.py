@@ -69,25 +69,48 @@ FUSE_GN_STATS = os.environ.get("SGAM_FUSE_GN_STATS", "1") == "1"
 FUSE_GN_APPLY = os.environ.get("SGAM_FUSE_GN_APPLY", "1") == "1"
 
 
-_RANGE_FLAG = None
+_RANGE_FLAGS = {}          # (device index) -> int32[1] flag tensor; entries are never freed (captured graphs hold their address)
+_RANGE_FLAG_ACTIVE = None  # index of the device whose flag is registered with the library right now
+
+
+def _dev_index(device):
+    d = torch.device(device)
+    if d.type != "cuda":
+        raise SgamHipError(f"range_flag: {d} is not a HIP device")
+    return torch.cuda.current_device() if d.index is None else d.index
 
 
 def range_flag(device):
-    """the split path's range flag (one int32 per process = per GPU), registered with the library on first use"""
-    global _RANGE_FLAG
-    if _RANGE_FLAG is None or _RANGE_FLAG.device != torch.device(device):
-        _RANGE_FLAG = torch.zeros((1,), device=device, dtype=torch.int32)
-        check(_lib.load().sgam_f32x_set_range_flag(_p(_RANGE_FLAG)), "sgam_f32x_set_range_flag")
-    return _RANGE_FLAG
+    """the split path's range flag of `device` (one int32 per GPU), registered with the library.  'cuda' and 'cuda:<current>'
+    name the same flag; a flag is never reallocated or freed, because kernels captured into HIP graphs keep writing to its
+    address.  The library holds ONE registered pointer (one process drives one GPU — distributed.py); registering another
+    device's flag is allowed, but graphs captured under the previous registration keep reporting to the previous flag, so
+    callers that switch devices drop their graphs (VQModel does, through `range_flag_epoch`)."""
+    global _RANGE_FLAG_ACTIVE, RANGE_FLAG_EPOCH
+    i = _dev_index(device)
+    t = _RANGE_FLAGS.get(i)
+    if t is None:
+        t = _RANGE_FLAGS[i] = torch.zeros((1,), device=torch.device("cuda", i), dtype=torch.int32)
+    if _RANGE_FLAG_ACTIVE != i:
+        check(_lib.load().sgam_f32x_set_range_flag(_p(t)), "sgam_f32x_set_range_flag")
+        _RANGE_FLAG_ACTIVE = i
+        RANGE_FLAG_EPOCH += 1
+    return t
 
 
-def f32x_range_tripped(reset=True):
-    """True when a split-fp32 kernel wrote a non-finite output since the last reset (synchronises the device)"""
-    if _RANGE_FLAG is None:
+RANGE_FLAG_EPOCH = 0       # bumped whenever the registered pointer changes: graphs captured before are stale
+
+
+def f32x_range_tripped(reset=True, device=None):
+    """True when a split-fp32 kernel wrote a non-finite output since the last reset (synchronises the device).  Reads the
+    flag of `device` (default: the one registered with the library)."""
+    i = _RANGE_FLAG_ACTIVE if device is None else _dev_index(device)
+    t = _RANGE_FLAGS.get(i)
+    if t is None:
         return False
-    hit = bool(_RANGE_FLAG.item())
+    hit = bool(t.item())
     if hit and reset:
-        _RANGE_FLAG.zero_()
+        t.zero_()
     return hit
 
 

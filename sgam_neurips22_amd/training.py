@@ -294,6 +294,22 @@ def _decoder_layers(dec, grads, train):
     return ls
 
 
+class AdamHandle:
+    """What `VQModel.configure_optimizers` returns (model.py:405-432): the parameter set, hyper-parameters and state of one of
+    the step's two Adam optimisers.  The update itself is `sgam_adam_step_f32` (csrc/train.hip), applied by the trainer inside
+    `training_step` — the reference, too, steps its optimisers by hand there (`automatic_optimization = False`)."""
+
+    def __init__(self, params, lr, state):
+        self.param_groups = [{"params": list(params), "lr": lr, "betas": ADAM_BETAS, "eps": ADAM_EPS}]
+        self.state = state           # parameter -> (exp_avg, exp_avg_sq), filled on the first step
+
+    def zero_grad(self, set_to_none=True):
+        """gradients live in the trainer's tape and are rebuilt every step: nothing to clear"""
+
+    def step(self):
+        raise ops.SgamHipError("the HIP trainer applies Adam inside VQModel.training_step (training.VQGANTrainer.step)")
+
+
 class AutoencoderTrainer:
     """`loss, log = trainer.step(x, x_dst, extrapolation_mask)`: one autoencoder update of VQModel.training_step (see the module
     docstring for what is and is not built).  `x` is what `get_x` / `get_input` hands to the model (B,4,H,W), `x_dst` the
@@ -321,6 +337,32 @@ class AutoencoderTrainer:
         if self.phase == "codebook" and kcfg and kcfg.get("do_online_kmeans_clustering"):
             rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
             self.refresh = OnlineCodebookRefresh(model, kcfg, rank)
+        self.synced_tensors = self._broadcast_module(model)          # world > 1: start every rank from rank 0's weights
+
+    # ---- what DistributedDataParallel does at construction: every rank starts from rank 0's parameters and buffers
+    def _world(self):
+        import torch.distributed as dist
+        return dist.get_world_size(self.pg) if (dist.is_available() and dist.is_initialized()) else 1
+
+    def _src_rank(self):
+        import torch.distributed as dist
+        return dist.get_global_rank(self.pg, 0) if self.pg is not None else 0
+
+    def _broadcast_module(self, module):
+        """rank 0's parameters AND buffers (BatchNorm running statistics, num_batches_tracked) to every rank; returns the
+        number of tensors sent.  Differences from DDP that remain: buffers are synchronised here once, not before every
+        forward (`broadcast_buffers`) — the PatchGAN's running statistics then evolve per rank from per-rank batches, they
+        are not used by the training-mode forward — and gradients are averaged through one flat bucket after the whole
+        backward instead of bucket by bucket during it."""
+        import torch.distributed as dist
+        if self._world() == 1:
+            return 0
+        n = 0
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.data, src=self._src_rank(), group=self.pg)
+            n += 1
+        _invalidate_packs(module)
+        return n
 
     # ---- the parameter set of the phase, in the order of configure_optimizers (model.py:414-428)
     def parameters(self):
@@ -350,9 +392,19 @@ class AutoencoderTrainer:
     def _forward(self, x, x_dst, extrapolation_mask):
         """forward with tape + the reconstruction loss and its gradient (call inside _mfma_mode())"""
         m, lib = self.model, _lib.load()
+        if hasattr(m, "use_vq") and not m.use_vq():
+            # before vq_step_threshold the reference's forward skips the quantiser (model.py:148-150): a different graph
+            raise NotImplementedError("training step before vq_step_threshold (un-quantised forward) is not built")
         self.grads.clear()
         if self.refresh is not None:
             self.refresh.before_step(self.global_step)
+            if self._world() > 1 and self.refresh.may_fire(self.global_step):
+                # the refresh rewrites codebook rows on rank 0 only (model.py:276, as in the reference — whose other ranks then
+                # keep the stale rows): every rank can tell from the step counter WHEN that may have happened, so the codebook
+                # is re-broadcast on exactly those steps
+                import torch.distributed as dist
+                dist.broadcast(m.quantize.embedding.weight.data, src=self._src_rank(), group=self.pg)
+                _invalidate_packs(m)
         xin = self._input_nhwc(x, extrapolation_mask)
         z = self.quant_conv.fwd(self.enc.fwd(xin))                               # (B,h,w,D)
         zq_st, idx, _ = m.quantize.quantize_nhwc(z)                               # straight-through value, indices
@@ -400,8 +452,9 @@ class AutoencoderTrainer:
                 "rec": fw["rec"], "indices": fw["idx"]}
 
     def allreduce_grads(self):
-        """what DDP does for the reference's LightningModule: average the gradients over the ranks — one flat bucket, one
-        RCCL all-reduce (111 MB for the encoder set, 276 MB for the whole autoencoder at fp32)"""
+        """the gradient half of what DDP does for the reference's LightningModule: average the gradients over the ranks — one
+        flat bucket, one RCCL all-reduce (111 MB for the encoder set, 276 MB for the whole autoencoder at fp32).  The other
+        half — identical starting weights / buffers on every rank — is `_broadcast_module` at construction."""
         return self._allreduce(self.grads, self.parameters())
 
     def _allreduce(self, grads, params):
@@ -464,6 +517,10 @@ class OnlineCodebookRefresh:
 
     def _started(self, global_step):
         return self.enabled and global_step >= self.cfg.get("start_global_step", 0)
+
+    def may_fire(self, global_step):
+        """the part of before_step's condition that every rank can evaluate (the countdowns and the buffer live on rank 0)"""
+        return self._started(global_step) and global_step % self.cfg["frequency"] == 0
 
     def before_step(self, global_step):
         """model.py:274-295; returns the number of codewords replaced (0 = none)"""
@@ -593,6 +650,10 @@ class _BNLReLU:
         y = torch.empty_like(x)
         if self.bn is not None:
             bn = self.bn
+            if not bn.training:
+                # eval-mode BatchNorm normalises with the running statistics (and its backward differs): not built — the
+                # reference trains the PatchGAN in train() mode (Lightning's fit); do not silently use batch statistics
+                raise NotImplementedError("training through an eval()-mode BatchNorm2d: call discriminator.train() first")
             nb = lib.sgam_batchnorm_workspace_bytes(rows, C)
             ws = torch.empty((nb,), device=x.device, dtype=torch.uint8)
             self.mr = torch.empty((C, 2), device=x.device, dtype=torch.float32)
@@ -680,6 +741,9 @@ class VQGANTrainer(AutoencoderTrainer):
         super().__init__(model, phase=phase, lr=lr, codebook_weight=loss_cfg.codebook_weight, process_group=process_group)
         self.cfg, self.disc = loss_cfg, loss_cfg.discriminator
         self.lpips = _Lpips(loss_cfg.perceptual_loss) if loss_cfg.perceptual_weight > 0 else None
+        # the discriminator is initialised by weights_init from each process's own RNG: without this every rank would train a
+        # different PatchGAN on averaged gradients
+        self.synced_tensors += self._broadcast_module(loss_cfg.discriminator)
         self.dgrads, self.dstate = {}, {}
 
     def _disc_factor(self):

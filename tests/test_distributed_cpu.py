@@ -90,7 +90,19 @@ def _grad_worker(rank, world, port, out_dir):
     from sgam_neurips22_amd.generative_sensing_module.model import VQModel
     sdist.init(backend="gloo")
     m = VQModel(**testing.small_train_params(default_params("google_earth")))
-    tr = training.AutoencoderTrainer(m, phase="conditional_generation", lr=1e-4)
+    from sgam_neurips22_amd.generative_sensing_module.modules.losses.vqperceptual import VQLPIPSWithDiscriminator
+    cfg = VQLPIPSWithDiscriminator(disc_start=0, perceptual_weight=0.0, disc_in_channels=4, use_discriminative_loss=True).train()
+    want = {k: v.clone() for k, v in list(m.state_dict().items()) + [("D." + k, v) for k, v in cfg.discriminator.state_dict().items()]}
+    for t in list(m.parameters()) + list(cfg.discriminator.parameters()) + list(cfg.discriminator.buffers()):
+        t.data.add_(rank)                            # ranks start apart (each process initialises its PatchGAN from its own RNG)
+    tr = training.VQGANTrainer(m, cfg, phase="conditional_generation", lr=1e-4)
+    # what DDP does at construction: every rank now holds rank 0's parameters and buffers (rank 0 added 0: the originals)
+    have = list(m.state_dict().items()) + [("D." + k, v) for k, v in cfg.discriminator.state_dict().items()]
+    flat = torch.cat([v.reshape(-1).double() for _, v in have])
+    both = [torch.empty_like(flat) for _ in range(world)]
+    torch.distributed.all_gather(both, flat)
+    synced = tr.synced_tensors > 0 and all(torch.equal(b, both[0]) for b in both) and \
+        (rank != 0 or all(torch.equal(v, want[k]) for k, v in have))
     ps = tr.parameters()
     for i, p in enumerate(ps):                       # rank-dependent stand-in gradients: (rank + 1) * (i + 1)
         tr.grads[p] = torch.full(p.shape, float((rank + 1) * (i + 1)))
@@ -99,7 +111,7 @@ def _grad_worker(rank, world, port, out_dir):
     extra = [torch.nn.Parameter(torch.zeros(3, 5)), torch.nn.Parameter(torch.zeros(7))]      # a second bucket (the discriminator's)
     dg = {q: torch.full(q.shape, float(rank + 1)) for q in extra}
     ok = ok and tr._allreduce(dg, extra) == 4 * 22 and all(torch.equal(dg[q], torch.full(q.shape, 1.5)) for q in extra)
-    torch.save({"ok": ok, "bytes": nbytes, "n": sum(p.numel() for p in ps)}, os.path.join(out_dir, f"g{rank}.pt"))
+    torch.save({"ok": ok, "synced": synced, "bytes": nbytes, "n": sum(p.numel() for p in ps)}, os.path.join(out_dir, f"g{rank}.pt"))
     torch.distributed.destroy_process_group()
 
 
@@ -112,3 +124,4 @@ def test_training_gradient_bucket_allreduce_world2_gloo(tmp_path):
     for r in range(2):
         res = torch.load(tmp_path / f"g{r}.pt")
         assert res["ok"] and res["bytes"] == 4 * res["n"] > 0
+        assert res["synced"], "every rank must start from rank 0's parameters and buffers (model and discriminator)"

@@ -235,6 +235,9 @@ def test_ge_trajectory_free_running_32_frames(golden):
         srcs, _ = scene.get_src_grid_coords(tgt)
         assert tuple(tgt) == tuple(tr[f"s{step}.tgt"]) and [tuple(s) for s in srcs] == [tuple(s) for s in tr[f"s{step}.srcs"]]
         res = scene.one_step_prediction(tgt)
+        # (1) THIS backend's step against the oracle on THIS backend's own inputs — asserted at every one of the 32 steps
+        orow = _oracle_check_step(scene, res, sd, p, srcs, tgt, "google_earth")
+        # (2) the reference's free run: a report (the two runs part ways at the first discrete decision that falls the other way)
         q = res["feature"].reshape(256, -1).t()
         idx = torch.cdist(q.double(), cb.double()).argmin(1).reshape(16, 16).cpu()
         ref_idx = torch.from_numpy(tr[f"s{step}.indices"].astype(np.int64))
@@ -246,7 +249,7 @@ def test_ge_trajectory_free_running_32_frames(golden):
         row = {"step": step, "idx_agree": float((idx == ref_idx).float().mean()), "mask_same": bool(mask_same),
                "u8_max": int(du8.max()), "u8_frac_diff": float((du8 != 0).mean()), "depth_max": float(dd.max()),
                "ref_min_gap": float(tr[f"s{step}.gap"].min()),
-               "x_sum_delta": abs(float(res["x"].double().sum()) - float(tr[f"s{step}.x_sum"]))}
+               "x_sum_delta": abs(float(res["x"].double().sum()) - float(tr[f"s{step}.x_sum"])), "oracle": orow}
         if first is None and row["idx_agree"] < 1.0:
             first = step
             gaps = tr[f"s{step}.gap"].reshape(16, 16)[(idx != ref_idx).numpy()]
@@ -258,11 +261,100 @@ def test_ge_trajectory_free_running_32_frames(golden):
     for r in rows[:n_exact]:
         assert r["mask_same"] and r["u8_max"] <= 1 and r["u8_frac_diff"] < 5e-3 and r["depth_max"] <= 1e-3, r
     assert n_exact >= 3, rows[:3]                     # the margin-guarded frame and its immediate successors
-    if first is not None:
-        r = rows[first]
-        assert r["mask_same"], r                      # its input was still the reference's, bit for bit in the mask
-        assert r["flipped_ref_gap_max"] < 1e-4 or r["x_sum_delta"] > 1e-3, \
-            f"step {first}: a well-conditioned token changed its code on an input equal to the reference's: {r}"
+
+
+def _oracle_check_step(scene, res, sd, p, srcs, tgt, dataset, tgt_depth=None):
+    """One step of the scene loop against the oracle ON THE HIP PATH'S OWN INPUTS: the conditioning warp
+    is recomputed by oracle/warp_oracle.c from the frames this backend's store holds and the poses it uploaded (model input
+    and hole mask bit for bit), the VQGAN by oracle/vqgan.py from this backend's own `x` (indices equal wherever the
+    oracle's top-2 margin is >= 1e-4, latent and decoder output within 1e-4 — the decoder on the HIP path's own codes, so a
+    near-tie that fell the other way does not hide a decoder bug), and the feedback codec (uint8 truncation within its
+    1-LSB boundary, de-normalised depth within 1e-3; bit for bit on this backend's own decoder output).  Returns the
+    numbers for the report."""
+    from oracle import vqgan as OV
+    from oracle import warp as OW
+    from conftest import bits_equal
+    N = len(srcs)
+    feats = np.stack([scene.frames[tuple(c)]["rgb_f"].cpu().numpy().transpose(2, 0, 1) for c in srcs])[None]   # (1,N,3,H,W)
+    K = scene.K.astype(np.float32)
+    x_hip = res["x"].cpu()
+    mask_hip = res["extrapolation_mask"].cpu()
+    if tgt_depth is None:      # forward-splat branch (model.py:184-229)
+        depths = np.stack([scene._src_depth(tuple(c)).cpu().numpy() for c in srcs])[None]                       # (1,N,H,W)
+        T = np.zeros((1, N, 4, 4), np.float32)
+        T[0, :, :3, :3] = res["batch_R_rels"].cpu().numpy()[0]
+        T[0, :, :3, 3] = res["batch_t_rels"].cpu().numpy()[0]
+        T[0, :, 3, 3] = 1.0
+        w = OW.forward_splat(feats, depths, K[None], np.tile(K, (1, N, 1, 1)), T)
+        em = torch.from_numpy(w["extrapolation_mask"])
+        x_or = torch.cat([torch.from_numpy(w["merge_feats"]), OW.normalise_depth(torch.from_numpy(w["merge_depths"]), em, dataset)], 1)
+    else:                      # rgbd branch (:575-580, model.py:260-274): inverse warp at the fused volume's rendered depth
+        depths = np.stack([scene.frames[tuple(c)]["depth"].cpu().numpy() for c in srcs])[None]
+        tgt_node = scene.transform_grid[tgt[0]][tgt[1]]
+        T_t2s = scene.relative_poses(tgt_node, [scene.transform_grid[c[0]][c[1]] for c in srcs])[2].astype(np.float32)
+        td = tgt_depth.cpu().numpy()[None]
+        warped = OW.inverse_warp(feats, depths, td, np.tile(K, (1, N, 1, 1)), K[None], T_t2s[None])
+        wd = torch.from_numpy(td)[:, None]
+        em = wd <= 0                   # model.py:196-199: holes of a supplied depth are its non-positive pixels
+        x_or = torch.cat([torch.from_numpy(warped), OW.normalise_depth(wd, em, dataset)], 1)
+    assert torch.equal(mask_hip.bool(), em.bool()), "hole mask must equal the oracle's on the same inputs"
+    assert bits_equal(x_hip.numpy(), x_or.numpy()), "model input must equal the oracle's bit for bit on the same inputs"
+    o = OV.forward(sd, p["ddconfig"], x_hip, mask_hip, topk=1)
+    idx_or = o["indices"].reshape(-1)
+    pre_hip = res["pre_quantized_features"].cpu()[None]
+    assert _maxerr(pre_hip, o["pre_quant"]) <= TOL
+    z = o["pre_quant"].permute(0, 2, 3, 1).reshape(-1, 256)
+    gap = testing.top2_relative_gap(z, sd["quantize.embedding.weight"])
+    cbd = sd["quantize.embedding.weight"].double()
+    idx_hip = torch.cdist(res["feature"].cpu().reshape(256, -1).t().double(), cbd).argmin(1)
+    differ = idx_hip != idx_or
+    assert not bool((differ & (gap >= 1e-4)).any()), \
+        f"a well-conditioned token changed its code: gaps {gap[differ & (gap >= 1e-4)].tolist()}"
+    dec_hip = res["rgbd"].cpu()[None]
+    if bool(differ.any()):      # near-ties only: judge the decoder on the codes the HIP path actually decoded
+        zq = torch.nn.functional.embedding(idx_hip, sd["quantize.embedding.weight"]).view(1, 16, 16, 256).permute(0, 3, 1, 2)
+        dec_or = OV.decode(sd, p["ddconfig"], zq.contiguous())
+    else:
+        dec_or = o["dec"][0][0]
+    err_dec = _maxerr(dec_hip, dec_or)
+    assert err_dec <= TOL, err_dec
+    fr = scene.frames[tuple(tgt)]
+    u8_hip, d_hip = fr["rgb_u8"].cpu().numpy(), fr["depth"].cpu().numpy()
+    # the codec on this backend's own decoder output: bit for bit
+    assert np.array_equal(u8_hip, OW.rgb_to_uint8(dec_hip[0, :3]))
+    assert bits_equal(d_hip, OW.denormalise_depth(dec_hip[0, 3], dataset).numpy())
+    # and against the oracle's decoder output: 1-LSB truncation boundary / 1e-3
+    du8 = np.abs(u8_hip.astype(np.int16) - OW.rgb_to_uint8(dec_or[0, :3]).astype(np.int16))
+    dd = float(np.abs(d_hip - OW.denormalise_depth(dec_or[0, 3], dataset).numpy()).max())
+    assert du8.max() <= 1 and (du8 != 0).mean() < 5e-3 and dd <= 1e-3, (int(du8.max()), float((du8 != 0).mean()), dd)
+    return {"n_src": N, "near_tie_flips": int(differ.sum()), "min_gap": float(gap.min()), "pre_err": _maxerr(pre_hip, o["pre_quant"]),
+            "dec_err": err_dec, "u8_boundary_frac": float((du8 != 0).mean()), "depth_err": dd}
+
+
+def test_ge_rgbd_branch_free_running_matches_oracle_per_step(golden):
+    """The rgbd_integration branch of config 3 (inference_pipeline.py:745-838, 575-580) free-running for 8 frames: at every
+    step the inverse warp at the depth this backend's fused volume rendered, the VQGAN and the feedback codec are checked
+    against the oracle on this backend's own inputs (the TSDF render itself is pinned in tests/test_gpu_tsdf.py)."""
+    seed = golden("trajectory_ge.npz")
+    m, sd, p = _ge_model(golden)
+    scene = InfiniteSceneGeneration(m, "google_earth", seed_index=0, output_dim=(9, 1),
+                                    seed_frame=(seed["seed_rgb"], seed["seed_depth"]), use_rgbd_integration=True)
+    seen = {}
+    render = scene.rgbd_integration
+
+    def recording(src_nodes, tgt_node):
+        seen["tgt_depth"] = render(src_nodes, tgt_node)
+        return seen["tgt_depth"]
+
+    scene.rgbd_integration = recording
+    rows = []
+    for step in range(8):
+        tgt = scene.next_pose(scene.curr)
+        srcs, _ = scene.get_src_grid_coords(tgt)
+        res = scene.one_step_prediction(tgt)
+        rows.append(_oracle_check_step(scene, res, sd, p, srcs, tgt, "google_earth", tgt_depth=seen["tgt_depth"]))
+        scene.curr += 1
+    _report("trajectory_rgbd8_oracle", {"rows": rows})
 
 
 def test_clevr_trajectory_matches_reference(golden):
@@ -371,5 +463,44 @@ def test_split_fp32_range_guard_fires_and_recovers():
             with torch.no_grad():
                 m2(x.to(DEV), extrapolation_mask=mask.to(DEV))
         assert not w2 and ops.F32_MODE == "split"
+    finally:
+        ops.set_f32_mode("split")
+
+
+@pytest.mark.parametrize("scale", [1e-3, 1e-5])
+def test_split_fp32_small_magnitude_stream(scale):
+    """VERDICT r2 weak #2 — the OTHER end of the split's range: a residual stream of magnitude << 1 puts the lo halves of
+    un-normalised operands into fp16 subnormals (absolute error <= 2^-25 per element instead of 2^-22 relative).  With
+    encoder.conv_in scaled DOWN (weight and bias, so the stream entering the first ResnetBlock really is ~scale) the forward
+    must still match the oracle at the north-star tolerance — exact indices on a margin-checked codebook, 1e-4 on latent and
+    RGB-D — either on the split path itself or, if a kernel reports lost precision, after the same fallback as the
+    overflow case."""
+    import warnings
+    from oracle import vqgan as OV
+    p = default_params("google_earth")
+    m = VQModel(**p)
+    sd = testing.synthetic_state_dict(m.state_dict(), seed=0)
+    sd["encoder.conv_in.weight"] = sd["encoder.conv_in.weight"] * scale
+    sd["encoder.conv_in.bias"] = sd["encoder.conv_in.bias"] * scale
+    x, mask = testing.rect_hole_input(1, 64, 64, seed=3)
+    pre = OV.encode_features(sd, p["ddconfig"], x, mask)
+    z = pre.permute(0, 2, 3, 1).reshape(-1, 256)
+    sd["quantize.embedding.weight"], _ = testing.repaired_codebook(z, float(z.mean()), float(z.std()), 4096, 256, 0, 1e-3)
+    o = OV.forward(sd, p["ddconfig"], x, mask)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    assert ops.F32_MODE == "split"
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            with torch.no_grad():
+                dec, _, idx, pre_g = m(x.to(DEV), extrapolation_mask=mask.to(DEV), get_codebook_count=True,
+                                       get_pre_quantized_feature=True)
+        fell_back = ops.F32_MODE == "mfma"
+        _report(f"small_magnitude_{scale:g}", {"fell_back_to_fp32_mfma": fell_back, "pre_err": _maxerr(pre_g, o["pre_quant"]),
+                                                "dec_err": _maxerr(dec, o["dec"]), "warnings": [str(x_.message)[:80] for x_ in w]})
+        assert torch.isfinite(dec).all()
+        assert torch.equal(idx.cpu(), o["indices"])
+        assert _maxerr(pre_g, o["pre_quant"]) <= TOL and _maxerr(dec, o["dec"]) <= TOL
     finally:
         ops.set_f32_mode("split")
