@@ -122,6 +122,64 @@ def roofline_from_timeline(agg, bracket_ms, ms_per_step):
     return out, rows
 
 
+def timed_loop(step_fn, warmup, steps):
+    """`warmup` untimed then `steps` timed calls of step_fn(), device-synchronised on both sides; seconds of the timed part"""
+    for _ in range(warmup):
+        step_fn()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t
+
+
+_PMC_FRAME = {}
+
+
+def pmc_frame_entry(mode, timeline_name):
+    """the in-frame counter record of a kernel (profiles/<pmc_index['in_frame'][mode]>, written by scripts/pmc_frame.sh +
+    pmc_frame.py from rocprofv3 --pmc passes over this same eager frame): the timeline spells a kernel as its launch site
+    does (`k<128,128,true>`), rocprofv3 with the defaulted template arguments (`k<128,128,true,false>`)"""
+    idx_path = os.path.join(ROOT, "profiles", "pmc_index.json")
+    if mode not in _PMC_FRAME:
+        _PMC_FRAME[mode] = (None, {})
+        if os.path.exists(idx_path):
+            fn = json.load(open(idx_path)).get("in_frame", {}).get(mode)
+            if fn and os.path.exists(os.path.join(ROOT, "profiles", fn)):
+                _PMC_FRAME[mode] = (fn, json.load(open(os.path.join(ROOT, "profiles", fn)))["kernels"])
+    fn, kernels = _PMC_FRAME[mode]
+    if timeline_name in kernels:
+        return fn, kernels[timeline_name]
+    if timeline_name.endswith(">"):
+        cands = [k for k in kernels if k.startswith(timeline_name[:-1] + ",")]
+        if len(cands) == 1:
+            return fn, kernels[cands[0]]
+    return fn, None
+
+
+def attach_counters(roofline, mode):
+    """per top-5 row: in-kernel MFMA-pipe busy fraction and HBM GB/s (counter bytes per launch / this run's average launch
+    time) from the committed in-frame PMC file; `roofline.traffic` = the named kernel's counter bytes per launch"""
+    if roofline is None:
+        return
+    for row in [roofline] + roofline.get("top5", []):
+        name = row.get("kernel")
+        fn, ent = pmc_frame_entry(mode, name) if name else (None, None)
+        if ent is None:
+            continue
+        us = row.get("avg_us", row.get("avg_launch_us"))
+        row["mfma_busy_frac"] = ent["mfma_busy_frac"]
+        row["hbm_bytes_per_launch"] = ent["hbm_traffic_bytes_per_launch"]
+        row["hbm_gb_per_s"] = round(ent["hbm_traffic_bytes_per_launch"] / (us * 1e3), 1) if (us and ent["hbm_traffic_bytes_per_launch"]) else None
+    fn, ent = pmc_frame_entry(mode, roofline["kernel"])
+    if ent is not None:
+        roofline["traffic"] = ent["hbm_traffic_bytes_per_launch"]
+        roofline["traffic_note"] = (f"HBM bytes per launch of {roofline['kernel']}, averaged over its {ent['launches_per_frame']} in-frame "
+                                    f"launches: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate rocprofv3 --pmc passes over "
+                                    f"the eager bench frame (profiles/{fn})")
+
+
 def cpu_baseline(sd, p, seed_frame, n_frames):
     """The oracle (CPU port of the same step: C forward splat + torch-CPU VQGAN + host feedback codec) on the
     host cores.  Reported baseline only."""
@@ -175,6 +233,8 @@ def main():
                     help="fp32 products: fp16-split MFMA (default) or fp32-in MFMA")
     ap.add_argument("--concurrent-scenes", type=int, default=4, help="secondary leg: this many independent trajectories "
                                                                       "on one GPU, one stream each (0/1 = skip)")
+    ap.add_argument("--lockstep-scenes", type=lambda v: [int(t) for t in v.split(",") if t], default=[4, 8],
+                    help="secondary leg: scenes per GPU advanced in lock step at batch S (comma list; empty = skip)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying HIP graphs")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "fp16"],
                     help="arithmetic of the VQGAN body: f32 = parity path (fp32-in MFMA), bf16/fp16 = 16-bit MFMA path")
@@ -238,14 +298,8 @@ def main():
     if rank == 0 and not args.no_roofline:
         agg, bracket = frame_timeline(scene)
         roofline, _rows = roofline_from_timeline(agg, bracket, 1e3 * t_max / args.steps)
-        # HBM traffic of that kernel: PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), rocprofv3 --pmc in
-        # separate passes (scripts/pmc_conv.sh), committed under profiles/ — keyed by kernel name
-        pmc = os.path.join(ROOT, "profiles", "pmc_index.json")
-        if os.path.exists(pmc):
-            ent = json.load(open(pmc)).get(roofline["kernel"])
-            if ent:
-                roofline["traffic"] = ent["hbm_traffic_bytes_per_launch"]
-                roofline["traffic_note"] = ent["note"]
+        # HBM traffic / MFMA-pipe occupancy per kernel: in-frame PMC counters (scripts/pmc_frame.sh), committed under profiles/
+        attach_counters(roofline, "f32" if args.dtype == "f32" else args.dtype)
 
     f32_mfma_leg = None
     if rank == 0 and world == 1 and args.dtype == "f32" and ops.F32_MODE == "split" and not args.no_secondary:
@@ -322,27 +376,71 @@ def main():
         # the 16-bit throughput mode on the same workload (16-bit activations / weights, fp32 accumulate): NOT the parity
         # path — reported beside the headline, never as `value`; fp16 and bf16 separately
         secondary = {"note": "16-bit MFMA path (halo-staged 3x3 kernel with fused GroupNorm, csrc/h16_halo.hip; fp32 accumulate); "
-                             "agreement-rate mode, never `value`: codebook-index agreement with the reference fp16 99.7 % "
-                             "(GoogleEarth 512x512 x4) / 99.6 % (CLEVR 256x256), bf16 96.1 % / 98.0 % (tests/test_gpu_configs.py)"}
+                             "agreement-rate mode, never `value`.  `index_agreement_vs_f32_path` is MEASURED in this run: one forward of "
+                             "each mode on the same seeded 256x256 input against this backend's fp32 parity path (agreement with "
+                             "the REFERENCE's indices on its fixtures: tests/test_gpu_configs.py, gpurun_out/report_*.json)"}
+        xa, ma = testing.rect_hole_input(1, 256, 256, seed=3)
+        xa, ma = xa.to(dev), ma.to(dev)
+        with torch.no_grad(), model.eager():
+            idx32 = model(xa, extrapolation_mask=ma, get_codebook_count=True)[2].clone()
         for dtn in ("fp16", "bf16"):
             model.set_compute_dtype(dtn)
+            with torch.no_grad(), model.eager():
+                agree = float((model(xa, extrapolation_mask=ma, get_codebook_count=True)[2] == idx32).float().mean())
             sc2 = InfiniteSceneGeneration(model, DATASET, seed_index=scene_id, output_dim=(args.warmup + args.steps + 4, 1),
                                           seed_frame=seed_frame)
-            for _ in range(args.warmup):
+
+            def one2():
                 sc2.one_step_prediction(sc2.next_pose(sc2.curr)); sc2.curr += 1
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                sc2.one_step_prediction(sc2.next_pose(sc2.curr)); sc2.curr += 1
-            torch.cuda.synchronize()
-            dt2 = time.perf_counter() - t1
+            dt2 = timed_loop(one2, args.warmup, args.steps)
             agg2, br2 = frame_timeline(sc2)
             r2, _ = roofline_from_timeline(agg2, br2, 1e3 * dt2 / args.steps)
+            attach_counters(r2, dtn)
             secondary[dtn] = {"value": round(args.steps / dt2, 3), "unit": "frames/s", "ms_per_step": round(1e3 * dt2 / args.steps, 3),
-                              "roofline": {k: r2[k] for k in ("kernel", "achieved", "peak", "frac", "calls_per_frame", "ms_per_frame",
-                                                              "top5", "frame", "kernel_time_ms_per_frame")}}
+                              "index_agreement_vs_f32_path": round(agree, 5),
+                              "roofline": {k: r2.get(k) for k in ("kernel", "achieved", "peak", "frac", "calls_per_frame", "ms_per_frame",
+                                                                  "mfma_busy_frac", "traffic", "top5", "frame", "kernel_time_ms_per_frame",
+                                                                  "kernels_per_frame")}}
             del sc2
         secondary["dtype"], secondary["value"] = "fp16", secondary["fp16"]["value"]
+        model.set_compute_dtype("f32")
+
+    lock_leg = None
+    if rank == 0 and world == 1 and args.dtype == "f32" and not args.no_secondary and args.lockstep_scenes:
+        # S independent trajectories of this GPU advanced in LOCK STEP: one launch sequence at B = S (one forward splat over
+        # S x N source frames, one VQGAN forward, one feedback launch) instead of S streams — what the kernels deliver when
+        # they are fed (sgam_neurips22_amd.distributed.LockstepScenes; every scene's frames match its solo run,
+        # tests/test_gpu_lockstep.py).  Aggregate frames/s; NOT `value` (BASELINE's N = 1 workload is one trajectory per GPU).
+        lock_leg = {"note": "S scenes per GPU through ONE launch sequence at batch S (LockstepScenes); aggregate frames/s = S x steps / "
+                            "seconds; `roofline` = the kernel with the most GPU time in one eager lock-stepped step (in-run timeline)"}
+        steps_l = max(4, min(args.steps, 12))
+        for dtn in ("f32", "fp16", "bf16"):
+            model.set_compute_dtype(dtn)
+            for S in args.lockstep_scenes:
+                seeds = [synthetic_seed_frame(DATASET, seed_index=i) for i in range(S)]
+                ls = sdist.LockstepScenes(model, DATASET, seeds, output_dim=(args.warmup + steps_l + 5, 1))
+                dtl = timed_loop(ls.step, args.warmup, steps_l)
+
+                def one_l():
+                    with model.eager():
+                        ls.step()
+                one_l()
+                recs, br = ops.kernel_timeline(one_l)
+                aggl = {}
+                for name, ms, flops, nbytes, _shp in recs:
+                    a = aggl.setdefault(name, {"calls": 0, "ms": 0.0, "gflop": 0.0, "gbyte": 0.0})
+                    a["calls"] += 1; a["ms"] += max(ms - br, 0.0); a["gflop"] += flops / 1e9; a["gbyte"] += nbytes / 1e9
+                rl, _ = roofline_from_timeline(aggl, br, 1e3 * dtl / steps_l)
+                rl["frame"] = {"gflop": GFLOP_PER_FRAME * S, "ms": round(1e3 * dtl / steps_l, 3),
+                               "tflops": round(GFLOP_PER_FRAME * S / (1e3 * dtl / steps_l), 1),
+                               "frac": round(GFLOP_PER_FRAME * S / (1e3 * dtl / steps_l) / rl["peak"], 4) if rl["peak"] else None}
+                lock_leg[f"{dtn}_S{S}"] = {
+                    "scenes": S, "dtype": dtn, "value": round(S * steps_l / dtl, 3), "unit": "frames/s (aggregate)",
+                    "ms_per_round": round(1e3 * dtl / steps_l, 3),
+                    "roofline": {k: rl.get(k) for k in ("kernel", "achieved", "peak", "frac", "calls_per_frame", "avg_launch_us",
+                                                        "share_of_kernel_time", "top5", "frame", "kernel_time_ms_per_frame",
+                                                        "kernels_per_frame")}}
+                del ls
         model.set_compute_dtype("f32")
 
     stress = None
@@ -417,7 +515,7 @@ def main():
                                         if ops.F32_MODE == "split" else "fp32-in MFMA") if args.dtype == "f32" else None},
             "vqgan_tflops_wallclock": round(GFLOP_PER_FRAME * g["total_frames"] / t_max / 1e3 / world, 2),
             "roofline": roofline, "cpu_baseline": cpu, "f32_mfma_mode": f32_mfma_leg, "numa_node": numa, "f32x_range_flag": int(range_tripped),
-            "rgbd_integration_branch": rgbd_leg, "concurrent_scenes": conc_leg, "throughput_mode": secondary, "config5_512sq_batch4": stress, "training_step": train_leg, "frame_checksums": [r[2] for r in g["per_rank"]],
+            "rgbd_integration_branch": rgbd_leg, "concurrent_scenes": conc_leg, "lockstep_scenes": lock_leg, "throughput_mode": secondary, "config5_512sq_batch4": stress, "training_step": train_leg, "frame_checksums": [r[2] for r in g["per_rank"]],
         }
         print(json.dumps(out), flush=True)
     if torch.distributed.is_available() and torch.distributed.is_initialized():

@@ -340,7 +340,7 @@ int sgam_forward_splat_f32(const float *src_feats, int64_t feat_cs, int64_t feat
 /* Same splat with the sources addressed through a table of device pointers instead of one stacked tensor: the scene
  * loop (prepare_batch_data, inference_pipeline.py:534-537) keeps every generated frame as its own HBM allocation and
  * the warp reads them in place.  src_feat_ptrs / src_depth_ptrs: HOST arrays of B*N device pointers (entry b*N+n: the
- * [HW] x 3 features of that source, strides feat_cs / feat_ps, and its [HW] depth map); B*N <= 16 (the table travels by
+ * [HW] x 3 features of that source, strides feat_cs / feat_ps, and its [HW] depth map); B*N <= 64 (the table travels by
  * value in the kernel arguments: no upload).  Everything else as sgam_forward_splat_f32. */
 int sgam_forward_splat_srcs_f32(const float *const *src_feat_ptrs, const float *const *src_depth_ptrs, int64_t feat_cs,
                                 int64_t feat_ps, const float *tgt_K, const float *src_Kinv, const float *T, int32_t B,
@@ -363,7 +363,7 @@ int sgam_depth_normalise_f32(const float *depth, int32_t compute_mask, uint8_t *
 int sgam_inverse_warp_f32(const float *src_imgs, const float *src_depths, const float *tgt_depth,
                           const float *src_K, const float *tgt_Kinv, const float *T_tgt2src, int32_t B,
                           int32_t N, int32_t H, int32_t W, float *warped, float *zbuf, void *stream);
-/* Same with a pointer table (HOST arrays of B*N <= 16 device pointers) and free channel / pixel strides of the source
+/* Same with a pointer table (HOST arrays of B*N <= 64 device pointers) and free channel / pixel strides of the source
  * images: (3,H,W) planes: img_cs = HW, img_ps = 1; the frame store's (H,W,3): img_cs = 1, img_ps = 3. */
 int sgam_inverse_warp_srcs_f32(const float *const *src_img_ptrs, const float *const *src_depth_ptrs, int64_t img_cs,
                                int64_t img_ps, const float *tgt_depth, const float *src_K, const float *tgt_Kinv,

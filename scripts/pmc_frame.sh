@@ -1,25 +1,17 @@
 #!/bin/bash
-# SQ counters of every kernel of the eager frame (one --pmc pass per group), averaged per kernel name.
+# In-frame counters: rocprofv3 --pmc over the EAGER bench frame (bench.py --no-graph), one pass per
+# counter group (SQ; FETCH_SIZE; WRITE_SIZE — the TCC slots do not hold both), kernel trace only; aggregated per kernel
+# name over that kernel's in-frame launches into gpurun_out/pmc_frame_<mode>.json by scripts/pmc_frame.py.
+#   MODE=f32 (split fp32, default) | fp16 | bf16      STEPS=frames per pass (default 6)
 export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/pmcf
+MODE=${MODE:-f32}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmcf_$MODE
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp
 run() { name=$1; shift
-  timeout 400 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --cpu-frames 0 --no-secondary --no-roofline --no-graph > $OUT/$name.log 2>&1; echo "$name rc=$?"; }
-run a SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE
-python3 - <<'PY'
-import csv,glob,os,collections
-out=os.environ["GRAFT_REPO_ROOT"]+"/gpurun_out/pmcf"
-for f in sorted(glob.glob(out+"/*/**/*counter_collection.csv", recursive=True)):
-    agg=collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(f)):
-        agg[r["Kernel_Name"][:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    rows=[]
-    for k,v in agg.items():
-        m={c:sum(x)/len(x) for c,x in v.items()}
-        n=len(next(iter(v.values())))
-        rows.append((n*m.get("GRBM_GUI_ACTIVE",0),k,n,m))
-    for tot,k,n,m in sorted(rows,reverse=True)[:12]:
-        wc=m.get("SQ_WAVE_CYCLES",1); g=m.get("GRBM_GUI_ACTIVE",1)
-        print(f"{k[:58]:58s} n={n:4d} gui={g:9.0f} mfma_busy={m.get('SQ_VALU_MFMA_BUSY_CYCLES',0)/4/256/(g/8):5.2f} wait_any/wave={m.get('SQ_WAIT_ANY',0)/wc:5.2f} wait_inst/wave={m.get('SQ_WAIT_INST_ANY',0)/wc:5.2f} wait_lds/wave={m.get('SQ_WAIT_INST_LDS',0)/wc:5.2f} waves={m.get('SQ_WAVES',0):6.0f}")
-PY
+  timeout 500 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- python $GRAFT_REPO_ROOT/bench.py --steps ${STEPS:-6} --warmup 2 --cpu-frames 0 --no-secondary --no-roofline --no-graph --dtype $MODE > $OUT/$name.log 2>&1; echo "$MODE $name rc=$?"; }
+run sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE
+run fetch FETCH_SIZE
+run write WRITE_SIZE
+python3 $GRAFT_REPO_ROOT/scripts/pmc_frame.py $OUT $GRAFT_REPO_ROOT/gpurun_out/pmc_frame_$MODE.json $((${STEPS:-6} + 2))
+find $OUT -name "*.csv" -size +8M -delete

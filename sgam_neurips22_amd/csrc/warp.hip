@@ -37,7 +37,7 @@ struct Cam {
 
 // Sources addressed through a by-value table of device pointers (one per (batch item, source)): the scene loop keeps
 // every generated frame as its own HBM allocation, and the warps read them in place — no stacked copy per step.
-constexpr int SGAM_MAX_SRCS = 16;
+constexpr int SGAM_MAX_SRCS = 64;   // 8 lock-stepped scenes x 5 sources (CLEVR) fit; 1 KB of kernel arguments
 struct SrcTable {
     const float *feat[SGAM_MAX_SRCS];
     const float *depth[SGAM_MAX_SRCS];

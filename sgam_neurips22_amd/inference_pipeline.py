@@ -164,7 +164,7 @@ class InfiniteSceneGeneration:
         self._Kinv_n = {}        # n sources -> (n,3,3) contiguous copy of the inverse intrinsics
         self._K_n = {}           # n sources -> (n,3,3) contiguous copy of the intrinsics
         # pinned staging ring for the per-step pose upload (see _upload)
-        self._stage = [torch.empty(256, dtype=torch.float32).pin_memory() for _ in range(8)] \
+        self._stage = [torch.empty(4096, dtype=torch.float32).pin_memory() for _ in range(8)] \
             if self.device.type == "cuda" else None
         self._stage_done = [None] * 8
         self._stage_i = 0
@@ -424,6 +424,10 @@ class InfiniteSceneGeneration:
                       f"{self.curr - 1} on the fp32-in MFMA path (SGAM_F32_MODE -> 'mfma')", RuntimeWarning)
         ops.set_f32_mode("mfma")
         self.dynamic_model._graphs = {}
+        return self._rewind_to(verified_curr)
+
+    def _rewind_to(self, verified_curr):
+        """drop the frames generated since `verified_curr` (they may hold non-finite values); returns the new `curr`"""
         for c in self._ordered_grid_coords[verified_curr:self.curr]:
             self.frames.pop(c, None)
             self.transform_grid[c[0]][c[1]]["visited"] = False

@@ -836,7 +836,7 @@ def forward_splat_srcs(src_feats, src_depths, tgt_K, src_Kinv, T, *, B=1, depth_
     contiguous and depths (H,W) — read in place through a pointer table (no stacked copy).  `out`: optional dict of
     preallocated outputs (persistent buffers of the scene loop)."""
     n_src = len(src_feats)
-    assert n_src == len(src_depths) and n_src % B == 0 and 0 < n_src <= 16
+    assert n_src == len(src_depths) and n_src % B == 0 and 0 < n_src <= 64
     N = n_src // B
     for f, d in zip(src_feats, src_depths):
         _need_cuda(f, d)
@@ -871,7 +871,7 @@ def inverse_warp_srcs(src_imgs, src_depths, tgt_depth, src_K, tgt_Kinv, T_tgt2sr
     """`inverse_warp` over a LIST of B*N per-frame sources: images (H,W,3) channels-last, depths (H,W), in place.
     `out`: optional contiguous (B,3,H,W) destination (e.g. the rgb planes of a persistent B = 1 model input)."""
     n_src = len(src_imgs)
-    assert n_src == len(src_depths) and n_src % B == 0 and 0 < n_src <= 16
+    assert n_src == len(src_depths) and n_src % B == 0 and 0 < n_src <= 64
     for f, d in zip(src_imgs, src_depths):
         _need_cuda(f, d)
         if f.dtype != torch.float32 or d.dtype != torch.float32 or not f.is_contiguous() or not d.is_contiguous():
