@@ -267,6 +267,19 @@ int64_t sgam_attention_h16_workspace_bytes(int32_t n, int32_t C);
 int sgam_attention_h16(const void *q, const void *k, const void *v, int32_t ht, int32_t ld, int32_t n, int32_t C, float scale,
                        void *out, int32_t ldo, void *workspace, int64_t workspace_bytes, void *stream);
 
+/* Batched forms (ABI v4): B images of n tokens each, stacked along the rows — q, k, v, out are [B * n][...] and every query
+ * attends to the keys of ITS image only (the AttnBlock at batch B, e.g. B lock-stepped scenes or B warp candidates: one
+ * launch sequence instead of B).  The number of key ranges per image is chosen from (n, B) so that the launch fills the chip
+ * with as few partial outputs as possible (8 ranges for one 64 x 64 image, 1 from eight images on); B = 1 is exactly the
+ * unbatched entry point.  workspace: the matching *_batched_workspace_bytes(n, C, B). */
+int64_t sgam_attention_f32x_batched_workspace_bytes(int32_t n, int32_t C, int32_t B);
+int sgam_attention_f32x_batched(const float *q, const float *k, const float *v, int32_t ld, int32_t n, int32_t C, int32_t B,
+                                float scale, float *out, int32_t ldo, void *workspace, int64_t workspace_bytes, void *stream);
+int64_t sgam_attention_h16_batched_workspace_bytes(int32_t n, int32_t C, int32_t B);
+int sgam_attention_h16_batched(const void *q, const void *k, const void *v, int32_t ht, int32_t ld, int32_t n, int32_t C,
+                               int32_t B, float scale, void *out, int32_t ldo, void *workspace, int64_t workspace_bytes,
+                               void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * K7/K8 — nearest-codeword quantiser.  Replaces VectorQuantizer2.forward
  * (modules/vqvae/quantize.py:285-307): d = (|z|^2 + |e|^2) - 2 z.e (that expression order, fp32),

@@ -125,6 +125,10 @@ PROTOTYPES = {
     "sgam_attention_f32x": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_i32, c_vp, c_i64, c_vp]),
     "sgam_attention_h16_workspace_bytes": (c_i64, [c_i32, c_i32]),
     "sgam_attention_h16": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_i32, c_vp, c_i64, c_vp]),
+    "sgam_attention_f32x_batched_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
+    "sgam_attention_f32x_batched": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_i32, c_vp, c_i64, c_vp]),
+    "sgam_attention_h16_batched_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
+    "sgam_attention_h16_batched": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_i32, c_vp, c_i64, c_vp]),
     "sgam_row_sumsq_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
     "sgam_vq_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
     "sgam_vq_nearest_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp,

@@ -100,7 +100,8 @@ struct AttnParams {
     const unsigned short *kf, *vf;  // fragment-ordered K and V^T
     float *ws_o;                    // [NSPLIT][n / 32][AD][32]   un-normalised O^T per (split, 32-query tile)
     float *ws_ml;                   // [NSPLIT][n][2]             running maximum (log2 domain), sum
-    int ld, n, blocks_per_split;
+    int ld, n, blocks_per_split;    // n = tokens of the whole batch (B images of n_img tokens, stacked along the rows)
+    int n_img, nsplit;              // tokens per image (keys are attended within an image); key ranges per image (1, 2, 4, 8)
     float qscale;                   // C^-1/2 (a power of two for C = 256: folding it into q is exact)
 };
 
@@ -118,10 +119,11 @@ typedef __attribute__((address_space(3))) void lptr_t;
 __global__ __launch_bounds__(256) void attn_flash_f32x_kernel(const AttnParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * BLK_BYTES];   // K buffers 0, 1 | V^T buffers 0, 1
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int sp = blockIdx.x % NSPLIT, qb = blockIdx.x / NSPLIT;
+    const int sp = blockIdx.x % p.nsplit, qb = blockIdx.x / p.nsplit;
     const int q0 = qb * 128 + wave * 32;
     const int lq = lane & 31, lh = lane >> 5;
-    const int kb0 = sp * p.blocks_per_split, kb1 = kb0 + p.blocks_per_split;
+    // the keys of THIS query block's image: key blocks [img * n_img / 32, (img + 1) * n_img / 32), cut into nsplit ranges
+    const int kb0 = ((qb * 128) / p.n_img) * (p.n_img / KB) + sp * p.blocks_per_split, kb1 = kb0 + p.blocks_per_split;
     const unsigned char *kg = reinterpret_cast<const unsigned char *>(p.kf), *vg = reinterpret_cast<const unsigned char *>(p.vf);
 
     // a block is already in fragment order: staging = a linear 32 KB copy, done by the LDS-DMA path (global -> LDS without
@@ -370,29 +372,35 @@ __global__ __launch_bounds__(256) void attn_flash_f32x_kernel(const AttnParams p
 // Workgroup = (32-query tile, 32 columns of d); thread = (query, 4 d): 32 independent loads in flight per thread; the
 // 32 x 32 result goes through LDS so that rows leave as 128-byte pieces.
 __global__ __launch_bounds__(256) void attn_combine_kernel(const float *__restrict__ ws_o, const float *__restrict__ ws_ml,
-                                                           float *__restrict__ out, int ldo, int n, int32_t *range_flag) {
+                                                           float *__restrict__ out, int ldo, int n, int ns, int32_t *range_flag) {
     __shared__ float tile[32][33];
     const int qt = blockIdx.x >> 3, dg = blockIdx.x & 7;
     const int q = threadIdx.x & 31, dsub = threadIdx.x >> 5;
-    float w[NSPLIT], M = -INFINITY, L = 0.f;
+    float w[NSPLIT], M = -INFINITY, L = 0.f;         // ns <= NSPLIT key ranges (wavefront-uniform)
 #pragma unroll
     for (int s = 0; s < NSPLIT; ++s) {
-        const float *ml = ws_ml + ((int64_t)s * n + qt * 32 + q) * 2;
-        w[s] = ml[0];
-        M = fmaxf(M, w[s]);
+        w[s] = -INFINITY;
+        if (s < ns) {
+            const float *ml = ws_ml + ((int64_t)s * n + qt * 32 + q) * 2;
+            w[s] = ml[0];
+            M = fmaxf(M, w[s]);
+        }
     }
 #pragma unroll
-    for (int s = 0; s < NSPLIT; ++s) {
-        w[s] = __builtin_amdgcn_exp2f(w[s] - M);
-        L += w[s] * ws_ml[((int64_t)s * n + qt * 32 + q) * 2 + 1];
-    }
+    for (int s = 0; s < NSPLIT; ++s)
+        if (s < ns) {
+            w[s] = __builtin_amdgcn_exp2f(w[s] - M);
+            L += w[s] * ws_ml[((int64_t)s * n + qt * 32 + q) * 2 + 1];
+        }
     const float inv = 1.0f / L;            // O and l both carry the 2^10 lift of the probabilities
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < NSPLIT; ++s)
+        if (s < ns) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            acc[j] += w[s] * ws_o[(((int64_t)s * (n / 32) + qt) * AD + dg * 32 + dsub * 4 + j) * 32 + q];
+            for (int j = 0; j < 4; ++j)
+                acc[j] += w[s] * ws_o[(((int64_t)s * (n / 32) + qt) * AD + dg * 32 + dsub * 4 + j) * 32 + q];
+        }
 #pragma unroll
     for (int j = 0; j < 4; ++j) tile[q][dsub * 4 + j] = acc[j] * inv;
     __syncthreads();
@@ -454,7 +462,8 @@ __global__ __launch_bounds__(256) void attn_split_kv_h16_kernel(const unsigned s
 struct AttnHParams {
     const unsigned short *q, *kf, *vf;
     float *ws_o, *ws_ml;
-    int ld, n, blocks_per_split;
+    int ld, n, blocks_per_split;    // n = tokens of the whole batch, as in AttnParams
+    int n_img, nsplit;
     float qscale_log2e;             // C^-1/2 * log2(e): applied to the fp32 scores
 };
 
@@ -462,10 +471,10 @@ template <int HT>
 __global__ __launch_bounds__(256, 2) void attn_flash_h16_kernel(const AttnHParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * HBLK_BYTES];   // K buffers 0, 1 | V^T buffers 0, 1
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int sp = blockIdx.x % NSPLIT, qb = blockIdx.x / NSPLIT;
+    const int sp = blockIdx.x % p.nsplit, qb = blockIdx.x / p.nsplit;
     const int q0 = qb * 128 + wave * 32;
     const int lq = lane & 31, lh = lane >> 5;
-    const int kb0 = sp * p.blocks_per_split, nb = p.blocks_per_split;
+    const int kb0 = ((qb * 128) / p.n_img) * (p.n_img / KB) + sp * p.blocks_per_split, nb = p.blocks_per_split;
     const unsigned char *kg = reinterpret_cast<const unsigned char *>(p.kf), *vg = reinterpret_cast<const unsigned char *>(p.vf);
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
     // a wavefront moves 4 KB of every 16 KB block: four 1 KB LDS-DMA pieces behind one (address, M0) setup
@@ -569,28 +578,34 @@ __global__ __launch_bounds__(256, 2) void attn_flash_h16_kernel(const AttnHParam
 // merge of the key ranges for the 16-bit variant: as attn_combine_kernel, output rounded to 16 bits
 template <int HT>
 __global__ __launch_bounds__(256) void attn_combine_h16_kernel(const float *__restrict__ ws_o, const float *__restrict__ ws_ml,
-                                                               unsigned short *__restrict__ out, int ldo, int n) {
+                                                               unsigned short *__restrict__ out, int ldo, int n, int ns) {
     __shared__ float tile[32][33];
     const int qt = blockIdx.x >> 3, dg = blockIdx.x & 7;
     const int q = threadIdx.x & 31, dsub = threadIdx.x >> 5;
     float w[NSPLIT], M = -INFINITY, L = 0.f;
 #pragma unroll
     for (int s = 0; s < NSPLIT; ++s) {
-        w[s] = ws_ml[((int64_t)s * n + qt * 32 + q) * 2];
-        M = fmaxf(M, w[s]);
+        w[s] = -INFINITY;
+        if (s < ns) {
+            w[s] = ws_ml[((int64_t)s * n + qt * 32 + q) * 2];
+            M = fmaxf(M, w[s]);
+        }
     }
 #pragma unroll
-    for (int s = 0; s < NSPLIT; ++s) {
-        w[s] = __builtin_amdgcn_exp2f(w[s] - M);
-        L += w[s] * ws_ml[((int64_t)s * n + qt * 32 + q) * 2 + 1];
-    }
+    for (int s = 0; s < NSPLIT; ++s)
+        if (s < ns) {
+            w[s] = __builtin_amdgcn_exp2f(w[s] - M);
+            L += w[s] * ws_ml[((int64_t)s * n + qt * 32 + q) * 2 + 1];
+        }
     const float inv = 1.0f / L;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < NSPLIT; ++s)
+        if (s < ns) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            acc[j] += w[s] * ws_o[(((int64_t)s * (n / 32) + qt) * AD + dg * 32 + dsub * 4 + j) * 32 + q];
+            for (int j = 0; j < 4; ++j)
+                acc[j] += w[s] * ws_o[(((int64_t)s * (n / 32) + qt) * AD + dg * 32 + dsub * 4 + j) * 32 + q];
+        }
 #pragma unroll
     for (int j = 0; j < 4; ++j) tile[q][dsub * 4 + j] = acc[j] * inv;
     __syncthreads();
@@ -604,79 +619,107 @@ __global__ __launch_bounds__(256) void attn_combine_h16_kernel(const float *__re
 
 }  // namespace
 
-extern "C" int64_t sgam_attention_f32x_workspace_bytes(int32_t n, int32_t C) {
-    if (C != AD || n < 256 || n % 256 != 0) return -1;
-    const int64_t nsplit = NSPLIT;
-    // K and V^T fragments (hi + lo fp16 = 4 bytes per element each), then the per-split partial O^T and {max, sum}
-    return 2 * (int64_t)n * AD * 4 + nsplit * (int64_t)n * AD * 4 + nsplit * (int64_t)n * 2 * 4;
+// key ranges per image: enough workgroups (n_img / 128 query blocks x ranges x images) to fill 256 CUs, as few ranges as that
+// allows (every range writes a partial O): 8 for one 64 x 64 image, 1 from eight images on
+static int attn_nsplit(int n_img, int B) {
+    int ns = NSPLIT;
+    while (ns > 1 && (int64_t)(n_img / 128) * (ns / 2) * B >= 256 && (n_img / KB) % (ns / 2) == 0) ns /= 2;
+    return ns;
 }
 
-extern "C" int sgam_attention_f32x(const float *q, const float *k, const float *v, int32_t ld, int32_t n, int32_t C,
-                                   float scale, float *out, int32_t ldo, void *workspace, int64_t workspace_bytes,
-                                   void *stream) {
+extern "C" int64_t sgam_attention_f32x_batched_workspace_bytes(int32_t n, int32_t C, int32_t B) {
+    if (C != AD || n < 256 || n % 256 != 0 || B < 1 || (int64_t)B * n >= (1 << 24)) return -1;
+    const int64_t nsplit = attn_nsplit(n, B), nt = (int64_t)B * n;
+    // K and V^T fragments (hi + lo fp16 = 4 bytes per element each), then the per-range partial O^T and {max, sum}
+    return 2 * nt * AD * 4 + nsplit * nt * AD * 4 + nsplit * nt * 2 * 4;
+}
+
+extern "C" int64_t sgam_attention_f32x_workspace_bytes(int32_t n, int32_t C) { return sgam_attention_f32x_batched_workspace_bytes(n, C, 1); }
+
+extern "C" int sgam_attention_f32x_batched(const float *q, const float *k, const float *v, int32_t ld, int32_t n, int32_t C, int32_t B,
+                                           float scale, float *out, int32_t ldo, void *workspace, int64_t workspace_bytes,
+                                           void *stream) {
     if (!q || !k || !v || !out || !workspace) return SGAM_EINVAL;
-    const int64_t need = sgam_attention_f32x_workspace_bytes(n, C);
+    const int64_t need = sgam_attention_f32x_batched_workspace_bytes(n, C, B);
     if (need < 0 || ld < C || ld % 4 != 0 || ldo < C) return SGAM_EINVAL;
     int ex;
     if (!(scale > 0.f) || frexpf(scale, &ex) != 0.5f) return SGAM_EINVAL;   // folded into q: must be an exact power of two
     if (workspace_bytes < need) return SGAM_EWORKSPACE;
     if (!sgam_aligned16(q) || !sgam_aligned16(k) || !sgam_aligned16(v) || !sgam_aligned16(workspace)) return SGAM_EALIGN;
-    const int nsplit = NSPLIT;
+    const int nsplit = attn_nsplit(n, B), nt = B * n;
     if ((n / KB) % nsplit != 0 || ldo % 4 != 0 || !sgam_aligned16(out)) return SGAM_EINVAL;
     hipStream_t s = sgam_stream(stream);
     unsigned short *kf = (unsigned short *)workspace;
-    unsigned short *vf = kf + (int64_t)n * AD * 2;
-    float *ws_o = (float *)(vf + (int64_t)n * AD * 2);
-    float *ws_ml = ws_o + (int64_t)nsplit * n * AD;
-    SGAM_KLAUNCH(attn_split_kv_kernel, dim3(n / KB * 8 * 128 / 256), dim3(256), 0, s, k, v, ld, n, kf, vf);
+    unsigned short *vf = kf + (int64_t)nt * AD * 2;
+    float *ws_o = (float *)(vf + (int64_t)nt * AD * 2);
+    float *ws_ml = ws_o + (int64_t)nsplit * nt * AD;
+    // the images are stacked along the rows: their key blocks follow one another in the fragment buffers
+    SGAM_KLAUNCH(attn_split_kv_kernel, dim3(nt / KB * 8 * 128 / 256), dim3(256), 0, s, k, v, ld, nt, kf, vf);
     SGAM_LAUNCH_CHECK();
     AttnParams p;
     p.q = q; p.kf = kf; p.vf = vf; p.ws_o = ws_o; p.ws_ml = ws_ml;
-    p.ld = ld; p.n = n; p.blocks_per_split = n / KB / nsplit; p.qscale = scale;
-    if (sgam_i_prof_on) sgam_i_prof_work(4.0 * n * (double)n * AD, 4.0 * 4.0 * n * AD);   // q k^T + P v; q, k, v, o once
-    SGAM_KLAUNCH(attn_flash_f32x_kernel, dim3(n / 128 * nsplit), dim3(256), 0, s, p);
+    p.ld = ld; p.n = nt; p.n_img = n; p.nsplit = nsplit; p.blocks_per_split = n / KB / nsplit; p.qscale = scale;
+    if (sgam_i_prof_on) sgam_i_prof_work(4.0 * B * n * (double)n * AD, 4.0 * 4.0 * nt * AD);   // q k^T + P v; q, k, v, o once
+    SGAM_KLAUNCH(attn_flash_f32x_kernel, dim3(nt / 128 * nsplit), dim3(256), 0, s, p);
     SGAM_LAUNCH_CHECK();
-    SGAM_KLAUNCH(attn_combine_kernel, dim3(n / 32 * 8), dim3(256), 0, s, ws_o, ws_ml, out, ldo, n, sgam_i_range_flag);
+    SGAM_KLAUNCH(attn_combine_kernel, dim3(nt / 32 * 8), dim3(256), 0, s, ws_o, ws_ml, out, ldo, nt, nsplit, sgam_i_range_flag);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
 }
 
-extern "C" int64_t sgam_attention_h16_workspace_bytes(int32_t n, int32_t C) {
-    if (C != AD || n < 256 || n % 256 != 0) return -1;
-    return 2 * (int64_t)n * AD * 2 + (int64_t)NSPLIT * n * AD * 4 + (int64_t)NSPLIT * n * 2 * 4;
+extern "C" int sgam_attention_f32x(const float *q, const float *k, const float *v, int32_t ld, int32_t n, int32_t C,
+                                   float scale, float *out, int32_t ldo, void *workspace, int64_t workspace_bytes,
+                                   void *stream) {
+    return sgam_attention_f32x_batched(q, k, v, ld, n, C, 1, scale, out, ldo, workspace, workspace_bytes, stream);
 }
 
-extern "C" int sgam_attention_h16(const void *q, const void *k, const void *v, int32_t ht, int32_t ld, int32_t n, int32_t C,
-                                  float scale, void *out, int32_t ldo, void *workspace, int64_t workspace_bytes, void *stream) {
+extern "C" int64_t sgam_attention_h16_batched_workspace_bytes(int32_t n, int32_t C, int32_t B) {
+    if (C != AD || n < 256 || n % 256 != 0 || B < 1 || (int64_t)B * n >= (1 << 24)) return -1;
+    const int64_t nsplit = attn_nsplit(n, B), nt = (int64_t)B * n;
+    return 2 * nt * AD * 2 + nsplit * nt * AD * 4 + nsplit * nt * 2 * 4;
+}
+
+extern "C" int64_t sgam_attention_h16_workspace_bytes(int32_t n, int32_t C) { return sgam_attention_h16_batched_workspace_bytes(n, C, 1); }
+
+extern "C" int sgam_attention_h16_batched(const void *q, const void *k, const void *v, int32_t ht, int32_t ld, int32_t n, int32_t C,
+                                          int32_t B, float scale, void *out, int32_t ldo, void *workspace, int64_t workspace_bytes,
+                                          void *stream) {
     if (!q || !k || !v || !out || !workspace || (ht != 0 && ht != 1)) return SGAM_EINVAL;
-    const int64_t need = sgam_attention_h16_workspace_bytes(n, C);
-    if (need < 0 || ld < C || ld % 8 != 0 || ldo < C || ldo % 4 != 0 || !(scale > 0.f) || (n / KB) % NSPLIT != 0) return SGAM_EINVAL;
+    const int64_t need = sgam_attention_h16_batched_workspace_bytes(n, C, B);
+    if (need < 0) return SGAM_EINVAL;
+    const int nsplit = attn_nsplit(n, B), nt = B * n;
+    if (ld < C || ld % 8 != 0 || ldo < C || ldo % 4 != 0 || !(scale > 0.f) || (n / KB) % nsplit != 0) return SGAM_EINVAL;
     if (workspace_bytes < need) return SGAM_EWORKSPACE;
     if (!sgam_aligned16(q) || !sgam_aligned16(k) || !sgam_aligned16(v) || !sgam_aligned16(workspace) ||
         (((uintptr_t)out) & 7u) != 0)
         return SGAM_EALIGN;
     hipStream_t s = sgam_stream(stream);
     unsigned short *kf = (unsigned short *)workspace;
-    unsigned short *vf = kf + (int64_t)n * AD;
-    float *ws_o = (float *)(vf + (int64_t)n * AD);
-    float *ws_ml = ws_o + (int64_t)NSPLIT * n * AD;
-    SGAM_KLAUNCH(attn_split_kv_h16_kernel, dim3(n / 8), dim3(256), 0, s, (const unsigned short *)k,
-                       (const unsigned short *)v, ld, n, kf, vf);
+    unsigned short *vf = kf + (int64_t)nt * AD;
+    float *ws_o = (float *)(vf + (int64_t)nt * AD);
+    float *ws_ml = ws_o + (int64_t)nsplit * nt * AD;
+    SGAM_KLAUNCH(attn_split_kv_h16_kernel, dim3(nt / 8), dim3(256), 0, s, (const unsigned short *)k,
+                       (const unsigned short *)v, ld, nt, kf, vf);
     SGAM_LAUNCH_CHECK();
     AttnHParams p;
     p.q = (const unsigned short *)q; p.kf = kf; p.vf = vf; p.ws_o = ws_o; p.ws_ml = ws_ml;
-    p.ld = ld; p.n = n; p.blocks_per_split = n / KB / NSPLIT; p.qscale_log2e = scale * LOG2E;
-    const dim3 grid(n / 128 * NSPLIT), cgrid(n / 32 * 8);
-    if (sgam_i_prof_on) sgam_i_prof_work(4.0 * n * (double)n * AD, 4.0 * 2.0 * n * AD);
+    p.ld = ld; p.n = nt; p.n_img = n; p.nsplit = nsplit; p.blocks_per_split = n / KB / nsplit; p.qscale_log2e = scale * LOG2E;
+    const dim3 grid(nt / 128 * nsplit), cgrid(nt / 32 * 8);
+    if (sgam_i_prof_on) sgam_i_prof_work(4.0 * B * n * (double)n * AD, 4.0 * 2.0 * nt * AD);
     if (ht == 0) {
         SGAM_KLAUNCH(attn_flash_h16_kernel<0>, grid, dim3(256), 0, s, p);
         SGAM_LAUNCH_CHECK();
-        SGAM_KLAUNCH(attn_combine_h16_kernel<0>, cgrid, dim3(256), 0, s, ws_o, ws_ml, (unsigned short *)out, ldo, n);
+        SGAM_KLAUNCH(attn_combine_h16_kernel<0>, cgrid, dim3(256), 0, s, ws_o, ws_ml, (unsigned short *)out, ldo, nt, nsplit);
     } else {
         SGAM_KLAUNCH(attn_flash_h16_kernel<1>, grid, dim3(256), 0, s, p);
         SGAM_LAUNCH_CHECK();
-        SGAM_KLAUNCH(attn_combine_h16_kernel<1>, cgrid, dim3(256), 0, s, ws_o, ws_ml, (unsigned short *)out, ldo, n);
+        SGAM_KLAUNCH(attn_combine_h16_kernel<1>, cgrid, dim3(256), 0, s, ws_o, ws_ml, (unsigned short *)out, ldo, nt, nsplit);
     }
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
+}
+
+extern "C" int sgam_attention_h16(const void *q, const void *k, const void *v, int32_t ht, int32_t ld, int32_t n, int32_t C,
+                                  float scale, void *out, int32_t ldo, void *workspace, int64_t workspace_bytes, void *stream) {
+    return sgam_attention_h16_batched(q, k, v, ht, ld, n, C, 1, scale, out, ldo, workspace, workspace_bytes, stream);
 }

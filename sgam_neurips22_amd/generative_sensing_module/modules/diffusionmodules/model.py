@@ -206,8 +206,14 @@ class AttnBlock(_NHWCModule):
             table, h = self.norm.stats_nhwc(x), x                         # (B, C, 2), no swish for attention
         else:
             table, h = None, self.norm.forward_nhwc(x, swish=False)
-        out = torch.empty_like(x)
         scale = int(C) ** (-0.5)
+        if B > 1 and fused_qkv and ops.attention_fusable(n, C):
+            # a batch (lock-stepped scenes, warp candidates) is ONE launch sequence: the images are stacked along the rows of
+            # the q | k | v projection, the fused attention keeps every query inside its image, and proj_out runs as the 1x1
+            # convolution it is (per-image GroupNorm statistics of the block output from its epilogue)
+            o = ops.attention(qkv_all, C, scale, B=B)
+            return self.proj_out.forward_nhwc(o.view(B, H, W, C), residual=x)
+        out = torch.empty_like(x)
         for b in range(B):
             xb = x[b].reshape(n, C)
             qkv = qkv_all[b * n:(b + 1) * n] if fused_qkv else ops.gemm_nt(
@@ -230,8 +236,12 @@ def _attn_h16(self, x, wqkv, bqkv, wp, bp):
     B, H, W, C = x.shape
     n = H * W
     h = self.norm.forward_nhwc(x, swish=False)
-    out = torch.empty_like(x)
     scale = int(C) ** (-0.5)
+    if B > 1 and ops.attention_fusable(n, C):
+        qkv = ops.gemm_nt(h.reshape(B * n, C), wqkv, bias=bqkv)                    # (B n, 3C): the whole batch in one GEMM
+        o = ops.attention_h16(qkv, C, scale, B=B)
+        return self.proj_out.forward_nhwc(o.view(B, H, W, C), residual=x)
+    out = torch.empty_like(x)
     for b in range(B):
         qkv = ops.gemm_nt(h[b].reshape(n, C), wqkv, bias=bqkv)                     # (n, 3C) 16-bit
         if ops.attention_fusable(n, C):

@@ -627,38 +627,41 @@ def attention_fusable(n, C):
     return FUSED_ATTENTION and _lib.load().sgam_attention_f32x_workspace_bytes(int(n), int(C)) > 0 and n % 256 == 0
 
 
-def attention(qkv, C, scale, out=None):
-    """softmax(q k^T * scale) v for the fused projection qkv = [q | k | v] (n, 3C) fp32, in one pass over the keys
-    (csrc/attention.hip): the (n, n) score matrix is never written."""
+def attention(qkv, C, scale, out=None, B=1):
+    """softmax(q k^T * scale) v for the fused projection qkv = [q | k | v] (B * n, 3C) fp32 — B images of n tokens stacked along
+    the rows, every query attending to the keys of its own image — in one pass over the keys (csrc/attention.hip): the (n, n)
+    score matrix is never written, and a batch is ONE launch sequence."""
     _need_cuda(qkv)
-    n = qkv.shape[0]
-    assert qkv.dtype == torch.float32 and qkv.shape[1] == 3 * C and qkv.stride(1) == 1
+    nt = qkv.shape[0]
+    assert qkv.dtype == torch.float32 and qkv.shape[1] == 3 * C and qkv.stride(1) == 1 and nt % B == 0
+    n = nt // B
     lib = _lib.load()
-    ws_bytes = lib.sgam_attention_f32x_workspace_bytes(n, C)
+    ws_bytes = lib.sgam_attention_f32x_batched_workspace_bytes(n, C, B)
     if ws_bytes < 0:
-        raise SgamHipError(f"sgam_attention_f32x: unsupported shape n={n} C={C}")
+        raise SgamHipError(f"sgam_attention_f32x: unsupported shape n={n} C={C} B={B}")
     ws = torch.empty((ws_bytes,), device=qkv.device, dtype=torch.uint8)
     if out is None:
-        out = torch.empty((n, C), device=qkv.device, dtype=torch.float32)
-    check(lib.sgam_attention_f32x(_p(qkv), _p(qkv[:, C:]), _p(qkv[:, 2 * C:]), qkv.stride(0), n, C, float(scale), _p(out),
-                                  out.stride(0), _p(ws), ws_bytes, _stream()), "sgam_attention_f32x")
+        out = torch.empty((nt, C), device=qkv.device, dtype=torch.float32)
+    check(lib.sgam_attention_f32x_batched(_p(qkv), _p(qkv[:, C:]), _p(qkv[:, 2 * C:]), qkv.stride(0), n, C, B, float(scale), _p(out),
+                                          out.stride(0), _p(ws), ws_bytes, _stream()), "sgam_attention_f32x_batched")
     return out
 
 
-def attention_h16(qkv, C, scale, out=None):
+def attention_h16(qkv, C, scale, out=None, B=1):
     """16-bit throughput variant of `attention` (qkv bf16 / fp16, result in the same dtype)."""
     _need_cuda(qkv)
-    n = qkv.shape[0]
-    assert qkv.dtype in H16 and qkv.shape[1] == 3 * C and qkv.stride(1) == 1
+    nt = qkv.shape[0]
+    assert qkv.dtype in H16 and qkv.shape[1] == 3 * C and qkv.stride(1) == 1 and nt % B == 0
+    n = nt // B
     lib = _lib.load()
-    ws_bytes = lib.sgam_attention_h16_workspace_bytes(n, C)
+    ws_bytes = lib.sgam_attention_h16_batched_workspace_bytes(n, C, B)
     if ws_bytes < 0:
-        raise SgamHipError(f"sgam_attention_h16: unsupported shape n={n} C={C}")
+        raise SgamHipError(f"sgam_attention_h16: unsupported shape n={n} C={C} B={B}")
     ws = torch.empty((ws_bytes,), device=qkv.device, dtype=torch.uint8)
     if out is None:
-        out = torch.empty((n, C), device=qkv.device, dtype=qkv.dtype)
-    check(lib.sgam_attention_h16(_p(qkv), _p(qkv[:, C:]), _p(qkv[:, 2 * C:]), H16[qkv.dtype], qkv.stride(0), n, C, float(scale),
-                                 _p(out), out.stride(0), _p(ws), ws_bytes, _stream()), "sgam_attention_h16")
+        out = torch.empty((nt, C), device=qkv.device, dtype=qkv.dtype)
+    check(lib.sgam_attention_h16_batched(_p(qkv), _p(qkv[:, C:]), _p(qkv[:, 2 * C:]), H16[qkv.dtype], qkv.stride(0), n, C, B,
+                                         float(scale), _p(out), out.stride(0), _p(ws), ws_bytes, _stream()), "sgam_attention_h16_batched")
     return out
 
 

@@ -20,7 +20,7 @@ def _declared_symbols():
 def test_library_is_built_and_loads():
     assert os.path.exists(_lib.LIB_PATH), "run `python -m sgam_neurips22_amd.build`"
     lib = _lib.load()
-    assert lib.sgam_abi_version() == 3
+    assert lib.sgam_abi_version() == 4
     assert b"gfx950" in lib.sgam_build_info()
 
 
@@ -69,6 +69,14 @@ def test_argument_validation_without_gpu():
     assert lib.sgam_attention_h16_workspace_bytes(4096, 256) == 2 * 4096 * 256 * 2 + 8 * 4096 * 256 * 4 + 8 * 4096 * 8
     assert lib.sgam_attention_h16_workspace_bytes(4096, 128) == -1
     assert lib.sgam_attention_h16(None, None, None, 1, 768, 4096, 256, 0.0625, None, 256, None, 0, None) == -1
+    # batched forms: fewer key ranges per image as the batch fills the chip by itself (8 images of 64 x 64: one range)
+    assert lib.sgam_attention_f32x_batched_workspace_bytes(4096, 256, 1) == lib.sgam_attention_f32x_workspace_bytes(4096, 256)
+    assert lib.sgam_attention_f32x_batched_workspace_bytes(4096, 256, 8) == 8 * (2 * 4096 * 256 * 4 + 4096 * 256 * 4 + 4096 * 8)
+    assert lib.sgam_attention_f32x_batched_workspace_bytes(4096, 256, 4) == 4 * (2 * 4096 * 256 * 4 + 2 * 4096 * 256 * 4 + 2 * 4096 * 8)
+    assert lib.sgam_attention_h16_batched_workspace_bytes(4096, 256, 2) == 2 * (2 * 4096 * 256 * 2 + 4 * 4096 * 256 * 4 + 4 * 4096 * 8)
+    assert lib.sgam_attention_f32x_batched_workspace_bytes(4096, 256, 0) == -1
+    assert lib.sgam_attention_f32x_batched(None, None, None, 768, 4096, 256, 4, 0.0625, None, 256, None, 0, None) == -1
+    assert lib.sgam_attention_h16_batched(None, None, None, 1, 768, 4096, 256, 4, 0.0625, None, 256, None, 0, None) == -1
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -391,6 +391,34 @@ def test_fused_attention_at_the_512sq_size():
     _close(o[rows], ref, 2e-5, "fused attention, n = 16384")
 
 
+@pytest.mark.parametrize("B,n,dt", [(2, 4096, "f32"), (4, 4096, "f32"), (8, 4096, "f32"), (3, 1024, "f32"), (8, 256, "f32"),
+                                    (4, 4096, "fp16"), (8, 4096, "bf16")])
+def test_batched_attention_keeps_every_query_inside_its_image(B, n, dt):
+    """sgam_attention_{f32x,h16}_batched: B images stacked along the rows in ONE launch sequence (fewer key ranges per image
+    as the batch fills the chip: 8, 4, 2, 1).  Every image's rows against its own unbatched run (same arithmetic per key
+    block, a different number of ranges merged at the end: fp32 round-off) and image 0 against fp64 — a query that saw another
+    image's keys would be off by O(1)."""
+    C = 256
+    scale = C ** -0.5
+    qkv = testing.seeded_tensor(f"attnB.{B}.{n}", (B * n, 3 * C)).to(DEV)
+    if dt == "f32":
+        o = ops.attention(qkv, C, scale, B=B)
+        solo = torch.cat([ops.attention(qkv[b * n:(b + 1) * n], C, scale) for b in range(B)])
+        tol_solo, tol64 = 2e-6, 2e-5
+    else:
+        qkv = qkv.to(ops.DTYPES[dt])
+        o = ops.attention_h16(qkv, C, scale, B=B)
+        solo = torch.cat([ops.attention_h16(qkv[b * n:(b + 1) * n], C, scale) for b in range(B)])
+        tol_solo, tol64 = (2e-3, 4e-3) if dt == "fp16" else (1.6e-2, 3e-2)
+    assert o.shape == (B * n, C) and torch.isfinite(o.float()).all()
+    _close(o.float(), solo.float(), tol_solo, "batched vs per-image launches")
+    assert torch.equal(o, ops.attention(qkv, C, scale, B=B) if dt == "f32" else ops.attention_h16(qkv, C, scale, B=B))
+    q, k, v = (qkv[:n, i * C:(i + 1) * C].double() for i in range(3))
+    _close(o[:n].float(), torch.softmax(q @ k.t() * scale, dim=1) @ v, tol64, "image 0 vs fp64")
+    q, k, v = (qkv[(B - 1) * n:, i * C:(i + 1) * C].double() for i in range(3))
+    _close(o[(B - 1) * n:].float(), torch.softmax(q @ k.t() * scale, dim=1) @ v, tol64, "last image vs fp64")
+
+
 @pytest.mark.parametrize("B,C,Cout,H,W,gn,with_res", [(1, 512, 512, 16, 16, True, True), (1, 256, 256, 32, 32, True, False),
                                                      (2, 256, 512, 16, 24, False, True), (1, 128, 160, 8, 16, False, False)])
 def test_small_map_k_in_workgroup_kernel(B, C, Cout, H, W, gn, with_res):
