@@ -270,7 +270,7 @@ int sgam_attention_h16(const void *q, const void *k, const void *v, int32_t ht, 
 /* Batched forms (ABI v4): B images of n tokens each, stacked along the rows — q, k, v, out are [B * n][...] and every query
  * attends to the keys of ITS image only (the AttnBlock at batch B, e.g. B lock-stepped scenes or B warp candidates: one
  * launch sequence instead of B).  The number of key ranges per image is chosen from (n, B) so that the launch fills the chip
- * with as few partial outputs as possible (8 ranges for one 64 x 64 image, 1 from eight images on); B = 1 is exactly the
+ * with as few partial outputs as possible, at most 2048 keys per range (8 ranges for one 64 x 64 image, 2 from four images on); B = 1 is exactly the
  * unbatched entry point.  workspace: the matching *_batched_workspace_bytes(n, C, B). */
 int64_t sgam_attention_f32x_batched_workspace_bytes(int32_t n, int32_t C, int32_t B);
 int sgam_attention_f32x_batched(const float *q, const float *k, const float *v, int32_t ld, int32_t n, int32_t C, int32_t B,

@@ -24,8 +24,7 @@ SOURCES = {
                       f"-DSGAM_XSB={os.environ.get('SGAM_XSB', '1')}",
                       f"-DSGAM_XNT={os.environ.get('SGAM_XNT', '0')}",
                       f"-DSGAM_XWGM={os.environ.get('SGAM_XWGM', '1')}",
-                      f"-DSGAM_XSOFF={os.environ.get('SGAM_XSOFF', '1')}",
-                      f"-DSGAM_XSTAGGER={os.environ.get('SGAM_XSTAGGER', '0')}"],
+                      f"-DSGAM_XSOFF={os.environ.get('SGAM_XSOFF', '1')}"],
     "h16_halo.hip": [f"-DSGAM_HABLATE={os.environ.get('SGAM_HABLATE', '0')}",
                      f"-DSGAM_HDIRECT={os.environ.get('SGAM_HDIRECT', '1')}"],
     "attention.hip": [f"-DSGAM_ATTN_ABLATE={os.environ.get('SGAM_ATTN_ABLATE', '0')}",

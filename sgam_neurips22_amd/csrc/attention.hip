@@ -619,11 +619,14 @@ __global__ __launch_bounds__(256) void attn_combine_h16_kernel(const float *__re
 
 }  // namespace
 
-// key ranges per image: enough workgroups (n_img / 128 query blocks x ranges x images) to fill 256 CUs, as few ranges as that
-// allows (every range writes a partial O): 8 for one 64 x 64 image, 1 from eight images on
+// key ranges per image: enough workgroups (n_img / 128 query blocks x ranges x images) to fill 256 CUs and as few ranges as
+// that allows (every range writes a partial O) — but never more than 2048 keys per range: a range is ONE running fp32
+// accumulation (soft-max sum and the MFMA accumulators), and the merge of the ranges is what keeps the summation tree
+// shallow (8 ranges of 2048 keys is what the 512 x 512 configuration has always run, and what its 1e-4 parity was measured
+// with; a single 16384-key range lost a digit).  8 for one 64 x 64 image, 2 from four images on.
 static int attn_nsplit(int n_img, int B) {
     int ns = NSPLIT;
-    while (ns > 1 && (int64_t)(n_img / 128) * (ns / 2) * B >= 256 && (n_img / KB) % (ns / 2) == 0) ns /= 2;
+    while (ns > 1 && (int64_t)(n_img / 128) * (ns / 2) * B >= 256 && (n_img / KB) % (ns / 2) == 0 && n_img / (ns / 2) <= 2048) ns /= 2;
     return ns;
 }
 

@@ -696,20 +696,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
     // the weight-fragment loads of the next tap through the 216 MFMAs of the running slab.
     const int s0 = it0 / 9, s1 = SGAM_XABLATE == 1 ? it0 / 9 : it1 / 9;
     int hcur = 0;
-#ifndef SGAM_XSTAGGER
-#define SGAM_XSTAGGER 0
-#endif
-    if constexpr (SGAM_XSTAGGER > 0 && BM == 128) {
-        // Phase offset (experiment): a 512-workgroup launch of this kernel is ONE wave of workgroups, two per CU, that start,
-        // multiply and store in step — the 33 MB of output leave in one un-overlapped burst.  The workgroups dispatched
-        // second (the upper half of the grid: each CU's second slot) sleep through roughly half of a tile's loop, so that
-        // every CU has one workgroup in its store phase while the other is still multiplying.  Placement only; results
-        // are unaffected.
-        if (gridDim.x > 256 && gridDim.x <= 512 && blockIdx.x >= gridDim.x / 2) {
-#pragma unroll 1
-            for (int i = 0; i < SGAM_XSTAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-        }
-    }
     hload(s0, s0 < s1);
     bload(0, 0, s0, s0 < s1);
     bload(1, 1, s0, s0 < s1);

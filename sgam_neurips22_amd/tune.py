@@ -113,7 +113,8 @@ def tune_shape(key, verbose=True):
     t_auto = _time(auto, x, w, out)
     if t_auto is not None and split and norm_input and _lib.load().sgam_conv2d_f32x_gn_fusable(ctypes.byref(auto)) != 1:
         t_auto += max(4e-3, 2.0 * B * Hi * Wi * Cin * 4 / 4e12 * 1e3)
-    for bm, bn in TILES:
+    # the 16-bit halo kernel also has a 256-row tile (16 x 16 patch, one workgroup per CU): a candidate where many tile waves run
+    for bm, bn in (TILES + [(256, 128)] if (dtype in ops.H16 and KH == 3 and stride == 1 and not ups) else TILES):
         if bn == 128 and N % 128:
             continue
         blocks = -(-M // bm) * -(-N // bn)

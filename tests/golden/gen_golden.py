@@ -399,6 +399,48 @@ def gen_train_gan():
          **{"bn." + k: v for k, v in dsd.items() if "running" in k or "num_batches" in k})
 
 
+FULL_TRAIN_KEEP = ["encoder.conv_in.weight", "decoder.conv_out.weight", "conv_in.weight", "quant_conv.weight",
+                   "encoder.mid.attn_1.q.weight", "encoder.down.0.block.0.conv1.weight", "decoder.up.4.block.0.norm1.weight",
+                   "decoder.up.1.upsample.conv.bias", "encoder.down.2.block.0.nin_shortcut.weight"]
+
+
+def gen_train_full():
+    """the same autoencoder update of the REFERENCE at the REAL configuration: the 68 990 620-parameter GoogleEarth model
+    (trained_models/google_earth/config.yaml), one 256 x 256 image with its hole mask — VQModel.forward + VQLPIPSWithDiscriminator
+    (optimizer_idx 0, perceptual_weight 0, before disc_start) + backward: loss terms, indices, the gradient norm of EVERY
+    parameter tensor and nine full gradient tensors (VERDICT r2 next #7a)"""
+    from sgam.generative_sensing_module.modules.losses.vqperceptual import VQLPIPSWithDiscriminator
+    print("training step (full 256x256 GoogleEarth model)")
+    p = R.load_params("google_earth")
+    p["phase"] = "codebook"
+    torch.manual_seed(0)
+    model = VQModel(**p).train()
+    sd = testing.synthetic_state_dict(model.state_dict(), seed=0)
+    model.load_state_dict(sd)
+    x, mask = testing.rect_hole_input(1, 256, 256, seed=9)
+    x_dst = testing.seeded_tensor("train_full.dst", (1, 4, 256, 256), scale=0.5).clamp(-1, 1)
+    with torch.no_grad():
+        pre = model.encode(x, extrapolation_mask=mask)[3]
+    z = pre.permute(0, 2, 3, 1).reshape(-1, pre.shape[1])
+    zmean, zstd = float(z.mean()), float(z.std())
+    cb, repairs = testing.repaired_codebook(z, zmean, zstd, 4096, 256, 0, 1e-4)
+    sd["quantize.embedding.weight"] = cb
+    model.load_state_dict(sd)
+    loss_fn = VQLPIPSWithDiscriminator(disc_start=10 ** 9, codebook_weight=1.0, perceptual_weight=0.0, disc_in_channels=4,
+                                       disc_weight=0.8, use_discriminative_loss=True)
+    xrec, qloss, idx, pre = model(x, extrapolation_mask=mask, get_codebook_count=True, get_pre_quantized_feature=True)
+    aeloss, log = loss_fn(qloss, x_dst, xrec, 0, 0, last_layer=model.get_last_layer(), split="train", extrapolation_mask=mask)
+    model.zero_grad()
+    aeloss.backward()
+    named = dict(model.named_parameters())
+    gn = {k: float(v.grad.double().norm()) for k, v in named.items() if v.grad is not None}
+    save("train_step_full256.npz", zmean=zmean, zstd=zstd, repairs=np.asarray(repairs, dtype=np.int64).reshape(-1, 2),
+         loss=float(aeloss), quant_loss=float(qloss), rec_loss=float(log["train/rec_loss"]),
+         indices=(idx[2] if isinstance(idx, tuple) else idx).to(torch.int16), xrec_sub=xrec.detach()[..., ::4, ::4],
+         grad_norm_names=np.array(sorted(gn)), grad_norms=np.array([gn[k] for k in sorted(gn)]),
+         **{"grad." + k: named[k].grad for k in FULL_TRAIN_KEEP})
+
+
 def gen_lpips():
     """the REFERENCE's LPIPS class (modules/losses/lpips.py) on 64 x 64 images, with its shipped `lin` weights, over a stand-in for
     `torchvision.models.vgg16`: torchvision is not installed and its ImageNet checkpoint cannot be fetched, so the trunk has the
@@ -503,5 +545,7 @@ if __name__ == "__main__":
     if not only or "train" in only:
         gen_train()
         gen_train_gan()
+    if not only or "trainfull" in only:
+        gen_train_full()
     if not only or "lpips" in only:
         gen_lpips()

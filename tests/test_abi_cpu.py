@@ -69,10 +69,12 @@ def test_argument_validation_without_gpu():
     assert lib.sgam_attention_h16_workspace_bytes(4096, 256) == 2 * 4096 * 256 * 2 + 8 * 4096 * 256 * 4 + 8 * 4096 * 8
     assert lib.sgam_attention_h16_workspace_bytes(4096, 128) == -1
     assert lib.sgam_attention_h16(None, None, None, 1, 768, 4096, 256, 0.0625, None, 256, None, 0, None) == -1
-    # batched forms: fewer key ranges per image as the batch fills the chip by itself (8 images of 64 x 64: one range)
+    # batched forms: fewer key ranges per image as the batch fills the chip by itself (four or more 64 x 64 images: two ranges of 2048 keys)
     assert lib.sgam_attention_f32x_batched_workspace_bytes(4096, 256, 1) == lib.sgam_attention_f32x_workspace_bytes(4096, 256)
-    assert lib.sgam_attention_f32x_batched_workspace_bytes(4096, 256, 8) == 8 * (2 * 4096 * 256 * 4 + 4096 * 256 * 4 + 4096 * 8)
+    assert lib.sgam_attention_f32x_batched_workspace_bytes(4096, 256, 8) == 8 * (2 * 4096 * 256 * 4 + 2 * 4096 * 256 * 4 + 2 * 4096 * 8)
     assert lib.sgam_attention_f32x_batched_workspace_bytes(4096, 256, 4) == 4 * (2 * 4096 * 256 * 4 + 2 * 4096 * 256 * 4 + 2 * 4096 * 8)
+    assert lib.sgam_attention_f32x_batched_workspace_bytes(16384, 256, 4) == 4 * lib.sgam_attention_f32x_workspace_bytes(16384, 256)
+    assert lib.sgam_attention_f32x_workspace_bytes(16384, 256) == 2 * 16384 * 256 * 4 + 8 * 16384 * 256 * 4 + 8 * 16384 * 8   # <= 2048 keys / range
     assert lib.sgam_attention_h16_batched_workspace_bytes(4096, 256, 2) == 2 * (2 * 4096 * 256 * 2 + 4 * 4096 * 256 * 4 + 4 * 4096 * 8)
     assert lib.sgam_attention_f32x_batched_workspace_bytes(4096, 256, 0) == -1
     assert lib.sgam_attention_f32x_batched(None, None, None, 768, 4096, 256, 4, 0.0625, None, 256, None, 0, None) == -1

@@ -395,7 +395,7 @@ def test_fused_attention_at_the_512sq_size():
                                     (4, 4096, "fp16"), (8, 4096, "bf16")])
 def test_batched_attention_keeps_every_query_inside_its_image(B, n, dt):
     """sgam_attention_{f32x,h16}_batched: B images stacked along the rows in ONE launch sequence (fewer key ranges per image
-    as the batch fills the chip: 8, 4, 2, 1).  Every image's rows against its own unbatched run (same arithmetic per key
+    as the batch fills the chip: 8, 4, 2; never more than 2048 keys per range).  Every image's rows against its own unbatched run (same arithmetic per key
     block, a different number of ranges merged at the end: fp32 round-off) and image 0 against fp64 — a query that saw another
     image's keys would be off by O(1)."""
     C = 256
