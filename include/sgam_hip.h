@@ -157,6 +157,15 @@ int sgam_conv2d_gn_nhwc_f32x(const sgam_conv_desc *d, const float *x, const floa
                              const float *gn_beta, int32_t gn_swish, const void *w_planes, float w_scale, const float *bias,
                              const float *residual, float *out, double *gn_partial, void *workspace, int64_t workspace_bytes,
                              void *stream);
+/* The same with the statistics of x still as its PRODUCER's chunk partials ([B][chunks_in][32][2] fp64 {sum, sumsq}, what
+ * sgam_conv2d_stats_nhwc_f32x / the split-K combine leave): the convolution folds them itself, no fold launch in between.  Offered
+ * where the fold is cheap — sgam_conv2d_f32x_gn_foldable(d, chunks_in) == 1: at most 16 chunks (the group-major combine of the
+ * 16^2 / 32^2 maps leaves 8 - 16) and at most two channel slabs per workgroup. */
+int32_t sgam_conv2d_f32x_gn_foldable(const sgam_conv_desc *d, int32_t chunks_in);
+int sgam_conv2d_gnp_nhwc_f32x(const sgam_conv_desc *d, const float *x, const double *gn_partial_in, int32_t chunks_in, float eps,
+                              const float *gn_gamma, const float *gn_beta, int32_t gn_swish, const void *w_planes, float w_scale,
+                              const float *bias, const float *residual, float *out, double *gn_partial, void *workspace,
+                              int64_t workspace_bytes, void *stream);
 int sgam_groupnorm_stats_from_partials_f32(const double *partial, int32_t nchunk, float *mean_rstd, int32_t B, int32_t HW,
                                            int32_t C, int32_t groups, float eps, void *stream);
 int sgam_groupnorm_meanrstd_nhwc_f32(const float *x, float *mean_rstd, int32_t B, int32_t HW, int32_t C, int32_t groups,
@@ -491,6 +500,12 @@ int sgam_axpby_f32(const float *a, const float *b, float *out, int64_t n, float 
 /* torch.optim.Adam step (no weight decay / amsgrad) on one tensor; step = 1, 2, ... */
 int sgam_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
                        float beta2, float eps, int32_t step, void *stream);
+/* The same step for a whole parameter set in ONE launch (`opt.step()` over the 159 / 345 tensors of a phase).  All seven arrays are
+ * DEVICE arrays: per tensor t the four pointers and numels[t]; per workgroup b the tensor block_tensor[b] it works on and the
+ * first element block_off[b] of its 4096-element chunk (the host lists ceil(numel / 4096) workgroups per tensor, n_blocks in all). */
+int sgam_adam_multi_step_f32(float *const *params, const float *const *grads, float *const *exp_avgs, float *const *exp_avg_sqs,
+                             const int64_t *numels, const int32_t *block_tensor, const int64_t *block_off, int32_t n_blocks, float lr,
+                             float beta1, float beta2, float eps, int32_t step, void *stream);
 
 /* PatchGAN discriminator pieces (modules/discriminator/model.py:17-67; hinge loss and adaptive weight,
  * modules/losses/vqperceptual.py:17-21, 63-75): nn.BatchNorm2d in training mode over [rows = B*H*W][C] NHWC matrices

@@ -55,6 +55,9 @@ PROTOTYPES = {
     "sgam_conv2d_f32x_uses_halo": (c_i32, [ctypes.POINTER(ConvDesc)]),
     "sgam_conv2d_gn_nhwc_f32x": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_f32, c_vp, c_vp,
                                          c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "sgam_conv2d_f32x_gn_foldable": (c_i32, [ctypes.POINTER(ConvDesc), c_i32]),
+    "sgam_conv2d_gnp_nhwc_f32x": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_i32, c_f32, c_vp, c_vp, c_i32, c_vp, c_f32, c_vp,
+                                          c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "sgam_groupnorm_stats_from_partials_f32": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp]),
     "sgam_groupnorm_meanrstd_nhwc_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_i64, c_vp]),
     "sgam_tsdf_integrate_f32": (c_i32, [ctypes.POINTER(TsdfGrid), c_vp, c_i32, c_i32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp,
@@ -79,6 +82,7 @@ PROTOTYPES = {
     "sgam_vq_codebook_grad_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_vp]),
     "sgam_axpby_f32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_vp]),
     "sgam_adam_step_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp]),
+    "sgam_adam_multi_step_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp]),
     "sgam_batchnorm_workspace_bytes": (c_i64, [c_i32, c_i32]),
     "sgam_batchnorm_stats_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_vp, c_i64, c_vp]),
     "sgam_bn_lrelu_fwd_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp]),

@@ -50,6 +50,13 @@ struct XParams {
     // [B][32][2] + the affine parameters [Cin]; the per-channel scale / shift are formed in the kernel
     const float *gn_stats, *gn_gamma, *gn_beta;
     int gn_swish;        // ... followed by swish
+    // ... or, instead of gn_stats, the producer's partial sums [B][gn_chunks_in][32][2] (fp64 {sum, sumsq} per chunk and group),
+    // folded by the consumer itself (GNF kernels: a few chunks, one or two channel slabs per workgroup — no fold launch)
+    const double *gn_partial_in;
+    double gn_inv_n;     // 1 / (pixels per image x channels per group)
+    int gn_chunks_in;
+    float gn_eps;
+    int red_tc;          // group-major split-K combine: channels per workgroup tile (32, 16 or 8); 0 = row-major combine
 
     double *gn_partial;  // optional: per-(row-half of the tile, group) {sum, sumsq} of the OUTPUT for the next GroupNorm
     int gn_cpg;          // channels per group of that GroupNorm (N / 32)
@@ -135,9 +142,36 @@ __device__ __forceinline__ void xcd_block(const XParams &p, int &bx, int &by, in
 // per-channel {scale, shift} of the fused input GroupNorm for channels c .. c+3 (one group: 32 groups of >= 4 channels):
 // scale = rstd * gamma, shift = beta - mean * scale — the same expressions, in the same order, as the stand-alone
 // GroupNorm kernels, so fused and two-pass results are bit-identical.  t0 = {s0, h0, s1, h1}, t1 = {s2, h2, s3, h3}.
+template <bool GNF = false>
 __device__ __forceinline__ void gn_scale_shift(const XParams &p, int b, int c, f32x4 &t0, f32x4 &t1) {
     const int g = c / (p.Cin / 32);
-    const float mean = p.gn_stats[(b * 32 + g) * 2], rstd = p.gn_stats[(b * 32 + g) * 2 + 1];
+    float mean, rstd;
+    if constexpr (GNF) {
+        // fold the producer's chunk partials of this group and finish like gn_finalize_stats_kernel.  The caller's staging map
+        // gives the eight lanes l, l ^ 8, l ^ 16, l ^ 32 ... of a wavefront the same channel quad, hence the same group: lane
+        // sub = l >> 3 fetches chunks sub and sub + 8 (both loads in flight at once — a per-chunk loop would be a chain of
+        // dependent L2 round trips: +4 .. 8 us per launch, measured), a three-step xor butterfly adds them in a fixed order
+        const int sub = (threadIdx.x & 63) >> 3;
+        const double *q = p.gn_partial_in + ((int64_t)b * p.gn_chunks_in * 32 + g) * 2;
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+        const f64x2 z = {0.0, 0.0};
+        const f64x2 a = sub < p.gn_chunks_in ? *reinterpret_cast<const f64x2 *>(q + (int64_t)sub * 64) : z;
+        const f64x2 c = sub + 8 < p.gn_chunks_in ? *reinterpret_cast<const f64x2 *>(q + (int64_t)(sub + 8) * 64) : z;
+        double s = a[0] + c[0], ss = a[1] + c[1];
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) {
+            s += __shfl_xor(s, o, 64);
+            ss += __shfl_xor(ss, o, 64);
+        }
+        const double m = s * p.gn_inv_n;
+        double var = ss * p.gn_inv_n - m * m;
+        if (var < 0.0) var = 0.0;
+        mean = (float)m;
+        rstd = (float)(1.0 / sqrt(var + (double)p.gn_eps));
+    } else {
+        mean = p.gn_stats[(b * 32 + g) * 2];
+        rstd = p.gn_stats[(b * 32 + g) * 2 + 1];
+    }
     const f32x4 ga = *reinterpret_cast<const f32x4 *>(p.gn_gamma + c), be = *reinterpret_cast<const f32x4 *>(p.gn_beta + c);
     float sc[4], sh[4];
 #pragma unroll
@@ -540,8 +574,9 @@ __global__ __launch_bounds__(256 * wk_of(BM, BN)) void conv_gemm_f32x_kernel(con
 // UPS: the conv runs on the nearest-2x upsampled input without materialising it — the staged halo is the SOURCE patch
 // ((TH/2 + 2) x (TW/2 + 2) pixels: a third of the pixels), and a lane finds the source pixel of (patch pixel, tap) as
 // ((p + k - 1) >> 1) + 1 per axis.
-template <int BM, int BN, bool GN, bool UPS = false>
+template <int BM, int BN, bool GN, bool UPS = false, bool GNF = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParams p) {
+    static_assert(!GNF || GN, "GNF = GroupNorm statistics folded from the producer's chunk partials: a GN kernel");
 #ifndef SGAM_XWGM
 #define SGAM_XWGM 1
 #endif
@@ -616,7 +651,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
         for (int j = 0; j < NH; ++j)
             hreg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(live ? h_off[j] : 0xFFFFFFFFu), (int)coff, SGAM_XNT));
         if constexpr (GN) {
-            gn_scale_shift(p, b, (live ? ch : 0) * XBK + (tid & 7) * 4, gt0, gt1);
+            gn_scale_shift<GNF>(p, b, (live ? ch : 0) * XBK + (tid & 7) * 4, gt0, gt1);
         }
     };
     auto hprep_piece = [&](const int j) {
@@ -1123,6 +1158,71 @@ __global__ __launch_bounds__(256) void splitk_reduce_f32x_kernel(const XParams p
     }
 }
 
+// GROUP-MAJOR form of the combine for the small maps (16^2, 32^2): a workgroup owns TR = 1024 / TC whole-column runs of TC
+// channels (a 128- / 64- / 32-byte piece of TR consecutive output rows) instead of 1024 / N whole rows, so that a GroupNorm group
+// is covered by hw / TR <= 16 workgroups instead of hw N / 1024 (128 - 256): few enough chunk partials for the CONSUMING
+// convolution to fold them itself (GNF kernels) — the 32-workgroup fold launch between the two disappears.  Same fixed
+// summation orders (slabs z = 0, 1, ...; rows top to bottom), so results do not depend on scheduling.
+template <int TC>
+__global__ __launch_bounds__(256) void splitk_reduce_gm_f32x_kernel(const XParams p) {
+    constexpr int TR = 1024 / TC, TPR = TC / 4;
+    const int col_tiles = p.N / TC;
+    const int rt = blockIdx.x / col_tiles, ct = blockIdx.x - rt * col_tiles;
+    const int row = threadIdx.x / TPR, c4 = threadIdx.x - row * TPR;
+    const int m = rt * TR + row, n = ct * TC + c4 * 4;            // host: M % TR == 0, N % TC == 0, n_valid == N
+    const float *w0 = p.ws + (int64_t)m * p.N + n;
+    const int64_t zs = (int64_t)p.M * p.N;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f}, rv = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bv = p.bias_per_row ? f32x4{p.bias[m], p.bias[m], p.bias[m], p.bias[m]} : *reinterpret_cast<const f32x4 *>(p.bias + n);
+    if (p.res) rv = *reinterpret_cast<const f32x4 *>(p.res + (int64_t)m * p.ldr + n);
+    f32x4 s = *reinterpret_cast<const f32x4 *>(w0);
+    int z = 1;
+    for (; z + 4 <= p.ksplit; z += 4) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(w0 + z * zs), b = *reinterpret_cast<const f32x4 *>(w0 + (z + 1) * zs);
+        const f32x4 c = *reinterpret_cast<const f32x4 *>(w0 + (z + 2) * zs), d = *reinterpret_cast<const f32x4 *>(w0 + (z + 3) * zs);
+        s += a;
+        s += b;
+        s += c;
+        s += d;
+    }
+    for (; z < p.ksplit; ++z) s += *reinterpret_cast<const f32x4 *>(w0 + z * zs);
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v[e] = s[e] * p.inv_w_scale;
+        if (p.bias) v[e] += bv[e];
+        if (p.res) v[e] += rv[e];
+    }
+    *reinterpret_cast<f32x4 *>(p.out + (int64_t)m * p.ldc + n) = v;
+    float gs = (v[0] + v[1]) + (v[2] + v[3]);
+    float gss = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    if (p.range_flag && sgam_not_finite(gs)) atomicOr(p.range_flag, 1);
+    if (!p.gn_partial) return;
+    const int lpg = p.gn_cpg / 4;                       // lanes per (row, group): 1, 2, 4 or 8 neighbours (cpg <= TC)
+    for (int o = 1; o < lpg; o <<= 1) {
+        gs += __shfl_xor(gs, o, 64);
+        gss += __shfl_xor(gss, o, 64);
+    }
+    __shared__ float sh[256][2];                        // [row][group in tile]: TR * (TC / cpg) = 1024 / cpg <= 256 entries
+    const int gt = TC / p.gn_cpg, gl = c4 / lpg;
+    if ((c4 % lpg) == 0) {
+        sh[row * gt + gl][0] = gs;
+        sh[row * gt + gl][1] = gss;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < gt) {
+        double ds = 0.0, dss = 0.0;
+        for (int r = 0; r < TR; ++r) {
+            ds += (double)sh[r * gt + threadIdx.x][0];
+            dss += (double)sh[r * gt + threadIdx.x][1];
+        }
+        // chunk = row tile inside the image (image-major: rt counts over the whole batch, hw % TR == 0)
+        double *o = p.gn_partial + ((int64_t)rt * 32 + ct * gt + threadIdx.x) * 2;
+        o[0] = ds;
+        o[1] = dss;
+    }
+}
+
 // B-operand storage = MFMA-fragment order: [row tile of 32][K slab of 32][plane hi/lo][k-step][k-half][row][8 halfs], i.e.
 // per (row tile, slab) 256 pieces of 16 bytes with piece = ((plane * 2 + k-step) * 2 + k-half) * 32 + row — exactly what
 // the 64 lanes of a wavefront need for one v_mfma_f32_32x32x16_f16 B operand sit in one contiguous kilobyte.
@@ -1271,6 +1371,9 @@ extern "C" int sgam_conv2d_f32x_plan(const sgam_conv_desc *d, int32_t *bm, int32
 struct XExtra {            // optional fusions around the product
     const float *gn_stats = nullptr, *gn_gamma = nullptr, *gn_beta = nullptr;   // GroupNorm(+swish) of the input (halo kernels)
     int gn_swish = 0;
+    const double *gn_partial_in = nullptr;   // ... with the statistics still as the producer's chunk partials (folded in the kernel)
+    int gn_chunks_in = 0;
+    float gn_eps = 1e-6f;
     double *gn_partial = nullptr;     // statistics of the output: per-chunk partial sums (epilogue or split-K combine)
 };
 
@@ -1293,6 +1396,19 @@ extern "C" int32_t sgam_conv2d_f32x_gn_fusable(const sgam_conv_desc *d) {
     return halo_eligible(d, make_xplan(d), 1.0f) ? 1 : 0;
 }
 
+// channels per workgroup tile of the group-major combine for this descriptor (32, 16 or 8), 0 = keep the row-major combine:
+// a group (N / 32 channels) must fit a tile and an image must fall into at most 16 row tiles
+static int red_tc_for(const sgam_conv_desc *d) {
+    static const int on = [] { const char *e = getenv("SGAM_GN_FOLD"); return (e && e[0] == '0') ? 0 : 1; }();
+    const int hw = d->Ho * d->Wo, cpg = d->N / 32;
+    if (!on || d->N % 128 != 0 || d->n_valid != d->N || d->N > 1024) return 0;
+    for (int tc = 32; tc >= 8; tc >>= 1) {
+        const int tr = 1024 / tc;
+        if (tc >= cpg && hw % tr == 0 && hw / tr <= 16) return tc;
+    }
+    return 0;
+}
+
 extern "C" int32_t sgam_conv2d_f32x_stats_chunks(const sgam_conv_desc *d) {
     if (xvalidate(d) != SGAM_OK) return -1;
     const XPlan pl = make_xplan(d);
@@ -1304,7 +1420,9 @@ extern "C" int32_t sgam_conv2d_f32x_stats_chunks(const sgam_conv_desc *d) {
         if (d->B > 1 && hw % pl.bm != 0) return 0;                                 // a tile must not straddle two images
         return ((hw + pl.bm - 1) / pl.bm) * 2;
     }
-    // from the split-K combine: one chunk per workgroup of 1024 outputs = 1024 / N whole rows
+    // from the split-K combine: group-major tiles on the small maps (hw / TR <= 16 chunks, foldable by the consumer), else
+    // one chunk per workgroup of 1024 outputs = 1024 / N whole rows
+    if (const int tc = red_tc_for(d)) return hw / (1024 / tc);
     if (d->N > 1024 || 1024 % d->N != 0 || ((int64_t)hw * d->N) % 1024 != 0) return 0;
     return (int32_t)((int64_t)hw * d->N / 1024);
 }
@@ -1328,6 +1446,33 @@ extern "C" int sgam_conv2d_gn_nhwc_f32x(const sgam_conv_desc *d, const float *x,
         return SGAM_EINVAL;
     XExtra ex;
     ex.gn_stats = gn_mean_rstd; ex.gn_gamma = gn_gamma; ex.gn_beta = gn_beta; ex.gn_swish = gn_swish ? 1 : 0;
+    ex.gn_partial = gn_partial;
+    if (check_stats_out(d, ex) != SGAM_OK) return SGAM_EINVAL;
+    return conv_f32x_impl(d, x, 1.0f, w_planes, w_scale, bias, residual, out, workspace, workspace_bytes, stream, ex);
+}
+
+// 1 when a convolution of this descriptor can normalise its input from `chunks_in` chunk partials per image by itself (the
+// folding form of the 64-row halo kernel: at most 16 chunks, at most two channel slabs per workgroup, so that the fold — which is
+// repeated per slab — stays a few hundred cycles in the prologue), 0: fold them first (sgam_groupnorm_stats_from_partials_f32)
+extern "C" int32_t sgam_conv2d_f32x_gn_foldable(const sgam_conv_desc *d, int32_t chunks_in) {
+    static const int on = [] { const char *e = getenv("SGAM_GN_FOLD"); return (e && e[0] == '0') ? 0 : 1; }();
+    if (!on || chunks_in < 1 || chunks_in > 16 || sgam_conv2d_f32x_gn_fusable(d) != 1 || d->Cin % 128 != 0) return 0;
+    const XPlan pl = make_xplan(d);
+    return (pl.bm == 64 && pl.bn == 128 && pl.iters_per_split <= 18) ? 1 : 0;
+}
+
+// sgam_conv2d_gn_nhwc_f32x with the statistics of x still as its producer's chunk partials [B][chunks_in][32][2] (fp64 {sum,
+// sumsq}): the kernel folds them (needs sgam_conv2d_f32x_gn_foldable(d, chunks_in) == 1)
+extern "C" int sgam_conv2d_gnp_nhwc_f32x(const sgam_conv_desc *d, const float *x, const double *gn_partial_in, int32_t chunks_in,
+                                         float eps, const float *gn_gamma, const float *gn_beta, int32_t gn_swish, const void *w_planes,
+                                         float w_scale, const float *bias, const float *residual, float *out, double *gn_partial,
+                                         void *workspace, int64_t workspace_bytes, void *stream) {
+    if (!gn_partial_in || !gn_gamma || !gn_beta || !sgam_aligned16(gn_partial_in) || !sgam_aligned16(gn_gamma) ||
+        !sgam_aligned16(gn_beta) || !(eps > 0.f) || sgam_conv2d_f32x_gn_foldable(d, chunks_in) != 1)
+        return SGAM_EINVAL;
+    XExtra ex;
+    ex.gn_partial_in = gn_partial_in; ex.gn_chunks_in = chunks_in; ex.gn_eps = eps;
+    ex.gn_gamma = gn_gamma; ex.gn_beta = gn_beta; ex.gn_swish = gn_swish ? 1 : 0;
     ex.gn_partial = gn_partial;
     if (check_stats_out(d, ex) != SGAM_OK) return SGAM_EINVAL;
     return conv_f32x_impl(d, x, 1.0f, w_planes, w_scale, bias, residual, out, workspace, workspace_bytes, stream, ex);
@@ -1370,6 +1515,9 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
     p.gn_cpg = d->N / 32;
     p.gn_stats = ex.gn_stats; p.gn_gamma = ex.gn_gamma; p.gn_beta = ex.gn_beta;
     p.gn_swish = ex.gn_swish;
+    p.gn_partial_in = ex.gn_partial_in; p.gn_chunks_in = ex.gn_chunks_in; p.gn_eps = ex.gn_eps;
+    p.gn_inv_n = 1.0 / ((double)d->Hi * d->Wi * (d->Cin / 32));
+    p.red_tc = 0;
 
     const int64_t xb = (((int64_t)d->B * d->Hi * d->Wi - 1) * d->lda + d->Cin) * 4;
     const int64_t wb = (int64_t)((d->N + 31) / 32 * 32) * d->ldb * 4;   // fragment order over [N rounded up to 32][ldb]
@@ -1396,7 +1544,8 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
     if (p.ups && a_scale != 1.0f) return SGAM_EINVAL;
     if (d->KH * d->KW > 32) return SGAM_EINVAL;   // tap validity mask is 32 bits
     const bool halo = halo_eligible(d, pl, a_scale);
-    if (ex.gn_stats && !halo) return SGAM_EINVAL;
+    if ((ex.gn_stats || ex.gn_partial_in) && !halo) return SGAM_EINVAL;
+    if (ex.gn_partial_in && (pl.bm != 64 || p.ups)) return SGAM_EINVAL;       // the folding consumer is the 64-row halo kernel
     // algorithmic work of this launch: 2 M N K fp32 FLOP; bytes = input + weights + output once
     if (sgam_i_prof_on) sgam_i_prof_shape(p.M, d->n_valid, d->KH * d->KW * d->Cin, pl.ksplit);
     if (sgam_i_prof_on)
@@ -1415,7 +1564,8 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
             if (p.gn_stats) SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<128, 128, true>), grid, dim3(256), 0, s, p);
             else SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<128, 128, false>), grid, dim3(256), 0, s, p);
         } else {
-            if (p.gn_stats) SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<64, 128, true>), grid, dim3(256), 0, s, p);
+            if (p.gn_partial_in) SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<64, 128, true, false, true>), grid, dim3(256), 0, s, p);
+            else if (p.gn_stats) SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<64, 128, true>), grid, dim3(256), 0, s, p);
             else SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<64, 128, false>), grid, dim3(256), 0, s, p);
         }
     } else if (pl.bm == 128 && pl.bn == 128) XLAUNCH(128, 128);
@@ -1425,7 +1575,11 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
     SGAM_LAUNCH_CHECK();
     if (pl.ksplit > 1) {
         const int64_t q = (int64_t)p.M * (p.N / 4);
-        SGAM_KLAUNCH(splitk_reduce_f32x_kernel, dim3(sgam_cdiv(q, 256)), dim3(256), 0, s, p);
+        const int tc = p.gn_partial ? red_tc_for(d) : 0;
+        if (tc == 32) SGAM_KLAUNCH(splitk_reduce_gm_f32x_kernel<32>, dim3((unsigned)(q / 256)), dim3(256), 0, s, p);
+        else if (tc == 16) SGAM_KLAUNCH(splitk_reduce_gm_f32x_kernel<16>, dim3((unsigned)(q / 256)), dim3(256), 0, s, p);
+        else if (tc == 8) SGAM_KLAUNCH(splitk_reduce_gm_f32x_kernel<8>, dim3((unsigned)(q / 256)), dim3(256), 0, s, p);
+        else SGAM_KLAUNCH(splitk_reduce_f32x_kernel, dim3(sgam_cdiv(q, 256)), dim3(256), 0, s, p);
         SGAM_LAUNCH_CHECK();
     }
     return SGAM_OK;

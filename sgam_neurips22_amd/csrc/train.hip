@@ -298,6 +298,32 @@ __global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, 
     p[i] -= step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
 }
 
+// the same update for a whole parameter SET in one launch (opt.step() of the reference walks ~160-350 tensors): workgroup b takes
+// elements [block_off[b], block_off[b] + 4096) of tensor block_tensor[b]; the four pointer tables are device arrays
+constexpr int ADAM_CHUNK = 4096;
+__global__ __launch_bounds__(256) void adam_multi_kernel(float *const *__restrict__ ps, const float *const *__restrict__ gs,
+                                                         float *const *__restrict__ ms, float *const *__restrict__ vs,
+                                                         const int64_t *__restrict__ ns, const int32_t *__restrict__ block_tensor,
+                                                         const int64_t *__restrict__ block_off, float b1, float b2, float step_size,
+                                                         float inv_sqrt_bc2, float eps) {
+    const int t = block_tensor[blockIdx.x];
+    const int64_t n = ns[t], i0 = block_off[blockIdx.x];
+    float *__restrict__ p = ps[t], *__restrict__ m = ms[t], *__restrict__ v = vs[t];
+    const float *__restrict__ g = gs[t];
+#pragma unroll 4
+    for (int k = 0; k < ADAM_CHUNK / 256; ++k) {
+        const int64_t i = i0 + k * 256 + threadIdx.x;
+        if (i < n) {
+            const float gi = g[i];
+            const float mi = b1 * m[i] + (1.0f - b1) * gi;
+            const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+            m[i] = mi;
+            v[i] = vi;
+            p[i] -= step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+        }
+    }
+}
+
 // ---- PatchGAN discriminator pieces (modules/discriminator/model.py: Conv 4x4 -> [BatchNorm2d] -> LeakyReLU(0.2)) ----
 // BatchNorm2d in training mode over the rows (= batch x pixels) of an NHWC matrix [rows][C]: per-channel partial sums of x and
 // x^2 over row chunks (fp64), folded by bn_fold_kernel into {mean, rstd} (biased variance, as F.batch_norm normalises) and
@@ -691,6 +717,18 @@ extern "C" int sgam_adam_step_f32(float *param, const float *grad, float *exp_av
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     SGAM_KLAUNCH(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sgam_stream(stream), param, grad, exp_avg, exp_avg_sq, n,
                  beta1, beta2, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), eps);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+extern "C" int sgam_adam_multi_step_f32(float *const *params, const float *const *grads, float *const *exp_avgs, float *const *exp_avg_sqs,
+                                        const int64_t *numels, const int32_t *block_tensor, const int64_t *block_off, int32_t n_blocks,
+                                        float lr, float beta1, float beta2, float eps, int32_t step, void *stream) {
+    if (!params || !grads || !exp_avgs || !exp_avg_sqs || !numels || !block_tensor || !block_off || n_blocks <= 0 || step <= 0)
+        return SGAM_EINVAL;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    SGAM_KLAUNCH(adam_multi_kernel, dim3((unsigned)n_blocks), dim3(256), 0, sgam_stream(stream), params, grads, exp_avgs, exp_avg_sqs,
+                 numels, block_tensor, block_off, beta1, beta2, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), eps);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
 }

@@ -349,7 +349,10 @@ def _run_conv(desc, x, w, bias, residual, out, gn=None, a_scale=1.0, norm=None):
         have = getattr(x, "_gn_partials", None) is not None
         h16_fusable = (x.dtype in H16 and FUSE_GN_APPLY and x.dim() == 4 and groups == 32 and eps == 1e-6
                        and x.shape[3] % 128 == 0 and not desc.upsample2x and _h16_frag(w, desc) is not None)
-        if fusable and (have or x.shape[1] * x.shape[2] > 1024):
+        if fusable and have and lib.sgam_conv2d_f32x_gn_foldable(ctypes.byref(desc), x._gn_partials[1]) == 1:
+            # few enough chunk partials (the group-major split-K combine of a 16^2 / 32^2 map): the conv folds them itself
+            gn = (x._gn_partials, gamma, beta, swish, eps)
+        elif fusable and (have or x.shape[1] * x.shape[2] > 1024):
             gn = (groupnorm_meanrstd(x, eps), gamma, beta, swish)
         elif h16_fusable:
             gn = (groupnorm_meanrstd(x, eps), _f32c(gamma), _f32c(beta), swish)
@@ -404,9 +407,16 @@ def _run_conv_inner(lib, desc, x, w, bias, residual, out, gn=None, a_scale=1.0):
 
         if gn is not None:
             # GroupNorm(+swish) of x applied while the 3x3 kernel stages its input patch
-            mean_rstd, gamma, beta, swish = gn
             if a_scale != 1.0 or lib.sgam_conv2d_f32x_gn_fusable(ctypes.byref(desc)) != 1:
                 raise SgamHipError("split fp32 conv: fused GroupNorm needs the halo-staged 3x3 kernel (sgam_conv2d_f32x_gn_fusable)")
+            if len(gn) == 5:           # statistics as the producer's chunk partials, folded inside the kernel
+                (part_in, chunks_in), gamma, beta, swish, eps = gn
+                gamma, beta = _f32c(gamma), _f32c(beta)
+                check(lib.sgam_conv2d_gnp_nhwc_f32x(ctypes.byref(desc), _p(x), _p(part_in), int(chunks_in), float(eps), _p(gamma), _p(beta),
+                                                    int(swish), _p(w.planes), float(w.scale), _p(bias), _p(residual), _p(out), _p(partial),
+                                                    _p(ws), ws_bytes, _stream()), "sgam_conv2d_gnp_nhwc_f32x")
+                return tag(out)
+            mean_rstd, gamma, beta, swish = gn
             gamma, beta = _f32c(gamma), _f32c(beta)
             check(lib.sgam_conv2d_gn_nhwc_f32x(ctypes.byref(desc), _p(x), _p(mean_rstd), _p(gamma), _p(beta), int(swish),
                                                _p(w.planes), float(w.scale), _p(bias), _p(residual), _p(out), _p(partial),

@@ -142,8 +142,17 @@ class _Conv:
                 self.grads[self.conv.bias] = _colsum(dy2)[:self.cout].contiguous() if self.cout_k != self.cout else _colsum(dy2)
         if not need_dx:
             return None
-        # W^T [K][cout_k]: the packed rows (padded to cout_k) transposed
-        wT = _transpose2d(ops.pack_conv_weight(self.conv.weight, cout_pad=self.cout_k, cin_pad=self.cin_pad, dtype=torch.float32))
+        # W^T [K][cout_k]: the packed rows (padded to cout_k) transposed.  A layer that is frozen in this phase (need_wgrad False: e.g.
+        # the whole decoder while `conditional_generation` trains the encoder) keeps the copy across steps (two launches fewer per
+        # layer and step); trained weights are re-packed every step (Adam writes through the raw pointer: no version bump to key on)
+        w = self.conv.weight
+        wkey = (w.data_ptr(), w._version)
+        if not self.need_wgrad and getattr(self, "_wT_key", None) == wkey:
+            wT = self._wT
+        else:
+            wT = _transpose2d(ops.pack_conv_weight(w, cout_pad=self.cout_k, cin_pad=self.cin_pad, dtype=torch.float32))
+            if not self.need_wgrad:
+                self._wT, self._wT_key = wT, wkey
         dcol = ops.gemm_nt(dy2, wT)                                        # [M][K]
         if pointwise:
             return dcol.reshape(x.shape)
@@ -206,7 +215,8 @@ class _ResBlock:
 
 
 class _Attn:
-    """AttnBlock (model.py:140-192): x + proj_out(softmax(q k^T c^-1/2) v) on norm(x), one image at a time"""
+    """AttnBlock (model.py:140-192): x + proj_out(softmax(q k^T c^-1/2) v) on norm(x), one image at a time, one panel of query
+    rows at a time"""
 
     def __init__(self, att, grads, train):
         self.att, self.grads = att, grads
@@ -214,19 +224,33 @@ class _Attn:
         self.q, self.k, self.v = (_Conv(m, grads, need_wgrad=train) for m in (att.q, att.k, att.v))
         self.proj = _Conv(att.proj_out, grads, need_wgrad=train)
 
+    CHUNK_BYTES = 64 << 20      # budget of one (rows x n) fp32 score panel: 4096 x 4096 in one piece, 1024 rows at n = 16384
+
+    def _rows(self, n):
+        r = max(32, min(n, (self.CHUNK_BYTES // (4 * n)) // 32 * 32))
+        while n % r:
+            r -= 32
+        return r
+
     def fwd(self, x):
         B, H, W, C = x.shape
         n = H * W
         h = self.norm.fwd(x)
         q, k, v = self.q.fwd(h), self.k.fwd(h), self.v.fwd(h)
         self.scale = float(C) ** -0.5
-        self.saved = []
+        # the tape keeps q, k, v only (3 n C floats per image): the n x n probabilities are RECOMPUTED in the backward pass, one
+        # panel of query rows at a time (flash-style at the GEMM level) — at n = 4096 that is 64 MB per image and block that no
+        # longer sit on the tape across the whole step, at n = 16384 (1 GiB per image) it is what makes the step fit at all
+        self.saved = (q, k, v)
         o = torch.empty_like(q)
+        R = self._rows(n)
         for b in range(B):
             qb, kb, vb = (t[b].reshape(n, C) for t in (q, k, v))
-            p = ops.softmax_rows_(ops.gemm_nt(qb, kb), self.scale)            # [n][n] = softmax over keys
-            ops.gemm_nt(p, _transpose2d(vb), out=o[b].reshape(n, C))
-            self.saved.append((qb, kb, vb, p))
+            vT = _transpose2d(vb)
+            ob = o[b].reshape(n, C)
+            for r0 in range(0, n, R):
+                p = ops.softmax_rows_(ops.gemm_nt(qb[r0:r0 + R], kb), self.scale)          # [R][n] = softmax over the keys
+                ops.gemm_nt(p, vT, out=ob[r0:r0 + R])
         return self.proj.fwd(o, residual=x)
 
     def bwd(self, dy):
@@ -234,18 +258,24 @@ class _Attn:
         do = self.proj.bwd(dy)
         B, H, W, C = do.shape
         n = H * W
+        q, k, v = self.saved
         dq, dk, dv = (torch.empty_like(do) for _ in range(3))
+        R = self._rows(n)
         for b in range(B):
-            qb, kb, vb, p = self.saved[b]
-            dob = do[b].reshape(n, C)
-            dp = ops.gemm_nt(dob, vb)                                         # dO v^T
-            pT = _transpose2d(p)
-            ops.gemm_nt(pT, _transpose2d(dob), out=dv[b].reshape(n, C))       # P^T dO
-            ds = torch.empty_like(p)
-            check(lib.sgam_softmax_bwd_rows_f32(_p(p), _p(dp), _p(ds), n, n, p.stride(0), self.scale, _stream()),
-                  "sgam_softmax_bwd_rows_f32")
-            ops.gemm_nt(ds, _transpose2d(kb), out=dq[b].reshape(n, C))        # dS k
-            ops.gemm_nt(_transpose2d(ds), _transpose2d(qb), out=dk[b].reshape(n, C))   # dS^T q
+            qb, kb, vb = (t[b].reshape(n, C) for t in (q, k, v))
+            dob, dqb, dkb, dvb = (t[b].reshape(n, C) for t in (do, dq, dk, dv))
+            kT = _transpose2d(kb)
+            for r0 in range(0, n, R):
+                first = r0 == 0
+                qc, doc = qb[r0:r0 + R], dob[r0:r0 + R]
+                p = ops.softmax_rows_(ops.gemm_nt(qc, kb), self.scale)               # recomputed probabilities of these queries
+                dp = ops.gemm_nt(doc, vb)                                            # dO v^T
+                ops.gemm_nt(_transpose2d(p), _transpose2d(doc), out=dvb, residual=None if first else dvb)      # dV += P^T dO
+                ds = torch.empty_like(p)
+                check(lib.sgam_softmax_bwd_rows_f32(_p(p), _p(dp), _p(ds), R, n, p.stride(0), self.scale, _stream()),
+                      "sgam_softmax_bwd_rows_f32")
+                ops.gemm_nt(ds, kT, out=dqb[r0:r0 + R])                              # dQ = dS k
+                ops.gemm_nt(_transpose2d(ds), _transpose2d(qc), out=dkb, residual=None if first else dkb)      # dK += dS^T q
         dh = _axpby(_axpby(self.q.bwd(dq), self.k.bwd(dk)), self.v.bwd(dv))
         return _axpby(self.norm.bwd(dh), dy)
 
@@ -474,17 +504,45 @@ class AutoencoderTrainer:
             o += n
         return flat.numel() * 4
 
+    ADAM_CHUNK = 4096          # elements per workgroup of sgam_adam_multi_step_f32 (csrc/train.hip)
+
     def _adam(self, params, grads, state):
+        """opt.step(): Adam on every tensor of `params` that has a gradient — ONE launch for the whole set
+        (sgam_adam_multi_step_f32: device tables of pointers; only the gradient pointers change from step to step and travel
+        through a pinned staging buffer), instead of one launch per tensor."""
         lib = _lib.load()
-        for p in params:
-            g = grads.get(p)
-            if g is None:
-                continue
-            st = state.get(p)
-            if st is None:
-                st = state[p] = (torch.zeros_like(p.data), torch.zeros_like(p.data))
-            check(lib.sgam_adam_step_f32(_p(p.data), _p(ops._f32c(g)), _p(st[0]), _p(st[1]), p.numel(), self.lr, ADAM_BETAS[0],
-                                         ADAM_BETAS[1], ADAM_EPS, self.global_step, _stream()), "sgam_adam_step_f32")
+        ps = [p for p in params if grads.get(p) is not None]
+        if not ps:
+            return
+        for p in ps:
+            if p not in state:
+                state[p] = (torch.zeros_like(p.data), torch.zeros_like(p.data))
+        dev = ps[0].device
+        tabs = self.__dict__.setdefault("_adam_tabs", {})
+        key = (id(state),) + tuple(id(p) for p in ps)
+        tab = tabs.get(key)
+        if tab is None:
+            i64 = lambda v: torch.tensor(v, dtype=torch.int64, device=dev)  # noqa: E731
+            bt, bo = [], []
+            for t, p in enumerate(ps):
+                for o in range(0, p.numel(), self.ADAM_CHUNK):
+                    bt.append(t)
+                    bo.append(o)
+            tab = tabs[key] = {"p": i64([p.data.data_ptr() for p in ps]), "m": i64([state[p][0].data_ptr() for p in ps]),
+                               "v": i64([state[p][1].data_ptr() for p in ps]), "n": i64([p.numel() for p in ps]),
+                               "bt": torch.tensor(bt, dtype=torch.int32, device=dev), "bo": i64(bo), "blocks": len(bt),
+                               "g": torch.empty((len(ps),), dtype=torch.int64, device=dev),
+                               "g_host": torch.empty((len(ps),), dtype=torch.int64).pin_memory(), "done": None}
+        gs = [ops._f32c(grads[p]) for p in ps]          # (kept alive until the launch is enqueued)
+        if tab["done"] is not None:
+            tab["done"].synchronize()                  # the previous step's upload has left the staging buffer
+        tab["g_host"].copy_(torch.tensor([g.data_ptr() for g in gs], dtype=torch.int64))
+        tab["g"].copy_(tab["g_host"], non_blocking=True)
+        tab["done"] = torch.cuda.Event()
+        tab["done"].record()
+        check(lib.sgam_adam_multi_step_f32(_p(tab["p"]), _p(tab["g"]), _p(tab["m"]), _p(tab["v"]), _p(tab["n"]), _p(tab["bt"]),
+                                           _p(tab["bo"]), tab["blocks"], self.lr, ADAM_BETAS[0], ADAM_BETAS[1], ADAM_EPS,
+                                           self.global_step, _stream()), "sgam_adam_multi_step_f32")
 
     def adam_step(self):
         self.global_step += 1

@@ -319,10 +319,14 @@ def test_halo_kernel_tile_plans(plan):
     _close(out.permute(0, 3, 1, 2), ref, 2e-5, f"halo plan {plan}")
 
 
-@pytest.mark.parametrize("C,H,W", [(512, 16, 16), (256, 32, 32), (256, 64, 64)])
-def test_splitk_combine_delivers_groupnorm_statistics(C, H, W):
+@pytest.mark.parametrize("C,H,W,ks,folds", [(512, 16, 16, 4, False), (256, 32, 32, 4, True), (256, 64, 64, 4, False),
+                                            (512, 16, 16, 16, True), (512, 16, 16, 8, True), (256, 32, 32, 8, True), (256, 32, 32, 2, False),
+                                            (128, 16, 32, 4, True)])
+def test_splitk_combine_delivers_groupnorm_statistics(C, H, W, ks, folds):
     """The split-K combine of a conv also leaves the partial GroupNorm sums of its output; the next 3x3 conv normalises
-    with them while staging (one 32-workgroup fold in between, no pass over the tensor).  Equals the explicit form."""
+    with them while staging (one 32-workgroup fold in between, no pass over the tensor).  Equals the explicit form.
+    `folds`: the 16^2 / 32^2 maps — the combine runs group-major (<= 16 chunk partials per image) and a consumer whose
+    workgroups walk at most two channel slabs folds them in its own prologue: no fold launch at all."""
     ops.set_f32_mode("split")
     x = _nhwc(testing.seeded_tensor("sms.x", (1, C, H, W), 1.1, 0.3)).to(DEV)
     w1 = testing.seeded_tensor("sms.w1", (C, C, 3, 3), scale=(1.0 / (C * 9)) ** 0.5)
@@ -334,10 +338,11 @@ def test_splitk_combine_delivers_groupnorm_statistics(C, H, W):
     kw = dict(cout=C, kh=3, kw=3, pad_t=1, pad_l=1)
     key = f"f32x|B1|{H}x{W}x{C}|{H}x{W}|N{C}|k3x3s1u0"
     old = ops.PLAN_CACHE.get(key)
-    ops.PLAN_CACHE[key] = (64, 128, 4)                 # force a split-K plan
+    ops.PLAN_CACHE[key] = (64, 128, ks)                # force a split-K plan
     try:
         h = ops.conv2d_nhwc(x, p1, None, residual=res, **kw)
         assert hasattr(h, "_gn_partials")
+        assert (h._gn_partials[1] <= 16) == (H * W <= 1024)
         ref_h = F.conv2d(x.permute(0, 3, 1, 2).cpu().double(), w1.double(), padding=1).float() + res.permute(0, 3, 1, 2).cpu()
         _close(h.permute(0, 3, 1, 2), ref_h, 2e-5, "conv + residual through the combine")
         st = ops.groupnorm_meanrstd(h).cpu()
@@ -346,6 +351,12 @@ def test_splitk_combine_delivers_groupnorm_statistics(C, H, W):
         assert torch.allclose(st[0, :, 1].double(), (hg.var(-1, unbiased=False) + 1e-6).rsqrt()[0], rtol=2e-6, atol=0)
         fused = ops.conv2d_nhwc(h, p2, None, norm=(g, bt, True, 32, 1e-6), **kw)
         plain = ops.conv2d_nhwc(ops.groupnorm_nhwc(h.clone(), g, bt, True), p2, None, **kw)
+        recs, _ = ops.kernel_timeline(lambda: ops.conv2d_nhwc(h, p2, None, norm=(g, bt, True, 32, 1e-6), **kw))
+        names = [r[0] for r in recs]
+        assert any("true,false,true" in n for n in names) == folds, names          # the folding form of the halo kernel
+        assert any("gn_finalize" in n for n in names) != folds, names              # ... replaces the fold launch
+        for _ in range(3):
+            assert torch.equal(fused, ops.conv2d_nhwc(h, p2, None, norm=(g, bt, True, 32, 1e-6), **kw))
     finally:
         if old is None:
             ops.PLAN_CACHE.pop(key, None)

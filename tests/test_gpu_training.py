@@ -106,9 +106,13 @@ def test_groupnorm_swish_backward(swish):
     assert _rel(grads[norm.weight], gr.grad) <= 1e-4 and _rel(grads[norm.bias], br.grad) <= 1e-4
 
 
-def test_attention_block_backward():
-    """AttnBlock (model.py:140-192) forward + backward through the GEMM chain and sgam_softmax_bwd_rows_f32"""
+@pytest.mark.parametrize("panel_rows", [None, 32], ids=["one_panel", "two_panels"])
+def test_attention_block_backward(panel_rows, monkeypatch):
+    """AttnBlock (model.py:140-192) forward + backward through the GEMM chain and sgam_softmax_bwd_rows_f32; the probabilities are
+    recomputed in the backward pass one panel of query rows at a time (dK / dV accumulated across the panels)"""
     B, C, H, W = 2, 128, 8, 8
+    if panel_rows:
+        monkeypatch.setattr(training._Attn, "CHUNK_BYTES", panel_rows * H * W * 4)
     att = AttnBlock(C)
     sd = testing.synthetic_state_dict(att.state_dict(), seed=3)
     att.load_state_dict(sd)
@@ -126,6 +130,7 @@ def test_attention_block_backward():
         assert _rel(y.permute(0, 3, 1, 2), yr) <= 2e-5
         dx = layer.bwd(_nhwc(gy).to(DEV))
     assert _rel(dx.permute(0, 3, 1, 2), xr.grad) <= 1e-4
+    assert layer._rows(H * W) == (panel_rows or H * W) and not any(t.shape[-1] == H * W and t.dim() == 2 for t in layer.saved)
     for name, p in att.named_parameters():
         if name == "k.bias":       # exactly zero in exact arithmetic (a constant added to every key leaves the soft-max unchanged):
             assert grads[p].abs().max().item() <= 1e-5 and ref["a." + name].grad.abs().max().item() <= 1e-5    # both are round-off
@@ -148,6 +153,37 @@ def test_adam_kernel_matches_torch_optim():
         ops.check(_lib.load().sgam_adam_step_f32(ops._p(p), ops._p(g.to(DEV)), ops._p(m), ops._p(v), p.numel(), 1e-3, 0.5, 0.9, 1e-8,
                                                  i + 1, ops._stream()), "adam")
         assert (p.cpu() - pr.detach()).abs().max().item() <= 2e-7, i
+
+
+def test_adam_multi_tensor_launch_matches_torch_optim():
+    """the trainer's opt.step(): ONE sgam_adam_multi_step_f32 launch over a set of tensors of unequal sizes (one of them without a
+    gradient, which Adam skips) against torch.optim.Adam over three steps"""
+    shapes = [(5000,), (3, 7), (4096,), (4097,), (1,), (64, 65)]
+    ps = [torch.nn.Parameter(testing.seeded_tensor(f"adamm.p{i}", s).to(DEV)) for i, s in enumerate(shapes)]
+    refs = [p.detach().cpu().clone().requires_grad_(True) for p in ps]
+    opt = torch.optim.Adam(refs, lr=1e-3, betas=(0.5, 0.9))
+
+    class T(training.AutoencoderTrainer):
+        def __init__(self):
+            self.lr, self.global_step = 1e-3, 0
+    tr, state = T(), {}
+    for step in range(3):
+        grads = {}
+        for i, (p, r) in enumerate(zip(ps, refs)):
+            if i == 4 and step == 1:
+                r.grad = None
+                continue
+            g = testing.seeded_tensor(f"adamm.g{i}.{step}", tuple(p.shape), scale=10.0 ** (-step))
+            grads[p], r.grad = g.to(DEV), g.clone()
+        tr.global_step += 1
+        opt.step()
+        if step == 1:       # torch counts steps per tensor; the reference's parameter sets always have gradients: keep them aligned
+            opt.state[refs[4]]["step"] += 1
+        tr._adam(ps, grads, state)
+    for i, (p, r) in enumerate(zip(ps, refs)):
+        if i == 4:
+            continue
+        assert (p.detach().cpu() - r.detach()).abs().max().item() <= 2e-7, i
 
 
 def _oracle_loss_and_grads(sd, dd, x, mask, x_dst, names):
@@ -220,6 +256,46 @@ def test_autoencoder_update_small_model(phase, golden):
     with torch.no_grad():
         dec2 = m(x.to(DEV), extrapolation_mask=mask.to(DEV))[0]
     assert torch.isfinite(dec2).all() and not torch.equal(dec2, ops.nhwc_to_nchw(out["rec"])) or phase == "conditional_generation"
+
+
+def test_full_size_training_step_matches_the_reference(golden):
+    """VERDICT r2 next #7a — the REAL configuration: the 68 990 620-parameter GoogleEarth model, one 256 x 256 image.  The HIP
+    forward + backward (phase `codebook`: every parameter trains) against the REFERENCE's own numbers
+    (tests/golden/train_step_full256.npz: VQModel.forward + VQLPIPSWithDiscriminator + backward, generated by importing the
+    reference): loss terms, all 256 codebook indices, the reconstruction, the gradient norm of every one of the 345 parameter
+    tensors, nine full gradient tensors.  Tolerances: the weight-gradient GEMMs contract over up to 65 536 pixels in a
+    different order than the reference's CPU kernels."""
+    g = golden("train_step_full256.npz")
+    p = default_params("google_earth")
+    p["phase"] = "codebook"
+    m = VQModel(**p)
+    sd = testing.synthetic_state_dict(m.state_dict(), seed=0)
+    sd["quantize.embedding.weight"] = testing.apply_codebook_repairs(
+        testing.codebook_from_stats(float(g["zmean"]), float(g["zstd"]), 4096, 256, 0), g["repairs"], float(g["zmean"]), float(g["zstd"]))
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    x, mask = testing.rect_hole_input(1, 256, 256, seed=9)
+    x_dst = testing.seeded_tensor("train_full.dst", (1, 4, 256, 256), scale=0.5).clamp(-1, 1)
+    tr = training.AutoencoderTrainer(m, phase="codebook", lr=4.5e-6)
+    out = tr.forward_backward(x.to(DEV), x_dst.to(DEV), mask.to(DEV))
+    assert torch.equal(out["indices"].cpu().reshape(-1), torch.from_numpy(g["indices"].astype(np.int64)).reshape(-1))
+    assert abs(out["nll_loss"] - float(g["rec_loss"])) <= 1e-5 * float(g["rec_loss"])
+    assert abs(out["quant_loss"] - float(g["quant_loss"])) <= 1e-4 * float(g["quant_loss"])
+    assert abs(float(out["loss"]) - float(g["loss"])) <= 1e-5 * float(g["loss"])
+    assert _rel(out["rec"].permute(0, 3, 1, 2)[..., ::4, ::4], torch.from_numpy(g["xrec_sub"])) <= 1e-4
+    named = dict(m.named_parameters())
+    for k in [f[5:] for f in g.files if f.startswith("grad.")]:
+        assert _rel(tr.grads[named[k]], torch.from_numpy(g["grad." + k])) <= 2e-3, k
+    names, norms = [str(n) for n in g["grad_norm_names"]], g["grad_norms"]
+    assert len(names) == 345
+    worst = 0.0
+    for n, want in zip(names, norms):
+        if n.endswith(".k.bias"):               # mathematically zero (the key bias shifts every logit of a row alike)
+            continue
+        got = float(tr.grads[named[n]].double().norm())
+        worst = max(worst, abs(got - want) / want)
+        assert abs(got - want) <= 1e-3 * want, (n, got, want)
+    print(f"full-size step: worst relative gradient-norm error over {len(names)} tensors {worst:.2e}")
 
 
 def test_loss_decreases_over_steps(golden):
