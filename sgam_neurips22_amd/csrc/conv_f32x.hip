@@ -1087,6 +1087,144 @@ __global__ __launch_bounds__(256) void conv3x3_f32x_k4_kernel(const XParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolution for the WEIGHT-DOMINATED maps (16^2, 32^2: M = 256 .. 1024 pixels against 256 .. 512
+// channels — 9.4 MB of split weights for 0.5 MB of activations at 16^2 x 512): a "weight-stationary" decomposition.
+// The 64 x 128 tile of the halo kernel above under its split-K plan makes every workgroup pull 147 KB of weights (re-read by
+// the four M tiles of the map) plus its halo: ~160 KB per CU at the ~11 B/clk a CU sustains from the fabric = the 10 - 11 us
+// those launches take.  Here a workgroup owns ALL 256 pixels of a 16 x 16 patch (the whole map at 16^2) x 32 output channels
+// x ONE channel slab (9 taps x 32 channels): 36.8 KB of weights that no other workgroup of the patch reads, + the 18 x 18
+// halo of the slab (41 KB of fp32, shared through L2 by the N / 32 workgroups of the slab: xcd_block keeps them on one XCD).
+// Every weight fragment is requested at kernel start — 36 x 1 KB per wavefront in flight while the halo is normalised, split
+// and staged — then 108 MFMAs per wavefront (rows 64 w .. 64 w + 63, two 32 x 32 tiles) read their A fragments from the halo.
+// The partial tile goes to the split-K workspace in the common [z][M][N] layout (a half-wave writes 128 contiguous bytes of
+// a row straight from the accumulator layout): the combine kernels above finish it (bias, residual, statistics).
+// GNM: 0 no GroupNorm, 1 {mean, rstd} given, 2 statistics folded from the producer's chunk partials (GNF).
+template <int GNM>
+__global__ __launch_bounds__(256) void conv3x3_f32x_ws_kernel(const XParams p) {
+    constexpr int TH = 16, TW = 16, HROWS = TH + 2, HWID = TW + 2, HR = HROWS * HWID;     // 18 x 18 halo pixels
+    constexpr int XBK = 32, XLD = XBK + 8, LP = 768, HPL = HROWS * LP;                     // as the 8 x 16 patch of halo2
+    constexpr int NH = (HR * 8 + 255) / 256;                                               // float4 pieces per thread (11)
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * HPL];                  // hi plane, lo plane: 55 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bx, by, bz;
+    xcd_block(p, bx, by, bz);
+    const int n0 = by * 32;
+    const int tiles_x = p.Wo / TW, tiles_img = tiles_x * (p.Ho / TH);
+    const int b = bx / tiles_img, t_img = bx - b * tiles_img;
+    const int ty0 = (t_img / tiles_x) * TH, tx0 = (t_img % tiles_x) * TW;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, (int)p.w_plane_bytes, 0x00020000);
+    const int s0 = (bz * p.iters_per_split) / 9, s1 = min(p.iters_total, (bz + 1) * p.iters_per_split) / 9;   // channel slabs
+
+    unsigned h_off[NH];
+    int h_lds[NH];
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+        const int idx = tid + 256 * j, row = idx >> 3, col4 = idx & 7;
+        const int hy = row / HWID, hx = row - hy * HWID;
+        const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
+        const bool ok = row < HR && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        h_off[j] = ok ? (unsigned)(((b * p.Hi + iy) * p.Wi + ix) * p.lda + col4 * 4) * 4u : 0xFFFFFFFFu;
+        h_lds[j] = row < HR ? hy * LP + hx * XLD + col4 * 4 : -1;
+    }
+    const unsigned bf_off = ((unsigned)(n0 >> 5) * ((unsigned)p.ldb / 32u) * 256u + (unsigned)lane) * 16u;
+    const int frag_row = lane & 31, frag_k = (lane >> 5) * 8;
+    unsigned a_lds[2];
+    const unsigned sm_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short *)smem;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = wave * 64 + i * 32 + frag_row;
+        a_lds[i] = sm_lds + 2u * (unsigned)((r >> 4) * LP + (r & 15) * XLD + frag_k);
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    for (int sl = s0; sl < s1; ++sl) {
+        // ---- every weight fragment of (this channel tile, this slab): 9 taps x 2 k-steps x {hi, lo}, all in flight at once
+        u32x4 bq[9][2][2];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const unsigned koff = (unsigned)(tap * p.Cin + sl * XBK) * 128u;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    bq[tap][kk][pl] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)bf_off, (int)(koff + (unsigned)((pl * 2 + kk) * 1024)), 0);
+        }
+        // ---- the slab's halo: load, GroupNorm(+swish), hi / lo split, LDS
+        f32x4 hreg[NH];
+        const unsigned coff = (unsigned)sl * (XBK * 4u);
+#pragma unroll
+        for (int j = 0; j < NH; ++j)
+            hreg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)h_off[j], (int)coff, 0));
+        f32x4 gt0, gt1;
+        if constexpr (GNM != 0) gn_scale_shift<GNM == 2>(p, b, sl * XBK + (tid & 7) * 4, gt0, gt1);
+        if (sl != s0) __syncthreads();                       // the previous slab's fragments have been read
+#pragma unroll
+        for (int j = 0; j < NH; ++j) {
+            f32x4 v = hreg[j];
+            if constexpr (GNM != 0) {
+                v[0] = v[0] * gt0[0] + gt0[1];
+                v[1] = v[1] * gt0[2] + gt0[3];
+                v[2] = v[2] * gt1[0] + gt1[1];
+                v[3] = v[3] * gt1[2] + gt1[3];
+                if (p.gn_swish) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = sgam_swish(v[e]);
+                }
+                if (h_off[j] == 0xFFFFFFFFu) v = f32x4{0.f, 0.f, 0.f, 0.f};      // zero padding is applied AFTER the norm
+            }
+            u32x2 hi, lo;
+            split4(v, hi, lo);
+            if (h_lds[j] >= 0) {
+                *reinterpret_cast<u32x2 *>(smem + h_lds[j]) = hi;
+                *reinterpret_cast<u32x2 *>(smem + HPL + h_lds[j]) = lo;
+            }
+        }
+        __syncthreads();
+        // ---- 18 k-steps: A fragments by explicit ds_read_b128, one step ahead, counted waits (as halo2)
+        u32x4 fa[2][2][2];                      // [step parity][m tile][hi, lo]
+#define WS_READ(set, tap, kk)                                                                                               \
+    do {                                                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                     \
+            XDS_READ(fa[set][i][0], a_lds[i], 2 * (((tap) / 3) * LP + ((tap) % 3) * XLD + (kk) * 16));                      \
+            XDS_READ(fa[set][i][1], a_lds[i], 2 * (((tap) / 3) * LP + ((tap) % 3) * XLD + (kk) * 16 + HPL));                \
+        }                                                                                                                   \
+    } while (0)
+        WS_READ(0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 18; ++q) {
+            const int tap = q >> 1, kk = q & 1;
+            if (q < 17) {
+                WS_READ((q + 1) & 1, (q + 1) >> 1, (q + 1) & 1);
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[q & 1][0][0]), "+v"(fa[q & 1][0][1]), "+v"(fa[q & 1][1][0]), "+v"(fa[q & 1][1][1]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[q & 1][0][0]), "+v"(fa[q & 1][0][1]), "+v"(fa[q & 1][1][0]), "+v"(fa[q & 1][1][1]));
+            }
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    acc[i] = mfma16(fa[q & 1][i][term == 0 ? 1 : 0], bq[tap][kk][term == 1 ? 1 : 0], acc[i]);
+        }
+#undef WS_READ
+    }
+    // ---- partial tile -> workspace [bz][M][N]: lane = column n0 + (lane & 31), rows 8 (e / 4) + 4 (lane >> 5) + e % 4 of a tile
+    float *wo = p.ws + (int64_t)bz * p.M * p.N + n0 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int r = wave * 64 + i * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
+            const int m = (b * p.Ho + ty0 + (r >> 4)) * p.Wo + tx0 + (r & 15);
+            wo[(int64_t)m * p.N] = acc[i][e];
+        }
+}
+
 // fixed-order split-K reduction (partials are still weight-scaled) + un-scale + bias + residual; optionally the GroupNorm
 // statistics of what it writes: a workgroup covers 1024 / N whole output rows (N in {128, 256, 512, 1024}), lanes of one
 // (row, group) are neighbours -> shuffle fold, rows -> LDS fold, one {sum, sumsq} pair per (workgroup = chunk, group).
@@ -1281,8 +1419,16 @@ static bool k4_shape(const sgam_conv_desc *d) {
            d->bias_per_row == 0;
 }
 
+// shapes the weight-stationary kernel takes (plan tile (256, 32)): 3x3 / s1 / p1, no upsampling, 16 x 16 patches, whole slabs
+static bool ws_shape(const sgam_conv_desc *d) {
+    return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 && !d->upsample2x &&
+           d->Ho == d->Hi && d->Wo == d->Wi && d->Ho % 16 == 0 && d->Wo % 16 == 0 && d->Cin % 32 == 0 && d->N % 32 == 0 &&
+           d->bias_per_row == 0;
+}
+
 static bool halo_shape(const sgam_conv_desc *d, int bm, int bn) {
     if (bm == 32 && bn == 32) return k4_shape(d);
+    if (bm == 256 && bn == 32) return ws_shape(d);
     static const int halo_on = [] { const char *e = getenv("SGAM_F32X_HALO"); return (e && e[0] == '0') ? 0 : 1; }();
     const bool tile_ok = (bm == 128 && bn == 128 && d->Wo % 16 == 0) || (bm == 64 && bn == 128 && d->Wo % 8 == 0);
     const int up = d->upsample2x ? 2 : 1;
@@ -1308,6 +1454,17 @@ XPlan make_xplan(const sgam_conv_desc *d) {
     if (pl.bm == 32 && pl.bn == 32) {
         pl.iters_total = pl.iters_per_split = 9 * (d->Cin / 32);
         pl.ksplit = 1;
+        return pl;
+    }
+    if (pl.bm == 256 && pl.bn == 32) {
+        // weight-stationary kernel: always a split-K plan (its epilogue writes partial tiles only), whole slabs per range
+        const int slabs = d->Cin / 32;
+        int ks = d->plan_ksplit > 0 ? d->plan_ksplit : slabs;
+        if (ks > slabs) ks = slabs;
+        if (ks < 2) ks = slabs >= 2 ? 2 : 1;
+        pl.iters_total = 9 * slabs;
+        pl.iters_per_split = 9 * ((slabs + ks - 1) / ks);
+        pl.ksplit = (pl.iters_total + pl.iters_per_split - 1) / pl.iters_per_split;
         return pl;
     }
     const int xbk = xbk_of(pl.bm, pl.bn);
@@ -1342,7 +1499,8 @@ int xvalidate(const sgam_conv_desc *d) {
     if (d->n_valid % 4 != 0 || d->ldc % 4 != 0 || d->ldr % 4 != 0) return SGAM_EALIGN;   // 16-byte epilogue accesses
     if (d->plan_bm != 0 || d->plan_bn != 0) {
         const bool ok = (d->plan_bm == 128 && d->plan_bn == 128) || (d->plan_bm == 64 && d->plan_bn == 128) ||
-                        (d->plan_bm == 64 && d->plan_bn == 64) || (d->plan_bm == 32 && d->plan_bn == 32 && k4_shape(d));
+                        (d->plan_bm == 64 && d->plan_bn == 64) || (d->plan_bm == 32 && d->plan_bn == 32 && k4_shape(d)) ||
+                        (d->plan_bm == 256 && d->plan_bn == 32 && ws_shape(d) && d->Cin >= 64);
         if (!ok || (d->plan_bn == 128 && d->N % 128 != 0)) return SGAM_EINVAL;
     }
     if (d->plan_ksplit < 0 || d->plan_ksplit > 64) return SGAM_EINVAL;
@@ -1458,7 +1616,7 @@ extern "C" int32_t sgam_conv2d_f32x_gn_foldable(const sgam_conv_desc *d, int32_t
     static const int on = [] { const char *e = getenv("SGAM_GN_FOLD"); return (e && e[0] == '0') ? 0 : 1; }();
     if (!on || chunks_in < 1 || chunks_in > 16 || sgam_conv2d_f32x_gn_fusable(d) != 1 || d->Cin % 128 != 0) return 0;
     const XPlan pl = make_xplan(d);
-    return (pl.bm == 64 && pl.bn == 128 && pl.iters_per_split <= 18) ? 1 : 0;
+    return (((pl.bm == 64 && pl.bn == 128) || (pl.bm == 256 && pl.bn == 32)) && pl.iters_per_split <= 18) ? 1 : 0;
 }
 
 // sgam_conv2d_gn_nhwc_f32x with the statistics of x still as its producer's chunk partials [B][chunks_in][32][2] (fp64 {sum,
@@ -1545,14 +1703,19 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
     if (d->KH * d->KW > 32) return SGAM_EINVAL;   // tap validity mask is 32 bits
     const bool halo = halo_eligible(d, pl, a_scale);
     if ((ex.gn_stats || ex.gn_partial_in) && !halo) return SGAM_EINVAL;
-    if (ex.gn_partial_in && (pl.bm != 64 || p.ups)) return SGAM_EINVAL;       // the folding consumer is the 64-row halo kernel
+    if (ex.gn_partial_in && ((pl.bm != 64 && pl.bm != 256) || p.ups)) return SGAM_EINVAL;   // folding consumers: 64-row halo / ws kernel
     // algorithmic work of this launch: 2 M N K fp32 FLOP; bytes = input + weights + output once
     if (sgam_i_prof_on) sgam_i_prof_shape(p.M, d->n_valid, d->KH * d->KW * d->Cin, pl.ksplit);
     if (sgam_i_prof_on)
         sgam_i_prof_work(2.0 * p.M * d->n_valid * (double)(d->KH * d->KW * d->Cin),
                          4.0 * ((double)d->B * d->Hi * d->Wi * d->Cin + (double)d->n_valid * d->KH * d->KW * d->Cin +
                                 (double)p.M * d->n_valid * (residual ? 2 : 1)));
-    if (halo && pl.bm == 32) {
+    if (halo && pl.bm == 256) {
+        if (a_scale != 1.0f || pl.ksplit < 2) return SGAM_EINVAL;
+        if (p.gn_partial_in) SGAM_KLAUNCH((conv3x3_f32x_ws_kernel<2>), grid, dim3(256), 0, s, p);
+        else if (p.gn_stats) SGAM_KLAUNCH((conv3x3_f32x_ws_kernel<1>), grid, dim3(256), 0, s, p);
+        else SGAM_KLAUNCH((conv3x3_f32x_ws_kernel<0>), grid, dim3(256), 0, s, p);
+    } else if (halo && pl.bm == 32) {
         if (a_scale != 1.0f) return SGAM_EINVAL;
         if (p.gn_stats) SGAM_KLAUNCH((conv3x3_f32x_k4_kernel<true>), grid, dim3(256), 0, s, p);
         else SGAM_KLAUNCH((conv3x3_f32x_k4_kernel<false>), grid, dim3(256), 0, s, p);

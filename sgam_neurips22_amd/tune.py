@@ -114,7 +114,12 @@ def tune_shape(key, verbose=True):
     if t_auto is not None and split and norm_input and _lib.load().sgam_conv2d_f32x_gn_fusable(ctypes.byref(auto)) != 1:
         t_auto += max(4e-3, 2.0 * B * Hi * Wi * Cin * 4 / 4e12 * 1e3)
     # the 16-bit halo kernel also has a 256-row tile (16 x 16 patch, one workgroup per CU): a candidate where many tile waves run
-    for bm, bn in (TILES + [(256, 128)] if (dtype in ops.H16 and KH == 3 and stride == 1 and not ups) else TILES):
+    tiles = list(TILES)
+    if dtype in ops.H16 and KH == 3 and stride == 1 and not ups:
+        tiles.append((256, 128))
+    if split and KH == 3 and stride == 1 and not ups and Ho % 16 == 0 and Wo % 16 == 0 and M <= 4096 and Cin >= 64:
+        tiles.append((256, 32))          # weight-stationary kernel of the small maps (always split-K)
+    for bm, bn in tiles:
         if bn == 128 and N % 128:
             continue
         blocks = -(-M // bm) * -(-N // bn)
@@ -125,6 +130,9 @@ def tune_shape(key, verbose=True):
             # lose there, measured — cap them)
             if ks <= iters // 2 and ks <= 16:
                 cands.add(ks)
+        if (bm, bn) == (256, 32):
+            slabs = Cin // 32
+            cands = {k for k in (slabs, slabs // 2, slabs // 4) if k >= 2}
         for ks in sorted(cands):
             if blocks * ks > 8192:
                 continue

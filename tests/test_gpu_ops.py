@@ -479,6 +479,64 @@ def test_small_map_k_in_workgroup_kernel(B, C, Cout, H, W, gn, with_res):
         assert torch.equal(out, again)
 
 
+@pytest.mark.parametrize("B,C,Cout,H,W,ks,gn,with_res", [(1, 512, 512, 16, 16, 16, True, True), (1, 512, 512, 16, 16, 8, True, False),
+                                                          (1, 256, 256, 32, 32, 8, True, True), (2, 256, 512, 16, 32, 4, False, True),
+                                                          (1, 128, 160, 16, 16, 4, False, False), (1, 512, 256, 16, 16, 16, True, False)])
+def test_weight_stationary_small_map_kernel(B, C, Cout, H, W, ks, gn, with_res):
+    """conv3x3_f32x_ws_kernel (plan tile (256, 32)): a workgroup owns a whole 16 x 16 patch x 32 output channels x one or two
+    channel slabs, every weight fragment requested at kernel start; partial tiles through the split-K combine.  Against fp64;
+    with GroupNorm(+swish) fused into the staging from {mean, rstd} and — where the producer was a split-K layer of a small
+    map — from its chunk partials folded in the kernel; statistics of the output; run-to-run bit-reproducible."""
+    ops.set_f32_mode("split")
+    x = _nhwc(testing.seeded_tensor("ws.x", (B, C, H, W), 1.2, 0.3)).to(DEV)
+    w = testing.seeded_tensor("ws.w", (Cout, C, 3, 3), scale=(1.0 / (C * 9)) ** 0.5)
+    bias = testing.seeded_tensor("ws.b", (Cout,), 0.1).to(DEV)
+    res = _nhwc(testing.seeded_tensor("ws.r", (B, Cout, H, W))).to(DEV) if with_res else None
+    g = (1 + 0.1 * testing.seeded_tensor("ws.g", (C,))).to(DEV)
+    bt = (0.1 * testing.seeded_tensor("ws.bt", (C,))).to(DEV)
+    wp = ops.pack_conv_weight(w.to(DEV), dtype="f32x")
+    key = f"f32x|B{B}|{H}x{W}x{C}|{H}x{W}|N{wp.shape[0]}|k3x3s1u0"
+    old = ops.PLAN_CACHE.get(key)
+    ops.PLAN_CACHE[key] = (256, 32, ks)
+    kw = dict(cout=Cout, kh=3, kw=3, pad_t=1, pad_l=1, residual=res)
+    nm = (g, bt, True, 32, 1e-6) if gn else None
+    try:
+        recs, _ = ops.kernel_timeline(lambda: ops.conv2d_nhwc(x, wp, bias, norm=nm, **kw))
+        assert any("conv3x3_f32x_ws_kernel" in r[0] for r in recs), [r[0] for r in recs]
+        out = ops.conv2d_nhwc(x, wp, bias, norm=nm, **kw)
+        for _ in range(3):
+            assert torch.equal(out, ops.conv2d_nhwc(x, wp, bias, norm=nm, **kw))
+        h = x.permute(0, 3, 1, 2).cpu().double()
+        if gn:
+            h = F.group_norm(h, 32, g.cpu().double(), bt.cpu().double(), eps=1e-6)
+            h = h * torch.sigmoid(h)
+        ref = F.conv2d(h, w.double(), bias.cpu().double(), padding=1)
+        if with_res:
+            ref = ref + res.permute(0, 3, 1, 2).cpu().double()
+        _close(out.permute(0, 3, 1, 2), ref.float(), 2e-5, "ws kernel vs fp64")
+        if Cout % 128 == 0:
+            assert hasattr(out, "_gn_partials")
+            st = ops.groupnorm_meanrstd(out).cpu()
+            og = out.permute(0, 3, 1, 2).cpu().double().reshape(B, 32, -1)
+            assert torch.allclose(st[..., 0].double(), og.mean(-1), rtol=0, atol=2e-6)
+            assert torch.allclose(st[..., 1].double(), (og.var(-1, unbiased=False) + 1e-6).rsqrt(), rtol=2e-6, atol=0)
+            if C == Cout and H * W <= 1024 and ks >= C // 64:
+                # producer and consumer both on this kernel: the consumer folds the producer's chunk partials itself
+                g2, bt2 = (1 + 0.1 * testing.seeded_tensor("ws.g2", (Cout,))).to(DEV), (0.1 * testing.seeded_tensor("ws.bt2", (Cout,))).to(DEV)
+                kw2 = dict(cout=Cout, kh=3, kw=3, pad_t=1, pad_l=1)
+                recs2, _ = ops.kernel_timeline(lambda: ops.conv2d_nhwc(out, wp, None, norm=(g2, bt2, True, 32, 1e-6), **kw2))
+                names = [r[0] for r in recs2]
+                assert any("ws_kernel<2>" in n for n in names) and not any("gn_finalize" in n for n in names), names
+                y = ops.conv2d_nhwc(out, wp, None, norm=(g2, bt2, True, 32, 1e-6), **kw2)
+                plain = ops.conv2d_nhwc(ops.groupnorm_nhwc(out.clone(), g2, bt2, True), wp, None, **kw2)
+                assert (y - plain).abs().max().item() <= 3e-6 * plain.abs().max().item()
+    finally:
+        if old is None:
+            ops.PLAN_CACHE.pop(key, None)
+        else:
+            ops.PLAN_CACHE[key] = old
+
+
 @pytest.mark.parametrize("case", [(1, 4096, 256), (2, 256, 512), (3, 1024, 256)], ids=lambda c: f"B{c[0]}n{c[1]}C{c[2]}")
 def test_fused_groupnorm_qkv_gemm(case):
     """csrc/gemm_gn_f32x.hip: GroupNorm(x) @ [Wq; Wk; Wv]^T + bias with the normalisation applied while the operand panel is
