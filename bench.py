@@ -153,8 +153,10 @@ def pmc_frame_entry(mode, timeline_name):
         return fn, kernels[timeline_name]
     if timeline_name.endswith(">"):
         cands = [k for k in kernels if k.startswith(timeline_name[:-1] + ",")]
-        if len(cands) == 1:
-            return fn, kernels[cands[0]]
+        # the omitted trailing template arguments are the defaulted ones (all `false` in this library)
+        dflt = [k for k in cands if set(k[len(timeline_name):-1].split(",")) <= {"false"}]
+        if len(dflt) == 1 or len(cands) == 1:
+            return fn, kernels[(dflt or cands)[0]]
     return fn, None
 
 

@@ -195,7 +195,7 @@ __device__ __forceinline__ void xepilogue(const XParams &p, f32x16 (&acc)[BM / (
     constexpr int WGN = 4 / WGM;
     constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
     constexpr int WM = 32 * TM, WN = 32 * TN, LDR = WN + 4;
-    const int wm = WGM == 2 ? wave >> 1 : 0, wn = WGM == 2 ? (wave & 1) : wave;
+    const int wm = WGM == 4 ? wave : (WGM == 2 ? wave >> 1 : 0), wn = WGM == 4 ? 0 : (WGM == 2 ? (wave & 1) : wave);
     float *region = smem_f + wave * (WM * LDR);
     const bool to_ws = p.ws != nullptr;
     const int n_lim = to_ws ? p.N : p.n_valid;
@@ -583,7 +583,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
     // wavefront layout: 1 = four wavefronts side by side along N (each owns all BM rows x BN / 4 channels: every A fragment
     // is read from LDS by all four), 2 = a 2 x 2 grid (each owns BM / 2 rows x BN / 2 channels: half the LDS reads of A,
     // twice the weight-fragment loads, which two wavefronts share in the vector L1)
-    constexpr int WGM_ = SGAM_XWGM, WGN_ = 4 / WGM_;
+    // BN = 32 (narrow outputs: the decoder's conv_out, 128 -> 4 channels, weights padded to ONE 32-channel tile instead of a
+    // 128-channel tile of mostly-zero columns): the four wavefronts stack along M, each 32 rows x 32 channels
+    constexpr int WGM_ = BN == 32 ? 4 : SGAM_XWGM, WGN_ = 4 / WGM_;
     constexpr int TH = 8, TW = BM / 8, TWS = (TW == 16) ? 4 : 3;
     constexpr int HROWS = UPS ? TH / 2 + 2 : TH + 2, HWID = UPS ? TW / 2 + 2 : TW + 2, HR = HROWS * HWID;
     static_assert(!(UPS && GN), "no GroupNorm precedes an upsampling conv");
@@ -605,7 +607,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = WGM_ == 2 ? wave >> 1 : 0, wn = WGM_ == 2 ? (wave & 1) : wave;
+    const int wm = WGM_ == 4 ? wave : (WGM_ == 2 ? wave >> 1 : 0), wn = WGM_ == 4 ? 0 : (WGM_ == 2 ? (wave & 1) : wave);
     int bx, by, bz;
     xcd_block(p, bx, by, bz);
     const int n0 = by * BN;
@@ -776,12 +778,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
             else
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[set][0][0]), "+v"(fa[set][0][1]), "+v"(fa[set][1][0]), "+v"(fa[set][1][1]),
                              "+v"(fa[set][2][0]), "+v"(fa[set][2][1]), "+v"(fa[set][3][0]), "+v"(fa[set][3][1]));
-        } else {
-            static_assert(TM == 2 || TM == 4, "wait counts are spelled for 2 or 4 row tiles");
+        } else if constexpr (TM == 2) {
             if (next_in_flight)
                 asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[set][0][0]), "+v"(fa[set][0][1]), "+v"(fa[set][1][0]), "+v"(fa[set][1][1]));
             else
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[set][0][0]), "+v"(fa[set][0][1]), "+v"(fa[set][1][0]), "+v"(fa[set][1][1]));
+        } else {
+            static_assert(TM == 1 || TM == 2 || TM == 4, "wait counts are spelled for 1, 2 or 4 row tiles");
+            if (next_in_flight) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[set][0][0]), "+v"(fa[set][0][1]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[set][0][0]), "+v"(fa[set][0][1]));
         }
     };
     constexpr bool XASM = !UPS && (SGAM_XABLATE != 30);
@@ -1430,7 +1435,8 @@ static bool halo_shape(const sgam_conv_desc *d, int bm, int bn) {
     if (bm == 32 && bn == 32) return k4_shape(d);
     if (bm == 256 && bn == 32) return ws_shape(d);
     static const int halo_on = [] { const char *e = getenv("SGAM_F32X_HALO"); return (e && e[0] == '0') ? 0 : 1; }();
-    const bool tile_ok = (bm == 128 && bn == 128 && d->Wo % 16 == 0) || (bm == 64 && bn == 128 && d->Wo % 8 == 0);
+    const bool tile_ok = (bm == 128 && bn == 128 && d->Wo % 16 == 0) || (bm == 64 && bn == 128 && d->Wo % 8 == 0) ||
+                         (bm == 128 && bn == 32 && d->Wo % 16 == 0 && d->N == 32 && !d->upsample2x);
     const int up = d->upsample2x ? 2 : 1;
     return halo_on && tile_ok && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 &&
            d->Ho == up * d->Hi && d->Wo == up * d->Wi && d->Ho % 8 == 0 && d->Cin % 32 == 0;
@@ -1440,7 +1446,8 @@ XPlan make_xplan(const sgam_conv_desc *d) {
     const int64_t M = (int64_t)d->B * d->Ho * d->Wo;
     XPlan pl;
     auto blocks = [&](int bm, int bn) { return (int64_t)sgam_cdiv(M, bm) * sgam_cdiv(d->N, bn); };
-    if (d->N % 128 == 0 && blocks(128, 128) >= 224) { pl.bm = 128; pl.bn = 128; }
+    if (d->N == 32 && d->plan_bm == 0 && blocks(128, 32) >= 224 && halo_shape(d, 128, 32)) { pl.bm = 128; pl.bn = 32; }   // conv_out
+    else if (d->N % 128 == 0 && blocks(128, 128) >= 224) { pl.bm = 128; pl.bn = 128; }
     else if (d->N % 128 == 0 && blocks(64, 128) >= 224) { pl.bm = 64; pl.bn = 128; }
     else { pl.bm = 64; pl.bn = 64; }
     // small maps with deep K (the 16^2 / 32^2 levels): K inside the workgroup instead of a split-K plan — opt-in
@@ -1499,6 +1506,7 @@ int xvalidate(const sgam_conv_desc *d) {
     if (d->n_valid % 4 != 0 || d->ldc % 4 != 0 || d->ldr % 4 != 0) return SGAM_EALIGN;   // 16-byte epilogue accesses
     if (d->plan_bm != 0 || d->plan_bn != 0) {
         const bool ok = (d->plan_bm == 128 && d->plan_bn == 128) || (d->plan_bm == 64 && d->plan_bn == 128) ||
+                        (d->plan_bm == 128 && d->plan_bn == 32 && d->N == 32) ||
                         (d->plan_bm == 64 && d->plan_bn == 64) || (d->plan_bm == 32 && d->plan_bn == 32 && k4_shape(d)) ||
                         (d->plan_bm == 256 && d->plan_bn == 32 && ws_shape(d) && d->Cin >= 64);
         if (!ok || (d->plan_bn == 128 && d->N % 128 != 0)) return SGAM_EINVAL;
@@ -1723,6 +1731,9 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
         if (p.ups) {
             if (pl.bm == 128) SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<128, 128, false, true>), grid, dim3(256), 0, s, p);
             else SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<64, 128, false, true>), grid, dim3(256), 0, s, p);
+        } else if (pl.bm == 128 && pl.bn == 32) {
+            if (p.gn_stats) SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<128, 32, true>), grid, dim3(256), 0, s, p);
+            else SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<128, 32, false>), grid, dim3(256), 0, s, p);
         } else if (pl.bm == 128) {
             if (p.gn_stats) SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<128, 128, true>), grid, dim3(256), 0, s, p);
             else SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<128, 128, false>), grid, dim3(256), 0, s, p);

@@ -275,6 +275,10 @@ def pack_conv_weight(w_oihw, cout_pad=None, cin_pad=None, dtype=torch.float32):
     # split-fp32 3x3 weights are padded to whole 128-channel tiles so that narrow convs (conv_out: 128 -> 4) run on the
     # halo-staged kernel too (one tile of mostly-zero columns costs less than the generic kernel's per-tap staging, and
     # the preceding GroupNorm fuses into it)
+    # ... except outputs of at most 32 channels on the split path (the decoder's conv_out: 128 -> 4): ONE 32-channel tile, which
+    # the halo kernel takes with its four wavefronts stacked along M (tile (128, 32)) — a quarter of the 128-wide tile's MFMAs
+    if cout_pad is None and dtype == "f32x" and kh * kw == 9 and cout <= 32:
+        cout_pad = 32
     cout_pad = cout_pad or round_up(cout, 128 if ((dtype == "f32x" or dtype in H16) and kh * kw == 9) else 64)
     cin_pad = cin_pad or round_up(cin, 32)
     if dtype == "f32x":

@@ -271,7 +271,8 @@ def test_conv_epilogue_groupnorm_statistics(B, C, Cout, H, W, k):
 
 
 @pytest.mark.parametrize("B,C,Cout,H,W,swish,with_res", [(1, 128, 128, 64, 64, True, True), (2, 128, 256, 32, 48, False, False),
-                                                        (1, 256, 128, 16, 16, True, False), (1, 128, 128, 256, 256, True, True)])
+                                                        (1, 256, 128, 16, 16, True, False), (1, 128, 128, 256, 256, True, True),
+                                                        (1, 128, 4, 256, 256, True, False), (2, 128, 8, 128, 128, True, True)])
 def test_conv_groupnorm_fused_into_halo_staging(B, C, Cout, H, W, swish, with_res):
     """Conv3x3(GroupNorm(+swish)(x)) with the normalisation applied while the halo-staged kernel stages its input
     equals the two-pass form (GroupNorm kernel, then conv) and the torch reference; zero padding is post-norm."""
