@@ -742,6 +742,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
     __syncthreads();
 
     u32x4 fa[2][TM][2];                    // [step parity][m tile][hi, lo]
+    if constexpr (SGAM_XABLATE == 27) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[a][i][0] = fa[a][i][1] = u32x4{(unsigned)lane, 0x3c003c00u, (unsigned)tid, 0x38003800u};
+    }
     const unsigned short *hb = smem;
     auto afrag = [&](const int set, const int tap, const int kk) {
         const int ky = tap / 3, kx = tap - 3 * ky;
@@ -801,7 +807,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int set = tap % 3;
-            constexpr bool NOB = SGAM_XABLATE == 21 || SGAM_XABLATE == 24, NOH = SGAM_XABLATE == 24 || SGAM_XABLATE == 25;
+            // timing experiments (results are wrong): 21 no weight loads, 25 no halo staging, 24 neither, 27 neither and no A-fragment
+            // reads (the bare MFMA stream), 26 everything but the MFMAs
+            constexpr bool NOB = SGAM_XABLATE == 21 || SGAM_XABLATE == 24 || SGAM_XABLATE == 27;
+            constexpr bool NOH = SGAM_XABLATE == 24 || SGAM_XABLATE == 25 || SGAM_XABLATE == 27;
+            constexpr bool NOA = SGAM_XABLATE == 27, NOM = SGAM_XABLATE == 26;
             if (!NOB) {
                 if (tap < 7) bload((tap + 2) % 3, tap + 2, sl, true);
                 else bload((tap + 2) % 3, tap - 7, sl + 1, has_next);
@@ -815,7 +825,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
             for (int kk = 0; kk < 2; ++kk) {
                 const int q = tap * 2 + kk;                 // step inside the slab: 0 .. 17
                 // A fragments are read one step ahead (register double buffer fa[q & 1]); step 0 reads its own
-                if constexpr (XASM) {
+                if constexpr (NOA) {
+                } else if constexpr (XASM) {
                     if (q == 0) afrag_asm(0, 0, 0);
                     if (q < 17) afrag_asm((q + 1) & 1, (q + 1) >> 1, (q + 1) & 1);
                     await(q & 1, q < 17);
@@ -829,8 +840,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = mfma16(fa[q & 1][i][term == 0 ? 1 : 0], bq[set][j][kk][term == 1 ? 1 : 0], acc[i][j]);
+                        for (int j = 0; j < TN; ++j) {
+                            if constexpr (NOM) acc[i][j][term] += __builtin_bit_cast(float, fa[q & 1][i][term == 0 ? 1 : 0][0] ^ bq[set][j][kk][term == 1 ? 1 : 0][0]);
+                            else acc[i][j] = mfma16(fa[q & 1][i][term == 0 ? 1 : 0], bq[set][j][kk][term == 1 ? 1 : 0], acc[i][j]);
+                        }
             }
         }
         __syncthreads();                                               // next halo visible; old one free for re-use
@@ -1568,6 +1581,8 @@ static int red_tc_for(const sgam_conv_desc *d) {
     static const int on = [] { const char *e = getenv("SGAM_GN_FOLD"); return (e && e[0] == '0') ? 0 : 1; }();
     const int hw = d->Ho * d->Wo, cpg = d->N / 32;
     if (!on || d->N % 128 != 0 || d->n_valid != d->N || d->N > 1024) return 0;
+    // (extending this to the 64 x 64 maps — 32 chunks of 128 rows x 8 channels, consumers that walk four slabs — was measured:
+    // 344 -> 337 frames/s; 32-byte row pieces make the combine slower than the fold launch it saves)
     for (int tc = 32; tc >= 8; tc >>= 1) {
         const int tr = 1024 / tc;
         if (tc >= cpg && hw % tr == 0 && hw / tr <= 16) return tc;
