@@ -816,10 +816,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
                 if (tap < 7) bload((tap + 2) % 3, tap + 2, sl, true);
                 else bload((tap + 2) % 3, tap - 7, sl + 1, has_next);
             }
-            if (!NOH && tap >= 1 && tap <= NH) hprep_piece(tap - 1);    // next slab's halo, one piece per tap
+            // (28: the staging arithmetic and LDS stores run, on stale registers, without the in-loop halo LOADS; 29: the loads are
+            // issued, nothing is done with them)
+            if (!NOH && SGAM_XABLATE != 29 && tap >= 1 && tap <= NH) hprep_piece(tap - 1);    // next slab's halo, one piece per tap
             if (!NOH && tap == NH + 1) {
-                hstore(hcur ^ 1);                                       // idle buffer: nobody reads it during this slab
-                hload(sl + 2, sl + 2 < s1);
+                if (SGAM_XABLATE != 29) hstore(hcur ^ 1);               // idle buffer: nobody reads it during this slab
+                if (SGAM_XABLATE != 28) hload(sl + 2, sl + 2 < s1);
             }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
