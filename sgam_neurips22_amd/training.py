@@ -38,6 +38,7 @@ from ._lib import ConvDesc
 from .ops import _p, _stream, check
 
 ADAM_BETAS = (0.5, 0.9)          # model.py:423-432
+DGRAD_AS_CONV = True             # 3x3 / s1 / p1 data gradients as a convolution with the flipped filter (False: GEMM + col2im gather)
 ADAM_EPS = 1e-8
 
 
@@ -147,6 +148,18 @@ class _Conv:
         # layer and step); trained weights are re-packed every step (Adam writes through the raw pointer: no version bump to key on)
         w = self.conv.weight
         wkey = (w.data_ptr(), w._version)
+        if self.kh == 3 and self.kw == 3 and self.stride == 1 and not self.ups and self.pad == (1, 1, 1, 1) and self.cin == self.cin_pad \
+                and DGRAD_AS_CONV:
+            # the data gradient of a 3x3 / stride 1 / pad 1 convolution IS such a convolution — of dy with the spatially flipped,
+            # channel-transposed filter: dx[i] = sum_k dy[i + k - 1] . W[:, :, 2 - k]^T — so it runs on the forward implicit-GEMM
+            # kernel: no [M][9 Cin] column matrix (302 MB for a 128-channel layer at 256^2) is written and gathered back
+            if not self.need_wgrad and getattr(self, "_wd_key", None) == wkey:
+                wd = self._wd
+            else:
+                wd = ops.pack_conv_weight(w.detach().flip(2, 3).transpose(0, 1).contiguous(), cin_pad=self.cout_k, dtype=torch.float32)
+                if not self.need_wgrad:
+                    self._wd, self._wd_key = wd, wkey
+            return ops.conv2d_nhwc(dy, wd, None, cout=self.cin, kh=3, kw=3, stride=1, pad_t=1, pad_l=1, cin=self.cout_k)
         if not self.need_wgrad and getattr(self, "_wT_key", None) == wkey:
             wT = self._wT
         else:

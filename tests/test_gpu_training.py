@@ -79,6 +79,14 @@ def test_conv_backward(case):
     assert dx[..., cin:].abs().max().item() == 0 if layer.cin_pad != cin else True
     assert _rel(grads[conv.weight], wr.grad) <= 1e-4, "weight gradient"
     assert _rel(grads[conv.bias], br.grad) <= 1e-4, "bias gradient"
+    if tag == "k3":      # the 3x3 / s1 / p1 data gradient runs as a convolution with the flipped filter; the GEMM + col2im form agrees
+        training.DGRAD_AS_CONV = False
+        try:
+            with training._mfma_mode():
+                dx2 = layer.bwd(_nhwc(gy, layer.cout_k).to(DEV))
+        finally:
+            training.DGRAD_AS_CONV = True
+        assert _rel(dx2[..., :cin].permute(0, 3, 1, 2), xr.grad) <= 1e-4 and _rel(dx2, dx) <= 1e-5
 
 
 @pytest.mark.parametrize("swish", [True, False])
