@@ -519,7 +519,8 @@ int sgam_bn_lrelu_fwd_f32(const float *x, const float *mean_rstd, const float *g
 int sgam_bn_lrelu_bwd_f32(const float *x, const float *dy, const float *mean_rstd, const float *gamma, const float *beta, float *dx,
                           float *dgamma, float *dbeta, float *gbuf, float *means, int32_t rows, int32_t C, float slope,
                           void *workspace, int64_t workspace_bytes, void *stream);
-/* mode +1: relu(1 + l), -1: relu(1 - l), 0: l; grad = d(term)/dl * grad_scale, partial[ceil(n / 256)] = sums of the terms */
+/* mode +1: relu(1 + l), -1: relu(1 - l) (hinge_d_loss); +2: softplus(l), -2: softplus(-l) (vanilla_d_loss, vqperceptual.py:17-28); 0: l;
+ * grad = d(term)/dl * grad_scale, partial[ceil(n / 256)] = sums of the terms */
 int sgam_hinge_terms_f32(const float *logits, float *grad, double *partial, int64_t n, int32_t mode, float grad_scale, void *stream);
 int sgam_sumsq_partial_f32(const float *a, double *partial, int64_t n, void *stream);
 

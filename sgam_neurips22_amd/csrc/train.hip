@@ -451,6 +451,12 @@ __global__ __launch_bounds__(256) void hinge_kernel(const float *__restrict__ l,
         if (mode == 0) {
             a = (double)v;
             grad[i] = gscale;
+        } else if (mode == 2 || mode == -2) {
+            // vanilla GAN loss (vqperceptual.py:24-28): softplus(s l), s = +1 (fake) / -1 (real); d/dl = s sigmoid(s l).
+            // softplus as torch evaluates it: x for x > 20 (its threshold), log1p(exp(x)) otherwise
+            const float sgn = mode > 0 ? 1.0f : -1.0f, x = sgn * v;
+            a = (double)(x > 20.f ? x : log1pf(expf(x)));
+            grad[i] = sgn * gscale / (1.0f + expf(-x));
         } else {
             const float t = 1.0f + (float)mode * v;
             a = t > 0.f ? (double)t : 0.0;
@@ -794,7 +800,7 @@ extern "C" int sgam_bn_lrelu_bwd_f32(const float *x, const float *dy, const floa
 // partial: sgam_cdiv(n, 256) doubles
 extern "C" int sgam_hinge_terms_f32(const float *logits, float *grad, double *partial, int64_t n, int32_t mode, float grad_scale,
                                     void *stream) {
-    if (!logits || !grad || !partial || n <= 0 || mode < -1 || mode > 1) return SGAM_EINVAL;
+    if (!logits || !grad || !partial || n <= 0 || mode < -2 || mode > 2) return SGAM_EINVAL;
     SGAM_KLAUNCH(hinge_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sgam_stream(stream), logits, grad, partial, n, mode, grad_scale);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;

@@ -13,10 +13,13 @@ class VQLPIPSWithDiscriminator(nn.Module):
                  disc_weight=1.0, perceptual_weight=1.0, use_actnorm=False, disc_conditional=False, disc_ndf=64, disc_loss="hinge",
                  use_discriminative_loss=False, disp_loss_weight=None, disc_update_every_n_step=None, kernel_width=4):
         super().__init__()
-        if disc_loss != "hinge":
-            raise NotImplementedError("only the hinge discriminator loss of the shipped configs is built")
+        if disc_loss not in ("hinge", "vanilla"):
+            raise ValueError(f"Unknown GAN loss '{disc_loss}'.")
         if disc_conditional:
-            raise NotImplementedError("disc_conditional")
+            # the reference's forward asserts `cond is not None` in this mode and its training_step never passes one (model.py:324):
+            # a conditional discriminator cannot be trained through the reference's own step either
+            raise NotImplementedError("disc_conditional: VQModel.training_step passes no `cond` (model.py:324-336)")
+        self.disc_loss_name = disc_loss
         self.codebook_weight, self.pixel_weight, self.perceptual_weight = codebook_weight, pixelloss_weight, perceptual_weight
         self.use_discriminative_loss = use_discriminative_loss
         self.perceptual_loss = LPIPS().eval()

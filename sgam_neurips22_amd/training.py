@@ -873,8 +873,9 @@ class VQGANTrainer(AutoencoderTrainer):
             self.dgrads.clear()
             logits_real = tape_r.fwd(ops.nchw_to_nhwc(x_dst, c_pad=32))
             logits_fake2 = tape_f.fwd(_pad_channels(rec, 32))
-            lr_mean, dl_real = self._hinge(logits_real, -1, 0.5 * disc_factor / logits_real.numel())
-            lf_mean, dl_fake = self._hinge(logits_fake2, +1, 0.5 * disc_factor / logits_fake2.numel())
+            dm = 2 if getattr(cfg, "disc_loss_name", "hinge") == "vanilla" else 1        # softplus(-/+ l) instead of relu(1 -/+ l)
+            lr_mean, dl_real = self._hinge(logits_real, -dm, 0.5 * disc_factor / logits_real.numel())
+            lf_mean, dl_fake = self._hinge(logits_fake2, +dm, 0.5 * disc_factor / logits_fake2.numel())
             d_loss = disc_factor * 0.5 * (lr_mean + lf_mean)
             if disc_factor != 0:
                 tape_r.bwd(dl_real, need_pgrad=True)

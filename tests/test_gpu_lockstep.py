@@ -96,3 +96,38 @@ def test_lockstep_expand_runs_the_whole_grid(golden):
     assert not torch.equal(frames[0][(9, 0)]["rgb_u8"], frames[1][(9, 0)]["rgb_u8"])
     assert len(m._graphs) == 1
     m.enable_hip_graph(False)
+
+
+def test_lockstep_clevr_five_sources(golden):
+    """CLEVR-Infinite in lock step (2 x 2 grid walk, up to 5 sources per scene -> a pointer table of up to 2 x 3 frames here,
+    16384-code quantiser): every step against the solo scene started from the same store, as above."""
+    g = golden("vqgan_full_clevr256_topk1.npz")
+    p = default_params("clevr-infinite")
+
+    def model():
+        m = VQModel(**p)
+        sd = testing.synthetic_state_dict(m.state_dict(), seed=0)
+        sd["quantize.embedding.weight"] = testing.codebook_from_stats(float(g["zmean"]), float(g["zstd"]), 16384, 256, int(g["cb_seed"]))
+        m.load_state_dict(sd)
+        return m.to(DEV).eval(), sd
+    (mL, sd), (mS, _) = model(), model()
+    seeds = [synthetic_seed_frame("clevr-infinite", i) for i in range(2)]
+    L = LockstepScenes(mL, "clevr-infinite", seeds, output_dim=(2, 2))
+    solos = [InfiniteSceneGeneration(mS, "clevr-infinite", seed_index=i, output_dim=(2, 2), seed_frame=seeds[i]) for i in range(2)]
+    cb = sd["quantize.embedding.weight"]
+    for step in range(3):
+        for i, solo in enumerate(solos):
+            solo.frames = {c: dict(fr) for c, fr in L.scenes[i].frames.items()}
+        r = L.step(keep_results=True)
+        for i, solo in enumerate(solos):
+            res = solo.one_step_prediction(tuple(r["tgt"]))
+            solo.curr += 1
+            assert len(res["src_coords"]) == step + 1
+            assert torch.equal(res["x"], r["x"][i:i + 1]) and torch.equal(res["extrapolation_mask"], r["extrapolation_mask"][i:i + 1])
+            assert _maxerr(res["pre_quantized_features"], r["pre_quantized_features"][i]) <= 5e-5
+            idx_s = torch.cdist(res["feature"].reshape(256, -1).t().double().cpu(), cb.double()).argmin(1)
+            differ = idx_s != r["indices"][i].reshape(-1).cpu()
+            gap = testing.top2_relative_gap(res["pre_quantized_features"].reshape(256, -1).t(), cb)
+            assert not bool((differ & (gap >= 1e-4)).any())
+            if not bool(differ.any()):
+                assert _maxerr(res["rgbd"], r["rgbd"][i]) <= 5e-5

@@ -319,6 +319,25 @@ def test_loss_decreases_over_steps(golden):
     assert losses[-1] < 0.9 * losses[0], losses
 
 
+@pytest.mark.parametrize("mode", [-2, 2, -1, 1])
+def test_discriminator_loss_terms(mode):
+    """sgam_hinge_terms_f32: the per-logit terms of hinge_d_loss (relu(1 -/+ l)) and vanilla_d_loss (softplus(-/+ l),
+    vqperceptual.py:17-28), their mean and their gradient, against torch"""
+    from sgam_neurips22_amd import _lib
+    l = testing.seeded_tensor("disc.logits", (2, 30, 30, 1), scale=8.0)
+    lr = l.clone().requires_grad_(True)
+    sgn = 1.0 if mode > 0 else -1.0
+    term = F.softplus(sgn * lr) if abs(mode) == 2 else F.relu(1.0 + sgn * lr)
+    term.mean().backward()
+    ld = l.to(DEV)
+    n = ld.numel()
+    grad = torch.empty((n,), device=DEV)
+    part = torch.empty(((n + 255) // 256,), device=DEV, dtype=torch.float64)
+    ops.check(_lib.load().sgam_hinge_terms_f32(ops._p(ld), ops._p(grad), ops._p(part), n, mode, 1.0 / n, ops._stream()), "terms")
+    assert abs(float(part.sum()) / n - float(term.mean())) <= 2e-6 * max(1.0, abs(float(term.mean())))
+    assert (grad.cpu().reshape(lr.shape) - lr.grad).abs().max().item() <= 2e-6 / n * n * float(lr.grad.abs().max())
+
+
 def test_batchnorm_lrelu_forward_backward():
     """nn.BatchNorm2d (training mode, running statistics) + LeakyReLU(0.2) of the PatchGAN, and LeakyReLU alone"""
     B, C, H, W = 2, 64, 7, 9                          # odd map sizes, like the discriminator's last two layers
