@@ -26,9 +26,9 @@ SOURCES = {
                       f"-DSGAM_XWGM={os.environ.get('SGAM_XWGM', '1')}",
                       f"-DSGAM_XSOFF={os.environ.get('SGAM_XSOFF', '1')}"],
     "h16_halo.hip": [f"-DSGAM_HABLATE={os.environ.get('SGAM_HABLATE', '0')}",
-                     f"-DSGAM_HDIRECT={os.environ.get('SGAM_HDIRECT', '1')}"],
-    "attention.hip": [f"-DSGAM_ATTN_ABLATE={os.environ.get('SGAM_ATTN_ABLATE', '0')}",
-                      f"-DSGAM_ATTN_STAGE={os.environ.get('SGAM_ATTN_STAGE', '0')}"],
+                     f"-DSGAM_HDIRECT={os.environ.get('SGAM_HDIRECT', '1')}",
+                     f"-DSGAM_HWGM={os.environ.get('SGAM_HWGM', '1')}"],
+    "attention.hip": [f"-DSGAM_ATTN_ABLATE={os.environ.get('SGAM_ATTN_ABLATE', '0')}"],
     "vq.hip": ["-ffp-contract=off"],
     "layout.hip": ["-ffp-contract=off"],
     "warp.hip": ["-ffp-contract=off"],

@@ -106,9 +106,6 @@ struct AttnParams {
 };
 
 constexpr int NSPLIT = 8;          // key ranges = XCDs
-#ifndef SGAM_ATTN_STAGE
-#define SGAM_ATTN_STAGE 0          // 1: K / V^T blocks reach LDS through registers (global_load -> ds_write), 0: by LDS-DMA
-#endif
 #ifndef SGAM_ATTN_ABLATE
 #define SGAM_ATTN_ABLATE 0         // timing experiments only (results are wrong when != 0), bit mask: 1 no staging in the
 #endif                             // loop, 2 no soft-max arithmetic, 4 no S MFMAs, 8 no PV MFMAs, 16 no loop at all
@@ -173,8 +170,17 @@ __global__ __launch_bounds__(256) void attn_flash_f32x_kernel(const AttnParams p
     // threaded through the MFMA stream by hand).  Trip j of the loop runs
     //     S(j+1) MFMAs   with   exp / sum / fp16 split of block j        (VALU in the shadow of the matrix pipe)
     //     PV(j)  MFMAs   with   scores -> log2 domain + maximum of block j+1
-    // and ends with the (rare) rescale of O when the running maximum moved.  K therefore runs one block ahead of V^T:
-    // K(j+1) and V(j) are resident during trip j while K(j+2) and V(j+1) arrive (two LDS buffers each).
+    // and ends with the (rare) rescale of O when the running maximum moved.
+    //
+    // Staging runs a whole trip ahead of its use.  A block takes 1 - 2 us from L2 / HBM under load and a trip lasts ~1.3 us,
+    // so a block requested during the phase before the one that needs it (the round-1 / round-2 order, one barrier per trip
+    // draining the whole queue) arrived late on every trip.  Now there are TWO barriers per trip, each behind a COUNTED
+    // vmcnt (LDS-DMA pieces retire in issue order):
+    //     S phase of trip j    issues V^T(j+1) -> the buffer PV(j-1) left at the end of trip j-1
+    //     mid barrier          waits for V^T(j) (issued a trip ago; K(j+2) and V^T(j+1) = 16 pieces may still fly);
+    //                          every wavefront is done with K(j+1)
+    //     PV phase of trip j   issues K(j+3)   -> the buffer of K(j+1)
+    //     end barrier          waits for K(j+2) (issued a trip ago; V^T(j+1), K(j+3) may still fly); all done with V^T(j)
     const int nb = kb1 - kb0;
     auto blk = [&](int j) { return kb0 + (j < nb ? j : nb - 1); };       // past the end: a valid block, result unused
     dma(kg, blk(0), 0);
@@ -194,6 +200,13 @@ __global__ __launch_bounds__(256) void attn_flash_f32x_kernel(const AttnParams p
 #define ATTN_DS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
     // reads retired so far = all but the newest `n`; ties the fragment registers to the wait so that no MFMA moves above it
 #define ATTN_DS_WAIT(n, set) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(fh[set]), "+v"(fl[set]))
+    // this wavefront's DMA pieces have landed except the newest 16; then the workgroup meets (no fence: the LDS traffic of
+    // this loop is asm / DMA, ordered by hand)
+#define ATTN_BARRIER(cnt)                                        \
+    do {                                                          \
+        asm volatile("s_waitcnt vmcnt(" #cnt ")" ::: "memory");   \
+        __builtin_amdgcn_s_barrier();                             \
+    } while (0)
     auto smfma = [&](const int t) {            // the three product terms of k-step t, alternating accumulators
         sacc[(3 * t) & 1] = mfma16(fh[t % 3], qh[t], sacc[(3 * t) & 1]);
         sacc[(3 * t + 1) & 1] = mfma16(fh[t % 3], ql[t], sacc[(3 * t + 1) & 1]);
@@ -206,15 +219,7 @@ __global__ __launch_bounds__(256) void attn_flash_f32x_kernel(const AttnParams p
         ATTN_DS_READ(fh[set], base, ((t) >> 1) * 4096 + ((t) & 1) * 1024);        \
         ATTN_DS_READ(fl[set], base, ((t) >> 1) * 4096 + (2 + ((t) & 1)) * 1024);  \
     } while (0)
-#if SGAM_ATTN_STAGE
-    u32x4 st[16];
-    const unsigned goff0 = lane * 16, goff1 = lane * 16 + 4096;
-#define ATTN_GLOAD(dst, voff, base, off) \
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=a"(dst) : "v"(voff), "s"(base), "n"(off))
-#define ATTN_STAGE(src, ldsaddr, off, cnt) \
-    asm volatile("s_waitcnt vmcnt(%2)\n\tds_write_b128 %1, %0 offset:%3" : : "a"(src), "v"(ldsaddr), "n"(cnt), "n"(off))
-#endif
-    __syncthreads();
+    ATTN_BARRIER(0);
 
     // ---- prologue: scores of the first block, their maximum
     {
@@ -238,22 +243,15 @@ __global__ __launch_bounds__(256) void attn_flash_f32x_kernel(const AttnParams p
             mloc = fmaxf(mloc, s[e]);
         }
         m_run = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        ATTN_BARRIER(0);                 // every wavefront has read K(0): its buffer takes K(2) (the PV phase of "trip -1")
+        dma(kg, blk(2), 0);
     }
 
     for (int j = 0; j < ((SGAM_ATTN_ABLATE & 16) ? 0 : nb); ++j) {
         const int buf = j & 1;
         const unsigned lk = lds_off(smem + (buf ^ 1) * BLK_BYTES + lane * 16);       // K(j+1)
         const unsigned lv = lds_off(smem + (2 + buf) * BLK_BYTES + lane * 16);       // V^T(j)
-        const int kb_k = blk(j + 2), kb_v = blk(j + 1);
-#if SGAM_ATTN_STAGE
-        // K(j+2) / V^T(j+1): this wavefront's 16 KB share leaves as sixteen 1 KB loads during the S steps (one per step,
-        // into AccVGPRs: the 208 arch VGPRs are taken) and is written to LDS during the PV steps, one piece per step behind
-        // a counted vmcnt — both destination buffers are free for the whole trip
-        const unsigned char *kbase = kg + (int64_t)kb_k * BLK_BYTES + wave_s * 8192;
-        const unsigned char *vbase = vg + (int64_t)kb_v * BLK_BYTES + wave_s * 8192;
-        const unsigned lkw = lds_off(smem + buf * BLK_BYTES + wave_s * 8192 + lane * 16);
-        const unsigned lvw = lds_off(smem + (2 + (buf ^ 1)) * BLK_BYTES + wave_s * 8192 + lane * 16);
-#endif
+        const int kb_k = blk(j + 3), kb_v = blk(j + 1);
         // ---- S(j+1) MFMAs + soft-max arithmetic of block j
 #pragma unroll
         for (int e = 0; e < 16; ++e) sacc[0][e] = sacc[1][e] = 0.f;
@@ -261,21 +259,11 @@ __global__ __launch_bounds__(256) void attn_flash_f32x_kernel(const AttnParams p
         ATTN_FRAG(1, lk, 1);
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            // two reads leave at every step of the trip: K steps 2..15, then the first two V^T fragments
             if (t + 2 < 16) ATTN_FRAG((t + 2) % 3, lk, t + 2);
-            else ATTN_FRAG((t + 2) % 3, lv, t + 2 - 16);
-            // K(j+2) into the buffer K(j) left, V^T(j+1) into V^T(j-1)'s: all sixteen pieces leave during the S steps so
-            // that they have the whole PV phase to land before the barrier drains the queue
-            if (!(SGAM_ATTN_ABLATE & 1)) {
-#if SGAM_ATTN_STAGE
-                if (t < 8) ATTN_GLOAD(st[t], (t & 4) ? goff1 : goff0, kbase, (t & 3) * 1024);
-                else ATTN_GLOAD(st[t], (t & 4) ? goff1 : goff0, vbase, (t & 3) * 1024);
-#else
-                if (t < 8) dma1(kg, kb_k, buf, t);
-                else dma1(vg, kb_v, 2 + (buf ^ 1), t - 8);
-#endif
-            }
-            ATTN_DS_WAIT(4, t % 3);
+            if (t < 8 && !(SGAM_ATTN_ABLATE & 1)) dma1(vg, kb_v, 2 + (buf ^ 1), t);
+            if (t + 2 < 16) ATTN_DS_WAIT(4, t % 3);
+            else if (t + 1 < 16) ATTN_DS_WAIT(2, t % 3);
+            else ATTN_DS_WAIT(0, t % 3);
             if (!(SGAM_ATTN_ABLATE & 4)) smfma(t);
             if (!(SGAM_ATTN_ABLATE & 2)) {
                 // p = 2^(s - m + 10): the lift by 2^10 rides in the exponent (l_run carries it too); the fp16 split
@@ -293,21 +281,19 @@ __global__ __launch_bounds__(256) void attn_flash_f32x_kernel(const AttnParams p
                 ph[t >> 3][(t & 7) >> 1] = pl[t >> 3][(t & 7) >> 1] = __builtin_bit_cast(unsigned, s[t]);
             }
         }
+        if (!(SGAM_ATTN_ABLATE & 1)) ATTN_BARRIER(16);
         // ---- PV(j) MFMAs + log2-domain scores and maximum of block j+1.  V^T step u uses set (16 + u) % 3.
         float mloc = -INFINITY;
+        ATTN_FRAG(16 % 3, lv, 0);
+        ATTN_FRAG(17 % 3, lv, 1);
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             if (u + 2 < 16) ATTN_FRAG((16 + u + 2) % 3, lv, u + 2);
+            if (u < 8 && !(SGAM_ATTN_ABLATE & 1)) dma1(kg, kb_k, buf ^ 1, u);
             if (u + 2 < 16) ATTN_DS_WAIT(4, (16 + u) % 3);
             else if (u + 1 < 16) ATTN_DS_WAIT(2, (16 + u) % 3);
             else ATTN_DS_WAIT(0, (16 + u) % 3);
             const int i = u >> 1, t = u & 1, set = (16 + u) % 3;
-#if SGAM_ATTN_STAGE
-            if (!(SGAM_ATTN_ABLATE & 1)) {
-                if (u < 8) ATTN_STAGE(st[u], lkw, u * 1024, 15 - u);
-                else ATTN_STAGE(st[u], lvw, (u - 8) * 1024, 15 - u);
-            }
-#endif
             if (!(SGAM_ATTN_ABLATE & 8)) {
                 o[i] = mfma16(fh[set], ph[t], o[i]);
                 o[i] = mfma16(fh[set], pl[t], o[i]);
@@ -345,12 +331,10 @@ __global__ __launch_bounds__(256) void attn_flash_f32x_kernel(const AttnParams p
                 m_run = m_new;
             }
         }
-#if SGAM_ATTN_STAGE
-        asm volatile("s_waitcnt lgkmcnt(0)");      // the staging writes above are invisible to the compiler's own counting
-#endif
-        __syncthreads();          // the arriving blocks have landed (the barrier drains the DMA queue); old ones are free
+        if (!(SGAM_ATTN_ABLATE & 1)) ATTN_BARRIER(16);
     }
 #undef ATTN_FRAG
+#undef ATTN_BARRIER
 #undef ATTN_DS_WAIT
 #undef ATTN_DS_READ
 
@@ -366,6 +350,9 @@ __global__ __launch_bounds__(256) void attn_flash_f32x_kernel(const AttnParams p
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) wo[(32 * i + 8 * (e >> 2) + 4 * lh + (e & 3)) * 32] = o[i][e];
+    // the blocks requested past the end of the range (same piece count on every trip keeps the waits countable) must have
+    // landed before this workgroup's LDS is handed to the next one
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // merge the key ranges: o[q][d] = sum_s w_s O_s[d][q] / sum_s w_s l_s,  w_s = 2^(m_s - max_s m_s).

@@ -11,9 +11,14 @@
 //   * weights are stored in MFMA-fragment order (one plane): per (32-row tile, 32-element K slab) 128 pieces of 16 bytes,
 //     piece = (k-step * 2 + k-half) * 32 + row — the B operand of one v_mfma_f32_32x32x16 is one contiguous kilobyte that
 //     goes straight from L2 / L1 to registers, two taps ahead;
-//   * with a third of the MFMA time per fragment, the wavefronts form a 2 x 2 grid (each owns BM / 2 rows x BN / 2 = 64
-//     channels): every A fragment read from LDS and every B fragment fetched feeds TWO MFMAs (the 1 x 4 layout of the
-//     split-fp32 kernel would need one 1 KB LDS read per MFMA — the LDS port's whole bandwidth);
+//   * wavefront layout (SGAM_HWGM): the four wavefronts sit side by side along N — each owns all BM rows x 32 channels, so
+//     a weight fragment fetched (1 KB, L2 / L1 -> registers) feeds BM / 32 MFMAs and nobody else in the workgroup fetches
+//     it, and every A fragment is read from LDS by all four.  At the matrix pipe's rate that is 32 B/clk/CU through the
+//     vector L1 (of ~64) and 128 B/clk/CU of ds_read_b128 (of 256).  Rounds 1 - 2 ran a 2 x 2 grid (BM / 2 rows x 64
+//     channels per wavefront: half the LDS reads, but every weight fragment fetched by two wavefronts = 64 B/clk/CU, the
+//     whole L1 port: the loop took 1.3 x its MFMA time with or without the MFMAs); the 1 x 4 layout is -5 % on the
+//     256^2 x 128 layer at B = 8, -8 ... -16 % on the 16^2 ... 128^2 maps, +2.7 % frames/s for the bf16 loop (A / B on one box,
+//     scripts/r03x.sh);
 //   * epilogue (SGAM_HDIRECT = 1, the default): the product is computed TRANSPOSED (weights = MFMA rows, pixels = columns)
 //     and the weight rows of a 32-channel tile are packed so that a lane's sixteen accumulator slots are sixteen
 //     CONSECUTIVE channels of one pixel: they leave as 16-byte stores with bias, residual and the output statistics applied
@@ -28,6 +33,9 @@
 #ifndef SGAM_HDIRECT
 #define SGAM_HDIRECT 1     // 1: the product is computed TRANSPOSED (weights = MFMA rows, pixels = columns) and leaves the
 #endif                     //    accumulators straight for memory; 0: pixels = rows, LDS transpose in the epilogue
+#ifndef SGAM_HWGM
+#define SGAM_HWGM 1        // wavefront layout of the 64- / 128-row tiles: 1 = four side by side along N (all BM rows x 32 channels
+#endif                     //    each), 2 = a 2 x 2 grid (BM / 2 rows x 64 channels each: twice the weight-fragment bytes through L1)
 #ifndef SGAM_HABLATE
 #define SGAM_HABLATE 0     // timing experiments only (results are wrong when != 0): 1 no MFMAs, 2 no epilogue, 4 no main loop,
                            // 8 no weight-fragment loads in the loop, 16 no halo staging in the loop, 32 stores dropped
@@ -101,22 +109,25 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
     constexpr int HROWS = UPS ? TH / 2 + 2 : TH + 2, HWID = UPS ? TW / 2 + 2 : TW + 2, HR = HROWS * HWID;
     static_assert(!(UPS && GN), "no GroupNorm precedes an upsampling conv");
     static_assert(BM == 256 || BM == 128 || BM == 64, "16 x 16, 8 x 16 or 8 x 8 output patches");
-    static_assert(BN == 128, "2 x 2 wavefronts of 64 channels");
+    static_assert(BN == 128, "2 x 2 wavefronts of 64 channels, or 1 x 4 of 32");
+    constexpr int WGM_ = BM == 256 ? 2 : SGAM_HWGM, WGN_ = 4 / WGM_;
+    static_assert(WGM_ == 2 || (WGM_ == 1 && SGAM_HDIRECT), "the 1 x 4 layout has the direct epilogue only");
     constexpr int XBK = 32, XLD = XBK + 8;
-    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int TM = BM / (32 * WGM_), TN = BN / (32 * WGN_);
+    constexpr int RH = WGM_ == 1 ? 2 : 1;               // row halves of the tile (= statistics chunks) a wavefront covers
     constexpr int LP = UPS ? ((TW == 16) ? 408 : 240) : ((TW == 16) ? 768 : 448);   // line pitch (halfs), see conv_f32x.hip
     constexpr int HPL = HROWS * LP;                     // halfs per halo buffer (one plane)
     constexpr int NH = (HR * 4 + 255) / 256;            // 16-byte halo pieces (8 channels) per thread
     constexpr int OP_BYTES = 2 * HPL * 2;
     constexpr int WM = 32 * TM, WN = 32 * TN, LDR = WN + 4;
-    constexpr int EPI_BYTES = SGAM_HDIRECT ? 4 * 2 * TN * 8 * 4 : 4 * WM * LDR * 4;
+    constexpr int EPI_BYTES = SGAM_HDIRECT ? 4 * RH * 2 * TN * 8 * 4 : 4 * WM * LDR * 4;
     constexpr int SM_BYTES = OP_BYTES > EPI_BYTES ? OP_BYTES : EPI_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned short smem[SM_BYTES / 2];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = WGM_ == 2 ? wave >> 1 : 0, wn = WGM_ == 2 ? (wave & 1) : wave;
     int bx, by;
     hxcd_block(p, bx, by);
     const int n0 = by * BN;
@@ -146,7 +157,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
     unsigned bf_off[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int nt = (n0 + wn * (BN / 2) + j * 32) >> 5;
+        const int nt = (n0 + wn * (BN / WGN_) + j * 32) >> 5;
         bf_off[j] = ((unsigned)nt * ((unsigned)p.ldb / 32u) * 128u + (unsigned)lane) * 16u;
     }
 
@@ -228,7 +239,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
     int a_base[TM], a_py[TM], a_px[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int r = wm * (BM / 2) + i * 32 + frag_row;
+        const int r = wm * (BM / WGM_) + i * 32 + frag_row;
         a_py[i] = r >> TWS;
         a_px[i] = r & (TW - 1);
         a_base[i] = a_py[i] * LP + a_px[i] * XLD + frag_k;
@@ -351,7 +362,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void *)p.res, 0, (int)r_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)p.bias, 0, (int)bias_bytes, 0x00020000);
     constexpr unsigned OOB = 0xFFFFFFF0u;
-    const int wn0 = n0 + wn * (BN / 2);
+    const int wn0 = n0 + wn * (BN / WGN_);
 #if SGAM_HDIRECT
     // ---- epilogue, transposed product: in the 32 x 32 accumulator layout lane (pixel = lane & 31, half = lane >> 5) holds
     // MFMA rows 8 (e / 4) + 4 half + e % 4, e = 0..15; the weight rows were packed in the order that makes those the
@@ -362,7 +373,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
     int mrow[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int trow = wm * (BM / 2) + i * 32 + pl;
+        const int trow = wm * (BM / WGM_) + i * 32 + pl;
         mrow[i] = (b * p.Ho + ty0 + (trow >> TWS)) * p.Wo + tx0 + (trow & (TW - 1));
     }
     if (p.ksplit > 1) {
@@ -391,7 +402,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
                 rq[i][j][k] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
                                                             rr, (int)hsel(n4 < n_lim, (unsigned)(mrow[i] * p.ldr + n4) * 2u, OOB), 0, 0));
             }
-    float us[TN][4], uss[TN][4];              // per 4-channel unit: sum, sum of squares over this lane's pixels
+    float us[RH][TN][4], uss[RH][TN][4];      // per (row half, 4-channel unit): sum, sum of squares over this lane's pixels
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int nb = wn0 + j * 32 + hh * 16;
@@ -400,7 +411,8 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
         for (int k = 0; k < 4; ++k) {
             bv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                                   rb, (int)hsel(nb + 4 * k < n_lim, (unsigned)(nb + 4 * k) * 4u, OOB), 0, 0));
-            us[j][k] = uss[j][k] = 0.f;
+#pragma unroll
+            for (int r = 0; r < RH; ++r) us[r][j][k] = uss[r][j][k] = 0.f;
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -429,8 +441,9 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
                     v = f32x4{HH<HT>::to_f(h0), HH<HT>::to_f(h1), HH<HT>::to_f(h2), HH<HT>::to_f(h3)};
                 }
                 if (ok) {
-                    us[j][k] += (v[0] + v[1]) + (v[2] + v[3]);
-                    uss[j][k] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                    constexpr int TMH = TM / RH > 0 ? TM / RH : 1;
+                    us[RH == 1 ? 0 : i / TMH][j][k] += (v[0] + v[1]) + (v[2] + v[3]);
+                    uss[RH == 1 ? 0 : i / TMH][j][k] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
                 }
             }
             if (!p.out_f32) {
@@ -454,39 +467,44 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
     if (p.gn_partial) {
         // over the 32 pixels of a lane half (xor shuffles stay inside it), then lane 0 of each half leaves its 4 x TN units
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int off = 16; off >= 1; off >>= 1) {
-                    us[j][k] += __shfl_xor(us[j][k], off, 64);
-                    uss[j][k] += __shfl_xor(uss[j][k], off, 64);
-                }
-        float *sl = reinterpret_cast<float *>(smem) + wave * (2 * TN * 8);      // wave-private: [unit = 8 j + 4 half + k][2]
-        if (pl == 0) {
+        for (int r = 0; r < RH; ++r)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    sl[(j * 8 + hh * 4 + k) * 2] = us[j][k];
-                    sl[(j * 8 + hh * 4 + k) * 2 + 1] = uss[j][k];
-                }
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int off = 16; off >= 1; off >>= 1) {
+                        us[r][j][k] += __shfl_xor(us[r][j][k], off, 64);
+                        uss[r][j][k] += __shfl_xor(uss[r][j][k], off, 64);
+                    }
+        float *sl = reinterpret_cast<float *>(smem) + wave * (RH * 2 * TN * 8);    // wave-private: [row half][unit = 8 j + 4 half + k][2]
+        if (pl == 0) {
+#pragma unroll
+            for (int r = 0; r < RH; ++r)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        sl[((r * TN + j) * 8 + hh * 4 + k) * 2] = us[r][j][k];
+                        sl[((r * TN + j) * 8 + hh * 4 + k) * 2 + 1] = uss[r][j][k];
+                    }
         }
         const int c4_per_group = p.gn_cpg / 4;
         const int groups_here = (TN * 8) / c4_per_group;
-        if (lane < groups_here) {
+        if (lane < groups_here * RH) {
+            const int r = lane / groups_here, gl = lane - r * groups_here;
             double ds = 0.0, dss = 0.0;
             for (int k = 0; k < c4_per_group; ++k) {
-                ds += (double)sl[(lane * c4_per_group + k) * 2];
-                dss += (double)sl[(lane * c4_per_group + k) * 2 + 1];
+                ds += (double)sl[(r * TN * 8 + gl * c4_per_group + k) * 2];
+                dss += (double)sl[(r * TN * 8 + gl * c4_per_group + k) * 2 + 1];
             }
-            const int g = (wn0 / p.gn_cpg) + lane;
+            const int g = (wn0 / p.gn_cpg) + gl;
             const int groups = p.N / p.gn_cpg;
             if (g < groups) {
-                // chunk = (tile, row half, column half): two wavefronts share a row half but own different channels, so
-                // each (chunk = tile * 2 + wm, group) is written by exactly one lane of one wavefront
+                // chunk = (tile, row half): the wavefronts that share a row half own different channels, so each
+                // (chunk = tile * 2 + row half, group) is written by exactly one lane of one wavefront
                 const int chunks_per_b = tiles_img * 2;
-                double *o = p.gn_partial + (((int64_t)b * chunks_per_b + t_img * 2 + wm) * groups + g) * 2;
+                double *o = p.gn_partial + (((int64_t)b * chunks_per_b + t_img * 2 + (RH == 1 ? wm : r)) * groups + g) * 2;
                 o[0] = ds;
                 o[1] = dss;
             }
