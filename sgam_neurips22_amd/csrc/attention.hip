@@ -42,6 +42,15 @@ constexpr int KB = 32;             // keys per LDS block
 constexpr int BLK_BYTES = KB * AD * 4;   // one block of K (or V^T) fragments: hi + lo halves = 32 KB
 constexpr float P_LIFT = 10.0f;    // probabilities are lifted by 2^10 before the fp16 split (keeps the lo half normal)
 constexpr float LOG2E = 1.4426950408889634f;
+// Lazy rescale of the output accumulators: the exponent reference of a query (its "running maximum") only follows the true
+// maximum when some query of the wavefront has outgrown it by more than 2^5.  Until then probabilities may exceed 1 — by at
+// most 2^5, which the fp32 sums do not notice, and 2^(5 + P_LIFT) = 2^15 still fits the fp16 hi half of the split.  (The
+// textbook form rescales whenever ANY of a wavefront's 32 queries sees a new maximum: with 16 key blocks per range that is
+// nearly every trip, and one rescale is 384 VALU instructions on the 128 accumulator registers — as long as half a trip's
+// MFMAs on the split-fp32 kernel, 1.5 x the trip's MFMAs on the 16-bit one.  rocprofv3: 10 860 VALU instructions per
+// wavefront, 6 100 of them rescales.)  The result is the same quotient: numerator and denominator share the reference, and
+// the merge of the key ranges reads the reference that was used.
+constexpr float RESCALE_TAU = 5.0f;
 
 __device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
@@ -310,7 +319,7 @@ __global__ __launch_bounds__(256) void attn_flash_f32x_kernel(const AttnParams p
         if (j + 1 < nb && !(SGAM_ATTN_ABLATE & 2)) {
             mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
             const float m_new = fmaxf(m_run, mloc);
-            if (__any(m_new > m_run)) {                   // wavefront-uniform: the maximum settles after a few blocks
+            if (__any(m_new > m_run + RESCALE_TAU)) {     // wavefront-uniform, rare (see RESCALE_TAU)
                 const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
                 l_run *= alpha;
                 // the output accumulators live in AccVGPRs (MFMA C/D); scale them in place, register by register, so
@@ -516,7 +525,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_h16_kernel(const AttnHParam
         }
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
         const float m_new = fmaxf(m_run, mloc);
-        if (__any(m_new > m_run)) {
+        if (__any(m_new > m_run + RESCALE_TAU)) {
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             l_run *= alpha;
 #pragma unroll
