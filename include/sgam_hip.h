@@ -186,6 +186,15 @@ int sgam_conv2d_h16_plan(const sgam_conv_desc *d, int32_t *bm, int32_t *bn, int3
 int sgam_conv2d_nhwc_h16(const sgam_conv_desc *d, int32_t ht, const void *x, const void *w_packed,
                          const float *bias, const void *residual, void *out, int32_t out_f32, void *workspace,
                          int64_t workspace_bytes, void *stream);
+/* (ABI v5) The same launch with the GroupNorm statistics of the OUTPUT left as per-chunk partial sums (gn_partial
+ * [B][sgam_conv2d_h16_generic_stats_chunks(d)][32][2] doubles, the layout of sgam_conv2d_h16_stats_chunks): the 1x1 / strided
+ * convolutions and the attention block's proj_out (diffusionmodules/model.py:63-75, 168-192) then feed the next Normalize
+ * without a statistics pass.  Available (chunks > 0) when the kernel runs whole-K workgroups with its direct epilogue:
+ * n_valid == N, N % 128 == 0, even row strides, no per-row bias, Ho * Wo a multiple of half the tile's rows. */
+int32_t sgam_conv2d_h16_generic_stats_chunks(const sgam_conv_desc *d);
+int sgam_conv2d_stats_nhwc_h16(const sgam_conv_desc *d, int32_t ht, const void *x, const void *w_packed, const float *bias,
+                               const void *residual, void *out, int32_t out_f32, double *gn_partial, void *workspace,
+                               int64_t workspace_bytes, void *stream);
 /* The 3x3 / stride 1 / pad 1 convolutions of the 16-bit mode on a halo-staged kernel (csrc/h16_halo.hip; ResnetBlock
  * conv1 / conv2, Upsample.conv, conv_out: diffusionmodules/model.py:43-53, 88-102, 117-137): input patch staged once per
  * 32-channel slab, weights in MFMA-fragment order straight to registers, optional GroupNorm(+swish) of the INPUT applied

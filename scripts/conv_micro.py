@@ -16,6 +16,7 @@ ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--ups", action="store_true")
 ap.add_argument("--gn", action="store_true")
 ap.add_argument("--norm", action="store_true", help="GroupNorm(+swish) fused into the staging of the split-fp32 / 16-bit halo kernel")
+ap.add_argument("--no-swish", action="store_true", help="with --norm: GroupNorm without the swish")
 ap.add_argument("--dtype", default="f32")
 a = ap.parse_args()
 B, Cin, Cout, H, W, k = map(int, a.shape.split(","))
@@ -28,7 +29,7 @@ b = testing.seeded_tensor("micro.b", (Cout,)).to(dev)
 gn = None
 if a.gn:
     gn = (ops.groupnorm_stats(x, torch.ones(Cin, device=dev), torch.zeros(Cin, device=dev)), True)
-norm = (torch.ones(Cin, device=dev), torch.zeros(Cin, device=dev), True, 32, 1e-6) if a.norm else None
+norm = (torch.ones(Cin, device=dev), torch.zeros(Cin, device=dev), not a.no_swish, 32, 1e-6) if a.norm else None
 if a.norm:
     x._gn_partials = None
     mr = ops.groupnorm_meanrstd(x)          # statistics once: the timed launches are the conv alone
@@ -49,4 +50,4 @@ torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / a.reps
 M = y.shape[0] * y.shape[1] * y.shape[2]
 fl = 2.0 * M * Cout * k * k * Cin
-print(f"shape {a.shape} ups={a.ups} gn={a.gn}: {ms * 1e3:.1f} us/launch, {fl / ms / 1e9:.1f} TFLOP/s, out {tuple(y.shape)}")
+print(f"shape {a.shape} ups={a.ups} gn={a.gn} norm={a.norm} swish={a.norm and not a.no_swish} {a.dtype}: {ms * 1e3:.1f} us/launch, {fl / ms / 1e9:.1f} TFLOP/s, out {tuple(y.shape)}")

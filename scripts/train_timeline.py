@@ -23,5 +23,5 @@ for name, ms, *_ in recs:
     agg[name][1] += max(ms - br, 0.0)
 tot = sum(v[1] for v in agg.values())
 print(f"{len(recs)} launches, {tot:.2f} ms of kernel time")
-for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:22]:
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
     print(f"{v[1]:8.3f} ms {v[0]:5d}  {k[:90]}")

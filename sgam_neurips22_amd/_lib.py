@@ -101,6 +101,9 @@ PROTOTYPES = {
                                      ctypes.POINTER(c_i32)]),
     "sgam_conv2d_nhwc_h16": (c_i32, [ctypes.POINTER(ConvDesc), c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i64,
                                      c_vp]),
+    "sgam_conv2d_h16_generic_stats_chunks": (c_i32, [ctypes.POINTER(ConvDesc)]),
+    "sgam_conv2d_stats_nhwc_h16": (c_i32, [ctypes.POINTER(ConvDesc), c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i64,
+                                           c_vp]),
     "sgam_conv2d_h16_uses_halo": (c_i32, [ctypes.POINTER(ConvDesc)]),
     "sgam_conv2d_h16_stats_chunks": (c_i32, [ctypes.POINTER(ConvDesc)]),
     "sgam_pack_conv_weight_h16_frag": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),

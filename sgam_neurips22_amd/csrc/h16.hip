@@ -46,6 +46,8 @@ struct H16Params {
     int lda, ldb, ldc, ldr, n_valid, bias_per_row, out_f32;
     int M, ksplit, iters_total, iters_per_split;
     unsigned x_bytes, w_bytes;
+    double *gn_partial;   // optional (direct epilogue, whole-K workgroups): per-(BM / 2 rows, group) {sum, sumsq} of the output
+    int gn_cpg;           // channels per group of the output (N / 32)
 };
 
 constexpr int HBK = 64;          // halfs per K slab
@@ -56,7 +58,13 @@ __device__ __forceinline__ unsigned selu(bool c, unsigned a, unsigned b) {
     return (a & m) | (b & ~m);
 }
 
-template <int BM, int BN, int HT>
+// DIR (the default whenever n_valid % 4 == 0 and the row strides are even): the product is computed TRANSPOSED (weights = MFMA
+// rows, pixels = columns) with the weight rows of every 32-channel tile stored to LDS in the order that makes a lane's sixteen
+// accumulator slots SIXTEEN CONSECUTIVE CHANNELS of one pixel (the h16_halo.hip epilogue): 16-byte stores, 8-byte residual
+// loads, bias / residual / rounding in registers, and — optionally — the GroupNorm statistics of the output as per-chunk
+// partial sums, so that a 1x1 / strided convolution or the attention block's proj_out feeds the next normalisation without a
+// statistics pass.  !DIR: pixels = MFMA rows, one 2- or 4-byte store per accumulator slot (any n_valid, any stride).
+template <int BM, int BN, int HT, bool DIR>
 __global__ __launch_bounds__(256) void conv_gemm_h16_kernel(const H16Params p) {
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int AR = BM / 32, BR = BN / 32;
@@ -146,8 +154,11 @@ __global__ __launch_bounds__(256) void conv_gemm_h16_kernel(const H16Params p) {
         unsigned short *b = Bs + buf * BN * HLD;
 #pragma unroll
         for (int r = 0; r < AR; ++r) *reinterpret_cast<u32x4 *>(a + (row_in_pass + 32 * r) * HLD + col8 * 8) = areg[ST][r];
+        // DIR: channel c = 16 half + e of a 32-channel tile sits in LDS row 8 (e / 4) + 4 half + e % 4 = the MFMA row whose
+        // accumulator slot e belongs to lane half `half`
+        const int brow = DIR ? 8 * ((row_in_pass & 15) >> 2) + 4 * (row_in_pass >> 4) + (row_in_pass & 3) : row_in_pass;
 #pragma unroll
-        for (int r = 0; r < BR; ++r) *reinterpret_cast<u32x4 *>(b + (row_in_pass + 32 * r) * HLD + col8 * 8) = breg[ST][r];
+        for (int r = 0; r < BR; ++r) *reinterpret_cast<u32x4 *>(b + (brow + 32 * r) * HLD + col8 * 8) = breg[ST][r];
     };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
@@ -176,7 +187,7 @@ __global__ __launch_bounds__(256) void conv_gemm_h16_kernel(const H16Params p) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = H<HT>::mfma(af[i], bf[j], acc[i][j]);
+                for (int j = 0; j < TN; ++j) acc[i][j] = DIR ? H<HT>::mfma(bf[j], af[i], acc[i][j]) : H<HT>::mfma(af[i], bf[j], acc[i][j]);
         }
     };
 
@@ -218,6 +229,121 @@ __global__ __launch_bounds__(256) void conv_gemm_h16_kernel(const H16Params p) {
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void *)p.res, 0, (int)r_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)p.bias, 0, (int)bias_bytes, 0x00020000);
     constexpr unsigned OOB = 0xFFFFFFF0u;
+    if constexpr (DIR) {
+        // lane (pixel = lane & 31, half = lane >> 5) holds channels 16 half + e, e = 0..15, of every (row tile, channel tile)
+        const int pl = lane & 31, hh = lane >> 5;
+        const int wn0 = n0 + wn * (BN / 2);
+        float us[TN][4], uss[TN][4];          // per 4-channel unit: sum, sum of squares over this lane's pixels
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nb = wn0 + j * 32 + hh * 16;
+            f32x4 bv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                bv[k] = p.bias_per_row ? f32x4{0.f, 0.f, 0.f, 0.f}
+                                       : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                                       rb, (int)selu(nb + 4 * k < n_lim, (unsigned)(nb + 4 * k) * 4u, OOB), 0, 0));
+                us[j][k] = uss[j][k] = 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = m0 + wm * (BM / 2) + i * 32 + pl;
+                const bool m_ok = m < p.M;
+                const float brow_v = p.bias_per_row ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                                                   rb, (int)selu(m_ok, (unsigned)m * 4u, OOB), 0, 0))
+                                                    : 0.f;
+                u32x4 o16[2];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int n4 = nb + 4 * k;
+                    const bool ok = m_ok && n4 < n_lim;
+                    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+                    const u32x2_t rq = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(
+                                                                       rr, (int)selu(ok, (unsigned)(m * p.ldr + n4) * 2u, OOB), 0, 0));
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (acc[i][j][4 * k + e] + (bv[k][e] + brow_v));
+                    v[0] += H<HT>::to_f((unsigned short)(rq[0] & 0xFFFFu));
+                    v[1] += H<HT>::to_f((unsigned short)(rq[0] >> 16));
+                    v[2] += H<HT>::to_f((unsigned short)(rq[1] & 0xFFFFu));
+                    v[3] += H<HT>::to_f((unsigned short)(rq[1] >> 16));
+                    if (f32o) {
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro,
+                                                               (int)selu(ok, (unsigned)(m * ldo + n4) * 4u, OOB), 0, 0);
+                    } else {
+                        const unsigned short h0 = H<HT>::from_f(v[0]), h1 = H<HT>::from_f(v[1]), h2 = H<HT>::from_f(v[2]),
+                                             h3 = H<HT>::from_f(v[3]);
+                        o16[k >> 1][(k & 1) * 2] = (unsigned)h0 | ((unsigned)h1 << 16);
+                        o16[k >> 1][(k & 1) * 2 + 1] = (unsigned)h2 | ((unsigned)h3 << 16);
+                        // the statistics describe the STORED (rounded) tensor: that is what the next GroupNorm normalises
+                        v = f32x4{H<HT>::to_f(h0), H<HT>::to_f(h1), H<HT>::to_f(h2), H<HT>::to_f(h3)};
+                    }
+                    if (ok) {
+                        us[j][k] += (v[0] + v[1]) + (v[2] + v[3]);
+                        uss[j][k] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                    }
+                }
+                if (!f32o) {
+                    if (nb + 16 <= n_lim) {               // the usual case: two 16-byte stores
+#pragma unroll
+                        for (int q2 = 0; q2 < 2; ++q2)
+                            __builtin_amdgcn_raw_buffer_store_b128(o16[q2], ro, (int)selu(m_ok, (unsigned)(m * ldo + nb + 8 * q2) * 2u, OOB), 0,
+                                                                   0);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+                            const u32x2_t o8 = {o16[k >> 1][(k & 1) * 2], o16[k >> 1][(k & 1) * 2 + 1]};
+                            __builtin_amdgcn_raw_buffer_store_b64(
+                                o8, ro, (int)selu(m_ok && nb + 4 * k < n_lim, (unsigned)(m * ldo + nb + 4 * k) * 2u, OOB), 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        if (p.gn_partial && !to_ws) {
+            // over the 32 pixels of a lane half (xor shuffles stay inside it), then lane 0 of each half leaves its 4 x TN units;
+            // chunk = BM / 2 consecutive rows (the host guarantees that a chunk lies inside one image and that N == n_valid)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int off = 16; off >= 1; off >>= 1) {
+                        us[j][k] += __shfl_xor(us[j][k], off, 64);
+                        uss[j][k] += __shfl_xor(uss[j][k], off, 64);
+                    }
+            __syncthreads();                   // (the operand buffers are dead: every wavefront is past its last MFMA)
+            float *sl = reinterpret_cast<float *>(smem) + wave * (2 * TN * 8);      // wave-private: [unit = 8 j + 4 half + k][2]
+            if (pl == 0) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        sl[(j * 8 + hh * 4 + k) * 2] = us[j][k];
+                        sl[(j * 8 + hh * 4 + k) * 2 + 1] = uss[j][k];
+                    }
+            }
+            const int c4_per_group = p.gn_cpg / 4;
+            const int groups_here = (TN * 8) / c4_per_group;
+            if (lane < groups_here) {
+                double ds = 0.0, dss = 0.0;
+                for (int k = 0; k < c4_per_group; ++k) {
+                    ds += (double)sl[(lane * c4_per_group + k) * 2];
+                    dss += (double)sl[(lane * c4_per_group + k) * 2 + 1];
+                }
+                const int g = (wn0 / p.gn_cpg) + lane;
+                const int groups = p.N / p.gn_cpg;
+                const int chunk = blockIdx.x * 2 + wm;          // image-major: chunks of an image are consecutive
+                if (g < groups && (int64_t)chunk * (BM / 2) < p.M) {
+                    double *o = p.gn_partial + ((int64_t)chunk * groups + g) * 2;
+                    o[0] = ds;
+                    o[1] = dss;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -446,9 +572,25 @@ int hvalidate(const sgam_conv_desc *d) {
     return SGAM_OK;
 }
 
+// the direct (transposed-product) epilogue needs 4-channel units and dword-aligned 8- / 16-byte accesses
+bool h16_direct_ok(const sgam_conv_desc *d) {
+    return d->n_valid % 4 == 0 && d->ldc % 2 == 0 && d->ldr % 2 == 0;
+}
+
+// chunks of output statistics per image the generic kernel can leave (0 = none): whole-K workgroups, the direct epilogue, no
+// padded channels, 32 groups of 4 ... 32 channels that do not straddle a wavefront's channel range, chunks of BM / 2 rows
+// that do not straddle an image
+int h16_generic_chunks(const sgam_conv_desc *d) {
+    if (hvalidate(d) != SGAM_OK || !h16_direct_ok(d) || d->n_valid != d->N || d->N % 128 != 0 || d->bias_per_row) return 0;
+    const HPlan pl = make_hplan(d);
+    const int cpg = d->N / 32, hw = d->Ho * d->Wo;
+    if (pl.ksplit != 1 || cpg % 4 != 0 || (pl.bn / 2) % cpg != 0 || hw % (pl.bm / 2) != 0) return 0;
+    return hw / (pl.bm / 2);
+}
+
 template <int HT>
 int conv_h16_launch(const sgam_conv_desc *d, const void *x, const void *w, const float *bias, const void *res, void *out,
-                    int out_f32, void *workspace, int64_t workspace_bytes, hipStream_t s) {
+                    int out_f32, void *workspace, int64_t workspace_bytes, hipStream_t s, double *gn_partial = nullptr) {
     const HPlan pl = make_hplan(d);
     H16Params p;
     p.x = (const unsigned short *)x; p.w = (const unsigned short *)w; p.res = (const unsigned short *)res; p.bias = bias;
@@ -463,6 +605,9 @@ int conv_h16_launch(const sgam_conv_desc *d, const void *x, const void *w, const
     const int64_t wb = (((int64_t)d->N - 1) * d->ldb + (int64_t)d->KH * d->KW * d->Cin) * 2;
     if (xb >= (1ll << 32) - 64 || wb >= (1ll << 32) - 64) return SGAM_EINVAL;
     p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
+    p.gn_partial = gn_partial; p.gn_cpg = d->N / 32;
+    if (gn_partial && h16_generic_chunks(d) <= 0) return SGAM_EINVAL;
+    const bool dir = h16_direct_ok(d);
     if (pl.ksplit > 1) {
         const int64_t need = (int64_t)pl.ksplit * p.M * p.N * (int64_t)sizeof(float);
         if (!workspace || workspace_bytes < need || !sgam_aligned16(workspace)) return SGAM_EWORKSPACE;
@@ -474,9 +619,15 @@ int conv_h16_launch(const sgam_conv_desc *d, const void *x, const void *w, const
         sgam_i_prof_work(2.0 * p.M * d->n_valid * (double)(d->KH * d->KW * d->Cin),
                          2.0 * ((double)d->B * d->Hi * d->Wi * d->Cin + (double)d->n_valid * d->KH * d->KW * d->Cin +
                                 (double)p.M * d->n_valid));
-    if (pl.bm == 128 && pl.bn == 128) SGAM_KLAUNCH((conv_gemm_h16_kernel<128, 128, HT>), grid, dim3(256), 0, s, p);
-    else if (pl.bm == 64 && pl.bn == 128) SGAM_KLAUNCH((conv_gemm_h16_kernel<64, 128, HT>), grid, dim3(256), 0, s, p);
-    else SGAM_KLAUNCH((conv_gemm_h16_kernel<64, 64, HT>), grid, dim3(256), 0, s, p);
+#define H16_LAUNCH(DIR_)                                                                                              \
+    do {                                                                                                              \
+        if (pl.bm == 128 && pl.bn == 128) SGAM_KLAUNCH((conv_gemm_h16_kernel<128, 128, HT, DIR_>), grid, dim3(256), 0, s, p); \
+        else if (pl.bm == 64 && pl.bn == 128) SGAM_KLAUNCH((conv_gemm_h16_kernel<64, 128, HT, DIR_>), grid, dim3(256), 0, s, p); \
+        else SGAM_KLAUNCH((conv_gemm_h16_kernel<64, 64, HT, DIR_>), grid, dim3(256), 0, s, p);                          \
+    } while (0)
+    if (dir) H16_LAUNCH(true);
+    else H16_LAUNCH(false);
+#undef H16_LAUNCH
     SGAM_LAUNCH_CHECK();
     if (pl.ksplit > 1) {
         const int64_t q = (int64_t)p.M * (p.N / 4);
@@ -522,6 +673,21 @@ extern "C" int sgam_conv2d_nhwc_h16(const sgam_conv_desc *d, int32_t ht, const v
     hipStream_t s = sgam_stream(stream);
     HT_DISPATCH(ht, return conv_h16_launch<0>(d, x, w_packed, bias, residual, out, out_f32, workspace, workspace_bytes, s),
                 return conv_h16_launch<1>(d, x, w_packed, bias, residual, out, out_f32, workspace, workspace_bytes, s));
+    return SGAM_OK;
+}
+
+extern "C" int32_t sgam_conv2d_h16_generic_stats_chunks(const sgam_conv_desc *d) { return d ? h16_generic_chunks(d) : 0; }
+
+extern "C" int sgam_conv2d_stats_nhwc_h16(const sgam_conv_desc *d, int32_t ht, const void *x, const void *w_packed,
+                                          const float *bias, const void *residual, void *out, int32_t out_f32, double *gn_partial,
+                                          void *workspace, int64_t workspace_bytes, void *stream) {
+    const int rc = hvalidate(d);
+    if (rc != SGAM_OK) return rc;
+    if (!x || !w_packed || !out || !gn_partial) return SGAM_EINVAL;
+    if (!sgam_aligned16(x) || !sgam_aligned16(w_packed) || !sgam_aligned16(gn_partial)) return SGAM_EALIGN;
+    hipStream_t s = sgam_stream(stream);
+    HT_DISPATCH(ht, return conv_h16_launch<0>(d, x, w_packed, bias, residual, out, out_f32, workspace, workspace_bytes, s, gn_partial),
+                return conv_h16_launch<1>(d, x, w_packed, bias, residual, out, out_f32, workspace, workspace_bytes, s, gn_partial));
     return SGAM_OK;
 }
 

@@ -251,7 +251,9 @@ def _attn_h16(self, x, wqkv, bqkv, wp, bp):
             s = ops.gemm_nt(qkv[:, :C], qkv[:, C:2 * C], out_dtype=torch.float32)  # (n, n) fp32 scores
             p = ops.softmax_rows_h16(s, scale, x.dtype)                            # (n, n) 16-bit probabilities
             o = ops.gemm_nt(p, vt)                                                 # (n, C)
-        ops.gemm_nt(o, wp, bias=bp, residual=x[b].reshape(n, C), out=out[b].reshape(n, C))
+        ob = ops.gemm_nt(o, wp, bias=bp, residual=x[b].reshape(n, C), out=out[b].reshape(n, C))
+        if B == 1 and hasattr(ob, "_gn_partials"):
+            out._gn_partials = ob._gn_partials   # statistics of the block output for the next GroupNorm
     return out
 
 

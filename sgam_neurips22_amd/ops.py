@@ -458,6 +458,15 @@ def _run_conv_inner(lib, desc, x, w, bias, residual, out, gn=None, a_scale=1.0):
         if ws_bytes < 0:
             raise SgamHipError(f"sgam_conv2d_h16: unsupported shape {[(f, getattr(desc, f)) for f, _ in desc._fields_]}")
         ws = torch.empty((ws_bytes,), device=x.device, dtype=torch.uint8) if ws_bytes else None
+        # statistics of `out` for the GroupNorm that usually follows (1x1 / strided convolutions, proj_out): per-chunk partial
+        # sums from the direct epilogue of the generic kernel
+        chunks = lib.sgam_conv2d_h16_generic_stats_chunks(ctypes.byref(desc)) if (FUSE_GN_STATS and out.dtype in H16) else 0
+        if chunks > 0:
+            partial = torch.empty((desc.B * chunks * 32 * 2,), device=x.device, dtype=torch.float64)
+            check(lib.sgam_conv2d_stats_nhwc_h16(ctypes.byref(desc), H16[x.dtype], _p(x), _p(w), _p(bias), _p(residual), _p(out), 0,
+                                                 _p(partial), _p(ws), ws_bytes, _stream()), "sgam_conv2d_stats_nhwc_h16")
+            out._gn_partials = (partial, chunks)
+            return out
         check(lib.sgam_conv2d_nhwc_h16(ctypes.byref(desc), H16[x.dtype], _p(x), _p(w), _p(bias), _p(residual), _p(out),
                                        int(out.dtype == torch.float32), _p(ws), ws_bytes, _stream()),
               "sgam_conv2d_nhwc_h16")

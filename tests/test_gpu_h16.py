@@ -50,6 +50,46 @@ def test_conv_h16(dt, case):
 
 
 @pytest.mark.parametrize("dt", DT, ids=["bf16", "fp16"])
+@pytest.mark.parametrize("case", [("proj64", 1, 256, 256, 64, 64, 1, 1, (0, 0, 0, 0)), ("nin32_b2", 2, 256, 512, 32, 32, 1, 1, (0, 0, 0, 0)),
+                                  ("down128", 1, 128, 128, 128, 128, 3, 2, (0, 0, 1, 1)), ("down_b3", 3, 128, 128, 32, 32, 3, 2, (0, 0, 1, 1)),
+                                  ("proj16", 1, 512, 512, 16, 16, 1, 1, (0, 0, 0, 0))], ids=lambda c: c[0])
+def test_generic_conv_h16_leaves_groupnorm_statistics(dt, case):
+    """the generic 16-bit kernel's direct epilogue (csrc/h16.hip): the output equals the fp32 operator on the same rounded
+    operands, and where it runs whole-K workgroups the GroupNorm statistics of the STORED output leave with it (the 1x1 /
+    strided convolutions and proj_out feed the next Normalize without a statistics pass); a split-K plan leaves none."""
+    tag, B, Cin, Cout, H, W, k, stride, pad = case
+    x = testing.seeded_tensor(tag + ".x", (B, Cin, H, W), 1.2, 0.3).to(dt)
+    w = testing.seeded_tensor(tag + ".w", (Cout, Cin, k, k), scale=(1.0 / (Cin * k * k)) ** 0.5)
+    b = testing.seeded_tensor(tag + ".b", (Cout,), scale=0.1)
+    ref = F.conv2d(F.pad(x.float(), (pad[1], pad[3], pad[0], pad[2])), w.to(dt).float(), b, stride=stride)
+    res = testing.seeded_tensor(tag + ".r", tuple(ref.shape)).to(dt)
+    wp = ops.pack_conv_weight(w.to(DEV), dtype=dt)
+    kw = dict(cout=Cout, kh=k, kw=k, stride=stride, pad_t=pad[0], pad_l=pad[1], pad_b=pad[2], pad_r=pad[3])
+    out = ops.conv2d_nhwc(_nhwc(x).to(DEV), wp, b.to(DEV), residual=_nhwc(res).to(DEV), **kw)
+    assert out.dtype == dt and _rel(out.permute(0, 3, 1, 2), ref + res.float()) <= 1.5 * EPS[dt]
+    Ho, Wo = ref.shape[2:]
+    if not hasattr(out, "_gn_partials"):
+        assert tag in ("proj16", "down_b3")      # 16 x 16 maps: too few tiles for whole-K workgroups -> split-K, no statistics
+        return
+    assert out._gn_partials[1] in (Ho * Wo // 32, Ho * Wo // 64)      # (the tile, hence the chunk, is the tuned plan's)
+    st = ops.groupnorm_meanrstd(out).cpu()
+    og = out.float().permute(0, 3, 1, 2).cpu().double().reshape(B, 32, -1)
+    assert torch.allclose(st[:, :, 0].double(), og.mean(-1), rtol=0, atol=1e-5)
+    assert torch.allclose(st[:, :, 1].double(), (og.var(-1, unbiased=False) + 1e-6).rsqrt(), rtol=1e-5, atol=0)
+    # ... and a GEMM whose rows are not images at all (B = 1, one "image" of M rows): same statistics over the whole matrix
+    if B == 1:
+        w2 = ops.cast(testing.seeded_tensor(tag + ".w2", (Cout, Cout), scale=Cout ** -0.5).to(DEV), dt)
+        o2 = ops.gemm_nt(out.reshape(-1, Cout), w2)
+        if hasattr(o2, "_gn_partials"):
+            v2 = o2.view(1, Ho, Wo, Cout)
+            v2._gn_partials = o2._gn_partials
+            st2 = ops.groupnorm_meanrstd(v2).cpu()
+            og2 = o2.float().view(1, Ho * Wo, Cout).permute(0, 2, 1).cpu().double().reshape(1, 32, -1)
+            assert torch.allclose(st2[:, :, 0].double(), og2.mean(-1), rtol=0, atol=1e-5)
+            assert torch.allclose(st2[:, :, 1].double(), (og2.var(-1, unbiased=False) + 1e-6).rsqrt(), rtol=1e-5, atol=0)
+
+
+@pytest.mark.parametrize("dt", DT, ids=["bf16", "fp16"])
 @pytest.mark.parametrize("B,C,H,W", [(1, 128, 64, 64), (2, 256, 12, 12), (1, 512, 16, 16), (1, 128, 256, 256), (2, 256, 80, 80)])
 def test_groupnorm_h16(dt, B, C, H, W):
     x = testing.seeded_tensor("gn16.x", (B, C, H, W), 3.0, 0.5).to(dt)
