@@ -233,6 +233,11 @@ int sgam_groupnorm_nhwc_h16(const void *x, const float *gamma, const float *beta
 /* p_out[r][:] (16-bit) = softmax(scale * s_in[r][:]) (fp32 scores) */
 int sgam_softmax_rows_h16(const float *s_in, void *p_out, int32_t ht, int32_t rows, int32_t cols, int32_t lds,
                           int32_t ldp, float scale, void *stream);
+/* (ABI v5) block-diagonal form: row r keeps the columns of its own block [r / block * block, + block), the others become
+ * exact zeros — the attention of B images whose tokens do not fill the fused kernel (16 x 16 maps, C = 512) as ONE
+ * (B n) x (B n) score matrix instead of B small GEMM / softmax / GEMM chains. */
+int sgam_softmax_rows_blockdiag_h16(const float *s_in, void *p_out, int32_t ht, int32_t rows, int32_t cols, int32_t lds,
+                                    int32_t ldp, float scale, int32_t block, void *stream);
 int sgam_encode_head_h16(const float *x, const uint8_t *mask, const float *w, const float *bias, void *y,
                          int32_t ht, int32_t B, int32_t HW, int32_t ldy, void *stream);
 /* y[c][p] = x[p][c] for a [HW][ldx] 16-bit matrix (v -> v^T for the P.V product) */
@@ -263,6 +268,8 @@ int sgam_groupnorm_stats_nhwc_f32(const float *x, const float *gamma, const floa
  * Replaces `w_ * c**-0.5` + softmax(dim=2): diffusionmodules/model.py:181-182.
  * ------------------------------------------------------------------------------------------ */
 int sgam_softmax_rows_f32(float *s, int32_t rows, int32_t cols, int32_t ld, float scale, void *stream);
+int sgam_softmax_rows_blockdiag_f32(float *s, int32_t rows, int32_t cols, int32_t ld, float scale, int32_t block,
+                                    void *stream);   /* (ABI v5) see sgam_softmax_rows_blockdiag_h16 */
 
 /* ------------------------------------------------------------------------------------------
  * K4-K6 fused — single-head self-attention of the AttnBlock in one pass over the keys (attention.hip):

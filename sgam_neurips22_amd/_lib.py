@@ -23,6 +23,8 @@ class TsdfGrid(ctypes.Structure):
 
 
 # name -> (restype, argtypes); must list every symbol include/sgam_hip.h declares
+ABI_VERSION = 5      # include/sgam_hip.h: sgam_abi_version() of the library these prototypes were written against
+
 PROTOTYPES = {
     "sgam_abi_version": (c_i32, []),
     "sgam_build_info": (ctypes.c_char_p, []),
@@ -120,6 +122,7 @@ PROTOTYPES = {
     "sgam_groupnorm_nhwc_h16": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp,
                                         c_i64, c_vp]),
     "sgam_softmax_rows_h16": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp]),
+    "sgam_softmax_rows_blockdiag_h16": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp]),
     "sgam_encode_head_h16": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "sgam_transpose_h16": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "sgam_groupnorm_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
@@ -128,6 +131,7 @@ PROTOTYPES = {
     "sgam_groupnorm_stats_nhwc_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_i64,
                                               c_vp]),
     "sgam_softmax_rows_f32": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_f32, c_vp]),
+    "sgam_softmax_rows_blockdiag_f32": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp]),
     "sgam_attention_f32x_workspace_bytes": (c_i64, [c_i32, c_i32]),
     "sgam_attention_f32x": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_i32, c_vp, c_i64, c_vp]),
     "sgam_attention_h16_workspace_bytes": (c_i64, [c_i32, c_i32]),
@@ -190,6 +194,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    if lib.sgam_abi_version() != ABI_VERSION:
+        raise SgamHipError(f"{LIB_PATH} speaks ABI v{lib.sgam_abi_version()}, these bindings v{ABI_VERSION}: rebuild "
+                           "(`python -m sgam_neurips22_amd.build`)")
     _lib = lib
     return lib
 

@@ -428,19 +428,25 @@ __global__ void cast_h16_to_f32_kernel(const unsigned short *x, float *y, int64_
 // softmax over fp32 scores, probabilities written in the 16-bit type (the A operand of the P.V GEMM)
 template <int HT, int MAXV>
 __global__ __launch_bounds__(256) void softmax_rows_h16_kernel(const float *__restrict__ s, unsigned short *__restrict__ pout,
-                                                               int cols, int lds, int ldp, float scale) {
+                                                               int cols, int lds, int ldp, float scale, int block) {
     const float *row = s + (int64_t)blockIdx.x * lds;
     unsigned short *orow = pout + (int64_t)blockIdx.x * ldp;
     const int c4 = cols >> 2;
+    // block > 0: block-diagonal form (norm_softmax.hip): the columns outside the row's own block become exact zeros
+    const int lo4 = block ? ((int)blockIdx.x / block) * (block >> 2) : 0, hi4 = block ? lo4 + (block >> 2) : c4;
     f32x4 v[MAXV];
     float mx = -INFINITY;
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) {
         const int i = threadIdx.x + k * 256;
         if (i < c4) {
-            v[k] = reinterpret_cast<const f32x4 *>(row)[i];
+            if (i >= lo4 && i < hi4) {
+                v[k] = reinterpret_cast<const f32x4 *>(row)[i];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[k][e] *= scale; mx = fmaxf(mx, v[k][e]); }
+                for (int e = 0; e < 4; ++e) { v[k][e] *= scale; mx = fmaxf(mx, v[k][e]); }
+            } else {
+                v[k] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            }
         }
     }
     __shared__ float red[4];
@@ -721,13 +727,13 @@ extern "C" int sgam_cast_h16_f32(const void *x, float *y, int32_t ht, int64_t n,
     return SGAM_OK;
 }
 
-extern "C" int sgam_softmax_rows_h16(const float *s_in, void *p_out, int32_t ht, int32_t rows, int32_t cols, int32_t lds,
-                                     int32_t ldp, float scale, void *stream) {
+static int softmax_rows_h16_impl(const float *s_in, void *p_out, int32_t ht, int32_t rows, int32_t cols, int32_t lds,
+                                 int32_t ldp, float scale, int32_t block, void *stream) {
     if (!s_in || !p_out || rows <= 0 || cols <= 0 || cols % 4 != 0 || lds < cols || ldp < cols || lds % 4 != 0 || ldp % 4 != 0)
         return SGAM_EINVAL;
     hipStream_t s = sgam_stream(stream);
     unsigned short *po = (unsigned short *)p_out;
-#define SM_LAUNCH(HTV, MV) SGAM_KLAUNCH((softmax_rows_h16_kernel<HTV, MV>), dim3(rows), dim3(256), 0, s, s_in, po, cols, lds, ldp, scale)
+#define SM_LAUNCH(HTV, MV) SGAM_KLAUNCH((softmax_rows_h16_kernel<HTV, MV>), dim3(rows), dim3(256), 0, s, s_in, po, cols, lds, ldp, scale, block)
     if (cols <= 1024) HT_DISPATCH(ht, SM_LAUNCH(0, 1), SM_LAUNCH(1, 1));
     else if (cols <= 4096) HT_DISPATCH(ht, SM_LAUNCH(0, 4), SM_LAUNCH(1, 4));
     else if (cols <= 16384) HT_DISPATCH(ht, SM_LAUNCH(0, 16), SM_LAUNCH(1, 16));
@@ -735,6 +741,17 @@ extern "C" int sgam_softmax_rows_h16(const float *s_in, void *p_out, int32_t ht,
 #undef SM_LAUNCH
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
+}
+
+extern "C" int sgam_softmax_rows_h16(const float *s_in, void *p_out, int32_t ht, int32_t rows, int32_t cols, int32_t lds,
+                                     int32_t ldp, float scale, void *stream) {
+    return softmax_rows_h16_impl(s_in, p_out, ht, rows, cols, lds, ldp, scale, 0, stream);
+}
+
+extern "C" int sgam_softmax_rows_blockdiag_h16(const float *s_in, void *p_out, int32_t ht, int32_t rows, int32_t cols, int32_t lds,
+                                               int32_t ldp, float scale, int32_t block, void *stream) {
+    if (block <= 0 || block % 4 != 0 || rows % block != 0 || cols % block != 0 || rows / block > cols / block) return SGAM_EINVAL;
+    return softmax_rows_h16_impl(s_in, p_out, ht, rows, cols, lds, ldp, scale, block, stream);
 }
 
 extern "C" int sgam_encode_head_h16(const float *x, const uint8_t *mask, const float *w, const float *bias, void *y, int32_t ht,

@@ -159,6 +159,9 @@ class ResnetBlock(_NHWCModule):
         return super().forward(x)
 
 
+BLOCKDIAG_MAX_ROWS = 4096      # B * n up to which a batch of small attention blocks runs as one block-diagonal chain (64 MB of scores)
+
+
 class AttnBlock(_NHWCModule):
     """Single-head spatial self-attention (reference :168-192) as MFMA GEMMs + a row softmax:
     [q|k|v] = GN(x) Wqkv^T (GroupNorm fused into the operand staging), S = q k^T, P = softmax(S c^-1/2),
@@ -213,6 +216,15 @@ class AttnBlock(_NHWCModule):
             # convolution it is (per-image GroupNorm statistics of the block output from its epilogue)
             o = ops.attention(qkv_all, C, scale, B=B)
             return self.proj_out.forward_nhwc(o.view(B, H, W, C), residual=x)
+        if B > 1 and fused_qkv and B * n <= BLOCKDIAG_MAX_ROWS and n % 4 == 0:
+            # the small blocks of a batch (16 x 16 maps, C = 512: not the fused kernel's shape) as ONE block-diagonal chain: a
+            # (B n) x (B n) score matrix whose soft-max keeps a query inside its image — 8 x the score FLOPs of B separate
+            # chains, all of 4 GF at B = 8, against 5 launches per IMAGE
+            vt = ops.nhwc_to_nchw(qkv_all[:, 2 * C:].unsqueeze(0).unsqueeze(0), c=C).view(C, B * n)
+            s = ops.gemm_nt(qkv_all[:, :C], qkv_all[:, C:2 * C])
+            ops.softmax_rows_(s, scale, block=n)
+            o = ops.gemm_nt(s, vt, a_scale=1024.0)
+            return self.proj_out.forward_nhwc(o.view(B, H, W, C), residual=x)
         out = torch.empty_like(x)
         for b in range(B):
             xb = x[b].reshape(n, C)
@@ -240,6 +252,12 @@ def _attn_h16(self, x, wqkv, bqkv, wp, bp):
     if B > 1 and ops.attention_fusable(n, C):
         qkv = ops.gemm_nt(h.reshape(B * n, C), wqkv, bias=bqkv)                    # (B n, 3C): the whole batch in one GEMM
         o = ops.attention_h16(qkv, C, scale, B=B)
+        return self.proj_out.forward_nhwc(o.view(B, H, W, C), residual=x)
+    if B > 1 and B * n <= BLOCKDIAG_MAX_ROWS and n % 4 == 0:
+        qkv = ops.gemm_nt(h.reshape(B * n, C), wqkv, bias=bqkv)                    # block-diagonal chain (forward_nhwc)
+        vt = ops.transpose_h16(qkv[:, 2 * C:])
+        s = ops.gemm_nt(qkv[:, :C], qkv[:, C:2 * C], out_dtype=torch.float32)
+        o = ops.gemm_nt(ops.softmax_rows_h16(s, scale, x.dtype, block=n), vt)
         return self.proj_out.forward_nhwc(o.view(B, H, W, C), residual=x)
     out = torch.empty_like(x)
     for b in range(B):

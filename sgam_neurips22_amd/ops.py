@@ -622,11 +622,15 @@ def groupnorm_meanrstd(x, eps=1e-6):
     return out
 
 
-def softmax_rows_h16(s, scale, dtype):
-    """fp32 scores (rows, cols) -> 16-bit probabilities softmax(scale * s)."""
+def softmax_rows_h16(s, scale, dtype, block=0):
+    """fp32 scores (rows, cols) -> 16-bit probabilities softmax(scale * s); block > 0: block-diagonal (softmax_rows_)."""
     _need_cuda(s)
     rows, cols = s.shape
     p = torch.empty((rows, cols), device=s.device, dtype=dtype)
+    if block:
+        check(_lib.load().sgam_softmax_rows_blockdiag_h16(_p(s), _p(p), H16[dtype], rows, cols, s.stride(0), p.stride(0), float(scale),
+                                                          int(block), _stream()), "sgam_softmax_rows_blockdiag_h16")
+        return p
     check(_lib.load().sgam_softmax_rows_h16(_p(s), _p(p), H16[dtype], rows, cols, s.stride(0), p.stride(0), float(scale),
                                             _stream()), "sgam_softmax_rows_h16")
     return p
@@ -688,9 +692,15 @@ def attention_h16(qkv, C, scale, out=None, B=1):
     return out
 
 
-def softmax_rows_(s, scale):
+def softmax_rows_(s, scale, block=0):
+    """in place: s = softmax(scale * s) over each row; block > 0: every row over the columns of ITS diagonal block only, exact
+    zeros elsewhere (B images' scores as one matrix: a query never attends to another image's keys)."""
     _need_cuda(s)
     rows, cols = s.shape
+    if block:
+        check(_lib.load().sgam_softmax_rows_blockdiag_f32(_p(s), rows, cols, s.stride(0), float(scale), int(block), _stream()),
+              "sgam_softmax_rows_blockdiag_f32")
+        return s
     check(_lib.load().sgam_softmax_rows_f32(_p(s), rows, cols, s.stride(0), float(scale), _stream()),
           "sgam_softmax_rows_f32")
     return s

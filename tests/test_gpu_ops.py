@@ -162,6 +162,23 @@ def test_softmax_rows(rows, cols):
     assert torch.allclose(out.sum(1).cpu(), torch.ones(rows), atol=1e-5)
 
 
+@pytest.mark.parametrize("B,n", [(3, 256), (8, 256), (2, 64)])
+def test_softmax_rows_block_diagonal(B, n):
+    """the block-diagonal form (B images' scores as ONE matrix): every row is the soft-max over its own diagonal block, exact
+    zeros elsewhere — fp32 in place and the 16-bit output form — and an attention block at batch B equals the per-image chain."""
+    s = testing.seeded_tensor("smbd", (B * n, B * n), 4.0)
+    ref = torch.zeros_like(s)
+    for b in range(B):
+        ref[b * n:(b + 1) * n, b * n:(b + 1) * n] = F.softmax(s[b * n:(b + 1) * n, b * n:(b + 1) * n] * 0.0625, dim=1)
+    out = ops.softmax_rows_(s.to(DEV).clone(), 0.0625, block=n)
+    _close(out, ref, 1e-6, "block-diagonal softmax")
+    assert bool((out.cpu()[ref == 0] == 0).all()), "another image's keys must get exactly zero"
+    p16 = ops.softmax_rows_h16(s.to(DEV), 0.0625, torch.bfloat16, block=n)
+    assert bool((p16.float().cpu()[ref == 0] == 0).all()) and (p16.float().cpu() - ref).abs().max().item() <= 2 ** -8
+    with pytest.raises(ops.SgamHipError):
+        ops.softmax_rows_(s.to(DEV).clone(), 0.0625, block=n + 2)
+
+
 def test_encode_head():
     x, mask = testing.rect_hole_input(2, 32, 48)
     w = testing.seeded_tensor("head.w", (4, 5, 1, 1), 0.4)

@@ -58,6 +58,31 @@ def test_attn_block_c128_matches_oracle(shape):
     assert _maxerr(y, ref) <= 5e-5
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_small_attention_blocks_of_a_batch_run_block_diagonal(dt):
+    """the 16 x 16 x 512 AttnBlocks of a batch (lock-stepped scenes) run as ONE block-diagonal chain — a (B n) x (B n) score
+    matrix whose soft-max zeroes every other image's keys: against the oracle (fp32) and against the per-image chain at B = 1."""
+    from oracle import vqgan as OV
+    mod = dm.AttnBlock(512)
+    sd = testing.synthetic_state_dict(mod.state_dict(), seed=5)
+    mod.load_state_dict(sd)
+    mod = mod.to(DEV).eval()
+    x = testing.seeded_tensor("attn512b", (3, 512, 16, 16))
+    with torch.no_grad():
+        if dt == "f32":
+            y = mod(x.to(DEV))
+            ref = OV.attn_block({"a." + k: v for k, v in sd.items()}, "a", x)
+            assert _maxerr(y, ref) <= 5e-5
+            for b in range(3):
+                assert _maxerr(mod(x[b:b + 1].to(DEV)), y[b:b + 1]) <= 2e-5
+        else:
+            xh = ops.cast(ops.nchw_to_nhwc(x.to(DEV)), torch.bfloat16)
+            yb = mod.forward_nhwc(xh).float()
+            for b in range(3):
+                y1 = mod.forward_nhwc(xh[b:b + 1].contiguous()).float()
+                assert _maxerr(y1, yb[b:b + 1]) <= 2 ** -5, "bf16: one rounding step of an O(1) activation"
+
+
 def test_normalize_matches_reference_golden(golden):
     g = golden("vqgan_ops.npz")
     gn = dm.Normalize(256)
