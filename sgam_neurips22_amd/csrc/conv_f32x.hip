@@ -585,7 +585,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
     // twice the weight-fragment loads, which two wavefronts share in the vector L1)
     // BN = 32 (narrow outputs: the decoder's conv_out, 128 -> 4 channels, weights padded to ONE 32-channel tile instead of a
     // 128-channel tile of mostly-zero columns): the four wavefronts stack along M, each 32 rows x 32 channels
-    constexpr int WGM_ = BN == 32 ? 4 : SGAM_XWGM, WGN_ = 4 / WGM_;
+    // BN = 64 (whole-K workgroups for the 64 x 64 maps: 64 tiles x N / 64 = 256 workgroups WITHOUT a split-K plan and its combine
+    // launch): a 2 x 2 grid, each wavefront 32 rows x 32 channels
+    constexpr int WGM_ = BN == 32 ? 4 : (BN == 64 ? 2 : SGAM_XWGM), WGN_ = 4 / WGM_;
     constexpr int TH = 8, TW = BM / 8, TWS = (TW == 16) ? 4 : 3;
     constexpr int HROWS = UPS ? TH / 2 + 2 : TH + 2, HWID = UPS ? TW / 2 + 2 : TW + 2, HR = HROWS * HWID;
     static_assert(!(UPS && GN), "no GroupNorm precedes an upsampling conv");
@@ -1450,8 +1452,10 @@ static bool halo_shape(const sgam_conv_desc *d, int bm, int bn) {
     if (bm == 32 && bn == 32) return k4_shape(d);
     if (bm == 256 && bn == 32) return ws_shape(d);
     static const int halo_on = [] { const char *e = getenv("SGAM_F32X_HALO"); return (e && e[0] == '0') ? 0 : 1; }();
+    static const int h64_on = [] { const char *e = getenv("SGAM_F32X_HALO64"); return (e && e[0] == '0') ? 0 : 1; }();
     const bool tile_ok = (bm == 128 && bn == 128 && d->Wo % 16 == 0) || (bm == 64 && bn == 128 && d->Wo % 8 == 0) ||
-                         (bm == 128 && bn == 32 && d->Wo % 16 == 0 && d->N == 32 && !d->upsample2x);
+                         (bm == 128 && bn == 32 && d->Wo % 16 == 0 && d->N == 32 && !d->upsample2x) ||
+                         (bm == 64 && bn == 64 && h64_on && d->Wo % 8 == 0 && d->N % 64 == 0 && !d->upsample2x);
     const int up = d->upsample2x ? 2 : 1;
     return halo_on && tile_ok && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 &&
            d->Ho == up * d->Hi && d->Wo == up * d->Wi && d->Ho % 8 == 0 && d->Cin % 32 == 0;
@@ -1489,7 +1493,7 @@ XPlan make_xplan(const sgam_conv_desc *d) {
         pl.ksplit = (pl.iters_total + pl.iters_per_split - 1) / pl.iters_per_split;
         return pl;
     }
-    const int xbk = xbk_of(pl.bm, pl.bn);
+    const int xbk = halo_shape(d, pl.bm, pl.bn) ? 32 : xbk_of(pl.bm, pl.bn);     // (the halo kernels walk 32-channel slabs)
     pl.iters_total = d->KH * d->KW * ((d->Cin + xbk - 1) / xbk);
     const int64_t nb = blocks(pl.bm, pl.bn);
     int ks = 1;
@@ -1754,6 +1758,10 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
         } else if (pl.bm == 128) {
             if (p.gn_stats) SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<128, 128, true>), grid, dim3(256), 0, s, p);
             else SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<128, 128, false>), grid, dim3(256), 0, s, p);
+        } else if (pl.bn == 64) {
+            if (p.gn_partial_in) return SGAM_EINVAL;
+            if (p.gn_stats) SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<64, 64, true>), grid, dim3(256), 0, s, p);
+            else SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<64, 64, false>), grid, dim3(256), 0, s, p);
         } else {
             if (p.gn_partial_in) SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<64, 128, true, false, true>), grid, dim3(256), 0, s, p);
             else if (p.gn_stats) SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<64, 128, true>), grid, dim3(256), 0, s, p);

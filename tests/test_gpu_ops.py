@@ -315,7 +315,7 @@ def test_conv_groupnorm_fused_into_halo_staging(B, C, Cout, H, W, swish, with_re
     assert (fused - two_pass).abs().max().item() <= 2e-6 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("plan", [(64, 128, 1), (64, 128, 3), (128, 128, 2)])
+@pytest.mark.parametrize("plan", [(64, 128, 1), (64, 128, 3), (128, 128, 2), (64, 64, 1), (64, 64, 2)])
 def test_halo_kernel_tile_plans(plan):
     """the halo-staged 3x3 kernel under each of its tile plans (8x8 and 8x16 patches, split-K) against fp64"""
     ops.set_f32_mode("split")
@@ -335,6 +335,39 @@ def test_halo_kernel_tile_plans(plan):
             ops.PLAN_CACHE[key] = old
     ref = F.conv2d(x.permute(0, 3, 1, 2).cpu().double(), w.double(), padding=1).float()
     _close(out.permute(0, 3, 1, 2), ref, 2e-5, f"halo plan {plan}")
+
+
+def test_halo_kernel_64_channel_tile_with_fused_groupnorm():
+    """plan tile (64, 64) on a 3x3 / s1 / p1 shape = the halo kernel with a 2 x 2 wavefront grid of 32 rows x 32 channels (whole-K
+    workgroups for the 64 x 64 maps: no split-K plan, no combine launch): GroupNorm + swish fused into its staging and the output
+    statistics from its epilogue, against the (64, 128) tile of the same kernel."""
+    ops.set_f32_mode("split")
+    B, C, H, W = 1, 256, 64, 64
+    x = _nhwc(testing.seeded_tensor("h64.x", (B, C, H, W), 1.5, 0.3)).to(DEV)
+    w = testing.seeded_tensor("h64.w", (C, C, 3, 3), scale=(1.0 / (C * 9)) ** 0.5)
+    b = testing.seeded_tensor("h64.b", (C,), scale=0.1).to(DEV)
+    g, bt = (1 + 0.1 * testing.seeded_tensor("h64.g", (C,))).to(DEV), (0.1 * testing.seeded_tensor("h64.bt", (C,))).to(DEV)
+    res = _nhwc(testing.seeded_tensor("h64.r", (B, C, H, W))).to(DEV)
+    wp = ops.pack_conv_weight(w.to(DEV), dtype="f32x")
+    key = f"f32x|B{B}|{H}x{W}x{C}|{H}x{W}|N{C}|k3x3s1u0"
+    old = ops.PLAN_CACHE.get(key)
+    outs = {}
+    try:
+        for plan in ((64, 128, 1), (64, 64, 1)):
+            ops.PLAN_CACHE[key] = plan
+            outs[plan] = ops.conv2d_nhwc(x, wp, b, cout=C, kh=3, kw=3, pad_t=1, pad_l=1, residual=res, norm=(g, bt, True, 32, 1e-6))
+    finally:
+        if old is None:
+            ops.PLAN_CACHE.pop(key, None)
+        else:
+            ops.PLAN_CACHE[key] = old
+    a, c = outs[(64, 128, 1)], outs[(64, 64, 1)]
+    assert (a - c).abs().max().item() <= 1e-6      # same products, same K order per output
+    assert hasattr(c, "_gn_partials")
+    st = ops.groupnorm_meanrstd(c).cpu()
+    og = c.permute(0, 3, 1, 2).cpu().double().reshape(B, 32, -1)
+    assert torch.allclose(st[:, :, 0].double(), og.mean(-1), rtol=0, atol=1e-6)
+    assert torch.allclose(st[:, :, 1].double(), (og.var(-1, unbiased=False) + 1e-6).rsqrt(), rtol=1e-5, atol=0)
 
 
 @pytest.mark.parametrize("C,H,W,ks,folds", [(512, 16, 16, 4, False), (256, 32, 32, 4, True), (256, 64, 64, 4, False),
