@@ -109,8 +109,10 @@ def test_split_fp32_plan_queries_without_gpu():
     # stride 2 / 1x1 / maps that do not tile into 8x8 patches: generic kernel
     for g in (_desc(Ho=32, Wo=32, stride=2, pad_t=0, pad_l=0, plan_bm=64, plan_bn=128, plan_ksplit=1),
               _desc(KH=1, KW=1, pad_t=0, pad_l=0, ldb=128, plan_bm=64, plan_bn=128, plan_ksplit=1),
-              _desc(Hi=20, Wi=20, Ho=20, Wo=20, plan_bm=64, plan_bn=128, plan_ksplit=1), _desc()):   # last: heuristic 64x64
+              _desc(Hi=20, Wi=20, Ho=20, Wo=20, plan_bm=64, plan_bn=128, plan_ksplit=1)):
         assert lib.sgam_conv2d_f32x_uses_halo(ref(g)) == 0
+    # the heuristic's (64, 64) tile on a 3x3 / s1 / p1 shape is the halo kernel's 64-channel tile (2 x 2 wavefronts), not the generic kernel
+    assert lib.sgam_conv2d_f32x_uses_halo(ref(_desc())) == 1
     # halo plans split K on whole channel slabs (9 taps): 4 slabs of 9 taps -> ranges of 9, 18 or 36
     bm, bn, ks = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
     s = _desc(plan_bm=64, plan_bn=128, plan_ksplit=3)
