@@ -26,9 +26,12 @@
 // style): grid = 8 x n/128, range s on XCD s (its K / V slice stays in that XCD's L2), each workgroup leaves its
 // un-normalised O, running maximum and sum; attn_combine_kernel merges the ranges.
 //
-// Measured (n = 4096, one MI355X): split 6 us + this kernel 64 us + combine 7 us = 77 us against 141 us for the
-// GEMM / softmax / GEMM chain.  Of the 64 us, 24 are the 1536 MFMAs per wavefront at full rate; LDS-DMA issue (~16 us:
-// a piece costs the issuing wavefront ~100 cycles) and the prologue / epilogue (~13 us: 32 MB of partial O) are the rest.
+// Measured (n = 4096, one MI355X, round 3): split 2.4 us + this kernel 52 us + combine 8 us (70 us for the three launches back
+// to back) against 141 us for the GEMM / softmax / GEMM chain.  rocprofv3 counters of the 52 us (profiles/
+// r03_pmc_attn_flash_f32x.json): a wavefront lives 90 k of the kernel's 122 k cycles (the rest is the launch and the write-back
+// of 32 MB of partial O behind the last wavefront), 49 k of them are its 1 584 MFMAs — the loop runs at 0.82 of the matrix
+// pipe, the kernel at 0.42.  (Rounds 1 - 2: 64 us; 6 100 of a wavefront's 10 860 VALU instructions were accumulator
+// rescales, see RESCALE_TAU.)
 #include "sgam_common.h"
 
 namespace {
