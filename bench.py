@@ -235,7 +235,7 @@ def main():
                     help="fp32 products: fp16-split MFMA (default) or fp32-in MFMA")
     ap.add_argument("--concurrent-scenes", type=int, default=4, help="secondary leg: this many independent trajectories "
                                                                       "on one GPU, one stream each (0/1 = skip)")
-    ap.add_argument("--lockstep-scenes", type=lambda v: [int(t) for t in v.split(",") if t], default=[4, 8],
+    ap.add_argument("--lockstep-scenes", type=lambda v: [int(t) for t in v.split(",") if t], default=[4, 8, 16],
                     help="secondary leg: scenes per GPU advanced in lock step at batch S (comma list; empty = skip)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying HIP graphs")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "fp16"],

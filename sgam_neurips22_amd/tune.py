@@ -145,6 +145,10 @@ def tune_shape(key, verbose=True):
                     t += max(4e-3, 2.0 * B * Hi * Wi * Cin * 4 / 4e12 * 1e3)
                 results.append((t, bm, bn, ks))
     results.sort()
+    if not results:                      # every candidate grid past the launch limit (the largest batches): keep the heuristic
+        if verbose:
+            print(f"{key:70s} no candidate plan fits: heuristic kept", flush=True)
+        return None, t_auto, (t_auto if t_auto is not None else 0.0, 0, 0, 0)
     best = results[0]
     if verbose:
         gf = 2.0 * M * N * K / 1e9
