@@ -216,6 +216,17 @@ int sgam_conv2d_halo_nhwc_h16(const sgam_conv_desc *d, int32_t ht, const void *x
                               const float *gn_gamma, const float *gn_beta, int32_t gn_swish, const void *w_frag,
                               const float *bias, const void *residual, void *out, int32_t out_f32, double *gn_partial,
                               void *workspace, int64_t workspace_bytes, void *stream);
+/* (ABI v5) The same launch with the statistics of the INPUT still as its producer's chunk partials (gn_partial_in
+ * [B][chunks_in][32][2] doubles — what sgam_conv2d_halo_nhwc_h16 leaves in `gn_partial` — instead of folded {mean, rstd}): the
+ * kernel folds them itself while it stages (no fold launch between two convolutions of a ResnetBlock).  Offered where
+ * sgam_conv2d_h16_gn_foldable(d, chunks_in) == 1: the 64-row tile walking <= 2 channel slabs per workgroup (the split-K plans
+ * of the 16 x 16 / 32 x 32 maps), Cin % 256 == 0, chunks_in <= 16 — which is what the group-major split-K combine of those
+ * maps produces (sgam_conv2d_h16_stats_chunks). */
+int32_t sgam_conv2d_h16_gn_foldable(const sgam_conv_desc *d, int32_t chunks_in);
+int sgam_conv2d_halo_gnp_nhwc_h16(const sgam_conv_desc *d, int32_t ht, const void *x, const double *gn_partial_in,
+                                  int32_t chunks_in, float gn_eps, const float *gn_gamma, const float *gn_beta, int32_t gn_swish,
+                                  const void *w_frag, const float *bias, const void *residual, void *out, int32_t out_f32,
+                                  double *gn_partial, void *workspace, int64_t workspace_bytes, void *stream);
 /* GroupNorm of 16-bit tensors from the partial statistics the halo kernel left / {mean, rstd} of any 16-bit tensor */
 int sgam_groupnorm_from_partials_h16(const void *x, const double *partial, int32_t nchunk, const float *gamma, const float *beta,
                                      void *y, int32_t ht, int32_t B, int32_t HW, int32_t C, int32_t groups, float eps,

@@ -112,6 +112,9 @@ PROTOTYPES = {
     "sgam_conv2d_halo_h16_workspace_bytes": (c_i64, [ctypes.POINTER(ConvDesc)]),
     "sgam_conv2d_halo_nhwc_h16": (c_i32, [ctypes.POINTER(ConvDesc), c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp,
                                           c_i32, c_vp, c_vp, c_i64, c_vp]),
+    "sgam_conv2d_h16_gn_foldable": (c_i32, [ctypes.POINTER(ConvDesc), c_i32]),
+    "sgam_conv2d_halo_gnp_nhwc_h16": (c_i32, [ctypes.POINTER(ConvDesc), c_i32, c_vp, c_vp, c_i32, c_f32, c_vp, c_vp, c_i32, c_vp, c_vp,
+                                              c_vp, c_vp, c_i32, c_vp, c_vp, c_i64, c_vp]),
     "sgam_groupnorm_from_partials_h16": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32,
                                                  c_i32, c_vp, c_i64, c_vp]),
     "sgam_groupnorm_meanrstd_nhwc_h16": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_i64, c_vp]),

@@ -79,6 +79,11 @@ struct HHParams {
     int gn_swish;
     double *gn_partial;           // optional: per-(tile row half, group) {sum, sumsq} of the output
     int gn_cpg;
+    // GNF: the statistics of the INPUT as its producer's chunk partials [B][gn_chunks_in <= 16][32][2] (the group-major split-K
+    // combine of a small map), folded by the kernel itself instead of a fold launch
+    const double *gn_partial_in;
+    int gn_chunks_in;
+    float gn_inv_n, gn_eps;
 };
 
 __device__ __forceinline__ unsigned hsel(bool c, unsigned a, unsigned b) {
@@ -99,7 +104,7 @@ __device__ __forceinline__ void hxcd_block(const HHParams &p, int &bx, int &by) 
 
 // `SW`: the fused GroupNorm is followed by swish (a template parameter, not a flag: a run-time test per staged piece cuts the
 // main loop into a dozen basic blocks and the MFMA / VALU interleaving stops at each of their borders)
-template <int BM, int BN, int HT, bool GN, bool UPS, bool SW = true>
+template <int BM, int BN, int HT, bool GN, bool UPS, bool SW = true, bool GNF = false>
 __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kernel(const HHParams p) {
     // BM = 256 (a 16 x 16 patch, every wavefront 128 rows x 64 channels, TM = 4: a weight fragment fetched feeds four MFMAs,
     // one workgroup per CU with the 128 accumulators in AccVGPRs) compiles and passes the tests but is not dispatched:
@@ -108,6 +113,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
     constexpr int TH = BM == 256 ? 16 : 8, TW = BM / TH, TWS = (TW == 16) ? 4 : 3;
     constexpr int HROWS = UPS ? TH / 2 + 2 : TH + 2, HWID = UPS ? TW / 2 + 2 : TW + 2, HR = HROWS * HWID;
     static_assert(!(UPS && GN), "no GroupNorm precedes an upsampling conv");
+    static_assert(!GNF || (GN && BM == 64), "GNF = GroupNorm statistics folded from the producer's chunk partials: the 64-row GN kernel");
     static_assert(BM == 256 || BM == 128 || BM == 64, "16 x 16, 8 x 16 or 8 x 8 output patches");
     static_assert(BN == 128, "2 x 2 wavefronts of 64 channels, or 1 x 4 of 32");
     constexpr int WGM_ = BM == 256 ? 2 : SGAM_HWGM, WGN_ = 4 / WGM_;
@@ -171,10 +177,32 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
         if constexpr (GN) {
             const int c = (live ? ch : 0) * XBK + (tid & 3) * 8;
             const int cpg = p.Cin / 32;
+            float fmean = 0.f, frstd = 0.f;
+            if constexpr (GNF) {
+                // (host: cpg >= 8, so the thread's eight channels are ONE group.)  The staging map gives the sixteen lanes l,
+                // l ^ 4, l ^ 8, l ^ 16, l ^ 32 of a wavefront the same eight channels: lane sub = l >> 2 fetches chunk `sub`
+                // (all loads in flight at once), a four-step xor butterfly adds them in a fixed order, in fp64, and the result is
+                // finished like gn_finalize_stats_kernel
+                const int sub = (tid & 63) >> 2;
+                typedef double f64x2 __attribute__((ext_vector_type(2)));
+                const double *q = p.gn_partial_in + ((int64_t)b * p.gn_chunks_in * 32 + c / cpg) * 2;
+                const f64x2 a = sub < p.gn_chunks_in ? *reinterpret_cast<const f64x2 *>(q + (int64_t)sub * 64) : f64x2{0.0, 0.0};
+                double ps = a[0], pss = a[1];
+#pragma unroll
+                for (int o = 4; o < 64; o <<= 1) {
+                    ps += __shfl_xor(ps, o, 64);
+                    pss += __shfl_xor(pss, o, 64);
+                }
+                const double m = ps * (double)p.gn_inv_n;
+                double var = pss * (double)p.gn_inv_n - m * m;
+                if (var < 0.0) var = 0.0;
+                fmean = (float)m;
+                frstd = (float)(1.0 / sqrt(var + (double)p.gn_eps));
+            }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {            // two float4 halves: a 4-channel group never straddles one
                 const int g = (c + 4 * h) / cpg;
-                const float mean = p.gn_stats[(b * 32 + g) * 2], rstd = p.gn_stats[(b * 32 + g) * 2 + 1];
+                const float mean = GNF ? fmean : p.gn_stats[(b * 32 + g) * 2], rstd = GNF ? frstd : p.gn_stats[(b * 32 + g) * 2 + 1];
                 const f32x4 ga = *reinterpret_cast<const f32x4 *>(p.gn_gamma + c + 4 * h);
                 const f32x4 be = *reinterpret_cast<const f32x4 *>(p.gn_beta + c + 4 * h);
 #pragma unroll
@@ -664,6 +692,76 @@ __global__ __launch_bounds__(256) void h16_splitk_reduce_kernel(const HHParams p
     }
 }
 
+// the combine of the SMALL maps (16^2, 32^2), group-major: a workgroup owns TR = 1024 / TC rows x TC channels (whole 64- / 32-
+// byte row pieces), so an image falls into hw / TR <= 16 chunks of statistics — few enough for the consuming conv to fold by
+// itself (GNF), which removes the fold launch between two convolutions (conv_f32x.hip: splitk_reduce_gm_f32x_kernel).
+template <int HT, int TC>
+__global__ __launch_bounds__(256) void h16_splitk_reduce_gm_kernel(const HHParams p) {
+    constexpr int TR = 1024 / TC, TPR = TC / 4;
+    const int col_tiles = p.N / TC;
+    const int rt = blockIdx.x / col_tiles, ct = blockIdx.x - rt * col_tiles;
+    const int row = threadIdx.x / TPR, c4 = threadIdx.x - row * TPR;
+    const int m = rt * TR + row, n = ct * TC + c4 * 4;            // host: M % TR == 0, N % TC == 0, n_valid == N
+    const float *w0 = p.ws + (int64_t)m * p.N + n;
+    const int64_t zs = (int64_t)p.M * p.N;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bv = *reinterpret_cast<const f32x4 *>(p.bias + n);
+    u32x2 rq = {0u, 0u};
+    if (p.res) rq = *reinterpret_cast<const u32x2 *>(p.res + (int64_t)m * p.ldr + n);
+    f32x4 sum = *reinterpret_cast<const f32x4 *>(w0);
+    int z = 1;
+    for (; z + 4 <= p.ksplit; z += 4) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(w0 + z * zs), b2 = *reinterpret_cast<const f32x4 *>(w0 + (z + 1) * zs);
+        const f32x4 c = *reinterpret_cast<const f32x4 *>(w0 + (z + 2) * zs), d = *reinterpret_cast<const f32x4 *>(w0 + (z + 3) * zs);
+        sum += a;
+        sum += b2;
+        sum += c;
+        sum += d;
+    }
+    for (; z < p.ksplit; ++z) sum += *reinterpret_cast<const f32x4 *>(w0 + z * zs);
+    f32x4 v = sum + bv;
+    if (p.res) {
+        v[0] += HH<HT>::to_f((unsigned short)(rq[0] & 0xFFFFu));
+        v[1] += HH<HT>::to_f((unsigned short)(rq[0] >> 16));
+        v[2] += HH<HT>::to_f((unsigned short)(rq[1] & 0xFFFFu));
+        v[3] += HH<HT>::to_f((unsigned short)(rq[1] >> 16));
+    }
+    if (p.out_f32) {
+        *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(p.out) + (int64_t)m * p.ldc + n) = v;
+    } else {
+        const unsigned short h0 = HH<HT>::from_f(v[0]), h1 = HH<HT>::from_f(v[1]), h2 = HH<HT>::from_f(v[2]), h3 = HH<HT>::from_f(v[3]);
+        const u32x2 o = {(unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16)};
+        *reinterpret_cast<u32x2 *>(reinterpret_cast<unsigned short *>(p.out) + (int64_t)m * p.ldc + n) = o;
+        v = f32x4{HH<HT>::to_f(h0), HH<HT>::to_f(h1), HH<HT>::to_f(h2), HH<HT>::to_f(h3)};     // statistics of the STORED tensor
+    }
+    float gs = (v[0] + v[1]) + (v[2] + v[3]);
+    float gss = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    if (!p.gn_partial) return;
+    const int lpg = p.gn_cpg / 4;                       // lanes per (row, group): 1, 2, 4 or 8 neighbours (cpg <= TC)
+    for (int o = 1; o < lpg; o <<= 1) {
+        gs += __shfl_xor(gs, o, 64);
+        gss += __shfl_xor(gss, o, 64);
+    }
+    __shared__ float sh[256][2];                        // [row][group in tile]: TR * (TC / cpg) = 1024 / cpg <= 256 entries
+    const int gt = TC / p.gn_cpg, gl = c4 / lpg;
+    if ((c4 % lpg) == 0) {
+        sh[row * gt + gl][0] = gs;
+        sh[row * gt + gl][1] = gss;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < gt) {
+        double ds = 0.0, dss = 0.0;
+        for (int r = 0; r < TR; ++r) {
+            ds += (double)sh[r * gt + threadIdx.x][0];
+            dss += (double)sh[r * gt + threadIdx.x][1];
+        }
+        // chunk = row tile inside the image (image-major: rt counts over the whole batch, hw % TR == 0)
+        double *o = p.gn_partial + ((int64_t)rt * 32 + ct * gt + threadIdx.x) * 2;
+        o[0] = ds;
+        o[1] = dss;
+    }
+}
+
 template <int HT>
 __global__ void pack_weight_h16_frag_kernel(const float *w, unsigned short *o, int Cout, int Cin, int KH, int KW, int Cout_pad,
                                             int Cin_pad) {
@@ -742,11 +840,25 @@ extern "C" int64_t sgam_conv2d_halo_h16_workspace_bytes(const sgam_conv_desc *d)
 
 // chunks of output statistics per image the halo kernel leaves (sgam_conv2d_halo_nhwc_h16 with gn_partial), 0 = none:
 // one per (tile, wavefront row) from the epilogue, one per 1024 outputs (1024 / N whole rows) from the split-K combine
+// channels per workgroup tile of the group-major combine for this descriptor (32, 16 or 8), 0 = the row-major combine: a
+// group (N / 32 channels) must fit a tile and an image must fall into at most 16 row tiles (conv_f32x.hip: red_tc_for)
+static int hh_red_tc_for(const sgam_conv_desc *d) {
+    static const int on = [] { const char *e = getenv("SGAM_GN_FOLD"); return (e && e[0] == '0') ? 0 : 1; }();
+    const int hw = d->Ho * d->Wo, cpg = d->N / 32;
+    if (!on || d->N % 128 != 0 || d->n_valid != d->N || d->N > 1024) return 0;
+    for (int tc = 32; tc >= 8; tc >>= 1) {
+        const int tr = 1024 / tc;
+        if (tc >= cpg && hw % tr == 0 && hw / tr <= 16) return tc;
+    }
+    return 0;
+}
+
 extern "C" int32_t sgam_conv2d_h16_stats_chunks(const sgam_conv_desc *d) {
     const HHPlan pl = hh_plan(d);
     if (!pl.bm || d->n_valid != d->N) return 0;
     const int hw = d->Ho * d->Wo;
     if (pl.ksplit == 1) return (hw / pl.bm) * 2;
+    if (const int tc = hh_red_tc_for(d)) return hw / (1024 / tc);
     if (d->N > 1024 || 1024 % d->N != 0 || ((int64_t)hw * d->N) % 1024 != 0) return 0;
     return (int32_t)((int64_t)hw * d->N / 1024);
 }
@@ -768,16 +880,28 @@ extern "C" int sgam_pack_conv_weight_h16_frag(const float *w_oihw, void *w_frag,
     return SGAM_OK;
 }
 
-extern "C" int sgam_conv2d_halo_nhwc_h16(const sgam_conv_desc *d, int32_t ht, const void *x, const float *gn_mean_rstd,
-                                         const float *gn_gamma, const float *gn_beta, int32_t gn_swish, const void *w_frag,
-                                         const float *bias, const void *residual, void *out, int32_t out_f32, double *gn_partial,
-                                         void *workspace, int64_t workspace_bytes, void *stream) {
+// 1 when sgam_conv2d_halo_gnp_nhwc_h16 can take the statistics of its input as `chunks_in` chunk partials per image and fold
+// them itself: the 64-row tile of the halo kernel, a workgroup that walks at most two channel slabs (it repeats the fold per
+// slab), groups of >= 8 channels (a thread's eight staged channels are one group), at most 16 chunks
+extern "C" int32_t sgam_conv2d_h16_gn_foldable(const sgam_conv_desc *d, int32_t chunks_in) {
+    static const int on = [] { const char *e = getenv("SGAM_GN_FOLD"); return (e && e[0] == '0') ? 0 : 1; }();
+    if (!on || !d || chunks_in < 1 || chunks_in > 16 || d->upsample2x || d->Cin % 256 != 0) return 0;
+    const HHPlan pl = hh_plan(d);
+    return (pl.bm == 64 && pl.slabs_per_split <= 2) ? 1 : 0;
+}
+
+static int hh_conv_impl(const sgam_conv_desc *d, int32_t ht, const void *x, const float *gn_mean_rstd, const double *gn_partial_in,
+                        int32_t chunks_in, float gn_eps, const float *gn_gamma, const float *gn_beta, int32_t gn_swish,
+                        const void *w_frag, const float *bias, const void *residual, void *out, int32_t out_f32, double *gn_partial,
+                        void *workspace, int64_t workspace_bytes, void *stream) {
     const HHPlan pl = hh_plan(d);
     const int bm = pl.bm;
     if (!bm || !x || !w_frag || !out || (ht != 0 && ht != 1)) return SGAM_EINVAL;
     if (!sgam_aligned16(x) || !sgam_aligned16(w_frag) || (((uintptr_t)out) & 7u) || (residual && (((uintptr_t)residual) & 7u)))
         return SGAM_EALIGN;
-    const bool gn = gn_mean_rstd != nullptr;
+    if (gn_partial_in && (gn_mean_rstd || sgam_conv2d_h16_gn_foldable(d, chunks_in) != 1 || !sgam_aligned16(gn_partial_in)))
+        return SGAM_EINVAL;
+    const bool gn = gn_mean_rstd != nullptr || gn_partial_in != nullptr;
     if (gn && (!gn_gamma || !gn_beta || !sgam_aligned16(gn_gamma) || !sgam_aligned16(gn_beta) || d->upsample2x || d->Cin % 128))
         return SGAM_EINVAL;
     if (gn_partial && sgam_conv2d_h16_stats_chunks(d) <= 0) return SGAM_EINVAL;
@@ -798,6 +922,8 @@ extern "C" int sgam_conv2d_halo_nhwc_h16(const sgam_conv_desc *d, int32_t ht, co
     p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
     p.gn_stats = gn_mean_rstd; p.gn_gamma = gn_gamma; p.gn_beta = gn_beta; p.gn_swish = gn_swish ? 1 : 0;
     p.gn_partial = gn_partial; p.gn_cpg = d->N / 32;
+    p.gn_partial_in = gn_partial_in; p.gn_chunks_in = chunks_in; p.gn_eps = gn_eps;
+    p.gn_inv_n = 1.0f / ((float)d->Hi * (float)d->Wi * (float)(d->Cin / 32));
     p.gx = p.M / bm; p.gy = d->N / 128;
     static const int swz = [] { const char *e = getenv("SGAM_XCD_SWIZZLE"); return (e && e[0] == '0') ? 0 : 1; }();
     p.xcd_swizzle = swz;
@@ -814,7 +940,12 @@ extern "C" int sgam_conv2d_halo_nhwc_h16(const sgam_conv_desc *d, int32_t ht, co
         else if (gn) SGAM_KLAUNCH((conv3x3_h16_halo_kernel<BM_, 128, HT_, true, false, false>), grid, dim3(256), 0, s, p);        \
         else SGAM_KLAUNCH((conv3x3_h16_halo_kernel<BM_, 128, HT_, false, false>), grid, dim3(256), 0, s, p);                     \
     } while (0)
-    if (bm == 256) {
+    if (gn_partial_in) {
+        if (ht == 0 && p.gn_swish) SGAM_KLAUNCH((conv3x3_h16_halo_kernel<64, 128, 0, true, false, true, true>), grid, dim3(256), 0, s, p);
+        else if (ht == 0) SGAM_KLAUNCH((conv3x3_h16_halo_kernel<64, 128, 0, true, false, false, true>), grid, dim3(256), 0, s, p);
+        else if (p.gn_swish) SGAM_KLAUNCH((conv3x3_h16_halo_kernel<64, 128, 1, true, false, true, true>), grid, dim3(256), 0, s, p);
+        else SGAM_KLAUNCH((conv3x3_h16_halo_kernel<64, 128, 1, true, false, false, true>), grid, dim3(256), 0, s, p);
+    } else if (bm == 256) {
         if (ht == 0) HH_LAUNCH(256, 0); else HH_LAUNCH(256, 1);
     } else if (bm == 128) {
         if (ht == 0) HH_LAUNCH(128, 0); else HH_LAUNCH(128, 1);
@@ -826,9 +957,37 @@ extern "C" int sgam_conv2d_halo_nhwc_h16(const sgam_conv_desc *d, int32_t ht, co
     if (pl.ksplit > 1) {
         const int64_t q = (int64_t)p.M * (d->N / 4);
         if (sgam_i_prof_on) sgam_i_prof_work(0.0, (double)pl.ksplit * p.M * d->N * 4.0 + 2.0 * p.M * d->n_valid);
-        if (ht == 0) SGAM_KLAUNCH(h16_splitk_reduce_kernel<0>, dim3(sgam_cdiv(q, 256)), dim3(256), 0, s, p);
-        else SGAM_KLAUNCH(h16_splitk_reduce_kernel<1>, dim3(sgam_cdiv(q, 256)), dim3(256), 0, s, p);
+        const int tc = gn_partial ? hh_red_tc_for(d) : 0;
+#define HH_RED(HT_)                                                                                                       \
+    do {                                                                                                                  \
+        if (tc == 32) SGAM_KLAUNCH((h16_splitk_reduce_gm_kernel<HT_, 32>), dim3((unsigned)(q / 256)), dim3(256), 0, s, p);       \
+        else if (tc == 16) SGAM_KLAUNCH((h16_splitk_reduce_gm_kernel<HT_, 16>), dim3((unsigned)(q / 256)), dim3(256), 0, s, p);  \
+        else if (tc == 8) SGAM_KLAUNCH((h16_splitk_reduce_gm_kernel<HT_, 8>), dim3((unsigned)(q / 256)), dim3(256), 0, s, p);    \
+        else SGAM_KLAUNCH(h16_splitk_reduce_kernel<HT_>, dim3(sgam_cdiv(q, 256)), dim3(256), 0, s, p);                    \
+    } while (0)
+        if (ht == 0) HH_RED(0); else HH_RED(1);
+#undef HH_RED
         SGAM_LAUNCH_CHECK();
     }
     return SGAM_OK;
+}
+
+extern "C" int sgam_conv2d_halo_nhwc_h16(const sgam_conv_desc *d, int32_t ht, const void *x, const float *gn_mean_rstd,
+                                         const float *gn_gamma, const float *gn_beta, int32_t gn_swish, const void *w_frag,
+                                         const float *bias, const void *residual, void *out, int32_t out_f32, double *gn_partial,
+                                         void *workspace, int64_t workspace_bytes, void *stream) {
+    return hh_conv_impl(d, ht, x, gn_mean_rstd, nullptr, 0, 0.f, gn_gamma, gn_beta, gn_swish, w_frag, bias, residual, out, out_f32,
+                        gn_partial, workspace, workspace_bytes, stream);
+}
+
+// sgam_conv2d_halo_nhwc_h16 with the statistics of x still as its producer's chunk partials [B][chunks_in][32][2] (fp64 {sum,
+// sumsq}): the kernel folds them (needs sgam_conv2d_h16_gn_foldable(d, chunks_in) == 1)
+extern "C" int sgam_conv2d_halo_gnp_nhwc_h16(const sgam_conv_desc *d, int32_t ht, const void *x, const double *gn_partial_in,
+                                             int32_t chunks_in, float gn_eps, const float *gn_gamma, const float *gn_beta,
+                                             int32_t gn_swish, const void *w_frag, const float *bias, const void *residual, void *out,
+                                             int32_t out_f32, double *gn_partial, void *workspace, int64_t workspace_bytes,
+                                             void *stream) {
+    if (!gn_partial_in) return SGAM_EINVAL;
+    return hh_conv_impl(d, ht, x, nullptr, gn_partial_in, chunks_in, gn_eps, gn_gamma, gn_beta, gn_swish, w_frag, bias, residual, out,
+                        out_f32, gn_partial, workspace, workspace_bytes, stream);
 }

@@ -358,6 +358,8 @@ def _run_conv(desc, x, w, bias, residual, out, gn=None, a_scale=1.0, norm=None):
             gn = (x._gn_partials, gamma, beta, swish, eps)
         elif fusable and (have or x.shape[1] * x.shape[2] > 1024):
             gn = (groupnorm_meanrstd(x, eps), gamma, beta, swish)
+        elif h16_fusable and have and lib.sgam_conv2d_h16_gn_foldable(ctypes.byref(desc), x._gn_partials[1]) == 1:
+            gn = (x._gn_partials, _f32c(gamma), _f32c(beta), swish, eps)      # folded inside the 16-bit halo kernel
         elif h16_fusable:
             gn = (groupnorm_meanrstd(x, eps), _f32c(gamma), _f32c(beta), swish)
         else:
@@ -443,9 +445,18 @@ def _run_conv_inner(lib, desc, x, w, bias, residual, out, gn=None, a_scale=1.0):
             # statistics of `out` from the epilogue
             chunks = lib.sgam_conv2d_h16_stats_chunks(ctypes.byref(desc)) if (FUSE_GN_STATS and out.dtype in H16) else 0
             partial = torch.empty((desc.B * chunks * 32 * 2,), device=x.device, dtype=torch.float64) if chunks > 0 else None
-            mr, gamma, beta, swish = gn if gn is not None else (None, None, None, False)
             ws_bytes = lib.sgam_conv2d_halo_h16_workspace_bytes(ctypes.byref(desc))
             ws = torch.empty((ws_bytes,), device=x.device, dtype=torch.uint8) if ws_bytes > 0 else None
+            if gn is not None and len(gn) == 5:          # statistics as the producer's chunk partials, folded inside the kernel
+                (part_in, chunks_in), gamma, beta, swish, eps = gn
+                check(lib.sgam_conv2d_halo_gnp_nhwc_h16(ctypes.byref(desc), H16[x.dtype], _p(x), _p(part_in), int(chunks_in), float(eps),
+                                                        _p(gamma), _p(beta), int(swish), _p(fw.planes), _p(bias), _p(residual), _p(out),
+                                                        int(out.dtype == torch.float32), _p(partial), _p(ws), max(ws_bytes, 0),
+                                                        _stream()), "sgam_conv2d_halo_gnp_nhwc_h16")
+                if partial is not None:
+                    out._gn_partials = (partial, chunks)
+                return out
+            mr, gamma, beta, swish = gn if gn is not None else (None, None, None, False)
             check(lib.sgam_conv2d_halo_nhwc_h16(ctypes.byref(desc), H16[x.dtype], _p(x), _p(mr), _p(gamma), _p(beta), int(swish),
                                                 _p(fw.planes), _p(bias), _p(residual), _p(out), int(out.dtype == torch.float32),
                                                 _p(partial), _p(ws), max(ws_bytes, 0), _stream()), "sgam_conv2d_halo_nhwc_h16")

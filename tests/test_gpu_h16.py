@@ -90,6 +90,55 @@ def test_generic_conv_h16_leaves_groupnorm_statistics(dt, case):
 
 
 @pytest.mark.parametrize("dt", DT, ids=["bf16", "fp16"])
+@pytest.mark.parametrize("B,C,H,W,ks,folds", [(1, 512, 16, 16, 8, True), (2, 256, 32, 32, 4, True), (1, 512, 16, 16, 4, False),
+                                              (1, 256, 64, 64, 2, False)])
+def test_h16_splitk_combine_statistics_folded_by_the_consumer(dt, B, C, H, W, ks, folds):
+    """16-bit mode, small maps: the split-K combine runs group-major and leaves <= 16 chunk partials per image, and the next
+    3x3 conv folds them itself while it stages (sgam_conv2d_halo_gnp_nhwc_h16: no fold launch between the two convolutions of a
+    ResnetBlock).  Equals the explicit form (statistics pass + fold + fused staging); where the consumer's workgroups would walk
+    more than two slabs, or the producer's map is too large for 16 chunks, the explicit form is what runs."""
+    import ctypes
+    from sgam_neurips22_amd._lib import ConvDesc, load
+    x = testing.seeded_tensor("hf.x", (B, C, H, W), 1.2, 0.3).to(dt)
+    w1 = testing.seeded_tensor("hf.w1", (C, C, 3, 3), scale=(1.0 / (C * 9)) ** 0.5)
+    w2 = testing.seeded_tensor("hf.w2", (C, C, 3, 3), scale=(1.0 / (C * 9)) ** 0.5)
+    b = testing.seeded_tensor("hf.b", (C,), scale=0.1).to(DEV)
+    g, bt = (1 + 0.1 * testing.seeded_tensor("hf.g", (C,))).to(DEV), (0.1 * testing.seeded_tensor("hf.bt", (C,))).to(DEV)
+    wp1, wp2 = ops.pack_conv_weight(w1.to(DEV), dtype=dt), ops.pack_conv_weight(w2.to(DEV), dtype=dt)
+    wp1._sgam_frag_src, wp2._sgam_frag_src = w1.to(DEV), w2.to(DEV)
+    key = ops.plan_key(ConvDesc(B=B, Hi=H, Wi=W, Cin=C, Ho=H, Wo=W, N=C, KH=3, KW=3, stride=1, pad_t=1, pad_l=1, upsample2x=0, lda=C,
+                                ldb=wp1.stride(0), ldc=C, ldr=0, n_valid=C, bias_per_row=0), dt)
+    old = ops.PLAN_CACHE.get(key)
+    ops.PLAN_CACHE[key] = (64, 128, ks)
+    try:
+        xd = _nhwc(x).to(DEV)
+        h = ops.conv2d_nhwc(xd, wp1, b, cout=C, kh=3, kw=3, pad_t=1, pad_l=1)
+        assert hasattr(h, "_gn_partials")
+        chunks = h._gn_partials[1]
+        d2 = ConvDesc(B=B, Hi=H, Wi=W, Cin=C, Ho=H, Wo=W, N=C, KH=3, KW=3, stride=1, pad_t=1, pad_l=1, upsample2x=0, lda=C,
+                      ldb=wp2.stride(0), ldc=C, ldr=0, n_valid=C, bias_per_row=0, plan_bm=64, plan_bn=128, plan_ksplit=ks)
+        assert (load().sgam_conv2d_h16_gn_foldable(ctypes.byref(d2), chunks) == 1) == folds, (chunks, folds)
+        if folds:
+            assert chunks <= 16
+        st = ops.groupnorm_meanrstd(h).cpu()
+        og = h.float().permute(0, 3, 1, 2).cpu().double().reshape(B, 32, -1)
+        assert torch.allclose(st[:, :, 0].double(), og.mean(-1), rtol=0, atol=1e-5)
+        assert torch.allclose(st[:, :, 1].double(), (og.var(-1, unbiased=False) + 1e-6).rsqrt(), rtol=1e-5, atol=0)
+        y = ops.conv2d_nhwc(h, wp2, b, cout=C, kh=3, kw=3, pad_t=1, pad_l=1, norm=(g, bt, True, 32, 1e-6))     # folds (or not)
+        h2 = h.clone()                                     # no partials travel with the copy: statistics pass + fold + fused staging
+        y2 = ops.conv2d_nhwc(h2, wp2, b, cout=C, kh=3, kw=3, pad_t=1, pad_l=1, norm=(g, bt, True, 32, 1e-6))
+    finally:
+        if old is None:
+            ops.PLAN_CACHE.pop(key, None)
+        else:
+            ops.PLAN_CACHE[key] = old
+    assert _rel(y, y2.float()) <= 2 * EPS[dt]
+    hn = F.group_norm(h.float().permute(0, 3, 1, 2).cpu(), 32, g.cpu(), bt.cpu(), eps=1e-6)
+    ref = F.conv2d((hn * torch.sigmoid(hn)).to(dt).float(), w2.to(dt).float(), b.cpu(), padding=1)
+    assert _rel(y.permute(0, 3, 1, 2), ref) <= 4 * EPS[dt]
+
+
+@pytest.mark.parametrize("dt", DT, ids=["bf16", "fp16"])
 @pytest.mark.parametrize("B,C,H,W", [(1, 128, 64, 64), (2, 256, 12, 12), (1, 512, 16, 16), (1, 128, 256, 256), (2, 256, 80, 80)])
 def test_groupnorm_h16(dt, B, C, H, W):
     x = testing.seeded_tensor("gn16.x", (B, C, H, W), 3.0, 0.5).to(dt)
