@@ -48,8 +48,10 @@ GFLOP_PER_FRAME = 486.4         # VQGAN at 256x256, B=1
 
 
 def build_model(device):
+    import contextlib
     p = default_params(DATASET)
-    m = VQModel(**p)
+    with contextlib.redirect_stdout(sys.stderr):      # the constructor prints "Working with z of shape ..." like the reference's
+        m = VQModel(**p)
     sd = testing.synthetic_state_dict(m.state_dict(), seed=0)
     sd["quantize.embedding.weight"] = testing.codebook_from_stats(0.0, 0.5, p["n_embed"], 256, 1)
     m.load_state_dict(sd)
@@ -65,6 +67,14 @@ def kernel_peak(name):
     if "conv_gemm_f32" in name:
         return FP32_MFMA_PEAK_TFLOPS, "fp32-in v_mfma_f32_32x32x2_f32"
     return None, None
+
+
+def peak_basis(name):
+    if "f32x" in name:
+        return "fp16 dense MFMA 2500 TFLOP/s / 3 MFMA products per fp32 product = 833.3 (builder-defined roof of the exact hi/lo split)"
+    if "h16" in name:
+        return "bf16/fp16 dense MFMA 2500 TFLOP/s"
+    return "fp32-in MFMA 157.3 TFLOP/s"
 
 
 def frame_timeline(scene):
@@ -108,6 +118,11 @@ def roofline_from_timeline(agg, bracket_ms, ms_per_step):
     peak = top_mfma["peak"]
     out = {"bound": "mfma", "achieved": top_mfma["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": top_mfma["frac"],
            "traffic": None, "kernel": top_mfma["kernel"], "how": top_mfma["how"],
+           "peak_basis": peak_basis(top_mfma["kernel"]),
+           "frac_vs_fp32_mfma_peak": None if top_mfma["tflops"] is None else round(top_mfma["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4),
+           "frac_vs_h16_dense_peak": None if top_mfma["tflops"] is None else round(
+               top_mfma["tflops"] * (3.0 if "f32x" in top_mfma["kernel"] else 1.0) / H16_MFMA_PEAK_TFLOPS, 4),
+           "gflop_per_launch": round(top_mfma["gflop"] / max(top_mfma["calls"], 1), 3),
            "calls_per_frame": top_mfma["calls"], "ms_per_frame": top_mfma["ms"], "avg_launch_us": top_mfma["avg_us"],
            "gflop_per_frame_in_kernel": top_mfma["gflop"],
            "share_of_kernel_time": round(top_mfma["ms"] / total_ms, 4),
@@ -135,6 +150,7 @@ def timed_loop(step_fn, warmup, steps):
 
 
 _PMC_FRAME = {}
+_PMC_COMMIT = [None]    # "library @ <commit>" the committed counter files were collected on (profiles/pmc_index.json)
 
 
 def pmc_frame_entry(mode, timeline_name):
@@ -145,7 +161,9 @@ def pmc_frame_entry(mode, timeline_name):
     if mode not in _PMC_FRAME:
         _PMC_FRAME[mode] = (None, {})
         if os.path.exists(idx_path):
-            fn = json.load(open(idx_path)).get("in_frame", {}).get(mode)
+            idx = json.load(open(idx_path))
+            fn = idx.get("in_frame", {}).get(mode)
+            _PMC_COMMIT[0] = idx.get("collected_at")
             if fn and os.path.exists(os.path.join(ROOT, "profiles", fn)):
                 _PMC_FRAME[mode] = (fn, json.load(open(os.path.join(ROOT, "profiles", fn)))["kernels"])
     fn, kernels = _PMC_FRAME[mode]
@@ -177,6 +195,8 @@ def attach_counters(roofline, mode):
     fn, ent = pmc_frame_entry(mode, roofline["kernel"])
     if ent is not None:
         roofline["traffic"] = ent["hbm_traffic_bytes_per_launch"]
+        roofline["counters_source"] = (f"traffic + mfma_busy_frac: NOT measured in this run — committed rocprofv3 --pmc passes over the same "
+                                       f"eager frame, profiles/{fn}" + (f" ({_PMC_COMMIT[0]})" if _PMC_COMMIT[0] else ""))
         roofline["traffic_note"] = (f"HBM bytes per launch of {roofline['kernel']}, averaged over its {ent['launches_per_frame']} in-frame "
                                     f"launches: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate rocprofv3 --pmc passes over "
                                     f"the eager bench frame (profiles/{fn})")
@@ -221,6 +241,148 @@ def cpu_baseline(sd, p, seed_frame, n_frames):
     return {"value": n_frames / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
             "cpu": f"{cpu_name} ({os.cpu_count()} hardware threads visible)",
             "sample": f"{n_frames} frames of the same 256x256 GoogleEarth step (oracle: C splat + torch-CPU fp32 VQGAN)"}
+
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E, 8 stacks
+HBM_ACHIEVABLE_GBS = 6300.0    # same guide: best sustained streaming rate measured on the part
+
+
+def warp_roofline(dev, reps=8):
+    """HBM roofline of the two conditioning warps (forward splat + median + mask = H*W*(16N+17) bytes per target
+    frame, inverse warp H*W*(16N+16)), measured with the library's per-kernel HIP-event brackets over `reps` launches on
+    synthetic sources read in place through the pointer table, exactly as the scene loop calls them.  Cases: config 3
+    (256x256, N = 3), config 5 (512x512, B = 4 candidates, N = 2), lock step S = 16 (48 sources in one launch) and one
+    deliberately large launch (512x512, B = 16, N = 3) where launch latency no longer hides the kernel."""
+    cases = [("config3_256_N3", 1, 3, 256), ("config5_512_B4_N2", 4, 2, 512), ("lockstep_256_S16_N3", 16, 3, 256),
+             ("large_512_B16_N3", 16, 3, 512)]
+    out = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achievable": HBM_ACHIEVABLE_GBS,
+           "bytes_model": "forward splat H*W*(16N+17)*B, inverse warp H*W*(16N+16)*B (SURVEY 8d)", "cases": {}, "inverse_warp": {}}
+    for tag, B, N, res in cases:
+        f, d, Ks, T = testing.synth_warp_inputs(11, B, N, res, res, 0.02, False)
+        feats = [torch.from_numpy(np.ascontiguousarray(f[b, n].transpose(1, 2, 0))).to(dev) for b in range(B) for n in range(N)]
+        depths = [torch.from_numpy(np.ascontiguousarray(d[b, n])).to(dev) for b in range(B) for n in range(N)]
+        K = torch.from_numpy(Ks[:, 0].copy()).to(dev)
+        Kinv = torch.inverse(torch.from_numpy(Ks).reshape(-1, 3, 3)).to(dev)
+        Td = torch.from_numpy(T).reshape(-1, 4, 4).to(dev)
+        bufs = {"x": torch.empty((B, 4, res, res), device=dev), "extrap": torch.empty((B, 1, res, res), device=dev, dtype=torch.bool),
+                "winner": torch.empty((B, res * res), device=dev, dtype=torch.int32)}
+
+        def splat():
+            ops.forward_splat_srcs(feats, depths, K, Kinv, Td, B=B, dataset=DATASET, want=("x", "extrap"), extrap_bool=True, out=bufs)
+        splat()
+        recs, br = ops.kernel_timeline(lambda: [splat() for _ in range(reps)])
+        per = {}
+        for name, ms, *_ in recs:
+            per[name.split("<")[0]] = per.get(name.split("<")[0], 0.0) + max(ms - br, 0.0)
+        us = {k: round(1e3 * v / reps, 2) for k, v in per.items()}
+        tot_us = sum(us.values())
+        nbytes = res * res * (16 * N + 17) * B
+        out["cases"][tag] = {"B": B, "N": N, "H": res, "W": res, "algorithmic_bytes": nbytes, "us": round(tot_us, 2), "kernels_us": us,
+                             "achieved": round(nbytes / tot_us / 1e3, 1), "frac": round(nbytes / tot_us / 1e3 / HBM_PEAK_GBS, 4),
+                             "frac_of_achievable": round(nbytes / tot_us / 1e3 / HBM_ACHIEVABLE_GBS, 4)}
+        # inverse warp at the same geometry (target depth = the first source's depth: any finite depth does for timing)
+        tgt_depth = torch.stack([depths[b * N] for b in range(B)])
+        outw = torch.empty((B, 3, res, res), device=dev)
+
+        def inv():
+            ops.inverse_warp_srcs(feats, depths, tgt_depth, torch.from_numpy(Ks).reshape(-1, 3, 3).to(dev), torch.inverse(K), Td, B=B, out=outw)
+        inv()
+        recs, br = ops.kernel_timeline(lambda: [inv() for _ in range(reps)])
+        t_us = 1e3 * sum(max(ms - br, 0.0) for name, ms, *_ in recs if name.startswith("inverse_warp")) / reps
+        nb2 = res * res * (16 * N + 16) * B
+        out["inverse_warp"][tag] = {"algorithmic_bytes": nb2, "us": round(t_us, 2), "achieved": round(nb2 / t_us / 1e3, 1),
+                                    "frac": round(nb2 / t_us / 1e3 / HBM_PEAK_GBS, 4)}
+        del feats, depths, bufs
+    return out
+
+
+LINE_BUDGET = 4096      # bytes of the ONE JSON line (the driver's parser choked on the 20 KB line of round 3)
+
+
+def _git_head():
+    try:
+        import subprocess
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True,
+                              timeout=5).stdout.strip() or None
+    except Exception:
+        return None
+
+
+def compact_line(full):
+    """The ONE line of the contract from the full record: headline fields, `roofline` (dominant kernel, both roofs, where the
+    counter figures come from), `cpu_baseline`, `roofline_warp` (one number per case) and one number per secondary leg.
+    Everything else (top-5 tables, every lock-step leg, throughput-mode tables, config 5, training) lives in the side file."""
+    def pick(d, keys):
+        return None if d is None else {k: d.get(k) for k in keys if k in d}
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data")
+    line = {k: full.get(k) for k in keep}
+    cfg = full.get("config") or {}
+    line["config"] = {k: cfg.get(k) for k in ("workload", "frames_per_gpu", "scenes", "parallelism", "launch", "f32_products") if k in cfg}
+    r = full.get("roofline")
+    if r is not None:
+        line["roofline"] = pick(r, ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us", "calls_per_frame",
+                                    "gflop_per_launch", "peak_basis", "frac_vs_fp32_mfma_peak", "frac_vs_h16_dense_peak",
+                                    "mfma_busy_frac", "counters_source", "share_of_kernel_time", "kernels_per_frame",
+                                    "kernel_time_ms_per_frame", "frame"))
+    else:
+        line["roofline"] = None
+    line["cpu_baseline"] = pick(full.get("cpu_baseline"), ("value", "unit", "cores", "kind", "sample", "cpu"))
+    w = full.get("roofline_warp")
+    if w is not None:
+        line["roofline_warp"] = {"bound": "hbm", "unit": "GB/s", "peak": w.get("peak"),
+                                 "cases": {k: pick(v, ("achieved", "frac", "us", "algorithmic_bytes")) for k, v in (w.get("cases") or {}).items()}}
+    summ = {}
+    def put(name, leg, key="value"):
+        if leg is not None and leg.get(key) is not None:
+            summ[name] = leg[key]
+    put("f32_mfma_mode_fps", full.get("f32_mfma_mode"))
+    put("rgbd_branch_fps", full.get("rgbd_integration_branch"))
+    put("concurrent_scenes_fps", full.get("concurrent_scenes"))
+    tm = full.get("throughput_mode") or {}
+    for dtn in ("fp16", "bf16"):
+        if dtn in tm:
+            summ[f"{dtn}_fps"] = tm[dtn]["value"]
+            rr = tm[dtn].get("roofline") or {}
+            summ[f"{dtn}_halo128_frac"] = tm[dtn].get("halo128_frac")
+            summ[f"{dtn}_kernels_per_frame"] = rr.get("kernels_per_frame")
+    for k, v in (full.get("lockstep_scenes") or {}).items():
+        if isinstance(v, dict) and "value" in v:
+            summ[f"lockstep_{k}_fps"] = v["value"]
+    c5 = full.get("config5_512sq_batch4") or {}
+    for dtn in ("f32", "fp16"):
+        if dtn in c5:
+            summ[f"config5_{dtn}_ms_per_batch"] = c5[dtn]["ms_per_batch"]
+    put("training_ms_per_update", full.get("training_step"), "ms_per_update")
+    line["secondary"] = {k: v for k, v in summ.items() if v is not None}
+    for k in ("f32x_range_flag", "numa_node", "frame_checksums", "head", "extra"):
+        if k in full:
+            line[k] = full[k]
+    text = json.dumps(line, separators=(",", ":"))
+    # belt and braces: never emit a line the driver cannot take — drop the optional objects, largest first
+    for drop in ("secondary", "roofline_warp", "frame_checksums"):
+        if len(text) <= LINE_BUDGET:
+            break
+        line.pop(drop, None)
+        text = json.dumps(line, separators=(",", ":"))
+    return text
+
+
+def write_extra(full):
+    """the full record (every leg, every table) beside the line: ./bench_extra.json and, when the scratch directory of a
+    gpurun call exists, gpurun_out/bench_extra.json (copied into profiles/ for the judge)"""
+    paths = [os.path.join(ROOT, "bench_extra.json")]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        paths.append(os.path.join(ROOT, "gpurun_out", "bench_extra.json"))
+    written = []
+    for pth in paths:
+        try:
+            with open(pth, "w") as f:
+                json.dump(full, f, indent=1)
+            written.append(os.path.relpath(pth, ROOT))
+        except OSError:
+            pass
+    return written
 
 
 def main():
@@ -396,10 +558,12 @@ def main():
                 sc2.one_step_prediction(sc2.next_pose(sc2.curr)); sc2.curr += 1
             dt2 = timed_loop(one2, args.warmup, args.steps)
             agg2, br2 = frame_timeline(sc2)
-            r2, _ = roofline_from_timeline(agg2, br2, 1e3 * dt2 / args.steps)
+            r2, _rows2 = roofline_from_timeline(agg2, br2, 1e3 * dt2 / args.steps)
             attach_counters(r2, dtn)
+            h128 = next((r for r in _rows2 if r["kernel"].startswith("conv3x3_h16_halo") and "<128,128" in r["kernel"]), None)
             secondary[dtn] = {"value": round(args.steps / dt2, 3), "unit": "frames/s", "ms_per_step": round(1e3 * dt2 / args.steps, 3),
                               "index_agreement_vs_f32_path": round(agree, 5),
+                              "halo128_frac": None if h128 is None else h128["frac"], "halo128_avg_us": None if h128 is None else h128["avg_us"],
                               "roofline": {k: r2.get(k) for k in ("kernel", "achieved", "peak", "frac", "calls_per_frame", "ms_per_frame",
                                                                   "mfma_busy_frac", "traffic", "top5", "frame", "kernel_time_ms_per_frame",
                                                                   "kernels_per_frame")}}
@@ -498,28 +662,37 @@ def main():
                              "LPIPS on (synthetic VGG16 trunk); fp32-in MFMA GEMMs + csrc/train.hip; untuned"}
         del mt, tr
 
+    warp_leg = None
+    if rank == 0 and world == 1 and not args.no_roofline:
+        warp_leg = warp_roofline(dev)
+
     cpu = None
     if rank == 0 and world == 1 and args.cpu_frames > 0:
         cpu = cpu_baseline({k: v.cpu() for k, v in sd.items()}, p, seed_frame, args.cpu_frames)
 
     if rank == 0:
-        out = {
+        full = {
             "metric": "generated RGB-D frames/sec (256x256, GoogleEarth)", "value": round(g["total_frames"] / t_max, 3),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * t_max / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "GoogleEarth-Infinite 256x256 inference loop: forward-splat warp (N<=3) + VQGAN "
+            "config": {"workload": "GoogleEarth-Infinite 256x256 inference loop (BASELINE configs[2]): forward-splat warp (N<=3) + VQGAN "
                                    "encode/quantise(4096)/decode + frame feedback, in-HBM frame store",
                        "frames_per_gpu": args.steps, "scenes": world, "parallelism": f"scene-parallel x{world}",
                        "weights": "seeded synthetic (68 990 620 params)", "topk": 1,
                        "launch": "eager" if args.no_graph else "hip-graph replay of the VQGAN forward",
-                       "f32_products": ("exact hi/lo fp16 split on the fp16 matrix cores, fp32 accumulate (fp32-class accuracy)"
+                       "f32_products": ("exact hi/lo fp16 split on the fp16 matrix cores, fp32 accumulate"
                                         if ops.F32_MODE == "split" else "fp32-in MFMA") if args.dtype == "f32" else None},
             "vqgan_tflops_wallclock": round(GFLOP_PER_FRAME * g["total_frames"] / t_max / 1e3 / world, 2),
-            "roofline": roofline, "cpu_baseline": cpu, "f32_mfma_mode": f32_mfma_leg, "numa_node": numa, "f32x_range_flag": int(range_tripped),
-            "rgbd_integration_branch": rgbd_leg, "concurrent_scenes": conc_leg, "lockstep_scenes": lock_leg, "throughput_mode": secondary, "config5_512sq_batch4": stress, "training_step": train_leg, "frame_checksums": [r[2] for r in g["per_rank"]],
+            "roofline": roofline, "cpu_baseline": cpu, "roofline_warp": warp_leg, "f32_mfma_mode": f32_mfma_leg, "numa_node": numa,
+            "f32x_range_flag": int(range_tripped), "rgbd_integration_branch": rgbd_leg, "concurrent_scenes": conc_leg,
+            "lockstep_scenes": lock_leg, "throughput_mode": secondary, "config5_512sq_batch4": stress, "training_step": train_leg,
+            "frame_checksums": [r[2] for r in g["per_rank"]], "head": _git_head(),
         }
-        print(json.dumps(out), flush=True)
+        written = write_extra(full)
+        full["extra"] = written[0] if written else None
+        sys.stdout.flush()
+        print(compact_line(full), flush=True)
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.barrier()          # ranks leave together (rank 0 was still profiling)
         torch.distributed.destroy_process_group()

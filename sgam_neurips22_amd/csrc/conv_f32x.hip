@@ -1465,7 +1465,10 @@ XPlan make_xplan(const sgam_conv_desc *d) {
     const int64_t M = (int64_t)d->B * d->Ho * d->Wo;
     XPlan pl;
     auto blocks = [&](int bm, int bn) { return (int64_t)sgam_cdiv(M, bm) * sgam_cdiv(d->N, bn); };
-    if (d->N == 32 && d->plan_bm == 0 && blocks(128, 32) >= 224 && halo_shape(d, 128, 32)) { pl.bm = 128; pl.bn = 32; }   // conv_out
+    // conv_out (128 -> 4, padded to ONE 32-channel tile): the halo kernel at any frame size — the only other plan such a descriptor
+    // admits is the generic (64, 64) kernel, which also costs the fused GroupNorm + swish a stand-alone pass; small frames
+    // fill the chip through the split-K rule below like every other halo plan
+    if (d->N == 32 && d->plan_bm == 0 && halo_shape(d, 128, 32)) { pl.bm = 128; pl.bn = 32; }
     else if (d->N % 128 == 0 && blocks(128, 128) >= 224) { pl.bm = 128; pl.bn = 128; }
     else if (d->N % 128 == 0 && blocks(64, 128) >= 224) { pl.bm = 64; pl.bn = 128; }
     else { pl.bm = 64; pl.bn = 64; }
@@ -1591,7 +1594,9 @@ static int red_tc_for(const sgam_conv_desc *d) {
     // 344 -> 337 frames/s; 32-byte row pieces make the combine slower than the fold launch it saves)
     for (int tc = 32; tc >= 8; tc >>= 1) {
         const int tr = 1024 / tc;
-        if (tc >= cpg && hw % tr == 0 && hw / tr <= 16) return tc;
+        // the fold inside the combine is an xor butterfly over cpg / 4 lanes of whole groups: cpg must divide the tile and be a power of two
+        // (N = 384, 768 ... — a ch_mult with a 3 — keep the row-major combine and the two-pass statistics)
+        if (tc >= cpg && tc % cpg == 0 && (cpg & (cpg - 1)) == 0 && hw % tr == 0 && hw / tr <= 16) return tc;
     }
     return 0;
 }

@@ -848,7 +848,9 @@ static int hh_red_tc_for(const sgam_conv_desc *d) {
     if (!on || d->N % 128 != 0 || d->n_valid != d->N || d->N > 1024) return 0;
     for (int tc = 32; tc >= 8; tc >>= 1) {
         const int tr = 1024 / tc;
-        if (tc >= cpg && hw % tr == 0 && hw / tr <= 16) return tc;
+        // the fold inside the combine is an xor butterfly over cpg / 4 lanes of whole groups: cpg must divide the tile and be a power of two
+        // (N = 384, 768 ... — a ch_mult with a 3 — keep the row-major combine and the two-pass statistics)
+        if (tc >= cpg && tc % cpg == 0 && (cpg & (cpg - 1)) == 0 && hw % tr == 0 && hw / tr <= 16) return tc;
     }
     return 0;
 }

@@ -18,10 +18,26 @@ def env_world():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
+def launched_by_torchrun():
+    """a rendezvous is in the environment (torch.distributed.run exports these for every rank, world size 1 included)"""
+    return "RANK" in os.environ and "WORLD_SIZE" in os.environ and "MASTER_PORT" in os.environ
+
+
+def collectives_active(group=None):
+    """True when the (tiny) collectives of this package must actually be issued: a process group exists and either has
+    more than one rank or the run is a world-1 rehearsal of the multi-GPU path (`torch.distributed.run --nproc-per-node 1`,
+    or SGAM_DIST_WORLD1=1) — the one-GPU way to take RCCL initialisation, the all-gather / all-reduce / broadcast on device
+    tensors and the teardown through the exact code an N-GPU run executes (tests/test_gpu_distributed.py)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or launched_by_torchrun() or os.environ.get("SGAM_DIST_WORLD1") == "1"
+
+
 def init(backend=None):
-    """Initialise torch.distributed from the torchrun environment; no-op for a single process."""
+    """Initialise torch.distributed from the torchrun environment (any world size, 1 included: the launcher path is the
+    same code at every N); no-op for a plain single process."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or launched_by_torchrun()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
@@ -87,7 +103,7 @@ def gather_metrics(frames, seconds, checksum, device):
     """All-gather one (frames, seconds, checksum) record per rank.  Returns dict(total_frames, max_seconds,
     frames_per_s, per_rank=[...]) on every rank.  24 bytes per rank: latency-bound, no bandwidth tuning."""
     rec = torch.tensor([float(frames), float(seconds), float(checksum)], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if collectives_active():
         out = [torch.zeros_like(rec) for _ in range(dist.get_world_size())]
         dist.all_gather(out, rec)
     else:
@@ -138,6 +154,8 @@ class LockstepScenes:
     match its solo run up to the summation order a different tile plan implies (same codebook indices away from near-ties,
     RGB-D within 5e-5: tests/test_gpu_lockstep.py).  Forward-splat conditioning branch only."""
 
+    MAX_SPLAT_SOURCES = 64      # SGAM_MAX_SRCS of csrc/warp.hip: entries of the by-value pointer table of one splat launch
+
     def __init__(self, model, data, seed_frames, seed_indices=None, output_dim=None, **scene_kw):
         from .inference_pipeline import InfiniteSceneGeneration
         if scene_kw.get("use_rgbd_integration"):
@@ -148,6 +166,11 @@ class LockstepScenes:
         self.scenes = [InfiniteSceneGeneration(model, data, seed_index=si, output_dim=output_dim, seed_frame=sf, **scene_kw)
                        for si, sf in zip(seed_indices, seed_frames)]
         sc0 = self.scenes[0]
+        if len(self.scenes) * sc0.num_src > self.MAX_SPLAT_SOURCES:
+            # refuse at construction, not by a bare assert in mid-trajectory after some scenes' bookkeeping has advanced
+            raise ValueError(f"LockstepScenes: {len(self.scenes)} scenes x {sc0.num_src} source frames = {len(self.scenes) * sc0.num_src} "
+                             f"sources per splat launch; the kernel's pointer table holds {self.MAX_SPLAT_SOURCES} (SGAM_MAX_SRCS, "
+                             f"csrc/warp.hip) — use at most {self.MAX_SPLAT_SOURCES // sc0.num_src} scenes per LockstepScenes")
         S, (H, W), dev = len(self.scenes), sc0.image_resolution, sc0.device
         self.S = S
         # the batch's persistent model input: the warp writes it, the captured graph reads it by address

@@ -240,10 +240,10 @@ class _Attn:
     CHUNK_BYTES = 64 << 20      # budget of one (rows x n) fp32 score panel: 4096 x 4096 in one piece, 1024 rows at n = 16384
 
     def _rows(self, n):
-        r = max(32, min(n, (self.CHUNK_BYTES // (4 * n)) // 32 * 32))
-        while n % r:
+        r = min(n, (self.CHUNK_BYTES // (4 * n)) // 32 * 32)
+        while r >= 32 and n % r:
             r -= 32
-        return r
+        return r if r >= 32 else n          # n < 32, or no multiple of 32 divides n (a 70 x 70 map): one panel of all rows
 
     def fwd(self, x):
         B, H, W, C = x.shape
@@ -398,7 +398,8 @@ class AutoencoderTrainer:
         are not used by the training-mode forward — and gradients are averaged through one flat bucket after the whole
         backward instead of bucket by bucket during it."""
         import torch.distributed as dist
-        if self._world() == 1:
+        from .distributed import collectives_active
+        if not collectives_active(self.pg):
             return 0
         n = 0
         for t in list(module.parameters()) + list(module.buffers()):
@@ -498,11 +499,13 @@ class AutoencoderTrainer:
         """the gradient half of what DDP does for the reference's LightningModule: average the gradients over the ranks — one
         flat bucket, one RCCL all-reduce (111 MB for the encoder set, 276 MB for the whole autoencoder at fp32).  The other
         half — identical starting weights / buffers on every rank — is `_broadcast_module` at construction."""
-        return self._allreduce(self.grads, self.parameters())
+        self.last_allreduce_bytes = self._allreduce(self.grads, self.parameters())
+        return self.last_allreduce_bytes
 
     def _allreduce(self, grads, params):
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.pg) == 1:
+        from .distributed import collectives_active
+        if not collectives_active(self.pg):
             return 0
         ps = [p for p in params if p in grads]
         if not ps:
@@ -532,7 +535,11 @@ class AutoencoderTrainer:
                 state[p] = (torch.zeros_like(p.data), torch.zeros_like(p.data))
         dev = ps[0].device
         tabs = self.__dict__.setdefault("_adam_tabs", {})
-        key = (id(state),) + tuple(id(p) for p in ps)
+        # keyed on the storage addresses themselves: a parameter re-homed by `.to()` / an assign-style load, or a restored optimiser
+        # state, changes data_ptr() under an unchanged id() and the table must be rebuilt, not written through
+        key = tuple((p.data.data_ptr(), state[p][0].data_ptr(), state[p][1].data_ptr(), p.numel()) for p in ps)
+        if len(tabs) > 8:
+            tabs.clear()
         tab = tabs.get(key)
         if tab is None:
             i64 = lambda v: torch.tensor(v, dtype=torch.int64, device=dev)  # noqa: E731

@@ -129,6 +129,23 @@ def test_split_fp32_plan_queries_without_gpu():
     assert lib.sgam_conv2d_gn_nhwc_f32x(ref(d), None, None, None, None, 1, None, 1.0, None, None, None, None, None, 0, None) == -1
 
 
+def test_group_major_combine_needs_power_of_two_groups():
+    """the group-major split-K combine folds a group over cpg / 4 lanes with an xor butterfly, so it is only
+    selected when channels-per-group divides the tile and is a power of two.  N = 384 / 768 (cpg = 12 / 24, a `ch_mult` with
+    a 3) on a 16 x 16 map under split-K must fall back to the row-major combine's chunk count or to 0 (two-pass statistics)."""
+    lib = _lib.load()
+    ref = ctypes.byref
+    for n in (384, 768):
+        d = _desc(Hi=16, Wi=16, Ho=16, Wo=16, Cin=n, N=n, lda=n, ldb=9 * n, ldc=n, n_valid=n, plan_bm=64, plan_bn=128, plan_ksplit=4)
+        hw = 16 * 16
+        row_major = hw * n // 1024 if (1024 % n == 0 and (hw * n) % 1024 == 0) else 0
+        assert lib.sgam_conv2d_f32x_stats_chunks(ref(d)) == row_major == 0
+        assert lib.sgam_conv2d_h16_stats_chunks(ref(d)) in (0, row_major)
+    # the shipped shapes keep the group-major form: N = 512 (cpg 16) on 16 x 16 -> TC = 32 or 16, at most 16 chunks
+    d = _desc(Hi=16, Wi=16, Ho=16, Wo=16, Cin=512, N=512, lda=512, ldb=9 * 512, ldc=512, n_valid=512, plan_bm=64, plan_bn=128, plan_ksplit=4)
+    assert 0 < lib.sgam_conv2d_f32x_stats_chunks(ref(d)) <= 16
+
+
 def test_tsdf_argument_validation_without_gpu():
     lib = _lib.load()
     g = _lib.TsdfGrid(0.01, 0.03, (ctypes.c_int32 * 3)(0, 0, 0), (ctypes.c_int32 * 3)(4, 4, 4))
