@@ -84,6 +84,7 @@ struct HHParams {
     const double *gn_partial_in;
     int gn_chunks_in;
     float gn_inv_n, gn_eps;
+    int pf;                       // L2 warm-up touches at kernel start (SGAM_HPF bits: 1 halo lines, 2 weights, 4 residual)
 };
 
 __device__ __forceinline__ unsigned hsel(bool c, unsigned a, unsigned b) {
@@ -166,6 +167,52 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
         const int nt = (n0 + wn * (BN / WGN_) + j * 32) >> 5;
         bf_off[j] = ((unsigned)nt * ((unsigned)p.ldb / 32u) * 128u + (unsigned)lane) * 16u;
     }
+
+    // L2 warm-up (p.pf): one dword per 128-byte line of what this workgroup — or, for the weights, its XCD — will read later,
+    // all requested at kernel start so that the HBM / fabric latencies overlap instead of arriving one slab (halo), one tap
+    // (weights) or one epilogue (residual) at a time behind the in-order vector-memory queue.  The values are never used: the
+    // loads are inline asm into ONE register that stays reserved to the end of the kernel (the compiler would otherwise wait
+    // for each value where it is "used", i.e. at once); the compiler's own vmcnt arithmetic stays valid with extra loads in
+    // the queue (its waits only become stricter).
+    unsigned pf_sink = 0;
+#define HPF_TOUCH(ptr) asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(ptr) : "memory")
+    if (p.pf) {
+        if (p.pf & 1) {
+            // halo: a pixel's Cin 16-bit channels are Cin / 64 lines; the slab-0 load below touches line 0, this touches the others
+            const int lines_pp = (p.Cin * 2 + 127) / 128;
+            for (int idx = tid; idx < HR * (lines_pp - 1); idx += 256) {
+                const int row = idx / (lines_pp - 1), ln = idx - row * (lines_pp - 1) + 1;
+                const int hy = row / HWID, hx = row - hy * HWID;
+                const int iy = (UPS ? ty0 / 2 : ty0) + hy - 1, ix = (UPS ? tx0 / 2 : tx0) + hx - 1;
+                if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) {
+                    const unsigned short *q = p.x + (int64_t)((b * p.Hi + iy) * p.Wi + ix) * p.lda + ln * 64;
+                    HPF_TOUCH(q);
+                }
+            }
+        }
+        if (p.pf & 2) {
+            // weights of this channel tile (BN x 9 Cin 16-bit = 2304 lines at Cin = 128), dealt over the workgroups that share an
+            // XCD (consecutive block ids go round the 8 XCDs): workgroup w of its XCD touches lines w, w + nw, ...
+            const unsigned lines = (unsigned)(BN * 9 * p.Cin * 2) / 128u;
+            const unsigned short *wb = p.w + (int64_t)(n0 >> 5) * (p.ldb / 32) * 1024;
+            const unsigned nw = (gridDim.x + 7u) / 8u, wi = blockIdx.x >> 3;
+            for (unsigned ln = wi * 256u + (unsigned)tid; ln < lines; ln += nw * 256u) {
+                const unsigned short *q = wb + (int64_t)ln * 64;
+                HPF_TOUCH(q);
+            }
+        }
+        if ((p.pf & 4) && p.res && p.ksplit == 1) {
+            // residual tile: BM pixels x BN 16-bit channels
+            constexpr int lines_pp = (BN * 2) / 128;
+            for (int idx = tid; idx < BM * lines_pp; idx += 256) {
+                const int trow = idx / lines_pp, ln = idx - trow * lines_pp;
+                const int m = (b * p.Ho + ty0 + (trow >> TWS)) * p.Wo + tx0 + (trow & (TW - 1));
+                const unsigned short *q = p.res + (int64_t)m * p.ldr + n0 + ln * 64;
+                HPF_TOUCH(q);
+            }
+        }
+    }
+#undef HPF_TOUCH
 
     u32x4 hreg[NH];
     float gsc[8], gsh[8];                  // GroupNorm scale / shift of this thread's 8 channels of the slab in flight
@@ -381,6 +428,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
         if (keep == 12345.678f) reinterpret_cast<float *>(p.out)[tid] = keep;
         return;
     }
+    asm volatile("" : : "v"(pf_sink));      // the warm-up register is reserved up to here
     const int n_lim = p.n_valid;
     const unsigned osz = p.out_f32 ? 4u : 2u;
     const unsigned o_bytes = (unsigned)(((int64_t)(p.M - 1) * p.ldc + n_lim) * osz);
@@ -927,6 +975,8 @@ static int hh_conv_impl(const sgam_conv_desc *d, int32_t ht, const void *x, cons
     p.gn_partial_in = gn_partial_in; p.gn_chunks_in = chunks_in; p.gn_eps = gn_eps;
     p.gn_inv_n = 1.0f / ((float)d->Hi * (float)d->Wi * (float)(d->Cin / 32));
     p.gx = p.M / bm; p.gy = d->N / 128;
+    static const int hpf = [] { const char *e = getenv("SGAM_HPF"); return e ? atoi(e) : 0; }();
+    p.pf = hpf;
     static const int swz = [] { const char *e = getenv("SGAM_XCD_SWIZZLE"); return (e && e[0] == '0') ? 0 : 1; }();
     p.xcd_swizzle = swz;
     const dim3 grid((unsigned)((int64_t)p.gx * p.gy), (unsigned)pl.ksplit);

@@ -21,6 +21,12 @@ def _free_port():
         return sk.getsockname()[1]
 
 
+def _last_json(r):
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert lines, f"no JSON line; stdout: {r.stdout[-1500:]!r} stderr: {r.stderr[-1500:]!r}"
+    return json.loads(lines[-1])
+
+
 def _env(**extra):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -47,7 +53,7 @@ torch.cuda.synchronize()
 ok = bool(torch.equal(flat, want))
 sdist.barrier()
 dist.destroy_process_group()
-print(json.dumps({"g": g, "ok": ok}))
+print(json.dumps({"g": g, "ok": ok}), flush=True)
 """
 
 
@@ -55,7 +61,7 @@ def test_nccl_world1_init_gather_teardown():
     env = _env(RANK=0, LOCAL_RANK=0, WORLD_SIZE=1, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port())
     r = subprocess.run([sys.executable, "-c", _WORLD1], capture_output=True, text=True, env=env, timeout=280, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
-    out = json.loads(r.stdout.strip().splitlines()[-1])
+    out = _last_json(r)
     assert out["ok"] and out["g"]["total_frames"] == 31 and out["g"]["per_rank"] == [[31.0, 0.125, 4242.0]]
     assert abs(out["g"]["frames_per_s"] - 248.0) < 1e-9
 
@@ -106,6 +112,6 @@ def test_trainer_collectives_on_device_tensors_world1():
     env = _env(RANK=0, LOCAL_RANK=0, WORLD_SIZE=1, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port())
     r = subprocess.run([sys.executable, "-c", _TRAIN_WORLD1], capture_output=True, text=True, env=env, timeout=560, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
-    out = json.loads(r.stdout.strip().splitlines()[-1])
+    out = _last_json(r)
     assert out["synced"] > 100 and out["bucket_bytes"] > 0
     assert out["l0"] == out["l0"] and out["l1"] == out["l1"]          # finite losses, two updates
