@@ -30,6 +30,10 @@
 
 #include "sgam_common.h"
 
+#ifndef SGAM_XGN_MAXC
+#define SGAM_XGN_MAXC 1024   // most input channels the fused GroupNorm of the halo kernels takes (scale / shift table in LDS)
+#endif
+
 
 namespace {
 
@@ -603,8 +607,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
     constexpr int NH = (HR * 8 + 255) / 256;            // float4 halo loads per thread
     constexpr int OP_BYTES = 2 * HBUF * 2;
     constexpr int EPI_BYTES = 4 * (32 * TM) * (32 * TN + 4) * 4;
-    constexpr int SM_BYTES = OP_BYTES > EPI_BYTES ? OP_BYTES : EPI_BYTES;
+    // fused GroupNorm (not the folding form): per-channel {scale, shift} pairs of the input, formed ONCE per workgroup behind the
+    // operand buffers (the 128 x 128 tile has 12 KB to spare there under its epilogue's transpose region) and read back per
+    // slab.  Round 3 formed them per slab from global loads issued right behind the halo loads of slab s + 2: the vector-memory
+    // queue returns in order, so the wait in front of `rstd * gamma` drained the halo loads' trip to L2 / HBM as well (the
+    // listing showed s_waitcnt vmcnt(1), vmcnt(0) 24 MFMAs after the loads) — every wavefront, every slab.
+    constexpr int TAB_BYTES = (GN && !GNF) ? SGAM_XGN_MAXC * 8 : 0;
+    constexpr int SM_BYTES = (OP_BYTES + TAB_BYTES) > EPI_BYTES ? (OP_BYTES + TAB_BYTES) : EPI_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned short smem[SM_BYTES / 2];
+    float *gn_tab = reinterpret_cast<float *>(smem + OP_BYTES / 2);        // [Cin][{scale, shift}]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -647,16 +658,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
 
     f32x4 hreg[NH];
     f32x4 gt0, gt1;
-    auto hload = [&](int ch, bool live) {            // !live: out-of-range offsets (zeros come back, no memory traffic)
+    auto hload_issue = [&](int ch, bool live) {      // !live: out-of-range offsets (zeros come back, no memory traffic)
         // the slab's channel offset is wave-uniform: it rides in the load's scalar offset (no VALU per load); the bounds
         // check only sees the vector offset, so a dead load / a padding pixel (h_off = ~0) stays out of range
         const unsigned coff = (unsigned)ch * (XBK * 4u);
 #pragma unroll
         for (int j = 0; j < NH; ++j)
             hreg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(live ? h_off[j] : 0xFFFFFFFFu), (int)coff, SGAM_XNT));
-        if constexpr (GN) {
+    };
+    auto hparams = [&](int ch, bool live) {
+        if constexpr (GN && GNF) {
             gn_scale_shift<GNF>(p, b, (live ? ch : 0) * XBK + (tid & 7) * 4, gt0, gt1);
+        } else if constexpr (GN) {
+            const float *t = gn_tab + 2 * ((live ? ch : 0) * XBK + (tid & 7) * 4);
+            gt0 = *reinterpret_cast<const f32x4 *>(t);
+            gt1 = *reinterpret_cast<const f32x4 *>(t + 4);
         }
+    };
+    auto hload = [&](int ch, bool live) {
+        hload_issue(ch, live);
+        hparams(ch, live);
     };
     auto hprep_piece = [&](const int j) {
         {
@@ -735,9 +756,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
     // the weight-fragment loads of the next tap through the 216 MFMAs of the running slab.
     const int s0 = it0 / 9, s1 = SGAM_XABLATE == 1 ? it0 / 9 : it1 / 9;
     int hcur = 0;
-    hload(s0, s0 < s1);
+    hload_issue(s0, s0 < s1);
     bload(0, 0, s0, s0 < s1);
     bload(1, 1, s0, s0 < s1);
+    if constexpr (GN && !GNF) {
+        // (behind the first halo and weight loads, so that its own round trip overlaps theirs; same expressions and order as
+        // gn_scale_shift / the stand-alone GroupNorm kernels)
+        const int cpg = p.Cin / 32;
+        for (int c = tid; c < p.Cin; c += 256) {
+            const int g = c / cpg;
+            const float mean = p.gn_stats[(b * 32 + g) * 2], rstd = p.gn_stats[(b * 32 + g) * 2 + 1];
+            const float sc = rstd * p.gn_gamma[c];
+            gn_tab[2 * c] = sc;
+            gn_tab[2 * c + 1] = p.gn_beta[c] - mean * sc;
+        }
+        __syncthreads();
+    }
+    hparams(s0, s0 < s1);
     hprep();
     hstore(0);
     hload(s0 + 1, s0 + 1 < s1);
@@ -1580,7 +1615,7 @@ extern "C" int32_t sgam_conv2d_f32x_uses_halo(const sgam_conv_desc *d) {
 }
 
 extern "C" int32_t sgam_conv2d_f32x_gn_fusable(const sgam_conv_desc *d) {
-    if (xvalidate(d) != SGAM_OK || d->upsample2x) return 0;
+    if (xvalidate(d) != SGAM_OK || d->upsample2x || d->Cin > SGAM_XGN_MAXC) return 0;
     return halo_eligible(d, make_xplan(d), 1.0f) ? 1 : 0;
 }
 
@@ -1737,6 +1772,7 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
     if (d->KH * d->KW > 32) return SGAM_EINVAL;   // tap validity mask is 32 bits
     const bool halo = halo_eligible(d, pl, a_scale);
     if ((ex.gn_stats || ex.gn_partial_in) && !halo) return SGAM_EINVAL;
+    if (ex.gn_stats && d->Cin > SGAM_XGN_MAXC) return SGAM_EINVAL;           // the scale / shift table of the fused GroupNorm (LDS)
     if (ex.gn_partial_in && ((pl.bm != 64 && pl.bm != 256) || p.ups)) return SGAM_EINVAL;   // folding consumers: 64-row halo / ws kernel
     // algorithmic work of this launch: 2 M N K fp32 FLOP; bytes = input + weights + output once
     if (sgam_i_prof_on) sgam_i_prof_shape(p.M, d->n_valid, d->KH * d->KW * d->Cin, pl.ksplit);

@@ -36,6 +36,9 @@
 #ifndef SGAM_HWGM
 #define SGAM_HWGM 1        // wavefront layout of the 64- / 128-row tiles: 1 = four side by side along N (all BM rows x 32 channels
 #endif                     //    each), 2 = a 2 x 2 grid (BM / 2 rows x 64 channels each: twice the weight-fragment bytes through L1)
+#ifndef SGAM_HGN_MAXC
+#define SGAM_HGN_MAXC 1024  // most input channels the fused GroupNorm takes (its per-channel scale / shift table lives in LDS)
+#endif
 #ifndef SGAM_HABLATE
 #define SGAM_HABLATE 0     // timing experiments only (results are wrong when != 0): 1 no MFMAs, 2 no epilogue, 4 no main loop,
                            // 8 no weight-fragment loads in the loop, 16 no halo staging in the loop, 32 stores dropped
@@ -84,7 +87,6 @@ struct HHParams {
     const double *gn_partial_in;
     int gn_chunks_in;
     float gn_inv_n, gn_eps;
-    int pf;                       // L2 warm-up touches at kernel start (SGAM_HPF bits: 1 halo lines, 2 weights, 4 residual)
 };
 
 __device__ __forceinline__ unsigned hsel(bool c, unsigned a, unsigned b) {
@@ -130,6 +132,13 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
     constexpr int EPI_BYTES = SGAM_HDIRECT ? 4 * RH * 2 * TN * 8 * 4 : 4 * WM * LDR * 4;
     constexpr int SM_BYTES = OP_BYTES > EPI_BYTES ? OP_BYTES : EPI_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned short smem[SM_BYTES / 2];
+    // GroupNorm of the input as per-channel {scale = rstd * gamma, shift = beta - mean * scale}, formed ONCE per workgroup in the
+    // prologue (same expressions and order as before) and read back from LDS per slab.  Round 3 formed them per slab from
+    // global loads issued right behind the halo loads of slab s + 2: the vector-memory queue returns in order, so the
+    // `s_waitcnt vmcnt(1)` in front of `rstd * gamma` waited out the halo loads' trip to L2 / HBM as well — every wavefront,
+    // every slab.
+    constexpr int GN_TAB = (GN && !GNF) ? SGAM_HGN_MAXC : 4;
+    __shared__ __attribute__((aligned(16))) float gn_tab[2][GN_TAB];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -168,61 +177,30 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
         bf_off[j] = ((unsigned)nt * ((unsigned)p.ldb / 32u) * 128u + (unsigned)lane) * 16u;
     }
 
-    // L2 warm-up (p.pf): one dword per 128-byte line of what this workgroup — or, for the weights, its XCD — will read later,
-    // all requested at kernel start so that the HBM / fabric latencies overlap instead of arriving one slab (halo), one tap
-    // (weights) or one epilogue (residual) at a time behind the in-order vector-memory queue.  The values are never used: the
-    // loads are inline asm into ONE register that stays reserved to the end of the kernel (the compiler would otherwise wait
-    // for each value where it is "used", i.e. at once); the compiler's own vmcnt arithmetic stays valid with extra loads in
-    // the queue (its waits only become stricter).
-    unsigned pf_sink = 0;
-#define HPF_TOUCH(ptr) asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(ptr) : "memory")
-    if (p.pf) {
-        if (p.pf & 1) {
-            // halo: a pixel's Cin 16-bit channels are Cin / 64 lines; the slab-0 load below touches line 0, this touches the others
-            const int lines_pp = (p.Cin * 2 + 127) / 128;
-            for (int idx = tid; idx < HR * (lines_pp - 1); idx += 256) {
-                const int row = idx / (lines_pp - 1), ln = idx - row * (lines_pp - 1) + 1;
-                const int hy = row / HWID, hx = row - hy * HWID;
-                const int iy = (UPS ? ty0 / 2 : ty0) + hy - 1, ix = (UPS ? tx0 / 2 : tx0) + hx - 1;
-                if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) {
-                    const unsigned short *q = p.x + (int64_t)((b * p.Hi + iy) * p.Wi + ix) * p.lda + ln * 64;
-                    HPF_TOUCH(q);
-                }
-            }
-        }
-        if (p.pf & 2) {
-            // weights of this channel tile (BN x 9 Cin 16-bit = 2304 lines at Cin = 128), dealt over the workgroups that share an
-            // XCD (consecutive block ids go round the 8 XCDs): workgroup w of its XCD touches lines w, w + nw, ...
-            const unsigned lines = (unsigned)(BN * 9 * p.Cin * 2) / 128u;
-            const unsigned short *wb = p.w + (int64_t)(n0 >> 5) * (p.ldb / 32) * 1024;
-            const unsigned nw = (gridDim.x + 7u) / 8u, wi = blockIdx.x >> 3;
-            for (unsigned ln = wi * 256u + (unsigned)tid; ln < lines; ln += nw * 256u) {
-                const unsigned short *q = wb + (int64_t)ln * 64;
-                HPF_TOUCH(q);
-            }
-        }
-        if ((p.pf & 4) && p.res && p.ksplit == 1) {
-            // residual tile: BM pixels x BN 16-bit channels
-            constexpr int lines_pp = (BN * 2) / 128;
-            for (int idx = tid; idx < BM * lines_pp; idx += 256) {
-                const int trow = idx / lines_pp, ln = idx - trow * lines_pp;
-                const int m = (b * p.Ho + ty0 + (trow >> TWS)) * p.Wo + tx0 + (trow & (TW - 1));
-                const unsigned short *q = p.res + (int64_t)m * p.ldr + n0 + ln * 64;
-                HPF_TOUCH(q);
-            }
-        }
-    }
-#undef HPF_TOUCH
-
     u32x4 hreg[NH];
     float gsc[8], gsh[8];                  // GroupNorm scale / shift of this thread's 8 channels of the slab in flight
-    auto hload = [&](int ch, bool live) {
+    auto hload_issue = [&](int ch, bool live) {
         const unsigned coff = (unsigned)ch * (XBK * 2u);       // wave-uniform: the load's scalar offset (no VALU per load)
 #pragma unroll
         for (int j = 0; j < NH; ++j)
             hreg[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(live ? h_off[j] : 0xFFFFFFFFu), (int)coff, 0);
+    };
+    auto hparams = [&](int ch, bool live) {
         if constexpr (GN) {
             const int c = (live ? ch : 0) * XBK + (tid & 3) * 8;
+            if constexpr (!GNF) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 a = *reinterpret_cast<const f32x4 *>(&gn_tab[0][c + 4 * h]);
+                    const f32x4 d = *reinterpret_cast<const f32x4 *>(&gn_tab[1][c + 4 * h]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        gsc[4 * h + e] = a[e];
+                        gsh[4 * h + e] = d[e];
+                    }
+                }
+                return;
+            }
             const int cpg = p.Cin / 32;
             float fmean = 0.f, frstd = 0.f;
             if constexpr (GNF) {
@@ -259,6 +237,10 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
                 }
             }
         }
+    };
+    auto hload = [&](int ch, bool live) {
+        hload_issue(ch, live);
+        hparams(ch, live);
     };
     auto hprep_piece = [&](const int j) {
         if constexpr (GN) {
@@ -323,7 +305,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
     const int s0 = (int)blockIdx.y * p.slabs_per_split;            // this workgroup's range of K slabs (split-K: grid.y)
     const int s1 = min(p.slabs, s0 + p.slabs_per_split);
     int hcur = 0;
-    hload(s0, true);
+    hload_issue(s0, true);
     if constexpr (NBR == 9) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) bload(t, t, s0, true);
@@ -331,6 +313,19 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
         bload(0, 0, s0, true);
         bload(1, 1, s0, true);
     }
+    if constexpr (GN && !GNF) {
+        // (behind the first halo and weight loads, so that its own round trip overlaps theirs)
+        const int cpg = p.Cin / 32;
+        for (int c = tid; c < p.Cin; c += 256) {
+            const int g = c / cpg;
+            const float mean = p.gn_stats[(b * 32 + g) * 2], rstd = p.gn_stats[(b * 32 + g) * 2 + 1];
+            const float sc = rstd * p.gn_gamma[c];
+            gn_tab[0][c] = sc;
+            gn_tab[1][c] = p.gn_beta[c] - mean * sc;
+        }
+        __syncthreads();
+    }
+    hparams(s0, true);
 #pragma unroll
     for (int j = 0; j < NH; ++j) hprep_piece(j);
     hstore(0);
@@ -384,6 +379,10 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
                 else bload((tap + 2) % 3, tap - 7, sl + 1, has_next);
             }
             if constexpr (!(SGAM_HABLATE & 16)) {
+                // (the barrier keeps the scheduler from hoisting the staging arithmetic to the head of the slab body, in front of
+                // this iteration's first loads: the wait it then needs counts loads across the loop's back edge and comes out as
+                // vmcnt(0) — the whole vector-memory queue drained at the top of every slab)
+                if (tap == 1) __builtin_amdgcn_sched_barrier(0);
                 if (tap >= 1 && tap <= NH) hprep_piece(tap - 1);            // next slab's halo, one piece per tap
                 if (tap == NH + 1) {
                     hstore(hcur ^ 1);
@@ -428,7 +427,6 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
         if (keep == 12345.678f) reinterpret_cast<float *>(p.out)[tid] = keep;
         return;
     }
-    asm volatile("" : : "v"(pf_sink));      // the warm-up register is reserved up to here
     const int n_lim = p.n_valid;
     const unsigned osz = p.out_f32 ? 4u : 2u;
     const unsigned o_bytes = (unsigned)(((int64_t)(p.M - 1) * p.ldc + n_lim) * osz);
@@ -952,7 +950,8 @@ static int hh_conv_impl(const sgam_conv_desc *d, int32_t ht, const void *x, cons
     if (gn_partial_in && (gn_mean_rstd || sgam_conv2d_h16_gn_foldable(d, chunks_in) != 1 || !sgam_aligned16(gn_partial_in)))
         return SGAM_EINVAL;
     const bool gn = gn_mean_rstd != nullptr || gn_partial_in != nullptr;
-    if (gn && (!gn_gamma || !gn_beta || !sgam_aligned16(gn_gamma) || !sgam_aligned16(gn_beta) || d->upsample2x || d->Cin % 128))
+    if (gn && (!gn_gamma || !gn_beta || !sgam_aligned16(gn_gamma) || !sgam_aligned16(gn_beta) || d->upsample2x || d->Cin % 128 ||
+               d->Cin > SGAM_HGN_MAXC))
         return SGAM_EINVAL;
     if (gn_partial && sgam_conv2d_h16_stats_chunks(d) <= 0) return SGAM_EINVAL;
     if (pl.ksplit > 1 && (!workspace || workspace_bytes < sgam_conv2d_halo_h16_workspace_bytes(d) || !sgam_aligned16(workspace) ||
@@ -975,8 +974,6 @@ static int hh_conv_impl(const sgam_conv_desc *d, int32_t ht, const void *x, cons
     p.gn_partial_in = gn_partial_in; p.gn_chunks_in = chunks_in; p.gn_eps = gn_eps;
     p.gn_inv_n = 1.0f / ((float)d->Hi * (float)d->Wi * (float)(d->Cin / 32));
     p.gx = p.M / bm; p.gy = d->N / 128;
-    static const int hpf = [] { const char *e = getenv("SGAM_HPF"); return e ? atoi(e) : 0; }();
-    p.pf = hpf;
     static const int swz = [] { const char *e = getenv("SGAM_XCD_SWIZZLE"); return (e && e[0] == '0') ? 0 : 1; }();
     p.xcd_swizzle = swz;
     const dim3 grid((unsigned)((int64_t)p.gx * p.gy), (unsigned)pl.ksplit);

@@ -352,7 +352,7 @@ def _run_conv(desc, x, w, bias, residual, out, gn=None, a_scale=1.0, norm=None):
         # the one-launch statistics+apply kernel
         have = getattr(x, "_gn_partials", None) is not None
         h16_fusable = (x.dtype in H16 and FUSE_GN_APPLY and x.dim() == 4 and groups == 32 and eps == 1e-6
-                       and x.shape[3] % 128 == 0 and not desc.upsample2x and _h16_frag(w, desc) is not None)
+                       and x.shape[3] % 128 == 0 and x.shape[3] <= 1024 and not desc.upsample2x and _h16_frag(w, desc) is not None)
         if fusable and have and lib.sgam_conv2d_f32x_gn_foldable(ctypes.byref(desc), x._gn_partials[1]) == 1:
             # few enough chunk partials (the group-major split-K combine of a 16^2 / 32^2 map): the conv folds them itself
             gn = (x._gn_partials, gamma, beta, swish, eps)

@@ -12,10 +12,19 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
+    config.addinivalue_line("markers", "experimental: kernels outside the default plans (SGAM_TEST_EXPERIMENTAL=1 to run)")
 
 
 def pytest_collection_modifyitems(config, items):
     import torch
+    if os.environ.get("SGAM_TEST_EXPERIMENTAL") != "1":
+        # kernels that are built and reachable by an explicit plan / environment switch but are NOT in the default plans
+        # (DESIGN.md 5.5 / 5.5b "what did not pay"): their tests stay in the tree and run on request
+        # (SGAM_TEST_EXPERIMENTAL=1 pytest -m experimental), not in the driver's `-m gpu` pass (budget: < 600 s)
+        skip_x = pytest.mark.skip(reason="experimental kernel, not in the default plans (SGAM_TEST_EXPERIMENTAL=1 to run)")
+        for item in items:
+            if "experimental" in item.keywords:
+                item.add_marker(skip_x)
     if torch.cuda.is_available():
         return
     skip = pytest.mark.skip(reason="no GPU visible")

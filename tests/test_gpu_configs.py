@@ -101,8 +101,10 @@ def test_config5_16bit_mfma_path(golden, dt):
     _report(f"config5_{dt}", {"index_agreement_vs_reference": agree, "latent_rel_err": err_pre,
                               "decoder_rel_err_same_codes": err_dec})
     assert dec.dtype == torch.float32 and torch.isfinite(dec).all()
-    assert agree >= (0.90 if dt == "fp16" else 0.70)
-    assert err_pre <= (1.5e-2 if dt == "fp16" else 8e-2) and err_dec <= (1.5e-2 if dt == "fp16" else 8e-2)
+    # floors within 3 points of / bounds 1.5x what the deterministic kernels measure (report_config5_*.json: agreement 0.9966 /
+    # 0.9583, latent 7.4e-3 / 5.3e-2, decoder 2.1e-3 / 1.7e-2 for fp16 / bf16): a regression of a few percent must fail
+    assert agree >= (0.99 if dt == "fp16" else 0.93)
+    assert err_pre <= (1.1e-2 if dt == "fp16" else 8e-2) and err_dec <= (3.2e-3 if dt == "fp16" else 2.6e-2)
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
@@ -150,8 +152,10 @@ def test_config2_clevr_16bit(golden, dt):
     _report(f"config2_clevr_{dt}", {"index_agreement_vs_reference": agree, "latent_rel_err": err_pre,
                                     "decoder_rel_err_same_codes": err_dec})
     assert decs[0].shape == (1, 1, 4, 256, 256) and torch.isfinite(decs[0]).all()
-    assert agree >= (0.70 if dt == "bf16" else 0.90)
-    assert err_pre <= (8e-2 if dt == "bf16" else 1.5e-2) and err_dec <= (8e-2 if dt == "bf16" else 1.5e-2)
+    # (report_config2_clevr_*.json: agreement 0.9727 / 0.9961 — 7 and 1 of 256 tokens —, latent 1.5e-2 / 1.6e-3, decoder
+    # 1.7e-2 / 2.5e-3 for bf16 / fp16; floors within 3 points, bounds 1.5x)
+    assert agree >= (0.94 if dt == "bf16" else 0.99)
+    assert err_pre <= (2.2e-2 if dt == "bf16" else 2.5e-3) and err_dec <= (2.6e-2 if dt == "bf16" else 3.7e-3)
 
 
 # ------------------------------------------------------------------------------------------------ top-k > 1
@@ -261,6 +265,19 @@ def test_ge_trajectory_free_running_32_frames(golden):
     for r in rows[:n_exact]:
         assert r["mask_same"] and r["u8_max"] <= 1 and r["u8_frac_diff"] < 5e-3 and r["depth_max"] <= 1e-3, r
     assert n_exact >= 3, rows[:3]                     # the margin-guarded frame and its immediate successors
+    if first is not None:
+        # the first difference must be EXPLAINED (docstring): every flipped token is a near-tie of the reference's own run, or the
+        # model input of that step already differs from the reference's (identical fp32 inputs give x_sum_delta == 0 exactly: both
+        # sides sum the same values in float64; one uint8 feedback LSB is 7.8e-3) while the hole mask is still the reference's
+        r = rows[first]
+        near_tie = r["flipped_ref_gap_max"] < 1e-4
+        input_differs = r["x_sum_delta"] > 1e-6 and r["mask_same"]
+        assert near_tie or input_differs, r
+        if not near_tie:
+            # ... and that input difference must itself come from the discrete feedback (uint8 truncation boundary pixels of an
+            # EARLIER frame, bounded by 1 LSB each), not from a wrong frame: every earlier frame was within the boundary
+            assert all(q["u8_max"] <= 1 and q["depth_max"] <= 1e-3 for q in rows[:first]), rows[:first]
+            assert any(q["u8_frac_diff"] > 0 for q in rows[:first]) or rows[first]["x_sum_delta"] < 1e-2, rows[:first + 1]
 
 
 def _oracle_check_step(scene, res, sd, p, srcs, tgt, dataset, tgt_depth=None):

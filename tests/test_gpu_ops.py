@@ -481,6 +481,7 @@ def test_batched_attention_keeps_every_query_inside_its_image(B, n, dt):
     _close(o[(B - 1) * n:].float(), torch.softmax(q @ k.t() * scale, dim=1) @ v, tol64, "last image vs fp64")
 
 
+@pytest.mark.experimental
 @pytest.mark.parametrize("B,C,Cout,H,W,gn,with_res", [(1, 512, 512, 16, 16, True, True), (1, 256, 256, 32, 32, True, False),
                                                      (2, 256, 512, 16, 24, False, True), (1, 128, 160, 8, 16, False, False)])
 def test_small_map_k_in_workgroup_kernel(B, C, Cout, H, W, gn, with_res):
@@ -530,6 +531,7 @@ def test_small_map_k_in_workgroup_kernel(B, C, Cout, H, W, gn, with_res):
         assert torch.equal(out, again)
 
 
+@pytest.mark.experimental
 @pytest.mark.parametrize("B,C,Cout,H,W,ks,gn,with_res", [(1, 512, 512, 16, 16, 16, True, True), (1, 512, 512, 16, 16, 8, True, False),
                                                           (1, 256, 256, 32, 32, 8, True, True), (2, 256, 512, 16, 32, 4, False, True),
                                                           (1, 128, 160, 16, 16, 4, False, False), (1, 512, 256, 16, 16, 16, True, False)])
@@ -617,6 +619,7 @@ def test_fused_groupnorm_qkv_gemm(case):
     assert (got - two).abs().max().item() <= 4e-6 * scale
 
 
+@pytest.mark.experimental
 @pytest.mark.parametrize("case", [(1, 64, 64, 256, 256, True), (1, 128, 128, 256, 128, False), (2, 64, 64, 128, 256, False)],
                          ids=lambda c: f"B{c[0]}_{c[1]}x{c[2]}_{c[3]}to{c[4]}")
 def test_panel_gemm_1x1_conv_with_residual_and_statistics(case):
