@@ -277,7 +277,16 @@ def warp_roofline(dev, reps=8):
         us = {k: round(1e3 * v / reps, 2) for k, v in per.items()}
         tot_us = sum(us.values())
         nbytes = res * res * (16 * N + 17) * B
+        # the round-3 form (device-scope atomicMax per point into a winner buffer + its memset, which the timeline does not see)
+        old_mode, ops.SPLAT_TILED = ops.SPLAT_TILED, False
+        try:
+            splat()
+            recs2, br2 = ops.kernel_timeline(lambda: [splat() for _ in range(reps)])
+        finally:
+            ops.SPLAT_TILED = old_mode
+        two_pass_us = round(1e3 * sum(max(ms - br2, 0.0) for _n, ms, *_ in recs2) / reps, 2)
         out["cases"][tag] = {"B": B, "N": N, "H": res, "W": res, "algorithmic_bytes": nbytes, "us": round(tot_us, 2), "kernels_us": us,
+                             "two_pass_global_atomics_us": two_pass_us,
                              "achieved": round(nbytes / tot_us / 1e3, 1), "frac": round(nbytes / tot_us / 1e3 / HBM_PEAK_GBS, 4),
                              "frac_of_achievable": round(nbytes / tot_us / 1e3 / HBM_ACHIEVABLE_GBS, 4)}
         # inverse warp at the same geometry (target depth = the first source's depth: any finite depth does for timing)

@@ -397,6 +397,26 @@ int sgam_forward_splat_srcs_f32(const float *const *src_feat_ptrs, const float *
                                 int32_t *winner, float *merge_depths, float *merge_feats, uint8_t *extrap, float *x_out,
                                 float *proj_feats, float *proj_depth, uint8_t *inb_mask, int32_t *pix_xy, void *stream);
 
+/* (ABI v6) The same forward splat WITHOUT global atomics — target-owned tiles with an LDS z-tile (csrc/warp.hip):
+ * pass 1 caches every source point's target pixel and the bounding box of each 8 x 32 source bin, pass 2 gives a workgroup a
+ * 32 x 32 (16 x 16 for small launches) tile of the target image + 1-pixel halo, resolves "largest point index wins"
+ * (warp.py:217-262) with LDS atomicMax over the bins whose box meets the tile, and finishes median fill / merge / mask /
+ * depth normalisation (warp.py:264-286, model.py:210-229) from LDS.  Results are bit-identical to sgam_forward_splat_f32
+ * for any geometry; the by-products inb_mask / pix_xy are only offered by the two-pass form above.
+ *   workspace: sgam_forward_splat_workspace_bytes(B, N, H, W) bytes, 16-byte aligned (the cached target pixels [B][N][HW]
+ *   int32 + the bin boxes), contents irrelevant on entry (no memset); H, W <= 32767.  -1 from the query: shape refused. */
+int64_t sgam_forward_splat_workspace_bytes(int32_t B, int32_t N, int32_t H, int32_t W);
+int sgam_forward_splat_tiled_f32(const float *src_feats, int64_t feat_cs, int64_t feat_ps, const float *src_depths,
+                                 const float *tgt_K, const float *src_Kinv, const float *T, int32_t B, int32_t N, int32_t H,
+                                 int32_t W, const float *depth_range, int32_t dataset_norm, void *workspace,
+                                 int64_t workspace_bytes, float *merge_depths, float *merge_feats, uint8_t *extrap,
+                                 float *x_out, float *proj_feats, float *proj_depth, void *stream);
+int sgam_forward_splat_tiled_srcs_f32(const float *const *src_feat_ptrs, const float *const *src_depth_ptrs, int64_t feat_cs,
+                                      int64_t feat_ps, const float *tgt_K, const float *src_Kinv, const float *T, int32_t B,
+                                      int32_t N, int32_t H, int32_t W, const float *depth_range, int32_t dataset_norm,
+                                      void *workspace, int64_t workspace_bytes, float *merge_depths, float *merge_feats,
+                                      uint8_t *extrap, float *x_out, float *proj_feats, float *proj_depth, void *stream);
+
 /* K12 standalone (VQModel.get_x, model.py:196-199 + 210-229, when the warped view is supplied by the
  * caller): compute_mask=1: extrap = depth <= 0, out = normalised inverse depth with holes = -2;
  * compute_mask=0: out = 2*norm(depth)-1 only (the ground-truth branch x_scaled_inverse_depth). */

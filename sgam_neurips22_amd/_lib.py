@@ -23,7 +23,7 @@ class TsdfGrid(ctypes.Structure):
 
 
 # name -> (restype, argtypes); must list every symbol include/sgam_hip.h declares
-ABI_VERSION = 5      # include/sgam_hip.h: sgam_abi_version() of the library these prototypes were written against
+ABI_VERSION = 6      # include/sgam_hip.h: sgam_abi_version() of the library these prototypes were written against
 
 PROTOTYPES = {
     "sgam_abi_version": (c_i32, []),
@@ -159,6 +159,12 @@ PROTOTYPES = {
     "sgam_forward_splat_srcs_f32": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,
                                             ctypes.POINTER(c_f32), c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                             c_vp, c_vp, c_vp]),
+    "sgam_forward_splat_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32, c_i32]),
+    "sgam_forward_splat_tiled_f32": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,
+                                             ctypes.POINTER(c_f32), c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "sgam_forward_splat_tiled_srcs_f32": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,
+                                                  ctypes.POINTER(c_f32), c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                                  c_vp]),
     "sgam_depth_normalise_f32": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_i32, c_i64, c_vp]),
     "sgam_inverse_warp_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp,
                                       c_vp]),

@@ -230,6 +230,194 @@ __global__ __launch_bounds__(TS *TS) void splat_resolve_kernel(
     if (x_out) x_out[((int64_t)b * 4 + 3) * HW + o] = normalise_depth(md, hole, dataset_norm);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Forward splat, target-owned tiles (round 4): no global atomics.
+//
+// The two-pass form above sends one device-scope atomicMax per source point to a [B][HW] winner buffer.  On MI355X those
+// are executed at the memory side (the eight XCD L2s are not coherent with each other): measured 65 G atomics/s for a
+// coherent scatter — 12.6 M points (512 x 512, B = 16, N = 3) take 190 us + the buffer's memset, against 22 us for the same
+// scatter as plain stores and 37 us for the design below (scripts/micro/atomic_splat.hip); issuing them at workgroup scope
+// from the XCD that owns a band of the buffer changes nothing (same instruction, same place of execution).  So:
+//   pass 1  splat_project_kernel: one lane per source point, in bins of 8 rows x 32 pixels (whole 128-byte lines of the depth
+//           map): target pixel of the point -> tgt[b][s][pix] = (py << 16 | px), -1 when out of bounds; the bounding box of
+//           the bin's target pixels -> bbox[b][s][bin] (4 x int16).  4 N bytes read + 4 N written per pixel, no atomics.
+//   pass 2  splat_tile_kernel<TT>: a workgroup OWNS a TT x TT tile of the target image plus its 1-pixel halo.  It scans the
+//           bounding boxes of all N x bins source bins (8 bytes each), and for every bin whose box meets the tile it reads the
+//           bin's cached target pixels and resolves "largest linear point index p = pix * N + s wins" (warp.py:217-218 and
+//           the oracle's sequential loop) with LDS atomicMax — integer max: order-independent, deterministic — on its own
+//           (TT + 2)^2 z-tile.  Exact for ANY geometry (the boxes are exact, not estimates): a wild warp only makes more
+//           bins meet a tile.  Then, still in LDS: (r, g, b, z) of every winner, the four 3 x 3 medians, the `== 0` merge, the
+//           mask and the inverse-depth normalisation, outputs written once (the arithmetic is splat_resolve_kernel's).
+// HBM bytes per target pixel: 12 N + 33 against the algorithmic 16 N + 17 — the cached target pixel replaces
+// the re-read of x / y / z planes the reference materialises.
+// ------------------------------------------------------------------------------------------------
+constexpr int SBW = 32, SBH = 8;      // source bin: 8 rows x 32 pixels = 256 points, one per thread
+struct alignas(8) SBox {
+    short x0, y0, x1, y1;             // inclusive; empty: x0 > x1
+};
+
+template <bool TAB>
+__global__ __launch_bounds__(256) void splat_project_kernel(const float *__restrict__ src_depths, SrcTable tab,
+                                                            const float *__restrict__ tgt_K, const float *__restrict__ src_Kinv,
+                                                            const float *__restrict__ T, int N, int H, int W, int bins_x, int nbins,
+                                                            int *__restrict__ tgt, SBox *__restrict__ bbox) {
+    const int bin = blockIdx.x, s = blockIdx.y, b = blockIdx.z;
+    const int bn = b * N + s, HW = H * W;
+    const int by = bin / bins_x, bxx = bin - by * bins_x;
+    const int i = by * SBH + (threadIdx.x >> 5), j = bxx * SBW + (threadIdx.x & 31);
+    const bool valid = i < H && j < W;
+    int px = 0, py = 0;
+    bool inb = false;
+    if (valid) {
+        Cam c;
+        load_cam(c, src_Kinv + 9 * bn, T + 16 * bn, tgt_K + 9 * b);
+        const int pix = i * W + j;
+        const float sd = TAB ? tab.depth[bn][pix] : src_depths[(int64_t)bn * HW + pix];
+        float X, Y, Z;
+        to_target_cam(c, (float)j, (float)i, sd, X, Y, Z);
+        inb = project_pixel(c, X, Y, Z, H, W, px, py);
+        tgt[(int64_t)bn * HW + pix] = inb ? ((py << 16) | px) : -1;
+    }
+    int x0 = inb ? px : 32767, y0 = inb ? py : 32767, x1 = inb ? px : -1, y1 = inb ? py : -1;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        x0 = min(x0, __shfl_xor(x0, o, 64));
+        y0 = min(y0, __shfl_xor(y0, o, 64));
+        x1 = max(x1, __shfl_xor(x1, o, 64));
+        y1 = max(y1, __shfl_xor(y1, o, 64));
+    }
+    __shared__ int red[4][4];
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6][0] = x0; red[threadIdx.x >> 6][1] = y0; red[threadIdx.x >> 6][2] = x1; red[threadIdx.x >> 6][3] = y1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        SBox o;
+        o.x0 = (short)min(min(red[0][0], red[1][0]), min(red[2][0], red[3][0]));
+        o.y0 = (short)min(min(red[0][1], red[1][1]), min(red[2][1], red[3][1]));
+        o.x1 = (short)max(max(red[0][2], red[1][2]), max(red[2][2], red[3][2]));
+        o.y1 = (short)max(max(red[0][3], red[1][3]), max(red[2][3], red[3][3]));
+        bbox[(int64_t)bn * nbins + bin] = o;
+    }
+}
+
+template <int TT, bool TAB>
+__global__ __launch_bounds__(256) void splat_tile_kernel(
+    const float *__restrict__ src_feats, int64_t feat_cs, int64_t feat_ps, const float *__restrict__ src_depths, SrcTable tab,
+    const float *__restrict__ src_Kinv, const float *__restrict__ T, const int *__restrict__ tgt, const SBox *__restrict__ bbox, int N,
+    int H, int W, int bins_x, int nbins, float r0, float r1, int use_range, int dataset_norm, float *__restrict__ merge_depths,
+    float *__restrict__ merge_feats, uint8_t *__restrict__ extrap, float *__restrict__ x_out, float *__restrict__ proj_feats,
+    float *__restrict__ proj_depth) {
+    constexpr int TE = TT + 2;                       // tile edge with the 1-pixel halo
+    __shared__ int win[TE * TE];
+    __shared__ float tile[4][TE][TE + 1];
+    __shared__ int list[256];
+    __shared__ int cnt;
+    const int b = blockIdx.z, HW = H * W;
+    const int ty0 = blockIdx.y * TT, tx0 = blockIdx.x * TT;
+    const int tid = threadIdx.x;
+    for (int c = tid; c < TE * TE; c += 256) win[c] = -1;
+    // the tile with its halo, clipped to the image, in target pixels (inclusive)
+    const int ex0 = max(tx0 - 1, 0), ey0 = max(ty0 - 1, 0), ex1 = min(tx0 + TT, W - 1), ey1 = min(ty0 + TT, H - 1);
+    const int total = N * nbins;
+    const SBox *bb = bbox + (int64_t)b * total;
+    const int *tg = tgt + (int64_t)b * N * HW;
+    for (int base = 0; base < total; base += 256) {
+        if (tid == 0) cnt = 0;
+        __syncthreads();                             // (also: win[] initialised / the previous round's list consumed)
+        const int e = base + tid;
+        if (e < total) {
+            const SBox q = bb[e];
+            if (q.x0 <= ex1 && q.x1 >= ex0 && q.y0 <= ey1 && q.y1 >= ey0) list[atomicAdd(&cnt, 1)] = e;
+        }
+        __syncthreads();
+        const int n = cnt;
+        for (int k = 0; k < n; ++k) {
+            const int e2 = list[k];
+            const int s = e2 / nbins, bin = e2 - s * nbins;
+            const int by = bin / bins_x, bxx = bin - by * bins_x;
+            const int i = by * SBH + (tid >> 5), j = bxx * SBW + (tid & 31);
+            if (i < H && j < W) {
+                const int pix = i * W + j;
+                const int t = tg[(int64_t)s * HW + pix];
+                if (t >= 0) {
+                    const int lx = (t & 0xFFFF) - (tx0 - 1), ly = (t >> 16) - (ty0 - 1);
+                    if ((unsigned)lx < (unsigned)TE && (unsigned)ly < (unsigned)TE) atomicMax(&win[ly * TE + lx], pix * N + s);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // (r, g, b, z) of every cell's winner; cells outside the image and empty cells are zero (splat_resolve_kernel)
+    for (int c = tid; c < TE * TE; c += 256) {
+        const int hy = c / TE, hx = c - hy * TE;
+        const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+        float f0 = 0.f, f1 = 0.f, f2 = 0.f, z = 0.f;
+        const int wv = win[c];
+        if (wv >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            const int pix = wv / N, s = wv - pix * N;
+            const int bn = b * N + s;
+            const float *fp = (TAB ? tab.feat[bn] : src_feats + (int64_t)bn * 3 * HW) + (int64_t)pix * feat_ps;
+            f0 = fp[0];
+            f1 = fp[feat_cs];
+            f2 = fp[2 * feat_cs];
+            Cam cm;
+            load_cam(cm, src_Kinv + 9 * bn, T + 16 * bn, src_Kinv);  // Kt unused here
+            const int i = pix / W, j = pix - i * W;
+            float X, Y;
+            to_target_cam(cm, (float)j, (float)i, TAB ? tab.depth[bn][pix] : src_depths[(int64_t)bn * HW + pix], X, Y, z);
+        }
+        tile[0][hy][hx] = f0;
+        tile[1][hy][hx] = f1;
+        tile[2][hy][hx] = f2;
+        tile[3][hy][hx] = z;
+    }
+    __syncthreads();
+    for (int q = tid; q < TT * TT; q += 256) {
+        const int ly = q / TT, lx = q - ly * TT;
+        const int gy = ty0 + ly, gx = tx0 + lx;
+        if (gy >= H || gx >= W) continue;
+        const int o = gy * W + gx;
+        float merged[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v[9];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) v[dy * 3 + dx] = tile[c][ly + dy][lx + dx];
+            const float centre = v[4];
+            const float med = median9(v);
+            // mask * median + (~mask) * plane, in fp32 like warp.py:277-278 (NaN/Inf propagate the same way)
+            const float mk = (centre == 0.0f) ? 1.0f : 0.0f, nmk = (centre == 0.0f) ? 0.0f : 1.0f;
+            merged[c] = __fadd_rn(__fmul_rn(mk, med), __fmul_rn(nmk, centre));
+            if (c < 3) {
+                if (proj_feats) proj_feats[((int64_t)b * 3 + c) * HW + o] = centre;
+            } else if (proj_depth) {
+                proj_depth[(int64_t)b * HW + o] = centre;
+            }
+        }
+        const float md = merged[3];
+        bool hole;
+        if (use_range) {  // training branch, warp.py:280-283
+            const float le = (md <= r1) ? 1.0f : 0.0f, ge = (md >= r0) ? 1.0f : 0.0f;
+            hole = __fsub_rn(1.0f, __fmul_rn(le, ge)) != 0.0f;
+            if (md >= r1) merged[0] = merged[1] = merged[2] = 0.0f;
+        } else {
+            hole = md <= 0.0f;  // warp.py:285
+        }
+        if (merge_depths) merge_depths[(int64_t)b * HW + o] = md;
+        if (extrap) extrap[(int64_t)b * HW + o] = hole ? 1 : 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (merge_feats) merge_feats[((int64_t)b * 3 + c) * HW + o] = merged[c];
+            if (x_out) x_out[((int64_t)b * 4 + c) * HW + o] = merged[c];
+        }
+        if (x_out) x_out[((int64_t)b * 4 + 3) * HW + o] = normalise_depth(md, hole, dataset_norm);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // inverse_warping: one lane per target pixel, sources visited in order with a running z-buffer on
 // |z_reprojected - src_depth(at the TARGET pixel, sic)| (inference_pipeline.py:719-737).
@@ -400,6 +588,79 @@ extern "C" int sgam_forward_splat_srcs_f32(const float *const *src_feat_ptrs, co
     return forward_splat_launch(nullptr, nullptr, &tab, feat_cs, feat_ps, tgt_K, src_Kinv, T, B, N, H, W, depth_range,
                                 dataset_norm, winner, merge_depths, merge_feats, extrap, x_out, proj_feats, proj_depth,
                                 inb_mask, pix_xy, stream);
+}
+
+// ---- target-owned tiles (no global atomics): workspace = tgt [B][N][HW] int32 + bbox [B][N][bins] 8 bytes
+static inline int splat_bins_x(int W) { return (W + SBW - 1) / SBW; }
+static inline int splat_bins(int H, int W) { return splat_bins_x(W) * ((H + SBH - 1) / SBH); }
+
+extern "C" int64_t sgam_forward_splat_workspace_bytes(int32_t B, int32_t N, int32_t H, int32_t W) {
+    if (B <= 0 || N <= 0 || H <= 0 || W <= 0 || H > 32767 || W > 32767 || (int64_t)H * W * N >= (1ll << 31)) return -1;
+    const int64_t tgt = (int64_t)B * N * H * W * 4;
+    return ((tgt + 15) / 16) * 16 + (int64_t)B * N * splat_bins(H, W) * (int64_t)sizeof(SBox);
+}
+
+static int forward_splat_tiled_launch(const float *src_feats, const float *src_depths, const SrcTable *tab, int64_t feat_cs,
+                                      int64_t feat_ps, const float *tgt_K, const float *src_Kinv, const float *T, int32_t B, int32_t N,
+                                      int32_t H, int32_t W, const float *depth_range, int32_t dataset_norm, void *workspace,
+                                      int64_t workspace_bytes, float *merge_depths, float *merge_feats, uint8_t *extrap, float *x_out,
+                                      float *proj_feats, float *proj_depth, void *stream) {
+    if (!tgt_K || !src_Kinv || !T || !workspace) return SGAM_EINVAL;
+    const int64_t need = sgam_forward_splat_workspace_bytes(B, N, H, W);
+    if (need < 0) return SGAM_EINVAL;
+    if (workspace_bytes < need || !sgam_aligned16(workspace)) return SGAM_EWORKSPACE;
+    if (x_out && dataset_norm != 1 && dataset_norm != 2) return SGAM_EINVAL;
+    hipStream_t s = sgam_stream(stream);
+    const int bins_x = splat_bins_x(W), nbins = splat_bins(H, W);
+    int *tgt = (int *)workspace;
+    SBox *bbox = (SBox *)((char *)workspace + (((int64_t)B * N * H * W * 4 + 15) / 16) * 16);
+    const float r0 = depth_range ? depth_range[0] : 0.f, r1 = depth_range ? depth_range[1] : 0.f;
+    const int use_range = depth_range ? 1 : 0;
+    SrcTable none = {};
+    const dim3 g1(nbins, N, B);
+    if (sgam_i_prof_on) sgam_i_prof_work(0.0, (double)B * H * W * (8.0 * N));
+    if (tab) SGAM_KLAUNCH(splat_project_kernel<true>, g1, dim3(256), 0, s, src_depths, *tab, tgt_K, src_Kinv, T, N, H, W, bins_x, nbins, tgt, bbox);
+    else SGAM_KLAUNCH(splat_project_kernel<false>, g1, dim3(256), 0, s, src_depths, none, tgt_K, src_Kinv, T, N, H, W, bins_x, nbins, tgt, bbox);
+    SGAM_LAUNCH_CHECK();
+    // 32 x 32 tiles when they still give every CU a workgroup, 16 x 16 tiles (more redundancy in the bin scan, 4 x the workgroups) below
+    const int64_t wg32 = (int64_t)B * sgam_cdiv(W, 32) * sgam_cdiv(H, 32);
+    if (sgam_i_prof_on) sgam_i_prof_work(0.0, (double)B * H * W * (4.0 * N + 33.0));
+#define SPLAT_TILE(TT_, TAB_)                                                                                                      \
+    SGAM_KLAUNCH((splat_tile_kernel<TT_, TAB_>), dim3(sgam_cdiv(W, TT_), sgam_cdiv(H, TT_), B), dim3(256), 0, s, src_feats, feat_cs,  \
+                 feat_ps, src_depths, TAB_ ? *tab : none, src_Kinv, T, tgt, bbox, N, H, W, bins_x, nbins, r0, r1, use_range,            \
+                 dataset_norm, merge_depths, merge_feats, extrap, x_out, proj_feats, proj_depth)
+    if (wg32 >= 256) {
+        if (tab) SPLAT_TILE(32, true); else SPLAT_TILE(32, false);
+    } else {
+        if (tab) SPLAT_TILE(16, true); else SPLAT_TILE(16, false);
+    }
+#undef SPLAT_TILE
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+extern "C" int sgam_forward_splat_tiled_f32(const float *src_feats, int64_t feat_cs, int64_t feat_ps, const float *src_depths,
+                                            const float *tgt_K, const float *src_Kinv, const float *T, int32_t B, int32_t N,
+                                            int32_t H, int32_t W, const float *depth_range, int32_t dataset_norm, void *workspace,
+                                            int64_t workspace_bytes, float *merge_depths, float *merge_feats, uint8_t *extrap,
+                                            float *x_out, float *proj_feats, float *proj_depth, void *stream) {
+    if (!src_feats || !src_depths) return SGAM_EINVAL;
+    return forward_splat_tiled_launch(src_feats, src_depths, nullptr, feat_cs, feat_ps, tgt_K, src_Kinv, T, B, N, H, W, depth_range,
+                                      dataset_norm, workspace, workspace_bytes, merge_depths, merge_feats, extrap, x_out, proj_feats,
+                                      proj_depth, stream);
+}
+
+extern "C" int sgam_forward_splat_tiled_srcs_f32(const float *const *src_feat_ptrs, const float *const *src_depth_ptrs,
+                                                 int64_t feat_cs, int64_t feat_ps, const float *tgt_K, const float *src_Kinv,
+                                                 const float *T, int32_t B, int32_t N, int32_t H, int32_t W, const float *depth_range,
+                                                 int32_t dataset_norm, void *workspace, int64_t workspace_bytes, float *merge_depths,
+                                                 float *merge_feats, uint8_t *extrap, float *x_out, float *proj_feats,
+                                                 float *proj_depth, void *stream) {
+    SrcTable tab;
+    if (B <= 0 || N <= 0 || !fill_table(tab, src_feat_ptrs, src_depth_ptrs, B * N)) return SGAM_EINVAL;
+    return forward_splat_tiled_launch(nullptr, nullptr, &tab, feat_cs, feat_ps, tgt_K, src_Kinv, T, B, N, H, W, depth_range,
+                                      dataset_norm, workspace, workspace_bytes, merge_depths, merge_feats, extrap, x_out, proj_feats,
+                                      proj_depth, stream);
 }
 
 extern "C" int sgam_inverse_warp_f32(const float *src_imgs, const float *src_depths, const float *tgt_depth,

@@ -831,6 +831,28 @@ def vq_topk(dist, k):
 # ------------------------------------------------------------------------------------------------
 # warps and frame feedback
 # ------------------------------------------------------------------------------------------------
+SPLAT_TILED = os.environ.get("SGAM_SPLAT_TILED", "1") != "0"     # target-owned LDS z-tiles (csrc/warp.hip); 0: the two-pass global-atomic form
+_SPLAT_WS = {}
+
+
+def _splat_workspace(dev, B, N, H, W, out=None):
+    """scratch of the tiled splat (cached target pixels + bin boxes): the caller's persistent `out["splat_ws"]` when it
+    gives one, else one buffer per (device, shape) — contents are irrelevant between calls"""
+    nb = _lib.load().sgam_forward_splat_workspace_bytes(B, N, H, W)
+    if nb < 0:
+        return None, 0
+    if out is not None and "splat_ws" in out and out["splat_ws"].numel() >= nb:
+        return out["splat_ws"], nb
+    key = (str(dev), B, N, H, W)
+    if key not in _SPLAT_WS:
+        if len(_SPLAT_WS) > 16:
+            _SPLAT_WS.clear()
+        _SPLAT_WS[key] = torch.empty((nb,), device=dev, dtype=torch.uint8)
+    if out is not None:
+        out["splat_ws"] = _SPLAT_WS[key]
+    return _SPLAT_WS[key], nb
+
+
 def forward_splat(src_feats, src_depths, tgt_K, src_Kinv, T, *, channels_last=False, depth_range=None,
                   dataset=None, want=("merge_depths", "merge_feats", "extrap"), extrap_bool=False):
     """Forward splat + median fill + mask (+ normalised x).  src_feats (B,N,3,H,W) or, with
@@ -854,7 +876,6 @@ def forward_splat(src_feats, src_depths, tgt_K, src_Kinv, T, *, channels_last=Fa
     if "proj_depth" in want: o["proj_depth"] = mk((B, 1, H, W))
     if "inb_mask" in want: o["inb_mask"] = mk((B * HW * N,), torch.uint8)
     if "pix_xy" in want: o["pix_xy"] = mk((B * HW * N, 2), torch.int32)
-    winner = mk((B, HW), torch.int32)
     dr = None
     if depth_range is not None:
         dr = (ctypes.c_float * 2)(float(depth_range[0]), float(depth_range[1]))
@@ -865,6 +886,14 @@ def forward_splat(src_feats, src_depths, tgt_K, src_Kinv, T, *, channels_last=Fa
     # `_p(_f32c(t))` is freed right after `_p` returns, and the caching allocator may hand its block to the NEXT
     # temporary, whose copy kernel then lands before ours on the same stream
     kt, kinv, tt = _f32c(tgt_K), _f32c(src_Kinv), _f32c(T)
+    ws, nb = _splat_workspace(dev, B, N, H, W) if (SPLAT_TILED and "inb_mask" not in want and "pix_xy" not in want) else (None, 0)
+    if ws is not None:
+        check(_lib.load().sgam_forward_splat_tiled_f32(
+            _p(f), cs, ps, _p(d), _p(kt), _p(kinv), _p(tt), B, N, H, W, dr, norm, _p(ws), nb,
+            _p(o.get("merge_depths")), _p(o.get("merge_feats")), _p(o.get("extrap")), _p(o.get("x")),
+            _p(o.get("proj_feats")), _p(o.get("proj_depth")), _stream()), "sgam_forward_splat_tiled_f32")
+        return o
+    winner = mk((B, HW), torch.int32)
     check(_lib.load().sgam_forward_splat_f32(
         _p(f), cs, ps, _p(d), _p(kt), _p(kinv), _p(tt), B, N, H, W, dr, norm, _p(winner),
         _p(o.get("merge_depths")), _p(o.get("merge_feats")), _p(o.get("extrap")), _p(o.get("x")),
@@ -899,7 +928,6 @@ def forward_splat_srcs(src_feats, src_depths, tgt_K, src_Kinv, T, *, B=1, depth_
     if "merge_feats" in want: o["merge_feats"] = mk("merge_feats", (B, 3, H, W))
     if "extrap" in want: o["extrap"] = mk("extrap", (B, 1, H, W), torch.bool if extrap_bool else torch.uint8)
     if "x" in want: o["x"] = mk("x", (B, 4, H, W))
-    winner = mk("winner", (B, HW), torch.int32)
     dr = None
     if depth_range is not None:
         dr = (ctypes.c_float * 2)(float(depth_range[0]), float(depth_range[1]))
@@ -907,6 +935,14 @@ def forward_splat_srcs(src_feats, src_depths, tgt_K, src_Kinv, T, *, B=1, depth_
     if "x" in want and norm == 0:
         raise NotImplementedError(f"dataset {dataset!r}")
     kt, kinv, tt = _f32c(tgt_K), _f32c(src_Kinv), _f32c(T)       # locals keep any contiguous copy alive until enqueued
+    ws, nb = _splat_workspace(dev, B, N, H, W, out) if SPLAT_TILED else (None, 0)
+    if ws is not None:
+        check(_lib.load().sgam_forward_splat_tiled_srcs_f32(
+            _ptr_table(src_feats), _ptr_table(src_depths), 1, 3, _p(kt), _p(kinv), _p(tt), B, N, H, W, dr, norm, _p(ws), nb,
+            _p(o.get("merge_depths")), _p(o.get("merge_feats")), _p(o.get("extrap")), _p(o.get("x")), None, None, _stream()),
+            "sgam_forward_splat_tiled_srcs_f32")
+        return o
+    winner = mk("winner", (B, HW), torch.int32)
     check(_lib.load().sgam_forward_splat_srcs_f32(
         _ptr_table(src_feats), _ptr_table(src_depths), 1, 3, _p(kt), _p(kinv), _p(tt), B, N, H, W, dr, norm, _p(winner),
         _p(o.get("merge_depths")), _p(o.get("merge_feats")), _p(o.get("extrap")), _p(o.get("x")), None, None, None, None,

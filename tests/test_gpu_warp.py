@@ -93,6 +93,69 @@ def test_full_size_splat_properties():
     assert int(r["extrap"].sum()) == 0
 
 
+def _both_paths(fn):
+    """run fn() with the tiled (LDS z-tile, no global atomics) and the two-pass (global atomicMax) splat; returns both results"""
+    old = ops.SPLAT_TILED
+    try:
+        ops.SPLAT_TILED = True
+        a = fn()
+        ops.SPLAT_TILED = False
+        b = fn()
+    finally:
+        ops.SPLAT_TILED = old
+    return a, b
+
+
+@pytest.mark.parametrize("case", testing.SPLAT_CASES, ids=lambda c: c[0])
+def test_tiled_splat_matches_reference_goldens(golden, case):
+    """the target-owned-tile splat (ABI v6) against the REFERENCE's outputs: merged depth / features, mask and the pre-fill
+    planes bit for bit, for every golden case (1..5 sources, B = 2, non-square 48 x 80, bad depths, depth_range branch)"""
+    tag, seed, B, N, H, W, rs, dr, bad = case
+    g = golden(f"splat_{tag}.npz")
+    f, d, Ks, T = testing.synth_warp_inputs(seed, B, N, H, W, rs, bad)
+    Kinv = torch.inverse(torch.from_numpy(Ks).reshape(-1, 3, 3)).to(DEV)
+    want = ("merge_depths", "merge_feats", "extrap", "proj_feats", "proj_depth")
+    a, b = _both_paths(lambda: ops.forward_splat(t(f), t(d), t(Ks[:, 0]), Kinv, t(T).reshape(-1, 4, 4), depth_range=dr, want=want))
+    assert bits_equal(a["merge_depths"].cpu().numpy(), g["merge_depths"]) and bits_equal(a["merge_feats"].cpu().numpy(), g["merge_feats"])
+    assert np.array_equal(a["extrap"].cpu().numpy().astype(bool), g["extrapolation_mask"].astype(bool))
+    for k in want:
+        assert torch.equal(a[k].view(torch.uint8), b[k].view(torch.uint8)), k
+
+
+@pytest.mark.parametrize("B,N,H,W,rot", [(1, 3, 256, 256, 0.02), (4, 2, 512, 512, 0.05), (2, 5, 100, 72, 0.3), (16, 3, 256, 256, 0.02),
+                                         (1, 1, 40, 24, 1.0), (3, 4, 136, 264, 0.6)])
+def test_tiled_splat_equals_two_pass_splat(B, N, H, W, rot):
+    """any geometry — gentle scene-loop motion, wild rotations that scatter a source bin over the whole image, ragged sizes,
+    16 x 16 and 32 x 32 tiles — through the pointer-table entry point the scene loop uses: bit-identical to the two-pass form
+    (itself pinned to the reference), run twice (no state survives in the workspace)"""
+    f, d, Ks, T = testing.synth_warp_inputs(101 + B + N, B, N, H, W, rot, True)
+    feats = [t(f[b, n].transpose(1, 2, 0)) for b in range(B) for n in range(N)]
+    depths = [t(d[b, n]) for b in range(B) for n in range(N)]
+    Kinv = torch.inverse(torch.from_numpy(Ks).reshape(-1, 3, 3)).to(DEV)
+    fn = lambda: ops.forward_splat_srcs(feats, depths, t(Ks[:, 0]), Kinv, t(T).reshape(-1, 4, 4), B=B, dataset="google_earth",  # noqa: E731
+                                        want=("x", "extrap", "merge_depths", "merge_feats"))
+    a, b = _both_paths(fn)
+    a2, _ = _both_paths(fn)
+    for k in ("x", "extrap", "merge_depths", "merge_feats"):
+        assert torch.equal(a[k].view(torch.uint8), b[k].view(torch.uint8)), k
+        assert torch.equal(a[k].view(torch.uint8), a2[k].view(torch.uint8)), k
+    o = OW.forward_splat(f, d, Ks[:, 0], Ks, T)
+    assert bits_equal(a["merge_feats"].cpu().numpy(), o["merge_feats"]) and bits_equal(a["merge_depths"].cpu().numpy(), o["merge_depths"])
+
+
+def test_tiled_splat_workspace_contract():
+    lib = ops._lib.load()
+    assert lib.sgam_forward_splat_workspace_bytes(1, 3, 256, 256) == 3 * 65536 * 4 + 3 * 8 * 32 * 8
+    assert lib.sgam_forward_splat_workspace_bytes(1, 1, 40000, 8) == -1          # H beyond the 16-bit packed target pixel
+    f, d, Ks, T = testing.synth_warp_inputs(5, 1, 2, 64, 64, 0.05, False)
+    Kinv = torch.inverse(torch.from_numpy(Ks).reshape(-1, 3, 3)).to(DEV)
+    ws = torch.empty((1024,), device=DEV, dtype=torch.uint8)
+    out = torch.empty((1, 1, 64, 64), device=DEV)
+    rc = lib.sgam_forward_splat_tiled_f32(ops._p(t(f)), 64 * 64, 1, ops._p(t(d)), ops._p(t(Ks[:, 0])), ops._p(Kinv), ops._p(t(T)), 1, 2, 64, 64,
+                                          None, 0, ops._p(ws), 1024, ops._p(out), None, None, None, None, None, None)
+    assert rc == -3                                                                # SGAM_EWORKSPACE: too small
+
+
 @pytest.mark.parametrize("case", testing.INVWARP_CASES, ids=lambda c: c[0])
 def test_inverse_warp_bit_exact(golden, case):
     tag, seed, N, H, W, s, bad = case
