@@ -502,6 +502,18 @@ int sgam_tsdf_raycast_depth_f32(const sgam_tsdf_grid *grid, int32_t H, int32_t W
                                 const float *brick_tsdf, float *depth_out, const float *brick_color, float *color_out,
                                 void *stream);
 
+/* (ABI v6) Zero-crossing point extraction from the fused bricks: `volume.extract_point_cloud()` of the reference's run tail
+ * (sgam/inference_pipeline.py:446-450 -> rgbd_integrated_mesh.ply), Open3D's published ScalableTSDFVolume::ExtractPointCloud
+ * rule: per observed voxel with |tsdf| < 0.98 and each +x / +y / +z neighbour (same test) with the opposite sign, one point on
+ * the edge at the |tsdf|-weighted position; colour weighted the same way (0..255, needs brick_color); normal = normalised
+ * central difference of the trilinear field, one voxel each way.
+ *   counter: device uint64, zero on entry; holds the number of points FOUND on return (a first call with points = NULL only
+ *   counts).  points / normals / colors [max_points][3] fp32, keys [max_points] int64 = ((unit slot * 4096 + voxel) * 3 + axis)
+ *   — the points arrive in no particular order, sorting by key gives a run-independent one.  Parity unpinned vs Open3D. */
+int sgam_tsdf_extract_points_f32(const sgam_tsdf_grid *grid, const int32_t *unit_table, const float *brick_tsdf,
+                                 const float *brick_color, uint64_t *counter, int64_t max_points, float *points,
+                                 float *normals, float *colors, int64_t *keys, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * f4 — backward / optimiser kernels of the training step: VQModel.training_step
  * (sgam/generative_sensing_module/model.py:271-345) with VQLPIPSWithDiscriminator.forward(optimizer_idx = 0)

@@ -66,6 +66,7 @@ PROTOTYPES = {
                                         c_f32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "sgam_tsdf_raycast_depth_f32": (c_i32, [ctypes.POINTER(TsdfGrid), c_i32, c_i32, c_f32, c_f32, c_f32, c_f32, c_vp, c_f32,
                                             c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "sgam_tsdf_extract_points_f32": (c_i32, [ctypes.POINTER(TsdfGrid), c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "sgam_gemm_gn_f32x_fits": (c_i32, [c_i32, c_i32, c_i32, c_i32]),
     "sgam_gemm_panel_f32x": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32,
                                      c_i32, c_vp]),

@@ -339,6 +339,80 @@ int grid_ok(const sgam_tsdf_grid *g) {
     return ((int64_t)g->unit_dims[0] * g->unit_dims[1] * g->unit_dims[2]) < (1ll << 31);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Zero-crossing point extraction from the bricks: the `volume.extract_point_cloud()` the reference writes to
+// rgbd_integrated_mesh.ply at the end of a run (sgam/inference_pipeline.py:446-450).  Open3D's published rule
+// (ScalableTSDFVolume::ExtractPointCloud): for every observed voxel with |tsdf| < 0.98 and each of its +x / +y / +z
+// neighbours (same test), a sign change between the two puts ONE point on the edge, linearly interpolated by the two
+// |tsdf| values; colour interpolated the same way; the normal is the normalised central difference of the TSDF field at the
+// point (one voxel each way, through the ray cast's sampler).  One workgroup per opened unit (grid-stride over the unit
+// table), one atomic per point for its slot in the output; `key` = ((unit slot * 4096 + voxel) * 3 + axis) lets the host put
+// the points in a run-independent order.  Parity: unpinned against Open3D (absent), held against the independent dense
+// float64 reference (oracle/tsdf_dense.py) in tests/test_gpu_tsdf.py.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tsdf_extract_kernel(TsdfGrid g, int64_t n_units, const int *__restrict__ table,
+                                                           const float *__restrict__ tsdf, const float *__restrict__ color,
+                                                           unsigned long long *__restrict__ counter, int64_t max_points,
+                                                           float *__restrict__ points, float *__restrict__ normals,
+                                                           float *__restrict__ colors, int64_t *__restrict__ keys) {
+    const float inv_voxel = __fdiv_rn(1.0f, g.voxel);
+    for (int64_t slot = blockIdx.x; slot < n_units; slot += gridDim.x) {
+        const int entry = table[slot];
+        if (entry < 0 || !(entry & NEAR_BIT)) continue;              // unopened, or no voxel inside the truncation band
+        const int brick = entry & BRICK_MASK;
+        const int ux = (int)(slot % g.dims[0]) + g.base[0], uy = (int)((slot / g.dims[0]) % g.dims[1]) + g.base[1],
+                  uz = (int)(slot / ((int64_t)g.dims[0] * g.dims[1])) + g.base[2];
+        for (int q = threadIdx.x; q < UV; q += 256) {
+            const float f0 = tsdf[(int64_t)brick * UV + q];
+            if (!(f0 < 0.98f && f0 >= -0.98f)) continue;             // (unobserved voxels hold the sentinel 2.0)
+            const int ix = ux * UR + (q & 15), iy = uy * UR + ((q >> 4) & 15), iz = uz * UR + (q >> 8);
+            const float p0[3] = {__fmul_rn((float)ix + 0.5f, g.voxel), __fmul_rn((float)iy + 0.5f, g.voxel),
+                                 __fmul_rn((float)iz + 0.5f, g.voxel)};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const int jx = ix + (a == 0), jy = iy + (a == 1), jz = iz + (a == 2);
+                float f1;
+                if (!lattice(g, table, tsdf, jx, jy, jz, f1)) continue;
+                if (!(f1 < 0.98f && f1 >= -0.98f) || !(f0 * f1 < 0.f)) continue;
+                const float r0 = fabsf(f0), r1 = fabsf(f1), den = __fadd_rn(r0, r1);
+                float p[3] = {p0[0], p0[1], p0[2]};
+                p[a] = __fdiv_rn(__fadd_rn(__fmul_rn(p0[a], r1), __fmul_rn(__fadd_rn(p0[a], g.voxel), r0)), den);
+                const unsigned long long at = atomicAdd(counter, 1ull);
+                if ((int64_t)at >= max_points || !points) continue;  // counting pass / caller's buffer exhausted
+                points[at * 3 + 0] = p[0];
+                points[at * 3 + 1] = p[1];
+                points[at * 3 + 2] = p[2];
+                if (keys) keys[at] = (slot * UV + q) * 3 + a;
+                if (colors && color) {
+                    const int64_t s1 = unit_slot(g, jx >> 4, jy >> 4, jz >> 4);
+                    const int b1 = table[s1] & BRICK_MASK;
+                    const int q1 = ((jz & 15) << 8) | ((jy & 15) << 4) | (jx & 15);
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        const float c0 = color[((int64_t)brick * UV + q) * 3 + ch], c1 = color[((int64_t)b1 * UV + q1) * 3 + ch];
+                        colors[at * 3 + ch] = __fdiv_rn(__fadd_rn(__fmul_rn(c0, r1), __fmul_rn(c1, r0)), den);
+                    }
+                }
+                if (normals) {
+                    float n[3];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        float pa[3] = {p[0], p[1], p[2]}, pb[3] = {p[0], p[1], p[2]};
+                        pa[r] = __fadd_rn(p[r], g.voxel);
+                        pb[r] = __fsub_rn(p[r], g.voxel);
+                        float va, vb;
+                        const bool oa = sample(g, table, tsdf, pa, inv_voxel, va), ob = sample(g, table, tsdf, pb, inv_voxel, vb);
+                        n[r] = (oa && ob) ? __fsub_rn(va, vb) : 0.f;
+                    }
+                    const float len = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(n[0], n[0]), __fmul_rn(n[1], n[1])), __fmul_rn(n[2], n[2])));
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) normals[at * 3 + r] = len > 0.f ? __fdiv_rn(n[r], len) : 0.f;
+                }
+            }
+        }
+    }
+}
+
 TsdfGrid to_dev(const sgam_tsdf_grid *g) {
     TsdfGrid d;
     d.voxel = g->voxel_length;
@@ -397,6 +471,21 @@ extern "C" int sgam_tsdf_raycast_depth_f32(const sgam_tsdf_grid *grid, int32_t H
     for (int i = 0; i < 16; ++i) c2w.m[i] = cam2world[i];
     SGAM_KLAUNCH(tsdf_raycast_kernel, dim3(sgam_cdiv((int64_t)H * W * RS, 256)), dim3(256), 0, sgam_stream(stream), H, W, fx, fy,
                        cx, cy, c2w, g, z_near, z_far, unit_table, brick_tsdf, depth_out, brick_color, color_out);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+extern "C" int sgam_tsdf_extract_points_f32(const sgam_tsdf_grid *grid, const int32_t *unit_table, const float *brick_tsdf,
+                                            const float *brick_color, uint64_t *counter, int64_t max_points, float *points,
+                                            float *normals, float *colors, int64_t *keys, void *stream) {
+    if (!grid_ok(grid) || !unit_table || !brick_tsdf || !counter || max_points < 0) return SGAM_EINVAL;
+    if (!points && (normals || colors || keys)) return SGAM_EINVAL;           // counting pass: no outputs at all
+    if (colors && !brick_color) return SGAM_EINVAL;
+    const TsdfGrid g = to_dev(grid);
+    const int64_t n_units = (int64_t)g.dims[0] * g.dims[1] * g.dims[2];
+    const int blocks = (int)(n_units < 4096 ? n_units : 4096);
+    SGAM_KLAUNCH(tsdf_extract_kernel, dim3(blocks), dim3(256), 0, sgam_stream(stream), g, n_units, unit_table, brick_tsdf, brick_color,
+                 (unsigned long long *)counter, max_points, points, normals, colors, keys);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
 }

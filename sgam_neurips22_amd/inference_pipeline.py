@@ -462,6 +462,31 @@ class InfiniteSceneGeneration:
             np.save(os.path.join(out_dir, f"t_{fr['index']:05d}{suffix}.npy"), node["t"])
             np.save(os.path.join(out_dir, f"dm_{fr['index']:05d}{suffix}.npy"), fr["depth"].cpu().numpy())
             Image.fromarray(fr["rgb_u8"].cpu().numpy()).save(os.path.join(out_dir, f"im_{fr['index']:05d}{suffix}.png"))
+        return self.export_point_clouds(out_dir)
+
+
+    def export_point_clouds(self, out_dir):
+        """the two artefacts the reference's scene_expansion leaves behind the frames (inference_pipeline.py:441-450):
+        `merged_pcds.ply` — every stored frame unprojected with its own depth, colour and pose, merged in the order of the
+        frame index (the reference globs its R_<index>_*.npy files sorted: the same order) — and, on the rgbd_integration
+        branch, `rgbd_integrated_mesh.ply` — the zero-crossing points of the fused volume (extracted on the device).  Returns
+        {file name: number of points}."""
+        from . import pointcloud
+        os.makedirs(out_dir, exist_ok=True)
+        pts, cols = [], []
+        for (i, j), fr in sorted(self.frames.items(), key=lambda kv: (kv[1]["index"], kv[0])):
+            node = self.transform_grid[i][j]
+            Rt = np.eye(4)
+            Rt[:3, :3], Rt[:3, 3] = node["R"], np.asarray(node["t"]).reshape(3)
+            p, c = pointcloud.unproject_frame(fr["depth"].cpu().numpy(), fr["rgb_u8"].cpu().numpy(), self.K, Rt)
+            pts.append(p)
+            cols.append(c)
+        out = {"merged_pcds.ply": pointcloud.write_ply(os.path.join(out_dir, "merged_pcds.ply"), np.concatenate(pts), np.concatenate(cols))}
+        if self.use_rgbd_integration and self.volume is not None:
+            pc = self.volume.extract_point_cloud()
+            out["rgbd_integrated_mesh.ply"] = pointcloud.write_ply(os.path.join(out_dir, "rgbd_integrated_mesh.ply"), pc["points"],
+                                                                   pc.get("colors"), pc["normals"])
+        return out
 
 
 def step_unit(step, k):

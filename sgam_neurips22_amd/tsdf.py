@@ -107,6 +107,32 @@ class TsdfVolume:
             "sgam_tsdf_raycast_depth_f32")
         return (out, col) if want_color else out
 
+    def extract_point_cloud(self):
+        """`volume.extract_point_cloud()` of the reference's run tail (inference_pipeline.py:446-450): the zero crossings of the
+        fused TSDF as points (float32 (n,3) world coordinates), normals (n,3) and — when colour was fused — colours (n,3) in
+        0..1, in a run-independent order (sorted by (unit, voxel, axis)).  Two launches (count, then fill) and one host sync:
+        an export step after the run, not part of the loop."""
+        lib = _lib.load()
+        counter = torch.zeros((1,), dtype=torch.int64, device=self.device)
+        check(lib.sgam_tsdf_extract_points_f32(ctypes.byref(self.grid), ops._p(self.unit_table), ops._p(self.brick_tsdf), None,
+                                               ops._p(counter), 0, None, None, None, None, ops._stream()), "sgam_tsdf_extract_points_f32")
+        n = int(counter.item())
+        pts = torch.empty((max(n, 1), 3), dtype=torch.float32, device=self.device)
+        nrm = torch.empty_like(pts)
+        col = torch.empty_like(pts) if self.brick_color is not None else None
+        keys = torch.empty((max(n, 1),), dtype=torch.int64, device=self.device)
+        counter.zero_()
+        check(lib.sgam_tsdf_extract_points_f32(ctypes.byref(self.grid), ops._p(self.unit_table), ops._p(self.brick_tsdf),
+                                               ops._p(self.brick_color), ops._p(counter), n, ops._p(pts), ops._p(nrm), ops._p(col),
+                                               ops._p(keys), ops._stream()), "sgam_tsdf_extract_points_f32")
+        if int(counter.item()) != n:
+            raise ops.SgamHipError("TSDF point extraction: the volume changed between the counting and the filling pass")
+        order = torch.argsort(keys[:n])
+        out = {"points": pts[:n][order].cpu().numpy(), "normals": nrm[:n][order].cpu().numpy(), "keys": keys[:n][order].cpu().numpy()}
+        if col is not None:
+            out["colors"] = (col[:n][order] / 255.0).cpu().numpy()
+        return out
+
     def stats(self):
         """(bricks allocated, last frame's brick count, samples outside the box, pool overflows) — host sync."""
         return tuple(int(v) for v in self.counters.cpu())
