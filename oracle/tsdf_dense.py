@@ -103,3 +103,31 @@ class DenseTsdf:
         idx = np.where(okc[..., None], idx, 0)
         col = np.where(okc[..., None], self.color[idx[..., 2], idx[..., 1], idx[..., 0]], 0.0)
         return depth, col
+
+    def extract_points(self):
+        """zero-crossing points of the dense field by Open3D's published ExtractPointCloud rule (per observed voxel with
+        |tsdf| < 0.98 and each +x / +y / +z neighbour passing the same test with the opposite sign: one point on the edge at
+        the |tsdf|-weighted position, colour weighted the same way), in float64.  Returns dict(points (n,3), colors (n,3) in
+        0..255, voxel (n,3) global voxel index of the edge's first end, axis (n,))."""
+        t, w = self.tsdf, self.weight
+        ok = (w > 0) & (t < 0.98) & (t >= -0.98)
+        X, Y, Z = self.centres()
+        cen = [np.broadcast_to(X, t.shape), np.broadcast_to(Y, t.shape), np.broadcast_to(Z, t.shape)]
+        pts, cols, vox, axes = [], [], [], []
+        for a in range(3):                      # axis 0 = x = last array dimension
+            dim = 2 - a
+            s0 = [slice(None)] * 3
+            s1 = [slice(None)] * 3
+            s0[dim], s1[dim] = slice(0, -1), slice(1, None)
+            s0, s1 = tuple(s0), tuple(s1)
+            f0, f1 = t[s0], t[s1]
+            hit = ok[s0] & ok[s1] & (f0 * f1 < 0)
+            zi, yi, xi = np.nonzero(hit)
+            r0, r1 = np.abs(f0[hit]), np.abs(f1[hit])
+            p = np.stack([cen[0][s0][hit], cen[1][s0][hit], cen[2][s0][hit]], 1)
+            p[:, a] = (p[:, a] * r1 + (p[:, a] + self.voxel) * r0) / (r0 + r1)
+            pts.append(p)
+            cols.append((self.color[s0][hit] * r1[:, None] + self.color[s1][hit] * r0[:, None]) / (r0 + r1)[:, None])
+            vox.append(np.stack([xi, yi, zi], 1) + self.i0)
+            axes.append(np.full(len(zi), a))
+        return {"points": np.concatenate(pts), "colors": np.concatenate(cols), "voxel": np.concatenate(vox), "axis": np.concatenate(axes)}

@@ -39,6 +39,9 @@
 #ifndef SGAM_HGN_MAXC
 #define SGAM_HGN_MAXC 1024  // most input channels the fused GroupNorm takes (its per-channel scale / shift table lives in LDS)
 #endif
+#ifndef SGAM_HSB
+#define SGAM_HSB 1         // scheduling barriers in the slab body: 0 none, 1 in front of the staging arithmetic of tap 1, 2 at every tap
+#endif
 #ifndef SGAM_HABLATE
 #define SGAM_HABLATE 0     // timing experiments only (results are wrong when != 0): 1 no MFMAs, 2 no epilogue, 4 no main loop,
                            // 8 no weight-fragment loads in the loop, 16 no halo staging in the loop, 32 stores dropped
@@ -382,7 +385,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
                 // (the barrier keeps the scheduler from hoisting the staging arithmetic to the head of the slab body, in front of
                 // this iteration's first loads: the wait it then needs counts loads across the loop's back edge and comes out as
                 // vmcnt(0) — the whole vector-memory queue drained at the top of every slab)
-                if (tap == 1) __builtin_amdgcn_sched_barrier(0);
+                if (SGAM_HSB == 2 || (SGAM_HSB == 1 && tap == 1)) __builtin_amdgcn_sched_barrier(0);
                 if (tap >= 1 && tap <= NH) hprep_piece(tap - 1);            // next slab's halo, one piece per tap
                 if (tap == NH + 1) {
                     hstore(hcur ^ 1);

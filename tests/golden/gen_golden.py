@@ -521,8 +521,41 @@ def gen_trajectory_clevr():
     save("trajectory_clevr.npz", zmean=full["zmean"], zstd=full["zstd"], cb_seed=full["cb_seed"], **final)
 
 
+def pcd_inputs():
+    """seeded inputs of the per-view unprojection fixture (shared with tests/test_pointcloud_cpu.py through the .npz)"""
+    rs = np.random.RandomState(77)
+    h, w = 20, 24
+    depth = rs.uniform(1.4, 3.4, (h, w)).astype(np.float32)
+    color = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
+    K = np.array([[497.77774 * w / 512, 0, w / 2], [0, 497.77774 * h / 512, h / 2], [0, 0, 1]])
+    a = 0.3
+    R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]]) @ np.array([[1, 0, 0], [0, np.cos(0.1), -np.sin(0.1)], [0, np.sin(0.1), np.cos(0.1)]])
+    Rt = np.eye(4)
+    Rt[:3, :3], Rt[:3, 3] = R, [0.2, -0.1, 0.35]
+    return depth, color, K, Rt
+
+
+def gen_pcd():
+    """the reference's own `prepare_pcd` (inference_pipeline.py:1014-1039), run with a two-attribute stand-in for the Open3D
+    container it fills (PointCloud.points / .colors, Vector3dVector = the array itself): pins the float64 unprojection that
+    `merged_pcds.ply` is made of"""
+    print("per-view unprojection (prepare_pcd)")
+    import types
+    import sgam.inference_pipeline as ref_ip
+
+    class _PC:
+        points = colors = None
+    ref_ip.o3d.geometry = types.SimpleNamespace(PointCloud=_PC)
+    ref_ip.o3d.utility = types.SimpleNamespace(Vector3dVector=lambda a: np.asarray(a))
+    depth, color, K, Rt = pcd_inputs()
+    pcd = InfiniteSceneGeneration.prepare_pcd(None, depth, color, K, Rt)
+    save("prepare_pcd.npz", depth=depth, color=color, K=K, Rt=Rt, points=np.asarray(pcd.points), colors=np.asarray(pcd.colors))
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
+    if not only or "pcd" in only:
+        gen_pcd()
     rgb0, dm0 = gen_splat() if (not only or "splat" in only or "traj" in only) else (None, None)
     if not only or "inv" in only:
         gen_invwarp()
