@@ -269,24 +269,28 @@ def warp_roofline(dev, reps=8):
 
         def splat():
             ops.forward_splat_srcs(feats, depths, K, Kinv, Td, B=B, dataset=DATASET, want=("x", "extrap"), extrap_bool=True, out=bufs)
-        splat()
-        recs, br = ops.kernel_timeline(lambda: [splat() for _ in range(reps)])
-        per = {}
-        for name, ms, *_ in recs:
-            per[name.split("<")[0]] = per.get(name.split("<")[0], 0.0) + max(ms - br, 0.0)
-        us = {k: round(1e3 * v / reps, 2) for k, v in per.items()}
+
+        def timed(tiled):
+            old_mode, ops.SPLAT_TILED = ops.SPLAT_TILED, tiled
+            try:
+                splat()
+                recs, br = ops.kernel_timeline(lambda: [splat() for _ in range(reps)])
+            finally:
+                ops.SPLAT_TILED = old_mode
+            per = {}
+            for name, ms, *_ in recs:
+                per[name.split("<")[0]] = per.get(name.split("<")[0], 0.0) + max(ms - br, 0.0)
+            return {k: round(1e3 * v / reps, 2) for k, v in per.items()}
+        # both forms: target-owned LDS z-tiles (no global atomics) and the two-pass device-scope atomicMax form (whose winner-buffer
+        # memset the timeline does not see); `us` is the one ops.forward_splat_srcs picks for this size
+        us_tiled, us_two = timed(True), timed(False)
+        picked_tiled = ops.SPLAT_TILED if ops.SPLAT_TILED is not None else (B * N * res * res >= ops.SPLAT_TILED_MIN_POINTS)
+        us = us_tiled if picked_tiled else us_two
         tot_us = sum(us.values())
         nbytes = res * res * (16 * N + 17) * B
-        # the round-3 form (device-scope atomicMax per point into a winner buffer + its memset, which the timeline does not see)
-        old_mode, ops.SPLAT_TILED = ops.SPLAT_TILED, False
-        try:
-            splat()
-            recs2, br2 = ops.kernel_timeline(lambda: [splat() for _ in range(reps)])
-        finally:
-            ops.SPLAT_TILED = old_mode
-        two_pass_us = round(1e3 * sum(max(ms - br2, 0.0) for _n, ms, *_ in recs2) / reps, 2)
         out["cases"][tag] = {"B": B, "N": N, "H": res, "W": res, "algorithmic_bytes": nbytes, "us": round(tot_us, 2), "kernels_us": us,
-                             "two_pass_global_atomics_us": two_pass_us,
+                             "form": "tiled" if picked_tiled else "two_pass",
+                             "tiled_us": round(sum(us_tiled.values()), 2), "two_pass_global_atomics_us": round(sum(us_two.values()), 2),
                              "achieved": round(nbytes / tot_us / 1e3, 1), "frac": round(nbytes / tot_us / 1e3 / HBM_PEAK_GBS, 4),
                              "frac_of_achievable": round(nbytes / tot_us / 1e3 / HBM_ACHIEVABLE_GBS, 4)}
         # inverse warp at the same geometry (target depth = the first source's depth: any finite depth does for timing)

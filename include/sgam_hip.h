@@ -398,14 +398,17 @@ int sgam_forward_splat_srcs_f32(const float *const *src_feat_ptrs, const float *
                                 float *proj_feats, float *proj_depth, uint8_t *inb_mask, int32_t *pix_xy, void *stream);
 
 /* (ABI v6) The same forward splat WITHOUT global atomics — target-owned tiles with an LDS z-tile (csrc/warp.hip):
- * pass 1 caches every source point's target pixel and the bounding box of each 8 x 32 source bin, pass 2 gives a workgroup a
- * 32 x 32 (16 x 16 for small launches) tile of the target image + 1-pixel halo, resolves "largest point index wins"
- * (warp.py:217-262) with LDS atomicMax over the bins whose box meets the tile, and finishes median fill / merge / mask /
+ * pass 1 caches every source point's target pixel and registers each 8 x 32 source bin with the target tiles its bounding
+ * box meets, pass 2 gives a workgroup a 32 x 32 (16 x 16 for small launches) tile of the target image + 1-pixel halo, resolves
+ * "largest point index wins" (warp.py:217-262) with LDS atomicMax over the registered bins, and finishes median fill / merge / mask /
  * depth normalisation (warp.py:264-286, model.py:210-229) from LDS.  Results are bit-identical to sgam_forward_splat_f32
  * for any geometry; the by-products inb_mask / pix_xy are only offered by the two-pass form above.
- *   workspace: sgam_forward_splat_workspace_bytes(B, N, H, W) bytes, 16-byte aligned (the cached target pixels [B][N][HW]
- *   int32 + the bin boxes), contents irrelevant on entry (no memset); H, W <= 32767.  -1 from the query: shape refused. */
+ *   workspace: sgam_forward_splat_workspace_bytes(B, N, H, W) bytes, 16-byte aligned: per-tile counters, the cached target
+ *   pixels [B][N][HW] int32 and the per-tile lists of registered source bins.  Its first
+ *   sgam_forward_splat_workspace_zero_bytes(B, N, H, W) bytes (the counters) must be ZERO when the workspace is first used;
+ *   every call leaves them zero again (no memset per call).  H, W <= 32767, N <= 64.  -1 from the queries: shape refused. */
 int64_t sgam_forward_splat_workspace_bytes(int32_t B, int32_t N, int32_t H, int32_t W);
+int64_t sgam_forward_splat_workspace_zero_bytes(int32_t B, int32_t N, int32_t H, int32_t W);
 int sgam_forward_splat_tiled_f32(const float *src_feats, int64_t feat_cs, int64_t feat_ps, const float *src_depths,
                                  const float *tgt_K, const float *src_Kinv, const float *T, int32_t B, int32_t N, int32_t H,
                                  int32_t W, const float *depth_range, int32_t dataset_norm, void *workspace,

@@ -161,6 +161,7 @@ PROTOTYPES = {
                                             ctypes.POINTER(c_f32), c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                             c_vp, c_vp, c_vp]),
     "sgam_forward_splat_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32, c_i32]),
+    "sgam_forward_splat_workspace_zero_bytes": (c_i64, [c_i32, c_i32, c_i32, c_i32]),
     "sgam_forward_splat_tiled_f32": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,
                                              ctypes.POINTER(c_f32), c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "sgam_forward_splat_tiled_srcs_f32": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,

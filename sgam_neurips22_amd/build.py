@@ -28,7 +28,7 @@ SOURCES = {
     "h16_halo.hip": [f"-DSGAM_HABLATE={os.environ.get('SGAM_HABLATE', '0')}",
                      f"-DSGAM_HDIRECT={os.environ.get('SGAM_HDIRECT', '1')}",
                      f"-DSGAM_HWGM={os.environ.get('SGAM_HWGM', '1')}",
-                     f"-DSGAM_HSB={os.environ.get('SGAM_HSB', '1')}"],
+                     f"-DSGAM_HSB={os.environ.get('SGAM_HSB', '2')}"],
     "attention.hip": [f"-DSGAM_ATTN_ABLATE={os.environ.get('SGAM_ATTN_ABLATE', '0')}"],
     "vq.hip": ["-ffp-contract=off"],
     "layout.hip": ["-ffp-contract=off"],

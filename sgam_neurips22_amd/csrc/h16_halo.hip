@@ -40,7 +40,7 @@
 #define SGAM_HGN_MAXC 1024  // most input channels the fused GroupNorm takes (its per-channel scale / shift table lives in LDS)
 #endif
 #ifndef SGAM_HSB
-#define SGAM_HSB 1         // scheduling barriers in the slab body: 0 none, 1 in front of the staging arithmetic of tap 1, 2 at every tap
+#define SGAM_HSB 2         // scheduling barriers in the slab body: 0 none, 1 in front of the staging arithmetic of tap 1, 2 at every tap
 #endif
 #ifndef SGAM_HABLATE
 #define SGAM_HABLATE 0     // timing experiments only (results are wrong when != 0): 1 no MFMAs, 2 no epilogue, 4 no main loop,

@@ -253,15 +253,17 @@ __global__ __launch_bounds__(TS *TS) void splat_resolve_kernel(
 // the re-read of x / y / z planes the reference materialises.
 // ------------------------------------------------------------------------------------------------
 constexpr int SBW = 32, SBH = 8;      // source bin: 8 rows x 32 pixels = 256 points, one per thread
-struct alignas(8) SBox {
-    short x0, y0, x1, y1;             // inclusive; empty: x0 > x1
-};
+typedef short s16x2 __attribute__((ext_vector_type(2)));
 
+// pass 1.  Besides the cached target pixels, every bin REGISTERS itself with the target tiles its bounding box (grown by the
+// 1-pixel halo) meets: tile_list[b][tile][slot], slot from one atomicAdd on tile_cnt[b][tile] — a handful of device-scope
+// atomics per 256 points instead of 256, and pass 2 needs no search.  The counters are zero on entry (pass 2 leaves them so).
 template <bool TAB>
 __global__ __launch_bounds__(256) void splat_project_kernel(const float *__restrict__ src_depths, SrcTable tab,
                                                             const float *__restrict__ tgt_K, const float *__restrict__ src_Kinv,
                                                             const float *__restrict__ T, int N, int H, int W, int bins_x, int nbins,
-                                                            int *__restrict__ tgt, SBox *__restrict__ bbox) {
+                                                            int tt, int tiles_x, int tiles, int *__restrict__ tgt,
+                                                            int *__restrict__ tile_cnt, int *__restrict__ tile_list) {
     const int bin = blockIdx.x, s = blockIdx.y, b = blockIdx.z;
     const int bn = b * N + s, HW = H * W;
     const int by = bin / bins_x, bxx = bin - by * bins_x;
@@ -279,99 +281,138 @@ __global__ __launch_bounds__(256) void splat_project_kernel(const float *__restr
         inb = project_pixel(c, X, Y, Z, H, W, px, py);
         tgt[(int64_t)bn * HW + pix] = inb ? ((py << 16) | px) : -1;
     }
-    int x0 = inb ? px : 32767, y0 = inb ? py : 32767, x1 = inb ? px : -1, y1 = inb ? py : -1;
+    // bounding box of the bin's target pixels: packed 16-bit (x, y) pairs, min and max by v_pk_min_i16 / v_pk_max_i16
+    s16x2 lo = {(short)(inb ? px : 32767), (short)(inb ? py : 32767)}, hi = {(short)(inb ? px : -1), (short)(inb ? py : -1)};
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
-        x0 = min(x0, __shfl_xor(x0, o, 64));
-        y0 = min(y0, __shfl_xor(y0, o, 64));
-        x1 = max(x1, __shfl_xor(x1, o, 64));
-        y1 = max(y1, __shfl_xor(y1, o, 64));
+        lo = __builtin_elementwise_min(lo, __builtin_bit_cast(s16x2, __shfl_xor(__builtin_bit_cast(int, lo), o, 64)));
+        hi = __builtin_elementwise_max(hi, __builtin_bit_cast(s16x2, __shfl_xor(__builtin_bit_cast(int, hi), o, 64)));
     }
-    __shared__ int red[4][4];
+    __shared__ int red[4][2];
     if ((threadIdx.x & 63) == 0) {
-        red[threadIdx.x >> 6][0] = x0; red[threadIdx.x >> 6][1] = y0; red[threadIdx.x >> 6][2] = x1; red[threadIdx.x >> 6][3] = y1;
+        red[threadIdx.x >> 6][0] = __builtin_bit_cast(int, lo);
+        red[threadIdx.x >> 6][1] = __builtin_bit_cast(int, hi);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        SBox o;
-        o.x0 = (short)min(min(red[0][0], red[1][0]), min(red[2][0], red[3][0]));
-        o.y0 = (short)min(min(red[0][1], red[1][1]), min(red[2][1], red[3][1]));
-        o.x1 = (short)max(max(red[0][2], red[1][2]), max(red[2][2], red[3][2]));
-        o.y1 = (short)max(max(red[0][3], red[1][3]), max(red[2][3], red[3][3]));
-        bbox[(int64_t)bn * nbins + bin] = o;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        lo = __builtin_elementwise_min(lo, __builtin_bit_cast(s16x2, red[w][0]));
+        hi = __builtin_elementwise_max(hi, __builtin_bit_cast(s16x2, red[w][1]));
+    }
+    if (lo[0] > hi[0]) return;                       // no point of this bin lands in the image
+    // tiles met by the box grown by one pixel (a tile also needs the winners of its halo)
+    const int tx0 = max(lo[0] - 1, 0) / tt, tx1 = min(hi[0] + 1, W - 1) / tt, ty0 = max(lo[1] - 1, 0) / tt, ty1 = min(hi[1] + 1, H - 1) / tt;
+    const int nx = tx1 - tx0 + 1, cnt = nx * (ty1 - ty0 + 1);
+    const int64_t cap = (int64_t)N * nbins;
+    for (int k = threadIdx.x; k < cnt; k += 256) {
+        const int tile = (ty0 + k / nx) * tiles_x + tx0 + k % nx;
+        const int slot = atomicAdd(&tile_cnt[b * tiles + tile], 1);
+        tile_list[((int64_t)b * tiles + tile) * cap + slot] = s * nbins + bin;
     }
 }
 
+// pass 2: one workgroup per TT x TT target tile (+ 1-pixel halo): LDS z-tile over the registered bins, then the resolve
 template <int TT, bool TAB>
 __global__ __launch_bounds__(256) void splat_tile_kernel(
     const float *__restrict__ src_feats, int64_t feat_cs, int64_t feat_ps, const float *__restrict__ src_depths, SrcTable tab,
-    const float *__restrict__ src_Kinv, const float *__restrict__ T, const int *__restrict__ tgt, const SBox *__restrict__ bbox, int N,
-    int H, int W, int bins_x, int nbins, float r0, float r1, int use_range, int dataset_norm, float *__restrict__ merge_depths,
-    float *__restrict__ merge_feats, uint8_t *__restrict__ extrap, float *__restrict__ x_out, float *__restrict__ proj_feats,
-    float *__restrict__ proj_depth) {
+    const float *__restrict__ src_Kinv, const float *__restrict__ T, const int *__restrict__ tgt, int *__restrict__ tile_cnt,
+    const int *__restrict__ tile_list, int N, int H, int W, int bins_x, int nbins, float r0, float r1, int use_range, int dataset_norm,
+    float *__restrict__ merge_depths, float *__restrict__ merge_feats, uint8_t *__restrict__ extrap, float *__restrict__ x_out,
+    float *__restrict__ proj_feats, float *__restrict__ proj_depth) {
     constexpr int TE = TT + 2;                       // tile edge with the 1-pixel halo
+    constexpr int CPT = (TE * TE + 255) / 256;       // halo-tile cells per thread
     __shared__ int win[TE * TE];
     __shared__ float tile[4][TE][TE + 1];
-    __shared__ int list[256];
-    __shared__ int cnt;
+    __shared__ float camz[SGAM_MAX_SRCS][13];        // per source: Kinv (9) and row 2 of T (4): what a winner's camera-z needs
     const int b = blockIdx.z, HW = H * W;
     const int ty0 = blockIdx.y * TT, tx0 = blockIdx.x * TT;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles = gridDim.x * gridDim.y, tile_id = blockIdx.y * gridDim.x + blockIdx.x;
     for (int c = tid; c < TE * TE; c += 256) win[c] = -1;
-    // the tile with its halo, clipped to the image, in target pixels (inclusive)
-    const int ex0 = max(tx0 - 1, 0), ey0 = max(ty0 - 1, 0), ex1 = min(tx0 + TT, W - 1), ey1 = min(ty0 + TT, H - 1);
-    const int total = N * nbins;
-    const SBox *bb = bbox + (int64_t)b * total;
+    for (int c = tid; c < N * 13; c += 256) {
+        const int s = c / 13, k = c - s * 13, bn = b * N + s;
+        camz[s][k] = k < 9 ? src_Kinv[9 * bn + k] : T[16 * bn + 8 + (k - 9)];
+    }
+    const int n = tile_cnt[b * tiles + tile_id];
+    const int *list = tile_list + ((int64_t)b * tiles + tile_id) * ((int64_t)N * nbins);
     const int *tg = tgt + (int64_t)b * N * HW;
-    for (int base = 0; base < total; base += 256) {
-        if (tid == 0) cnt = 0;
-        __syncthreads();                             // (also: win[] initialised / the previous round's list consumed)
-        const int e = base + tid;
-        if (e < total) {
-            const SBox q = bb[e];
-            if (q.x0 <= ex1 && q.x1 >= ex0 && q.y0 <= ey1 && q.y1 >= ey0) list[atomicAdd(&cnt, 1)] = e;
-        }
-        __syncthreads();
-        const int n = cnt;
-        for (int k = 0; k < n; ++k) {
-            const int e2 = list[k];
-            const int s = e2 / nbins, bin = e2 - s * nbins;
+    __syncthreads();
+    if (tid == 0) tile_cnt[b * tiles + tile_id] = 0;     // ready for the next call (nobody else touches this counter now)
+    // wavefront w takes the registered bins w, w + 4, ...; a lane owns one column of the bin and four of its rows: the four
+    // cached target pixels are requested together, two bins per trip (eight loads in flight per lane)
+    const int col = lane & 31, row0 = (lane >> 5) * 4;
+    for (int k = wave; k < n; k += 8) {
+        int e[2], t[2][4], pixs[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) e[u] = (k + 4 * u) < n ? list[k + 4 * u] : -1;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int s = e[u] >= 0 ? e[u] / nbins : 0, bin = e[u] >= 0 ? e[u] - s * nbins : 0;
             const int by = bin / bins_x, bxx = bin - by * bins_x;
-            const int i = by * SBH + (tid >> 5), j = bxx * SBW + (tid & 31);
-            if (i < H && j < W) {
-                const int pix = i * W + j;
-                const int t = tg[(int64_t)s * HW + pix];
-                if (t >= 0) {
-                    const int lx = (t & 0xFFFF) - (tx0 - 1), ly = (t >> 16) - (ty0 - 1);
-                    if ((unsigned)lx < (unsigned)TE && (unsigned)ly < (unsigned)TE) atomicMax(&win[ly * TE + lx], pix * N + s);
-                }
+            const int j = bxx * SBW + col;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = by * SBH + row0 + r;
+                const bool ok = e[u] >= 0 && i < H && j < W;
+                pixs[u][r] = i * W + j;
+                t[u][r] = ok ? tg[(int64_t)s * HW + pixs[u][r]] : -1;
             }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int s = e[u] >= 0 ? e[u] / nbins : 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (t[u][r] >= 0) {
+                    const int lx = (t[u][r] & 0xFFFF) - (tx0 - 1), ly = (t[u][r] >> 16) - (ty0 - 1);
+                    if ((unsigned)lx < (unsigned)TE && (unsigned)ly < (unsigned)TE) atomicMax(&win[ly * TE + lx], pixs[u][r] * N + s);
+                }
         }
     }
     __syncthreads();
-    // (r, g, b, z) of every cell's winner; cells outside the image and empty cells are zero (splat_resolve_kernel)
-    for (int c = tid; c < TE * TE; c += 256) {
-        const int hy = c / TE, hx = c - hy * TE;
-        const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
-        float f0 = 0.f, f1 = 0.f, f2 = 0.f, z = 0.f;
-        const int wv = win[c];
-        if (wv >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-            const int pix = wv / N, s = wv - pix * N;
-            const int bn = b * N + s;
-            const float *fp = (TAB ? tab.feat[bn] : src_feats + (int64_t)bn * 3 * HW) + (int64_t)pix * feat_ps;
-            f0 = fp[0];
-            f1 = fp[feat_cs];
-            f2 = fp[2 * feat_cs];
-            Cam cm;
-            load_cam(cm, src_Kinv + 9 * bn, T + 16 * bn, src_Kinv);  // Kt unused here
-            const int i = pix / W, j = pix - i * W;
-            float X, Y;
-            to_target_cam(cm, (float)j, (float)i, TAB ? tab.depth[bn][pix] : src_depths[(int64_t)bn * HW + pix], X, Y, z);
+    // (r, g, b, z) of every cell's winner; cells outside the image and empty cells are zero.  All of a thread's gathers are
+    // requested before the first is used.
+    {
+        int wv[CPT];
+        float f0[CPT], f1[CPT], f2[CPT], sd[CPT];
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {
+            const int c = tid + 256 * q;
+            const int hy = c / TE, hx = c - hy * TE;
+            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+            wv[q] = (c < TE * TE && gy >= 0 && gy < H && gx >= 0 && gx < W) ? win[c] : -1;
+            f0[q] = f1[q] = f2[q] = sd[q] = 0.f;
+            if (wv[q] >= 0) {
+                const int pix = wv[q] / N, s = wv[q] - pix * N;
+                const int bn = b * N + s;
+                const float *fp = (TAB ? tab.feat[bn] : src_feats + (int64_t)bn * 3 * HW) + (int64_t)pix * feat_ps;
+                f0[q] = fp[0];
+                f1[q] = fp[feat_cs];
+                f2[q] = fp[2 * feat_cs];
+                sd[q] = TAB ? tab.depth[bn][pix] : src_depths[(int64_t)bn * HW + pix];
+            }
         }
-        tile[0][hy][hx] = f0;
-        tile[1][hy][hx] = f1;
-        tile[2][hy][hx] = f2;
-        tile[3][hy][hx] = z;
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {
+            const int c = tid + 256 * q;
+            if (c >= TE * TE) continue;
+            const int hy = c / TE, hx = c - hy * TE;
+            float z = 0.f;
+            if (wv[q] >= 0) {
+                const int pix = wv[q] / N, s = wv[q] - pix * N;
+                const int i = pix / W, j = pix - i * W;
+                // to_target_cam's Z, same expressions: cz.. = (Kinv row . (j, i, 1)) * depth, Z = (T row 2 . c) + T[2][3]
+                const float *cz = camz[s];
+                const float cx = __fmul_rn(dot3_fma(cz + 0, (float)j, (float)i, 1.0f), sd[q]);
+                const float cy = __fmul_rn(dot3_fma(cz + 3, (float)j, (float)i, 1.0f), sd[q]);
+                const float cc = __fmul_rn(dot3_fma(cz + 6, (float)j, (float)i, 1.0f), sd[q]);
+                z = __fadd_rn(dot3_fma(cz + 9, cx, cy, cc), cz[12]);
+            }
+            tile[0][hy][hx] = f0[q];
+            tile[1][hy][hx] = f1[q];
+            tile[2][hy][hx] = f2[q];
+            tile[3][hy][hx] = z;
+        }
     }
     __syncthreads();
     for (int q = tid; q < TT * TT; q += 256) {
@@ -590,14 +631,26 @@ extern "C" int sgam_forward_splat_srcs_f32(const float *const *src_feat_ptrs, co
                                 inb_mask, pix_xy, stream);
 }
 
-// ---- target-owned tiles (no global atomics): workspace = tgt [B][N][HW] int32 + bbox [B][N][bins] 8 bytes
+// ---- target-owned tiles: workspace = tile counters [B][tiles] int32 (ZERO on first use, left zero by every call) + tgt
+// [B][N][HW] int32 + tile lists [B][tiles][N * bins] int32, each part rounded up to 256 bytes
 static inline int splat_bins_x(int W) { return (W + SBW - 1) / SBW; }
 static inline int splat_bins(int H, int W) { return splat_bins_x(W) * ((H + SBH - 1) / SBH); }
+// 32 x 32 tiles when they still give every CU a workgroup, 16 x 16 tiles (4 x the workgroups) below
+static inline int splat_tt(int B, int H, int W) { return (int64_t)B * sgam_cdiv(W, 32) * sgam_cdiv(H, 32) >= 256 ? 32 : 16; }
+static inline int64_t splat_r256(int64_t v) { return (v + 255) / 256 * 256; }
 
 extern "C" int64_t sgam_forward_splat_workspace_bytes(int32_t B, int32_t N, int32_t H, int32_t W) {
-    if (B <= 0 || N <= 0 || H <= 0 || W <= 0 || H > 32767 || W > 32767 || (int64_t)H * W * N >= (1ll << 31)) return -1;
-    const int64_t tgt = (int64_t)B * N * H * W * 4;
-    return ((tgt + 15) / 16) * 16 + (int64_t)B * N * splat_bins(H, W) * (int64_t)sizeof(SBox);
+    if (B <= 0 || N <= 0 || N > SGAM_MAX_SRCS || H <= 0 || W <= 0 || H > 32767 || W > 32767 || (int64_t)H * W * N >= (1ll << 31)) return -1;
+    const int tt = splat_tt(B, H, W);
+    const int64_t tiles = (int64_t)sgam_cdiv(W, tt) * sgam_cdiv(H, tt);
+    return splat_r256(B * tiles * 4) + splat_r256((int64_t)B * N * H * W * 4) + splat_r256(B * tiles * (int64_t)N * splat_bins(H, W) * 4);
+}
+
+// bytes at the start of the workspace that must be zero when it is first used (the tile counters)
+extern "C" int64_t sgam_forward_splat_workspace_zero_bytes(int32_t B, int32_t N, int32_t H, int32_t W) {
+    if (sgam_forward_splat_workspace_bytes(B, N, H, W) < 0) return -1;
+    const int tt = splat_tt(B, H, W);
+    return splat_r256((int64_t)B * sgam_cdiv(W, tt) * sgam_cdiv(H, tt) * 4);
 }
 
 static int forward_splat_tiled_launch(const float *src_feats, const float *src_depths, const SrcTable *tab, int64_t feat_cs,
@@ -612,24 +665,24 @@ static int forward_splat_tiled_launch(const float *src_feats, const float *src_d
     if (x_out && dataset_norm != 1 && dataset_norm != 2) return SGAM_EINVAL;
     hipStream_t s = sgam_stream(stream);
     const int bins_x = splat_bins_x(W), nbins = splat_bins(H, W);
-    int *tgt = (int *)workspace;
-    SBox *bbox = (SBox *)((char *)workspace + (((int64_t)B * N * H * W * 4 + 15) / 16) * 16);
+    const int tt = splat_tt(B, H, W), tiles_x = sgam_cdiv(W, tt), tiles = tiles_x * sgam_cdiv(H, tt);
+    int *tile_cnt = (int *)workspace;
+    int *tgt = (int *)((char *)workspace + splat_r256((int64_t)B * tiles * 4));
+    int *tile_list = (int *)((char *)tgt + splat_r256((int64_t)B * N * H * W * 4));
     const float r0 = depth_range ? depth_range[0] : 0.f, r1 = depth_range ? depth_range[1] : 0.f;
     const int use_range = depth_range ? 1 : 0;
     SrcTable none = {};
     const dim3 g1(nbins, N, B);
     if (sgam_i_prof_on) sgam_i_prof_work(0.0, (double)B * H * W * (8.0 * N));
-    if (tab) SGAM_KLAUNCH(splat_project_kernel<true>, g1, dim3(256), 0, s, src_depths, *tab, tgt_K, src_Kinv, T, N, H, W, bins_x, nbins, tgt, bbox);
-    else SGAM_KLAUNCH(splat_project_kernel<false>, g1, dim3(256), 0, s, src_depths, none, tgt_K, src_Kinv, T, N, H, W, bins_x, nbins, tgt, bbox);
+    if (tab) SGAM_KLAUNCH(splat_project_kernel<true>, g1, dim3(256), 0, s, src_depths, *tab, tgt_K, src_Kinv, T, N, H, W, bins_x, nbins, tt, tiles_x, tiles, tgt, tile_cnt, tile_list);
+    else SGAM_KLAUNCH(splat_project_kernel<false>, g1, dim3(256), 0, s, src_depths, none, tgt_K, src_Kinv, T, N, H, W, bins_x, nbins, tt, tiles_x, tiles, tgt, tile_cnt, tile_list);
     SGAM_LAUNCH_CHECK();
-    // 32 x 32 tiles when they still give every CU a workgroup, 16 x 16 tiles (more redundancy in the bin scan, 4 x the workgroups) below
-    const int64_t wg32 = (int64_t)B * sgam_cdiv(W, 32) * sgam_cdiv(H, 32);
     if (sgam_i_prof_on) sgam_i_prof_work(0.0, (double)B * H * W * (4.0 * N + 33.0));
 #define SPLAT_TILE(TT_, TAB_)                                                                                                      \
     SGAM_KLAUNCH((splat_tile_kernel<TT_, TAB_>), dim3(sgam_cdiv(W, TT_), sgam_cdiv(H, TT_), B), dim3(256), 0, s, src_feats, feat_cs,  \
-                 feat_ps, src_depths, TAB_ ? *tab : none, src_Kinv, T, tgt, bbox, N, H, W, bins_x, nbins, r0, r1, use_range,            \
-                 dataset_norm, merge_depths, merge_feats, extrap, x_out, proj_feats, proj_depth)
-    if (wg32 >= 256) {
+                 feat_ps, src_depths, TAB_ ? *tab : none, src_Kinv, T, tgt, tile_cnt, tile_list, N, H, W, bins_x, nbins, r0, r1,       \
+                 use_range, dataset_norm, merge_depths, merge_feats, extrap, x_out, proj_feats, proj_depth)
+    if (tt == 32) {
         if (tab) SPLAT_TILE(32, true); else SPLAT_TILE(32, false);
     } else {
         if (tab) SPLAT_TILE(16, true); else SPLAT_TILE(16, false);

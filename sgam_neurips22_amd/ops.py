@@ -831,25 +831,28 @@ def vq_topk(dist, k):
 # ------------------------------------------------------------------------------------------------
 # warps and frame feedback
 # ------------------------------------------------------------------------------------------------
-SPLAT_TILED = os.environ.get("SGAM_SPLAT_TILED", "1") != "0"     # target-owned LDS z-tiles (csrc/warp.hip); 0: the two-pass global-atomic form
+# which forward splat runs: True = target-owned LDS z-tiles (no global atomics), False = the two-pass device-scope atomicMax form,
+# None (default, SGAM_SPLAT_TILED unset / "auto") = by size: the tiled form from SPLAT_TILED_MIN_POINTS source points on — below
+# it a launch is latency-bound and the two forms cost the same few microseconds
+SPLAT_TILED = {"0": False, "1": True}.get(os.environ.get("SGAM_SPLAT_TILED", "auto"))
+SPLAT_TILED_MIN_POINTS = int(os.environ.get("SGAM_SPLAT_TILED_MIN_POINTS", 1 << 20))
 _SPLAT_WS = {}
 
 
 def _splat_workspace(dev, B, N, H, W, out=None):
-    """scratch of the tiled splat (cached target pixels + bin boxes): the caller's persistent `out["splat_ws"]` when it
-    gives one, else one buffer per (device, shape) — contents are irrelevant between calls"""
+    """scratch of the tiled splat (tile counters, cached target pixels, per-tile bin lists), zero-filled ONCE at allocation
+    (the kernels leave the counters zero): one buffer per (device, shape), cached; (None, 0) when the two-pass form is to run"""
+    use = SPLAT_TILED if SPLAT_TILED is not None else (B * N * H * W >= SPLAT_TILED_MIN_POINTS)
+    if not use:
+        return None, 0
     nb = _lib.load().sgam_forward_splat_workspace_bytes(B, N, H, W)
     if nb < 0:
         return None, 0
-    if out is not None and "splat_ws" in out and out["splat_ws"].numel() >= nb:
-        return out["splat_ws"], nb
     key = (str(dev), B, N, H, W)
     if key not in _SPLAT_WS:
         if len(_SPLAT_WS) > 16:
             _SPLAT_WS.clear()
-        _SPLAT_WS[key] = torch.empty((nb,), device=dev, dtype=torch.uint8)
-    if out is not None:
-        out["splat_ws"] = _SPLAT_WS[key]
+        _SPLAT_WS[key] = torch.zeros((nb,), device=dev, dtype=torch.uint8)
     return _SPLAT_WS[key], nb
 
 
@@ -886,7 +889,7 @@ def forward_splat(src_feats, src_depths, tgt_K, src_Kinv, T, *, channels_last=Fa
     # `_p(_f32c(t))` is freed right after `_p` returns, and the caching allocator may hand its block to the NEXT
     # temporary, whose copy kernel then lands before ours on the same stream
     kt, kinv, tt = _f32c(tgt_K), _f32c(src_Kinv), _f32c(T)
-    ws, nb = _splat_workspace(dev, B, N, H, W) if (SPLAT_TILED and "inb_mask" not in want and "pix_xy" not in want) else (None, 0)
+    ws, nb = _splat_workspace(dev, B, N, H, W) if ("inb_mask" not in want and "pix_xy" not in want) else (None, 0)
     if ws is not None:
         check(_lib.load().sgam_forward_splat_tiled_f32(
             _p(f), cs, ps, _p(d), _p(kt), _p(kinv), _p(tt), B, N, H, W, dr, norm, _p(ws), nb,
@@ -935,7 +938,7 @@ def forward_splat_srcs(src_feats, src_depths, tgt_K, src_Kinv, T, *, B=1, depth_
     if "x" in want and norm == 0:
         raise NotImplementedError(f"dataset {dataset!r}")
     kt, kinv, tt = _f32c(tgt_K), _f32c(src_Kinv), _f32c(T)       # locals keep any contiguous copy alive until enqueued
-    ws, nb = _splat_workspace(dev, B, N, H, W, out) if SPLAT_TILED else (None, 0)
+    ws, nb = _splat_workspace(dev, B, N, H, W, out)
     if ws is not None:
         check(_lib.load().sgam_forward_splat_tiled_srcs_f32(
             _ptr_table(src_feats), _ptr_table(src_depths), 1, 3, _p(kt), _p(kinv), _p(tt), B, N, H, W, dr, norm, _p(ws), nb,

@@ -145,11 +145,14 @@ def test_tiled_splat_equals_two_pass_splat(B, N, H, W, rot):
 
 def test_tiled_splat_workspace_contract():
     lib = ops._lib.load()
-    assert lib.sgam_forward_splat_workspace_bytes(1, 3, 256, 256) == 3 * 65536 * 4 + 3 * 8 * 32 * 8
+    # counters [tiles] + cached target pixels [N][HW] + per-tile bin lists [tiles][N * bins], 16 x 16 tiles below 256 workgroups
+    assert lib.sgam_forward_splat_workspace_bytes(1, 3, 256, 256) == 256 * 4 + 3 * 65536 * 4 + 256 * 3 * 256 * 4
+    assert lib.sgam_forward_splat_workspace_zero_bytes(1, 3, 256, 256) == 1024
+    assert lib.sgam_forward_splat_workspace_bytes(1, 65, 64, 64) == -1                 # more sources than the pointer table holds
     assert lib.sgam_forward_splat_workspace_bytes(1, 1, 40000, 8) == -1          # H beyond the 16-bit packed target pixel
     f, d, Ks, T = testing.synth_warp_inputs(5, 1, 2, 64, 64, 0.05, False)
     Kinv = torch.inverse(torch.from_numpy(Ks).reshape(-1, 3, 3)).to(DEV)
-    ws = torch.empty((1024,), device=DEV, dtype=torch.uint8)
+    ws = torch.zeros((1024,), device=DEV, dtype=torch.uint8)
     out = torch.empty((1, 1, 64, 64), device=DEV)
     rc = lib.sgam_forward_splat_tiled_f32(ops._p(t(f)), 64 * 64, 1, ops._p(t(d)), ops._p(t(Ks[:, 0])), ops._p(Kinv), ops._p(t(T)), 1, 2, 64, 64,
                                           None, 0, ops._p(ws), 1024, ops._p(out), None, None, None, None, None, None)
