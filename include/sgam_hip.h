@@ -403,10 +403,10 @@ int sgam_forward_splat_srcs_f32(const float *const *src_feat_ptrs, const float *
  * "largest point index wins" (warp.py:217-262) with LDS atomicMax over the registered bins, and finishes median fill / merge / mask /
  * depth normalisation (warp.py:264-286, model.py:210-229) from LDS.  Results are bit-identical to sgam_forward_splat_f32
  * for any geometry; the by-products inb_mask / pix_xy are only offered by the two-pass form above.
- *   workspace: sgam_forward_splat_workspace_bytes(B, N, H, W) bytes, 16-byte aligned: per-tile counters, the cached target
- *   pixels [B][N][HW] int32 and the per-tile lists of registered source bins.  Its first
- *   sgam_forward_splat_workspace_zero_bytes(B, N, H, W) bytes (the counters) must be ZERO when the workspace is first used;
- *   every call leaves them zero again (no memset per call).  H, W <= 32767, N <= 64.  -1 from the queries: shape refused. */
+ *   workspace: sgam_forward_splat_workspace_bytes(B, N, H, W) bytes, 16-byte aligned: the per-tile bitmaps of registered
+ *   source bins, then the cached target pixels [B][N][HW] int32.  Its first sgam_forward_splat_workspace_zero_bytes(B, N, H, W)
+ *   bytes (the bitmaps) must be ZERO when the workspace is first used; every call leaves them zero again (no memset per
+ *   call).  H, W <= 32767, N <= 64.  -1 from the queries: shape refused. */
 int64_t sgam_forward_splat_workspace_bytes(int32_t B, int32_t N, int32_t H, int32_t W);
 int64_t sgam_forward_splat_workspace_zero_bytes(int32_t B, int32_t N, int32_t H, int32_t W);
 int sgam_forward_splat_tiled_f32(const float *src_feats, int64_t feat_cs, int64_t feat_ps, const float *src_depths,

@@ -239,75 +239,78 @@ __global__ __launch_bounds__(TS *TS) void splat_resolve_kernel(
 // coherent scatter — 12.6 M points (512 x 512, B = 16, N = 3) take 190 us + the buffer's memset, against 22 us for the same
 // scatter as plain stores and 37 us for the design below (scripts/micro/atomic_splat.hip); issuing them at workgroup scope
 // from the XCD that owns a band of the buffer changes nothing (same instruction, same place of execution).  So:
-//   pass 1  splat_project_kernel: one lane per source point, in bins of 8 rows x 32 pixels (whole 128-byte lines of the depth
-//           map): target pixel of the point -> tgt[b][s][pix] = (py << 16 | px), -1 when out of bounds; the bounding box of
-//           the bin's target pixels -> bbox[b][s][bin] (4 x int16).  4 N bytes read + 4 N written per pixel, no atomics.
-//   pass 2  splat_tile_kernel<TT>: a workgroup OWNS a TT x TT tile of the target image plus its 1-pixel halo.  It scans the
-//           bounding boxes of all N x bins source bins (8 bytes each), and for every bin whose box meets the tile it reads the
-//           bin's cached target pixels and resolves "largest linear point index p = pix * N + s wins" (warp.py:217-218 and
-//           the oracle's sequential loop) with LDS atomicMax — integer max: order-independent, deterministic — on its own
-//           (TT + 2)^2 z-tile.  Exact for ANY geometry (the boxes are exact, not estimates): a wild warp only makes more
-//           bins meet a tile.  Then, still in LDS: (r, g, b, z) of every winner, the four 3 x 3 medians, the `== 0` merge, the
-//           mask and the inverse-depth normalisation, outputs written once (the arithmetic is splat_resolve_kernel's).
+//   pass 1  splat_project_kernel: source points in bins of 8 rows x 32 pixels (whole 128-byte lines of the depth map), one
+//           wavefront per bin: target pixel of every point -> tgt[b][s][pix] = (py << 16 | px), -1 when out of bounds; and
+//           the bin sets its bit in the bitmap of every target tile its bounding box meets (fire-and-forget atomicOr: a
+//           handful per 256 points).  4 N bytes read + 4 N written per pixel.
+//   pass 2  splat_tile_kernel<TT>: a workgroup OWNS a TT x TT tile of the target image plus its 1-pixel halo.  It reads (and
+//           clears) its bitmap, and for every registered bin reads the bin's cached target pixels and resolves "largest linear
+//           point index p = pix * N + s wins" (warp.py:217-218 and the oracle's sequential loop) with LDS atomicMax — integer
+//           max: order-independent, deterministic — on its own (TT + 2)^2 z-tile.  Exact for ANY geometry (the boxes are
+//           exact, not estimates): a wild warp only makes more bins register with a tile.  Then, still in LDS: (r, g, b, z)
+//           of every winner, the four 3 x 3 medians, the `== 0` merge, the mask and the inverse-depth normalisation, outputs
+//           written once (the arithmetic is splat_resolve_kernel's).
 // HBM bytes per target pixel: 12 N + 33 against the algorithmic 16 N + 17 — the cached target pixel replaces
 // the re-read of x / y / z planes the reference materialises.
 // ------------------------------------------------------------------------------------------------
 constexpr int SBW = 32, SBH = 8;      // source bin: 8 rows x 32 pixels = 256 points, one per thread
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 
-// pass 1.  Besides the cached target pixels, every bin REGISTERS itself with the target tiles its bounding box (grown by the
-// 1-pixel halo) meets: tile_list[b][tile][slot], slot from one atomicAdd on tile_cnt[b][tile] — a handful of device-scope
-// atomics per 256 points instead of 256, and pass 2 needs no search.  The counters are zero on entry (pass 2 leaves them so).
+// pass 1.  A WAVEFRONT owns a bin (lane = one column, four rows: four independent projections in flight per lane, the
+// bin's bounding box by a wave reduction — no LDS, no barrier).  Besides the cached target pixels, every bin REGISTERS itself with
+// the target tiles its bounding box (grown by the 1-pixel halo) meets: one bit per (source, bin) in the tile's bitmap, set with an
+// atomicOr WITHOUT return value — a handful of fire-and-forget atomics per 256 points (a first version appended to per-tile lists
+// through atomicAdd and waited a device-scope round trip per bin: 88 us for 12.6 M points against 60 without registration).
+// The bitmaps are zero on entry; pass 2 clears what it reads.
 template <bool TAB>
 __global__ __launch_bounds__(256) void splat_project_kernel(const float *__restrict__ src_depths, SrcTable tab,
                                                             const float *__restrict__ tgt_K, const float *__restrict__ src_Kinv,
                                                             const float *__restrict__ T, int N, int H, int W, int bins_x, int nbins,
-                                                            int tt, int tiles_x, int tiles, int *__restrict__ tgt,
-                                                            int *__restrict__ tile_cnt, int *__restrict__ tile_list) {
-    const int bin = blockIdx.x, s = blockIdx.y, b = blockIdx.z;
+                                                            int tt, int tiles_x, int tiles, int words, int *__restrict__ tgt,
+                                                            unsigned *__restrict__ tile_bits) {
+    const int lane = threadIdx.x & 63;
+    const int bin = blockIdx.x * 4 + (threadIdx.x >> 6), s = blockIdx.y, b = blockIdx.z;
+    if (bin >= nbins) return;
     const int bn = b * N + s, HW = H * W;
     const int by = bin / bins_x, bxx = bin - by * bins_x;
-    const int i = by * SBH + (threadIdx.x >> 5), j = bxx * SBW + (threadIdx.x & 31);
-    const bool valid = i < H && j < W;
-    int px = 0, py = 0;
-    bool inb = false;
-    if (valid) {
-        Cam c;
-        load_cam(c, src_Kinv + 9 * bn, T + 16 * bn, tgt_K + 9 * b);
-        const int pix = i * W + j;
-        const float sd = TAB ? tab.depth[bn][pix] : src_depths[(int64_t)bn * HW + pix];
+    const int j = bxx * SBW + (lane & 31), i0 = by * SBH + (lane >> 5) * 4;
+    Cam c;
+    load_cam(c, src_Kinv + 9 * bn, T + 16 * bn, tgt_K + 9 * b);
+    float sd[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const bool valid = (i0 + r) < H && j < W;
+        const int pix = (i0 + r) * W + j;
+        sd[r] = valid ? (TAB ? tab.depth[bn][pix] : src_depths[(int64_t)bn * HW + pix]) : 0.f;
+    }
+    s16x2 lo = {32767, 32767}, hi = {-1, -1};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const bool valid = (i0 + r) < H && j < W;
         float X, Y, Z;
-        to_target_cam(c, (float)j, (float)i, sd, X, Y, Z);
-        inb = project_pixel(c, X, Y, Z, H, W, px, py);
-        tgt[(int64_t)bn * HW + pix] = inb ? ((py << 16) | px) : -1;
+        to_target_cam(c, (float)j, (float)(i0 + r), sd[r], X, Y, Z);
+        int px = 0, py = 0;
+        const bool inb = valid && project_pixel(c, X, Y, Z, H, W, px, py);
+        if (valid) tgt[(int64_t)bn * HW + (i0 + r) * W + j] = inb ? ((py << 16) | px) : -1;
+        if (inb) {
+            lo = __builtin_elementwise_min(lo, s16x2{(short)px, (short)py});
+            hi = __builtin_elementwise_max(hi, s16x2{(short)px, (short)py});
+        }
     }
     // bounding box of the bin's target pixels: packed 16-bit (x, y) pairs, min and max by v_pk_min_i16 / v_pk_max_i16
-    s16x2 lo = {(short)(inb ? px : 32767), (short)(inb ? py : 32767)}, hi = {(short)(inb ? px : -1), (short)(inb ? py : -1)};
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
         lo = __builtin_elementwise_min(lo, __builtin_bit_cast(s16x2, __shfl_xor(__builtin_bit_cast(int, lo), o, 64)));
         hi = __builtin_elementwise_max(hi, __builtin_bit_cast(s16x2, __shfl_xor(__builtin_bit_cast(int, hi), o, 64)));
     }
-    __shared__ int red[4][2];
-    if ((threadIdx.x & 63) == 0) {
-        red[threadIdx.x >> 6][0] = __builtin_bit_cast(int, lo);
-        red[threadIdx.x >> 6][1] = __builtin_bit_cast(int, hi);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        lo = __builtin_elementwise_min(lo, __builtin_bit_cast(s16x2, red[w][0]));
-        hi = __builtin_elementwise_max(hi, __builtin_bit_cast(s16x2, red[w][1]));
-    }
     if (lo[0] > hi[0]) return;                       // no point of this bin lands in the image
     // tiles met by the box grown by one pixel (a tile also needs the winners of its halo)
     const int tx0 = max(lo[0] - 1, 0) / tt, tx1 = min(hi[0] + 1, W - 1) / tt, ty0 = max(lo[1] - 1, 0) / tt, ty1 = min(hi[1] + 1, H - 1) / tt;
     const int nx = tx1 - tx0 + 1, cnt = nx * (ty1 - ty0 + 1);
-    const int64_t cap = (int64_t)N * nbins;
-    for (int k = threadIdx.x; k < cnt; k += 256) {
+    const int e = s * nbins + bin;
+    for (int k = lane; k < cnt; k += 64) {
         const int tile = (ty0 + k / nx) * tiles_x + tx0 + k % nx;
-        const int slot = atomicAdd(&tile_cnt[b * tiles + tile], 1);
-        tile_list[((int64_t)b * tiles + tile) * cap + slot] = s * nbins + bin;
+        __hip_atomic_fetch_or(&tile_bits[((int64_t)b * tiles + tile) * words + (e >> 5)], 1u << (e & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -315,8 +318,8 @@ __global__ __launch_bounds__(256) void splat_project_kernel(const float *__restr
 template <int TT, bool TAB>
 __global__ __launch_bounds__(256) void splat_tile_kernel(
     const float *__restrict__ src_feats, int64_t feat_cs, int64_t feat_ps, const float *__restrict__ src_depths, SrcTable tab,
-    const float *__restrict__ src_Kinv, const float *__restrict__ T, const int *__restrict__ tgt, int *__restrict__ tile_cnt,
-    const int *__restrict__ tile_list, int N, int H, int W, int bins_x, int nbins, float r0, float r1, int use_range, int dataset_norm,
+    const float *__restrict__ src_Kinv, const float *__restrict__ T, const int *__restrict__ tgt, unsigned *__restrict__ tile_bits,
+    int words, int N, int H, int W, int bins_x, int nbins, float r0, float r1, int use_range, int dataset_norm,
     float *__restrict__ merge_depths, float *__restrict__ merge_feats, uint8_t *__restrict__ extrap, float *__restrict__ x_out,
     float *__restrict__ proj_feats, float *__restrict__ proj_depth) {
     constexpr int TE = TT + 2;                       // tile edge with the 1-pixel halo
@@ -324,6 +327,9 @@ __global__ __launch_bounds__(256) void splat_tile_kernel(
     __shared__ int win[TE * TE];
     __shared__ float tile[4][TE][TE + 1];
     __shared__ float camz[SGAM_MAX_SRCS][13];        // per source: Kinv (9) and row 2 of T (4): what a winner's camera-z needs
+    constexpr int CHW = 64;                          // bitmap words per round: at most 2048 registered bins in the list
+    __shared__ int list[CHW * 32];
+    __shared__ int cnt;
     const int b = blockIdx.z, HW = H * W;
     const int ty0 = blockIdx.y * TT, tx0 = blockIdx.x * TT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -333,41 +339,57 @@ __global__ __launch_bounds__(256) void splat_tile_kernel(
         const int s = c / 13, k = c - s * 13, bn = b * N + s;
         camz[s][k] = k < 9 ? src_Kinv[9 * bn + k] : T[16 * bn + 8 + (k - 9)];
     }
-    const int n = tile_cnt[b * tiles + tile_id];
-    const int *list = tile_list + ((int64_t)b * tiles + tile_id) * ((int64_t)N * nbins);
+    unsigned *bits = tile_bits + ((int64_t)b * tiles + tile_id) * words;
     const int *tg = tgt + (int64_t)b * N * HW;
-    __syncthreads();
-    if (tid == 0) tile_cnt[b * tiles + tile_id] = 0;     // ready for the next call (nobody else touches this counter now)
-    // wavefront w takes the registered bins w, w + 4, ...; a lane owns one column of the bin and four of its rows: the four
-    // cached target pixels are requested together, two bins per trip (eight loads in flight per lane)
     const int col = lane & 31, row0 = (lane >> 5) * 4;
-    for (int k = wave; k < n; k += 8) {
-        int e[2], t[2][4], pixs[2][4];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) e[u] = (k + 4 * u) < n ? list[k + 4 * u] : -1;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int s = e[u] >= 0 ? e[u] / nbins : 0, bin = e[u] >= 0 ? e[u] - s * nbins : 0;
-            const int by = bin / bins_x, bxx = bin - by * bins_x;
-            const int j = bxx * SBW + col;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = by * SBH + row0 + r;
-                const bool ok = e[u] >= 0 && i < H && j < W;
-                pixs[u][r] = i * W + j;
-                t[u][r] = ok ? tg[(int64_t)s * HW + pixs[u][r]] : -1;
+    for (int wbase = 0; wbase < words; wbase += CHW) {
+        if (tid == 0) cnt = 0;
+        __syncthreads();                             // (also: win[] / camz[] initialised, the previous round's list consumed)
+        if (tid < CHW && wbase + tid < words) {
+            unsigned m = bits[wbase + tid];
+            if (m) {
+                bits[wbase + tid] = 0u;              // ready for the next call (this tile's words are nobody else's now)
+                int at = atomicAdd(&cnt, __popc(m));
+                while (m) {
+                    const int bit = __ffs(m) - 1;
+                    m &= m - 1;
+                    list[at++] = (wbase + tid) * 32 + bit;
+                }
             }
         }
+        __syncthreads();
+        const int n = cnt;
+        // wavefront w takes the registered bins w, w + 4, ...; a lane owns one column of the bin and four of its rows: the four
+        // cached target pixels are requested together, two bins per trip (eight loads in flight per lane)
+        for (int k = wave; k < n; k += 8) {
+            int e[2], t[2][4], pixs[2][4];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int s = e[u] >= 0 ? e[u] / nbins : 0;
+            for (int u = 0; u < 2; ++u) e[u] = (k + 4 * u) < n ? list[k + 4 * u] : -1;
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (t[u][r] >= 0) {
-                    const int lx = (t[u][r] & 0xFFFF) - (tx0 - 1), ly = (t[u][r] >> 16) - (ty0 - 1);
-                    if ((unsigned)lx < (unsigned)TE && (unsigned)ly < (unsigned)TE) atomicMax(&win[ly * TE + lx], pixs[u][r] * N + s);
+            for (int u = 0; u < 2; ++u) {
+                const int s = e[u] >= 0 ? e[u] / nbins : 0, bin = e[u] >= 0 ? e[u] - s * nbins : 0;
+                const int by = bin / bins_x, bxx = bin - by * bins_x;
+                const int j = bxx * SBW + col;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = by * SBH + row0 + r;
+                    const bool ok = e[u] >= 0 && i < H && j < W;
+                    pixs[u][r] = i * W + j;
+                    t[u][r] = ok ? tg[(int64_t)s * HW + pixs[u][r]] : -1;
                 }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int s = e[u] >= 0 ? e[u] / nbins : 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (t[u][r] >= 0) {
+                        const int lx = (t[u][r] & 0xFFFF) - (tx0 - 1), ly = (t[u][r] >> 16) - (ty0 - 1);
+                        if ((unsigned)lx < (unsigned)TE && (unsigned)ly < (unsigned)TE) atomicMax(&win[ly * TE + lx], pixs[u][r] * N + s);
+                    }
+            }
         }
+        __syncthreads();                             // every wavefront has read this round's count and list
     }
     __syncthreads();
     // (r, g, b, z) of every cell's winner; cells outside the image and empty cells are zero.  All of a thread's gathers are
@@ -631,26 +653,24 @@ extern "C" int sgam_forward_splat_srcs_f32(const float *const *src_feat_ptrs, co
                                 inb_mask, pix_xy, stream);
 }
 
-// ---- target-owned tiles: workspace = tile counters [B][tiles] int32 (ZERO on first use, left zero by every call) + tgt
-// [B][N][HW] int32 + tile lists [B][tiles][N * bins] int32, each part rounded up to 256 bytes
+// ---- target-owned tiles: workspace = per-tile bitmaps of registered source bins [B][tiles][words] uint32 (ZERO on first use,
+// left zero by every call) + tgt [B][N][HW] int32, each part rounded up to 256 bytes
 static inline int splat_bins_x(int W) { return (W + SBW - 1) / SBW; }
 static inline int splat_bins(int H, int W) { return splat_bins_x(W) * ((H + SBH - 1) / SBH); }
 // 32 x 32 tiles when they still give every CU a workgroup, 16 x 16 tiles (4 x the workgroups) below
 static inline int splat_tt(int B, int H, int W) { return (int64_t)B * sgam_cdiv(W, 32) * sgam_cdiv(H, 32) >= 256 ? 32 : 16; }
 static inline int64_t splat_r256(int64_t v) { return (v + 255) / 256 * 256; }
+static inline int splat_words(int N, int H, int W) { return (N * splat_bins(H, W) + 31) / 32; }
 
-extern "C" int64_t sgam_forward_splat_workspace_bytes(int32_t B, int32_t N, int32_t H, int32_t W) {
+extern "C" int64_t sgam_forward_splat_workspace_zero_bytes(int32_t B, int32_t N, int32_t H, int32_t W) {
     if (B <= 0 || N <= 0 || N > SGAM_MAX_SRCS || H <= 0 || W <= 0 || H > 32767 || W > 32767 || (int64_t)H * W * N >= (1ll << 31)) return -1;
     const int tt = splat_tt(B, H, W);
-    const int64_t tiles = (int64_t)sgam_cdiv(W, tt) * sgam_cdiv(H, tt);
-    return splat_r256(B * tiles * 4) + splat_r256((int64_t)B * N * H * W * 4) + splat_r256(B * tiles * (int64_t)N * splat_bins(H, W) * 4);
+    return splat_r256((int64_t)B * sgam_cdiv(W, tt) * sgam_cdiv(H, tt) * splat_words(N, H, W) * 4);
 }
 
-// bytes at the start of the workspace that must be zero when it is first used (the tile counters)
-extern "C" int64_t sgam_forward_splat_workspace_zero_bytes(int32_t B, int32_t N, int32_t H, int32_t W) {
-    if (sgam_forward_splat_workspace_bytes(B, N, H, W) < 0) return -1;
-    const int tt = splat_tt(B, H, W);
-    return splat_r256((int64_t)B * sgam_cdiv(W, tt) * sgam_cdiv(H, tt) * 4);
+extern "C" int64_t sgam_forward_splat_workspace_bytes(int32_t B, int32_t N, int32_t H, int32_t W) {
+    const int64_t z = sgam_forward_splat_workspace_zero_bytes(B, N, H, W);
+    return z < 0 ? -1 : z + splat_r256((int64_t)B * N * H * W * 4);
 }
 
 static int forward_splat_tiled_launch(const float *src_feats, const float *src_depths, const SrcTable *tab, int64_t feat_cs,
@@ -664,23 +684,22 @@ static int forward_splat_tiled_launch(const float *src_feats, const float *src_d
     if (workspace_bytes < need || !sgam_aligned16(workspace)) return SGAM_EWORKSPACE;
     if (x_out && dataset_norm != 1 && dataset_norm != 2) return SGAM_EINVAL;
     hipStream_t s = sgam_stream(stream);
-    const int bins_x = splat_bins_x(W), nbins = splat_bins(H, W);
+    const int bins_x = splat_bins_x(W), nbins = splat_bins(H, W), words = splat_words(N, H, W);
     const int tt = splat_tt(B, H, W), tiles_x = sgam_cdiv(W, tt), tiles = tiles_x * sgam_cdiv(H, tt);
-    int *tile_cnt = (int *)workspace;
-    int *tgt = (int *)((char *)workspace + splat_r256((int64_t)B * tiles * 4));
-    int *tile_list = (int *)((char *)tgt + splat_r256((int64_t)B * N * H * W * 4));
+    unsigned *tile_bits = (unsigned *)workspace;
+    int *tgt = (int *)((char *)workspace + sgam_forward_splat_workspace_zero_bytes(B, N, H, W));
     const float r0 = depth_range ? depth_range[0] : 0.f, r1 = depth_range ? depth_range[1] : 0.f;
     const int use_range = depth_range ? 1 : 0;
     SrcTable none = {};
-    const dim3 g1(nbins, N, B);
+    const dim3 g1(sgam_cdiv(nbins, 4), N, B);
     if (sgam_i_prof_on) sgam_i_prof_work(0.0, (double)B * H * W * (8.0 * N));
-    if (tab) SGAM_KLAUNCH(splat_project_kernel<true>, g1, dim3(256), 0, s, src_depths, *tab, tgt_K, src_Kinv, T, N, H, W, bins_x, nbins, tt, tiles_x, tiles, tgt, tile_cnt, tile_list);
-    else SGAM_KLAUNCH(splat_project_kernel<false>, g1, dim3(256), 0, s, src_depths, none, tgt_K, src_Kinv, T, N, H, W, bins_x, nbins, tt, tiles_x, tiles, tgt, tile_cnt, tile_list);
+    if (tab) SGAM_KLAUNCH(splat_project_kernel<true>, g1, dim3(256), 0, s, src_depths, *tab, tgt_K, src_Kinv, T, N, H, W, bins_x, nbins, tt, tiles_x, tiles, words, tgt, tile_bits);
+    else SGAM_KLAUNCH(splat_project_kernel<false>, g1, dim3(256), 0, s, src_depths, none, tgt_K, src_Kinv, T, N, H, W, bins_x, nbins, tt, tiles_x, tiles, words, tgt, tile_bits);
     SGAM_LAUNCH_CHECK();
     if (sgam_i_prof_on) sgam_i_prof_work(0.0, (double)B * H * W * (4.0 * N + 33.0));
 #define SPLAT_TILE(TT_, TAB_)                                                                                                      \
     SGAM_KLAUNCH((splat_tile_kernel<TT_, TAB_>), dim3(sgam_cdiv(W, TT_), sgam_cdiv(H, TT_), B), dim3(256), 0, s, src_feats, feat_cs,  \
-                 feat_ps, src_depths, TAB_ ? *tab : none, src_Kinv, T, tgt, tile_cnt, tile_list, N, H, W, bins_x, nbins, r0, r1,       \
+                 feat_ps, src_depths, TAB_ ? *tab : none, src_Kinv, T, tgt, tile_bits, words, N, H, W, bins_x, nbins, r0, r1,          \
                  use_range, dataset_norm, merge_depths, merge_feats, extrap, x_out, proj_feats, proj_depth)
     if (tt == 32) {
         if (tab) SPLAT_TILE(32, true); else SPLAT_TILE(32, false);

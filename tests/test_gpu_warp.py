@@ -145,9 +145,9 @@ def test_tiled_splat_equals_two_pass_splat(B, N, H, W, rot):
 
 def test_tiled_splat_workspace_contract():
     lib = ops._lib.load()
-    # counters [tiles] + cached target pixels [N][HW] + per-tile bin lists [tiles][N * bins], 16 x 16 tiles below 256 workgroups
-    assert lib.sgam_forward_splat_workspace_bytes(1, 3, 256, 256) == 256 * 4 + 3 * 65536 * 4 + 256 * 3 * 256 * 4
-    assert lib.sgam_forward_splat_workspace_zero_bytes(1, 3, 256, 256) == 1024
+    # per-tile bitmaps of registered bins [tiles][N * bins / 32] (16 x 16 tiles below 256 workgroups) + cached target pixels [N][HW]
+    assert lib.sgam_forward_splat_workspace_zero_bytes(1, 3, 256, 256) == 256 * (3 * 256 // 32) * 4
+    assert lib.sgam_forward_splat_workspace_bytes(1, 3, 256, 256) == 256 * 24 * 4 + 3 * 65536 * 4
     assert lib.sgam_forward_splat_workspace_bytes(1, 65, 64, 64) == -1                 # more sources than the pointer table holds
     assert lib.sgam_forward_splat_workspace_bytes(1, 1, 40000, 8) == -1          # H beyond the 16-bit packed target pixel
     f, d, Ks, T = testing.synth_warp_inputs(5, 1, 2, 64, 64, 0.05, False)
