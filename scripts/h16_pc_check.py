@@ -1,0 +1,68 @@
+#!/usr/bin/env python
+"""The persistent producer / consumer form of the 16-bit 128-row halo kernel against the one-role kernel it replaces: every
+output (16-bit / fp32 tensor, GroupNorm chunk statistics) must be BIT-IDENTICAL.  The kernel is chosen per process
+(SGAM_HPC), so the script runs itself twice and compares digests:   python scripts/h16_pc_check.py"""
+import ctypes
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+
+CASES = [  # (B, H, W, Cin, N, dtype, gn, swish, res, out_f32)
+    (1, 32, 32, 128, 128, "bf16", True, True, True, False), (1, 256, 256, 128, 128, "bf16", True, True, True, False),
+    (2, 64, 48, 128, 256, "fp16", True, False, False, False), (3, 32, 64, 256, 128, "bf16", False, False, True, False),
+    (1, 128, 128, 128, 128, "fp16", True, True, False, True), (8, 64, 64, 128, 128, "bf16", True, True, True, False),
+    (5, 24, 32, 64, 128, "bf16", True, True, True, False), (1, 8, 16, 32, 128, "fp16", False, False, False, False)]
+
+
+def dump():
+    import torch
+    from sgam_neurips22_amd import _lib, ops, testing
+    from sgam_neurips22_amd._lib import ConvDesc
+    lib = _lib.load()
+    out = {}
+    for ci, (B, H, W, C, N, dtn, gn, sw, res, f32) in enumerate(CASES):
+        dt = ops.DTYPES[dtn]
+        x = testing.seeded_tensor(f"pc.x{ci}", (B * H * W, C)).cuda().to(dt)
+        r = testing.seeded_tensor(f"pc.r{ci}", (B * H * W, N)).cuda().to(dt) if res else None
+        w = (testing.seeded_tensor(f"pc.w{ci}", (N // 32, 9 * C // 32, 128, 8)) * 0.03).cuda().to(dt)
+        bias = testing.seeded_tensor(f"pc.b{ci}", (N,)).cuda()
+        gamma, beta = testing.seeded_tensor(f"pc.g{ci}", (C,)).cuda() + 1.0, testing.seeded_tensor(f"pc.be{ci}", (C,)).cuda()
+        mr = (testing.seeded_tensor(f"pc.mr{ci}", (B, 32, 2)) * 0.2 + torch.tensor([0.0, 1.0])).cuda().contiguous()
+        d = ConvDesc(B=B, Hi=H, Wi=W, Cin=C, Ho=H, Wo=W, N=N, KH=3, KW=3, stride=1, pad_t=1, pad_l=1, upsample2x=0, lda=C, ldb=9 * C,
+                     ldc=N, ldr=N if res else 0, n_valid=N, bias_per_row=0, plan_bm=128, plan_bn=128, plan_ksplit=1)
+        chunks = lib.sgam_conv2d_h16_stats_chunks(ctypes.byref(d))
+        part = torch.zeros((B, max(chunks, 1), 32, 2), device="cuda", dtype=torch.float64)
+        y = torch.empty((B * H * W, N), device="cuda", dtype=torch.float32 if f32 else dt)
+        for rep in range(2):
+            rc = lib.sgam_conv2d_halo_nhwc_h16(ctypes.byref(d), ops.H16[dt], ops._p(x), ops._p(mr) if gn else None, ops._p(gamma) if gn else None,
+                                               ops._p(beta) if gn else None, int(sw), ops._p(w), ops._p(bias), ops._p(r) if res else None, ops._p(y),
+                                               int(f32), ops._p(part) if chunks > 0 else None, None, 0, ops._stream())
+            assert rc == 0, (ci, rc)
+        torch.cuda.synchronize()
+        out[str(ci)] = [hashlib.sha256(y.cpu().numpy().tobytes()).hexdigest()[:16], hashlib.sha256(part.cpu().numpy().tobytes()).hexdigest()[:16],
+                        float(y.float().abs().mean())]
+    print("DUMP " + json.dumps(out))
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "dump":
+        dump()
+        sys.exit(0)
+    res = {}
+    for mode in ("0", "1"):
+        r = subprocess.run(["timeout", "240", sys.executable, os.path.abspath(__file__), "dump"], capture_output=True, text=True,
+                           env=dict(os.environ, SGAM_HPC=mode))
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("DUMP ")]
+        if r.returncode != 0 or not line:
+            print(f"SGAM_HPC={mode}: rc {r.returncode}\n{r.stderr[-1500:]}")
+            sys.exit(1)
+        res[mode] = json.loads(line[0][5:])
+    bad = [k for k in res["0"] if res["0"][k][:2] != res["1"][k][:2]]
+    for k in res["0"]:
+        print(k, CASES[int(k)], "one-role", res["0"][k], "producer/consumer", res["1"][k], "" if k not in bad else "  <-- DIFFERENT")
+    print("BIT-IDENTICAL" if not bad else f"MISMATCH in cases {bad}")
+    sys.exit(0 if not bad else 2)

@@ -668,6 +668,420 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Producer / consumer form of the 128-row tile (round 4; whole-K, no upsampling).
+//
+// What the counters of the kernel above said (rocprofv3 on the 256^2 x 128 -> 128 layer, bf16, GroupNorm + swish fused,
+// profiles/r04_pmc_h16_halo128_b{1,8}.json): a wavefront lives 45 - 47 k cycles per tile for 288 MFMAs = 9.2 k cycles of the
+// matrix pipe; 16 k cycles it spends ISSUING its other 3 100 instructions (2 050 VALU — two thirds of them the GroupNorm /
+// swish / 16-bit packing of the halo —, 515 scalar, 412 LDS, 110 vector-memory), 18 k issue-stalled behind an MFMA, 10 - 12 k
+// parked at s_waitcnt / barriers.  Two such wavefronts per SIMD leave the pipe 0.24 - 0.30 busy, and no placement of scheduling
+// barriers, deeper prefetch or L2 warm-up moved it: the wavefront is in-order, and it does everything.
+// Here the roles are split.  A workgroup is EIGHT wavefronts on one CU:
+//   * wavefronts 0 - 3, the consumers: each owns all 128 rows x 32 channels (the 1 x 4 layout above) and issues nothing but
+//     A-fragment reads (explicit ds_read_b128, two k-steps ahead, three register sets), weight-fragment loads (nine register
+//     sets, one per tap, each refilled for the NEXT slab as soon as its tap is done: 4 600 MFMA-cycles ahead) and MFMAs —
+//     ~13 instructions per four MFMAs;
+//   * wavefronts 4 - 7, the producers: load the next slab's halo (one slab ahead of the one they normalise), apply GroupNorm
+//     (+ swish), round to 16 bits and store it to the other LDS buffer — on the VALU of the same four SIMDs, beside the
+//     consumers' MFMAs instead of in front of them.
+// One s_barrier per slab couples them.  The workgroup is PERSISTENT: 256 workgroups walk tiles blockIdx.x, + gridDim.x, ...
+// as ONE stream of slabs, so the producers are already staging the next tile's first slab while the consumers store the
+// finished tile (the epilogue of tile t overlaps the prologue of tile t + 1), and the consumers' weight ring never drains.
+// All vector-memory loads of the slab loop are inline asm with counted waits: the compiler's own vmcnt arithmetic turns
+// conservative across a loop's back edge (it drained the whole queue at the top of every slab of the kernel above).
+// Results are bit-identical to the kernel above: same MFMA order per accumulator, same staging arithmetic, same epilogue.
+// ---------------------------------------------------------------------------------------------------------------------
+#define HPC_GLOAD(dst, voff, base, imm) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #imm : "=v"(dst) : "v"(voff), "s"(base))
+
+template <int HT, bool GN, bool SW>
+__global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p) {
+    constexpr int BM = 128, BN = 128, TH = 8, TW = 16, TWS = 4;
+    constexpr int HROWS = TH + 2, HWID = TW + 2, HR = HROWS * HWID;       // 10 x 18 halo pixels
+    constexpr int XBK = 32, XLD = XBK + 8, LP = 768, HPL = HROWS * LP;    // halfs per slab buffer
+    constexpr int NH = (HR * 4 + 255) / 256;                               // 16-byte halo pieces per producer thread: 3
+    constexpr int TM = 4;
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * HPL];
+    __shared__ __attribute__((aligned(16))) float gn_tab[2][GN ? SGAM_HGN_MAXC : 4];
+    __shared__ float epi[4][32];                                           // consumers' output statistics: [wave][row half][unit][2]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool producer = wave >= 4;
+    const int tiles_total = p.gx * p.gy, slabs = p.slabs, G = (int)gridDim.x;
+    const int my_tiles = (tiles_total - (int)blockIdx.x + G - 1) / G;      // (host: gridDim.x <= tiles)
+    const int Q = my_tiles * slabs;                                        // this workgroup's stream of slab steps
+    const int tiles_x = p.Wo / TW, tiles_img = tiles_x * (p.Ho / TH);
+    // tile of the workgroup's it-th turn: virtual block id v = blockIdx.x + it * G through the XCD-aware map of hxcd_block
+    auto decode = [&](int it, int &b, int &ty0, int &tx0, int &n0) {
+        const unsigned L = blockIdx.x + (unsigned)it * (unsigned)G, Tt = (unsigned)tiles_total;
+        unsigned Lp = L;
+        if (p.xcd_swizzle) {
+            const unsigned qq = Tt >> 3, r = Tt & 7u, xcd = L & 7u, idx = L >> 3;
+            Lp = xcd * qq + (xcd < r ? xcd : r) + idx;
+        }
+        const int bx = (int)(Lp % (unsigned)p.gx), by = (int)(Lp / (unsigned)p.gx);
+        n0 = by * BN;
+        b = bx / tiles_img;
+        const int t_img = bx - b * tiles_img;
+        ty0 = (t_img / tiles_x) * TH;
+        tx0 = (t_img % tiles_x) * TW;
+    };
+    // the workgroup's it-th tile starts a different image than its (it - 1)-th: the producers' scale / shift table must be
+    // rewritten before that tile's first slab is staged — both roles evaluate this and meet at an extra barrier (rare)
+    auto image_changes = [&](int it) -> bool {
+        if (!GN || it <= 0 || it >= my_tiles) return false;
+        int b0, b1, a_, c_, d_;
+        decode(it - 1, b0, a_, c_, d_);
+        decode(it, b1, a_, c_, d_);
+        return b0 != b1;
+    };
+    auto fill_table = [&](int b) {                                         // producers only: 256 threads
+        if constexpr (GN) {
+            const int cpg = p.Cin / 32;
+            for (int c = tid - 256; c < p.Cin; c += 256) {
+                const int g = c / cpg;
+                const float mean = p.gn_stats[(b * 32 + g) * 2], rstd = p.gn_stats[(b * 32 + g) * 2 + 1];
+                const float sc = rstd * p.gn_gamma[c];
+                gn_tab[0][c] = sc;
+                gn_tab[1][c] = p.gn_beta[c] - mean * sc;
+            }
+        }
+    };
+
+    if (producer) {
+        // ===================================================================================== producers
+        const int ptid = tid - 256;
+        int h_lds[NH], h_row[NH];
+#pragma unroll
+        for (int j = 0; j < NH; ++j) {
+            int idx = ptid + 256 * j;
+            if (idx >= HR * 4) idx -= 256;                                 // (a piece staged twice: same bytes to the same place)
+            h_row[j] = idx >> 2;
+            h_lds[j] = (h_row[j] / HWID) * LP + (h_row[j] % HWID) * XLD + (idx & 3) * 8;
+        }
+        const int c8 = (ptid & 3) * 8;
+        u32x4 hreg[2][NH];
+        unsigned oob[2] = {0u, 0u};                                        // bit j: piece j of the set is zero padding
+        // issue the raw halo loads of stream step `st` into register set `set`
+        int l_it = 0, l_s = 0;                                             // (tile turn, slab) of the next step to LOAD
+        unsigned l_off[NH];
+        unsigned l_oob = 0;
+        auto retile = [&]() {
+            int b, ty0, tx0, n0;
+            decode(l_it, b, ty0, tx0, n0);
+            l_oob = 0;
+#pragma unroll
+            for (int j = 0; j < NH; ++j) {
+                const int hy = h_row[j] / HWID, hx = h_row[j] - hy * HWID;
+                const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
+                const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+                l_off[j] = ok ? (unsigned)(((b * p.Hi + iy) * p.Wi + ix) * p.lda + c8) * 2u : 0u;
+                l_oob |= ok ? 0u : (1u << j);
+            }
+        };
+        auto issue = [&](const int set) {
+            if (l_s == 0) retile();
+            const unsigned short *base = p.x + l_s * XBK;                  // wave-uniform: the slab's channel offset rides in the scalar base
+#pragma unroll
+            for (int j = 0; j < NH; ++j) HPC_GLOAD(hreg[set][j], l_off[j], base, 0);     // (a padding piece reads offset 0: the counts stay fixed)
+            oob[set] = l_oob;
+            if (++l_s == slabs) { l_s = 0; ++l_it; }
+        };
+        int p_s = 0, p_it = 0;                                             // (slab, tile turn) of the next step to PROCESS
+        auto process = [&](const int set, const int buf, const bool more_in_flight) {
+            if (p_s == 0 && image_changes(p_it)) {
+                int b, a_, c_, d_;
+                decode(p_it, b, a_, c_, d_);
+                fill_table(b);
+                __syncthreads();                                           // (C) with the consumers
+            }
+            // the set's loads have landed (the NH loads of the other set may still be in flight)
+            if (more_in_flight) asm volatile("s_waitcnt vmcnt(3)" : "+v"(hreg[set][0]), "+v"(hreg[set][1]), "+v"(hreg[set][2]));
+            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(hreg[set][0]), "+v"(hreg[set][1]), "+v"(hreg[set][2]));
+            float gsc[8], gsh[8];
+            if constexpr (GN) {
+                const int c = p_s * XBK + c8;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 a = *reinterpret_cast<const f32x4 *>(&gn_tab[0][c + 4 * h]);
+                    const f32x4 d = *reinterpret_cast<const f32x4 *>(&gn_tab[1][c + 4 * h]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        gsc[4 * h + e] = a[e];
+                        gsh[4 * h + e] = d[e];
+                    }
+                }
+            }
+            unsigned short *halo = smem + buf * HPL;
+#pragma unroll
+            for (int j = 0; j < NH; ++j) {
+                u32x4 q = hreg[set][j];
+                if constexpr (GN) {
+#pragma unroll
+                    for (int w2 = 0; w2 < 4; ++w2) {
+                        float v0 = HH<HT>::to_f((unsigned short)(q[w2] & 0xFFFFu)), v1 = HH<HT>::to_f((unsigned short)(q[w2] >> 16));
+                        v0 = v0 * gsc[2 * w2] + gsh[2 * w2];
+                        v1 = v1 * gsc[2 * w2 + 1] + gsh[2 * w2 + 1];
+                        if constexpr (SW) {
+                            v0 = sgam_swish(v0);
+                            v1 = sgam_swish(v1);
+                        }
+                        q[w2] = (unsigned)HH<HT>::from_f(v0) | ((unsigned)HH<HT>::from_f(v1) << 16);
+                    }
+                }
+                if (oob[set] & (1u << j)) q = u32x4{0u, 0u, 0u, 0u};       // zero padding (of the NORMALISED tensor)
+                *reinterpret_cast<u32x4 *>(halo + h_lds[j]) = q;
+            }
+            if (++p_s == slabs) { p_s = 0; ++p_it; }
+        };
+        static_assert(NH == 3, "the producers' counted waits are spelled for three pieces per set");
+        // prologue: steps 0 and 1 requested, the scale / shift table of the first image, step 0 staged
+        int b0, ty0_, tx0_, n0_;
+        decode(0, b0, ty0_, tx0_, n0_);
+        issue(0);
+        if (Q > 1) issue(1);
+        fill_table(b0);
+        __syncthreads();                                                   // (A) table visible to all producers
+        process(0, 0, Q > 1);
+        __syncthreads();                                                   // (B) step 0 staged
+        for (int q = 0; q < Q; q += 2) {
+            // ---- consumers multiply step q (buffer 0); stage step q + 1 into buffer 1, request step q + 2 into set 0
+            if (q + 2 < Q) issue(0);
+            if (q + 1 < Q) process(1, 1, q + 2 < Q);
+            __syncthreads();
+            if (q + 1 >= Q) break;
+            // ---- consumers multiply step q + 1 (buffer 1); stage step q + 2 into buffer 0, request step q + 3 into set 1
+            if (q + 3 < Q) issue(1);
+            if (q + 2 < Q) process(0, 0, q + 3 < Q);
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ========================================================================================= consumers
+    const int wn = wave;                                                   // channel quarter of the 128-channel tile
+    const int frag_row = lane & 31, frag_k = (lane >> 5) * 8;
+    unsigned a_rel[TM];                                                    // byte offset of (row of m tile i, tap (0,0), k-step 0) in a slab buffer
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = i * 32 + frag_row;
+        a_rel[i] = 2u * (unsigned)((r >> TWS) * LP + (r & (TW - 1)) * XLD + frag_k);
+    }
+    const unsigned smem_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short *)smem;
+    const unsigned w_voff = (unsigned)lane * 16u;
+    // weight ring: one register set per tap, refilled for the next step right after its tap
+    u32x4 bq[9][2];
+    int w_it = 0, w_s = 0;                                                 // (tile turn, slab) the NEXT weight loads belong to
+    const unsigned short *w_tile = p.w;                                    // fragment base of that step's channel tile (wave-uniform)
+    auto w_retile = [&]() {
+        int b, ty0, tx0, n0;
+        decode(w_it, b, ty0, tx0, n0);
+        const int nt = (n0 + wn * 32) >> 5;
+        w_tile = p.w + (int64_t)nt * (p.ldb / 32) * 1024;                  // 128 pieces x 8 halfs per (row tile, slab)
+    };
+    auto bload = [&](const int tap) {                                      // the fragments of (w_it, w_s, tap) into set `tap`
+        const unsigned short *base = w_tile + (int64_t)(tap * p.Cin + w_s * XBK) * 32;     // 2048 bytes per (row tile, slab)
+        HPC_GLOAD(bq[tap][0], w_voff, base, 0);
+        HPC_GLOAD(bq[tap][1], w_voff, base, 1024);
+    };
+    auto w_advance = [&]() {
+        if (++w_s == slabs) { w_s = 0; ++w_it; if (w_it < my_tiles) w_retile(); }
+    };
+    f32x16 acc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    u32x4 fa[3][TM];
+#define HPC_DS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+    unsigned a_lds[TM];
+    auto afrag = [&](const int set, const int tap, const int kk) {
+        const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) HPC_DS_READ(fa[set][i], a_lds[i], 2 * (ky * LP + kx * XLD + kk * 16));
+    };
+    // one slab step out of LDS buffer `buf`: 9 taps x 2 k-steps x 4 MFMAs
+    auto consume = [&](const int buf, const bool refill) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a_lds[i] = smem_lds + (unsigned)(buf * HPL * 2) + a_rel[i];
+        afrag(0, 0, 0);
+        afrag(1, 0, 1);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            // this tap's weight set: everything older than the 16 loads of the eight taps refilled after it has landed
+            if (refill) asm volatile("s_waitcnt vmcnt(16)" : "+v"(bq[tap][0]), "+v"(bq[tap][1]));
+            else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(bq[tap][0]), "+v"(bq[tap][1]) : "i"(2 * (8 - tap)));     // last step: the ring drains
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int k18 = tap * 2 + kk;
+                if (k18 + 2 < 18) afrag((k18 + 2) % 3, (k18 + 2) >> 1, (k18 + 2) & 1);
+                const int s3 = k18 % 3;
+                if (k18 + 2 < 18) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(fa[s3][0]), "+v"(fa[s3][1]), "+v"(fa[s3][2]), "+v"(fa[s3][3]));
+                else if (k18 + 1 < 18) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[s3][0]), "+v"(fa[s3][1]), "+v"(fa[s3][2]), "+v"(fa[s3][3]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[s3][0]), "+v"(fa[s3][1]), "+v"(fa[s3][2]), "+v"(fa[s3][3]));
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i] = HH<HT>::mfma(bq[tap][kk], fa[s3][i], acc[i]);
+            }
+            if (refill) bload(tap);                                        // same tap, next step
+        }
+        if (refill) w_advance();
+    };
+
+    // ---- epilogue of one tile (the direct epilogue of conv3x3_h16_halo_kernel: lane = one pixel x 16 consecutive channels)
+    auto epilogue = [&](int it) {
+        int b, ty0, tx0, n0;
+        decode(it, b, ty0, tx0, n0);
+        const int t_img = (ty0 / TH) * tiles_x + tx0 / TW;
+        const int n_lim = p.n_valid;
+        const unsigned osz = p.out_f32 ? 4u : 2u;
+        const unsigned o_bytes = (unsigned)(((int64_t)(p.M - 1) * p.ldc + n_lim) * osz);
+        const unsigned r_bytes = p.res ? (unsigned)(((int64_t)(p.M - 1) * p.ldr + p.n_valid) * 2) : 0u;
+        const unsigned bias_bytes = p.bias ? (unsigned)(p.N * 4) : 0u;
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)o_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void *)p.res, 0, (int)r_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)p.bias, 0, (int)bias_bytes, 0x00020000);
+        constexpr unsigned OOB = 0xFFFFFFF0u;
+        const int wn0 = n0 + wn * 32;
+        const int pl = lane & 31, hh = lane >> 5;
+        int mrow[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int trow = i * 32 + pl;
+            mrow[i] = (b * p.Ho + ty0 + (trow >> TWS)) * p.Wo + tx0 + (trow & (TW - 1));
+        }
+        float us[2][4], uss[2][4];
+        const int nb = wn0 + hh * 16;
+        f32x4 bv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            bv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                  rb, (int)hsel(nb + 4 * k < n_lim, (unsigned)(nb + 4 * k) * 4u, OOB), 0, 0));
+            us[0][k] = us[1][k] = uss[0][k] = uss[1][k] = 0.f;
+        }
+        // two row halves (= the two statistics chunks of the tile), the residual of one half in registers at a time
+#pragma unroll
+        for (int ih = 0; ih < 2; ++ih) {
+            u32x2 rq[2][4];
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int n4 = nb + k * 4;
+                    rq[i2][k] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
+                                                              rr, (int)hsel(n4 < n_lim, (unsigned)(mrow[2 * ih + i2] * p.ldr + n4) * 2u, OOB), 0, 0));
+                }
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2) {
+                const int i = 2 * ih + i2;
+                u32x4 o16[2];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int n4 = nb + 4 * k;
+                    const bool ok = n4 < n_lim;
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][4 * k + e] + bv[k][e];
+                    v[0] += HH<HT>::to_f((unsigned short)(rq[i2][k][0] & 0xFFFFu));
+                    v[1] += HH<HT>::to_f((unsigned short)(rq[i2][k][0] >> 16));
+                    v[2] += HH<HT>::to_f((unsigned short)(rq[i2][k][1] & 0xFFFFu));
+                    v[3] += HH<HT>::to_f((unsigned short)(rq[i2][k][1] >> 16));
+                    if (p.out_f32) {
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro,
+                                                               (int)hsel(ok, (unsigned)(mrow[i] * p.ldc + n4) * 4u, OOB), 0, 0);
+                    } else {
+                        const unsigned short h0 = HH<HT>::from_f(v[0]), h1 = HH<HT>::from_f(v[1]), h2 = HH<HT>::from_f(v[2]),
+                                             h3 = HH<HT>::from_f(v[3]);
+                        o16[k >> 1][(k & 1) * 2] = (unsigned)h0 | ((unsigned)h1 << 16);
+                        o16[k >> 1][(k & 1) * 2 + 1] = (unsigned)h2 | ((unsigned)h3 << 16);
+                        v = f32x4{HH<HT>::to_f(h0), HH<HT>::to_f(h1), HH<HT>::to_f(h2), HH<HT>::to_f(h3)};     // statistics of the STORED tensor
+                    }
+                    if (ok) {
+                        us[ih][k] += (v[0] + v[1]) + (v[2] + v[3]);
+                        uss[ih][k] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                    }
+                }
+                if (!p.out_f32) {
+                    if (nb + 16 <= n_lim) {
+#pragma unroll
+                        for (int q2 = 0; q2 < 2; ++q2)
+                            __builtin_amdgcn_raw_buffer_store_b128(o16[q2], ro, (int)((unsigned)(mrow[i] * p.ldc + nb + 8 * q2) * 2u), 0, 0);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const u32x2 o8 = {o16[k >> 1][(k & 1) * 2], o16[k >> 1][(k & 1) * 2 + 1]};
+                            __builtin_amdgcn_raw_buffer_store_b64(o8, ro, (int)hsel(nb + 4 * k < n_lim, (unsigned)(mrow[i] * p.ldc + nb + 4 * k) * 2u, OOB), 0, 0);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;              // the next tile starts from zero
+            }
+        }
+        if (p.gn_partial) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int off = 16; off >= 1; off >>= 1) {
+                        us[r][k] += __shfl_xor(us[r][k], off, 64);
+                        uss[r][k] += __shfl_xor(uss[r][k], off, 64);
+                    }
+            float *sl = epi[wave];                                          // [row half][unit = 4 half + k][2]
+            if (pl == 0) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        sl[(r * 8 + hh * 4 + k) * 2] = us[r][k];
+                        sl[(r * 8 + hh * 4 + k) * 2 + 1] = uss[r][k];
+                    }
+            }
+            // (same wavefront wrote and reads: program order on LDS suffices)
+            const int c4_per_group = p.gn_cpg / 4;
+            const int groups_here = 8 / c4_per_group;
+            if (lane < groups_here * 2) {
+                const int r = lane / groups_here, gl = lane - r * groups_here;
+                double ds = 0.0, dss = 0.0;
+                for (int k = 0; k < c4_per_group; ++k) {
+                    ds += (double)sl[(r * 8 + gl * c4_per_group + k) * 2];
+                    dss += (double)sl[(r * 8 + gl * c4_per_group + k) * 2 + 1];
+                }
+                const int g = (wn0 / p.gn_cpg) + gl;
+                const int groups = p.N / p.gn_cpg;
+                if (g < groups) {
+                    const int chunks_per_b = tiles_img * 2;
+                    double *o = p.gn_partial + (((int64_t)b * chunks_per_b + t_img * 2 + r) * groups + g) * 2;
+                    o[0] = ds;
+                    o[1] = dss;
+                }
+            }
+        }
+    };
+
+    // prologue: the whole weight ring of step 0 requested; barriers (A), (B) with the producers
+    w_retile();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) bload(tap);
+    w_advance();
+    __syncthreads();                                                       // (A)
+    __syncthreads();                                                       // (B) step 0 staged
+    int c_s = 0, c_it = 0;                                                 // (slab, tile turn) of the step being multiplied
+    // barrier (C): the producers stage step q + 1 while this role multiplies step q; when that step opens a new image they
+    // rewrite their table first and everybody meets
+    auto meet_retable = [&](bool next_exists) {
+        if (next_exists && c_s + 1 == slabs && image_changes(c_it + 1)) __syncthreads();
+    };
+    for (int q = 0; q < Q; ++q) {                    // (the buffer parity is only an LDS base address here: no unrolling by two)
+        meet_retable(q + 1 < Q);
+        consume(q & 1, q + 1 < Q);
+        __syncthreads();
+        if (++c_s == slabs) { c_s = 0; epilogue(c_it++); }
+    }
+#undef HPC_DS_READ
+}
+#undef HPC_GLOAD
+
 // split-K combine: out = round16(sum_z ws[z] + bias + residual), ranges added in the order z = 0, 1, 2, ...; thread = 4
 // channels of one pixel, workgroup = 1024 outputs = 1024 / N whole rows = one chunk of output statistics (the scheme of
 // splitk_reduce_f32x_kernel, conv_f32x.hip)
@@ -992,6 +1406,27 @@ static int hh_conv_impl(const sgam_conv_desc *d, int32_t ht, const void *x, cons
         else if (gn) SGAM_KLAUNCH((conv3x3_h16_halo_kernel<BM_, 128, HT_, true, false, false>), grid, dim3(256), 0, s, p);        \
         else SGAM_KLAUNCH((conv3x3_h16_halo_kernel<BM_, 128, HT_, false, false>), grid, dim3(256), 0, s, p);                     \
     } while (0)
+    // the 128-row tile, whole K, no upsampling: the persistent producer / consumer kernel (SGAM_HPC=0: the kernel above)
+    static const int hpc_on = [] { const char *e = getenv("SGAM_HPC"); return (e && e[0] == '0') ? 0 : 1; }();
+    static const int n_cu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    if (hpc_on && bm == 128 && !p.ups && pl.ksplit == 1 && !gn_partial_in && d->Cin <= SGAM_HGN_MAXC) {
+        const int64_t tiles_total = (int64_t)p.gx * p.gy;
+        const dim3 pg((unsigned)(tiles_total < n_cu ? tiles_total : n_cu));
+#define HPC_LAUNCH(HT_)                                                                                                   \
+    do {                                                                                                                  \
+        if (gn && p.gn_swish) SGAM_KLAUNCH((conv3x3_h16_pc_kernel<HT_, true, true>), pg, dim3(512), 0, s, p);             \
+        else if (gn) SGAM_KLAUNCH((conv3x3_h16_pc_kernel<HT_, true, false>), pg, dim3(512), 0, s, p);                     \
+        else SGAM_KLAUNCH((conv3x3_h16_pc_kernel<HT_, false, false>), pg, dim3(512), 0, s, p);                            \
+    } while (0)
+        if (ht == 0) HPC_LAUNCH(0); else HPC_LAUNCH(1);
+#undef HPC_LAUNCH
+        SGAM_LAUNCH_CHECK();
+        return SGAM_OK;
+    }
     if (gn_partial_in) {
         if (ht == 0 && p.gn_swish) SGAM_KLAUNCH((conv3x3_h16_halo_kernel<64, 128, 0, true, false, true, true>), grid, dim3(256), 0, s, p);
         else if (ht == 0) SGAM_KLAUNCH((conv3x3_h16_halo_kernel<64, 128, 0, true, false, false, true>), grid, dim3(256), 0, s, p);
