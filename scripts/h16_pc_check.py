@@ -43,7 +43,7 @@ def dump():
                                                int(f32), ops._p(part) if chunks > 0 else None, None, 0, ops._stream())
             assert rc == 0, (ci, rc)
         torch.cuda.synchronize()
-        out[str(ci)] = [hashlib.sha256(y.cpu().numpy().tobytes()).hexdigest()[:16], hashlib.sha256(part.cpu().numpy().tobytes()).hexdigest()[:16],
+        out[str(ci)] = [hashlib.sha256(y.contiguous().view(torch.uint8).cpu().numpy().tobytes()).hexdigest()[:16], hashlib.sha256(part.cpu().numpy().tobytes()).hexdigest()[:16],
                         float(y.float().abs().mean())]
     print("DUMP " + json.dumps(out))
 
