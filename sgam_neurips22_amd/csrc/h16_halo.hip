@@ -693,6 +693,12 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
 // Results are bit-identical to the kernel above: same MFMA order per accumulator, same staging arithmetic, same epilogue.
 // ---------------------------------------------------------------------------------------------------------------------
 #define HPC_GLOAD(dst, voff, base, imm) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #imm : "=v"(dst) : "v"(voff), "s"(base))
+// a wave-uniform pointer the compiler cannot prove uniform (it depends on the wavefront's index in the workgroup): into SGPRs
+__device__ __forceinline__ const unsigned short *hpc_uniform(const unsigned short *q) {
+    const unsigned long long v = (unsigned long long)(uintptr_t)q;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (const unsigned short *)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+}
 
 template <int HT, bool GN, bool SW>
 __global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p) {
@@ -781,7 +787,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p
         };
         auto issue = [&](const int set) {
             if (l_s == 0) retile();
-            const unsigned short *base = p.x + l_s * XBK;                  // wave-uniform: the slab's channel offset rides in the scalar base
+            const unsigned short *base = hpc_uniform(p.x + l_s * XBK);     // wave-uniform: the slab's channel offset rides in the scalar base
 #pragma unroll
             for (int j = 0; j < NH; ++j) HPC_GLOAD(hreg[set][j], l_off[j], base, 0);     // (a padding piece reads offset 0: the counts stay fixed)
             oob[set] = l_oob;
@@ -880,7 +886,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p
         w_tile = p.w + (int64_t)nt * (p.ldb / 32) * 1024;                  // 128 pieces x 8 halfs per (row tile, slab)
     };
     auto bload = [&](const int tap) {                                      // the fragments of (w_it, w_s, tap) into set `tap`
-        const unsigned short *base = w_tile + (int64_t)(tap * p.Cin + w_s * XBK) * 32;     // 2048 bytes per (row tile, slab)
+        const unsigned short *base = hpc_uniform(w_tile + (int64_t)(tap * p.Cin + w_s * XBK) * 32);     // 2048 bytes per (row tile, slab)
         HPC_GLOAD(bq[tap][0], w_voff, base, 0);
         HPC_GLOAD(bq[tap][1], w_voff, base, 1024);
     };
