@@ -688,17 +688,11 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
 // One s_barrier per slab couples them.  The workgroup is PERSISTENT: 256 workgroups walk tiles blockIdx.x, + gridDim.x, ...
 // as ONE stream of slabs, so the producers are already staging the next tile's first slab while the consumers store the
 // finished tile (the epilogue of tile t overlaps the prologue of tile t + 1), and the consumers' weight ring never drains.
-// All vector-memory loads of the slab loop are inline asm with counted waits: the compiler's own vmcnt arithmetic turns
-// conservative across a loop's back edge (it drained the whole queue at the top of every slab of the kernel above).
+// Loads stay compiler-visible; the loops are arranged so that whatever crosses a back edge is the ONLY thing outstanding there
+// (the compiler's vmcnt arithmetic turns conservative across a back edge: it drained the whole queue at the top of every slab
+// of the kernel above).
 // Results are bit-identical to the kernel above: same MFMA order per accumulator, same staging arithmetic, same epilogue.
 // ---------------------------------------------------------------------------------------------------------------------
-#define HPC_GLOAD(dst, voff, base, imm) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #imm : "=v"(dst) : "v"(voff), "s"(base))
-// a wave-uniform pointer the compiler cannot prove uniform (it depends on the wavefront's index in the workgroup): into SGPRs
-__device__ __forceinline__ const unsigned short *hpc_uniform(const unsigned short *q) {
-    const unsigned long long v = (unsigned long long)(uintptr_t)q;
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
-    return (const unsigned short *)(uintptr_t)(((unsigned long long)hi << 32) | lo);
-}
 
 template <int HT, bool GN, bool SW>
 __global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p) {
@@ -754,8 +748,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p
         }
     };
 
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, (int)p.w_bytes, 0x00020000);
     if (producer) {
         // ===================================================================================== producers
+        // One register set: stage step q + 1 (requested during the previous turn — the only loads outstanding, so the wait the
+        // compiler puts in front of the first use is exact even across the loop's back edge), then request step q + 2, then meet
+        // the consumers.  The staging arithmetic is a fraction of a consumer's slab, so the producers arrive early and the loads
+        // fly while they wait at the barrier.
         const int ptid = tid - 256;
         int h_lds[NH], h_row[NH];
 #pragma unroll
@@ -766,44 +766,37 @@ __global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p
             h_lds[j] = (h_row[j] / HWID) * LP + (h_row[j] % HWID) * XLD + (idx & 3) * 8;
         }
         const int c8 = (ptid & 3) * 8;
-        u32x4 hreg[2][NH];
-        unsigned oob[2] = {0u, 0u};                                        // bit j: piece j of the set is zero padding
-        // issue the raw halo loads of stream step `st` into register set `set`
+        u32x4 hreg[NH];
+        unsigned h_off[NH], p_off[NH];                                     // byte offsets (~0: zero padding) of the tile being LOADED / PROCESSED
         int l_it = 0, l_s = 0;                                             // (tile turn, slab) of the next step to LOAD
-        unsigned l_off[NH];
-        unsigned l_oob = 0;
-        auto retile = [&]() {
-            int b, ty0, tx0, n0;
-            decode(l_it, b, ty0, tx0, n0);
-            l_oob = 0;
+        auto issue = [&]() {
+            if (l_s == 0) {
+                int b, ty0, tx0, n0;
+                decode(l_it, b, ty0, tx0, n0);
+#pragma unroll
+                for (int j = 0; j < NH; ++j) {
+                    const int hy = h_row[j] / HWID, hx = h_row[j] - hy * HWID;
+                    const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
+                    const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+                    h_off[j] = ok ? (unsigned)(((b * p.Hi + iy) * p.Wi + ix) * p.lda + c8) * 2u : 0xFFFFFFFFu;
+                }
+            }
+            const unsigned coff = (unsigned)l_s * (XBK * 2u);              // wave-uniform: the load's scalar offset
 #pragma unroll
             for (int j = 0; j < NH; ++j) {
-                const int hy = h_row[j] / HWID, hx = h_row[j] - hy * HWID;
-                const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
-                const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-                l_off[j] = ok ? (unsigned)(((b * p.Hi + iy) * p.Wi + ix) * p.lda + c8) * 2u : 0u;
-                l_oob |= ok ? 0u : (1u << j);
+                hreg[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)h_off[j], (int)coff, 0);
+                p_off[j] = h_off[j];
             }
-        };
-        auto issue = [&](const int set) {
-            if (l_s == 0) retile();
-            const unsigned short *base = hpc_uniform(p.x + l_s * XBK);     // wave-uniform: the slab's channel offset rides in the scalar base
-#pragma unroll
-            for (int j = 0; j < NH; ++j) HPC_GLOAD(hreg[set][j], l_off[j], base, 0);     // (a padding piece reads offset 0: the counts stay fixed)
-            oob[set] = l_oob;
             if (++l_s == slabs) { l_s = 0; ++l_it; }
         };
         int p_s = 0, p_it = 0;                                             // (slab, tile turn) of the next step to PROCESS
-        auto process = [&](const int set, const int buf, const bool more_in_flight) {
+        auto process = [&](const int buf) {
             if (p_s == 0 && image_changes(p_it)) {
                 int b, a_, c_, d_;
                 decode(p_it, b, a_, c_, d_);
                 fill_table(b);
                 __syncthreads();                                           // (C) with the consumers
             }
-            // the set's loads have landed (the NH loads of the other set may still be in flight)
-            if (more_in_flight) asm volatile("s_waitcnt vmcnt(3)" : "+v"(hreg[set][0]), "+v"(hreg[set][1]), "+v"(hreg[set][2]));
-            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(hreg[set][0]), "+v"(hreg[set][1]), "+v"(hreg[set][2]));
             float gsc[8], gsh[8];
             if constexpr (GN) {
                 const int c = p_s * XBK + c8;
@@ -821,7 +814,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p
             unsigned short *halo = smem + buf * HPL;
 #pragma unroll
             for (int j = 0; j < NH; ++j) {
-                u32x4 q = hreg[set][j];
+                u32x4 q = hreg[j];
                 if constexpr (GN) {
 #pragma unroll
                     for (int w2 = 0; w2 < 4; ++w2) {
@@ -834,31 +827,25 @@ __global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p
                         }
                         q[w2] = (unsigned)HH<HT>::from_f(v0) | ((unsigned)HH<HT>::from_f(v1) << 16);
                     }
+                    if (p_off[j] == 0xFFFFFFFFu) q = u32x4{0u, 0u, 0u, 0u};       // zero padding applies to the normalised tensor
                 }
-                if (oob[set] & (1u << j)) q = u32x4{0u, 0u, 0u, 0u};       // zero padding (of the NORMALISED tensor)
                 *reinterpret_cast<u32x4 *>(halo + h_lds[j]) = q;
             }
             if (++p_s == slabs) { p_s = 0; ++p_it; }
         };
-        static_assert(NH == 3, "the producers' counted waits are spelled for three pieces per set");
-        // prologue: steps 0 and 1 requested, the scale / shift table of the first image, step 0 staged
+        // prologue: step 0 requested, the scale / shift table of the first image, step 0 staged, step 1 requested
         int b0, ty0_, tx0_, n0_;
         decode(0, b0, ty0_, tx0_, n0_);
-        issue(0);
-        if (Q > 1) issue(1);
+        issue();
         fill_table(b0);
         __syncthreads();                                                   // (A) table visible to all producers
-        process(0, 0, Q > 1);
+        process(0);
+        if (Q > 1) issue();
         __syncthreads();                                                   // (B) step 0 staged
-        for (int q = 0; q < Q; q += 2) {
-            // ---- consumers multiply step q (buffer 0); stage step q + 1 into buffer 1, request step q + 2 into set 0
-            if (q + 2 < Q) issue(0);
-            if (q + 1 < Q) process(1, 1, q + 2 < Q);
-            __syncthreads();
-            if (q + 1 >= Q) break;
-            // ---- consumers multiply step q + 1 (buffer 1); stage step q + 2 into buffer 0, request step q + 3 into set 1
-            if (q + 3 < Q) issue(1);
-            if (q + 2 < Q) process(0, 0, q + 3 < Q);
+        for (int q = 0; q < Q; ++q) {
+            // consumers multiply step q out of buffer q & 1
+            if (q + 1 < Q) process((q + 1) & 1);
+            if (q + 2 < Q) issue();
             __syncthreads();
         }
         return;
@@ -874,21 +861,27 @@ __global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p
         a_rel[i] = 2u * (unsigned)((r >> TWS) * LP + (r & (TW - 1)) * XLD + frag_k);
     }
     const unsigned smem_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short *)smem;
-    const unsigned w_voff = (unsigned)lane * 16u;
-    // weight ring: one register set per tap, refilled for the next step right after its tap
+    // weight ring: one register set per tap, refilled for the next step right after its tap.  Plain buffer loads: the compiler
+    // counts the waits (exactly inside the four-slab body below; conservatively only where the ring crosses its back edge, i.e.
+    // behind an epilogue when a tile is four slabs — by then everything has landed).  (A first version issued them as inline asm
+    // with hand-counted waits: under register pressure the compiler copies such a "defined" value elsewhere and re-uses the
+    // register before the data lands — the late write then hit live addresses: memory faults.)
     u32x4 bq[9][2];
     int w_it = 0, w_s = 0;                                                 // (tile turn, slab) the NEXT weight loads belong to
-    const unsigned short *w_tile = p.w;                                    // fragment base of that step's channel tile (wave-uniform)
+    unsigned w_voff = 0;                                                   // fragment offset of that step's channel tile + lane
     auto w_retile = [&]() {
         int b, ty0, tx0, n0;
         decode(w_it, b, ty0, tx0, n0);
         const int nt = (n0 + wn * 32) >> 5;
-        w_tile = p.w + (int64_t)nt * (p.ldb / 32) * 1024;                  // 128 pieces x 8 halfs per (row tile, slab)
+        w_voff = ((unsigned)nt * ((unsigned)p.ldb / 32u) * 128u + (unsigned)lane) * 16u;
     };
-    auto bload = [&](const int tap) {                                      // the fragments of (w_it, w_s, tap) into set `tap`
-        const unsigned short *base = hpc_uniform(w_tile + (int64_t)(tap * p.Cin + w_s * XBK) * 32);     // 2048 bytes per (row tile, slab)
-        HPC_GLOAD(bq[tap][0], w_voff, base, 0);
-        HPC_GLOAD(bq[tap][1], w_voff, base, 1024);
+    // (the fragments of (w_it, w_s, tap) into set `tap`; !live: an out-of-range offset — zeros come back, no memory traffic, and
+    // the slab body stays free of branches, which is what keeps the compiler's wait counts exact)
+    auto bload = [&](const int tap, const bool live) {
+        const unsigned koff = (unsigned)(tap * p.Cin + w_s * XBK) * 64u;   // 2048 bytes per (row tile, slab); scalar offset
+        const unsigned vo = live ? w_voff : 0xFFFFFFF0u;
+        bq[tap][0] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)vo, (int)koff, 0);
+        bq[tap][1] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)vo, (int)(koff + 1024u), 0);
     };
     auto w_advance = [&]() {
         if (++w_s == slabs) { w_s = 0; ++w_it; if (w_it < my_tiles) w_retile(); }
@@ -914,9 +907,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p
         afrag(1, 0, 1);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            // this tap's weight set: everything older than the 16 loads of the eight taps refilled after it has landed
-            if (refill) asm volatile("s_waitcnt vmcnt(16)" : "+v"(bq[tap][0]), "+v"(bq[tap][1]));
-            else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(bq[tap][0]), "+v"(bq[tap][1]) : "i"(2 * (8 - tap)));     // last step: the ring drains
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const int k18 = tap * 2 + kk;
@@ -928,7 +918,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p
 #pragma unroll
                 for (int i = 0; i < TM; ++i) acc[i] = HH<HT>::mfma(bq[tap][kk], fa[s3][i], acc[i]);
             }
-            if (refill) bload(tap);                                        // same tap, next step
+            bload(tap, refill);                                            // same tap, next step
         }
         if (refill) w_advance();
     };
@@ -1068,7 +1058,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p
     // prologue: the whole weight ring of step 0 requested; barriers (A), (B) with the producers
     w_retile();
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) bload(tap);
+    for (int tap = 0; tap < 9; ++tap) bload(tap, true);
     w_advance();
     __syncthreads();                                                       // (A)
     __syncthreads();                                                       // (B) step 0 staged
@@ -1078,15 +1068,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p
     auto meet_retable = [&](bool next_exists) {
         if (next_exists && c_s + 1 == slabs && image_changes(c_it + 1)) __syncthreads();
     };
-    for (int q = 0; q < Q; ++q) {                    // (the buffer parity is only an LDS base address here: no unrolling by two)
-        meet_retable(q + 1 < Q);
-        consume(q & 1, q + 1 < Q);
-        __syncthreads();
-        if (++c_s == slabs) { c_s = 0; epilogue(c_it++); }
+    for (int q = 0; q < Q; q += 4) {                 // (host: slabs % 4 == 0 — a tile ends on a multiple of four steps)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            meet_retable(q + u + 1 < Q);
+            consume(u & 1, q + u + 1 < Q);
+            __syncthreads();
+            ++c_s;
+        }
+        if (c_s == slabs) { c_s = 0; epilogue(c_it++); }
     }
 #undef HPC_DS_READ
 }
-#undef HPC_GLOAD
 
 // split-K combine: out = round16(sum_z ws[z] + bias + residual), ranges added in the order z = 0, 1, 2, ...; thread = 4
 // channels of one pixel, workgroup = 1024 outputs = 1024 / N whole rows = one chunk of output statistics (the scheme of
@@ -1419,7 +1412,7 @@ static int hh_conv_impl(const sgam_conv_desc *d, int32_t ht, const void *x, cons
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         return n;
     }();
-    if (hpc_on && bm == 128 && !p.ups && pl.ksplit == 1 && !gn_partial_in && d->Cin <= SGAM_HGN_MAXC) {
+    if (hpc_on && bm == 128 && !p.ups && pl.ksplit == 1 && !gn_partial_in && d->Cin <= SGAM_HGN_MAXC && p.slabs % 4 == 0) {
         const int64_t tiles_total = (int64_t)p.gx * p.gy;
         const dim3 pg((unsigned)(tiles_total < n_cu ? tiles_total : n_cu));
 #define HPC_LAUNCH(HT_)                                                                                                   \
