@@ -66,6 +66,9 @@ if __name__ == "__main__":
             sys.exit(1)
         res[mode] = json.loads(line[0][5:])
     bad = [k for k in res["0"] if res["0"][k][:2] != res["1"][k][:2]]
+    for k in bad:
+        print("case", k, "tensor differs" if res["0"][k][0] != res["1"][k][0] else "tensor equal", "/",
+              "statistics differ" if res["0"][k][1] != res["1"][k][1] else "statistics equal")
     for k in res["0"]:
         print(k, CASES[int(k)], "one-role", res["0"][k], "producer/consumer", res["1"][k], "" if k not in bad else "  <-- DIFFERENT")
     print("BIT-IDENTICAL" if not bad else f"MISMATCH in cases {bad}")

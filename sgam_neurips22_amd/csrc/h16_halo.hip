@@ -26,6 +26,7 @@
 //   * the maps too small to fill the chip with whole-K workgroups (16^2 ... 64^2) split the K slabs over grid.y: fp32
 //     partial tiles in the same lane-owned layout, then h16_splitk_reduce_kernel adds them in a fixed order, applies bias /
 //     residual, rounds and leaves the per-chunk statistics (so those layers, too, normalise while staging).
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "sgam_common.h"
@@ -90,6 +91,7 @@ struct HHParams {
     const double *gn_partial_in;
     int gn_chunks_in;
     float gn_inv_n, gn_eps;
+    unsigned long long *dbg;      // SGAM_HPC_DBG=1: cycle stamps of workgroup 0 (producer / consumer kernel), else NULL
 };
 
 __device__ __forceinline__ unsigned hsel(bool c, unsigned a, unsigned b) {
@@ -704,9 +706,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p
     __shared__ __attribute__((aligned(16))) unsigned short smem[2 * HPL];
     __shared__ __attribute__((aligned(16))) float gn_tab[2][GN ? SGAM_HGN_MAXC : 4];
     __shared__ float epi[4][32];                                           // consumers' output statistics: [wave][row half][unit][2]
+    __shared__ float estat[4][16][65];                                     // ... and their per-lane partials [wave][statistic][lane] (+1: banks)
+    // the residual tile, fetched by the PRODUCERS during the tile's last two slabs, in the consumers' epilogue order:
+    // [channel quarter][row tile][4-channel unit] rows of 64 lanes x 8 bytes (+ 8 bytes: the producers' column-wise writes spread over the banks)
+    constexpr int RROW = 64 * 2 + 2;                                       // dwords per row
+    __shared__ __attribute__((aligned(8))) unsigned res_lds[4 * 4 * 4 * RROW];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool producer = wave >= 4;
+    // (debug: s_memtime stamps of workgroup 0 — consumer wavefront 0 in slots 0.., producer wavefront 4 in slots 64..)
+#define HPC_STAMP(slot) do { if (p.dbg && blockIdx.x == 0 && lane == 0 && (wave & 3) == 0 && (slot) < 64) p.dbg[(producer ? 64 : 0) + (slot)] = __builtin_readcyclecounter(); } while (0)
     const int tiles_total = p.gx * p.gy, slabs = p.slabs, G = (int)gridDim.x;
     const int my_tiles = (tiles_total - (int)blockIdx.x + G - 1) / G;      // (host: gridDim.x <= tiles)
     const int Q = my_tiles * slabs;                                        // this workgroup's stream of slab steps
@@ -766,10 +775,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p
             h_lds[j] = (h_row[j] / HWID) * LP + (h_row[j] % HWID) * XLD + (idx & 3) * 8;
         }
         const int c8 = (ptid & 3) * 8;
-        u32x4 hreg[NH];
-        unsigned h_off[NH], p_off[NH];                                     // byte offsets (~0: zero padding) of the tile being LOADED / PROCESSED
+        u32x4 hreg[2][NH];
+        unsigned h_off[NH], p_off[2][NH];                                  // byte offsets (~0: zero padding): tile being LOADED / of each set
         int l_it = 0, l_s = 0;                                             // (tile turn, slab) of the next step to LOAD
-        auto issue = [&]() {
+        auto issue = [&](const int set) {
             if (l_s == 0) {
                 int b, ty0, tx0, n0;
                 decode(l_it, b, ty0, tx0, n0);
@@ -784,13 +793,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p
             const unsigned coff = (unsigned)l_s * (XBK * 2u);              // wave-uniform: the load's scalar offset
 #pragma unroll
             for (int j = 0; j < NH; ++j) {
-                hreg[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)h_off[j], (int)coff, 0);
-                p_off[j] = h_off[j];
+                hreg[set][j] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)h_off[j], (int)coff, 0);
+                p_off[set][j] = h_off[j];
             }
             if (++l_s == slabs) { l_s = 0; ++l_it; }
         };
         int p_s = 0, p_it = 0;                                             // (slab, tile turn) of the next step to PROCESS
-        auto process = [&](const int buf) {
+        auto process = [&](const int set, const int buf) {
             if (p_s == 0 && image_changes(p_it)) {
                 int b, a_, c_, d_;
                 decode(p_it, b, a_, c_, d_);
@@ -814,7 +823,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p
             unsigned short *halo = smem + buf * HPL;
 #pragma unroll
             for (int j = 0; j < NH; ++j) {
-                u32x4 q = hreg[j];
+                u32x4 q = hreg[set][j];
                 if constexpr (GN) {
 #pragma unroll
                     for (int w2 = 0; w2 < 4; ++w2) {
@@ -827,26 +836,81 @@ __global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p
                         }
                         q[w2] = (unsigned)HH<HT>::from_f(v0) | ((unsigned)HH<HT>::from_f(v1) << 16);
                     }
-                    if (p_off[j] == 0xFFFFFFFFu) q = u32x4{0u, 0u, 0u, 0u};       // zero padding applies to the normalised tensor
+                    if (p_off[set][j] == 0xFFFFFFFFu) q = u32x4{0u, 0u, 0u, 0u};       // zero padding applies to the normalised tensor
                 }
                 *reinterpret_cast<u32x4 *>(halo + h_lds[j]) = q;
             }
             if (++p_s == slabs) { p_s = 0; ++p_it; }
         };
-        // prologue: step 0 requested, the scale / shift table of the first image, step 0 staged, step 1 requested
+        // residual of the tile the consumers are finishing: requested while they multiply its second-to-last slab, written to LDS
+        // (their epilogue's order) while they multiply its last: the epilogue finds it behind the barrier instead of waiting two
+        // memory round trips for it (cycle stamps: 8.4 k of the epilogue's 11 k cycles went until its stores were issued)
+        u32x2 rres[16];
+        int r_s = 0, r_it = 0;                                             // (slab, tile turn) of the step the consumers multiply
+        auto residual = [&]() {
+            if (p.res) {
+                if (r_s == slabs - 2) {
+                    int b, ty0, tx0, n0;
+                    decode(r_it, b, ty0, tx0, n0);
+                    const unsigned r_bytes = (unsigned)(((int64_t)(p.M - 1) * p.ldr + p.n_valid) * 2);
+                    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void *)p.res, 0, (int)r_bytes, 0x00020000);
+                    const int c = ptid & 31;                               // 8-byte chunk of the pixel's 128 channels
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int trow = (ptid >> 5) + 8 * r;
+                        const int m = (b * p.Ho + ty0 + (trow >> TWS)) * p.Wo + tx0 + (trow & (TW - 1));
+                        const int n4 = n0 + 4 * c;
+                        rres[r] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
+                                                                rr, (int)hsel(n4 < p.n_valid, (unsigned)(m * p.ldr + n4) * 2u, 0xFFFFFFF0u), 0, 0));
+                    }
+                } else if (r_s == slabs - 1) {
+                    const int c = ptid & 31;
+                    const int wn_ = c >> 3, hh_ = (c >> 2) & 1, k_ = c & 3;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int trow = (ptid >> 5) + 8 * r;
+                        const int i_ = trow >> 5, lane_ = hh_ * 32 + (trow & 31);
+                        *reinterpret_cast<u32x2 *>(&res_lds[((wn_ * 4 + i_) * 4 + k_) * RROW + lane_ * 2]) = rres[r];
+                    }
+                }
+            }
+            if (++r_s == slabs) { r_s = 0; ++r_it; }
+        };
+        __builtin_amdgcn_s_setprio(2);          // the second-dispatched half of the workgroup loses every arbitration otherwise
+        // Two register sets, every load requested TWO steps before it is staged: step q + 1 is staged (set (q + 1) & 1) while the
+        // consumers multiply step q, then step q + 3 is requested into the set just freed.  What is outstanding when a set is
+        // waited for is the other set, requested a whole step earlier: a conservative wait of the compiler (across the back edge)
+        // costs nothing.  (With one set — request after staging — the producers waited a full memory latency per step and the
+        // consumers waited for them: cycle stamps, 3.9 k cycles per step against 2.8 k of MFMA work.)
         int b0, ty0_, tx0_, n0_;
         decode(0, b0, ty0_, tx0_, n0_);
-        issue();
+        HPC_STAMP(0);
+        issue(0);
+        if (Q > 1) issue(1);
         fill_table(b0);
         __syncthreads();                                                   // (A) table visible to all producers
-        process(0);
-        if (Q > 1) issue();
+        HPC_STAMP(1);
+        process(0, 0);
+        if (Q > 2) issue(0);
+        HPC_STAMP(2);
         __syncthreads();                                                   // (B) step 0 staged
-        for (int q = 0; q < Q; ++q) {
-            // consumers multiply step q out of buffer q & 1
-            if (q + 1 < Q) process((q + 1) & 1);
-            if (q + 2 < Q) issue();
+        HPC_STAMP(3);
+        for (int q = 0; q < Q; q += 2) {
+            // consumers multiply step q (buffer 0): stage step q + 1 from set 1 into buffer 1, request step q + 3 into set 1
+            if (q + 1 < Q) process(1, 1);
+            if (q + 3 < Q) issue(1);
+            residual();
+            HPC_STAMP(4 + 2 * q);                                          // staging done
             __syncthreads();
+            HPC_STAMP(5 + 2 * q);                                          // past the barrier
+            if (q + 1 >= Q) break;
+            // consumers multiply step q + 1 (buffer 1): stage step q + 2 from set 0 into buffer 0, request step q + 4 into set 0
+            if (q + 2 < Q) process(0, 0);
+            if (q + 4 < Q) issue(0);
+            residual();
+            HPC_STAMP(6 + 2 * q);
+            __syncthreads();
+            HPC_STAMP(7 + 2 * q);
         }
         return;
     }
@@ -931,10 +995,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p
         const int n_lim = p.n_valid;
         const unsigned osz = p.out_f32 ? 4u : 2u;
         const unsigned o_bytes = (unsigned)(((int64_t)(p.M - 1) * p.ldc + n_lim) * osz);
-        const unsigned r_bytes = p.res ? (unsigned)(((int64_t)(p.M - 1) * p.ldr + p.n_valid) * 2) : 0u;
         const unsigned bias_bytes = p.bias ? (unsigned)(p.N * 4) : 0u;
         const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)o_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void *)p.res, 0, (int)r_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)p.bias, 0, (int)bias_bytes, 0x00020000);
         constexpr unsigned OOB = 0xFFFFFFF0u;
         const int wn0 = n0 + wn * 32;
@@ -954,18 +1016,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p
                                                   rb, (int)hsel(nb + 4 * k < n_lim, (unsigned)(nb + 4 * k) * 4u, OOB), 0, 0));
             us[0][k] = us[1][k] = uss[0][k] = uss[1][k] = 0.f;
         }
-        // two row halves (= the two statistics chunks of the tile), the residual of one half in registers at a time
+        // two row halves (= the two statistics chunks of the tile); the residual comes out of LDS (the producers put it there)
 #pragma unroll
         for (int ih = 0; ih < 2; ++ih) {
             u32x2 rq[2][4];
 #pragma unroll
             for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int n4 = nb + k * 4;
-                    rq[i2][k] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
-                                                              rr, (int)hsel(n4 < n_lim, (unsigned)(mrow[2 * ih + i2] * p.ldr + n4) * 2u, OOB), 0, 0));
-                }
+                for (int k = 0; k < 4; ++k)
+                    rq[i2][k] = p.res ? *reinterpret_cast<const u32x2 *>(&res_lds[((wn * 4 + 2 * ih + i2) * 4 + k) * RROW + lane * 2]) : u32x2{0u, 0u};
 #pragma unroll
             for (int i2 = 0; i2 < 2; ++i2) {
                 const int i = 2 * ih + i2;
@@ -1013,27 +1072,32 @@ __global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p
                 for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;              // the next tile starts from zero
             }
         }
+        HPC_STAMP(50 + 3 * it);                                            // stores issued
         if (p.gn_partial) {
 #pragma unroll
             for (int r = 0; r < 2; ++r)
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-#pragma unroll
-                    for (int off = 16; off >= 1; off >>= 1) {
-                        us[r][k] += __shfl_xor(us[r][k], off, 64);
-                        uss[r][k] += __shfl_xor(uss[r][k], off, 64);
-                    }
-            float *sl = epi[wave];                                          // [row half][unit = 4 half + k][2]
-            if (pl == 0) {
-#pragma unroll
-                for (int r = 0; r < 2; ++r)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        sl[(r * 8 + hh * 4 + k) * 2] = us[r][k];
-                        sl[(r * 8 + hh * 4 + k) * 2 + 1] = uss[r][k];
-                    }
-            }
+                for (int k = 0; k < 4; ++k) {
+                    estat[wave][(r * 4 + k) * 2][lane] = us[r][k];
+                    estat[wave][(r * 4 + k) * 2 + 1][lane] = uss[r][k];
+                }
+            // The sum over the 32 pixel lanes of a lane half, in the ORDER of the xor butterfly (16, 8, 4, 2, 1) the one-role kernel
+            // runs with 160 cross-lane shuffles (ds_bpermute: ~3 k cycles of an 11 k-cycle epilogue): lane (half, v) reads the 32
+            // values of statistic v and adds them as the same balanced tree — same bits, 32 LDS reads.
             // (same wavefront wrote and reads: program order on LDS suffices)
+            float *sl = epi[wave];                                          // [row half][unit = 4 half + k][2]
+            if (lane < 32) {
+                const int v = lane & 15, h2 = lane >> 4;
+                float t[32];
+#pragma unroll
+                for (int i2 = 0; i2 < 32; ++i2) t[i2] = estat[wave][v][32 * h2 + i2];
+#pragma unroll
+                for (int w2 = 16; w2 >= 1; w2 >>= 1)
+#pragma unroll
+                    for (int i2 = 0; i2 < w2; ++i2) t[i2] = t[i2] + t[i2 + w2];
+                const int r = v >> 3, k = (v >> 1) & 3, which = v & 1;
+                sl[(r * 8 + h2 * 4 + k) * 2 + which] = t[0];
+            }
             const int c4_per_group = p.gn_cpg / 4;
             const int groups_here = 8 / c4_per_group;
             if (lane < groups_here * 2) {
@@ -1056,12 +1120,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p
     };
 
     // prologue: the whole weight ring of step 0 requested; barriers (A), (B) with the producers
+    HPC_STAMP(0);
     w_retile();
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) bload(tap, true);
     w_advance();
     __syncthreads();                                                       // (A)
+    HPC_STAMP(1);
     __syncthreads();                                                       // (B) step 0 staged
+    HPC_STAMP(3);
     int c_s = 0, c_it = 0;                                                 // (slab, tile turn) of the step being multiplied
     // barrier (C): the producers stage step q + 1 while this role multiplies step q; when that step opens a new image they
     // rewrite their table first and everybody meets
@@ -1073,12 +1140,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p
         for (int u = 0; u < 4; ++u) {
             meet_retable(q + u + 1 < Q);
             consume(u & 1, q + u + 1 < Q);
+            HPC_STAMP(4 + 2 * (q + u));                                    // slab multiplied
             __syncthreads();
+            HPC_STAMP(5 + 2 * (q + u));                                    // past the barrier
             ++c_s;
         }
-        if (c_s == slabs) { c_s = 0; epilogue(c_it++); }
+        if (c_s == slabs) { c_s = 0; epilogue(c_it++); HPC_STAMP(40 + c_it); }
     }
 #undef HPC_DS_READ
+#undef HPC_STAMP
 }
 
 // split-K combine: out = round16(sum_z ws[z] + bias + residual), ranges added in the order z = 0, 1, 2, ...; thread = 4
@@ -1390,6 +1460,7 @@ static int hh_conv_impl(const sgam_conv_desc *d, int32_t ht, const void *x, cons
     p.gn_partial_in = gn_partial_in; p.gn_chunks_in = chunks_in; p.gn_eps = gn_eps;
     p.gn_inv_n = 1.0f / ((float)d->Hi * (float)d->Wi * (float)(d->Cin / 32));
     p.gx = p.M / bm; p.gy = d->N / 128;
+    p.dbg = nullptr;
     static const int swz = [] { const char *e = getenv("SGAM_XCD_SWIZZLE"); return (e && e[0] == '0') ? 0 : 1; }();
     p.xcd_swizzle = swz;
     const dim3 grid((unsigned)((int64_t)p.gx * p.gy), (unsigned)pl.ksplit);
@@ -1421,9 +1492,27 @@ static int hh_conv_impl(const sgam_conv_desc *d, int32_t ht, const void *x, cons
         else if (gn) SGAM_KLAUNCH((conv3x3_h16_pc_kernel<HT_, true, false>), pg, dim3(512), 0, s, p);                     \
         else SGAM_KLAUNCH((conv3x3_h16_pc_kernel<HT_, false, false>), pg, dim3(512), 0, s, p);                            \
     } while (0)
+        static const int dbg_on = [] { const char *e = getenv("SGAM_HPC_DBG"); return (e && e[0] == '1') ? 1 : 0; }();
+        static unsigned long long *dbg_buf = nullptr;
+        if (dbg_on) {
+            if (!dbg_buf && hipMalloc((void **)&dbg_buf, 128 * 8) != hipSuccess) dbg_buf = nullptr;
+            if (dbg_buf) (void)hipMemsetAsync(dbg_buf, 0, 128 * 8, s);
+            p.dbg = dbg_buf;
+        }
         if (ht == 0) HPC_LAUNCH(0); else HPC_LAUNCH(1);
 #undef HPC_LAUNCH
         SGAM_LAUNCH_CHECK();
+        if (dbg_on && dbg_buf) {               // debug only: synchronises and prints workgroup 0's stamps relative to its first
+            unsigned long long h[128];
+            if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h, dbg_buf, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+                const unsigned long long t0 = h[0] < h[64] ? h[0] : h[64];
+                fprintf(stderr, "HPC_DBG consumer:");
+                for (int i = 0; i < 64; ++i) if (h[i]) fprintf(stderr, " %d:%llu", i, h[i] - t0);
+                fprintf(stderr, "\nHPC_DBG producer:");
+                for (int i = 64; i < 128; ++i) if (h[i]) fprintf(stderr, " %d:%llu", i - 64, h[i] - t0);
+                fprintf(stderr, "\n");
+            }
+        }
         return SGAM_OK;
     }
     if (gn_partial_in) {
