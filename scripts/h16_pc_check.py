@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """The persistent producer / consumer form of the 16-bit 128-row halo kernel against the one-role kernel it replaces: every
 output (16-bit / fp32 tensor, GroupNorm chunk statistics) must be BIT-IDENTICAL.  The kernel is chosen per process
-(SGAM_HPC), so the script runs itself twice and compares digests:   python scripts/h16_pc_check.py"""
+(SGAM_HPC=1: producer / consumer), so the script runs itself twice and compares digests:   python scripts/h16_pc_check.py"""
 import ctypes
 import hashlib
 import json

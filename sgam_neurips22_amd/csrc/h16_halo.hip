@@ -1496,8 +1496,10 @@ static int hh_conv_impl(const sgam_conv_desc *d, int32_t ht, const void *x, cons
         else if (gn) SGAM_KLAUNCH((conv3x3_h16_halo_kernel<BM_, 128, HT_, true, false, false>), grid, dim3(256), 0, s, p);        \
         else SGAM_KLAUNCH((conv3x3_h16_halo_kernel<BM_, 128, HT_, false, false>), grid, dim3(256), 0, s, p);                     \
     } while (0)
-    // the 128-row tile, whole K, no upsampling: the persistent producer / consumer kernel (SGAM_HPC=0: the kernel above)
-    static const int hpc_on = [] { const char *e = getenv("SGAM_HPC"); return (e && e[0] == '0') ? 0 : 1; }();
+    // the 128-row tile, whole K, no upsampling: the persistent producer / consumer kernel — OPT-IN (SGAM_HPC=1).  Bit-identical to the
+    // one-role kernel (scripts/h16_pc_check.py) and its consumers run at 0.8 of the matrix pipe, but the launch as a whole measured
+    // 28.8 against 26.2 us at B = 1 and 108 against 100 us per launch at B = 8: not the default.
+    static const int hpc_on = [] { const char *e = getenv("SGAM_HPC"); return (e && e[0] == '1') ? 1 : 0; }();
     static const int n_cu = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;

@@ -831,10 +831,12 @@ def vq_topk(dist, k):
 # ------------------------------------------------------------------------------------------------
 # warps and frame feedback
 # ------------------------------------------------------------------------------------------------
-# which forward splat runs: True = target-owned LDS z-tiles (no global atomics), False = the two-pass device-scope atomicMax form,
-# None (default, SGAM_SPLAT_TILED unset / "auto") = by size: the tiled form from SPLAT_TILED_MIN_POINTS source points on — below
-# it a launch is latency-bound and the two forms cost the same few microseconds
-SPLAT_TILED = {"0": False, "1": True}.get(os.environ.get("SGAM_SPLAT_TILED", "auto"))
+# which forward splat runs: False (default) = the two-pass device-scope atomicMax form, True (SGAM_SPLAT_TILED=1) = target-owned LDS
+# z-tiles (no global atomics), None ("auto") = the tiled form from SPLAT_TILED_MIN_POINTS source points on.  Measured (DESIGN.md
+# 4.2, bench `roofline_warp`): on the scene loop's own geometry (smooth depth: neighbouring points hit neighbouring pixels, the
+# atomics coalesce) the two-pass form is 10 % FASTER at every size (150 against 167 us for 12.6 M points); on an incoherent scatter
+# (white-noise depth) the tiled form is 1.9 x faster (183 against 352 us).  Both are bit-identical to the reference.
+SPLAT_TILED = {"0": False, "1": True, "auto": None}.get(os.environ.get("SGAM_SPLAT_TILED", "0"), False)
 SPLAT_TILED_MIN_POINTS = int(os.environ.get("SGAM_SPLAT_TILED_MIN_POINTS", 1 << 20))
 _SPLAT_WS = {}
 
