@@ -162,10 +162,21 @@ def test_export_to_disk_writes_the_reference_layout(tmp_path):
         sc.frames[(i, j)] = {"index": n, "rgb_u8": torch.from_numpy(rs.randint(0, 256, (64, 64, 3), dtype=np.uint8)),
                              "depth": torch.from_numpy(rs.uniform(1, 4, (64, 64)).astype(np.float32))}
         sc.transform_grid[i][j] = {"R": rs.randn(3, 3), "t": rs.randn(3)}
-    sc.export_to_disk(str(tmp_path / "out"))
+    sc.K = np.array([[60.0, 0, 32], [0, 60.0, 32], [0, 0, 1]])
+    sc.use_rgbd_integration, sc.volume = False, None
+    counts = sc.export_to_disk(str(tmp_path / "out"))
     names = sorted(p.name for p in (tmp_path / "out").iterdir())
-    assert names == sorted(f"{k}_{n:05d}_{i:02d}_{j:02d}.{e}" for n, (i, j) in enumerate([(0, 0), (0, 1), (1, 2)])
-                           for k, e in (("im", "png"), ("dm", "npy"), ("R", "npy"), ("t", "npy")))
+    assert names == sorted([f"{k}_{n:05d}_{i:02d}_{j:02d}.{e}" for n, (i, j) in enumerate([(0, 0), (0, 1), (1, 2)])
+                            for k, e in (("im", "png"), ("dm", "npy"), ("R", "npy"), ("t", "npy"))] + ["merged_pcds.ply"])
+    # the run tail's merged per-view point cloud (inference_pipeline.py:441-445): every frame unprojected, in frame order
+    from sgam_neurips22_amd import pointcloud
+    assert counts == {"merged_pcds.ply": 3 * 64 * 64}
+    merged = pointcloud.read_ply(tmp_path / "out" / "merged_pcds.ply")
+    fr1 = sc.frames[(0, 1)]
+    Rt = np.eye(4)
+    Rt[:3, :3], Rt[:3, 3] = sc.transform_grid[0][1]["R"], sc.transform_grid[0][1]["t"]
+    pts, _ = pointcloud.unproject_frame(fr1["depth"].numpy(), fr1["rgb_u8"].numpy(), sc.K, Rt)
+    assert np.array_equal(merged["points"][4096:8192], pts) and np.array_equal(merged["colors_u8"][4096:8192], fr1["rgb_u8"].numpy().reshape(-1, 3))
     for (i, j), fr in sc.frames.items():
         sfx = f"{fr['index']:05d}_{i:02d}_{j:02d}"
         assert np.array_equal(np.array(Image.open(tmp_path / "out" / f"im_{sfx}.png")), fr["rgb_u8"].numpy())
