@@ -92,6 +92,7 @@ struct HHParams {
     int gn_chunks_in;
     float gn_inv_n, gn_eps;
     unsigned long long *dbg;      // SGAM_HPC_DBG=1: cycle stamps of workgroup 0 (producer / consumer kernel), else NULL
+    int dbg_flags;                // SGAM_HPC_DBGF: timing experiments of that kernel (results wrong): 1 no MFMAs, 2 no producer priority
 };
 
 __device__ __forceinline__ unsigned hsel(bool c, unsigned a, unsigned b) {
@@ -679,17 +680,14 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
 // swish / 16-bit packing of the halo —, 515 scalar, 412 LDS, 110 vector-memory), 18 k issue-stalled behind an MFMA, 10 - 12 k
 // parked at s_waitcnt / barriers.  Two such wavefronts per SIMD leave the pipe 0.24 - 0.30 busy, and no placement of scheduling
 // barriers, deeper prefetch or L2 warm-up moved it: the wavefront is in-order, and it does everything.
-// Here the roles are split.  A workgroup is TWELVE wavefronts on one CU (three per SIMD, <= 168 registers each):
+// Here the roles are split.  A workgroup is EIGHT wavefronts on one CU:
 //   * wavefronts 0 - 3, the consumers: each owns all 128 rows x 32 channels (the 1 x 4 layout above) and issues nothing but
-//     A-fragment reads (explicit ds_read_b128, one k-step ahead), weight-fragment loads (three register sets, two taps ahead)
-//     and MFMAs — ~11 instructions per four MFMAs.  Cycle stamps (SGAM_HPC_DBG): 2.8 - 3.0 k cycles per slab of 2.3 k MFMA
-//     cycles when nothing holds them up — 0.8 of the matrix pipe, against 0.3 for the one-role kernel;
-//   * wavefronts 4 - 11, the producers: load the halo two slabs ahead, apply GroupNorm (+ swish), round to 16 bits and store it
-//     to the other LDS buffer; they also bring the tile's residual into LDS in the consumers' epilogue order.  EIGHT of them
-//     because a single wavefront issues a VALU instruction only every 8 - 11 cycles (scripts/micro/mfma_valu_overlap.hip: 16 k
-//     independent v_fma_f32 in 64 us): four producers needed 3.3 k cycles for a slab's staging and the consumers waited for them.
-//     (The same micro-benchmark shows MFMA and VALU streams of different wavefronts on one SIMD overlapping almost perfectly —
-//     72 + 64 us of work in 83 — so the staging does hide beside the MFMAs once enough wavefronts issue it.)
+//     A-fragment reads (explicit ds_read_b128, two k-steps ahead, three register sets), weight-fragment loads (nine register
+//     sets, one per tap, each refilled for the NEXT slab as soon as its tap is done: 4 600 MFMA-cycles ahead) and MFMAs —
+//     ~13 instructions per four MFMAs;
+//   * wavefronts 4 - 7, the producers: load the next slab's halo (one slab ahead of the one they normalise), apply GroupNorm
+//     (+ swish), round to 16 bits and store it to the other LDS buffer — on the VALU of the same four SIMDs, beside the
+//     consumers' MFMAs instead of in front of them.
 // One s_barrier per slab couples them.  The workgroup is PERSISTENT: 256 workgroups walk tiles blockIdx.x, + gridDim.x, ...
 // as ONE stream of slabs, so the producers are already staging the next tile's first slab while the consumers store the
 // finished tile (the epilogue of tile t overlaps the prologue of tile t + 1), and the consumers' weight ring never drains.
@@ -700,12 +698,11 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
 // ---------------------------------------------------------------------------------------------------------------------
 
 template <int HT, bool GN, bool SW>
-__global__ __launch_bounds__(768) void conv3x3_h16_pc_kernel(const HHParams p) {
+__global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p) {
     constexpr int BM = 128, BN = 128, TH = 8, TW = 16, TWS = 4;
     constexpr int HROWS = TH + 2, HWID = TW + 2, HR = HROWS * HWID;       // 10 x 18 halo pixels
     constexpr int XBK = 32, XLD = XBK + 8, LP = 768, HPL = HROWS * LP;    // halfs per slab buffer
-    constexpr int NPROD = 512;                                             // producer threads (eight wavefronts)
-    constexpr int NH = (HR * 4 + NPROD - 1) / NPROD;                       // 16-byte halo pieces per producer thread: 2
+    constexpr int NH = (HR * 4 + 255) / 256;                               // 16-byte halo pieces per producer thread: 3
     constexpr int TM = 4;
     __shared__ __attribute__((aligned(16))) unsigned short smem[2 * HPL];
     __shared__ __attribute__((aligned(16))) float gn_tab[2][GN ? SGAM_HGN_MAXC : 4];
@@ -719,7 +716,7 @@ __global__ __launch_bounds__(768) void conv3x3_h16_pc_kernel(const HHParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool producer = wave >= 4;
     // (debug: s_memtime stamps of workgroup 0 — consumer wavefront 0 in slots 0.., producer wavefront 4 in slots 64..)
-#define HPC_STAMP(slot) do { if (p.dbg && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4) && (slot) < 64) p.dbg[(producer ? 64 : 0) + (slot)] = __builtin_readcyclecounter(); } while (0)
+#define HPC_STAMP(slot) do { if (p.dbg && blockIdx.x == 0 && lane == 0 && (wave & 3) == 0 && (slot) < 64) p.dbg[(producer ? 64 : 0) + (slot)] = __builtin_readcyclecounter(); } while (0)
     const int tiles_total = p.gx * p.gy, slabs = p.slabs, G = (int)gridDim.x;
     const int my_tiles = (tiles_total - (int)blockIdx.x + G - 1) / G;      // (host: gridDim.x <= tiles)
     const int Q = my_tiles * slabs;                                        // this workgroup's stream of slab steps
@@ -751,7 +748,7 @@ __global__ __launch_bounds__(768) void conv3x3_h16_pc_kernel(const HHParams p) {
     auto fill_table = [&](int b) {                                         // producers only: 256 threads
         if constexpr (GN) {
             const int cpg = p.Cin / 32;
-            for (int c = tid - 256; c < p.Cin; c += NPROD) {
+            for (int c = tid - 256; c < p.Cin; c += 256) {
                 const int g = c / cpg;
                 const float mean = p.gn_stats[(b * 32 + g) * 2], rstd = p.gn_stats[(b * 32 + g) * 2 + 1];
                 const float sc = rstd * p.gn_gamma[c];
@@ -773,8 +770,8 @@ __global__ __launch_bounds__(768) void conv3x3_h16_pc_kernel(const HHParams p) {
         int h_lds[NH], h_row[NH];
 #pragma unroll
         for (int j = 0; j < NH; ++j) {
-            int idx = ptid + NPROD * j;
-            if (idx >= HR * 4) idx -= NPROD;                               // (a piece staged twice: same bytes to the same place)
+            int idx = ptid + 256 * j;
+            if (idx >= HR * 4) idx -= 256;                                 // (a piece staged twice: same bytes to the same place)
             h_row[j] = idx >> 2;
             h_lds[j] = (h_row[j] / HWID) * LP + (h_row[j] % HWID) * XLD + (idx & 3) * 8;
         }
@@ -830,20 +827,30 @@ __global__ __launch_bounds__(768) void conv3x3_h16_pc_kernel(const HHParams p) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 HPC_STAMP(dbg_slot);
             }
+            // A single wavefront issues a VALU instruction only every 8 - 11 cycles (scripts/micro/mfma_valu_overlap.hip), so the
+            // staging is counted in INSTRUCTIONS: the two channels of a dword travel as one float2 through packed multiply-adds and
+            // leave through one packed conversion (the element-wise spelling of the one-role kernel compiles to ~8 per element —
+            // separate shifts, ors and selects around the same arithmetic); same operations on the same values: same bits.
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
             for (int j = 0; j < NH; ++j) {
                 u32x4 q = hreg[set][j];
                 if constexpr (GN) {
 #pragma unroll
                     for (int w2 = 0; w2 < 4; ++w2) {
-                        float v0 = HH<HT>::to_f((unsigned short)(q[w2] & 0xFFFFu)), v1 = HH<HT>::to_f((unsigned short)(q[w2] >> 16));
-                        v0 = v0 * gsc[2 * w2] + gsh[2 * w2];
-                        v1 = v1 * gsc[2 * w2 + 1] + gsh[2 * w2 + 1];
+                        f32x2 v;
+                        if constexpr (HT == 0) v = f32x2{__builtin_bit_cast(float, q[w2] << 16), __builtin_bit_cast(float, q[w2] & 0xFFFF0000u)};
+                        else v = f32x2{HH<HT>::to_f((unsigned short)(q[w2] & 0xFFFFu)), HH<HT>::to_f((unsigned short)(q[w2] >> 16))};
+                        const f32x2 sc = {gsc[2 * w2], gsc[2 * w2 + 1]}, sh = {gsh[2 * w2], gsh[2 * w2 + 1]};
+                        v = v * sc + sh;
                         if constexpr (SW) {
-                            v0 = sgam_swish(v0);
-                            v1 = sgam_swish(v1);
+                            const f32x2 t = v * -1.4426950408889634f;
+                            const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                            const f32x2 d = e + 1.0f;
+                            const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+                            v = v * r;
                         }
-                        q[w2] = (unsigned)HH<HT>::from_f(v0) | ((unsigned)HH<HT>::from_f(v1) << 16);
+                        q[w2] = (unsigned)HH<HT>::from_f(v[0]) | ((unsigned)HH<HT>::from_f(v[1]) << 16);
                     }
                     if (p_off[set][j] == 0xFFFFFFFFu) q = u32x4{0u, 0u, 0u, 0u};       // zero padding applies to the normalised tensor
                 }
@@ -858,7 +865,7 @@ __global__ __launch_bounds__(768) void conv3x3_h16_pc_kernel(const HHParams p) {
         // residual of the tile the consumers are finishing: requested while they multiply its second-to-last slab, written to LDS
         // (their epilogue's order) while they multiply its last: the epilogue finds it behind the barrier instead of waiting two
         // memory round trips for it (cycle stamps: 8.4 k of the epilogue's 11 k cycles went until its stores were issued)
-        u32x2 rres[8];
+        u32x2 rres[16];
         int r_s = 0, r_it = 0;                                             // (slab, tile turn) of the step the consumers multiply
         auto residual = [&]() {
             if (p.res) {
@@ -869,8 +876,8 @@ __global__ __launch_bounds__(768) void conv3x3_h16_pc_kernel(const HHParams p) {
                     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void *)p.res, 0, (int)r_bytes, 0x00020000);
                     const int c = ptid & 31;                               // 8-byte chunk of the pixel's 128 channels
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        const int trow = (ptid >> 5) + 16 * r;
+                    for (int r = 0; r < 16; ++r) {
+                        const int trow = (ptid >> 5) + 8 * r;
                         const int m = (b * p.Ho + ty0 + (trow >> TWS)) * p.Wo + tx0 + (trow & (TW - 1));
                         const int n4 = n0 + 4 * c;
                         rres[r] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
@@ -880,8 +887,8 @@ __global__ __launch_bounds__(768) void conv3x3_h16_pc_kernel(const HHParams p) {
                     const int c = ptid & 31;
                     const int wn_ = c >> 3, hh_ = (c >> 2) & 1, k_ = c & 3;
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        const int trow = (ptid >> 5) + 16 * r;
+                    for (int r = 0; r < 16; ++r) {
+                        const int trow = (ptid >> 5) + 8 * r;
                         const int i_ = trow >> 5, lane_ = hh_ * 32 + (trow & 31);
                         *reinterpret_cast<u32x2 *>(&res_lds[((wn_ * 4 + i_) * 4 + k_) * RROW + lane_ * 2]) = rres[r];
                     }
@@ -889,7 +896,7 @@ __global__ __launch_bounds__(768) void conv3x3_h16_pc_kernel(const HHParams p) {
             }
             if (++r_s == slabs) { r_s = 0; ++r_it; }
         };
-        __builtin_amdgcn_s_setprio(2);          // the second-dispatched half of the workgroup loses every arbitration otherwise
+        if (!(p.dbg_flags & 2)) __builtin_amdgcn_s_setprio(2);          // the second-dispatched half loses every arbitration otherwise (debug bit 1: off)
         // Two register sets, every load requested TWO steps before it is staged: step q + 1 is staged (set (q + 1) & 1) while the
         // consumers multiply step q, then step q + 3 is requested into the set just freed.  What is outstanding when a set is
         // waited for is the other set, requested a whole step earlier: a conservative wait of the compiler (across the back edge)
@@ -942,35 +949,37 @@ __global__ __launch_bounds__(768) void conv3x3_h16_pc_kernel(const HHParams p) {
         a_rel[i] = 2u * (unsigned)((r >> TWS) * LP + (r & (TW - 1)) * XLD + frag_k);
     }
     const unsigned smem_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short *)smem;
-    // weight ring: three register sets rotating with the tap, requested two taps ahead (the one-role kernel's ring; nine sets, one
-    // per tap, fit 512 threads but not the 168 registers of three wavefronts per SIMD).  Plain buffer loads: the compiler counts the
-    // waits — exactly, the four-slab body below is straight-line code.  (A first version issued them as inline asm with hand-
-    // counted waits: under register pressure the compiler copies such a "defined" value elsewhere and re-uses the register before
-    // the data lands — the late write then hit live addresses: memory faults.)
-    u32x4 bq[3][2];
-    int w_it = 0, w_s = 0;                                                 // (tile turn, slab) of the step AFTER the one being multiplied
-    unsigned w_voff = 0, c_voff = 0;                                       // fragment offset (channel tile + lane) of that step / the current one
-    int cs_ = 0;                                                           // slab of the current step
+    // weight ring: one register set per tap, refilled for the next step right after its tap.  Plain buffer loads: the compiler
+    // counts the waits (exactly inside the four-slab body below; conservatively only where the ring crosses its back edge, i.e.
+    // behind an epilogue when a tile is four slabs — by then everything has landed).  (A first version issued them as inline asm
+    // with hand-counted waits: under register pressure the compiler copies such a "defined" value elsewhere and re-uses the
+    // register before the data lands — the late write then hit live addresses: memory faults.)
+    u32x4 bq[9][2];
+    int w_it = 0, w_s = 0;                                                 // (tile turn, slab) the NEXT weight loads belong to
+    unsigned w_voff = 0;                                                   // fragment offset of that step's channel tile + lane
     auto w_retile = [&]() {
         int b, ty0, tx0, n0;
         decode(w_it, b, ty0, tx0, n0);
         const int nt = (n0 + wn * 32) >> 5;
         w_voff = ((unsigned)nt * ((unsigned)p.ldb / 32u) * 128u + (unsigned)lane) * 16u;
     };
-    // (!live: an out-of-range offset — zeros come back, no memory traffic, and the slab body stays free of branches, which is
-    // what keeps the compiler's wait counts exact)
-    auto bload = [&](const int set, const int tap, const int slab, const unsigned voff, const bool live) {
-        const unsigned koff = (unsigned)(tap * p.Cin + slab * XBK) * 64u;  // 2048 bytes per (row tile, slab); scalar offset
-        const unsigned vo = live ? voff : 0xFFFFFFF0u;
-        bq[set][0] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)vo, (int)koff, 0);
-        bq[set][1] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)vo, (int)(koff + 1024u), 0);
+    // (the fragments of (w_it, w_s, tap) into set `tap`; !live: an out-of-range offset — zeros come back, no memory traffic, and
+    // the slab body stays free of branches, which is what keeps the compiler's wait counts exact)
+    auto bload = [&](const int tap, const bool live) {
+        const unsigned koff = (unsigned)(tap * p.Cin + w_s * XBK) * 64u;   // 2048 bytes per (row tile, slab); scalar offset
+        const unsigned vo = live ? w_voff : 0xFFFFFFF0u;
+        bq[tap][0] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)vo, (int)koff, 0);
+        bq[tap][1] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)vo, (int)(koff + 1024u), 0);
+    };
+    auto w_advance = [&]() {
+        if (++w_s == slabs) { w_s = 0; ++w_it; if (w_it < my_tiles) w_retile(); }
     };
     f32x16 acc[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-    u32x4 fa[2][TM];
+    u32x4 fa[3][TM];
 #define HPC_DS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
     unsigned a_lds[TM];
     auto afrag = [&](const int set, const int tap, const int kk) {
@@ -978,32 +987,30 @@ __global__ __launch_bounds__(768) void conv3x3_h16_pc_kernel(const HHParams p) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) HPC_DS_READ(fa[set][i], a_lds[i], 2 * (ky * LP + kx * XLD + kk * 16));
     };
-    // one slab step out of LDS buffer `buf`: 9 taps x 2 k-steps x 4 MFMAs; `more`: another step follows (its taps 0, 1 are requested
-    // during taps 7, 8)
-    auto consume = [&](const int buf, const bool more) {
+    // one slab step out of LDS buffer `buf`: 9 taps x 2 k-steps x 4 MFMAs
+    auto consume = [&](const int buf, const bool refill) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) a_lds[i] = smem_lds + (unsigned)(buf * HPL * 2) + a_rel[i];
+        afrag(0, 0, 0);
+        afrag(1, 0, 1);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            if (tap < 7) bload((tap + 2) % 3, tap + 2, cs_, c_voff, true);
-            else bload((tap + 2) % 3, tap - 7, w_s, w_voff, more);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const int k18 = tap * 2 + kk;
-                if (k18 == 0) afrag(0, 0, 0);
-                if (k18 < 17) afrag((k18 + 1) & 1, (k18 + 1) >> 1, (k18 + 1) & 1);
-                const int s2 = k18 & 1;
-                if (k18 < 17) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[s2][0]), "+v"(fa[s2][1]), "+v"(fa[s2][2]), "+v"(fa[s2][3]));
-                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[s2][0]), "+v"(fa[s2][1]), "+v"(fa[s2][2]), "+v"(fa[s2][3]));
+                if (k18 + 2 < 18) afrag((k18 + 2) % 3, (k18 + 2) >> 1, (k18 + 2) & 1);
+                const int s3 = k18 % 3;
+                if (k18 + 2 < 18) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(fa[s3][0]), "+v"(fa[s3][1]), "+v"(fa[s3][2]), "+v"(fa[s3][3]));
+                else if (k18 + 1 < 18) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[s3][0]), "+v"(fa[s3][1]), "+v"(fa[s3][2]), "+v"(fa[s3][3]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[s3][0]), "+v"(fa[s3][1]), "+v"(fa[s3][2]), "+v"(fa[s3][3]));
+                if (!(p.dbg_flags & 1)) {                 // (debug bit 0: the consumers skip their MFMAs)
 #pragma unroll
-                for (int i = 0; i < TM; ++i) acc[i] = HH<HT>::mfma(bq[tap % 3][kk], fa[s2][i], acc[i]);
+                    for (int i = 0; i < TM; ++i) acc[i] = HH<HT>::mfma(bq[tap][kk], fa[s3][i], acc[i]);
+                }
             }
+            bload(tap, refill);                                            // same tap, next step
         }
-        if (more) {                                                        // the next step becomes the current one
-            cs_ = w_s;
-            c_voff = w_voff;
-            if (++w_s == slabs) { w_s = 0; ++w_it; if (w_it < my_tiles) w_retile(); }
-        }
+        if (refill) w_advance();
     };
 
     // ---- epilogue of one tile (the direct epilogue of conv3x3_h16_halo_kernel: lane = one pixel x 16 consecutive channels)
@@ -1138,13 +1145,12 @@ __global__ __launch_bounds__(768) void conv3x3_h16_pc_kernel(const HHParams p) {
         }
     };
 
-    // prologue: taps 0 and 1 of step 0 requested; barriers (A), (B) with the producers
+    // prologue: the whole weight ring of step 0 requested; barriers (A), (B) with the producers
     HPC_STAMP(0);
     w_retile();
-    c_voff = w_voff;
-    bload(0, 0, 0, c_voff, true);
-    bload(1, 1, 0, c_voff, true);
-    if (Q > 1) { if (++w_s == slabs) { w_s = 0; ++w_it; if (w_it < my_tiles) w_retile(); } }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) bload(tap, true);
+    w_advance();
     __syncthreads();                                                       // (A)
     HPC_STAMP(1);
     __syncthreads();                                                       // (B) step 0 staged
@@ -1481,6 +1487,8 @@ static int hh_conv_impl(const sgam_conv_desc *d, int32_t ht, const void *x, cons
     p.gn_inv_n = 1.0f / ((float)d->Hi * (float)d->Wi * (float)(d->Cin / 32));
     p.gx = p.M / bm; p.gy = d->N / 128;
     p.dbg = nullptr;
+    static const int dbgf = [] { const char *e = getenv("SGAM_HPC_DBGF"); return e ? atoi(e) : 0; }();
+    p.dbg_flags = dbgf;
     static const int swz = [] { const char *e = getenv("SGAM_XCD_SWIZZLE"); return (e && e[0] == '0') ? 0 : 1; }();
     p.xcd_swizzle = swz;
     const dim3 grid((unsigned)((int64_t)p.gx * p.gy), (unsigned)pl.ksplit);
@@ -1510,9 +1518,9 @@ static int hh_conv_impl(const sgam_conv_desc *d, int32_t ht, const void *x, cons
         const dim3 pg((unsigned)(tiles_total < n_cu ? tiles_total : n_cu));
 #define HPC_LAUNCH(HT_)                                                                                                   \
     do {                                                                                                                  \
-        if (gn && p.gn_swish) SGAM_KLAUNCH((conv3x3_h16_pc_kernel<HT_, true, true>), pg, dim3(768), 0, s, p);             \
-        else if (gn) SGAM_KLAUNCH((conv3x3_h16_pc_kernel<HT_, true, false>), pg, dim3(768), 0, s, p);                     \
-        else SGAM_KLAUNCH((conv3x3_h16_pc_kernel<HT_, false, false>), pg, dim3(768), 0, s, p);                            \
+        if (gn && p.gn_swish) SGAM_KLAUNCH((conv3x3_h16_pc_kernel<HT_, true, true>), pg, dim3(512), 0, s, p);             \
+        else if (gn) SGAM_KLAUNCH((conv3x3_h16_pc_kernel<HT_, true, false>), pg, dim3(512), 0, s, p);                     \
+        else SGAM_KLAUNCH((conv3x3_h16_pc_kernel<HT_, false, false>), pg, dim3(512), 0, s, p);                            \
     } while (0)
         static const int dbg_on = [] { const char *e = getenv("SGAM_HPC_DBG"); return (e && e[0] == '1') ? 1 : 0; }();
         static unsigned long long *dbg_buf = nullptr;
