@@ -78,6 +78,21 @@ typedef struct sgam_conv_desc {
     /* optional plan override (autotuner, sgam_neurips22_amd/tune.py); 0 = built-in heuristic.
      * (plan_bm, plan_bn) in {(128,128), (64,128), (64,64)}; plan_ksplit >= 1. */
     int32_t plan_bm, plan_bn, plan_ksplit;
+    /* optional (split fp32 and 16-bit families): `arrive_count` int32 arrival counters in device memory, ZERO on entry; a
+     * split-K launch whose tiles fit them sums the partial tiles inside the convolution kernel (the last split of a tile to
+     * arrive does it, in the fixed slab order of the combine kernels) instead of launching a combine, and leaves the
+     * counters zero again.  One launch at a time may use a given counter array (launches on ONE stream qualify).
+     * NULL / 0: partial tiles + combine launch.  sgam_conv2d_f32x_fixup / sgam_conv2d_h16_fixup say which it will be;
+     * the *_stats_chunks queries follow it (one statistics chunk per output tile). */
+    int32_t arrive_count;
+    /* 1: the statistics a launch leaves for the next GroupNorm (the `gn_partial` argument of the *_stats / *_gn / *_gnp entry
+     * points) are [B][16][32][4] int64 ACCUMULATORS instead of per-chunk records: {sum hi, sum lo, sumsq hi, sumsq lo} in 2^-40
+     * fixed point (hi in units of 2^-8, lo = 32 fraction bits), added with 64-bit atomics — integer sums do not depend on
+     * the order the workgroups arrive in, so no fold launch is needed between producer and consumer and results stay
+     * run-to-run identical.  ZERO before the launch.  Consumers take them through the *_gnp entry points with
+     * chunks_in = 0 (every GroupNorm-fusing kernel), sgam_groupnorm_stats_from_partials_f32 / *_from_partials_* with nchunk = 0. */
+    int32_t stats_acc;
+    int32_t *arrive;
 } sgam_conv_desc;
 
 int64_t sgam_conv2d_workspace_bytes(const sgam_conv_desc *d);
@@ -120,6 +135,8 @@ int sgam_pack_conv_weight(const float *w_oihw, float *w_packed, int32_t Cout, in
  * side does exactly that (VQModel.forward, InfiniteSceneGeneration.scene_expansion).  NULL (default) disables the
  * reporting.  This pointer is the library's only mutable global: one flag per process (= per GPU). */
 int sgam_f32x_set_range_flag(int32_t *device_flag);
+/* 1 when a launch of this descriptor (with its `arrive` counters) combines its split-K partial tiles inside the kernel */
+int32_t sgam_conv2d_f32x_fixup(const sgam_conv_desc *d);
 int64_t sgam_conv2d_f32x_workspace_bytes(const sgam_conv_desc *d);
 int sgam_conv2d_f32x_plan(const sgam_conv_desc *d, int32_t *bm, int32_t *bn, int32_t *ksplit);
 int sgam_conv2d_nhwc_f32x(const sgam_conv_desc *d, const float *x, float a_scale, const void *w_planes,
@@ -469,6 +486,10 @@ int sgam_gemm_panel_f32x(const float *x, int32_t lda, const float *mean_rstd, co
 int sgam_gemm_gn_f32x(const float *x, int32_t lda, const float *mean_rstd, const float *gamma, const float *beta, const void *w_planes,
                       float w_scale, const float *bias, float *out, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t HW,
                       void *stream);
+/* ... with the statistics of x as the [B][16][32][4] int64 accumulators its producer left (sgam_conv_desc.stats_acc): no fold launch */
+int sgam_gemm_gn_acc_f32x(const float *x, int32_t lda, const int64_t *gn_acc, float eps, const float *gamma, const float *beta,
+                          const void *w_planes, float w_scale, const float *bias, float *out, int32_t ldc, int32_t M, int32_t N,
+                          int32_t K, int32_t HW, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * f1 — TSDF fusion of the generated RGB-D frames + depth render at the target pose.  Replaces

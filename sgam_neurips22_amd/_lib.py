@@ -14,7 +14,7 @@ class ConvDesc(ctypes.Structure):
     """mirror of struct sgam_conv_desc"""
     _fields_ = [(n, c_i32) for n in (
         "B", "Hi", "Wi", "Cin", "Ho", "Wo", "N", "KH", "KW", "stride", "pad_t", "pad_l", "upsample2x",
-        "lda", "ldb", "ldc", "ldr", "n_valid", "bias_per_row", "plan_bm", "plan_bn", "plan_ksplit")]
+        "lda", "ldb", "ldc", "ldr", "n_valid", "bias_per_row", "plan_bm", "plan_bn", "plan_ksplit", "arrive_count", "stats_acc")] + [("arrive", c_vp)]
 
 
 class TsdfGrid(ctypes.Structure):
@@ -23,7 +23,7 @@ class TsdfGrid(ctypes.Structure):
 
 
 # name -> (restype, argtypes); must list every symbol include/sgam_hip.h declares
-ABI_VERSION = 6      # include/sgam_hip.h: sgam_abi_version() of the library these prototypes were written against
+ABI_VERSION = 7      # include/sgam_hip.h: sgam_abi_version() of the library these prototypes were written against
 
 PROTOTYPES = {
     "sgam_abi_version": (c_i32, []),
@@ -42,6 +42,7 @@ PROTOTYPES = {
                                         c_vp]),
     "sgam_pack_conv_weight": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "sgam_f32x_set_range_flag": (c_i32, [c_vp]),
+    "sgam_conv2d_f32x_fixup": (c_i32, [ctypes.POINTER(ConvDesc)]),
     "sgam_conv2d_f32x_workspace_bytes": (c_i64, [ctypes.POINTER(ConvDesc)]),
     "sgam_conv2d_f32x_plan": (c_i32, [ctypes.POINTER(ConvDesc), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32),
                                       ctypes.POINTER(c_i32)]),
@@ -70,6 +71,8 @@ PROTOTYPES = {
     "sgam_gemm_gn_f32x_fits": (c_i32, [c_i32, c_i32, c_i32, c_i32]),
     "sgam_gemm_panel_f32x": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32,
                                      c_i32, c_vp]),
+    "sgam_gemm_gn_acc_f32x": (c_i32, [c_vp, c_i32, c_vp, c_f32, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                      c_vp]),
     "sgam_gemm_gn_f32x": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "sgam_im2col_t_f32": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_i32, c_i64, c_vp]),
     "sgam_col2im_gather_f32": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_i32, c_vp]),

@@ -57,12 +57,15 @@ struct XParams {
     // ... or, instead of gn_stats, the producer's partial sums [B][gn_chunks_in][32][2] (fp64 {sum, sumsq} per chunk and group),
     // folded by the consumer itself (GNF kernels: a few chunks, one or two channel slabs per workgroup — no fold launch)
     const double *gn_partial_in;
+    const long long *gn_acc_in;   // ... or as the [B][32][4] int64 accumulators of sgam_common.h (any GN kernel: 32 bytes per group)
     double gn_inv_n;     // 1 / (pixels per image x channels per group)
     int gn_chunks_in;
     float gn_eps;
     int red_tc;          // group-major split-K combine: channels per workgroup tile (32, 16 or 8); 0 = row-major combine
+    int *arrive;         // optional: one arrival counter per output tile (zero between launches): the LAST split of a tile sums it (xfixup)
 
     double *gn_partial;  // optional: per-(row-half of the tile, group) {sum, sumsq} of the OUTPUT for the next GroupNorm
+    int gn_acc;          // ... 1: gn_partial is the [B][32][4] int64 ACCUMULATOR form (sgam_common.h: atomics instead of chunk records)
     int gn_cpg;          // channels per group of that GroupNorm (N / 32)
     int32_t *range_flag; // optional: set to 1 when an output is not finite (an operand left fp16's range, see sgam_hip.h)
     float inv_w_scale;   // 1 / (a_scale * w_scale), an exact power of two
@@ -187,6 +190,119 @@ __device__ __forceinline__ void gn_scale_shift(const XParams &p, int b, int c, f
     t1 = f32x4{sc[2], sh[2], sc[3], sh[3]};
 }
 
+// ---- split-K without a combine launch.  Every split of an output tile stores its partial tile to the workspace with the
+// device-coherent cache policy (sc1: written through the XCD's L2, which is NOT coherent with the other seven), waits for the
+// stores to be acknowledged and takes a ticket from the tile's arrival counter (a device-scope atomic, executed memory-side).
+// The workgroup that draws the last ticket sums the ksplit partial tiles — device-coherent loads, slabs in the FIXED order
+// z = 0, 1, 2 ... exactly like the combine kernels, so the result does not depend on which split arrives last — un-scales,
+// adds bias and residual, writes the output rows and, when asked, the GroupNorm statistics of what it wrote (one chunk per
+// tile: hw / BM chunks per image, <= 16 on the 16^2 / 32^2 maps, which the consuming convolution folds itself), then puts
+// the counter back to zero for the next launch.  256 threads (k-group 0 of the 64 x 64 tile), float4 per thread, 256 / (BN / 4)
+// rows per pass.  `SGAM_XFIX_FENCE` = 1 replaces the sc1 accesses by the memory model's release / acquire fences
+// (buffer_wbl2 / buffer_inv over the whole L2) — same results, kept for comparison.
+#ifndef SGAM_XFIX_FENCE
+#define SGAM_XFIX_FENCE 0
+#endif
+#define SGAM_XFIX_AUX (SGAM_XFIX_FENCE ? 0 : 16)
+template <int BM, int BN, class RowMap>
+__device__ __forceinline__ void xfixup(const XParams &p, float *smem_f, int bx, int n0, RowMap rowmap) {
+    constexpr int C4T = BN / 4, RPT = 256 / C4T, PASSES = BM / RPT;
+    const int tid = threadIdx.x;
+    const int tile = (n0 / BN) * p.gx + bx;
+    if (SGAM_XFIX_FENCE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                   // every wavefront's partial rows are out; the staging LDS is free
+    int *tk = reinterpret_cast<int *>(smem_f);
+    if (tid == 0) *tk = __hip_atomic_fetch_add(p.arrive + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int ticket = *tk;
+    if (ticket != p.ksplit - 1) return;
+    if (SGAM_XFIX_FENCE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();                                   // the ticket has been read: the LDS becomes the statistics'
+    const int64_t zs = (int64_t)p.M * p.N;
+    const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc((void *)p.ws, 0, (int)(unsigned)(zs * p.ksplit * 4), 0x00020000);
+    const unsigned r_bytes = p.res ? (unsigned)(((int64_t)(p.M - 1) * p.ldr + p.n_valid) * 4) : 0u;
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void *)p.res, 0, (int)r_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.out, 0, (int)(unsigned)(((int64_t)(p.M - 1) * p.ldc + p.n_valid) * 4), 0x00020000);
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    const unsigned zb = (unsigned)(zs * 4);
+    const int c4 = tid % C4T, r0 = tid / C4T;
+    const int n4 = n0 + c4 * 4;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && !p.bias_per_row && n4 < p.n_valid) bv = *reinterpret_cast<const f32x4 *>(p.bias + n4);
+    float gs = 0.f, gss = 0.f;
+    bool bad = false;
+#define XFIX_LD(z_) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, (int)wo, (int)((unsigned)(z_) * zb), SGAM_XFIX_AUX))
+#pragma unroll 2
+    for (int pass = 0; pass < PASSES; ++pass) {
+        const int m = rowmap(pass * RPT + r0);
+        const bool ok = m < p.M && n4 < p.n_valid;
+        const unsigned wo = xsel(ok, (unsigned)(m * p.N + n4) * 4u, OOB);
+        const f32x4 rv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                       rr, (int)xsel(ok, (unsigned)(m * p.ldr + n4) * 4u, OOB), 0, 0));
+        f32x4 s = XFIX_LD(0);
+        int z = 1;
+        for (; z + 4 <= p.ksplit; z += 4) {
+            const f32x4 a = XFIX_LD(z), b = XFIX_LD(z + 1), c = XFIX_LD(z + 2), d = XFIX_LD(z + 3);
+            s += a;
+            s += b;
+            s += c;
+            s += d;
+        }
+        for (; z < p.ksplit; ++z) s += XFIX_LD(z);
+        f32x4 v;
+        const float bm = (p.bias && p.bias_per_row && ok) ? p.bias[m] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = s[e] * p.inv_w_scale;
+            if (p.bias) v[e] += p.bias_per_row ? bm : bv[e];
+            if (p.res) v[e] += rv[e];
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, (int)xsel(ok, (unsigned)(m * p.ldc + n4) * 4u, OOB), 0, SGAM_XNT);
+        if (ok) {
+            const float t4 = (v[0] + v[1]) + (v[2] + v[3]);
+            gs += t4;
+            gss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            bad |= sgam_not_finite(t4);
+        }
+    }
+#undef XFIX_LD
+    if (bad && p.range_flag) atomicOr(p.range_flag, 1);
+    if (tid == 0) __hip_atomic_store(p.arrive + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!p.gn_partial) return;
+    // statistics of the tile (host: n_valid == N, hw % BM == 0, cpg a power of two in [4, 32]): the cpg / 4 neighbouring lanes of
+    // one (row, group) fold by an xor butterfly, the RPT row lanes through LDS in a fixed order and in fp64
+    const int lpg = p.gn_cpg / 4;
+    for (int o = 1; o < lpg; o <<= 1) {
+        gs += __shfl_xor(gs, o, 64);
+        gss += __shfl_xor(gss, o, 64);
+    }
+    const int gt = C4T / lpg, gl = c4 / lpg;           // groups inside the tile's BN columns; this lane's
+    float *sh = smem_f;                                // [RPT][gt][2]
+    if ((c4 % lpg) == 0) {
+        sh[(r0 * gt + gl) * 2] = gs;
+        sh[(r0 * gt + gl) * 2 + 1] = gss;
+    }
+    __syncthreads();
+    if (tid < gt) {
+        double ds = 0.0, dss = 0.0;
+        for (int r = 0; r < RPT; ++r) {
+            ds += (double)sh[(r * gt + tid) * 2];
+            dss += (double)sh[(r * gt + tid) * 2 + 1];
+        }
+        const int hw = p.Ho * p.Wo, chunks_per_b = hw / BM;
+        const int b = (bx * BM) / hw, cb = bx - b * chunks_per_b;
+        if (p.gn_acc) {
+            sgam_stats_acc_add(reinterpret_cast<long long *>(p.gn_partial), b, blockIdx.x, n0 / p.gn_cpg + tid, ds, dss);
+        } else {
+            double *o = p.gn_partial + (((int64_t)b * chunks_per_b + cb) * 32 + n0 / p.gn_cpg + tid) * 2;
+            o[0] = ds;
+            o[1] = dss;
+        }
+    }
+}
+
 // ---- epilogue shared by the tile kernels: each wavefront transposes its (32 TM) x (32 TN) fp32 tile through a private
 // LDS region so that a lane ends up with 4 CONSECUTIVE output channels of one pixel: residual comes in and the result
 // leaves as 16-byte accesses, 16 lanes covering a 256-byte row segment (the MFMA D layout alone gives 4-byte accesses:
@@ -202,6 +318,7 @@ __device__ __forceinline__ void xepilogue(const XParams &p, f32x16 (&acc)[BM / (
     const int wm = WGM == 4 ? wave : (WGM == 2 ? wave >> 1 : 0), wn = WGM == 4 ? 0 : (WGM == 2 ? (wave & 1) : wave);
     float *region = smem_f + wave * (WM * LDR);
     const bool to_ws = p.ws != nullptr;
+    const bool fix = to_ws && p.arrive != nullptr;
     const int n_lim = to_ws ? p.N : p.n_valid;
     const int ldo = to_ws ? p.N : p.ldc;
     float *obase = to_ws ? p.ws + (int64_t)bz * p.M * p.N : p.out;
@@ -250,8 +367,10 @@ __device__ __forceinline__ void xepilogue(const XParams &p, f32x16 (&acc)[BM / (
             v += bm;
         }
         v += rv;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro,
-                                               (int)xsel(ok, (unsigned)(m * ldo + n4) * 4u, OOB), 0, SGAM_XNT);
+        if (fix) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro,
+                                                        (int)xsel(ok, (unsigned)(m * ldo + n4) * 4u, OOB), 0, SGAM_XFIX_AUX);
+        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro,
+                                                    (int)xsel(ok, (unsigned)(m * ldo + n4) * 4u, OOB), 0, SGAM_XNT);
         if (ok) {
             const float t4 = (v[0] + v[1]) + (v[2] + v[3]);
             gs += t4;
@@ -285,16 +404,21 @@ __device__ __forceinline__ void xepilogue(const XParams &p, f32x16 (&acc)[BM / (
                 const int b = (bx * BM) / hw;                    // host guarantees a tile never straddles two images
                 const int chunks_per_b = ((hw + BM - 1) / BM) * 2;
                 const int cb = chunk - b * chunks_per_b;
-                double *o = p.gn_partial + (((int64_t)b * chunks_per_b + cb) * groups + g) * 2;
-                o[0] = ds;
-                o[1] = dss;
-                if (WGM == 1) {
-                    o[groups * 2] = 0.0;
-                    o[groups * 2 + 1] = 0.0;
+                if (p.gn_acc) {
+                    sgam_stats_acc_add(reinterpret_cast<long long *>(p.gn_partial), b, blockIdx.x, g, ds, dss);
+                } else {
+                    double *o = p.gn_partial + (((int64_t)b * chunks_per_b + cb) * groups + g) * 2;
+                    o[0] = ds;
+                    o[1] = dss;
+                    if (WGM == 1) {
+                        o[groups * 2] = 0.0;
+                        o[groups * 2 + 1] = 0.0;
+                    }
                 }
             }
         }
     }
+    if (fix) xfixup<BM, BN>(p, smem_f, bx, n0, rowmap);
 }
 
 template <int BM, int BN, bool UPS, bool ASCALE>
@@ -763,12 +887,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
         // (behind the first halo and weight loads, so that its own round trip overlaps theirs; same expressions and order as
         // gn_scale_shift / the stand-alone GroupNorm kernels)
         const int cpg = p.Cin / 32;
-        for (int c = tid; c < p.Cin; c += 256) {
-            const int g = c / cpg;
-            const float mean = p.gn_stats[(b * 32 + g) * 2], rstd = p.gn_stats[(b * 32 + g) * 2 + 1];
-            const float sc = rstd * p.gn_gamma[c];
-            gn_tab[2 * c] = sc;
-            gn_tab[2 * c + 1] = p.gn_beta[c] - mean * sc;
+        constexpr int CPT = SGAM_XGN_MAXC / 256;                   // channels per thread, at most
+        float mr[CPT][2];
+        if (p.gn_acc_in) {
+            // statistics as the producer's accumulator record, finished by the workgroup (one round trip); the table's first 64
+            // floats carry {mean, rstd} to the threads that own the channels
+            sgam_stats_acc_block_mean_rstd<256>(p.gn_acc_in, b, p.gn_inv_n, p.gn_eps, gn_tab, tid);
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                const int c = tid + 256 * k;
+                if (c < p.Cin) mr[k][0] = gn_tab[2 * (c / cpg)], mr[k][1] = gn_tab[2 * (c / cpg) + 1];
+            }
+            __syncthreads();
+        } else {
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                const int c = tid + 256 * k;
+                if (c < p.Cin) mr[k][0] = p.gn_stats[(b * 32 + c / cpg) * 2], mr[k][1] = p.gn_stats[(b * 32 + c / cpg) * 2 + 1];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int c = tid + 256 * k;
+            if (c < p.Cin) {
+                const float sc = mr[k][1] * p.gn_gamma[c];
+                gn_tab[2 * c] = sc;
+                gn_tab[2 * c + 1] = p.gn_beta[c] - mr[k][0] * sc;
+            }
         }
         __syncthreads();
     }
@@ -1137,9 +1282,13 @@ __global__ __launch_bounds__(256) void conv3x3_f32x_k4_kernel(const XParams p) {
                     dss += (double)sl[l * 2 + 1];
                 }
             const int g = n0 / p.gn_cpg + tid, groups = p.N / p.gn_cpg;
-            double *o = p.gn_partial + (((int64_t)b * tiles_img + t_img) * groups + g) * 2;
-            o[0] = ds;
-            o[1] = dss;
+            if (p.gn_acc) {
+                sgam_stats_acc_add(reinterpret_cast<long long *>(p.gn_partial), b, blockIdx.x, g, ds, dss);
+            } else {
+                double *o = p.gn_partial + (((int64_t)b * tiles_img + t_img) * groups + g) * 2;
+                o[0] = ds;
+                o[1] = dss;
+            }
         }
     }
 }
@@ -1347,9 +1496,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_f32x_kernel(const XParams p
             ds += (double)sh[r][threadIdx.x][0];
             dss += (double)sh[r][threadIdx.x][1];
         }
-        double *o = p.gn_partial + ((int64_t)blockIdx.x * 32 + threadIdx.x) * 2;     // chunk = workgroup (image-major)
-        o[0] = ds;
-        o[1] = dss;
+        if (p.gn_acc) {
+            const int b = (int)(((int64_t)blockIdx.x * rows) / (p.Ho * p.Wo));            // whole workgroups inside one image
+            sgam_stats_acc_add(reinterpret_cast<long long *>(p.gn_partial), b, blockIdx.x, threadIdx.x, ds, dss);
+        } else {
+            double *o = p.gn_partial + ((int64_t)blockIdx.x * 32 + threadIdx.x) * 2;     // chunk = workgroup (image-major)
+            o[0] = ds;
+            o[1] = dss;
+        }
     }
 }
 
@@ -1412,9 +1566,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_gm_f32x_kernel(const XParam
             dss += (double)sh[r * gt + threadIdx.x][1];
         }
         // chunk = row tile inside the image (image-major: rt counts over the whole batch, hw % TR == 0)
-        double *o = p.gn_partial + ((int64_t)rt * 32 + ct * gt + threadIdx.x) * 2;
-        o[0] = ds;
-        o[1] = dss;
+        if (p.gn_acc) {
+            const int b = (rt * TR) / (p.Ho * p.Wo);
+            sgam_stats_acc_add(reinterpret_cast<long long *>(p.gn_partial), b, blockIdx.x, ct * gt + threadIdx.x, ds, dss);
+        } else {
+            double *o = p.gn_partial + ((int64_t)rt * 32 + ct * gt + threadIdx.x) * 2;
+            o[0] = ds;
+            o[1] = dss;
+        }
     }
 }
 
@@ -1598,6 +1757,7 @@ struct XExtra {            // optional fusions around the product
     int gn_chunks_in = 0;
     float gn_eps = 1e-6f;
     double *gn_partial = nullptr;     // statistics of the output: per-chunk partial sums (epilogue or split-K combine)
+    const long long *gn_acc_in = nullptr;   // statistics of x as accumulators (sgam_conv2d_gnp_nhwc_f32x with chunks_in == 0)
 };
 
 static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale, const void *w_planes, float w_scale,
@@ -1636,9 +1796,40 @@ static int red_tc_for(const sgam_conv_desc *d) {
     return 0;
 }
 
+// chunks per image of the statistics a launch WITHOUT the in-kernel split-K fix-up delivers
+static int32_t stats_chunks_combine(const sgam_conv_desc *d, const XPlan &pl);
+
+// The in-kernel split-K fix-up (xfixup) serves this descriptor: the caller lent arrival counters (sgam_conv_desc.arrive, one per
+// output tile, zero on entry, left zero), the plan splits K, the kernel is one of the tile kernels with the shared epilogue,
+// the workspace is addressable through one buffer descriptor — and the statistics contract is not weakened: where the combine
+// launch would deliver GroupNorm statistics, the fix-up must be able to (complete rows, whole tiles per image, groups that are
+// a power of two of channels inside one tile)
+static bool fixup_stats_ok(const sgam_conv_desc *d, const XPlan &pl) {
+    const int hw = d->Ho * d->Wo, cpg = d->N / 32;
+    return d->N % 128 == 0 && d->n_valid == d->N && d->N <= 1024 && hw % pl.bm == 0 && (cpg & (cpg - 1)) == 0 && pl.bn % cpg == 0;
+}
+static bool fixup_on(const sgam_conv_desc *d, const XPlan &pl) {
+    static const int on = [] { const char *e = getenv("SGAM_XFIXUP"); return (e && e[0] == '0') ? 0 : 1; }();
+    if (!on || !d->arrive || pl.ksplit < 2 || pl.bm == 32 || pl.bm == 256) return false;
+    const int64_t tiles = (int64_t)sgam_cdiv((int64_t)d->B * d->Ho * d->Wo, pl.bm) * sgam_cdiv(d->N, pl.bn);
+    if (tiles > d->arrive_count) return false;
+    if ((int64_t)pl.ksplit * d->B * d->Ho * d->Wo * d->N * 4 >= (1ll << 32) - 64) return false;
+    return fixup_stats_ok(d, pl) || stats_chunks_combine(d, pl) == 0;
+}
+
+extern "C" int32_t sgam_conv2d_f32x_fixup(const sgam_conv_desc *d) {
+    if (xvalidate(d) != SGAM_OK) return 0;
+    return fixup_on(d, make_xplan(d)) ? 1 : 0;
+}
+
 extern "C" int32_t sgam_conv2d_f32x_stats_chunks(const sgam_conv_desc *d) {
     if (xvalidate(d) != SGAM_OK) return -1;
     const XPlan pl = make_xplan(d);
+    if (fixup_on(d, pl)) return fixup_stats_ok(d, pl) ? (d->Ho * d->Wo) / pl.bm : 0;      // one chunk per output tile
+    return stats_chunks_combine(d, pl);
+}
+
+static int32_t stats_chunks_combine(const sgam_conv_desc *d, const XPlan &pl) {
     const int hw = d->Ho * d->Wo;
     if (d->N % 128 != 0 || d->n_valid != d->N) return 0;                           // 32 groups of >= 4 channels, complete rows
     if (pl.bm == 32) return (d->B > 1 && hw % 32 != 0) ? 0 : hw / 32;               // K-in-workgroup kernel: one chunk per patch
@@ -1683,6 +1874,11 @@ extern "C" int sgam_conv2d_gn_nhwc_f32x(const sgam_conv_desc *d, const float *x,
 // repeated per slab — stays a few hundred cycles in the prologue), 0: fold them first (sgam_groupnorm_stats_from_partials_f32)
 extern "C" int32_t sgam_conv2d_f32x_gn_foldable(const sgam_conv_desc *d, int32_t chunks_in) {
     static const int on = [] { const char *e = getenv("SGAM_GN_FOLD"); return (e && e[0] == '0') ? 0 : 1; }();
+    if (chunks_in == 0) {                          // accumulator form: every GN kernel that fills the scale / shift table
+        if (sgam_conv2d_f32x_gn_fusable(d) != 1 || d->Cin % 128 != 0) return 0;
+        const XPlan pl0 = make_xplan(d);
+        return (pl0.bm == 32 || pl0.bm == 256) ? 0 : 1;
+    }
     if (!on || chunks_in < 1 || chunks_in > 16 || sgam_conv2d_f32x_gn_fusable(d) != 1 || d->Cin % 128 != 0) return 0;
     const XPlan pl = make_xplan(d);
     return (((pl.bm == 64 && pl.bn == 128) || (pl.bm == 256 && pl.bn == 32)) && pl.iters_per_split <= 18) ? 1 : 0;
@@ -1698,7 +1894,9 @@ extern "C" int sgam_conv2d_gnp_nhwc_f32x(const sgam_conv_desc *d, const float *x
         !sgam_aligned16(gn_beta) || !(eps > 0.f) || sgam_conv2d_f32x_gn_foldable(d, chunks_in) != 1)
         return SGAM_EINVAL;
     XExtra ex;
-    ex.gn_partial_in = gn_partial_in; ex.gn_chunks_in = chunks_in; ex.gn_eps = eps;
+    if (chunks_in == 0) ex.gn_acc_in = reinterpret_cast<const long long *>(gn_partial_in);
+    else ex.gn_partial_in = gn_partial_in;
+    ex.gn_chunks_in = chunks_in; ex.gn_eps = eps;
     ex.gn_gamma = gn_gamma; ex.gn_beta = gn_beta; ex.gn_swish = gn_swish ? 1 : 0;
     ex.gn_partial = gn_partial;
     if (check_stats_out(d, ex) != SGAM_OK) return SGAM_EINVAL;
@@ -1739,12 +1937,16 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
     p.range_flag = sgam_i_range_flag;
     p.a_scale = a_scale;
     p.gn_partial = ex.gn_partial;
+    p.gn_acc = (ex.gn_partial && d->stats_acc) ? 1 : 0;
+    p.gn_acc_in = ex.gn_acc_in;
     p.gn_cpg = d->N / 32;
     p.gn_stats = ex.gn_stats; p.gn_gamma = ex.gn_gamma; p.gn_beta = ex.gn_beta;
     p.gn_swish = ex.gn_swish;
     p.gn_partial_in = ex.gn_partial_in; p.gn_chunks_in = ex.gn_chunks_in; p.gn_eps = ex.gn_eps;
     p.gn_inv_n = 1.0 / ((double)d->Hi * d->Wi * (d->Cin / 32));
     p.red_tc = 0;
+    const bool fixup = fixup_on(d, pl);
+    p.arrive = fixup ? d->arrive : nullptr;
 
     const int64_t xb = (((int64_t)d->B * d->Hi * d->Wi - 1) * d->lda + d->Cin) * 4;
     const int64_t wb = (int64_t)((d->N + 31) / 32 * 32) * d->ldb * 4;   // fragment order over [N rounded up to 32][ldb]
@@ -1771,8 +1973,9 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
     if (p.ups && a_scale != 1.0f) return SGAM_EINVAL;
     if (d->KH * d->KW > 32) return SGAM_EINVAL;   // tap validity mask is 32 bits
     const bool halo = halo_eligible(d, pl, a_scale);
-    if ((ex.gn_stats || ex.gn_partial_in) && !halo) return SGAM_EINVAL;
-    if (ex.gn_stats && d->Cin > SGAM_XGN_MAXC) return SGAM_EINVAL;           // the scale / shift table of the fused GroupNorm (LDS)
+    const bool gn_tab_on = ex.gn_stats || ex.gn_acc_in;                      // statistics per (image, group): table-filling GN kernels
+    if ((gn_tab_on || ex.gn_partial_in) && !halo) return SGAM_EINVAL;
+    if (gn_tab_on && d->Cin > SGAM_XGN_MAXC) return SGAM_EINVAL;             // the scale / shift table of the fused GroupNorm (LDS)
     if (ex.gn_partial_in && ((pl.bm != 64 && pl.bm != 256) || p.ups)) return SGAM_EINVAL;   // folding consumers: 64-row halo / ws kernel
     // algorithmic work of this launch: 2 M N K fp32 FLOP; bytes = input + weights + output once
     if (sgam_i_prof_on) sgam_i_prof_shape(p.M, d->n_valid, d->KH * d->KW * d->Cin, pl.ksplit);
@@ -1783,29 +1986,29 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
     if (halo && pl.bm == 256) {
         if (a_scale != 1.0f || pl.ksplit < 2) return SGAM_EINVAL;
         if (p.gn_partial_in) SGAM_KLAUNCH((conv3x3_f32x_ws_kernel<2>), grid, dim3(256), 0, s, p);
-        else if (p.gn_stats) SGAM_KLAUNCH((conv3x3_f32x_ws_kernel<1>), grid, dim3(256), 0, s, p);
+        else if (gn_tab_on) SGAM_KLAUNCH((conv3x3_f32x_ws_kernel<1>), grid, dim3(256), 0, s, p);
         else SGAM_KLAUNCH((conv3x3_f32x_ws_kernel<0>), grid, dim3(256), 0, s, p);
     } else if (halo && pl.bm == 32) {
         if (a_scale != 1.0f) return SGAM_EINVAL;
-        if (p.gn_stats) SGAM_KLAUNCH((conv3x3_f32x_k4_kernel<true>), grid, dim3(256), 0, s, p);
+        if (gn_tab_on) SGAM_KLAUNCH((conv3x3_f32x_k4_kernel<true>), grid, dim3(256), 0, s, p);
         else SGAM_KLAUNCH((conv3x3_f32x_k4_kernel<false>), grid, dim3(256), 0, s, p);
     } else if (halo) {
         if (p.ups) {
             if (pl.bm == 128) SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<128, 128, false, true>), grid, dim3(256), 0, s, p);
             else SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<64, 128, false, true>), grid, dim3(256), 0, s, p);
         } else if (pl.bm == 128 && pl.bn == 32) {
-            if (p.gn_stats) SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<128, 32, true>), grid, dim3(256), 0, s, p);
+            if (gn_tab_on) SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<128, 32, true>), grid, dim3(256), 0, s, p);
             else SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<128, 32, false>), grid, dim3(256), 0, s, p);
         } else if (pl.bm == 128) {
-            if (p.gn_stats) SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<128, 128, true>), grid, dim3(256), 0, s, p);
+            if (gn_tab_on) SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<128, 128, true>), grid, dim3(256), 0, s, p);
             else SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<128, 128, false>), grid, dim3(256), 0, s, p);
         } else if (pl.bn == 64) {
             if (p.gn_partial_in) return SGAM_EINVAL;
-            if (p.gn_stats) SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<64, 64, true>), grid, dim3(256), 0, s, p);
+            if (gn_tab_on) SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<64, 64, true>), grid, dim3(256), 0, s, p);
             else SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<64, 64, false>), grid, dim3(256), 0, s, p);
         } else {
             if (p.gn_partial_in) SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<64, 128, true, false, true>), grid, dim3(256), 0, s, p);
-            else if (p.gn_stats) SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<64, 128, true>), grid, dim3(256), 0, s, p);
+            else if (gn_tab_on) SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<64, 128, true>), grid, dim3(256), 0, s, p);
             else SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<64, 128, false>), grid, dim3(256), 0, s, p);
         }
     } else if (pl.bm == 128 && pl.bn == 128) XLAUNCH(128, 128);
@@ -1813,7 +2016,7 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
     else XLAUNCH(64, 64);
 #undef XLAUNCH
     SGAM_LAUNCH_CHECK();
-    if (pl.ksplit > 1) {
+    if (pl.ksplit > 1 && !fixup) {
         const int64_t q = (int64_t)p.M * (p.N / 4);
         const int tc = p.gn_partial ? red_tc_for(d) : 0;
         if (tc == 32) SGAM_KLAUNCH(splitk_reduce_gm_f32x_kernel<32>, dim3((unsigned)(q / 256)), dim3(256), 0, s, p);

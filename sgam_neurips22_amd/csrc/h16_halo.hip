@@ -91,6 +91,8 @@ struct HHParams {
     const double *gn_partial_in;
     int gn_chunks_in;
     float gn_inv_n, gn_eps;
+    const long long *gn_acc_in;   // ... or as [B][32][4] int64 accumulators (sgam_common.h): every table-filling GN kernel takes them
+    int gn_acc;                   // gn_partial is the accumulator form (atomics instead of chunk records)
     unsigned long long *dbg;      // SGAM_HPC_DBG=1: cycle stamps of workgroup 0 (producer / consumer kernel), else NULL
     int dbg_flags;                // SGAM_HPC_DBGF: timing experiments of that kernel (results wrong): 1 no MFMAs, 2 no producer priority
 };
@@ -322,12 +324,33 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
     if constexpr (GN && !GNF) {
         // (behind the first halo and weight loads, so that its own round trip overlaps theirs)
         const int cpg = p.Cin / 32;
-        for (int c = tid; c < p.Cin; c += 256) {
-            const int g = c / cpg;
-            const float mean = p.gn_stats[(b * 32 + g) * 2], rstd = p.gn_stats[(b * 32 + g) * 2 + 1];
-            const float sc = rstd * p.gn_gamma[c];
-            gn_tab[0][c] = sc;
-            gn_tab[1][c] = p.gn_beta[c] - mean * sc;
+        constexpr int CPT = SGAM_HGN_MAXC / 256;                   // channels per thread, at most
+        float mr[CPT][2];
+        if (p.gn_acc_in) {
+            // statistics as the producer's accumulator record, finished by the workgroup (one round trip); the table's first 64
+            // floats carry {mean, rstd} to the threads that own the channels
+            sgam_stats_acc_block_mean_rstd<256>(p.gn_acc_in, b, (double)p.gn_inv_n, p.gn_eps, &gn_tab[0][0], tid);
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                const int c = tid + 256 * k;
+                if (c < p.Cin) mr[k][0] = gn_tab[0][2 * (c / cpg)], mr[k][1] = gn_tab[0][2 * (c / cpg) + 1];
+            }
+            __syncthreads();
+        } else {
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                const int c = tid + 256 * k;
+                if (c < p.Cin) mr[k][0] = p.gn_stats[(b * 32 + c / cpg) * 2], mr[k][1] = p.gn_stats[(b * 32 + c / cpg) * 2 + 1];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int c = tid + 256 * k;
+            if (c < p.Cin) {
+                const float sc = mr[k][1] * p.gn_gamma[c];
+                gn_tab[0][c] = sc;
+                gn_tab[1][c] = p.gn_beta[c] - mr[k][0] * sc;
+            }
         }
         __syncthreads();
     }
@@ -584,9 +607,18 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
                 // chunk = (tile, row half): the wavefronts that share a row half own different channels, so each
                 // (chunk = tile * 2 + row half, group) is written by exactly one lane of one wavefront
                 const int chunks_per_b = tiles_img * 2;
-                double *o = p.gn_partial + (((int64_t)b * chunks_per_b + t_img * 2 + (RH == 1 ? wm : r)) * groups + g) * 2;
-                o[0] = ds;
-                o[1] = dss;
+                if (p.gn_acc) {
+                    // (the two row halves of a wavefront go to the same record: joined first, half as many atomics)
+                    if constexpr (RH == 2) {
+                        ds += __shfl_down(ds, groups_here, 64);
+                        dss += __shfl_down(dss, groups_here, 64);
+                    }
+                    if (RH == 1 || r == 0) sgam_stats_acc_add(reinterpret_cast<long long *>(p.gn_partial), b, blockIdx.x, g, ds, dss);
+                } else {
+                    double *o = p.gn_partial + (((int64_t)b * chunks_per_b + t_img * 2 + (RH == 1 ? wm : r)) * groups + g) * 2;
+                    o[0] = ds;
+                    o[1] = dss;
+                }
             }
         }
     }
@@ -662,9 +694,13 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
                 // chunk = (tile, row half, column half): two wavefronts share a row half but own different channels, so
                 // each (chunk = tile * 2 + wm, group) is written by exactly one lane of one wavefront
                 const int chunks_per_b = tiles_img * 2;
-                double *o = p.gn_partial + (((int64_t)b * chunks_per_b + t_img * 2 + wm) * groups + g) * 2;
-                o[0] = ds;
-                o[1] = dss;
+                if (p.gn_acc) {
+                    sgam_stats_acc_add(reinterpret_cast<long long *>(p.gn_partial), b, blockIdx.x, g, ds, dss);
+                } else {
+                    double *o = p.gn_partial + (((int64_t)b * chunks_per_b + t_img * 2 + wm) * groups + g) * 2;
+                    o[0] = ds;
+                    o[1] = dss;
+                }
             }
         }
     }
@@ -750,7 +786,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p
             const int cpg = p.Cin / 32;
             for (int c = tid - 256; c < p.Cin; c += 256) {
                 const int g = c / cpg;
-                const float mean = p.gn_stats[(b * 32 + g) * 2], rstd = p.gn_stats[(b * 32 + g) * 2 + 1];
+                float mean, rstd;
+                if (p.gn_acc_in) sgam_stats_acc_mean_rstd(p.gn_acc_in, b, g, (double)p.gn_inv_n, p.gn_eps, mean, rstd);
+                else mean = p.gn_stats[(b * 32 + g) * 2], rstd = p.gn_stats[(b * 32 + g) * 2 + 1];
                 const float sc = rstd * p.gn_gamma[c];
                 gn_tab[0][c] = sc;
                 gn_tab[1][c] = p.gn_beta[c] - mean * sc;
@@ -1137,9 +1175,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p
                 const int groups = p.N / p.gn_cpg;
                 if (g < groups) {
                     const int chunks_per_b = tiles_img * 2;
-                    double *o = p.gn_partial + (((int64_t)b * chunks_per_b + t_img * 2 + r) * groups + g) * 2;
-                    o[0] = ds;
-                    o[1] = dss;
+                    if (p.gn_acc) {
+                        sgam_stats_acc_add(reinterpret_cast<long long *>(p.gn_partial), b, blockIdx.x, g, ds, dss);
+                    } else {
+                        double *o = p.gn_partial + (((int64_t)b * chunks_per_b + t_img * 2 + r) * groups + g) * 2;
+                        o[0] = ds;
+                        o[1] = dss;
+                    }
                 }
             }
         }
@@ -1244,9 +1286,13 @@ __global__ __launch_bounds__(256) void h16_splitk_reduce_kernel(const HHParams p
             ds += (double)sh[r][threadIdx.x][0];
             dss += (double)sh[r][threadIdx.x][1];
         }
-        double *o = p.gn_partial + ((int64_t)blockIdx.x * 32 + threadIdx.x) * 2;     // chunk = workgroup (image-major)
-        o[0] = ds;
-        o[1] = dss;
+        if (p.gn_acc) {
+            sgam_stats_acc_add(reinterpret_cast<long long *>(p.gn_partial), (int)(((int64_t)blockIdx.x * rows) / (p.Ho * p.Wo)), blockIdx.x, threadIdx.x, ds, dss);
+        } else {
+            double *o = p.gn_partial + ((int64_t)blockIdx.x * 32 + threadIdx.x) * 2;     // chunk = workgroup (image-major)
+            o[0] = ds;
+            o[1] = dss;
+        }
     }
 }
 
@@ -1314,9 +1360,13 @@ __global__ __launch_bounds__(256) void h16_splitk_reduce_gm_kernel(const HHParam
             dss += (double)sh[r * gt + threadIdx.x][1];
         }
         // chunk = row tile inside the image (image-major: rt counts over the whole batch, hw % TR == 0)
-        double *o = p.gn_partial + ((int64_t)rt * 32 + ct * gt + threadIdx.x) * 2;
-        o[0] = ds;
-        o[1] = dss;
+        if (p.gn_acc) {
+            sgam_stats_acc_add(reinterpret_cast<long long *>(p.gn_partial), (rt * TR) / (p.Ho * p.Wo), blockIdx.x, ct * gt + threadIdx.x, ds, dss);
+        } else {
+            double *o = p.gn_partial + ((int64_t)rt * 32 + ct * gt + threadIdx.x) * 2;
+            o[0] = ds;
+            o[1] = dss;
+        }
     }
 }
 
@@ -1445,6 +1495,8 @@ extern "C" int sgam_pack_conv_weight_h16_frag(const float *w_oihw, void *w_frag,
 // slab), groups of >= 8 channels (a thread's eight staged channels are one group), at most 16 chunks
 extern "C" int32_t sgam_conv2d_h16_gn_foldable(const sgam_conv_desc *d, int32_t chunks_in) {
     static const int on = [] { const char *e = getenv("SGAM_GN_FOLD"); return (e && e[0] == '0') ? 0 : 1; }();
+    if (d && chunks_in == 0)               // accumulator form (sgam_conv_desc.stats_acc of the producer): every GN-fusing launch of the halo kernel
+        return (!d->upsample2x && d->Cin % 128 == 0 && d->Cin <= SGAM_HGN_MAXC && hh_plan(d).bm != 0) ? 1 : 0;
     if (!on || !d || chunks_in < 1 || chunks_in > 16 || d->upsample2x || d->Cin % 256 != 0) return 0;
     const HHPlan pl = hh_plan(d);
     return (pl.bm == 64 && pl.slabs_per_split <= 2) ? 1 : 0;
@@ -1457,11 +1509,17 @@ static int hh_conv_impl(const sgam_conv_desc *d, int32_t ht, const void *x, cons
     const HHPlan pl = hh_plan(d);
     const int bm = pl.bm;
     if (!bm || !x || !w_frag || !out || (ht != 0 && ht != 1)) return SGAM_EINVAL;
+    const long long *gn_acc_in = nullptr;           // chunks_in == 0: the statistics of x are accumulators, not chunk records
+    if (gn_partial_in && chunks_in == 0) {
+        if (gn_mean_rstd || !(gn_eps > 0.f) || !sgam_aligned16(gn_partial_in) || sgam_conv2d_h16_gn_foldable(d, 0) != 1) return SGAM_EINVAL;
+        gn_acc_in = reinterpret_cast<const long long *>(gn_partial_in);
+        gn_partial_in = nullptr;
+    }
     if (!sgam_aligned16(x) || !sgam_aligned16(w_frag) || (((uintptr_t)out) & 7u) || (residual && (((uintptr_t)residual) & 7u)))
         return SGAM_EALIGN;
     if (gn_partial_in && (gn_mean_rstd || sgam_conv2d_h16_gn_foldable(d, chunks_in) != 1 || !sgam_aligned16(gn_partial_in)))
         return SGAM_EINVAL;
-    const bool gn = gn_mean_rstd != nullptr || gn_partial_in != nullptr;
+    const bool gn = gn_mean_rstd != nullptr || gn_partial_in != nullptr || gn_acc_in != nullptr;
     if (gn && (!gn_gamma || !gn_beta || !sgam_aligned16(gn_gamma) || !sgam_aligned16(gn_beta) || d->upsample2x || d->Cin % 128 ||
                d->Cin > SGAM_HGN_MAXC))
         return SGAM_EINVAL;
@@ -1484,6 +1542,7 @@ static int hh_conv_impl(const sgam_conv_desc *d, int32_t ht, const void *x, cons
     p.gn_stats = gn_mean_rstd; p.gn_gamma = gn_gamma; p.gn_beta = gn_beta; p.gn_swish = gn_swish ? 1 : 0;
     p.gn_partial = gn_partial; p.gn_cpg = d->N / 32;
     p.gn_partial_in = gn_partial_in; p.gn_chunks_in = chunks_in; p.gn_eps = gn_eps;
+    p.gn_acc_in = gn_acc_in; p.gn_acc = (gn_partial && d->stats_acc) ? 1 : 0;
     p.gn_inv_n = 1.0f / ((float)d->Hi * (float)d->Wi * (float)(d->Cin / 32));
     p.gx = p.M / bm; p.gy = d->N / 128;
     p.dbg = nullptr;

@@ -202,8 +202,13 @@ class AttnBlock(_NHWCModule):
         fused_qkv = wkey == "f32x" and FUSE_NORM_INTO_QKV and ops.gemm_gn_fits(B * n, 3 * C, C, n)
         if fused_qkv:
             # GroupNorm applied while the q | k | v GEMM stages its operand (csrc/gemm_gn_f32x.hip): no normalise pass
-            mr = ops.groupnorm_meanrstd(x, self.norm.eps)
-            qkv_all = ops.gemm_gn_f32x(x.reshape(B * n, C), mr, self.norm.weight.detach(), self.norm.bias.detach(), wqkv, bqkv, n)
+            pre = getattr(x, "_gn_partials", None)
+            if pre is not None and pre[1] == 0:      # statistics of x as its producer's accumulators: finished inside the GEMM
+                qkv_all = ops.gemm_gn_f32x(x.reshape(B * n, C), None, self.norm.weight.detach(), self.norm.bias.detach(), wqkv, bqkv, n,
+                                           acc=pre[0], eps=self.norm.eps)
+            else:
+                mr = ops.groupnorm_meanrstd(x, self.norm.eps)
+                qkv_all = ops.gemm_gn_f32x(x.reshape(B * n, C), mr, self.norm.weight.detach(), self.norm.bias.detach(), wqkv, bqkv, n)
             table, h = None, None
         elif FUSE_GROUPNORM_INTO_CONV:
             table, h = self.norm.stats_nhwc(x), x                         # (B, C, 2), no swish for attention

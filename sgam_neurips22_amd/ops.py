@@ -125,11 +125,12 @@ class SplitWeight:
     """fp32 matrix (N, K) pre-split into fp16 hi / lo halves of scale * w in MFMA-fragment order
     [Np/32][Kp/32][256 pieces][8 halfs] (N, K rounded up to 32; piece = ((plane*2 + k-step)*2 + k-half)*32 + row): the
     B operand of one v_mfma_f32_32x32x16_f16 is one contiguous kilobyte (conv_f32x.hip)."""
-    __slots__ = ("planes", "scale", "shape")
+    __slots__ = ("planes", "scale", "shape", "arrive")
 
-    def __init__(self, planes, scale, n=None, k=None):
+    def __init__(self, planes, scale, n=None, k=None, transient=False):
         np_, kp = planes.shape[0] * 32, planes.shape[1] * 32
         self.planes, self.scale, self.shape = planes, scale, (np_ if n is None else n, kp if k is None else k)
+        self.arrive = False if transient else None      # split-K arrival counters of the layer that owns this weight (_arrive)
 
     def stride(self, dim):
         return self.planes.shape[1] * 32 if dim == 0 else 1       # logical row length (ldb), in K elements
@@ -185,7 +186,7 @@ def split_rows(x2d, scale=1.0):
     planes = torch.empty((round_up(N, 32) // 32, round_up(K, 32) // 32, 256, 8), device=x2d.device, dtype=torch.float16)
     check(_lib.load().sgam_split_rows_f32x(_p(x2d), _p(planes), float(scale), N, K, x2d.stride(0), _stream()),
           "sgam_split_rows_f32x")
-    return SplitWeight(planes, float(scale), N, K)
+    return SplitWeight(planes, float(scale), N, K, transient=True)
 
 
 # 16-bit throughput path: `ht` code of the C ABI per torch dtype
@@ -337,12 +338,110 @@ def conv_plan(desc, h16=False, split=False):
     return bm.value, bn.value, ks.value
 
 
+# split-K arrival counters (sgam_conv_desc.arrive): one small zeroed int32 array per LAYER, kept on its weight — launches of one
+# layer are ordered on one stream, two model instances (ConcurrentScenes) own separate weights, and the kernels leave the
+# counters zero.  Created outside stream capture only (the eager warm-up ahead of a capture does it): a torch.zeros inside a
+# capture would become a fill node of every replay.  SGAM_XFIXUP=0: partial tiles + combine launch, as before.
+XFIXUP = os.environ.get("SGAM_XFIXUP", "0") == "1"
+ARRIVE_COUNT = 4096
+
+
+def _arrive(w, device):
+    if not XFIXUP:
+        return None
+    split = isinstance(w, SplitWeight)
+    t = w.arrive if split else getattr(w, "_sgam_arrive", None)
+    if t is False:
+        return None
+    if t is None or t.device != device:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        t = torch.zeros((ARRIVE_COUNT,), device=device, dtype=torch.int32)
+        if split:
+            w.arrive = t
+        else:
+            w._sgam_arrive = t
+    return t
+
+
+# GroupNorm statistics as accumulators (sgam_conv_desc.stats_acc, csrc/sgam_common.h): a pass of a model lends every producing launch
+# a zeroed [B][16 replicas][32][4] int64 record from ONE arena that is cleared once at the start of the pass; the launch adds its partial sums
+# with integer atomics and the consumer reads the finished sums — the fold launch between every producer / consumer pair
+# (33 - 39 per frame) is gone.  Tensors carry the record as `_gn_partials = (record, 0)`: chunk count 0 = accumulator form.
+# Outside a pass (no arena active) launches leave chunk records as before.  SGAM_STATS_ACC=0 switches the arenas off.
+STATS_ACC = os.environ.get("SGAM_STATS_ACC", "0") == "1"
+_ARENA = None
+
+
+STATS_R = 16                                      # replicas of a record (SGAM_STATS_R of csrc/sgam_common.h)
+STATS_RECORD = STATS_R * 32 * 4                   # int64 words per image
+
+
+class StatsArena:
+    SLOTS = 96                                    # producing launches per pass (a half of the 256^2 VQGAN forward has < 60)
+
+    def __init__(self, device, B):
+        self.buf = torch.zeros((self.SLOTS * B * STATS_RECORD,), device=device, dtype=torch.int64)
+        self.off = 0
+
+    def begin(self):
+        if os.environ.get("SGAM_STATS_ZERO") == "mul":
+            self.buf.mul_(0)
+        else:
+            self.buf.zero_()                      # one fill launch per pass (a memset node of a captured graph)
+        self.off = 0
+
+    def take(self, B):
+        n = B * STATS_RECORD
+        if self.off + n > self.buf.numel():
+            return None
+        t = self.buf[self.off:self.off + n]
+        self.off += n
+        return t
+
+
+class stats_arena:
+    """with ops.stats_arena(arena): ...   — convolutions inside leave / take GroupNorm statistics as accumulators of `arena`"""
+
+    def __init__(self, arena):
+        self.arena = arena if STATS_ACC else None
+
+    def __enter__(self):
+        global _ARENA
+        self.old, _ARENA = _ARENA, self.arena
+        if self.arena is not None:
+            self.arena.begin()
+        return self.arena
+
+    def __exit__(self, *exc):
+        global _ARENA
+        _ARENA = self.old
+        return False
+
+
+def _stats_out(desc, x, chunks):
+    """(record tensor, chunk count) for the statistics of a launch that can deliver `chunks` > 0 chunk records per image: an
+    accumulator of the active arena (chunk count 0, desc.stats_acc set) or a fresh [B][chunks][32][2] fp64 buffer"""
+    if chunks <= 0:
+        return None, 0
+    if _ARENA is not None:
+        acc = _ARENA.take(desc.B)
+        if acc is not None:
+            desc.stats_acc = 1
+            return acc, 0
+    return torch.empty((desc.B * chunks * 32 * 2,), device=x.device, dtype=torch.float64), chunks
+
+
 def _run_conv(desc, x, w, bias, residual, out, gn=None, a_scale=1.0, norm=None):
     """norm = (gamma, beta, swish, groups, eps): GroupNorm(+swish) of x ahead of the product — fused into the operand
     staging where the kernel family offers it (split fp32, halo-staged 3x3), a stand-alone pass otherwise."""
     lib = _lib.load()
     split = isinstance(w, SplitWeight)
     _apply_plan(desc, "f32x" if split else x.dtype)
+    if split:                                     # (16-bit family: see _run_conv_inner)
+        arr = _arrive(w, x.device)
+        if arr is not None:
+            desc.arrive, desc.arrive_count = arr.data_ptr(), arr.numel()
     if norm is not None:
         gamma, beta, swish, groups, eps = norm
         fusable = (split and FUSE_GN_APPLY and x.dtype == torch.float32 and x.dim() == 4 and groups == 32 and eps == 1e-6
@@ -404,7 +503,7 @@ def _run_conv_inner(lib, desc, x, w, bias, residual, out, gn=None, a_scale=1.0):
         # statistics of `out` for the GroupNorm that usually follows: per-chunk partial sums from the conv epilogue (no
         # split-K) or from the split-K combine (see include/sgam_hip.h)
         chunks = lib.sgam_conv2d_f32x_stats_chunks(ctypes.byref(desc)) if FUSE_GN_STATS else 0
-        partial = torch.empty((desc.B * chunks * 32 * 2,), device=x.device, dtype=torch.float64) if chunks > 0 else None
+        partial, chunks = _stats_out(desc, x, chunks)
 
         def tag(o):
             if partial is not None:
@@ -444,7 +543,7 @@ def _run_conv_inner(lib, desc, x, w, bias, residual, out, gn=None, a_scale=1.0):
             # halo-staged 3x3 kernel of the 16-bit mode (csrc/h16_halo.hip): optional GroupNorm(+swish) of x while staging,
             # statistics of `out` from the epilogue
             chunks = lib.sgam_conv2d_h16_stats_chunks(ctypes.byref(desc)) if (FUSE_GN_STATS and out.dtype in H16) else 0
-            partial = torch.empty((desc.B * chunks * 32 * 2,), device=x.device, dtype=torch.float64) if chunks > 0 else None
+            partial, chunks = _stats_out(desc, x, chunks)
             ws_bytes = lib.sgam_conv2d_halo_h16_workspace_bytes(ctypes.byref(desc))
             ws = torch.empty((ws_bytes,), device=x.device, dtype=torch.uint8) if ws_bytes > 0 else None
             if gn is not None and len(gn) == 5:          # statistics as the producer's chunk partials, folded inside the kernel
@@ -473,7 +572,7 @@ def _run_conv_inner(lib, desc, x, w, bias, residual, out, gn=None, a_scale=1.0):
         # sums from the direct epilogue of the generic kernel
         chunks = lib.sgam_conv2d_h16_generic_stats_chunks(ctypes.byref(desc)) if (FUSE_GN_STATS and out.dtype in H16) else 0
         if chunks > 0:
-            partial = torch.empty((desc.B * chunks * 32 * 2,), device=x.device, dtype=torch.float64)
+            partial, chunks = _stats_out(desc, x, chunks)
             check(lib.sgam_conv2d_stats_nhwc_h16(ctypes.byref(desc), H16[x.dtype], _p(x), _p(w), _p(bias), _p(residual), _p(out), 0,
                                                  _p(partial), _p(ws), ws_bytes, _stream()), "sgam_conv2d_stats_nhwc_h16")
             out._gn_partials = (partial, chunks)
@@ -536,14 +635,20 @@ def gemm_gn_fits(M, N, K, HW):
     return F32_MODE == "split" and _lib.load().sgam_gemm_gn_f32x_fits(M, N, K, HW) == 1
 
 
-def gemm_gn_f32x(x2d, mean_rstd, gamma, beta, w, bias, hw):
+def gemm_gn_f32x(x2d, mean_rstd, gamma, beta, w, bias, hw, acc=None, eps=1e-6):
     """out[M][N] = GroupNorm(x)[M][K] @ W^T + bias with the normalisation fused into the operand staging (AttnBlock's q | k | v
     projection on the split-fp32 path; csrc/gemm_gn_f32x.hip).  x2d (M, K) fp32 rows of NHWC pixels, `hw` rows per image,
-    mean_rstd (B, 32, 2), w a SplitWeight of the stacked (N, K) weights."""
-    _need_cuda(x2d, mean_rstd)
+    mean_rstd (B, 32, 2) — or `acc`, the statistics of x as the accumulators its producer left — w a SplitWeight of the stacked
+    (N, K) weights."""
+    _need_cuda(x2d)
     M, K = x2d.shape
     N = w.shape[0]
     out = torch.empty((M, N), device=x2d.device, dtype=torch.float32)
+    if acc is not None:
+        check(_lib.load().sgam_gemm_gn_acc_f32x(_p(x2d), x2d.stride(0), _p(acc), float(eps), _p(_f32c(gamma)), _p(_f32c(beta)),
+                                                _p(w.planes), float(w.scale), _p(bias), _p(out), N, M, N, K, hw, _stream()),
+              "sgam_gemm_gn_acc_f32x")
+        return out
     check(_lib.load().sgam_gemm_gn_f32x(_p(x2d), x2d.stride(0), _p(mean_rstd), _p(_f32c(gamma)), _p(_f32c(beta)), _p(w.planes),
                                         float(w.scale), _p(bias), _p(out), N, M, N, K, hw, _stream()), "sgam_gemm_gn_f32x")
     return out

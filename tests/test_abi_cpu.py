@@ -20,7 +20,7 @@ def _declared_symbols():
 def test_library_is_built_and_loads():
     assert os.path.exists(_lib.LIB_PATH), "run `python -m sgam_neurips22_amd.build`"
     lib = _lib.load()
-    assert lib.sgam_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.sgam_abi_version() == _lib.ABI_VERSION == 7
     assert b"gfx950" in lib.sgam_build_info()
 
 
@@ -42,8 +42,10 @@ def test_conv_desc_layout_matches_header():
     text = open(os.path.join(ROOT, "include", "sgam_hip.h")).read()
     body = re.search(r"typedef struct sgam_conv_desc \{(.*?)\} sgam_conv_desc;", text, flags=re.S).group(1)
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
-    fields = [f.strip() for decl in re.findall(r"int32_t ([^;]+);", body) for f in decl.split(",")]
+    fields = [f.strip().lstrip("*") for decl in re.findall(r"int32_t ([^;]+);", body) for f in decl.split(",")]
     assert fields == [n for n, _ in _lib.ConvDesc._fields_]
+    # the trailing pointer (`int32_t *arrive`) sits on its natural 8-byte boundary in both views of the struct
+    assert _lib.ConvDesc.arrive.offset == 96 and ctypes.sizeof(_lib.ConvDesc) == 104
 
 
 def test_argument_validation_without_gpu():
