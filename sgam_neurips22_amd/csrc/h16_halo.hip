@@ -748,6 +748,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p
     // [channel quarter][row tile][4-channel unit] rows of 64 lanes x 8 bytes (+ 8 bytes: the producers' column-wise writes spread over the banks)
     constexpr int RROW = 64 * 2 + 2;                                       // dwords per row
     __shared__ __attribute__((aligned(8))) unsigned res_lds[4 * 4 * 4 * RROW];
+    __shared__ __attribute__((aligned(16))) float bias_lds[BN];            // ... and the tile's 128 bias values, the same way
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool producer = wave >= 4;
@@ -904,8 +905,66 @@ __global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p
         // (their epilogue's order) while they multiply its last: the epilogue finds it behind the barrier instead of waiting two
         // memory round trips for it (cycle stamps: 8.4 k of the epilogue's 11 k cycles went until its stores were issued)
         u32x2 rres[16];
+        float rbias = 0.f;
         int r_s = 0, r_it = 0;                                             // (slab, tile turn) of the step the consumers multiply
+        // The consumers' epilogue leaves the per-lane partial statistics of tile `it` in `estat` and goes straight on to the next
+        // tile; the producer wavefront w + 4 finishes consumer w's chunk records one step later (the consumers are then
+        // multiplying slab 1 of the next tile): the same balanced tree, the same fp64 folds, the same records as the one-role
+        // kernel — 4.8 k cycles that used to sit between two tiles' MFMAs (cycle stamps).
+        auto stats_tree = [&](int it) {
+            int b, ty0, tx0, n0;
+            decode(it, b, ty0, tx0, n0);
+            const int t_img = (ty0 / TH) * tiles_x + tx0 / TW;
+            const int cw = wave - 4, wn0 = n0 + cw * 32;
+            float *sl = epi[cw];                                            // [row half][unit = 4 half + k][2]
+            if (lane < 32) {
+                const int v = lane & 15, h2 = lane >> 4;
+                float t[32];
+#pragma unroll
+                for (int i2 = 0; i2 < 32; ++i2) t[i2] = estat[cw][v][32 * h2 + i2];
+#pragma unroll
+                for (int w2 = 16; w2 >= 1; w2 >>= 1)
+#pragma unroll
+                    for (int i2 = 0; i2 < w2; ++i2) t[i2] = t[i2] + t[i2 + w2];
+                const int r = v >> 3, k = (v >> 1) & 3, which = v & 1;
+                sl[(r * 8 + h2 * 4 + k) * 2 + which] = t[0];
+            }
+            const int c4_per_group = p.gn_cpg / 4;
+            const int groups_here = 8 / c4_per_group;
+            if (lane < groups_here * 2) {
+                const int r = lane / groups_here, gl = lane - r * groups_here;
+                double ds = 0.0, dss = 0.0;
+                for (int k = 0; k < c4_per_group; ++k) {
+                    ds += (double)sl[(r * 8 + gl * c4_per_group + k) * 2];
+                    dss += (double)sl[(r * 8 + gl * c4_per_group + k) * 2 + 1];
+                }
+                const int g = (wn0 / p.gn_cpg) + gl;
+                const int groups = p.N / p.gn_cpg;
+                if (g < groups) {
+                    const int chunks_per_b = tiles_img * 2;
+                    if (p.gn_acc) {
+                        sgam_stats_acc_add(reinterpret_cast<long long *>(p.gn_partial), b, blockIdx.x, g, ds, dss);
+                    } else {
+                        double *o = p.gn_partial + (((int64_t)b * chunks_per_b + t_img * 2 + r) * groups + g) * 2;
+                        o[0] = ds;
+                        o[1] = dss;
+                    }
+                }
+            }
+        };
         auto residual = [&]() {
+            if (p.gn_partial && r_s == 1 && r_it >= 1) stats_tree(r_it - 1);
+            if (p.bias) {
+                if (r_s == slabs - 2) {
+                    int b, ty0, tx0, n0;
+                    decode(r_it, b, ty0, tx0, n0);
+                    rbias = (ptid < BN && n0 + ptid < p.n_valid) ? p.bias[n0 + ptid] : 0.f;
+                } else if (r_s == slabs - 1 && ptid < BN) {
+                    bias_lds[ptid] = rbias;
+                }
+            } else if (r_s == slabs - 1 && ptid < BN && r_it == 0) {
+                bias_lds[ptid] = 0.f;
+            }
             if (p.res) {
                 if (r_s == slabs - 2) {
                     int b, ty0, tx0, n0;
@@ -973,6 +1032,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p
             HPC_STAMP(6 + 2 * q);
             __syncthreads();
             HPC_STAMP(7 + 2 * q);
+        }
+        if (p.gn_partial) {
+            __syncthreads();                                               // (Z) the consumers' last epilogue has left its partials
+            stats_tree(my_tiles - 1);
         }
         return;
     }
@@ -1055,13 +1118,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p
     auto epilogue = [&](int it) {
         int b, ty0, tx0, n0;
         decode(it, b, ty0, tx0, n0);
-        const int t_img = (ty0 / TH) * tiles_x + tx0 / TW;
         const int n_lim = p.n_valid;
         const unsigned osz = p.out_f32 ? 4u : 2u;
         const unsigned o_bytes = (unsigned)(((int64_t)(p.M - 1) * p.ldc + n_lim) * osz);
-        const unsigned bias_bytes = p.bias ? (unsigned)(p.N * 4) : 0u;
         const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)o_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)p.bias, 0, (int)bias_bytes, 0x00020000);
         constexpr unsigned OOB = 0xFFFFFFF0u;
         const int wn0 = n0 + wn * 32;
         const int pl = lane & 31, hh = lane >> 5;
@@ -1076,8 +1136,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p
         f32x4 bv[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            bv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                  rb, (int)hsel(nb + 4 * k < n_lim, (unsigned)(nb + 4 * k) * 4u, OOB), 0, 0));
+            bv[k] = *reinterpret_cast<const f32x4 *>(&bias_lds[wn * 32 + hh * 16 + 4 * k]);      // (zeros beyond n_valid, like the OOB load)
             us[0][k] = us[1][k] = uss[0][k] = uss[1][k] = 0.f;
         }
         // two row halves (= the two statistics chunks of the tile); the residual comes out of LDS (the producers put it there)
@@ -1145,45 +1204,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p
                     estat[wave][(r * 4 + k) * 2][lane] = us[r][k];
                     estat[wave][(r * 4 + k) * 2 + 1][lane] = uss[r][k];
                 }
-            // The sum over the 32 pixel lanes of a lane half, in the ORDER of the xor butterfly (16, 8, 4, 2, 1) the one-role kernel
-            // runs with 160 cross-lane shuffles (ds_bpermute: ~3 k cycles of an 11 k-cycle epilogue): lane (half, v) reads the 32
-            // values of statistic v and adds them as the same balanced tree — same bits, 32 LDS reads.
-            // (same wavefront wrote and reads: program order on LDS suffices)
-            float *sl = epi[wave];                                          // [row half][unit = 4 half + k][2]
-            if (lane < 32) {
-                const int v = lane & 15, h2 = lane >> 4;
-                float t[32];
-#pragma unroll
-                for (int i2 = 0; i2 < 32; ++i2) t[i2] = estat[wave][v][32 * h2 + i2];
-#pragma unroll
-                for (int w2 = 16; w2 >= 1; w2 >>= 1)
-#pragma unroll
-                    for (int i2 = 0; i2 < w2; ++i2) t[i2] = t[i2] + t[i2 + w2];
-                const int r = v >> 3, k = (v >> 1) & 3, which = v & 1;
-                sl[(r * 8 + h2 * 4 + k) * 2 + which] = t[0];
-            }
-            const int c4_per_group = p.gn_cpg / 4;
-            const int groups_here = 8 / c4_per_group;
-            if (lane < groups_here * 2) {
-                const int r = lane / groups_here, gl = lane - r * groups_here;
-                double ds = 0.0, dss = 0.0;
-                for (int k = 0; k < c4_per_group; ++k) {
-                    ds += (double)sl[(r * 8 + gl * c4_per_group + k) * 2];
-                    dss += (double)sl[(r * 8 + gl * c4_per_group + k) * 2 + 1];
-                }
-                const int g = (wn0 / p.gn_cpg) + gl;
-                const int groups = p.N / p.gn_cpg;
-                if (g < groups) {
-                    const int chunks_per_b = tiles_img * 2;
-                    if (p.gn_acc) {
-                        sgam_stats_acc_add(reinterpret_cast<long long *>(p.gn_partial), b, blockIdx.x, g, ds, dss);
-                    } else {
-                        double *o = p.gn_partial + (((int64_t)b * chunks_per_b + t_img * 2 + r) * groups + g) * 2;
-                        o[0] = ds;
-                        o[1] = dss;
-                    }
-                }
-            }
+            // (the tree over the lanes and the fp64 folds: the producers' stats_tree, one step later)
         }
     };
 
@@ -1215,6 +1236,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p
         }
         if (c_s == slabs) { c_s = 0; epilogue(c_it++); HPC_STAMP(40 + c_it); }
     }
+    if (p.gn_partial) __syncthreads();                                     // (Z)
 #undef HPC_DS_READ
 #undef HPC_STAMP
 }
