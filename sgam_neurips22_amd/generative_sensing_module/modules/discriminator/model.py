@@ -35,4 +35,10 @@ class NLayerDiscriminator(nn.Module):
         self.main = nn.Sequential(*seq)
 
     def forward(self, input):
-        raise NotImplementedError("the discriminator runs inside sgam_neurips22_amd.training.VQGANTrainer (HIP forward + backward)")
+        """reference :65-67: (B,C,H,W) -> (B,1,h,w) patch logits — one forward of the tape training.py differentiates (train()
+        mode: BatchNorm on batch statistics, running statistics updated, as the reference's forward inside `fit`; an eval()-mode
+        BatchNorm raises, see training._BNLReLU), for callers of `loss.discriminator(x)`"""
+        from .... import ops, training
+        with training._mfma_mode():
+            logits = training._DiscTape(self, {}).fwd(ops.nchw_to_nhwc(input.float().contiguous(), c_pad=32))
+        return ops.nhwc_to_nchw(logits[..., :1].contiguous())

@@ -49,4 +49,10 @@ class LPIPS(nn.Module):
         return getattr(self, f"lin{k}").model[-1].weight.detach().reshape(-1).float().contiguous()
 
     def forward(self, input, target):
-        raise NotImplementedError("LPIPS runs inside sgam_neurips22_amd.training (HIP forward + backward)")
+        """reference lpips.py:41-55: (B,3,H,W) x 2 in [-1, 1] -> (B,1,1,1) perceptual distances — the forward half of the tape
+        training.py differentiates (same kernels, strict-fp32 MFMA mode), for callers of `loss.perceptual_loss(a, b)`"""
+        from .... import ops, training
+        with training._mfma_mode():
+            vals, _ = training._Lpips(self).loss_and_grad(ops.nchw_to_nhwc(input.float().contiguous(), c_pad=32),
+                                                         ops.nchw_to_nhwc(target.float().contiguous(), c_pad=32), 0.0, values_only=True)
+        return torch.tensor(vals, device=input.device, dtype=torch.float32).view(-1, 1, 1, 1)

@@ -682,9 +682,9 @@ class _Lpips:
               "sgam_channel_affine_f32")
         return y
 
-    def loss_and_grad(self, rec_nhwc, target_nhwc, grad_scale):
+    def loss_and_grad(self, rec_nhwc, target_nhwc, grad_scale, values_only=False):
         """rec / target (B,H,W,>=3) NHWC (RGB first) -> (values per image [B] host floats, grad_scale * d sum_b val_b / d rec
-        as (B,H,W,32) with the RGB channels filled)"""
+        as (B,H,W,32) with the RGB channels filled; None with values_only: the forward of LPIPS.forward)"""
         lib = _lib.load()
         B, H, W, _ = rec_nhwc.shape
         t0, t1 = self._trunk(), self._trunk()
@@ -702,6 +702,8 @@ class _Lpips:
             ph = part.cpu().numpy().sum(axis=1) / (Hk * Wk)
             vals = [v + float(a) for v, a in zip(vals, ph)]
             dfeat.append(df)
+        if values_only:
+            return vals, None
         # backward through the trunk of the reconstruction: the five level gradients enter at their depths
         g = dfeat[4]
         for k in (4, 3, 2, 1, 0):

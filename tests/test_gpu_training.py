@@ -521,3 +521,32 @@ def test_full_training_step_with_lpips_and_discriminator(golden):
     for n, q in cfg.discriminator.named_parameters():
         assert _rel(tr.dgrads[q], r["d_grads"][n]) <= 3e-3, n
     print(f"[lpips + gan] worst relative autoencoder gradient error {worst:.2e}, p_loss {log['train/p_loss']:.5f}, d_weight {log['train/d_weight']:.5f}")
+
+
+def test_loss_modules_keep_the_reference_forward_surface(golden):
+    """`loss.discriminator(x)` and `loss.perceptual_loss(a, b)` — the reference's nn.Module call surface (discriminator/model.py:65-67,
+    lpips.py:41-55) — run the same kernels as the trainer's tapes: patch logits against the oracle (train-mode BatchNorm, running
+    statistics updated once), LPIPS values against the reference class's own output"""
+    from test_oracle_golden import lpips_state_dict
+    from oracle import patchgan as OP
+    from sgam_neurips22_amd.generative_sensing_module.modules.discriminator.model import NLayerDiscriminator
+    from sgam_neurips22_amd.generative_sensing_module.modules.losses.lpips import LPIPS
+    disc = NLayerDiscriminator(input_nc=4, n_layers=3)
+    dsd = testing.synthetic_disc_state_dict(disc.state_dict(), seed=2)
+    disc.load_state_dict(dsd)
+    disc = disc.to(DEV).train()
+    x = testing.seeded_tensor("disc.x", (2, 4, 64, 64), scale=0.5)
+    logits = disc(x.to(DEV))
+    want = OP.discriminator({k: v.clone() for k, v in dsd.items()}, x, n_layers=3, training=True)
+    assert logits.shape == want.shape and _rel(logits, want) <= 1e-4
+    assert int(disc.main[3].num_batches_tracked) == 1
+    with pytest.raises(NotImplementedError):
+        disc.eval()(x.to(DEV))
+    g = golden("lpips_small.npz")
+    lp = LPIPS()
+    lp.load_state_dict(lpips_state_dict(golden))
+    lp = lp.to(DEV).eval()
+    a = testing.seeded_tensor("lpips.a", (2, 3, 64, 64), scale=0.5).clamp(-1, 1)
+    b = testing.seeded_tensor("lpips.b", (2, 3, 64, 64), scale=0.5).clamp(-1, 1)
+    v = lp(a.to(DEV), b.to(DEV))
+    assert v.shape == (2, 1, 1, 1) and np.allclose(v.reshape(-1).cpu().numpy(), g["value"], rtol=1e-4)
