@@ -28,7 +28,9 @@ SOURCES = {
     "h16_halo.hip": [f"-DSGAM_HABLATE={os.environ.get('SGAM_HABLATE', '0')}",
                      f"-DSGAM_HDIRECT={os.environ.get('SGAM_HDIRECT', '1')}",
                      f"-DSGAM_HWGM={os.environ.get('SGAM_HWGM', '1')}",
-                     f"-DSGAM_HSB={os.environ.get('SGAM_HSB', '2')}"],
+                     f"-DSGAM_HSB={os.environ.get('SGAM_HSB', '2')}",
+                     f"-DSGAM_HFD2={os.environ.get('SGAM_HFD2', '1')}",
+                     f"-DSGAM_HFD4={os.environ.get('SGAM_HFD4', '1')}"],
     "attention.hip": [f"-DSGAM_ATTN_ABLATE={os.environ.get('SGAM_ATTN_ABLATE', '0')}"],
     "vq.hip": ["-ffp-contract=off"],
     "layout.hip": ["-ffp-contract=off"],

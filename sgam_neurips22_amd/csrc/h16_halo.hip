@@ -43,6 +43,12 @@
 #ifndef SGAM_HSB
 #define SGAM_HSB 2         // scheduling barriers in the slab body: 0 none, 1 in front of the staging arithmetic of tap 1, 2 at every tap
 #endif
+#ifndef SGAM_HFD2
+#define SGAM_HFD2 1        // A-fragment read-ahead of the one-role kernel, in steps: tiles of two row tiles per wavefront (64-row) ...
+#endif
+#ifndef SGAM_HFD4
+#define SGAM_HFD4 1        // ... and of four (128-row; 256-row)
+#endif
 #ifndef SGAM_HABLATE
 #define SGAM_HABLATE 0     // timing experiments only (results are wrong when != 0): 1 no MFMAs, 2 no epilogue, 4 no main loop,
                            // 8 no weight-fragment loads in the loop, 16 no halo staging in the loop, 32 stores dropped
@@ -361,7 +367,13 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
     hload(s0 + 1, s0 + 1 < s1);
     __syncthreads();
 
-    u32x4 fa[2][TM];
+    // A fragments are read FD steps (of TM MFMAs) ahead into a ring of FD + 1 register sets.  One step ahead covers 32 TM cycles of
+    // MFMA work (128 at TM = 4, 64 at TM = 2: less than an LDS round trip); two to four steps were measured (scripts/r04p.sh):
+    // -4 % on the 64^2 x 256 layer behind a cache flush, nothing in the frame — the small-map launches (one wavefront per SIMD) are
+    // the sum of a 3 us prologue, a 2 us epilogue and slabs in which staging arithmetic, weight loads and MFMAs of ONE wavefront
+    // follow each other (ablations: 17.2 us; 14.0 without staging, 15.1 without weight loads, 11.5 without both), not LDS latency
+    constexpr int FD = TM >= 4 ? SGAM_HFD4 : SGAM_HFD2;
+    u32x4 fa[FD + 1][TM];
     const unsigned short *hb = smem;
     auto afrag = [&](const int set, const int tap, const int kk) {          // upsampling form: per-lane source pixel
         const int ky = tap / 3, kx = tap - 3 * ky;
@@ -378,20 +390,18 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
 #pragma unroll
         for (int i = 0; i < TM; ++i) HDS_READ(fa[set][i], a_lds[i], 2 * (ky * LP + kx * XLD + kk * 16));
     };
-    auto await = [&](const int set, const bool next_in_flight) {      // all reads but the newest TM have landed
-        if constexpr (TM == 4) {
-            if (next_in_flight)
-                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[set][0]), "+v"(fa[set][1]), "+v"(fa[set][2]), "+v"(fa[set][3]));
-            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[set][0]), "+v"(fa[set][1]), "+v"(fa[set][2]), "+v"(fa[set][3]));
-        } else if constexpr (TM == 2) {
-            if (next_in_flight) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[set][0]), "+v"(fa[set][1]));
-            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[set][0]), "+v"(fa[set][1]));
-        } else {
-            static_assert(TM == 1 || TM == 2 || TM == 4, "wait counts are spelled for 1, 2 or 4 row tiles");
-            if (next_in_flight) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(fa[set][0]));
-            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[set][0]));
-        }
+    // all reads but the newest `younger` (a multiple of TM <= FD TM: the sets issued for later steps) have landed; the fragment
+    // registers are tied to the wait so that no MFMA moves above it
+#define HAWAIT(n_) else if (younger == (n_)) { if constexpr (TM == 4) asm volatile("s_waitcnt lgkmcnt(" #n_ ")" : "+v"(fa[set][0]), "+v"(fa[set][1]), "+v"(fa[set][2]), "+v"(fa[set][3])); \
+                                                 else if constexpr (TM == 2) asm volatile("s_waitcnt lgkmcnt(" #n_ ")" : "+v"(fa[set][0]), "+v"(fa[set][1])); \
+                                                 else asm volatile("s_waitcnt lgkmcnt(" #n_ ")" : "+v"(fa[set][0])); }
+    auto await = [&](const int set, const int younger) {
+        static_assert(TM == 1 || TM == 2 || TM == 4, "fragment waits are spelled for 1, 2 or 4 row tiles");
+        static_assert(FD >= 1 && FD * TM <= 12, "wait counts are spelled up to 12 outstanding reads");
+        if (false) {}
+        HAWAIT(0) HAWAIT(1) HAWAIT(2) HAWAIT(3) HAWAIT(4) HAWAIT(6) HAWAIT(8) HAWAIT(12)
     };
+#undef HAWAIT
     for (int sl = s0; sl < ((SGAM_HABLATE & 4) ? s0 : s1); ++sl) {
         const bool has_next = sl + 1 < s1;
         hb = smem + hcur * HPL;
@@ -422,20 +432,23 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
             for (int kk = 0; kk < 2; ++kk) {
                 const int q = tap * 2 + kk;
                 if constexpr (!UPS) {
-                    if (q == 0) afrag_asm(0, 0, 0);
-                    if (q < 17) afrag_asm((q + 1) & 1, (q + 1) >> 1, (q + 1) & 1);
-                    await(q & 1, q < 17);
+                    if (q == 0) {
+#pragma unroll
+                        for (int d = 0; d < FD; ++d) afrag_asm(d, d >> 1, d & 1);
+                    }
+                    if (q + FD < 18) afrag_asm((q + FD) % (FD + 1), (q + FD) >> 1, (q + FD) & 1);
+                    await(q % (FD + 1), TM * (17 - q < FD ? 17 - q : FD));
                 } else {
                     if (q == 0) afrag(0, 0, 0);
-                    if (q < 17) afrag((q + 1) & 1, (q + 1) >> 1, (q + 1) & 1);
+                    if (q < 17) afrag((q + 1) % (FD + 1), (q + 1) >> 1, (q + 1) & 1);
                 }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        if constexpr (SGAM_HABLATE & 1) acc[i][j][0] += __builtin_bit_cast(float, fa[q & 1][i][0] ^ bq[set][j][kk][0]);
-                        else if constexpr (SGAM_HDIRECT) acc[i][j] = HH<HT>::mfma(bq[set][j][kk], fa[q & 1][i], acc[i][j]);
-                        else acc[i][j] = HH<HT>::mfma(fa[q & 1][i], bq[set][j][kk], acc[i][j]);
+                        if constexpr (SGAM_HABLATE & 1) acc[i][j][0] += __builtin_bit_cast(float, fa[q % (FD + 1)][i][0] ^ bq[set][j][kk][0]);
+                        else if constexpr (SGAM_HDIRECT) acc[i][j] = HH<HT>::mfma(bq[set][j][kk], fa[q % (FD + 1)][i], acc[i][j]);
+                        else acc[i][j] = HH<HT>::mfma(fa[q % (FD + 1)][i], bq[set][j][kk], acc[i][j]);
                     }
             }
             if constexpr (!(SGAM_HABLATE & 8) && NBR == 9) bload(tap, tap, sl + 1, has_next);      // this tap's set, next slab
