@@ -78,11 +78,11 @@ typedef struct sgam_conv_desc {
     /* optional plan override (autotuner, sgam_neurips22_amd/tune.py); 0 = built-in heuristic.
      * (plan_bm, plan_bn) in {(128,128), (64,128), (64,64)}; plan_ksplit >= 1. */
     int32_t plan_bm, plan_bn, plan_ksplit;
-    /* optional (split fp32 and 16-bit families): `arrive_count` int32 arrival counters in device memory, ZERO on entry; a
+    /* optional (split-fp32 family only; the 16-bit kernels ignore it): `arrive_count` int32 arrival counters in device memory, ZERO on entry; a
      * split-K launch whose tiles fit them sums the partial tiles inside the convolution kernel (the last split of a tile to
      * arrive does it, in the fixed slab order of the combine kernels) instead of launching a combine, and leaves the
      * counters zero again.  One launch at a time may use a given counter array (launches on ONE stream qualify).
-     * NULL / 0: partial tiles + combine launch.  sgam_conv2d_f32x_fixup / sgam_conv2d_h16_fixup say which it will be;
+     * NULL / 0: partial tiles + combine launch.  sgam_conv2d_f32x_fixup says which it will be;
      * the *_stats_chunks queries follow it (one statistics chunk per output tile). */
     int32_t arrive_count;
     /* 1: the statistics a launch leaves for the next GroupNorm (the `gn_partial` argument of the *_stats / *_gn / *_gnp entry
@@ -90,7 +90,8 @@ typedef struct sgam_conv_desc {
      * fixed point (hi in units of 2^-8, lo = 32 fraction bits), added with 64-bit atomics — integer sums do not depend on
      * the order the workgroups arrive in, so no fold launch is needed between producer and consumer and results stay
      * run-to-run identical.  ZERO before the launch.  Consumers take them through the *_gnp entry points with
-     * chunks_in = 0 (every GroupNorm-fusing kernel), sgam_groupnorm_stats_from_partials_f32 / *_from_partials_* with nchunk = 0. */
+     * chunks_in = 0 (every GroupNorm-fusing kernel), sgam_groupnorm_stats_from_partials_f32 / *_from_partials_* with nchunk = 0
+     * (32 groups only: the record is laid out per 32 groups). */
     int32_t stats_acc;
     int32_t *arrive;
 } sgam_conv_desc;

@@ -3,7 +3,7 @@
 residual, output statistics — timed two ways: HOT (one launch replayed back to back from a HIP graph: operands L2 / MALL
 resident) and CHAIN (six layers with their own weights ping-ponging three activation buffers behind a 1 GiB flush per
 round, replayed from a graph: operands arrive the way they do inside a frame).
-   python scripts/h16_layer_time.py [B=1] [dtype=bf16] [HW=256] [C=128] [bm=128]"""
+   python scripts/h16_layer_time.py [B=1] [dtype=bf16] [HW=256] [C=128] [bm=128] [swish=1]"""
 import ctypes
 import os
 import sys
@@ -19,6 +19,7 @@ dtn = sys.argv[2] if len(sys.argv) > 2 else "bf16"
 HW = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 C = int(sys.argv[4]) if len(sys.argv) > 4 else 128
 bm = int(sys.argv[5]) if len(sys.argv) > 5 else 128
+sw = int(sys.argv[6]) if len(sys.argv) > 6 else 1          # 0: GroupNorm without swish (bounds what a free swish would buy)
 dt = ops.DTYPES[dtn]
 dev = "cuda"
 lib = _lib.load()
@@ -36,7 +37,7 @@ gf = 2.0 * B * HW * HW * C * 9 * C / 1e9
 
 
 def launch(x, w, res, out):
-    rc = lib.sgam_conv2d_halo_nhwc_h16(ctypes.byref(d), ops.H16[dt], ops._p(x), ops._p(mr), ops._p(gamma), ops._p(beta), 1, ops._p(w),
+    rc = lib.sgam_conv2d_halo_nhwc_h16(ctypes.byref(d), ops.H16[dt], ops._p(x), ops._p(mr), ops._p(gamma), ops._p(beta), sw, ops._p(w),
                                        ops._p(bias), ops._p(res) if res is not None else None, ops._p(out), 0, ops._p(part), None, 0,
                                        ops._stream())
     assert rc == 0, rc
@@ -94,5 +95,5 @@ recs, br = ops.kernel_timeline(cold)
 cs = sorted(ms - br for name, ms, *_ in recs if "halo" in name)
 cold_us = cs[len(cs) // 2] * 1e3
 name = next(n for n, *_ in recs if "halo" in n)
-print(f"{name} B={B} {dtn} {HW}x{HW}x{C} bm={bm} HPF={os.environ.get('SGAM_HPF', '0')}: hot {hot_plain:6.1f} us ({gf / hot_plain / 1e-3 / 1e3:6.1f} TF/s)  "
+print(f"{name} B={B} {dtn} {HW}x{HW}x{C} bm={bm} sw={sw} HPF={os.environ.get('SGAM_HPF', '0')}: hot {hot_plain:6.1f} us ({gf / hot_plain / 1e-3 / 1e3:6.1f} TF/s)  "
       f"hot+res {hot_res:6.1f}  chain {chain_us:6.1f} ({gf / chain_us / 1e-3 / 1e3:6.1f} TF/s = {gf / chain_us / 2.5:.3f} of 2500)  cold {cold_us:6.1f}")

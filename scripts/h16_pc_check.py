@@ -37,16 +37,23 @@ def dump():
         gamma, beta = testing.seeded_tensor(f"pc.g{ci}", (C,)).cuda() + 1.0, testing.seeded_tensor(f"pc.be{ci}", (C,)).cuda()
         mr = (testing.seeded_tensor(f"pc.mr{ci}", (B, 32, 2)) * 0.2 + torch.tensor([0.0, 1.0])).cuda().contiguous()
         d = ConvDesc(B=B, Hi=H, Wi=W, Cin=C, Ho=H, Wo=W, N=N, KH=3, KW=3, stride=1, pad_t=1, pad_l=1, upsample2x=0, lda=C, ldb=9 * C,
-                     ldc=N, ldr=N if res else 0, n_valid=N, bias_per_row=0, plan_bm=128, plan_bn=128, plan_ksplit=1)
+                     ldc=N, ldr=N if res else 0, n_valid=N, bias_per_row=0, plan_bm=int(os.environ.get("PC_BM", "128")), plan_bn=128,
+                     plan_ksplit=int(os.environ.get("PC_KS", "1")))
         chunks = lib.sgam_conv2d_h16_stats_chunks(ctypes.byref(d))
         part = torch.zeros((B, max(chunks, 1), 32, 2), device="cuda", dtype=torch.float64)
         y = torch.empty((B * H * W, N), device="cuda", dtype=torch.float32 if f32 else dt)
+        wsb = lib.sgam_conv2d_halo_h16_workspace_bytes(ctypes.byref(d))
+        ws = torch.empty((max(wsb, 16),), device="cuda", dtype=torch.uint8)
         for rep in range(2):
             rc = lib.sgam_conv2d_halo_nhwc_h16(ctypes.byref(d), ops.H16[dt], ops._p(x), ops._p(mr) if gn else None, ops._p(gamma) if gn else None,
                                                ops._p(beta) if gn else None, int(sw), ops._p(w), ops._p(bias), ops._p(r) if res else None, ops._p(y),
-                                               int(f32), ops._p(part) if chunks > 0 else None, None, 0, ops._stream())
-            assert rc == 0, (ci, rc)
+                                               int(f32), ops._p(part) if chunks > 0 else None, ops._p(ws) if wsb > 0 else None, max(wsb, 0), ops._stream())
+            if rc != 0:
+                break
         torch.cuda.synchronize()
+        if rc != 0:                  # (a plan this build does not take: reported, compared like a digest)
+            out[str(ci)] = [f"rc={rc}", f"rc={rc}", 0.0]
+            continue
         out[str(ci)] = [hashlib.sha256(y.contiguous().view(torch.uint8).cpu().numpy().tobytes()).hexdigest()[:16], hashlib.sha256(part.cpu().numpy().tobytes()).hexdigest()[:16],
                         float(y.float().abs().mean())]
     print("DUMP " + json.dumps(out))

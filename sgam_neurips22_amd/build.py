@@ -24,13 +24,20 @@ SOURCES = {
                       f"-DSGAM_XSB={os.environ.get('SGAM_XSB', '1')}",
                       f"-DSGAM_XNT={os.environ.get('SGAM_XNT', '0')}",
                       f"-DSGAM_XWGM={os.environ.get('SGAM_XWGM', '1')}",
-                      f"-DSGAM_XSOFF={os.environ.get('SGAM_XSOFF', '1')}"],
+                      f"-DSGAM_XSOFF={os.environ.get('SGAM_XSOFF', '1')}",
+                      f"-DSGAM_XPEEL={os.environ.get('SGAM_XPEEL', '1')}",
+                      f"-DSGAM_XLB64={os.environ.get('SGAM_XLB64', '3')}"],
     "h16_halo.hip": [f"-DSGAM_HABLATE={os.environ.get('SGAM_HABLATE', '0')}",
                      f"-DSGAM_HDIRECT={os.environ.get('SGAM_HDIRECT', '1')}",
                      f"-DSGAM_HWGM={os.environ.get('SGAM_HWGM', '1')}",
                      f"-DSGAM_HSB={os.environ.get('SGAM_HSB', '2')}",
                      f"-DSGAM_HFD2={os.environ.get('SGAM_HFD2', '1')}",
-                     f"-DSGAM_HFD4={os.environ.get('SGAM_HFD4', '1')}"],
+                     f"-DSGAM_HFD4={os.environ.get('SGAM_HFD4', '1')}",
+                     f"-DSGAM_HNBR={os.environ.get('SGAM_HNBR', '3')}",
+                     f"-DSGAM_HLT={os.environ.get('SGAM_HLT', '0')}",
+                     f"-DSGAM_HPEEL={os.environ.get('SGAM_HPEEL', '1')}",
+                     f"-DSGAM_HRPF={os.environ.get('SGAM_HRPF', '1')}",
+                     f"-DSGAM_HSWISH={os.environ.get('SGAM_HSWISH', '0')}"],
     "attention.hip": [f"-DSGAM_ATTN_ABLATE={os.environ.get('SGAM_ATTN_ABLATE', '0')}"],
     "vq.hip": ["-ffp-contract=off"],
     "layout.hip": ["-ffp-contract=off"],

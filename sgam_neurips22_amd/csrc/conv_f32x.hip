@@ -57,7 +57,7 @@ struct XParams {
     // ... or, instead of gn_stats, the producer's partial sums [B][gn_chunks_in][32][2] (fp64 {sum, sumsq} per chunk and group),
     // folded by the consumer itself (GNF kernels: a few chunks, one or two channel slabs per workgroup — no fold launch)
     const double *gn_partial_in;
-    const long long *gn_acc_in;   // ... or as the [B][32][4] int64 accumulators of sgam_common.h (any GN kernel: 32 bytes per group)
+    const long long *gn_acc_in;   // ... or as the [B][16][32][4] int64 accumulators of sgam_common.h (any GN kernel: 32 bytes per group)
     double gn_inv_n;     // 1 / (pixels per image x channels per group)
     int gn_chunks_in;
     float gn_eps;
@@ -65,7 +65,7 @@ struct XParams {
     int *arrive;         // optional: one arrival counter per output tile (zero between launches): the LAST split of a tile sums it (xfixup)
 
     double *gn_partial;  // optional: per-(row-half of the tile, group) {sum, sumsq} of the OUTPUT for the next GroupNorm
-    int gn_acc;          // ... 1: gn_partial is the [B][32][4] int64 ACCUMULATOR form (sgam_common.h: atomics instead of chunk records)
+    int gn_acc;          // ... 1: gn_partial is the [B][16][32][4] int64 ACCUMULATOR form (sgam_common.h: atomics instead of chunk records)
     int gn_cpg;          // channels per group of that GroupNorm (N / 32)
     int32_t *range_flag; // optional: set to 1 when an output is not finite (an operand left fp16's range, see sgam_hip.h)
     float inv_w_scale;   // 1 / (a_scale * w_scale), an exact power of two
@@ -200,6 +200,19 @@ __device__ __forceinline__ void gn_scale_shift(const XParams &p, int b, int c, f
 // the counter back to zero for the next launch.  256 threads (k-group 0 of the 64 x 64 tile), float4 per thread, 256 / (BN / 4)
 // rows per pass.  `SGAM_XFIX_FENCE` = 1 replaces the sc1 accesses by the memory model's release / acquire fences
 // (buffer_wbl2 / buffer_inv over the whole L2) — same results, kept for comparison.
+// What the DEFAULT (sc1) form rests on — it is opt-in (SGAM_XFIXUP=1) for that reason among others: the ordering "partial tile
+// visible device-wide before the ticket" comes from gfx950's cache policies (an sc1 store is acknowledged only once it has been
+// written through to memory, `s_waitcnt vmcnt(0)` waits for that acknowledgement, an sc1 load bypasses the non-coherent L2), NOT
+// from the relaxed ticket atomic, which orders nothing in the language's memory model; the fence build is the model-conforming
+// spelling of the same protocol.  The counter array belongs to ONE weight and the header's rule "one launch at a time per
+// counter array" is the caller's to keep: ops.py lends a weight's counters only to launches on the stream that first used
+// them (`_arrive`: any other stream gets partial tiles + the combine launch).
+#ifndef SGAM_XLB64
+#define SGAM_XLB64 3       // workgroups per CU the 64-row halo tile is compiled for (3: <= 168 registers, three wavefronts per SIMD)
+#endif
+#ifndef SGAM_XPEEL
+#define SGAM_XPEEL 1       // halo kernels: the last two slabs of a workgroup peeled (no staging of a slab that does not exist)
+#endif
 #ifndef SGAM_XFIX_FENCE
 #define SGAM_XFIX_FENCE 0
 #endif
@@ -673,6 +686,9 @@ __global__ __launch_bounds__(256 * wk_of(BM, BN)) void conv_gemm_f32x_kernel(con
                     for (int e = 0; e < 16; ++e) xch[((i * TN + j) * 16 + e) * 64 + lane] = acc[i][j][e];
         }
         __syncthreads();
+        // (the second group's wavefronts END here while the first group still executes __syncthreads() in xepilogue / xfixup: that is
+        // defined on this hardware — s_barrier counts the wavefronts of the workgroup that have not terminated — and it is the only
+        // place the library relies on it; a port to a part whose barrier counts launched wavefronts must keep them alive instead)
         if (wk == 1) return;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -703,7 +719,7 @@ __global__ __launch_bounds__(256 * wk_of(BM, BN)) void conv_gemm_f32x_kernel(con
 // ((TH/2 + 2) x (TW/2 + 2) pixels: a third of the pixels), and a lane finds the source pixel of (patch pixel, tap) as
 // ((p + k - 1) >> 1) + 1 per axis.
 template <int BM, int BN, bool GN, bool UPS = false, bool GNF = false>
-__global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParams p) {
+__global__ __launch_bounds__(256, (BM == 64 && !GNF) ? SGAM_XLB64 : 2) void conv3x3_f32x_halo2_kernel(const XParams p) {
     static_assert(!GNF || GN, "GNF = GroupNorm statistics folded from the producer's chunk partials: a GN kernel");
 #ifndef SGAM_XWGM
 #define SGAM_XWGM 1
@@ -978,8 +994,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
         }
     };
     constexpr bool XASM = !UPS && (SGAM_XABLATE != 30);
-    for (int sl = s0; sl < s1; ++sl) {
-        const bool has_next = sl + 1 < s1;
+    // one slab.  MODE 0: run-time flags say whether a next slab / the one behind it exist (dead loads go out of range and the
+    // staging arithmetic runs on the zeros they return); the peeled forms (SGAM_XPEEL, round 5) know: 1 = two more slabs follow,
+    // 2 = one more follows (stage it, request nothing), 3 = the last — nothing to stage: a workgroup of a split-K plan on the
+    // 16^2 / 32^2 maps walks one or two slabs, so half or all of its in-loop GroupNorm / swish / split work ran on zeros
+    auto slab = [&](const int sl, auto mode_) {
+        constexpr int MODE = decltype(mode_)::value;
+        const bool has_next = MODE == 0 ? sl + 1 < s1 : MODE != 3;
+        const bool has_next2 = MODE == 0 ? sl + 2 < s1 : MODE == 1;
         hb = smem + hcur * HBUF;
         if constexpr (XASM) {
             const unsigned hb_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short *)hb;
@@ -992,18 +1014,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
             // timing experiments (results are wrong): 21 no weight loads, 25 no halo staging, 24 neither, 27 neither and no A-fragment
             // reads (the bare MFMA stream), 26 everything but the MFMAs
             constexpr bool NOB = SGAM_XABLATE == 21 || SGAM_XABLATE == 24 || SGAM_XABLATE == 27;
-            constexpr bool NOH = SGAM_XABLATE == 24 || SGAM_XABLATE == 25 || SGAM_XABLATE == 27;
+            constexpr bool NOH = SGAM_XABLATE == 24 || SGAM_XABLATE == 25 || SGAM_XABLATE == 27 || MODE == 3;
             constexpr bool NOA = SGAM_XABLATE == 27, NOM = SGAM_XABLATE == 26;
             if (!NOB) {
                 if (tap < 7) bload((tap + 2) % 3, tap + 2, sl, true);
-                else bload((tap + 2) % 3, tap - 7, sl + 1, has_next);
+                else if constexpr (MODE != 3) bload((tap + 2) % 3, tap - 7, sl + 1, has_next);
             }
             // (28: the staging arithmetic and LDS stores run, on stale registers, without the in-loop halo LOADS; 29: the loads are
             // issued, nothing is done with them)
             if (!NOH && SGAM_XABLATE != 29 && tap >= 1 && tap <= NH) hprep_piece(tap - 1);    // next slab's halo, one piece per tap
             if (!NOH && tap == NH + 1) {
                 if (SGAM_XABLATE != 29) hstore(hcur ^ 1);               // idle buffer: nobody reads it during this slab
-                if (SGAM_XABLATE != 28) hload(sl + 2, sl + 2 < s1);
+                if constexpr (MODE != 2) {
+                    if (SGAM_XABLATE != 28) hload(sl + 2, has_next2);
+                }
             }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
@@ -1032,6 +1056,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32x_halo2_kernel(const XParam
         }
         __syncthreads();                                               // next halo visible; old one free for re-use
         hcur ^= 1;
+    };
+    if constexpr (!SGAM_XPEEL) {
+        for (int sl = s0; sl < s1; ++sl) slab(sl, std::integral_constant<int, 0>{});
+    } else if (s0 < s1) {
+        int sl = s0;
+        for (; sl + 2 < s1; ++sl) slab(sl, std::integral_constant<int, 1>{});
+        if (s1 - s0 >= 2) slab(s1 - 2, std::integral_constant<int, 2>{});
+        slab(s1 - 1, std::integral_constant<int, 3>{});
     }
     __syncthreads();                                  // every wavefront is done with the halo: LDS becomes the epilogue's
 

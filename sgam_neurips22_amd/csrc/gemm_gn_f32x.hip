@@ -38,7 +38,7 @@ struct GemmGnParams {
     double *gn_partial;        // [B][M / HW * HW / 64][32][2] or NULL: statistics of the output per 64-row chunk
     int ldr;
     const float *mean_rstd;    // [B][32][2]
-    const long long *acc_in;   // ... or the statistics of x as [B][32][4] int64 accumulators (sgam_common.h), finished per workgroup
+    const long long *acc_in;   // ... or the statistics of x as [B][16][32][4] int64 accumulators (sgam_common.h), finished per workgroup
     float gn_eps;
     int gn_acc;                // gn_partial is the accumulator form
     const float *gamma, *beta; // [K]
@@ -219,7 +219,7 @@ extern "C" int sgam_gemm_panel_f32x(const float *x, int32_t lda, const float *me
                            HW, stream);
 }
 
-// sgam_gemm_gn_f32x with the statistics of x as the [B][32][4] int64 accumulators its producer left (sgam_conv_desc.stats_acc):
+// sgam_gemm_gn_f32x with the statistics of x as the [B][16][32][4] int64 accumulators its producer left (sgam_conv_desc.stats_acc):
 // every workgroup finishes {mean, rstd} of its image's 32 groups itself — no fold launch
 extern "C" int sgam_gemm_gn_acc_f32x(const float *x, int32_t lda, const int64_t *gn_acc, float eps, const float *gamma, const float *beta,
                                      const void *w_planes, float w_scale, const float *bias, float *out, int32_t ldc, int32_t M, int32_t N,

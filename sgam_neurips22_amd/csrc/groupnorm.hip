@@ -427,7 +427,7 @@ extern "C" int sgam_groupnorm_from_partials_f32(const float *x, const double *pa
                                                 const float *beta, float *y, int32_t B, int32_t HW, int32_t C,
                                                 int32_t groups, float eps, int32_t fuse_swish, void *workspace,
                                                 int64_t workspace_bytes, void *stream) {
-    if (!x || !y || !partial || nchunk < 0 || !gamma || !beta || !gn_shape_ok(B, HW, C, groups)) return SGAM_EINVAL;
+    if (!x || !y || !partial || nchunk < 0 || (nchunk == 0 && groups != 32) || !gamma || !beta || !gn_shape_ok(B, HW, C, groups)) return SGAM_EINVAL;
     if (!sgam_aligned16(x) || !sgam_aligned16(y) || !sgam_aligned16(workspace) || !sgam_aligned16(partial)) return SGAM_EALIGN;
     if (!workspace || workspace_bytes < (int64_t)B * C * 2 * (int64_t)sizeof(float)) return SGAM_EWORKSPACE;
     hipStream_t s = sgam_stream(stream);
@@ -447,7 +447,7 @@ extern "C" int sgam_groupnorm_from_partials_f32(const float *x, const double *pa
 // a convolution that normalises while staging its input (sgam_conv2d_gn_nhwc_f32x)
 extern "C" int sgam_groupnorm_stats_from_partials_f32(const double *partial, int32_t nchunk, float *mean_rstd, int32_t B,
                                                       int32_t HW, int32_t C, int32_t groups, float eps, void *stream) {
-    if (!partial || nchunk < 0 || !mean_rstd || !gn_shape_ok(B, HW, C, groups)) return SGAM_EINVAL;
+    if (!partial || nchunk < 0 || (nchunk == 0 && groups != 32) || !mean_rstd || !gn_shape_ok(B, HW, C, groups)) return SGAM_EINVAL;
     if (!sgam_aligned16(partial)) return SGAM_EALIGN;
     SGAM_KLAUNCH(gn_finalize_stats_kernel, dim3(groups, B), dim3(256), 0, sgam_stream(stream), partial, mean_rstd, HW, C,
                        groups, nchunk, eps);
@@ -478,7 +478,7 @@ extern "C" int sgam_groupnorm_from_partials_h16(const void *x, const double *par
                                                 const float *beta, void *y, int32_t ht, int32_t B, int32_t HW, int32_t C,
                                                 int32_t groups, float eps, int32_t fuse_swish, void *workspace,
                                                 int64_t workspace_bytes, void *stream) {
-    if (!x || !y || !partial || nchunk < 0 || !gamma || !beta || !gn_shape_ok(B, HW, C, groups) || (ht != 0 && ht != 1))
+    if (!x || !y || !partial || nchunk < 0 || (nchunk == 0 && groups != 32) || !gamma || !beta || !gn_shape_ok(B, HW, C, groups) || (ht != 0 && ht != 1))
         return SGAM_EINVAL;
     if (!sgam_aligned16(x) || !sgam_aligned16(y) || !sgam_aligned16(workspace) || !sgam_aligned16(partial)) return SGAM_EALIGN;
     if (!workspace || workspace_bytes < (int64_t)B * C * 2 * (int64_t)sizeof(float)) return SGAM_EWORKSPACE;

@@ -47,7 +47,7 @@ struct H16Params {
     int M, ksplit, iters_total, iters_per_split;
     unsigned x_bytes, w_bytes;
     double *gn_partial;   // optional (direct epilogue, whole-K workgroups): per-(BM / 2 rows, group) {sum, sumsq} of the output
-    int gn_acc;           // ... 1: in the [B][32][4] int64 accumulator form (sgam_common.h)
+    int gn_acc;           // ... 1: in the [B][16][32][4] int64 accumulator form (sgam_common.h)
     int gn_cpg;           // channels per group of the output (N / 32)
 };
 

@@ -29,6 +29,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "sgam_common.h"
 
 #ifndef SGAM_HDIRECT
@@ -49,6 +51,21 @@
 #ifndef SGAM_HFD4
 #define SGAM_HFD4 1        // ... and of four (128-row; 256-row)
 #endif
+#ifndef SGAM_HNBR
+#define SGAM_HNBR 3        // weight-fragment ring of the 64- / 128-row tiles, in taps: 3 (two taps ahead) or 6 (five ahead: every weight
+#endif                     //    load a slab still needs is in the in-order vector-memory queue BEFORE the next halo load; slab loop unrolled by 2)
+#ifndef SGAM_HLT
+#define SGAM_HLT 0         // tap at which the staged halo is stored and the next halo load issued (0: NH + 1, right behind the last piece)
+#endif
+#ifndef SGAM_HPEEL
+#define SGAM_HPEEL 1       // 1: the last two slabs of a workgroup are peeled: no staging of a slab that does not exist, and (SGAM_HRPF) the
+#endif                     //    residual tile is requested where the (dead) halo load of the second-to-last slab stood, not in the epilogue
+#ifndef SGAM_HRPF
+#define SGAM_HRPF 1        // residual prefetch of the peeled form: 0 off, 1 the 128-row tile only (the 64-row tile would pay its fourth
+#endif                     //    wavefront per SIMD for the 16 registers), 2 every tile
+#ifndef SGAM_HSWISH
+#define SGAM_HSWISH 0      // fused GroupNorm + swish arithmetic: 0 fp32 (v_exp_f32 / v_rcp_f32, one rounding to 16 bits), 1 packed fp16
+#endif                     //    after the affine step (v_pk_* + v_exp_f16 / v_rcp_f16) — an agreement-rate experiment, DESIGN.md 5.5d
 #ifndef SGAM_HABLATE
 #define SGAM_HABLATE 0     // timing experiments only (results are wrong when != 0): 1 no MFMAs, 2 no epilogue, 4 no main loop,
                            // 8 no weight-fragment loads in the loop, 16 no halo staging in the loop, 32 stores dropped
@@ -97,7 +114,7 @@ struct HHParams {
     const double *gn_partial_in;
     int gn_chunks_in;
     float gn_inv_n, gn_eps;
-    const long long *gn_acc_in;   // ... or as [B][32][4] int64 accumulators (sgam_common.h): every table-filling GN kernel takes them
+    const long long *gn_acc_in;   // ... or as [B][16][32][4] int64 accumulators (sgam_common.h): every table-filling GN kernel takes them
     int gn_acc;                   // gn_partial is the accumulator form (atomics instead of chunk records)
     unsigned long long *dbg;      // SGAM_HPC_DBG=1: cycle stamps of workgroup 0 (producer / consumer kernel), else NULL
     int dbg_flags;                // SGAM_HPC_DBGF: timing experiments of that kernel (results wrong): 1 no MFMAs, 2 no producer priority
@@ -264,7 +281,29 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
                 float v0 = HH<HT>::to_f((unsigned short)(q[w2] & 0xFFFFu)), v1 = HH<HT>::to_f((unsigned short)(q[w2] >> 16));
                 v0 = v0 * gsc[2 * w2] + gsh[2 * w2];
                 v1 = v1 * gsc[2 * w2 + 1] + gsh[2 * w2 + 1];
-                if constexpr (SW) {
+                if constexpr (SW && SGAM_HSWISH == 1) {
+                    // the affine step in fp32, everything behind it on PAIRS in packed fp16: y (v_cvt_pk_f16_f32), -y log2 e
+                    // (v_pk_mul_f16), 2^. per half (v_exp_f16: no packed transcendental exists), 1 + e (v_pk_add_f16), 1 / . per half
+                    // (v_rcp_f16), y r (v_pk_mul_f16; bf16: two fp32 products and one v_cvt_pk_bf16_f32)
+                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                    h2 y;
+                    y[0] = (_Float16)v0;
+                    y[1] = (_Float16)v1;
+                    const h2 z = y * (h2){(_Float16)-1.4426950408889634f, (_Float16)-1.4426950408889634f};
+                    h2 e, r;
+                    e[0] = __builtin_exp2f16(z[0]);
+                    e[1] = __builtin_exp2f16(z[1]);
+                    const h2 d = e + (h2){(_Float16)1.0f, (_Float16)1.0f};
+                    r[0] = __builtin_amdgcn_rcph(d[0]);
+                    r[1] = __builtin_amdgcn_rcph(d[1]);
+                    if constexpr (HT == 1) {
+                        q[w2] = __builtin_bit_cast(unsigned, y * r);
+                        continue;
+                    } else {
+                        v0 = (float)y[0] * (float)r[0];
+                        v1 = (float)y[1] * (float)r[1];
+                    }
+                } else if constexpr (SW) {
                     v0 = sgam_swish(v0);
                     v1 = sgam_swish(v1);
                 }
@@ -281,11 +320,16 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
             *reinterpret_cast<u32x4 *>(halo + h_lds[j]) = hreg[j];
     };
 
-    // weight-fragment ring: three sets, loaded two taps ahead (two workgroups per CU share the registers) — or, for the one-
-    // workgroup-per-CU 256-row tile, one set per tap, each refilled for the NEXT slab as soon as its tap is done (nine taps
+    // weight-fragment ring: SGAM_HNBR = 3 sets, loaded two taps ahead (two workgroups per CU share the registers), or 6 sets, five
+    // taps ahead (round 5: the vector-memory queue returns IN ORDER, so a weight fragment requested behind the halo load of slab
+    // s + 2 — HBM / MALL latency — cannot be consumed before that load has landed; with three sets the first such fragment is
+    // needed three taps after the halo request, with six it is needed when the halo itself is, one slab later) — or, for the
+    // one-workgroup-per-CU 256-row tile, one set per tap, each refilled for the NEXT slab as soon as its tap is done (nine taps
     // = 4 600 MFMA cycles ahead: an L2 round trip is ~0.7 us, two taps of this kernel are 0.2)
-    constexpr int NBR = BM == 256 ? 9 : 3;
-    u32x4 bq[NBR][TN][2];                  // [tap % NBR][n tile][k-step]
+    constexpr int NBR = BM == 256 ? 9 : SGAM_HNBR;
+    static_assert(NBR == 3 || NBR == 6 || NBR == 9, "ring of 3 (two taps ahead), 6 (five ahead) or 9 (one set per tap)");
+    constexpr int SUN = NBR == 6 ? 2 : 1;  // slabs per trip of the slab loop: the set of (slab, tap) must be a compile-time index, 9 taps mod 6 repeat every second slab
+    u32x4 bq[NBR][TN][2];                  // [(slab phase + tap) % NBR][n tile][k-step]
     auto bload = [&](const int set, int tap, int ch, bool live) {
         const unsigned koff = (unsigned)(tap * p.Cin + ch * XBK) * 64u;   // 2048 bytes per (row tile, slab); scalar offset
 #pragma unroll
@@ -324,8 +368,8 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
 #pragma unroll
         for (int t = 0; t < 9; ++t) bload(t, t, s0, true);
     } else {
-        bload(0, 0, s0, true);
-        bload(1, 1, s0, true);
+#pragma unroll
+        for (int t = 0; t < NBR - 1; ++t) bload(t, t, s0, true);
     }
     if constexpr (GN && !GNF) {
         // (behind the first halo and weight loads, so that its own round trip overlaps theirs)
@@ -391,41 +435,84 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
         for (int i = 0; i < TM; ++i) HDS_READ(fa[set][i], a_lds[i], 2 * (ky * LP + kx * XLD + kk * 16));
     };
     // all reads but the newest `younger` (a multiple of TM <= FD TM: the sets issued for later steps) have landed; the fragment
-    // registers are tied to the wait so that no MFMA moves above it
+    // registers are tied to the wait so that no MFMA moves above it.  EVERY count up to the asserted maximum of 12 is spelled, so
+    // whatever read-ahead depth the build parameters select (SGAM_HFD2 / SGAM_HFD4) finds its wait: a count without an arm would
+    // emit no s_waitcnt at all and the MFMAs would consume fragments that have not landed.
 #define HAWAIT(n_) else if (younger == (n_)) { if constexpr (TM == 4) asm volatile("s_waitcnt lgkmcnt(" #n_ ")" : "+v"(fa[set][0]), "+v"(fa[set][1]), "+v"(fa[set][2]), "+v"(fa[set][3])); \
                                                  else if constexpr (TM == 2) asm volatile("s_waitcnt lgkmcnt(" #n_ ")" : "+v"(fa[set][0]), "+v"(fa[set][1])); \
                                                  else asm volatile("s_waitcnt lgkmcnt(" #n_ ")" : "+v"(fa[set][0])); }
     auto await = [&](const int set, const int younger) {
         static_assert(TM == 1 || TM == 2 || TM == 4, "fragment waits are spelled for 1, 2 or 4 row tiles");
-        static_assert(FD >= 1 && FD * TM <= 12, "wait counts are spelled up to 12 outstanding reads");
+        static_assert(FD >= 1 && FD * TM <= 12, "wait counts are spelled for 0 .. 12 outstanding reads");
         if (false) {}
-        HAWAIT(0) HAWAIT(1) HAWAIT(2) HAWAIT(3) HAWAIT(4) HAWAIT(6) HAWAIT(8) HAWAIT(12)
+        HAWAIT(0) HAWAIT(1) HAWAIT(2) HAWAIT(3) HAWAIT(4) HAWAIT(5) HAWAIT(6) HAWAIT(7) HAWAIT(8) HAWAIT(9) HAWAIT(10) HAWAIT(11) HAWAIT(12)
     };
 #undef HAWAIT
-    for (int sl = s0; sl < ((SGAM_HABLATE & 4) ? s0 : s1); ++sl) {
-        const bool has_next = sl + 1 < s1;
+    // the residual tile (SGAM_HPEEL): requested where the second-to-last slab's halo load would stand — that load is dead, its place
+    // in the in-order queue is free, and a slab and a half of MFMAs cover the trip — instead of at the head of the epilogue, where
+    // every workgroup of the launch waits for it at once.  Without a residual (or with split-K, where the combine adds it) the
+    // descriptor is empty and the loads return zeros without touching memory.
+    constexpr bool PEEL = SGAM_HPEEL && SGAM_HDIRECT && BM != 256;
+    constexpr bool RPF = PEEL && (SGAM_HRPF == 2 || (SGAM_HRPF == 1 && TM >= 4));
+    u32x2 rq[TM][TN][4];                      // residual: four 4-channel units per (row tile, channel tile)
+    auto rload = [&]() {
+        const int pl_ = lane & 31, hh_ = lane >> 5;
+        const bool live = p.res && p.ksplit == 1;
+        const unsigned r_bytes_ = live ? (unsigned)(((int64_t)(p.M - 1) * p.ldr + p.n_valid) * 2) : 0u;
+        const __amdgpu_buffer_rsrc_t rr_ = __builtin_amdgcn_make_buffer_rsrc((void *)p.res, 0, (int)r_bytes_, 0x00020000);
+        const int wn0_ = n0 + wn * (BN / WGN_);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int trow = wm * (BM / WGM_) + i * 32 + pl_;
+            const int mrow_ = (b * p.Ho + ty0 + (trow >> TWS)) * p.Wo + tx0 + (trow & (TW - 1));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int n4 = wn0_ + j * 32 + hh_ * 16 + k * 4;
+                    rq[i][j][k] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
+                                                                rr_, (int)hsel(n4 < p.n_valid, (unsigned)(mrow_ * p.ldr + n4) * 2u, 0xFFFFFFF0u), 0, 0));
+                }
+        }
+    };
+    // one slab: nine taps of TM TN MFMAs per k-step.  RB = ring phase of its tap 0 (NBR = 6: 0, 3, 0, ...).  MODE 0: run-time flags
+    // decide whether the next slab / the one behind it exist (dead loads go out of range); the peeled forms know: 1 = two more
+    // slabs follow, 2 = one more follows (stages it, then requests the residual instead of a halo), 3 = the last (nothing to
+    // stage or to request: a quarter of the staging arithmetic of a four-slab tile used to run on zeros here)
+    auto slab = [&](const int sl, auto rb_, auto mode_) {
+        constexpr int RB = decltype(rb_)::value, MODE = decltype(mode_)::value;
+        const bool has_next = MODE == 0 ? sl + 1 < s1 : MODE != 3;
+        const bool has_next2 = MODE == 0 ? sl + 2 < s1 : MODE == 1;
         hb = smem + hcur * HPL;
         if constexpr (!UPS) {
             const unsigned hb_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short *)hb;
 #pragma unroll
             for (int i = 0; i < TM; ++i) a_lds[i] = hb_lds + 2u * (unsigned)a_base[i];
         }
+        constexpr int HLT = (SGAM_HLT >= NH && SGAM_HLT <= 8) ? SGAM_HLT : NH + 1;       // the staged pieces take taps HLT - NH .. HLT - 1
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int set = tap % NBR;
-            if constexpr (!(SGAM_HABLATE & 8) && NBR == 3) {
-                if (tap < 7) bload((tap + 2) % 3, tap + 2, sl, true);
-                else bload((tap + 2) % 3, tap - 7, sl + 1, has_next);
+            const int set = (tap + RB) % NBR;
+            if constexpr (!(SGAM_HABLATE & 8) && NBR != 9) {
+                const int tt = tap + NBR - 1;
+                if (tt < 9) bload((tt + RB) % NBR, tt, sl, true);
+                else if constexpr (MODE != 3) bload((tt + RB) % NBR, tt - 9, sl + 1, has_next);
             }
             if constexpr (!(SGAM_HABLATE & 16)) {
                 // (the barrier keeps the scheduler from hoisting the staging arithmetic to the head of the slab body, in front of
                 // this iteration's first loads: the wait it then needs counts loads across the loop's back edge and comes out as
                 // vmcnt(0) — the whole vector-memory queue drained at the top of every slab)
                 if (SGAM_HSB == 2 || (SGAM_HSB == 1 && tap == 1)) __builtin_amdgcn_sched_barrier(0);
-                if (tap >= 1 && tap <= NH) hprep_piece(tap - 1);            // next slab's halo, one piece per tap
-                if (tap == NH + 1) {
-                    hstore(hcur ^ 1);
-                    hload(sl + 2, sl + 2 < s1);
+                if constexpr (MODE != 3) {
+                    if (tap >= HLT - NH && tap < HLT) hprep_piece(tap - (HLT - NH));        // next slab's halo, one piece per tap
+                    if (tap == HLT) {
+                        hstore(hcur ^ 1);
+                        if constexpr (MODE == 2) {
+                            if constexpr (RPF) rload();
+                        } else {
+                            hload(sl + 2, has_next2);
+                        }
+                    }
                 }
             }
 #pragma unroll
@@ -455,6 +542,27 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
         }
         __syncthreads();
         hcur ^= 1;
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 2> I2;
+    typedef std::integral_constant<int, 3> I3;
+    if constexpr (SGAM_HABLATE & 4) {
+    } else if constexpr (!PEEL) {
+        for (int sl = s0; sl < s1; sl += SUN) {
+            slab(sl, I0{}, I0{});
+            if constexpr (SUN == 2) slab(sl + 1, I3{}, I0{});      // (host: an even number of slabs per workgroup in SGAM_HNBR = 6 builds)
+        }
+    } else {
+        int sl = s0;
+        for (; sl + 2 < s1; sl += SUN) {
+            slab(sl, I0{}, I1{});
+            if constexpr (SUN == 2) slab(sl + 1, I3{}, I1{});
+        }
+        if (s1 - s0 >= 2) slab(s1 - 2, I0{}, I2{});
+        else if constexpr (RPF) rload();
+        if constexpr (SUN == 2) slab(s1 - 1, I3{}, I3{});
+        else slab(s1 - 1, I0{}, I3{});
     }
     __syncthreads();
 
@@ -507,17 +615,18 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
                 }
         return;
     }
-    u32x2 rq[TM][TN][4];                      // residual: four 4-channel units per (row tile, channel tile)
+    if constexpr (!RPF) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int n4 = wn0 + j * 32 + hh * 16 + k * 4;
-                rq[i][j][k] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
-                                                            rr, (int)hsel(n4 < n_lim, (unsigned)(mrow[i] * p.ldr + n4) * 2u, OOB), 0, 0));
-            }
+                for (int k = 0; k < 4; ++k) {
+                    const int n4 = wn0 + j * 32 + hh * 16 + k * 4;
+                    rq[i][j][k] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
+                                                                rr, (int)hsel(n4 < n_lim, (unsigned)(mrow[i] * p.ldr + n4) * 2u, OOB), 0, 0));
+                }
+    }
     float us[RH][TN][4], uss[RH][TN][4];      // per (row half, 4-channel unit): sum, sum of squares over this lane's pixels
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -748,7 +857,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
 
 template <int HT, bool GN, bool SW>
 __global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p) {
-    constexpr int BM = 128, BN = 128, TH = 8, TW = 16, TWS = 4;
+    constexpr int BN = 128, TH = 8, TW = 16, TWS = 4;                    // (a 128-row tile: the 8 x 16 patch)
     constexpr int HROWS = TH + 2, HWID = TW + 2, HR = HROWS * HWID;       // 10 x 18 halo pixels
     constexpr int XBK = 32, XLD = XBK + 8, LP = 768, HPL = HROWS * LP;    // halfs per slab buffer
     constexpr int NH = (HR * 4 + 255) / 256;                               // 16-byte halo pieces per producer thread: 3
@@ -1544,6 +1653,7 @@ static int hh_conv_impl(const sgam_conv_desc *d, int32_t ht, const void *x, cons
     const HHPlan pl = hh_plan(d);
     const int bm = pl.bm;
     if (!bm || !x || !w_frag || !out || (ht != 0 && ht != 1)) return SGAM_EINVAL;
+    if (SGAM_HNBR == 6 && bm != 256 && ((pl.slabs_per_split & 1) || (d->Cin / 32) % pl.slabs_per_split)) return SGAM_EINVAL;   // (experiment builds: slab loop unrolled by two)
     const long long *gn_acc_in = nullptr;           // chunks_in == 0: the statistics of x are accumulators, not chunk records
     if (gn_partial_in && chunks_in == 0) {
         if (gn_mean_rstd || !(gn_eps > 0.f) || !sgam_aligned16(gn_partial_in) || sgam_conv2d_h16_gn_foldable(d, 0) != 1) return SGAM_EINVAL;

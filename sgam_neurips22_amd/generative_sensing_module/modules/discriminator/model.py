@@ -1,6 +1,7 @@
 """PatchGAN discriminator of the reference's loss (sgam/generative_sensing_module/modules/discriminator/model.py:17-67, the
 pix2pix NLayerDiscriminator): the parameter container with the reference's state_dict keys (`main.<i>.weight` ...); the
 arithmetic runs in sgam_neurips22_amd/training.py (forward with tape, backward) on the HIP kernels — SURVEY §8 f4."""
+import torch
 import torch.nn as nn
 
 from ..diffusionmodules.model import Conv2d
@@ -35,10 +36,14 @@ class NLayerDiscriminator(nn.Module):
         self.main = nn.Sequential(*seq)
 
     def forward(self, input):
-        """reference :65-67: (B,C,H,W) -> (B,1,h,w) patch logits — one forward of the tape training.py differentiates (train()
-        mode: BatchNorm on batch statistics, running statistics updated, as the reference's forward inside `fit`; an eval()-mode
-        BatchNorm raises, see training._BNLReLU), for callers of `loss.discriminator(x)`"""
+        """reference :65-67: (B,C,H,W) -> (B,1,h,w) patch logits on the HIP kernels, with torch's BatchNorm2d semantics per mode:
+        train() normalises with batch statistics and updates the running statistics; eval() normalises with the running statistics
+        and mutates nothing.  The result is DETACHED — no autograd graph is recorded here (gradients of this network are the
+        business of training.VQGANTrainer's tape) — so an input that requires grad is refused rather than silently cut off."""
         from .... import ops, training
+        if torch.is_grad_enabled() and input.requires_grad:
+            raise RuntimeError("NLayerDiscriminator.forward returns a detached tensor: differentiate through training.VQGANTrainer "
+                               "(or call under torch.no_grad() / on a detached input)")
         with training._mfma_mode():
-            logits = training._DiscTape(self, {}).fwd(ops.nchw_to_nhwc(input.float().contiguous(), c_pad=32))
+            logits = training._DiscTape(self, {}, inference=True).fwd(ops.nchw_to_nhwc(input.detach().float().contiguous(), c_pad=32))
         return ops.nhwc_to_nchw(logits[..., :1].contiguous())

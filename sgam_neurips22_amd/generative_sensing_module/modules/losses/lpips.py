@@ -50,8 +50,13 @@ class LPIPS(nn.Module):
 
     def forward(self, input, target):
         """reference lpips.py:41-55: (B,3,H,W) x 2 in [-1, 1] -> (B,1,1,1) perceptual distances — the forward half of the tape
-        training.py differentiates (same kernels, strict-fp32 MFMA mode), for callers of `loss.perceptual_loss(a, b)`"""
+        training.py differentiates (same kernels, strict-fp32 MFMA mode), for callers of `loss.perceptual_loss(a, b)`.  The
+        result is DETACHED (no autograd graph; the gradient w.r.t. the reconstruction comes from training._Lpips.loss_and_grad),
+        so inputs that require grad are refused rather than silently cut off."""
         from .... import ops, training
+        if torch.is_grad_enabled() and (input.requires_grad or target.requires_grad):
+            raise RuntimeError("LPIPS.forward returns a detached tensor: use training._Lpips(...).loss_and_grad for the gradient "
+                               "(or call under torch.no_grad() / on detached inputs)")
         with training._mfma_mode():
             vals, _ = training._Lpips(self).loss_and_grad(ops.nchw_to_nhwc(input.float().contiguous(), c_pad=32),
                                                          ops.nchw_to_nhwc(target.float().contiguous(), c_pad=32), 0.0, values_only=True)

@@ -357,10 +357,15 @@ def _arrive(w, device):
         if torch.cuda.is_current_stream_capturing():
             return None
         t = torch.zeros((ARRIVE_COUNT,), device=device, dtype=torch.int32)
+        t._sgam_stream = int(torch.cuda.current_stream(device).cuda_stream)
         if split:
             w.arrive = t
         else:
             w._sgam_arrive = t
+    # one launch at a time per counter array (include/sgam_hip.h): launches of ONE stream qualify; a second stream driving the same
+    # weight gets the partial tiles + combine launch instead of sharing the counters
+    if getattr(t, "_sgam_stream", None) != int(torch.cuda.current_stream(device).cuda_stream):
+        return None
     return t
 
 
@@ -438,7 +443,7 @@ def _run_conv(desc, x, w, bias, residual, out, gn=None, a_scale=1.0, norm=None):
     lib = _lib.load()
     split = isinstance(w, SplitWeight)
     _apply_plan(desc, "f32x" if split else x.dtype)
-    if split:                                     # (16-bit family: see _run_conv_inner)
+    if split:                                     # (split-fp32 family only: the 16-bit kernels have no in-kernel fix-up)
         arr = _arrive(w, x.device)
         if arr is not None:
             desc.arrive, desc.arrive_count = arr.data_ptr(), arr.numel()
@@ -947,20 +952,31 @@ _SPLAT_WS = {}
 
 
 def _splat_workspace(dev, B, N, H, W, out=None):
-    """scratch of the tiled splat (tile counters, cached target pixels, per-tile bin lists), zero-filled ONCE at allocation
-    (the kernels leave the counters zero): one buffer per (device, shape), cached; (None, 0) when the two-pass form is to run"""
+    """scratch of the tiled splat (tile bitmaps, cached target pixels), zero-filled ONCE at allocation (the kernels leave the
+    bitmaps zero): one buffer per (device, STREAM, shape), cached; (None, 0, None) when the two-pass form is to run.  The stream is
+    part of the key because pass 2 of a call reads (and clears) what its pass 1 wrote: two scenes of the same shape on two HIP
+    streams (`distributed.ConcurrentScenes`) sharing one buffer would overwrite each other's target pixels and bitmaps between
+    the passes — wrong winners, no error."""
     use = SPLAT_TILED if SPLAT_TILED is not None else (B * N * H * W >= SPLAT_TILED_MIN_POINTS)
     if not use:
-        return None, 0
+        return None, 0, None
     nb = _lib.load().sgam_forward_splat_workspace_bytes(B, N, H, W)
     if nb < 0:
-        return None, 0
-    key = (str(dev), B, N, H, W)
+        return None, 0, None
+    key = (str(dev), int(torch.cuda.current_stream(dev).cuda_stream), B, N, H, W)
     if key not in _SPLAT_WS:
-        if len(_SPLAT_WS) > 16:
+        if len(_SPLAT_WS) > 64:
             _SPLAT_WS.clear()
         _SPLAT_WS[key] = torch.zeros((nb,), device=dev, dtype=torch.uint8)
-    return _SPLAT_WS[key], nb
+    return _SPLAT_WS[key], nb, key
+
+
+def _splat_tiled_check(rc, what, key):
+    """`check` for the tiled splat: a launch that failed between the two passes may leave registered bins behind, and the next
+    call on this buffer relies on zero bitmaps — the buffer is dropped (the next call allocates a zero-filled one)"""
+    if rc != 0:
+        _SPLAT_WS.pop(key, None)
+    check(rc, what)
 
 
 def forward_splat(src_feats, src_depths, tgt_K, src_Kinv, T, *, channels_last=False, depth_range=None,
@@ -996,12 +1012,12 @@ def forward_splat(src_feats, src_depths, tgt_K, src_Kinv, T, *, channels_last=Fa
     # `_p(_f32c(t))` is freed right after `_p` returns, and the caching allocator may hand its block to the NEXT
     # temporary, whose copy kernel then lands before ours on the same stream
     kt, kinv, tt = _f32c(tgt_K), _f32c(src_Kinv), _f32c(T)
-    ws, nb = _splat_workspace(dev, B, N, H, W) if ("inb_mask" not in want and "pix_xy" not in want) else (None, 0)
+    ws, nb, wkey = _splat_workspace(dev, B, N, H, W) if ("inb_mask" not in want and "pix_xy" not in want) else (None, 0, None)
     if ws is not None:
-        check(_lib.load().sgam_forward_splat_tiled_f32(
+        _splat_tiled_check(_lib.load().sgam_forward_splat_tiled_f32(
             _p(f), cs, ps, _p(d), _p(kt), _p(kinv), _p(tt), B, N, H, W, dr, norm, _p(ws), nb,
             _p(o.get("merge_depths")), _p(o.get("merge_feats")), _p(o.get("extrap")), _p(o.get("x")),
-            _p(o.get("proj_feats")), _p(o.get("proj_depth")), _stream()), "sgam_forward_splat_tiled_f32")
+            _p(o.get("proj_feats")), _p(o.get("proj_depth")), _stream()), "sgam_forward_splat_tiled_f32", wkey)
         return o
     winner = mk((B, HW), torch.int32)
     check(_lib.load().sgam_forward_splat_f32(
@@ -1045,12 +1061,12 @@ def forward_splat_srcs(src_feats, src_depths, tgt_K, src_Kinv, T, *, B=1, depth_
     if "x" in want and norm == 0:
         raise NotImplementedError(f"dataset {dataset!r}")
     kt, kinv, tt = _f32c(tgt_K), _f32c(src_Kinv), _f32c(T)       # locals keep any contiguous copy alive until enqueued
-    ws, nb = _splat_workspace(dev, B, N, H, W, out)
+    ws, nb, wkey = _splat_workspace(dev, B, N, H, W, out)
     if ws is not None:
-        check(_lib.load().sgam_forward_splat_tiled_srcs_f32(
+        _splat_tiled_check(_lib.load().sgam_forward_splat_tiled_srcs_f32(
             _ptr_table(src_feats), _ptr_table(src_depths), 1, 3, _p(kt), _p(kinv), _p(tt), B, N, H, W, dr, norm, _p(ws), nb,
             _p(o.get("merge_depths")), _p(o.get("merge_feats")), _p(o.get("extrap")), _p(o.get("x")), None, None, _stream()),
-            "sgam_forward_splat_tiled_srcs_f32")
+            "sgam_forward_splat_tiled_srcs_f32", wkey)
         return o
     winner = mk("winner", (B, HW), torch.int32)
     check(_lib.load().sgam_forward_splat_srcs_f32(

@@ -719,8 +719,9 @@ class _Lpips:
 class _BNLReLU:
     """[BatchNorm2d in training mode ->] LeakyReLU(0.2) of the PatchGAN (discriminator/model.py:40-60)"""
 
-    def __init__(self, bn, grads, slope=0.2):            # slope 0: plain ReLU (the VGG16 trunk of LPIPS)
+    def __init__(self, bn, grads, slope=0.2, inference=False):            # slope 0: plain ReLU (the VGG16 trunk of LPIPS)
         self.bn, self.grads, self.slope = bn, grads, slope
+        self.inference = inference                       # forward only (module.forward): an eval()-mode BatchNorm uses its running statistics
 
     def fwd(self, x):
         lib = _lib.load()
@@ -730,6 +731,12 @@ class _BNLReLU:
         y = torch.empty_like(x)
         if self.bn is not None:
             bn = self.bn
+            if not bn.training and self.inference:
+                # eval(): y = (x - running_mean) / sqrt(running_var + eps) * gamma + beta, nothing mutated (torch BatchNorm2d.forward)
+                self.mr = torch.stack([bn.running_mean.float(), torch.rsqrt(bn.running_var.float() + bn.eps)], dim=1).contiguous()
+                check(lib.sgam_bn_lrelu_fwd_f32(_p(x), _p(self.mr), _p(bn.weight.data), _p(bn.bias.data), _p(y), rows, C, self.slope, _stream()),
+                      "sgam_bn_lrelu_fwd_f32")
+                return y
             if not bn.training:
                 # eval-mode BatchNorm normalises with the running statistics (and its backward differs): not built — the
                 # reference trains the PatchGAN in train() mode (Lightning's fit); do not silently use batch statistics
@@ -779,7 +786,7 @@ def _accumulate(grads, p, g):
 class _DiscTape:
     """one forward of NLayerDiscriminator.main on an NHWC batch (channels padded to 32) with everything the backward needs"""
 
-    def __init__(self, disc, grads):
+    def __init__(self, disc, grads, inference=False):
         self.grads = grads
         self.layers = []
         mods = list(disc.main)
@@ -788,7 +795,7 @@ class _DiscTape:
             conv = mods[i]
             bn = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], torch.nn.BatchNorm2d) else None
             has_act = any(isinstance(m, torch.nn.LeakyReLU) for m in mods[i + 1:i + 3])
-            self.layers.append((_Conv(conv, {}), _BNLReLU(bn, grads) if has_act else None))
+            self.layers.append((_Conv(conv, {}), _BNLReLU(bn, grads, inference=inference) if has_act else None))
             i += 1 + (1 if bn is not None else 0) + (1 if has_act else 0)
 
     def fwd(self, x):

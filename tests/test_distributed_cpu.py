@@ -72,6 +72,29 @@ def test_bench_gpus2_self_launches_two_ranks():
     assert abs(out["value"] - 10 / 1.01) < 1e-9          # 2 ranks x 5 frames / max(1.00, 1.01) s
 
 
+@pytest.mark.timeout(600)
+def test_bench_gpus8_rehearsal_at_the_real_world_size():
+    """BASELINE configs[3] (8 scenes on the 8 GPUs of one node) has never met hardware: rehearse everything about it that does
+    not need one — `bench.py --gpus 8` self-launches EIGHT ranks through torch.distributed.run, they rendezvous on 127.0.0.1, the
+    scene shards of the eight ranks partition the eight scenes, the metric all-gather returns eight records and exactly ONE JSON
+    line comes out, carrying n_gpus = 8 and the whole-job aggregate."""
+    import json
+    import subprocess
+    from sgam_neurips22_amd import distributed as sdist
+    shards = [sdist.shard_scenes(8, r, 8) for r in range(8)]
+    assert sorted(s for sh in shards for s in sh) == list(range(8)) and all(len(sh) == 1 for sh in shards)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "5", "--warmup", "1",
+                        "--dry-run"], capture_output=True, text=True, env=env, timeout=560)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1, r.stdout
+    out = json.loads(line[0])
+    assert out["n_gpus"] == 8 and out["dry_run"] is True
+    assert out["scenes_per_rank"] == [float(i) for i in range(8)]          # rank r reported scene r: a partition of the 8 scenes
+    assert abs(out["value"] - 8 * 5 / 1.07) < 1e-9                         # 8 ranks x 5 frames / max over ranks (1.00 .. 1.07 s)
+
+
 def test_bench_refuses_a_world_that_is_not_gpus():
     import subprocess
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")

@@ -540,8 +540,18 @@ def test_loss_modules_keep_the_reference_forward_surface(golden):
     want = OP.discriminator({k: v.clone() for k, v in dsd.items()}, x, n_layers=3, training=True)
     assert logits.shape == want.shape and _rel(logits, want) <= 1e-4
     assert int(disc.main[3].num_batches_tracked) == 1
-    with pytest.raises(NotImplementedError):
-        disc.eval()(x.to(DEV))
+    # eval(): running statistics (as that one train-mode call left them), nothing mutated; against the oracle in eval mode on the
+    # module's own state
+    disc.eval()
+    before = {k: v.clone() for k, v in disc.state_dict().items()}
+    ev = disc(x.to(DEV))
+    want_ev = OP.discriminator({k: v.cpu().clone() for k, v in before.items()}, x, n_layers=3, training=False)
+    assert _rel(ev, want_ev) <= 1e-4
+    assert all(torch.equal(v, before[k]) for k, v in disc.state_dict().items())
+    with pytest.raises(RuntimeError):                         # outputs are detached: an input that requires grad is refused
+        disc(x.to(DEV).requires_grad_(True))
+    with torch.no_grad():
+        assert torch.equal(disc(x.to(DEV).requires_grad_(True)), ev)
     g = golden("lpips_small.npz")
     lp = LPIPS()
     lp.load_state_dict(lpips_state_dict(golden))
@@ -550,3 +560,5 @@ def test_loss_modules_keep_the_reference_forward_surface(golden):
     b = testing.seeded_tensor("lpips.b", (2, 3, 64, 64), scale=0.5).clamp(-1, 1)
     v = lp(a.to(DEV), b.to(DEV))
     assert v.shape == (2, 1, 1, 1) and np.allclose(v.reshape(-1).cpu().numpy(), g["value"], rtol=1e-4)
+    with pytest.raises(RuntimeError):
+        lp(a.to(DEV).requires_grad_(True), b.to(DEV))

@@ -180,3 +180,39 @@ def test_frame_feedback_matches_host_codec():
             want_f = (want_u8 / 127.5 - 1.0).astype(np.float32)
             assert bits_equal(rgb_f[b].cpu().numpy(), want_f)
             assert bits_equal(depth[b].cpu().numpy(), OW.denormalise_depth(dec[b, 3], ds).numpy())
+
+
+def test_tiled_splat_on_two_streams_keeps_private_workspaces():
+    """same-shaped tiled splats in flight on two HIP streams (what `distributed.ConcurrentScenes` does with two scenes): each
+    stream has its own scratch — pass 2 of one must not read the target pixels / bitmaps pass 1 of the other is writing — and
+    each result equals the two-pass form's, for several interleaved rounds"""
+    B, N, H, W = 1, 3, 256, 256
+    jobs = []
+    for s in range(2):
+        f, d, Ks, T = testing.synth_warp_inputs(300 + s, B, N, H, W, 0.05 + 0.4 * s, True)
+        feats = [t(f[b, n].transpose(1, 2, 0)) for b in range(B) for n in range(N)]
+        depths = [t(d[b, n]) for b in range(B) for n in range(N)]
+        Kinv = torch.inverse(torch.from_numpy(Ks).reshape(-1, 3, 3)).to(DEV)
+        jobs.append((feats, depths, t(Ks[:, 0]), Kinv, t(T).reshape(-1, 4, 4)))
+    run = lambda j: ops.forward_splat_srcs(*j, B=B, dataset="google_earth", want=("x", "extrap", "merge_depths"))  # noqa: E731
+    old = ops.SPLAT_TILED
+    try:
+        ops.SPLAT_TILED = False
+        ref = [run(j) for j in jobs]
+        torch.cuda.synchronize()
+        ops.SPLAT_TILED = True
+        ops._SPLAT_WS.clear()
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        for rounds in range(6):
+            got = []
+            for s in (0, 1):
+                with torch.cuda.stream(streams[s]):
+                    got.append(run(jobs[s]))
+            torch.cuda.synchronize()
+            for s in (0, 1):
+                for k in ("x", "extrap", "merge_depths"):
+                    assert torch.equal(got[s][k].view(torch.uint8), ref[s][k].view(torch.uint8)), (rounds, s, k)
+        bufs = [v.data_ptr() for v in ops._SPLAT_WS.values()]
+        assert len(bufs) == 2 and bufs[0] != bufs[1]
+    finally:
+        ops.SPLAT_TILED = old
