@@ -165,7 +165,9 @@ def pmc_frame_entry(mode, timeline_name):
             fn = idx.get("in_frame", {}).get(mode)
             _PMC_COMMIT[0] = idx.get("collected_at")
             if fn and os.path.exists(os.path.join(ROOT, "profiles", fn)):
-                _PMC_FRAME[mode] = (fn, json.load(open(os.path.join(ROOT, "profiles", fn)))["kernels"])
+                doc = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                _PMC_FRAME[mode] = (fn, doc["kernels"])
+                _PMC_COMMIT[0] = doc.get("collected_at") or _PMC_COMMIT[0]      # the file's own stamp wins over the index's
     fn, kernels = _PMC_FRAME[mode]
     if timeline_name in kernels:
         return fn, kernels[timeline_name]
@@ -195,11 +197,41 @@ def attach_counters(roofline, mode):
     fn, ent = pmc_frame_entry(mode, roofline["kernel"])
     if ent is not None:
         roofline["traffic"] = ent["hbm_traffic_bytes_per_launch"]
+        roofline["counters_commit"] = _PMC_COMMIT[0]          # the build the committed counters were collected on; compare with `head`
         roofline["counters_source"] = (f"traffic + mfma_busy_frac: NOT measured in this run — committed rocprofv3 --pmc passes over the same "
                                        f"eager frame, profiles/{fn}" + (f" ({_PMC_COMMIT[0]})" if _PMC_COMMIT[0] else ""))
         roofline["traffic_note"] = (f"HBM bytes per launch of {roofline['kernel']}, averaged over its {ent['launches_per_frame']} in-frame "
                                     f"launches: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate rocprofv3 --pmc passes over "
                                     f"the eager bench frame (profiles/{fn})")
+
+
+def pin_cpu_leg(n):
+    """Bind EVERY thread of this process to `n` distinct physical cores (one hardware thread each) of one package, chosen from the
+    cores the process may use: the CPU leg drifted 2.5 -> 1.4 frames/s across rounds on the same host model because the 32 OpenMP
+    threads were free to share SMT siblings or straddle sockets.  Threads that exist already (torch's intra-op pool may) are bound
+    one by one through /proc/self/task; threads created afterwards inherit the mask.  Returns the cpu list (None: not pinned)."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        by_pkg = {}
+        for c in allowed:
+            base = f"/sys/devices/system/cpu/cpu{c}/topology/"
+            with open(base + "physical_package_id") as f:
+                pkg = int(f.read())
+            with open(base + "core_id") as f:
+                core = int(f.read())
+            by_pkg.setdefault(pkg, {}).setdefault(core, c)          # first hardware thread of every core
+        pkg = max(by_pkg, key=lambda k: (len(by_pkg[k]), -k))       # the package with most usable cores (lowest id on a tie)
+        cpus = sorted(by_pkg[pkg].values())[:n]
+        if not cpus:
+            return None
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                os.sched_setaffinity(int(tid), cpus)
+            except OSError:
+                pass
+        return cpus
+    except (OSError, AttributeError, ValueError):
+        return None
 
 
 def cpu_baseline(sd, p, seed_frame, n_frames):
@@ -209,8 +241,12 @@ def cpu_baseline(sd, p, seed_frame, n_frames):
     from oracle import warp as OW
     from sgam_neurips22_amd.inference_pipeline import intrinsics
     # all 256 hardware threads of the GPU box oversubscribe torch-CPU badly (measured 92 s/frame); 32 is the
-    # sweet spot on that host.  `cores` reports what was actually used.
-    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    # sweet spot on that host.  `cores` reports what was actually used, `pinned_cpus` where they ran.
+    nthr = min(32, os.cpu_count() or 1)
+    pinned = pin_cpu_leg(nthr)
+    if pinned:
+        nthr = len(pinned)
+    torch.set_num_threads(nthr)
     K = intrinsics(DATASET).astype(np.float32)
     lut = (np.arange(256, dtype=np.float64) / 127.5 - 1.0).astype(np.float32)
     rgb = lut[seed_frame[0]].transpose(2, 0, 1)
@@ -240,6 +276,7 @@ def cpu_baseline(sd, p, seed_frame, n_frames):
         pass
     return {"value": n_frames / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
             "cpu": f"{cpu_name} ({os.cpu_count()} hardware threads visible)",
+            "pinned_cpus": (f"{pinned[0]}-{pinned[-1]} ({len(pinned)} physical cores of one package, one thread each)" if pinned else None),
             "sample": f"{n_frames} frames of the same 256x256 GoogleEarth step (oracle: C splat + torch-CPU fp32 VQGAN)"}
 
 
@@ -349,11 +386,11 @@ def compact_line(full):
     if r is not None:
         line["roofline"] = pick(r, ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us", "calls_per_frame",
                                     "gflop_per_launch", "peak_basis", "frac_vs_fp32_mfma_peak", "frac_vs_h16_dense_peak",
-                                    "mfma_busy_frac", "counters_source", "share_of_kernel_time", "kernels_per_frame",
+                                    "mfma_busy_frac", "counters_source", "counters_commit", "share_of_kernel_time", "kernels_per_frame",
                                     "kernel_time_ms_per_frame", "frame"))
     else:
         line["roofline"] = None
-    line["cpu_baseline"] = pick(full.get("cpu_baseline"), ("value", "unit", "cores", "kind", "sample", "cpu"))
+    line["cpu_baseline"] = pick(full.get("cpu_baseline"), ("value", "unit", "cores", "kind", "sample", "cpu", "pinned_cpus"))
     w = full.get("roofline_warp")
     if w is not None:
         line["roofline_warp"] = {"bound": "hbm", "unit": "GB/s", "peak": w.get("peak"),

@@ -1,7 +1,10 @@
 #!/usr/bin/env python
 """Aggregate the rocprofv3 --pmc passes of scripts/pmc_frame.sh per KERNEL NAME over its in-frame launches.
 
-    python scripts/pmc_frame.py <dir with sq/ fetch/ write/ pass outputs> <out.json> <frames in the run>
+    python scripts/pmc_frame.py <dir with sq/ fetch/ write/ pass outputs> <out.json> <frames in the run> [collected_at]
+
+`collected_at` = "library @ <commit>" of the build the passes ran on (the GPU box has no .git: scripts/pmc_frame.sh takes it
+from $SGAM_COMMIT, which the caller bakes into the gpurun command line); bench.py prints it as roofline.counters_commit.
 
 Per kernel: launches per frame, and per-launch averages of HBM traffic = FETCH_SIZE x 2 (gfx950 correction,
 MI355X_MICROARCH.md: 128-byte requests tallied at 64 B) + WRITE_SIZE (both reported in KiB), the in-kernel matrix-pipe busy
@@ -43,7 +46,7 @@ def load(src, group):
     return agg
 
 
-def main(src, out, frames):
+def main(src, out, frames, collected_at=None):
     sq, fe, wr = load(src, "sq"), load(src, "fetch"), load(src, "write")
     rows = {}
     for k, c in sq.items():
@@ -70,6 +73,7 @@ def main(src, out, frames):
                       "--no-graph --no-secondary --no-roofline --dtype <mode>; passes: sq (SQ_* + GRBM_GUI_ACTIVE), fetch (FETCH_SIZE), "
                       "write (WRITE_SIZE)",
            "frames_in_run": frames,
+           "collected_at": collected_at,
            "notes": "per-launch averages over ALL launches of the kernel in the run (in-frame shapes mixed as the frame mixes them); "
                     "hbm_traffic = 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE; mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / "
                     "(1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); profiled passes clock ~3-5 % lower than un-profiled runs",
@@ -82,4 +86,4 @@ def main(src, out, frames):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], int(sys.argv[3]))
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4] if len(sys.argv) > 4 else None)

@@ -26,7 +26,7 @@ SOURCES = {
                       f"-DSGAM_XWGM={os.environ.get('SGAM_XWGM', '1')}",
                       f"-DSGAM_XSOFF={os.environ.get('SGAM_XSOFF', '1')}",
                       f"-DSGAM_XPEEL={os.environ.get('SGAM_XPEEL', '1')}",
-                      f"-DSGAM_XLB64={os.environ.get('SGAM_XLB64', '3')}"],
+                      f"-DSGAM_XLB64={os.environ.get('SGAM_XLB64', '2')}"],
     "h16_halo.hip": [f"-DSGAM_HABLATE={os.environ.get('SGAM_HABLATE', '0')}",
                      f"-DSGAM_HDIRECT={os.environ.get('SGAM_HDIRECT', '1')}",
                      f"-DSGAM_HWGM={os.environ.get('SGAM_HWGM', '1')}",

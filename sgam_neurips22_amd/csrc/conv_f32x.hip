@@ -208,8 +208,8 @@ __device__ __forceinline__ void gn_scale_shift(const XParams &p, int b, int c, f
 // counter array" is the caller's to keep: ops.py lends a weight's counters only to launches on the stream that first used
 // them (`_arrive`: any other stream gets partial tiles + the combine launch).
 #ifndef SGAM_XLB64
-#define SGAM_XLB64 3       // workgroups per CU the 64-row halo tile is compiled for (3: <= 168 registers, three wavefronts per SIMD)
-#endif
+#define SGAM_XLB64 2       // workgroups per CU the 64-row halo tile is compiled for.  3 caps it at 168 registers (three wavefronts per SIMD): the
+#endif                     //    peeled GroupNorm form then spills 12 bytes and measured 21.2 against 20.3 us in the frame; 2 lets it take 172
 #ifndef SGAM_XPEEL
 #define SGAM_XPEEL 1       // halo kernels: the last two slabs of a workgroup peeled (no staging of a slab that does not exist)
 #endif
@@ -936,7 +936,11 @@ __global__ __launch_bounds__(256, (BM == 64 && !GNF) ? SGAM_XLB64 : 2) void conv
     hparams(s0, s0 < s1);
     hprep();
     hstore(0);
-    hload(s0 + 1, s0 + 1 < s1);
+    if constexpr (SGAM_XPEEL) {
+        if (s0 + 1 < s1) hload(s0 + 1, true);          // (a one-slab workgroup has no second halo / second fold of the chunk statistics)
+    } else {
+        hload(s0 + 1, s0 + 1 < s1);
+    }
     __syncthreads();
 
     u32x4 fa[2][TM][2];                    // [step parity][m tile][hi, lo]

@@ -408,7 +408,13 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
 #pragma unroll
     for (int j = 0; j < NH; ++j) hprep_piece(j);
     hstore(0);
-    hload(s0 + 1, s0 + 1 < s1);
+    if constexpr (SGAM_HPEEL && SGAM_HDIRECT && BM != 256) {
+        // (a workgroup that walks ONE slab — split-K plans of the 16^2 maps — has no second halo to request and, in the folding
+        // form, no second fold of the chunk statistics to compute: one uniform branch, outside the slab loop)
+        if (s0 + 1 < s1) hload(s0 + 1, true);
+    } else {
+        hload(s0 + 1, s0 + 1 < s1);
+    }
     __syncthreads();
 
     // A fragments are read FD steps (of TM MFMAs) ahead into a ring of FD + 1 register sets.  One step ahead covers 32 TM cycles of

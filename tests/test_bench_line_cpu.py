@@ -24,6 +24,7 @@ def _roofline(name):
             "share_of_kernel_time": 0.2391, "is_top_kernel_by_time": True, "mfma_busy_frac": 0.4451,
             "counters_source": "traffic + mfma_busy_frac: NOT measured in this run — committed rocprofv3 --pmc passes over the same eager "
                                "frame, profiles/r04_pmc_frame_f32.json (libsgam_hip @ 0123456789ab)",
+            "counters_commit": "library @ 0123456789ab",
             "top5": [_row("conv3x3_f32x_halo2_kernel<64,128,true,false,true>") for _ in range(5)],
             "kernel_time_ms_per_frame": 2.3978, "kernels_per_frame": 212, "bracket_overhead_us": 4.41,
             "frame": {"gflop": 486.4, "ms": 2.923, "tflops": 166.4, "frac": 0.1997}, "method": "x" * 300}
@@ -54,6 +55,7 @@ def full_record():
         "vqgan_tflops_wallclock": 166.4, "roofline": _roofline("conv3x3_f32x_halo2_kernel<128,128,true>"),
         "cpu_baseline": {"value": 2.5612345, "unit": "frames/s", "cores": 32, "kind": "port",
                          "cpu": "AMD EPYC 9575F 64-Core Processor (256 hardware threads visible)",
+                         "pinned_cpus": "0-31 (32 physical cores of one package, one thread each)",
                          "sample": "6 frames of the same 256x256 GoogleEarth step (oracle: C splat + torch-CPU fp32 VQGAN)"},
         "roofline_warp": {"bound": "hbm", "unit": "GB/s", "peak": 8000.0, "achievable": 6300.0, "bytes_model": "w" * 100, "cases": warp_cases,
                           "inverse_warp": warp_cases},
@@ -112,3 +114,41 @@ def test_bench_line_degrades_instead_of_overflowing(monkeypatch):
     assert len(text) <= bench.LINE_BUDGET
     line = json.loads(text)
     assert "secondary" not in line and "roofline" in line and "cpu_baseline" in line
+
+
+def test_committed_in_frame_counters_are_one_collection():
+    """bench.py quotes `roofline.traffic` / `mfma_busy_frac` from committed rocprofv3 --pmc files (profiles/pmc_index.json ->
+    "in_frame"): every mode's file must exist, carry its own `collected_at` stamp and the SAME one — counters of one mode from an
+    older build than the others (round 4 served round-3 fp16 counters) are stale evidence — and the index must name that stamp."""
+    idx = json.load(open(os.path.join(ROOT, "profiles", "pmc_index.json")))
+    stamps = {}
+    for mode, fn in idx["in_frame"].items():
+        path = os.path.join(ROOT, "profiles", fn)
+        assert os.path.exists(path), fn
+        doc = json.load(open(path))
+        assert doc.get("collected_at", "").startswith("library @ "), (fn, doc.get("collected_at"))
+        assert doc["kernels"], fn
+        stamps[mode] = doc["collected_at"]
+    assert set(stamps) == {"f32", "bf16", "fp16"} and len(set(stamps.values())) == 1, stamps
+    assert idx["collected_at"] == next(iter(stamps.values()))
+
+
+def test_cpu_leg_pins_distinct_physical_cores():
+    """`cpu_baseline` binds its threads to distinct physical cores of one package (the leg drifted 2.5 -> 1.4 frames/s between rounds
+    unpinned); the helper must pick from the cores this process may use and restore nothing it did not set"""
+    import bench
+    before = os.sched_getaffinity(0)
+    try:
+        cpus = bench.pin_cpu_leg(2)
+        assert cpus is not None and 1 <= len(cpus) <= 2 and set(cpus) <= before and os.sched_getaffinity(0) == set(cpus)
+        cores = set()
+        for c in cpus:
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/core_id") as f:
+                cores.add(int(f.read()))
+        assert len(cores) == len(cpus)
+    finally:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                os.sched_setaffinity(int(tid), before)
+            except OSError:
+                pass

@@ -216,3 +216,28 @@ def test_tiled_splat_on_two_streams_keeps_private_workspaces():
         assert len(bufs) == 2 and bufs[0] != bufs[1]
     finally:
         ops.SPLAT_TILED = old
+
+
+def test_splat_auto_switches_forms_at_the_point_threshold():
+    """SGAM_SPLAT_TILED=auto: below SPLAT_TILED_MIN_POINTS source points the two-pass form runs (no workspace), from the threshold
+    on the tiled form — and the frame is the same either side of it"""
+    B, N, H, W = 1, 3, 64, 64
+    f, d, Ks, T = testing.synth_warp_inputs(77, B, N, H, W, 0.1, True)
+    feats = [t(f[b, n].transpose(1, 2, 0)) for b in range(B) for n in range(N)]
+    depths = [t(d[b, n]) for b in range(B) for n in range(N)]
+    Kinv = torch.inverse(torch.from_numpy(Ks).reshape(-1, 3, 3)).to(DEV)
+    run = lambda: ops.forward_splat_srcs(feats, depths, t(Ks[:, 0]), Kinv, t(T).reshape(-1, 4, 4), B=B, dataset="google_earth",  # noqa: E731
+                                         want=("x", "extrap", "merge_depths"))
+    old = (ops.SPLAT_TILED, ops.SPLAT_TILED_MIN_POINTS)
+    try:
+        ops.SPLAT_TILED = None                                   # "auto"
+        ops.SPLAT_TILED_MIN_POINTS = B * N * H * W + 1
+        assert ops._splat_workspace(DEV, B, N, H, W)[0] is None
+        below = run()
+        ops.SPLAT_TILED_MIN_POINTS = B * N * H * W
+        assert ops._splat_workspace(DEV, B, N, H, W)[0] is not None
+        at = run()
+    finally:
+        ops.SPLAT_TILED, ops.SPLAT_TILED_MIN_POINTS = old
+    for k in ("x", "extrap", "merge_depths"):
+        assert torch.equal(below[k].view(torch.uint8), at[k].view(torch.uint8)), k
