@@ -172,12 +172,24 @@ def pmc_frame_entry(mode, timeline_name):
     if timeline_name in kernels:
         return fn, kernels[timeline_name]
     if timeline_name.endswith(">"):
+        base, args = timeline_name[:-1].split("<", 1)
+        have = args.split(",")
         cands = [k for k in kernels if k.startswith(timeline_name[:-1] + ",")]
-        # the omitted trailing template arguments are the defaulted ones (all `false` in this library)
+        # the omitted trailing template arguments are the defaulted ones: `false` everywhere in this library except the 16-bit halo
+        # kernel's tail <..., SW = true, GNF = false, NB = 3>
+        tail = _TEMPLATE_DEFAULT_TAIL.get(base)
+        if tail is not None:
+            full = f"{base}<{','.join(have + tail[len(have) - (_TEMPLATE_ARITY[base] - len(tail)):])}>"
+            if full in kernels:
+                return fn, kernels[full]
         dflt = [k for k in cands if set(k[len(timeline_name):-1].split(",")) <= {"false"}]
         if len(dflt) == 1 or len(cands) == 1:
             return fn, kernels[(dflt or cands)[0]]
     return fn, None
+
+
+_TEMPLATE_ARITY = {"conv3x3_h16_halo_kernel": 8}
+_TEMPLATE_DEFAULT_TAIL = {"conv3x3_h16_halo_kernel": ["true", "false", "3"]}
 
 
 def attach_counters(roofline, mode):

@@ -34,6 +34,7 @@ SOURCES = {
                      f"-DSGAM_HFD2={os.environ.get('SGAM_HFD2', '1')}",
                      f"-DSGAM_HFD4={os.environ.get('SGAM_HFD4', '1')}",
                      f"-DSGAM_HNBR={os.environ.get('SGAM_HNBR', '3')}",
+                     f"-DSGAM_HNBR64={os.environ.get('SGAM_HNBR64', '6')}",
                      f"-DSGAM_HLT={os.environ.get('SGAM_HLT', '0')}",
                      f"-DSGAM_HPEEL={os.environ.get('SGAM_HPEEL', '1')}",
                      f"-DSGAM_HRPF={os.environ.get('SGAM_HRPF', '1')}",

@@ -85,51 +85,84 @@ __global__ __launch_bounds__(256, 2) void gemm_gn_f32x_kernel(const GemmGnParams
         lo = *reinterpret_cast<const u32x4 *>(q + 1024);           // lo plane: + 128 pieces
     };
 
+    // Round 5: the panel is LATENCY-bound, not bandwidth- or matrix-bound (1.6 GFLOP in 13 us at n = 4096): the staging loop used to
+    // keep four 16-byte loads in flight per thread and round (four to sixteen dependent trips to L2 / HBM per panel) and every
+    // weight fragment was requested ONE k-step (192 matrix cycles) ahead of its use — an L2 round trip is ~700.  Now all of a
+    // thread's panel loads of a chunk are in flight at once (16 x 16 bytes; the next chunk's are requested before this chunk's
+    // MFMAs), and the weight fragments run WD = 4 k-steps ahead in a register ring whose first sets are requested before the panel.
+    constexpr int NIT = GBM * (KC / 4) / 256;                       // 16-byte pieces of the panel per thread: 16 (KC = 256), 8 (128)
+    constexpr int WD = 4;                                           // weight read-ahead in k-steps
+    constexpr int KS = KC / 16;                                     // k-steps per chunk
+    static_assert(KS % WD == 0, "the ring index of a k-step must not depend on the chunk");
+    const int prow = tid / (KC / 4), pc4 = (tid % (KC / 4)) * 4;    // this thread's (row, 4 channels) in round 0; round `it` adds 256 / (KC / 4) rows
+    f32x4 xr[NIT];
+    auto xload = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+            xr[it] = *reinterpret_cast<const f32x4 *>(p.x + (int64_t)(m0 + prow + it * (256 / (KC / 4))) * p.lda + k0 + pc4);
+    };
+    u32x4 wh[WD], wl[WD];
+    const int nks = p.K / 16;
+#pragma unroll
+    for (int t = 0; t < WD; ++t) wfrag(t < nks ? t : nks - 1, wh[t], wl[t]);
+    xload(0);
     for (int k0 = 0; k0 < p.K; k0 += KC) {
         if (k0) __syncthreads();                                    // the previous panel has been consumed
         // ---- stage the 64 x KC panel: normalise, split, store.  Thread -> (row, 4 consecutive channels): a half-wave of 64
         // threads covers one row (256 channels), so global reads are whole rows and LDS writes are conflict free
-#pragma unroll 4
-        for (int it = 0; it < GBM * (KC / 4) / 256; ++it) {
-            const int idx = it * 256 + tid;
-            const int row = idx / (KC / 4), c4 = (idx % (KC / 4)) * 4;
-            const int c = k0 + c4;
-            f32x4 v = *reinterpret_cast<const f32x4 *>(p.x + (int64_t)(m0 + row) * p.lda + c);
+        {
+            const int c = k0 + pc4;
+            float mean = 0.f, rstd = 1.f;
+            f32x4 ga = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
             if constexpr (GN) {
                 const int g = c / cpg;
-                float mean, rstd;
                 if (p.acc_in) mean = s_mr[2 * g], rstd = s_mr[2 * g + 1];
                 else mean = p.mean_rstd[(b * 32 + g) * 2], rstd = p.mean_rstd[(b * 32 + g) * 2 + 1];
-                const f32x4 ga = *reinterpret_cast<const f32x4 *>(p.gamma + c), be = *reinterpret_cast<const f32x4 *>(p.beta + c);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (v[e] - mean) * rstd * ga[e] + be[e];
+                ga = *reinterpret_cast<const f32x4 *>(p.gamma + c);
+                be = *reinterpret_cast<const f32x4 *>(p.beta + c);
             }
-            unsigned hi[2], lo[2];
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const float a0 = v[2 * e], a1 = v[2 * e + 1];
-                const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
-                const _Float16 l0 = (_Float16)(a0 - (float)h0), l1 = (_Float16)(a1 - (float)h1);
-                hi[e] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-                lo[e] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+            for (int it = 0; it < NIT; ++it) {
+                const int row = prow + it * (256 / (KC / 4));
+                f32x4 v = xr[it];
+                if constexpr (GN) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (v[e] - mean) * rstd * ga[e] + be[e];
+                }
+                unsigned hi[2], lo[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float a0 = v[2 * e], a1 = v[2 * e + 1];
+                    const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
+                    const _Float16 l0 = (_Float16)(a0 - (float)h0), l1 = (_Float16)(a1 - (float)h1);
+                    hi[e] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+                    lo[e] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+                }
+                *reinterpret_cast<unsigned long long *>(&sA[0][row][pc4]) = (unsigned long long)hi[0] | ((unsigned long long)hi[1] << 32);
+                *reinterpret_cast<unsigned long long *>(&sA[1][row][pc4]) = (unsigned long long)lo[0] | ((unsigned long long)lo[1] << 32);
             }
-            *reinterpret_cast<unsigned long long *>(&sA[0][row][c4]) = (unsigned long long)hi[0] | ((unsigned long long)hi[1] << 32);
-            *reinterpret_cast<unsigned long long *>(&sA[1][row][c4]) = (unsigned long long)lo[0] | ((unsigned long long)lo[1] << 32);
         }
+        if (k0 + KC < p.K) xload(k0 + KC);                          // the next chunk's panel: its trip overlaps this chunk's MFMAs
         __syncthreads();
-        // ---- 16 k-steps of 16: A fragments from LDS (row = 32 i + lr, k = 16 t + 8 lh + 0..7), weights one step ahead
-        u32x4 wh[2], wl[2];
-        wfrag(k0 / 16, wh[0], wl[0]);
+        // ---- KS k-steps of 16: A fragments from LDS (row = 32 i + lr, k = 16 t + 8 lh + 0..7), weights WD steps ahead
+        const int ks0 = k0 / 16;
 #pragma unroll
-        for (int t = 0; t < KC / 16; ++t) {
-            if (t + 1 < KC / 16) wfrag(k0 / 16 + t + 1, wh[(t + 1) & 1], wl[(t + 1) & 1]);
+        for (int t = 0; t < KS; ++t) {
+            const u32x4 bh = wh[t % WD], bl = wl[t % WD];
+            {
+                const int nx = ks0 + t + WD;                        // refill this slot for k-step t + WD (clamped: a dead load of the last)
+                wfrag(nx < nks ? nx : nks - 1, wh[t % WD], wl[t % WD]);
+            }
+            // (pins the request in front of this step's MFMAs: left free, the scheduler sinks every weight load next to its use to
+            // save registers, and the ring collapses to the one-step read-ahead it replaced)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const u32x4 ah = *reinterpret_cast<const u32x4 *>(&sA[0][i * 32 + lr][t * 16 + lh * 8]);
                 const u32x4 al = *reinterpret_cast<const u32x4 *>(&sA[1][i * 32 + lr][t * 16 + lh * 8]);
-                acc[i] = mfma16(ah, wh[t & 1], acc[i]);
-                acc[i] = mfma16(ah, wl[t & 1], acc[i]);
-                acc[i] = mfma16(al, wh[t & 1], acc[i]);
+                acc[i] = mfma16(ah, bh, acc[i]);
+                acc[i] = mfma16(ah, bl, acc[i]);
+                acc[i] = mfma16(al, bh, acc[i]);
             }
         }
     }

@@ -52,8 +52,12 @@
 #define SGAM_HFD4 1        // ... and of four (128-row; 256-row)
 #endif
 #ifndef SGAM_HNBR
-#define SGAM_HNBR 3        // weight-fragment ring of the 64- / 128-row tiles, in taps: 3 (two taps ahead) or 6 (five ahead: every weight
+#define SGAM_HNBR 3        // weight-fragment ring of the 128-row tile, in taps: 3 (two taps ahead) or 6 (five ahead: every weight
 #endif                     //    load a slab still needs is in the in-order vector-memory queue BEFORE the next halo load; slab loop unrolled by 2)
+#ifndef SGAM_HNBR64
+#define SGAM_HNBR64 6      // ... of the 64-row tile's whole-K launches (grids of <= 256 workgroups: ONE wavefront per SIMD, two taps of its
+#endif                     //    own MFMAs = 256 cycles do not cover an L2 round trip: 13.2 -> 12.3 us per launch in the bf16 frame, +2.3 % frames/s, A / B x 3);
+                           //    launches with an odd slab count per workgroup (split-K plans) keep the ring of 3
 #ifndef SGAM_HLT
 #define SGAM_HLT 0         // tap at which the staged halo is stored and the next halo load issued (0: NH + 1, right behind the last piece)
 #endif
@@ -138,7 +142,7 @@ __device__ __forceinline__ void hxcd_block(const HHParams &p, int &bx, int &by) 
 
 // `SW`: the fused GroupNorm is followed by swish (a template parameter, not a flag: a run-time test per staged piece cuts the
 // main loop into a dozen basic blocks and the MFMA / VALU interleaving stops at each of their borders)
-template <int BM, int BN, int HT, bool GN, bool UPS, bool SW = true, bool GNF = false>
+template <int BM, int BN, int HT, bool GN, bool UPS, bool SW = true, bool GNF = false, int NB = 3>
 __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kernel(const HHParams p) {
     // BM = 256 (a 16 x 16 patch, every wavefront 128 rows x 64 channels, TM = 4: a weight fragment fetched feeds four MFMAs,
     // one workgroup per CU with the 128 accumulators in AccVGPRs) compiles and passes the tests but is not dispatched:
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
     // needed three taps after the halo request, with six it is needed when the halo itself is, one slab later) — or, for the
     // one-workgroup-per-CU 256-row tile, one set per tap, each refilled for the NEXT slab as soon as its tap is done (nine taps
     // = 4 600 MFMA cycles ahead: an L2 round trip is ~0.7 us, two taps of this kernel are 0.2)
-    constexpr int NBR = BM == 256 ? 9 : SGAM_HNBR;
+    constexpr int NBR = BM == 256 ? 9 : NB;
     static_assert(NBR == 3 || NBR == 6 || NBR == 9, "ring of 3 (two taps ahead), 6 (five ahead) or 9 (one set per tap)");
     constexpr int SUN = NBR == 6 ? 2 : 1;  // slabs per trip of the slab loop: the set of (slab, tap) must be a compile-time index, 9 taps mod 6 repeat every second slab
     u32x4 bq[NBR][TN][2];                  // [(slab phase + tap) % NBR][n tile][k-step]
@@ -1659,7 +1663,6 @@ static int hh_conv_impl(const sgam_conv_desc *d, int32_t ht, const void *x, cons
     const HHPlan pl = hh_plan(d);
     const int bm = pl.bm;
     if (!bm || !x || !w_frag || !out || (ht != 0 && ht != 1)) return SGAM_EINVAL;
-    if (SGAM_HNBR == 6 && bm != 256 && ((pl.slabs_per_split & 1) || (d->Cin / 32) % pl.slabs_per_split)) return SGAM_EINVAL;   // (experiment builds: slab loop unrolled by two)
     const long long *gn_acc_in = nullptr;           // chunks_in == 0: the statistics of x are accumulators, not chunk records
     if (gn_partial_in && chunks_in == 0) {
         if (gn_mean_rstd || !(gn_eps > 0.f) || !sgam_aligned16(gn_partial_in) || sgam_conv2d_h16_gn_foldable(d, 0) != 1) return SGAM_EINVAL;
@@ -1707,12 +1710,24 @@ static int hh_conv_impl(const sgam_conv_desc *d, int32_t ht, const void *x, cons
     if (sgam_i_prof_on)
         sgam_i_prof_work(2.0 * p.M * d->n_valid * (double)(9 * d->Cin),
                          2.0 * ((double)d->B * d->Hi * d->Wi * d->Cin + (double)d->n_valid * 9 * d->Cin + (double)p.M * d->n_valid));
+    // ring depth of this launch: six sets need an even number of slabs per workgroup (the slab loop is unrolled by two)
+    const bool even = (pl.slabs_per_split % 2 == 0) && (p.slabs % pl.slabs_per_split == 0);
+    const bool deep = even && ((bm == 128 && SGAM_HNBR == 6) || (bm == 64 && SGAM_HNBR64 == 6));
+    // (launch sites spell the template arguments the way the kernel timeline / bench.py name the instantiations: the defaulted
+    // tail — SW = true, GNF = false, NB = 3 — is left off)
 #define HH_LAUNCH(BM_, HT_)                                                                                                      \
     do {                                                                                                                         \
         if (p.ups) SGAM_KLAUNCH((conv3x3_h16_halo_kernel<BM_, 128, HT_, false, true>), grid, dim3(256), 0, s, p);                \
         else if (gn && p.gn_swish) SGAM_KLAUNCH((conv3x3_h16_halo_kernel<BM_, 128, HT_, true, false>), grid, dim3(256), 0, s, p); \
         else if (gn) SGAM_KLAUNCH((conv3x3_h16_halo_kernel<BM_, 128, HT_, true, false, false>), grid, dim3(256), 0, s, p);        \
         else SGAM_KLAUNCH((conv3x3_h16_halo_kernel<BM_, 128, HT_, false, false>), grid, dim3(256), 0, s, p);                     \
+    } while (0)
+#define HH_LAUNCH6(BM_, HT_)                                                                                                                \
+    do {                                                                                                                                    \
+        if (p.ups) SGAM_KLAUNCH((conv3x3_h16_halo_kernel<BM_, 128, HT_, false, true, true, false, 6>), grid, dim3(256), 0, s, p);           \
+        else if (gn && p.gn_swish) SGAM_KLAUNCH((conv3x3_h16_halo_kernel<BM_, 128, HT_, true, false, true, false, 6>), grid, dim3(256), 0, s, p); \
+        else if (gn) SGAM_KLAUNCH((conv3x3_h16_halo_kernel<BM_, 128, HT_, true, false, false, false, 6>), grid, dim3(256), 0, s, p);        \
+        else SGAM_KLAUNCH((conv3x3_h16_halo_kernel<BM_, 128, HT_, false, false, true, false, 6>), grid, dim3(256), 0, s, p);                \
     } while (0)
     // the 128-row tile, whole K, no upsampling: the persistent producer / consumer kernel — OPT-IN (SGAM_HPC=1).  Bit-identical to the
     // one-role kernel (scripts/h16_pc_check.py) and its consumers run at 0.8 of the matrix pipe, but the launch as a whole measured
@@ -1763,11 +1778,19 @@ static int hh_conv_impl(const sgam_conv_desc *d, int32_t ht, const void *x, cons
     } else if (bm == 256) {
         if (ht == 0) HH_LAUNCH(256, 0); else HH_LAUNCH(256, 1);
     } else if (bm == 128) {
+#if SGAM_HNBR == 6
+        if (deep) { if (ht == 0) HH_LAUNCH6(128, 0); else HH_LAUNCH6(128, 1); } else
+#endif
         if (ht == 0) HH_LAUNCH(128, 0); else HH_LAUNCH(128, 1);
     } else {
+#if SGAM_HNBR64 == 6
+        if (deep) { if (ht == 0) HH_LAUNCH6(64, 0); else HH_LAUNCH6(64, 1); } else
+#endif
         if (ht == 0) HH_LAUNCH(64, 0); else HH_LAUNCH(64, 1);
     }
+    (void)deep;
 #undef HH_LAUNCH
+#undef HH_LAUNCH6
     SGAM_LAUNCH_CHECK();
     if (pl.ksplit > 1) {
         const int64_t q = (int64_t)p.M * (d->N / 4);

@@ -63,6 +63,7 @@ F32_MODE = os.environ.get("SGAM_F32_MODE", "split")
 # frame than the generic kernel under its tuned plans (scripts/exp_panel.sh), so opt-in; the fused GroupNorm + q|k|v projection
 # (where the kernel removes a whole pass) is independent of this switch
 PANEL_GEMM = os.environ.get("SGAM_PANEL_GEMM", "0") == "1"
+PANEL_MIN_WGS = int(os.environ.get("SGAM_PANEL_MIN_WGS", "64"))    # ... for shapes of at least this many 64 x 128 tiles
 # split-mode convolutions also emit the GroupNorm statistics of their output from the epilogue (no statistics pass)
 FUSE_GN_STATS = os.environ.get("SGAM_FUSE_GN_STATS", "1") == "1"
 # ... and normalise(+swish) their INPUT while staging it (halo-staged 3x3 kernel): no stand-alone normalise pass
@@ -490,7 +491,7 @@ def _run_conv_inner(lib, desc, x, w, bias, residual, out, gn=None, a_scale=1.0):
         # (csrc/gemm_gn_f32x.hip: one barrier per 256 of K instead of one per 32, direct row stores, statistics from registers)
         M_, HW_ = desc.B * desc.Ho * desc.Wo, desc.Ho * desc.Wo
         if (PANEL_GEMM and gn is None and a_scale == 1.0 and desc.KH == 1 and desc.KW == 1 and desc.stride == 1 and not desc.upsample2x
-                and desc.bias_per_row == 0 and desc.n_valid == desc.N and (M_ // 64) * (desc.N // 128) >= 64
+                and desc.bias_per_row == 0 and desc.n_valid == desc.N and (M_ // 64) * (desc.N // 128) >= PANEL_MIN_WGS
                 and lib.sgam_gemm_gn_f32x_fits(M_, desc.N, desc.Cin, HW_) == 1):
             cpo = desc.N // 32
             chunks = HW_ // 64 if (FUSE_GN_STATS and cpo <= 32 and cpo & (cpo - 1) == 0) else 0
