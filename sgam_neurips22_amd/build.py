@@ -26,7 +26,8 @@ SOURCES = {
                       f"-DSGAM_XWGM={os.environ.get('SGAM_XWGM', '1')}",
                       f"-DSGAM_XSOFF={os.environ.get('SGAM_XSOFF', '1')}",
                       f"-DSGAM_XPEEL={os.environ.get('SGAM_XPEEL', '1')}",
-                      f"-DSGAM_XLB64={os.environ.get('SGAM_XLB64', '2')}"],
+                      f"-DSGAM_XLB64={os.environ.get('SGAM_XLB64', '2')}",
+                      f"-DSGAM_XNBR64={os.environ.get('SGAM_XNBR64', '6')}"],
     "h16_halo.hip": [f"-DSGAM_HABLATE={os.environ.get('SGAM_HABLATE', '0')}",
                      f"-DSGAM_HDIRECT={os.environ.get('SGAM_HDIRECT', '1')}",
                      f"-DSGAM_HWGM={os.environ.get('SGAM_HWGM', '1')}",
@@ -35,6 +36,7 @@ SOURCES = {
                      f"-DSGAM_HFD4={os.environ.get('SGAM_HFD4', '1')}",
                      f"-DSGAM_HNBR={os.environ.get('SGAM_HNBR', '3')}",
                      f"-DSGAM_HNBR64={os.environ.get('SGAM_HNBR64', '6')}",
+                     f"-DSGAM_HNBRF={os.environ.get('SGAM_HNBRF', '6')}",
                      f"-DSGAM_HLT={os.environ.get('SGAM_HLT', '0')}",
                      f"-DSGAM_HPEEL={os.environ.get('SGAM_HPEEL', '1')}",
                      f"-DSGAM_HRPF={os.environ.get('SGAM_HRPF', '1')}",

@@ -210,6 +210,9 @@ __device__ __forceinline__ void gn_scale_shift(const XParams &p, int b, int c, f
 #ifndef SGAM_XLB64
 #define SGAM_XLB64 2       // workgroups per CU the 64-row halo tile is compiled for.  3 caps it at 168 registers (three wavefronts per SIMD): the
 #endif                     //    peeled GroupNorm form then spills 12 bytes and measured 21.2 against 20.3 us in the frame; 2 lets it take 172
+#ifndef SGAM_XNBR64
+#define SGAM_XNBR64 6      // weight-fragment ring of the 64-row halo tile's GroupNorm launches on grids of <= 2 workgroups per CU: 3 or 6 sets
+#endif
 #ifndef SGAM_XPEEL
 #define SGAM_XPEEL 1       // halo kernels: the last two slabs of a workgroup peeled (no staging of a slab that does not exist)
 #endif
@@ -718,7 +721,7 @@ __global__ __launch_bounds__(256 * wk_of(BM, BN)) void conv_gemm_f32x_kernel(con
 // UPS: the conv runs on the nearest-2x upsampled input without materialising it — the staged halo is the SOURCE patch
 // ((TH/2 + 2) x (TW/2 + 2) pixels: a third of the pixels), and a lane finds the source pixel of (patch pixel, tap) as
 // ((p + k - 1) >> 1) + 1 per axis.
-template <int BM, int BN, bool GN, bool UPS = false, bool GNF = false>
+template <int BM, int BN, bool GN, bool UPS = false, bool GNF = false, int NB = 3>
 __global__ __launch_bounds__(256, (BM == 64 && !GNF) ? SGAM_XLB64 : 2) void conv3x3_f32x_halo2_kernel(const XParams p) {
     static_assert(!GNF || GN, "GNF = GroupNorm statistics folded from the producer's chunk partials: a GN kernel");
 #ifndef SGAM_XWGM
@@ -854,10 +857,13 @@ __global__ __launch_bounds__(256, (BM == 64 && !GNF) ? SGAM_XLB64 : 2) void conv
         }
     };
 
-    // B fragments: three register sets rotate with the tap (9 taps = 3 full turns, so a slab ends where it began); the
+    // B fragments: NB = 3 register sets rotate with the tap (9 taps = 3 full turns, so a slab ends where it began); the
     // fragments are requested TWO taps ahead — one tap of MFMAs (384 cycles on the 64-row tile) does not cover an L2
-    // round trip when a SIMD holds a single wavefront
-    u32x4 bq[3][TN][2][2];                 // [tap % 3][n tile][k-step][hi, lo]
+    // round trip when a SIMD holds a single wavefront.  NB = 6 (round 5, the 64-row tile's launches of <= 2 workgroups per CU):
+    // FIVE taps ahead; the ring phase of a slab's tap 0 then alternates 0, 3, 0 ... and the slab loop is spelled for the
+    // slab counts those launches have (h16_halo.hip has the same ring and the measurements)
+    static_assert(NB == 3 || (NB == 6 && SGAM_XPEEL), "ring of three, or of six with the peeled slab loop");
+    u32x4 bq[NB][TN][2][2];                // [(slab phase + tap) % NB][n tile][k-step][hi, lo]
     auto bload = [&](const int set, int tap, int ch, bool live) {
         const unsigned koff = (unsigned)(tap * p.Cin + ch * XBK) * 128u;   // 4096 bytes per (row tile, slab); scalar offset
 #pragma unroll
@@ -897,8 +903,8 @@ __global__ __launch_bounds__(256, (BM == 64 && !GNF) ? SGAM_XLB64 : 2) void conv
     const int s0 = it0 / 9, s1 = SGAM_XABLATE == 1 ? it0 / 9 : it1 / 9;
     int hcur = 0;
     hload_issue(s0, s0 < s1);
-    bload(0, 0, s0, s0 < s1);
-    bload(1, 1, s0, s0 < s1);
+#pragma unroll
+    for (int t = 0; t < NB - 1; ++t) bload(t, t, s0, s0 < s1);
     if constexpr (GN && !GNF) {
         // (behind the first halo and weight loads, so that its own round trip overlaps theirs; same expressions and order as
         // gn_scale_shift / the stand-alone GroupNorm kernels)
@@ -1002,8 +1008,8 @@ __global__ __launch_bounds__(256, (BM == 64 && !GNF) ? SGAM_XLB64 : 2) void conv
     // staging arithmetic runs on the zeros they return); the peeled forms (SGAM_XPEEL, round 5) know: 1 = two more slabs follow,
     // 2 = one more follows (stage it, request nothing), 3 = the last — nothing to stage: a workgroup of a split-K plan on the
     // 16^2 / 32^2 maps walks one or two slabs, so half or all of its in-loop GroupNorm / swish / split work ran on zeros
-    auto slab = [&](const int sl, auto mode_) {
-        constexpr int MODE = decltype(mode_)::value;
+    auto slab = [&](const int sl, auto mode_, auto rb_) {
+        constexpr int MODE = decltype(mode_)::value, RB = decltype(rb_)::value;      // RB: ring phase of this slab's tap 0
         const bool has_next = MODE == 0 ? sl + 1 < s1 : MODE != 3;
         const bool has_next2 = MODE == 0 ? sl + 2 < s1 : MODE == 1;
         hb = smem + hcur * HBUF;
@@ -1014,15 +1020,16 @@ __global__ __launch_bounds__(256, (BM == 64 && !GNF) ? SGAM_XLB64 : 2) void conv
         }
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int set = tap % 3;
+            const int set = (tap + RB) % NB;
             // timing experiments (results are wrong): 21 no weight loads, 25 no halo staging, 24 neither, 27 neither and no A-fragment
             // reads (the bare MFMA stream), 26 everything but the MFMAs
             constexpr bool NOB = SGAM_XABLATE == 21 || SGAM_XABLATE == 24 || SGAM_XABLATE == 27;
             constexpr bool NOH = SGAM_XABLATE == 24 || SGAM_XABLATE == 25 || SGAM_XABLATE == 27 || MODE == 3;
             constexpr bool NOA = SGAM_XABLATE == 27, NOM = SGAM_XABLATE == 26;
             if (!NOB) {
-                if (tap < 7) bload((tap + 2) % 3, tap + 2, sl, true);
-                else if constexpr (MODE != 3) bload((tap + 2) % 3, tap - 7, sl + 1, has_next);
+                const int tt = tap + NB - 1;
+                if (tt < 9) bload((tt + RB) % NB, tt, sl, true);
+                else if constexpr (MODE != 3) bload((tt + RB) % NB, tt - 9, sl + 1, has_next);
             }
             // (28: the staging arithmetic and LDS stores run, on stale registers, without the in-loop halo LOADS; 29: the loads are
             // issued, nothing is done with them)
@@ -1061,13 +1068,34 @@ __global__ __launch_bounds__(256, (BM == 64 && !GNF) ? SGAM_XLB64 : 2) void conv
         __syncthreads();                                               // next halo visible; old one free for re-use
         hcur ^= 1;
     };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 2> I2;
+    typedef std::integral_constant<int, 3> I3;
     if constexpr (!SGAM_XPEEL) {
-        for (int sl = s0; sl < s1; ++sl) slab(sl, std::integral_constant<int, 0>{});
-    } else if (s0 < s1) {
+        for (int sl = s0; sl < s1; ++sl) slab(sl, I0{}, I0{});
+    } else if constexpr (NB == 3) {
+        if (s0 < s1) {
+            int sl = s0;
+            for (; sl + 2 < s1; ++sl) slab(sl, I1{}, I0{});
+            if (s1 - s0 >= 2) slab(s1 - 2, I2{}, I0{});
+            slab(s1 - 1, I3{}, I0{});
+        }
+    } else if constexpr (GNF) {                       // (host: a folding workgroup walks one or two slabs)
+        if (s1 - s0 >= 2) {
+            slab(s0, I2{}, I0{});
+            slab(s0 + 1, I3{}, I3{});
+        } else if (s0 < s1) {
+            slab(s0, I3{}, I0{});
+        }
+    } else if (s0 < s1) {                             // (host: an even number of slabs per workgroup)
         int sl = s0;
-        for (; sl + 2 < s1; ++sl) slab(sl, std::integral_constant<int, 1>{});
-        if (s1 - s0 >= 2) slab(s1 - 2, std::integral_constant<int, 2>{});
-        slab(s1 - 1, std::integral_constant<int, 3>{});
+        for (; sl + 2 < s1; sl += 2) {
+            slab(sl, I1{}, I0{});
+            slab(sl + 1, I1{}, I3{});
+        }
+        slab(s1 - 2, I2{}, I0{});
+        slab(s1 - 1, I3{}, I3{});
     }
     __syncthreads();                                  // every wavefront is done with the halo: LDS becomes the epilogue's
 
@@ -2043,9 +2071,20 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
             if (gn_tab_on) SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<64, 64, true>), grid, dim3(256), 0, s, p);
             else SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<64, 64, false>), grid, dim3(256), 0, s, p);
         } else {
+            // ring of six for the launches that leave a SIMD one or two wavefronts (grid <= 2 workgroups per CU) and whose slab count the
+            // kernel spells: even, or the one / two slabs of the folding form
+            const int slabs_wg = p.iters_per_split / 9;
+            const bool deep6 = SGAM_XNBR64 == 6 && SGAM_XPEEL && (int64_t)grid.x * grid.y * grid.z <= 2 * 256 && p.iters_per_split % 9 == 0 &&
+                               (p.gn_partial_in ? slabs_wg <= 2 : (slabs_wg % 2 == 0 && (p.iters_total / 9) % slabs_wg == 0));
+#if SGAM_XNBR64 == 6 && SGAM_XPEEL
+            if (deep6 && p.gn_partial_in) SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<64, 128, true, false, true, 6>), grid, dim3(256), 0, s, p);
+            else if (deep6 && gn_tab_on) SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<64, 128, true, false, false, 6>), grid, dim3(256), 0, s, p);
+            else
+#endif
             if (p.gn_partial_in) SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<64, 128, true, false, true>), grid, dim3(256), 0, s, p);
             else if (gn_tab_on) SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<64, 128, true>), grid, dim3(256), 0, s, p);
             else SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<64, 128, false>), grid, dim3(256), 0, s, p);
+            (void)deep6;
         }
     } else if (pl.bm == 128 && pl.bn == 128) XLAUNCH(128, 128);
     else if (pl.bm == 64 && pl.bn == 128) XLAUNCH(64, 128);

@@ -58,6 +58,9 @@
 #define SGAM_HNBR64 6      // ... of the 64-row tile's whole-K launches (grids of <= 256 workgroups: ONE wavefront per SIMD, two taps of its
 #endif                     //    own MFMAs = 256 cycles do not cover an L2 round trip: 13.2 -> 12.3 us per launch in the bf16 frame, +2.3 % frames/s, A / B x 3);
                            //    launches with an odd slab count per workgroup (split-K plans) keep the ring of 3
+#ifndef SGAM_HNBRF
+#define SGAM_HNBRF 6       // ... and of its folding form (split-K workgroups of the 16^2 / 32^2 maps: one or two slabs)
+#endif
 #ifndef SGAM_HLT
 #define SGAM_HLT 0         // tap at which the staged halo is stored and the next halo load issued (0: NH + 1, right behind the last piece)
 #endif
@@ -332,6 +335,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
     // = 4 600 MFMA cycles ahead: an L2 round trip is ~0.7 us, two taps of this kernel are 0.2)
     constexpr int NBR = BM == 256 ? 9 : NB;
     static_assert(NBR == 3 || NBR == 6 || NBR == 9, "ring of 3 (two taps ahead), 6 (five ahead) or 9 (one set per tap)");
+    static_assert(NBR != 6 || (SGAM_HPEEL && SGAM_HDIRECT), "the ring of six is written for the peeled slab loop");
     constexpr int SUN = NBR == 6 ? 2 : 1;  // slabs per trip of the slab loop: the set of (slab, tap) must be a compile-time index, 9 taps mod 6 repeat every second slab
     u32x4 bq[NBR][TN][2];                  // [(slab phase + tap) % NBR][n tile][k-step]
     auto bload = [&](const int set, int tap, int ch, bool live) {
@@ -561,18 +565,35 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
     } else if constexpr (!PEEL) {
         for (int sl = s0; sl < s1; sl += SUN) {
             slab(sl, I0{}, I0{});
-            if constexpr (SUN == 2) slab(sl + 1, I3{}, I0{});      // (host: an even number of slabs per workgroup in SGAM_HNBR = 6 builds)
+            if constexpr (SUN == 2) slab(sl + 1, I3{}, I0{});      // (unreachable: the ring of six needs the peeled loop, asserted above)
         }
-    } else {
+    } else if constexpr (SUN == 1) {
         int sl = s0;
-        for (; sl + 2 < s1; sl += SUN) {
-            slab(sl, I0{}, I1{});
-            if constexpr (SUN == 2) slab(sl + 1, I3{}, I1{});
-        }
+        for (; sl + 2 < s1; ++sl) slab(sl, I0{}, I1{});
         if (s1 - s0 >= 2) slab(s1 - 2, I0{}, I2{});
         else if constexpr (RPF) rload();
-        if constexpr (SUN == 2) slab(s1 - 1, I3{}, I3{});
-        else slab(s1 - 1, I0{}, I3{});
+        slab(s1 - 1, I0{}, I3{});
+    } else {
+        // ring of six: the ring phase of a slab's tap 0 alternates 0, 3, 0, ...  Two shapes of slab loop are spelled — every
+        // further (phase, mode) copy of the slab body costs registers (a dispatch for ANY slab count compiled to 250+ VGPRs, or to
+        // 168 with 200 - 500 bytes of scratch): the folding form's workgroups walk one or two slabs (host: sgam_conv2d_h16_gn_foldable),
+        // every other launch that takes this ring an even number (host: `deep`)
+        if constexpr (GNF) {
+            if (s1 - s0 >= 2) {
+                slab(s0, I0{}, I2{});
+                slab(s0 + 1, I3{}, I3{});
+            } else {
+                slab(s0, I0{}, I3{});
+            }
+        } else {
+            int sl = s0;
+            for (; sl + 2 < s1; sl += 2) {
+                slab(sl, I0{}, I1{});
+                slab(sl + 1, I3{}, I1{});
+            }
+            slab(s1 - 2, I0{}, I2{});
+            slab(s1 - 1, I3{}, I3{});
+        }
     }
     __syncthreads();
 
@@ -1710,7 +1731,7 @@ static int hh_conv_impl(const sgam_conv_desc *d, int32_t ht, const void *x, cons
     if (sgam_i_prof_on)
         sgam_i_prof_work(2.0 * p.M * d->n_valid * (double)(9 * d->Cin),
                          2.0 * ((double)d->B * d->Hi * d->Wi * d->Cin + (double)d->n_valid * 9 * d->Cin + (double)p.M * d->n_valid));
-    // ring depth of this launch: six sets need an even number of slabs per workgroup (the slab loop is unrolled by two)
+    // ring depth of this launch: the ring of six is spelled for even slab counts per workgroup (and for the one or two of the folding form)
     const bool even = (pl.slabs_per_split % 2 == 0) && (p.slabs % pl.slabs_per_split == 0);
     const bool deep = even && ((bm == 128 && SGAM_HNBR == 6) || (bm == 64 && SGAM_HNBR64 == 6));
     // (launch sites spell the template arguments the way the kernel timeline / bench.py name the instantiations: the defaulted
@@ -1771,10 +1792,17 @@ static int hh_conv_impl(const sgam_conv_desc *d, int32_t ht, const void *x, cons
         return SGAM_OK;
     }
     if (gn_partial_in) {
+#if SGAM_HNBRF == 6
+        if (ht == 0 && p.gn_swish) SGAM_KLAUNCH((conv3x3_h16_halo_kernel<64, 128, 0, true, false, true, true, 6>), grid, dim3(256), 0, s, p);
+        else if (ht == 0) SGAM_KLAUNCH((conv3x3_h16_halo_kernel<64, 128, 0, true, false, false, true, 6>), grid, dim3(256), 0, s, p);
+        else if (p.gn_swish) SGAM_KLAUNCH((conv3x3_h16_halo_kernel<64, 128, 1, true, false, true, true, 6>), grid, dim3(256), 0, s, p);
+        else SGAM_KLAUNCH((conv3x3_h16_halo_kernel<64, 128, 1, true, false, false, true, 6>), grid, dim3(256), 0, s, p);
+#else
         if (ht == 0 && p.gn_swish) SGAM_KLAUNCH((conv3x3_h16_halo_kernel<64, 128, 0, true, false, true, true>), grid, dim3(256), 0, s, p);
         else if (ht == 0) SGAM_KLAUNCH((conv3x3_h16_halo_kernel<64, 128, 0, true, false, false, true>), grid, dim3(256), 0, s, p);
         else if (p.gn_swish) SGAM_KLAUNCH((conv3x3_h16_halo_kernel<64, 128, 1, true, false, true, true>), grid, dim3(256), 0, s, p);
         else SGAM_KLAUNCH((conv3x3_h16_halo_kernel<64, 128, 1, true, false, false, true>), grid, dim3(256), 0, s, p);
+#endif
     } else if (bm == 256) {
         if (ht == 0) HH_LAUNCH(256, 0); else HH_LAUNCH(256, 1);
     } else if (bm == 128) {
