@@ -210,6 +210,10 @@ __device__ __forceinline__ void gn_scale_shift(const XParams &p, int b, int c, f
 #ifndef SGAM_XLB64
 #define SGAM_XLB64 2       // workgroups per CU the 64-row halo tile is compiled for.  3 caps it at 168 registers (three wavefronts per SIMD): the
 #endif                     //    peeled GroupNorm form then spills 12 bytes and measured 21.2 against 20.3 us in the frame; 2 lets it take 172
+#ifndef SGAM_XRWARM
+#define SGAM_XRWARM 0      // halo kernels: L2 warm-up of the residual tile from the second-to-last slab (see rwarm).  Measured: no effect —
+#endif                     //    340.7 / 340.8 / 340.0 against 341.1 / 340.4 / 340.6 frames/s (the tile is L2 / MALL resident inside the frame): off
+
 #ifndef SGAM_XNBR64
 #define SGAM_XNBR64 6      // weight-fragment ring of the 64-row halo tile's GroupNorm launches on grids of <= 2 workgroups per CU: 3 or 6 sets
 #endif
@@ -1004,6 +1008,28 @@ __global__ __launch_bounds__(256, (BM == 64 && !GNF) ? SGAM_XLB64 : 2) void conv
         }
     };
     constexpr bool XASM = !UPS && (SGAM_XABLATE != 30);
+    // L2 warm-up of the residual tile (SGAM_XRWARM, peeled loops): every 128-byte line of the rows this workgroup will add in its
+    // epilogue is touched ONCE where the second-to-last slab's (dead) halo request stood — no younger weight load is held up longer than
+    // a halo request would have, a slab and a half of MFMAs cover the trip, and the epilogue's float4 loads (issued by all 512
+    // workgroups of a one-wave launch at once: 33.5 MB at B = 1 on the 256^2 layers) find the lines in this XCD's L2.  Without a
+    // residual (or with split-K partial tiles, whose combine adds it) the descriptor is empty: nothing is fetched.
+    constexpr int NWARM = SGAM_XRWARM ? (BM * (BN / 32) + 255) / 256 : 0;
+    unsigned rwarm_v[NWARM > 0 ? NWARM : 1];
+    auto rwarm = [&]() {
+        if constexpr (NWARM > 0) {
+            const bool live = p.res != nullptr && p.ws == nullptr;
+            const unsigned r_bytes_ = live ? (unsigned)(((int64_t)(p.M - 1) * p.ldr + p.n_valid) * 4) : 0u;
+            const __amdgpu_buffer_rsrc_t rr_ = __builtin_amdgcn_make_buffer_rsrc((void *)p.res, 0, (int)r_bytes_, 0x00020000);
+#pragma unroll
+            for (int k = 0; k < NWARM; ++k) {
+                const int idx = tid + 256 * k, row = idx / (BN / 32), q = idx - row * (BN / 32);
+                const int m = (b * p.Ho + ty0 + (row >> TWS)) * p.Wo + tx0 + (row & (TW - 1));
+                const int n = n0 + q * 32;
+                rwarm_v[k] = __builtin_amdgcn_raw_buffer_load_b32(
+                    rr_, (int)xsel(row < BM && n < p.n_valid, (unsigned)(m * p.ldr + n) * 4u, 0xFFFFFFF0u), 0, 0);
+            }
+        }
+    };
     // one slab.  MODE 0: run-time flags say whether a next slab / the one behind it exist (dead loads go out of range and the
     // staging arithmetic runs on the zeros they return); the peeled forms (SGAM_XPEEL, round 5) know: 1 = two more slabs follow,
     // 2 = one more follows (stage it, request nothing), 3 = the last — nothing to stage: a workgroup of a split-K plan on the
@@ -1038,6 +1064,8 @@ __global__ __launch_bounds__(256, (BM == 64 && !GNF) ? SGAM_XLB64 : 2) void conv
                 if (SGAM_XABLATE != 29) hstore(hcur ^ 1);               // idle buffer: nobody reads it during this slab
                 if constexpr (MODE != 2) {
                     if (SGAM_XABLATE != 28) hload(sl + 2, has_next2);
+                } else {
+                    rwarm();
                 }
             }
 #pragma unroll
@@ -1098,6 +1126,10 @@ __global__ __launch_bounds__(256, (BM == 64 && !GNF) ? SGAM_XLB64 : 2) void conv
         slab(s1 - 1, I3{}, I3{});
     }
     __syncthreads();                                  // every wavefront is done with the halo: LDS becomes the epilogue's
+    if constexpr (NWARM > 0 && SGAM_XPEEL) {
+#pragma unroll
+        for (int k = 0; k < NWARM; ++k) asm volatile("" ::"v"(rwarm_v[k]));          // (the touches are loads with a destination: retire them here)
+    }
 
     xepilogue<BM, BN, WGM_>(p, acc, reinterpret_cast<float *>(smem), wave, lane, bx, bz, n0, [&](int row) {
         return (b * p.Ho + ty0 + (row >> TWS)) * p.Wo + tx0 + (row & (TW - 1));
