@@ -51,6 +51,8 @@ SOURCES = {
     "tsdf.hip": ["-ffp-contract=off"] + (["-DSGAM_TSDF_DEBUG_STEPS"] if os.environ.get("SGAM_TSDF_DEBUG_STEPS") else []),
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+if os.environ.get("SGAM_STATS_R"):          # replicas of a GroupNorm accumulator record (csrc/sgam_common.h; ops.STATS_R must match)
+    COMMON.append(f"-DSGAM_STATS_R={int(os.environ['SGAM_STATS_R'])}")
 
 
 def _hipcc():

@@ -48,7 +48,9 @@ __device__ __forceinline__ bool sgam_not_finite(float t) { return !(__builtin_fa
 // replica made a 26 us kernel take 100); a workgroup adds to replica (workgroup index mod 16) and the consumer adds the sixteen
 // replicas — integers again, so still exact and order-free.  |v| is clamped to 2^54 (an fp32 tensor whose group sums leave that
 // range has left fp32's useful range too).
+#ifndef SGAM_STATS_R
 #define SGAM_STATS_R 16
+#endif
 __device__ __forceinline__ void sgam_stats_split(double v, long long &hi, long long &lo) {
     v = fmin(fmax(v, -0x1p54), 0x1p54);
     const double t = v * 0x1p8, h = floor(t);

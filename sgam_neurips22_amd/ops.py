@@ -379,7 +379,7 @@ STATS_ACC = os.environ.get("SGAM_STATS_ACC", "0") == "1"
 _ARENA = None
 
 
-STATS_R = 16                                      # replicas of a record (SGAM_STATS_R of csrc/sgam_common.h)
+STATS_R = int(os.environ.get("SGAM_STATS_R", "16"))   # replicas of a record (SGAM_STATS_R of csrc/sgam_common.h: a variant build's value travels in the environment)
 STATS_RECORD = STATS_R * 32 * 4                   # int64 words per image
 
 
