@@ -132,6 +132,16 @@ __device__ __forceinline__ unsigned hsel(bool c, unsigned a, unsigned b) {
     return (a & m) | (b & ~m);
 }
 
+// a lane's contribution of four stored values to the output statistics {sum, sum of squares}: ONE spelled sequence of roundings
+// (explicit fused multiply-adds, no further contraction) shared by the one-role and the producer / consumer kernel — left to the
+// compiler's fp-contract choice the two kernels rounded the sum of squares differently on the fp32-output path (the experimental
+// bit-identity test of round 5 found it: tensors equal, chunk statistics one ulp apart)
+__device__ __forceinline__ void hstat_add(float &s, float &ss, const f32x4 v) {
+#pragma clang fp contract(off)
+    s += (v[0] + v[1]) + (v[2] + v[3]);
+    ss += __builtin_fmaf(v[3], v[3], __builtin_fmaf(v[2], v[2], __builtin_fmaf(v[1], v[1], v[0] * v[0])));
+}
+
 __device__ __forceinline__ void hxcd_block(const HHParams &p, int &bx, int &by) {
     const unsigned L = blockIdx.x, T = gridDim.x;
     unsigned Lp = L;
@@ -698,8 +708,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
                 }
                 if (ok) {
                     constexpr int TMH = TM / RH > 0 ? TM / RH : 1;
-                    us[RH == 1 ? 0 : i / TMH][j][k] += (v[0] + v[1]) + (v[2] + v[3]);
-                    uss[RH == 1 ? 0 : i / TMH][j][k] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                    hstat_add(us[RH == 1 ? 0 : i / TMH][j][k], uss[RH == 1 ? 0 : i / TMH][j][k], v);
                 }
             }
             if (!p.out_f32) {
@@ -1326,10 +1335,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p
                         o16[k >> 1][(k & 1) * 2 + 1] = (unsigned)h2 | ((unsigned)h3 << 16);
                         v = f32x4{HH<HT>::to_f(h0), HH<HT>::to_f(h1), HH<HT>::to_f(h2), HH<HT>::to_f(h3)};     // statistics of the STORED tensor
                     }
-                    if (ok) {
-                        us[ih][k] += (v[0] + v[1]) + (v[2] + v[3]);
-                        uss[ih][k] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-                    }
+                    if (ok) hstat_add(us[ih][k], uss[ih][k], v);
                 }
                 if (!p.out_f32) {
                     if (nb + 16 <= n_lim) {
