@@ -329,6 +329,17 @@ int sgam_attention_h16(const void *q, const void *k, const void *v, int32_t ht, 
 int64_t sgam_attention_f32x_batched_workspace_bytes(int32_t n, int32_t C, int32_t B);
 int sgam_attention_f32x_batched(const float *q, const float *k, const float *v, int32_t ld, int32_t n, int32_t C, int32_t B,
                                 float scale, float *out, int32_t ldo, void *workspace, int64_t workspace_bytes, void *stream);
+/* (ABI v8) sgam_attention_f32x_batched followed by AttnBlock.proj_out (+ residual) — reference modules/diffusionmodules/model.py:176-191,
+ * `h_ = bmm(v, w_); h_ = self.proj_out(h_); return x + h_` — with the merge of the key ranges fused into the projection: no [B n][C]
+ * attention output is written and read back, one launch fewer.  w_planes / w_scale: proj_out's [C][C] weight as sgam_split_rows_f32x
+ * returns it; bias [C] or NULL; residual [B n][ldr] or NULL; out [B n][ldc]; gn_partial (optional): [B][n / 32][32][2] fp64 {sum, sumsq}
+ * of `out` per (32-row tile, group of C / 32 channels) for the GroupNorm that follows (fold with sgam_groupnorm_stats_from_partials_f32,
+ * nchunk = n / 32) — or, with gn_acc = 1, the zeroed [B][16][32][4] int64 accumulator record of sgam_conv_desc.stats_acc.  Same shape
+ * limits and workspace as sgam_attention_f32x_batched. */
+int sgam_attention_proj_f32x_batched(const float *q, const float *k, const float *v, int32_t ld, int32_t n, int32_t C, int32_t B,
+                                     float scale, const void *w_planes, float w_scale, const float *bias, const float *residual,
+                                     int32_t ldr, float *out, int32_t ldc, double *gn_partial, int32_t gn_acc, void *workspace,
+                                     int64_t workspace_bytes, void *stream);
 int64_t sgam_attention_h16_batched_workspace_bytes(int32_t n, int32_t C, int32_t B);
 int sgam_attention_h16_batched(const void *q, const void *k, const void *v, int32_t ht, int32_t ld, int32_t n, int32_t C,
                                int32_t B, float scale, void *out, int32_t ldo, void *workspace, int64_t workspace_bytes,

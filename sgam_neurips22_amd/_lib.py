@@ -23,7 +23,7 @@ class TsdfGrid(ctypes.Structure):
 
 
 # name -> (restype, argtypes); must list every symbol include/sgam_hip.h declares
-ABI_VERSION = 7      # include/sgam_hip.h: sgam_abi_version() of the library these prototypes were written against
+ABI_VERSION = 8      # include/sgam_hip.h: sgam_abi_version() of the library these prototypes were written against
 
 PROTOTYPES = {
     "sgam_abi_version": (c_i32, []),
@@ -145,6 +145,8 @@ PROTOTYPES = {
     "sgam_attention_h16": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_i32, c_vp, c_i64, c_vp]),
     "sgam_attention_f32x_batched_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
     "sgam_attention_f32x_batched": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_i32, c_vp, c_i64, c_vp]),
+    "sgam_attention_proj_f32x_batched": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_f32, c_vp, c_vp, c_i32, c_vp,
+                                                 c_i32, c_vp, c_i32, c_vp, c_i64, c_vp]),
     "sgam_attention_h16_batched_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
     "sgam_attention_h16_batched": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_i32, c_vp, c_i64, c_vp]),
     "sgam_row_sumsq_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),

@@ -370,36 +370,40 @@ __global__ __launch_bounds__(256) void attn_flash_f32x_kernel(const AttnParams p
 // merge the key ranges: o[q][d] = sum_s w_s O_s[d][q] / sum_s w_s l_s,  w_s = 2^(m_s - max_s m_s).
 // Workgroup = (32-query tile, 32 columns of d); thread = (query, 4 d): 32 independent loads in flight per thread; the
 // 32 x 32 result goes through LDS so that rows leave as 128-byte pieces.
+// Round 5: the number of ranges is a template parameter.  With `ns` a run-time bound every load of the merge sat behind its own
+// `s < ns` branch and its own s_waitcnt (the listing: global_load_dword / s_waitcnt vmcnt(0), forty-eight times per thread — a
+// chain of dependent round trips that only the 1024 workgroups' parallelism kept at 8 us); now a thread's 2 NS statistics and
+// 4 NS partial values are each requested together.  Same arithmetic, same order.
+template <int NS>
 __global__ __launch_bounds__(256) void attn_combine_kernel(const float *__restrict__ ws_o, const float *__restrict__ ws_ml,
-                                                           float *__restrict__ out, int ldo, int n, int ns, int32_t *range_flag) {
+                                                           float *__restrict__ out, int ldo, int n, int32_t *range_flag) {
     __shared__ float tile[32][33];
     const int qt = blockIdx.x >> 3, dg = blockIdx.x & 7;
     const int q = threadIdx.x & 31, dsub = threadIdx.x >> 5;
-    float w[NSPLIT], M = -INFINITY, L = 0.f;         // ns <= NSPLIT key ranges (wavefront-uniform)
+    float w[NS], l[NS], o[NS][4], M = -INFINITY, L = 0.f;
 #pragma unroll
-    for (int s = 0; s < NSPLIT; ++s) {
-        w[s] = -INFINITY;
-        if (s < ns) {
-            const float *ml = ws_ml + ((int64_t)s * n + qt * 32 + q) * 2;
-            w[s] = ml[0];
-            M = fmaxf(M, w[s]);
-        }
+    for (int s = 0; s < NS; ++s) {
+        const float *ml = ws_ml + ((int64_t)s * n + qt * 32 + q) * 2;
+        w[s] = ml[0];
+        l[s] = ml[1];
     }
 #pragma unroll
-    for (int s = 0; s < NSPLIT; ++s)
-        if (s < ns) {
-            w[s] = __builtin_amdgcn_exp2f(w[s] - M);
-            L += w[s] * ws_ml[((int64_t)s * n + qt * 32 + q) * 2 + 1];
-        }
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[s][j] = ws_o[(((int64_t)s * (n / 32) + qt) * AD + dg * 32 + dsub * 4 + j) * 32 + q];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) M = fmaxf(M, w[s]);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        w[s] = __builtin_amdgcn_exp2f(w[s] - M);
+        L += w[s] * l[s];
+    }
     const float inv = 1.0f / L;            // O and l both carry the 2^10 lift of the probabilities
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < NSPLIT; ++s)
-        if (s < ns) {
+    for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[j] += w[s] * ws_o[(((int64_t)s * (n / 32) + qt) * AD + dg * 32 + dsub * 4 + j) * 32 + q];
-        }
+        for (int j = 0; j < 4; ++j) acc[j] += w[s] * o[s][j];
 #pragma unroll
     for (int j = 0; j < 4; ++j) tile[q][dsub * 4 + j] = acc[j] * inv;
     __syncthreads();
@@ -407,6 +411,173 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float *__restri
     const f32x4 v = {tile[r][c4], tile[r][c4 + 1], tile[r][c4 + 2], tile[r][c4 + 3]};
     *reinterpret_cast<f32x4 *>(out + (int64_t)(qt * 32 + r) * ldo + dg * 32 + c4) = v;
     if (range_flag && sgam_not_finite((v[0] + v[1]) + (v[2] + v[3]))) atomicOr(range_flag, 1);   // q, k or v left fp16's range
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// attn_combine + AttnBlock.proj_out (+ residual) in ONE launch (round 5; reference modules/diffusionmodules/model.py:187-191:
+// h_ = self.proj_out(h_); return x + h_).  The merge of the key ranges writes [n][C] (4 MB at n = 4096) that the 1x1 convolution
+// reads back one dependent launch later: two fixed costs of a B = 1 frame (a ~1.6 us graph edge + a kernel that is a chain of
+// round trips) for 0.5 GFLOP.  Here a workgroup owns one 32-query tile: it merges the ranges of its tile exactly as
+// attn_combine_kernel does (same weights, same order of the fused multiply-adds, same final product with 1 / L), splits the
+// result into fp16 hi / lo halves on its way into LDS — the A panel of the projection, 32 x 256 — and multiplies it with the
+// fragment-ordered weights of proj_out (four wavefronts side by side, 64 output channels each; weights four k-steps ahead), adds
+// bias and residual and leaves the GroupNorm statistics of the block output (one chunk per 32-row tile).
+// ---------------------------------------------------------------------------------------------------------------------
+struct CombProjParams {
+    const float *ws_o, *ws_ml;      // partial O^T [ns][n / 32][AD][32] and {max, sum} [ns][n][2] of the flash kernel
+    const unsigned short *w;        // proj_out weights, fragment-ordered hi / lo planes [AD / 32][AD / 32][256 pieces][8 halfs]
+    const float *bias, *res;        // [AD]; residual [n][ldr] (the block's input x) or NULL
+    float *out;                     // [n][ldc]
+    double *gn_partial;             // optional [n / 32][32][2]: {sum, sumsq} of the output per (32-row tile, group of 8 channels) ...
+    int gn_acc, n_img;              // ... or (gn_acc) the [B][16][32][4] int64 accumulator record of sgam_common.h; tokens per image
+    int32_t *range_flag;
+    int n, ns, ldr, ldc;
+    float inv_w_scale;
+};
+
+template <int NS>
+__global__ __launch_bounds__(256) void attn_combine_proj_f32x_kernel(const CombProjParams p) {
+    constexpr int LDK = AD + 8;                                      // LDS row pitch in halfs (rows 4 banks apart, 16-byte aligned)
+    __shared__ __attribute__((aligned(16))) unsigned short sA[2][32][LDK];       // hi plane, lo plane of the merged 32 x 256 tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qt = blockIdx.x;
+    const int lr = lane & 31, lh = lane >> 5;
+    constexpr int WD = 4, KS = AD / 16, SLABS = AD / 32;
+    // weight fragments of (32-column tile nt, k-step t): pieces ((plane * 2 + t % 2) * 2 + lh) * 32 + lr of slab t / 2
+    const unsigned short *wt0 = p.w + (int64_t)(wave * 2) * SLABS * 2048, *wt1 = wt0 + (int64_t)SLABS * 2048;
+    u32x4 wh[WD][2], wl[WD][2];
+    auto wfrag = [&](int kstep, u32x4 (&hi)[2], u32x4 (&lo)[2]) {
+        const int off = (kstep >> 1) * 2048 + (((kstep & 1) * 2 + lh) * 32 + lr) * 8;
+        hi[0] = *reinterpret_cast<const u32x4 *>(wt0 + off);
+        lo[0] = *reinterpret_cast<const u32x4 *>(wt0 + off + 1024);
+        hi[1] = *reinterpret_cast<const u32x4 *>(wt1 + off);
+        lo[1] = *reinterpret_cast<const u32x4 *>(wt1 + off + 1024);
+    };
+    // ---- merge of the key ranges: thread = (query q, channel group dg of 32): weights as attn_combine_kernel
+    const int q = tid & 31, dg = tid >> 5;
+    float w[NS], l[NS], M = -INFINITY, L = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        w[s] = p.ws_ml[((int64_t)s * p.n + qt * 32 + q) * 2];
+        l[s] = p.ws_ml[((int64_t)s * p.n + qt * 32 + q) * 2 + 1];
+    }
+    const float *ob = p.ws_o + ((int64_t)qt * AD + dg * 32) * 32 + q;          // + s * n * AD, + d * 32
+    const int64_t sstride = (int64_t)p.n * AD;
+    // CPS channels per step with ALL ranges' loads of the step in flight (CPS NS registers: 128 at eight ranges), two steps = two trips
+    // to memory per thread.  (128 workgroups merge what attn_combine_kernel spreads over 1024: the memory-level parallelism has to
+    // come from loads in flight per thread — four channels per step with the next step requested ahead measured 21.8 us for this
+    // kernel, eight 17.4.)
+    constexpr int CPS = NS >= 8 ? 16 : 32, NSTEP = 32 / CPS;
+    for (int s = 0; s < NS; ++s) M = fmaxf(M, w[s]);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        w[s] = __builtin_amdgcn_exp2f(w[s] - M);
+        L += w[s] * l[s];
+    }
+    const float inv = 1.0f / L;
+    bool bad = false;
+#pragma unroll
+    for (int step = 0; step < NSTEP; ++step) {
+        float cur[CPS][NS];
+#pragma unroll
+        for (int j = 0; j < CPS; ++j)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) cur[j][s] = ob[s * sstride + (step * CPS + j) * 32];
+        float a[CPS];
+#pragma unroll
+        for (int j = 0; j < CPS; ++j) a[j] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int j = 0; j < CPS; ++j) a[j] += w[s] * cur[j][s];
+#pragma unroll
+        for (int h4 = 0; h4 < CPS / 4; ++h4) {
+            unsigned hi[2], lo[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float a0 = a[4 * h4 + 2 * e] * inv, a1 = a[4 * h4 + 2 * e + 1] * inv;
+                bad |= sgam_not_finite(a0 + a1);
+                const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
+                const _Float16 l0 = (_Float16)(a0 - (float)h0), l1 = (_Float16)(a1 - (float)h1);
+                hi[e] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+                lo[e] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+            }
+            const int d = dg * 32 + step * CPS + 4 * h4;
+            *reinterpret_cast<u32x2 *>(&sA[0][q][d]) = u32x2{hi[0], hi[1]};
+            *reinterpret_cast<u32x2 *>(&sA[1][q][d]) = u32x2{lo[0], lo[1]};
+        }
+    }
+    if (bad && p.range_flag) atomicOr(p.range_flag, 1);                // q, k or v left fp16's range (what attn_combine_kernel reports)
+#pragma unroll
+    for (int t = 0; t < WD; ++t) wfrag(t, wh[t], wl[t]);               // (behind the merge: its registers are the merge's loads in flight)
+    // the residual rows and the bias of this lane's outputs, requested under the projection's MFMAs instead of in the epilogue
+    const int m0 = qt * 32;
+    float rres[2][16], rbias[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int nn = wave * 64 + j * 32 + lr;
+        rbias[j] = p.bias ? p.bias[nn] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) rres[j][e] = p.res ? p.res[(int64_t)(m0 + 8 * (e >> 2) + 4 * lh + (e & 3)) * p.ldr + nn] : 0.f;
+    }
+    __syncthreads();
+    // ---- out tile = merged . Wp^T: 16 k-steps, A fragments from LDS (row lr, k = 16 t + 8 lh + 0..7), weights WD steps ahead
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+#pragma unroll
+    for (int t = 0; t < KS; ++t) {
+        u32x4 bh[2] = {wh[t % WD][0], wh[t % WD][1]}, bl[2] = {wl[t % WD][0], wl[t % WD][1]};
+        wfrag(t + WD < KS ? t + WD : KS - 1, wh[t % WD], wl[t % WD]);
+        __builtin_amdgcn_sched_barrier(0);                                 // (keeps the request in front of this step's MFMAs: gemm_gn_f32x.hip)
+        const u32x4 ah = *reinterpret_cast<const u32x4 *>(&sA[0][lr][t * 16 + lh * 8]);
+        const u32x4 al = *reinterpret_cast<const u32x4 *>(&sA[1][lr][t * 16 + lh * 8]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            acc[j] = mfma16(ah, bh[j], acc[j]);
+            acc[j] = mfma16(ah, bl[j], acc[j]);
+            acc[j] = mfma16(al, bh[j], acc[j]);
+        }
+    }
+    // ---- epilogue: lane = column, rows 8 (e / 4) + 4 lh + e % 4 of the 32-row tile; a half-wave writes 128 B of a row
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int nn = wave * 64 + j * 32 + lr;
+        const float bias = rbias[j];
+        float gs = 0.f, gss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = m0 + 8 * (e >> 2) + 4 * lh + (e & 3);
+            float v = acc[j][e] * p.inv_w_scale + bias;
+            v += rres[j][e];
+            p.out[(int64_t)row * p.ldc + nn] = v;
+            gs += v;
+            gss += v * v;
+        }
+        if (p.range_flag && sgam_not_finite(gs)) atomicOr(p.range_flag, 1);
+        if (p.gn_partial) {
+            constexpr int CPO = AD / 32;                               // 8 adjacent columns are one group of the next GroupNorm
+            double ds = (double)gs, dss = (double)gss;
+#pragma unroll
+            for (int o = 1; o < CPO; o <<= 1) {
+                ds += __shfl_xor(ds, o, 64);
+                dss += __shfl_xor(dss, o, 64);
+            }
+            ds += __shfl_xor(ds, 32, 64);
+            dss += __shfl_xor(dss, 32, 64);
+            if (lh == 0 && (lr % CPO) == 0) {
+                if (p.gn_acc) {
+                    sgam_stats_acc_add(reinterpret_cast<long long *>(p.gn_partial), m0 / p.n_img, blockIdx.x, nn / CPO, ds, dss);
+                } else {
+                    double *o = p.gn_partial + ((int64_t)qt * 32 + nn / CPO) * 2;
+                    o[0] = ds;
+                    o[1] = dss;
+                }
+            }
+        }
+    }
 }
 
 // =====================================================================================================================
@@ -575,36 +746,36 @@ __global__ __launch_bounds__(256, 2) void attn_flash_h16_kernel(const AttnHParam
 }
 
 // merge of the key ranges for the 16-bit variant: as attn_combine_kernel, output rounded to 16 bits
-template <int HT>
+template <int HT, int NS>
 __global__ __launch_bounds__(256) void attn_combine_h16_kernel(const float *__restrict__ ws_o, const float *__restrict__ ws_ml,
-                                                               unsigned short *__restrict__ out, int ldo, int n, int ns) {
+                                                               unsigned short *__restrict__ out, int ldo, int n) {
     __shared__ float tile[32][33];
     const int qt = blockIdx.x >> 3, dg = blockIdx.x & 7;
     const int q = threadIdx.x & 31, dsub = threadIdx.x >> 5;
-    float w[NSPLIT], M = -INFINITY, L = 0.f;
+    float w[NS], l[NS], o[NS][4], M = -INFINITY, L = 0.f;
 #pragma unroll
-    for (int s = 0; s < NSPLIT; ++s) {
-        w[s] = -INFINITY;
-        if (s < ns) {
-            w[s] = ws_ml[((int64_t)s * n + qt * 32 + q) * 2];
-            M = fmaxf(M, w[s]);
-        }
+    for (int s = 0; s < NS; ++s) {
+        const float *ml = ws_ml + ((int64_t)s * n + qt * 32 + q) * 2;
+        w[s] = ml[0];
+        l[s] = ml[1];
     }
 #pragma unroll
-    for (int s = 0; s < NSPLIT; ++s)
-        if (s < ns) {
-            w[s] = __builtin_amdgcn_exp2f(w[s] - M);
-            L += w[s] * ws_ml[((int64_t)s * n + qt * 32 + q) * 2 + 1];
-        }
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[s][j] = ws_o[(((int64_t)s * (n / 32) + qt) * AD + dg * 32 + dsub * 4 + j) * 32 + q];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) M = fmaxf(M, w[s]);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        w[s] = __builtin_amdgcn_exp2f(w[s] - M);
+        L += w[s] * l[s];
+    }
     const float inv = 1.0f / L;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < NSPLIT; ++s)
-        if (s < ns) {
+    for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[j] += w[s] * ws_o[(((int64_t)s * (n / 32) + qt) * AD + dg * 32 + dsub * 4 + j) * 32 + q];
-        }
+        for (int j = 0; j < 4; ++j) acc[j] += w[s] * o[s][j];
 #pragma unroll
     for (int j = 0; j < 4; ++j) tile[q][dsub * 4 + j] = acc[j] * inv;
     __syncthreads();
@@ -664,7 +835,13 @@ extern "C" int sgam_attention_f32x_batched(const float *q, const float *k, const
     if (sgam_i_prof_on) sgam_i_prof_work(4.0 * B * n * (double)n * AD, 4.0 * 4.0 * nt * AD);   // q k^T + P v; q, k, v, o once
     SGAM_KLAUNCH(attn_flash_f32x_kernel, dim3(nt / 128 * nsplit), dim3(256), 0, s, p);
     SGAM_LAUNCH_CHECK();
-    SGAM_KLAUNCH(attn_combine_kernel, dim3(nt / 32 * 8), dim3(256), 0, s, ws_o, ws_ml, out, ldo, nt, nsplit, sgam_i_range_flag);
+    switch (nsplit) {                         // (the number of ranges is a template argument of the merge: all its loads in flight)
+        case 8: SGAM_KLAUNCH(attn_combine_kernel<8>, dim3(nt / 32 * 8), dim3(256), 0, s, ws_o, ws_ml, out, ldo, nt, sgam_i_range_flag); break;
+        case 4: SGAM_KLAUNCH(attn_combine_kernel<4>, dim3(nt / 32 * 8), dim3(256), 0, s, ws_o, ws_ml, out, ldo, nt, sgam_i_range_flag); break;
+        case 2: SGAM_KLAUNCH(attn_combine_kernel<2>, dim3(nt / 32 * 8), dim3(256), 0, s, ws_o, ws_ml, out, ldo, nt, sgam_i_range_flag); break;
+        case 1: SGAM_KLAUNCH(attn_combine_kernel<1>, dim3(nt / 32 * 8), dim3(256), 0, s, ws_o, ws_ml, out, ldo, nt, sgam_i_range_flag); break;
+        default: return SGAM_EINVAL;
+    }
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
 }
@@ -673,6 +850,57 @@ extern "C" int sgam_attention_f32x(const float *q, const float *k, const float *
                                    float scale, float *out, int32_t ldo, void *workspace, int64_t workspace_bytes,
                                    void *stream) {
     return sgam_attention_f32x_batched(q, k, v, ld, n, C, 1, scale, out, ldo, workspace, workspace_bytes, stream);
+}
+
+// sgam_attention_f32x_batched + AttnBlock.proj_out (+ residual) with the merge of the key ranges fused into the projection
+// (attn_combine_proj_f32x_kernel): out[B n][ldc] = residual + bias + softmax(q k^T scale) v . Wp^T.  w_planes: proj_out's weights as
+// sgam_split_rows_f32x lays them out (fragment-ordered hi / lo planes, [C][C]), w_scale their power-of-two scale.  gn_partial
+// (optional): [B][n / 32][32][2] fp64 {sum, sumsq} of `out` per (32-row tile, group of C / 32 channels) — or, with gn_acc, the zeroed
+// [B][16][32][4] int64 accumulator record of sgam_conv_desc.stats_acc.  Same workspace as sgam_attention_f32x_batched.
+extern "C" int sgam_attention_proj_f32x_batched(const float *q, const float *k, const float *v, int32_t ld, int32_t n, int32_t C,
+                                                int32_t B, float scale, const void *w_planes, float w_scale, const float *bias,
+                                                const float *residual, int32_t ldr, float *out, int32_t ldc, double *gn_partial,
+                                                int32_t gn_acc, void *workspace, int64_t workspace_bytes, void *stream) {
+    if (!q || !k || !v || !out || !workspace || !w_planes || !(w_scale > 0.f)) return SGAM_EINVAL;
+    const int64_t need = sgam_attention_f32x_batched_workspace_bytes(n, C, B);
+    if (need < 0 || ld < C || ld % 4 != 0 || ldc < C || (residual && ldr < C)) return SGAM_EINVAL;
+    int ex;
+    if (!(scale > 0.f) || frexpf(scale, &ex) != 0.5f) return SGAM_EINVAL;   // folded into q: must be an exact power of two
+    if (workspace_bytes < need) return SGAM_EWORKSPACE;
+    if (!sgam_aligned16(q) || !sgam_aligned16(k) || !sgam_aligned16(v) || !sgam_aligned16(workspace) || !sgam_aligned16(w_planes) ||
+        (gn_partial && !sgam_aligned16(gn_partial)))
+        return SGAM_EALIGN;
+    const int nsplit = attn_nsplit(n, B), nt = B * n;
+    if ((n / KB) % nsplit != 0) return SGAM_EINVAL;
+    hipStream_t s = sgam_stream(stream);
+    unsigned short *kf = (unsigned short *)workspace;
+    unsigned short *vf = kf + (int64_t)nt * AD * 2;
+    float *ws_o = (float *)(vf + (int64_t)nt * AD * 2);
+    float *ws_ml = ws_o + (int64_t)nsplit * nt * AD;
+    SGAM_KLAUNCH(attn_split_kv_kernel, dim3(nt / KB * 8 * 128 / 256), dim3(256), 0, s, k, v, ld, nt, kf, vf);
+    SGAM_LAUNCH_CHECK();
+    AttnParams p;
+    p.q = q; p.kf = kf; p.vf = vf; p.ws_o = ws_o; p.ws_ml = ws_ml;
+    p.ld = ld; p.n = nt; p.n_img = n; p.nsplit = nsplit; p.blocks_per_split = n / KB / nsplit; p.qscale = scale;
+    if (sgam_i_prof_on) sgam_i_prof_work(4.0 * B * n * (double)n * AD, 4.0 * 4.0 * nt * AD);
+    SGAM_KLAUNCH(attn_flash_f32x_kernel, dim3(nt / 128 * nsplit), dim3(256), 0, s, p);
+    SGAM_LAUNCH_CHECK();
+    CombProjParams c;
+    c.ws_o = ws_o; c.ws_ml = ws_ml; c.w = (const unsigned short *)w_planes; c.bias = bias; c.res = residual; c.out = out;
+    c.gn_partial = gn_partial; c.gn_acc = (gn_partial && gn_acc) ? 1 : 0; c.n_img = n;
+    c.range_flag = sgam_i_range_flag; c.n = nt; c.ns = nsplit; c.ldr = ldr; c.ldc = ldc;
+    c.inv_w_scale = 1.0f / w_scale;
+    if (sgam_i_prof_on) sgam_i_prof_shape(nt, AD, AD, 1);
+    if (sgam_i_prof_on) sgam_i_prof_work(2.0 * nt * (double)AD * AD, 4.0 * ((double)nsplit * nt * AD + 2.0 * nt * AD + (double)AD * AD));
+    switch (nsplit) {
+        case 8: SGAM_KLAUNCH(attn_combine_proj_f32x_kernel<8>, dim3(nt / 32), dim3(256), 0, s, c); break;
+        case 4: SGAM_KLAUNCH(attn_combine_proj_f32x_kernel<4>, dim3(nt / 32), dim3(256), 0, s, c); break;
+        case 2: SGAM_KLAUNCH(attn_combine_proj_f32x_kernel<2>, dim3(nt / 32), dim3(256), 0, s, c); break;
+        case 1: SGAM_KLAUNCH(attn_combine_proj_f32x_kernel<1>, dim3(nt / 32), dim3(256), 0, s, c); break;
+        default: return SGAM_EINVAL;
+    }
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
 }
 
 extern "C" int64_t sgam_attention_h16_batched_workspace_bytes(int32_t n, int32_t C, int32_t B) {
@@ -708,15 +936,22 @@ extern "C" int sgam_attention_h16_batched(const void *q, const void *k, const vo
     p.ld = ld; p.n = nt; p.n_img = n; p.nsplit = nsplit; p.blocks_per_split = n / KB / nsplit; p.qscale_log2e = scale * LOG2E;
     const dim3 grid(nt / 128 * nsplit), cgrid(nt / 32 * 8);
     if (sgam_i_prof_on) sgam_i_prof_work(4.0 * B * n * (double)n * AD, 4.0 * 2.0 * nt * AD);
-    if (ht == 0) {
-        SGAM_KLAUNCH(attn_flash_h16_kernel<0>, grid, dim3(256), 0, s, p);
-        SGAM_LAUNCH_CHECK();
-        SGAM_KLAUNCH(attn_combine_h16_kernel<0>, cgrid, dim3(256), 0, s, ws_o, ws_ml, (unsigned short *)out, ldo, nt, nsplit);
-    } else {
-        SGAM_KLAUNCH(attn_flash_h16_kernel<1>, grid, dim3(256), 0, s, p);
-        SGAM_LAUNCH_CHECK();
-        SGAM_KLAUNCH(attn_combine_h16_kernel<1>, cgrid, dim3(256), 0, s, ws_o, ws_ml, (unsigned short *)out, ldo, nt, nsplit);
+    if (ht == 0) SGAM_KLAUNCH(attn_flash_h16_kernel<0>, grid, dim3(256), 0, s, p);
+    else SGAM_KLAUNCH(attn_flash_h16_kernel<1>, grid, dim3(256), 0, s, p);
+    SGAM_LAUNCH_CHECK();
+#define HCOMBINE(HT_, NS_) SGAM_KLAUNCH((attn_combine_h16_kernel<HT_, NS_>), cgrid, dim3(256), 0, s, ws_o, ws_ml, (unsigned short *)out, ldo, nt)
+    switch (nsplit * 2 + (ht ? 1 : 0)) {
+        case 16: HCOMBINE(0, 8); break;
+        case 17: HCOMBINE(1, 8); break;
+        case 8: HCOMBINE(0, 4); break;
+        case 9: HCOMBINE(1, 4); break;
+        case 4: HCOMBINE(0, 2); break;
+        case 5: HCOMBINE(1, 2); break;
+        case 2: HCOMBINE(0, 1); break;
+        case 3: HCOMBINE(1, 1); break;
+        default: return SGAM_EINVAL;
     }
+#undef HCOMBINE
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
 }

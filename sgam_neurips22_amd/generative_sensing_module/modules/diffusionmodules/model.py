@@ -219,6 +219,12 @@ class AttnBlock(_NHWCModule):
             # a batch (lock-stepped scenes, warp candidates) is ONE launch sequence: the images are stacked along the rows of
             # the q | k | v projection, the fused attention keeps every query inside its image, and proj_out runs as the 1x1
             # convolution it is (per-image GroupNorm statistics of the block output from its epilogue)
+            if ops.ATTN_PROJ and isinstance(wp, ops.SplitWeight):
+                ob = ops.attention_proj(qkv_all, C, scale, wp, bp, x.reshape(B * n, C), B=B)
+                out = ob.view(B, H, W, C)
+                if hasattr(ob, "_gn_partials"):
+                    out._gn_partials = ob._gn_partials       # per-image chunk statistics of the block output
+                return out
             o = ops.attention(qkv_all, C, scale, B=B)
             return self.proj_out.forward_nhwc(o.view(B, H, W, C), residual=x)
         if B > 1 and fused_qkv and B * n <= BLOCKDIAG_MAX_ROWS and n % 4 == 0:
@@ -235,6 +241,12 @@ class AttnBlock(_NHWCModule):
             xb = x[b].reshape(n, C)
             qkv = qkv_all[b * n:(b + 1) * n] if fused_qkv else ops.gemm_nt(
                 h[b].reshape(n, C), wqkv, bias=bqkv, gn=None if table is None else (table[b:b + 1], False))   # (n, 3C)
+            if ops.F32_MODE == "split" and ops.attention_fusable(n, C) and ops.ATTN_PROJ and isinstance(wp, ops.SplitWeight):
+                # one pass over the keys AND proj_out + residual: the merge of the key ranges is the projection's operand staging
+                ob = ops.attention_proj(qkv, C, scale, wp, bp, xb, out=out[b].reshape(n, C))
+                if B == 1 and hasattr(ob, "_gn_partials"):
+                    out._gn_partials = ob._gn_partials
+                continue
             if ops.F32_MODE == "split" and ops.attention_fusable(n, C):
                 o = ops.attention(qkv, C, scale)                           # one pass over the keys, no (n, n) scores
             else:

@@ -796,6 +796,44 @@ def attention(qkv, C, scale, out=None, B=1):
     return out
 
 
+# AttnBlock.proj_out inside the attention call (csrc/attention.hip: attn_combine_proj_f32x_kernel): the merge of the key ranges becomes
+# the operand staging of the projection — one launch and a [n][C] round trip fewer per block.  SGAM_ATTN_PROJ=0: separate launches.
+ATTN_PROJ = os.environ.get("SGAM_ATTN_PROJ", "1") == "1"
+
+
+def attention_proj(qkv, C, scale, wp, bias, residual, out=None, B=1):
+    """`attention` followed by proj_out (+ bias, + residual) as one launch sequence: qkv (B * n, 3C) fp32, wp the SplitWeight of
+    proj_out's (C, C) weight, residual / out (B * n, C).  The result carries the GroupNorm chunk statistics of the block output
+    (`_gn_partials`, one chunk per 32-row tile) like every convolution's."""
+    _need_cuda(qkv)
+    nt = qkv.shape[0]
+    assert qkv.dtype == torch.float32 and qkv.shape[1] == 3 * C and qkv.stride(1) == 1 and nt % B == 0
+    assert isinstance(wp, SplitWeight)
+    n = nt // B
+    lib = _lib.load()
+    ws_bytes = lib.sgam_attention_f32x_batched_workspace_bytes(n, C, B)
+    if ws_bytes < 0:
+        raise SgamHipError(f"sgam_attention_proj_f32x: unsupported shape n={n} C={C} B={B}")
+    ws = torch.empty((ws_bytes,), device=qkv.device, dtype=torch.uint8)
+    if out is None:
+        out = torch.empty((nt, C), device=qkv.device, dtype=torch.float32)
+    assert out.stride(1) == 1 and (residual is None or (residual.stride(1) == 1 and residual.dtype == torch.float32))
+    chunks, partial, acc = n // 32, None, 0
+    if FUSE_GN_STATS:
+        rec = _ARENA.take(B) if _ARENA is not None else None              # accumulator form while a statistics arena is active
+        if rec is not None:
+            partial, chunks, acc = rec, 0, 1
+        else:
+            partial = torch.empty((B * chunks * 32 * 2,), device=qkv.device, dtype=torch.float64)
+    check(lib.sgam_attention_proj_f32x_batched(_p(qkv), _p(qkv[:, C:]), _p(qkv[:, 2 * C:]), qkv.stride(0), n, C, B, float(scale),
+                                               _p(wp.planes), float(wp.scale), _p(bias), _p(residual),
+                                               residual.stride(0) if residual is not None else 0, _p(out), out.stride(0), _p(partial),
+                                               acc, _p(ws), ws_bytes, _stream()), "sgam_attention_proj_f32x_batched")
+    if partial is not None:
+        out._gn_partials = (partial, chunks)
+    return out
+
+
 def attention_h16(qkv, C, scale, out=None, B=1):
     """16-bit throughput variant of `attention` (qkv bf16 / fp16, result in the same dtype)."""
     _need_cuda(qkv)

@@ -453,6 +453,37 @@ def test_fused_attention_at_the_512sq_size():
     _close(o[rows], ref, 2e-5, "fused attention, n = 16384")
 
 
+@pytest.mark.parametrize("B,n", [(1, 4096), (1, 1024), (2, 4096), (8, 256)])
+def test_attention_with_fused_projection_matches_the_separate_launches(B, n):
+    """sgam_attention_proj_f32x_batched (ABI v8): the merge of the key ranges as the operand staging of proj_out + residual, against
+    `attention` followed by the 1x1 convolution it replaces (same merge arithmetic, a different order of the K = 256 MFMA chain:
+    fp32 round-off), against fp64, run-to-run identical, and the chunk statistics it leaves against the sums of what it wrote."""
+    C = 256
+    scale = C ** -0.5
+    qkv = testing.seeded_tensor(f"attnP.{B}.{n}", (B * n, 3 * C)).to(DEV)
+    x = testing.seeded_tensor(f"attnP.x.{B}.{n}", (B * n, C)).to(DEV)
+    w = (testing.seeded_tensor("attnP.w", (C, C)) * 0.06).to(DEV)
+    bias = testing.seeded_tensor("attnP.b", (C,)).to(DEV)
+    wp = ops.split_rows(w, ops._pow2_scale(float(w.abs().max())))
+    got = ops.attention_proj(qkv, C, scale, wp, bias, x, B=B)
+    o = ops.attention(qkv, C, scale, B=B)
+    sep = ops.gemm_nt(o, wp, bias=bias, residual=x)
+    _close(got, sep, 2e-6, "fused projection vs separate launches")
+    ref = o.double() @ w.double().t() + bias.double() + x.double()
+    _close(got, ref, 2e-5, "fused projection vs fp64 product of the attention output")
+    for _ in range(5):
+        assert torch.equal(got, ops.attention_proj(qkv, C, scale, wp, bias, x, B=B))
+    part, chunks = got._gn_partials
+    assert chunks == n // 32
+    st = part.view(B * chunks, 32, 2)
+    blk = got.double().view(B * chunks, 32, 32, C // 32)                     # (tile, row, group, channel in group)
+    assert torch.allclose(st[..., 0], blk.sum(dim=(1, 3)), rtol=1e-6, atol=1e-4)
+    assert torch.allclose(st[..., 1], (blk * blk).sum(dim=(1, 3)), rtol=1e-6, atol=1e-4)
+    # without a residual / bias
+    got0 = ops.attention_proj(qkv, C, scale, wp, None, None, B=B)
+    _close(got0, o.double() @ w.double().t(), 2e-5, "fused projection, no bias / residual")
+
+
 @pytest.mark.parametrize("B,n,dt", [(2, 4096, "f32"), (4, 4096, "f32"), (8, 4096, "f32"), (3, 1024, "f32"), (8, 256, "f32"),
                                     (4, 4096, "fp16"), (8, 4096, "bf16")])
 def test_batched_attention_keeps_every_query_inside_its_image(B, n, dt):
