@@ -28,7 +28,8 @@ SOURCES = {
                       f"-DSGAM_XPEEL={os.environ.get('SGAM_XPEEL', '1')}",
                       f"-DSGAM_XLB64={os.environ.get('SGAM_XLB64', '2')}",
                       f"-DSGAM_XNBR64={os.environ.get('SGAM_XNBR64', '6')}",
-                      f"-DSGAM_XRWARM={os.environ.get('SGAM_XRWARM', '0')}"],
+                      f"-DSGAM_XRWARM={os.environ.get('SGAM_XRWARM', '0')}",
+                      f"-DSGAM_XFIX_LF={os.environ.get('SGAM_XFIX_LF', '32')}"],
     "h16_halo.hip": [f"-DSGAM_HABLATE={os.environ.get('SGAM_HABLATE', '0')}",
                      f"-DSGAM_HDIRECT={os.environ.get('SGAM_HDIRECT', '1')}",
                      f"-DSGAM_HWGM={os.environ.get('SGAM_HWGM', '1')}",

@@ -738,52 +738,81 @@ __global__ __launch_bounds__(256, 2) void attn_flash_h16_kernel(const AttnHParam
         ml[0] = m_run;
         ml[1] = l_run;
     }
-    float *wo = p.ws_o + ((int64_t)sp * (p.n / 32) + (q0 >> 5)) * (AD * 32) + lq;
+    // The partial output of a key range leaves NORMALISED (o / l: a convex combination of 16-bit v rows, so |o / l| <= max |v|), as
+    // fp16 and ROW-MAJOR [range][query][256]: 2 bytes per element instead of the 4 of the un-normalised fp32 sums (round 5: 56 MB
+    // of HBM traffic per launch against 8.4 MB algorithmic was the write and re-read of 8 x 4 MB of fp32 partials).  A lane holds
+    // 4 consecutive channels of ONE query per accumulator quad, so the tile goes through the (now idle) K / V buffers — each
+    // wavefront its own 16 KB, 16-byte units XOR-swizzled by the row — and leaves as whole 512-byte rows, two per store
+    // instruction (the first form of this epilogue stored 2 bytes per lane straight from the accumulators: half-line writes, the
+    // kernel got 2 us SLOWER than with twice the bytes).  fp16's 11 bits are finer than the bf16 output and equal to the fp16
+    // output's own rounding; the merge weighs range s by l_s 2^(m_s - M).  (bf16 inputs beyond fp16's range would saturate at
+    // +-65504 here; activations behind a GroupNorm and a 1 x 1 projection are five orders below.)
+    const float inv_l = 1.0f / l_run;
+    unsigned char *tw = smem + wave * HBLK_BYTES;          // (every wavefront passed the loop's last barrier: the buffers are free)
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) wo[(32 * i + 8 * (e >> 2) + 4 * lh + (e & 3)) * 32] = o[i][e];
+        for (int j = 0; j < 4; ++j) {
+            unsigned pk[2];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const float a0 = __builtin_amdgcn_fmed3f(o[i][4 * j + 2 * h2] * inv_l, -65504.f, 65504.f);
+                const float a1 = __builtin_amdgcn_fmed3f(o[i][4 * j + 2 * h2 + 1] * inv_l, -65504.f, 65504.f);
+                pk[h2] = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)a0) |
+                         ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)a1) << 16);
+            }
+            // channels 32 i + 8 j + 4 lh + 0..3 of query lq: 16-byte unit 4 i + j (swizzled), half lh
+            *reinterpret_cast<u32x2 *>(tw + lq * 512 + (((4 * i + j) ^ lq) << 4) + lh * 8) = u32x2{pk[0], pk[1]};
+        }
+    // (wave-private region, but the reads below cross lanes: LDS operations of one wavefront complete in order)
+    unsigned short *wo = reinterpret_cast<unsigned short *>(p.ws_o) + ((int64_t)sp * p.n + q0) * AD;
+#pragma unroll
+    for (int r2 = 0; r2 < 16; ++r2) {
+        const int row = 2 * r2 + lh;
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(tw + row * 512 + ((lq ^ row) << 4));
+        *reinterpret_cast<u32x4 *>(wo + (int64_t)row * AD + lq * 8) = v;
+    }
 }
 
-// merge of the key ranges for the 16-bit variant: as attn_combine_kernel, output rounded to 16 bits
+// merge of the key ranges for the 16-bit variant: the flash kernel left NORMALISED fp16 partials o_s / l_s, row-major
+// [range][query][256], so range s weighs l_s 2^(m_s - M) / sum of those; thread = (query row, 4 channels) for loads and store alike;
+// output rounded to 16 bits
 template <int HT, int NS>
-__global__ __launch_bounds__(256) void attn_combine_h16_kernel(const float *__restrict__ ws_o, const float *__restrict__ ws_ml,
+__global__ __launch_bounds__(256) void attn_combine_h16_kernel(const float *__restrict__ ws_o_f, const float *__restrict__ ws_ml,
                                                                unsigned short *__restrict__ out, int ldo, int n) {
-    __shared__ float tile[32][33];
+    const unsigned short *ws_o = reinterpret_cast<const unsigned short *>(ws_o_f);
     const int qt = blockIdx.x >> 3, dg = blockIdx.x & 7;
-    const int q = threadIdx.x & 31, dsub = threadIdx.x >> 5;
-    float w[NS], l[NS], o[NS][4], M = -INFINITY, L = 0.f;
+    const int r = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
+    const int64_t row = (int64_t)qt * 32 + r;
+    float w[NS], M = -INFINITY, L = 0.f;
+    u32x2 o[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) o[s] = *reinterpret_cast<const u32x2 *>(ws_o + ((int64_t)s * n + row) * AD + dg * 32 + c4);
+    float l[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        const float *ml = ws_ml + ((int64_t)s * n + qt * 32 + q) * 2;
+        const float *ml = ws_ml + ((int64_t)s * n + row) * 2;
         w[s] = ml[0];
         l[s] = ml[1];
     }
 #pragma unroll
-    for (int s = 0; s < NS; ++s)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[s][j] = ws_o[(((int64_t)s * (n / 32) + qt) * AD + dg * 32 + dsub * 4 + j) * 32 + q];
-#pragma unroll
     for (int s = 0; s < NS; ++s) M = fmaxf(M, w[s]);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        w[s] = __builtin_amdgcn_exp2f(w[s] - M);
-        L += w[s] * l[s];
+        w[s] = __builtin_amdgcn_exp2f(w[s] - M) * l[s];
+        L += w[s];
     }
     const float inv = 1.0f / L;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < NS; ++s)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] += w[s] * o[s][j];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) tile[q][dsub * 4 + j] = acc[j] * inv;
-    __syncthreads();
-    const int r = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
-    unsigned short *dst = out + (int64_t)(qt * 32 + r) * ldo + dg * 32 + c4;
+        for (int j = 0; j < 4; ++j)
+            acc[j] += w[s] * (float)__builtin_bit_cast(_Float16, (unsigned short)((o[s][j >> 1] >> (16 * (j & 1))) & 0xffffu));
+    unsigned short *dst = out + row * ldo + dg * 32 + c4;
     u32x2 pk;
-    pk[0] = (unsigned)HM<HT>::from_f(tile[r][c4]) | ((unsigned)HM<HT>::from_f(tile[r][c4 + 1]) << 16);
-    pk[1] = (unsigned)HM<HT>::from_f(tile[r][c4 + 2]) | ((unsigned)HM<HT>::from_f(tile[r][c4 + 3]) << 16);
+    pk[0] = (unsigned)HM<HT>::from_f(acc[0] * inv) | ((unsigned)HM<HT>::from_f(acc[1] * inv) << 16);
+    pk[1] = (unsigned)HM<HT>::from_f(acc[2] * inv) | ((unsigned)HM<HT>::from_f(acc[3] * inv) << 16);
     *reinterpret_cast<u32x2 *>(dst) = pk;
 }
 

@@ -224,6 +224,9 @@ __device__ __forceinline__ void gn_scale_shift(const XParams &p, int b, int c, f
 #define SGAM_XFIX_FENCE 0
 #endif
 #define SGAM_XFIX_AUX (SGAM_XFIX_FENCE ? 0 : 16)
+#ifndef SGAM_XFIX_LF
+#define SGAM_XFIX_LF 32    // coherent partial-tile loads a thread of the last arriver keeps in flight (0: the four-at-a-time form of round 4)
+#endif
 template <int BM, int BN, class RowMap>
 __device__ __forceinline__ void xfixup(const XParams &p, float *smem_f, int bx, int n0, RowMap rowmap) {
     constexpr int C4T = BN / 4, RPT = 256 / C4T, PASSES = BM / RPT;
@@ -253,24 +256,9 @@ __device__ __forceinline__ void xfixup(const XParams &p, float *smem_f, int bx, 
     if (p.bias && !p.bias_per_row && n4 < p.n_valid) bv = *reinterpret_cast<const f32x4 *>(p.bias + n4);
     float gs = 0.f, gss = 0.f;
     bool bad = false;
-#define XFIX_LD(z_) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, (int)wo, (int)((unsigned)(z_) * zb), SGAM_XFIX_AUX))
-#pragma unroll 2
-    for (int pass = 0; pass < PASSES; ++pass) {
-        const int m = rowmap(pass * RPT + r0);
-        const bool ok = m < p.M && n4 < p.n_valid;
-        const unsigned wo = xsel(ok, (unsigned)(m * p.N + n4) * 4u, OOB);
-        const f32x4 rv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                       rr, (int)xsel(ok, (unsigned)(m * p.ldr + n4) * 4u, OOB), 0, 0));
-        f32x4 s = XFIX_LD(0);
-        int z = 1;
-        for (; z + 4 <= p.ksplit; z += 4) {
-            const f32x4 a = XFIX_LD(z), b = XFIX_LD(z + 1), c = XFIX_LD(z + 2), d = XFIX_LD(z + 3);
-            s += a;
-            s += b;
-            s += c;
-            s += d;
-        }
-        for (; z < p.ksplit; ++z) s += XFIX_LD(z);
+#define XFIX_LD(wo_, z_) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, (int)(wo_), (int)((unsigned)(z_) * zb), SGAM_XFIX_AUX))
+    // finish one output row segment: un-scale, bias, residual, store, statistics (the order of every operation is the combine kernels')
+    auto finish = [&](int m, bool ok, const f32x4 &s, const f32x4 &rv) {
         f32x4 v;
         const float bm = (p.bias && p.bias_per_row && ok) ? p.bias[m] : 0.f;
 #pragma unroll
@@ -286,7 +274,66 @@ __device__ __forceinline__ void xfixup(const XParams &p, float *smem_f, int bx, 
             gss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
             bad |= sgam_not_finite(t4);
         }
+    };
+    // The last arriver is ONE workgroup reading ksplit x (BM x BN x 4) bytes through device-coherent loads, each a ~1 us round trip
+    // to the fabric: what decides its tail is how many of them a thread keeps in flight.  SGAM_XFIX_LF (32) loads = G rows x KS
+    // slabs are requested before the first is summed (128 registers, free here: the accumulators are dead); the sum of a row still
+    // runs z = 0, 1, 2 ... — bit-identical to the four-at-a-time form below (kept for split counts outside {2, 4, 8, 16}).
+    auto deep = [&](auto ks_c, auto g_c) {
+        constexpr int KS = decltype(ks_c)::value, G = decltype(g_c)::value;
+        static_assert(PASSES % G == 0, "row groups tile the passes");
+#pragma unroll 1
+        for (int pass0 = 0; pass0 < PASSES; pass0 += G) {
+            f32x4 part[G][KS], rv[G];
+            int mm[G];
+            bool okk[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                mm[g] = rowmap((pass0 + g) * RPT + r0);
+                okk[g] = mm[g] < p.M && n4 < p.n_valid;
+                const unsigned wo = xsel(okk[g], (unsigned)(mm[g] * p.N + n4) * 4u, OOB);
+#pragma unroll
+                for (int z = 0; z < KS; ++z) part[g][z] = XFIX_LD(wo, z);
+                rv[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                      rr, (int)xsel(okk[g], (unsigned)(mm[g] * p.ldr + n4) * 4u, OOB), 0, 0));
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                f32x4 s = part[g][0];
+#pragma unroll
+                for (int z = 1; z < KS; ++z) s += part[g][z];
+                finish(mm[g], okk[g], s, rv[g]);
+            }
+        }
+    };
+    constexpr int LF = SGAM_XFIX_LF;
+#define XFIX_DEEP(KS_) deep(std::integral_constant<int, KS_>{}, std::integral_constant<int, (LF / KS_ < PASSES ? (LF / KS_ < 1 ? 1 : LF / KS_) : PASSES)>{})
+    if (LF >= 8 && p.ksplit == 2) XFIX_DEEP(2);
+    else if (LF >= 8 && p.ksplit == 4) XFIX_DEEP(4);
+    else if (LF >= 8 && p.ksplit == 8) XFIX_DEEP(8);
+    else if (LF >= 16 && p.ksplit == 16) XFIX_DEEP(16);
+    else {
+#pragma unroll 2
+        for (int pass = 0; pass < PASSES; ++pass) {
+            const int m = rowmap(pass * RPT + r0);
+            const bool ok = m < p.M && n4 < p.n_valid;
+            const unsigned wo = xsel(ok, (unsigned)(m * p.N + n4) * 4u, OOB);
+            const f32x4 rv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                           rr, (int)xsel(ok, (unsigned)(m * p.ldr + n4) * 4u, OOB), 0, 0));
+            f32x4 s = XFIX_LD(wo, 0);
+            int z = 1;
+            for (; z + 4 <= p.ksplit; z += 4) {
+                const f32x4 a = XFIX_LD(wo, z), b = XFIX_LD(wo, z + 1), c = XFIX_LD(wo, z + 2), d = XFIX_LD(wo, z + 3);
+                s += a;
+                s += b;
+                s += c;
+                s += d;
+            }
+            for (; z < p.ksplit; ++z) s += XFIX_LD(wo, z);
+            finish(m, ok, s, rv);
+        }
     }
+#undef XFIX_DEEP
 #undef XFIX_LD
     if (bad && p.range_flag) atomicOr(p.range_flag, 1);
     if (tid == 0) __hip_atomic_store(p.arrive + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -314,7 +361,9 @@ __device__ __forceinline__ void xfixup(const XParams &p, float *smem_f, int bx, 
         const int hw = p.Ho * p.Wo, chunks_per_b = hw / BM;
         const int b = (bx * BM) / hw, cb = bx - b * chunks_per_b;
         if (p.gn_acc) {
-            sgam_stats_acc_add(reinterpret_cast<long long *>(p.gn_partial), b, blockIdx.x, n0 / p.gn_cpg + tid, ds, dss);
+            // replica by TILE, not by workgroup: which split arrives last changes from run to run, and with it blockIdx — the record
+            // would hold the same sums in different replicas (found by test_gpu_fixup under SGAM_XFIXUP=1 + SGAM_STATS_ACC=1)
+            sgam_stats_acc_add(reinterpret_cast<long long *>(p.gn_partial), b, (unsigned)tile, n0 / p.gn_cpg + tid, ds, dss);
         } else {
             double *o = p.gn_partial + (((int64_t)b * chunks_per_b + cb) * 32 + n0 / p.gn_cpg + tid) * 2;
             o[0] = ds;
@@ -1909,6 +1958,10 @@ static bool fixup_on(const sgam_conv_desc *d, const XPlan &pl) {
     if (!on || !d->arrive || pl.ksplit < 2 || pl.bm == 32 || pl.bm == 256) return false;
     const int64_t tiles = (int64_t)sgam_cdiv((int64_t)d->B * d->Ho * d->Wo, pl.bm) * sgam_cdiv(d->N, pl.bn);
     if (tiles > d->arrive_count) return false;
+    // SGAM_XFIXUP_MAXWG=n: only launches of <= n workgroups (one or two per CU: the register file is theirs, and the last arriver's
+    // tail is not hidden by other tiles anyway) take the fix-up; larger grids keep partial tiles + the combine launch.  0: no limit
+    static const int64_t maxwg = [] { const char *e = getenv("SGAM_XFIXUP_MAXWG"); return e ? (int64_t)atoll(e) : (int64_t)0; }();
+    if (maxwg > 0 && tiles * pl.ksplit > maxwg) return false;
     if ((int64_t)pl.ksplit * d->B * d->Ho * d->Wo * d->N * 4 >= (1ll << 32) - 64) return false;
     return fixup_stats_ok(d, pl) || stats_chunks_combine(d, pl) == 0;
 }

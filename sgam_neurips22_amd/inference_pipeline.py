@@ -124,9 +124,19 @@ class InfiniteSceneGeneration:
     def __init__(self, dynamic_model, data, topk=1, step_size_denom=2, use_rgbd_integration=False,
                  use_discriminator_loss=False, discriminator_loss_weight=0, recon_on_visible=False,
                  offscreen_rendering=True, output_dim=None, seed_index=0, num_src=None, seed_frame=None,
-                 templates_root="templates", tgt_depth_provider=None, image_resolution=(256, 256)):
+                 templates_root="templates", tgt_depth_provider=None, image_resolution=(256, 256),
+                 trajectory_shape="grid", grid_transform_path=None):
+        """`trajectory_shape` / `grid_transform_path` are this backend's spelling of what the reference hard-codes: its
+        constructor sets trajectory_shape = 'grid' (:67, :82) and fills `grid_res/<data>_seed<k>` with the seed frame, so its
+        'spiral' / 'cylinder' / 'trajectory' pose sets (:206-421) and the known-frame map (:144-155) are reachable only by
+        editing it.  Here they are arguments: the shape selects the pose set, and a `grid_transform_path` folder holding
+        `dm_<frame>_<ii>_<jj>.npy` + `im_<frame>_<ii>_<jj>.png` pairs (the layout export_to_disk writes — i.e. a previous run:
+        RESUME) marks those poses visited and loads them into the frame store as sources; 'trajectory' also reads
+        `cam0_to_world.txt` there."""
         if data not in _START:
             raise NotImplementedError(data)
+        if trajectory_shape not in ("grid", "spiral", "cylinder", "trajectory"):
+            raise NotImplementedError(trajectory_shape)
         self.dynamic_model, self.data, self.topk = dynamic_model, data, topk
         self.seed_index, self.step_size_denom = seed_index, step_size_denom
         self.use_rgbd_integration = use_rgbd_integration
@@ -139,7 +149,9 @@ class InfiniteSceneGeneration:
         default_src = 5 if data == "clevr-infinite" else 3
         self.num_src = (default_src if num_src is None else num_src) if is_vq else 1
         self.curr = 1
-        self.trajectory_shape = "grid"
+        self.trajectory_shape = trajectory_shape
+        self.grid_transform_path = None if grid_transform_path is None else Path(grid_transform_path)
+        self.anchor_poses = {}
         self.device = dynamic_model.device
         if seed_frame is None:
             if os.path.isdir(os.path.join(templates_root, data)):
@@ -150,9 +162,23 @@ class InfiniteSceneGeneration:
                               "template", RuntimeWarning)
                 seed_frame = synthetic_seed_frame(data, seed_index, self.image_resolution[0])
         self.frames = {}        # grid coord -> dict(rgb_f (H,W,3) fp32, depth (H,W) fp32, rgb_u8, index)
-        self.prepare_grid(self.output_dim)
-        self._ordered_grid_coords = self.zig_zag_order()
+        known_map = self.get_known_map()
+        if trajectory_shape == "grid":                      # reference :104-116
+            self.prepare_grid(self.output_dim, known_map)
+            self._ordered_grid_coords = self.zig_zag_order()
+        elif trajectory_shape == "spiral":
+            self.prepare_spiral(self.output_dim, known_map)
+            self._ordered_grid_coords = self.zig_zag_order()
+        elif trajectory_shape == "cylinder":
+            self.prepare_ring(self.output_dim, known_map, horizontal_offset=0.002)
+            self._ordered_grid_coords = self.zig_zag_order()
+        else:
+            if self.grid_transform_path is None:
+                raise ValueError("trajectory_shape='trajectory' reads <grid_transform_path>/cam0_to_world.txt")
+            self._ordered_grid_coords = self.prepare_trajectory(self.output_dim[0], known_map,
+                                                                pose_path=self.grid_transform_path / "cam0_to_world.txt")
         self._store_seed(seed_frame)
+        self._load_known_frames(known_map)
         self.dynamic_model.use_rgbd_integration = use_rgbd_integration
         self.volume = None
         if use_rgbd_integration and tgt_depth_provider is None:
@@ -216,10 +242,53 @@ class InfiniteSceneGeneration:
         return self.volume.render_depth(self.K, T, H, W, z0, z1)
 
     # ---------------------------------------------------------------- grid / order / source choice
-    def prepare_grid(self, grid_size):
+    def get_known_map(self):
+        """reference :144-155: the frames a result folder already holds, keyed by grid coordinate — file names
+        `dm_<frame index>_<ii>_<jj>.npy` (+ the `im_*.png` beside each).  No folder: nothing is known but the seed."""
+        known = {}
+        if self.grid_transform_path is None:
+            return known
+        for f in Path(self.grid_transform_path).glob("dm*"):
+            idx, gi, gj = (int(v) for v in f.name[3:-4].split("_")[:3])
+            known[(gi, gj)] = {"rgb_path": str(f).replace("dm", "im").replace("npy", "png"), "depth_path": str(f),
+                               "orig_frame_idx": idx}
+        return known
+
+    def _node(self, R, t, coord, known_map):
+        node = {"R": R, "t": t, "K": self.K, "position": -R.T @ t, "visited": coord in known_map, "grid_coord": coord}
+        if coord in known_map:
+            node["rgb_path"], node["depth_path"] = known_map[coord]["rgb_path"], known_map[coord]["depth_path"]
+            self.anchor_poses[coord] = node
+        return node
+
+    def _load_known_frames(self, known_map):
+        """RESUME: the known frames of the folder become sources exactly as the reference reads them back in
+        prepare_batch_data (:534-537, 570-574): PIL LANCZOS resize of the PNG, nearest resize of the depth map, RGB through
+        the uint8 codec.  The seed pose keeps the seed frame handed to the constructor."""
+        if not known_map:
+            return
+        from PIL import Image
+        import torch.nn.functional as F
+        H, W = self.image_resolution
+        for coord in sorted(known_map, key=lambda c: known_map[c]["orig_frame_idx"]):
+            if coord == self._ordered_grid_coords[0] and coord in self.frames:
+                continue
+            if coord[0] >= len(self.transform_grid) or coord[1] >= len(self.transform_grid[coord[0]]):
+                continue                                     # a frame outside this run's pose set
+            rgb = np.array(Image.open(known_map[coord]["rgb_path"]).convert("RGB").resize((W, H), resample=Image.LANCZOS))
+            depth = np.load(known_map[coord]["depth_path"])
+            depth = F.interpolate(torch.from_numpy(np.ascontiguousarray(depth, dtype=np.float32)[None, None]), size=(H, W))[0][0]
+            u8 = torch.from_numpy(np.ascontiguousarray(rgb)).to(self.device)
+            self.frames[coord] = {"rgb_u8": u8, "rgb_f": ops.rgb_u8_to_f32(u8), "depth": depth.contiguous().to(self.device),
+                                  "index": known_map[coord]["orig_frame_idx"]}
+            self.transform_grid[coord[0]][coord[1]]["visited"] = True
+
+    def prepare_grid(self, grid_size, known_map=None):
+        known_map = known_map or {}
         start, step_i, step_j = _START[self.data]
         step_i, step_j = step_i / self.step_size_denom, step_j / self.step_size_denom
         self.transform_grid = []
+        self.anchor_poses = {}
         for i in range(grid_size[0]):
             row = []
             for j in range(grid_size[1]):
@@ -227,10 +296,93 @@ class InfiniteSceneGeneration:
                 c2w[:3, :3] = start[:3, :3]
                 c2w[:3, 3] = start[:3, 3] + step_unit(step_j, j) + step_unit(step_i, i)
                 w2c = np.linalg.inv(c2w @ _GL2CV)
-                R, t = w2c[:3, :3], w2c[:3, 3]
-                row.append({"R": R, "t": t, "K": self.K, "position": -R.T @ t, "visited": False,
-                            "grid_coord": (i, j)})
+                row.append(self._node(w2c[:3, :3], w2c[:3, 3], (i, j), known_map))
             self.transform_grid.append(row)
+
+    def prepare_spiral(self, grid_size, known_map=None):
+        """reference :206-288: an Archimedean spiral of grid_size[0] poses in the seed camera's plane (arc 1, separation 1,
+        positions theta (cos theta, sin theta) / 10 from the seed position), each camera turned about z by the reference's
+        `90 - theta` — radians, as written there — one pose per row of the grid."""
+        known_map = known_map or {}
+        start = _START[self.data][0]
+        self.transform_grid, self.anchor_poses = [], {}
+        w2c = np.linalg.inv(start @ _GL2CV)
+        R, t = w2c[:3, :3], w2c[:3, 3]
+        origin = -R.T @ t
+        arc, separation = 1, 1
+        r = arc
+        b = separation / (2 * np.pi)
+        theta = float(r) / b
+        for i in range(grid_size[0]):
+            a = 90 - theta
+            c2w = np.eye(4)
+            c2w[:3, 3] = origin
+            c2w[0, 3] += theta * np.cos(theta) / 10
+            c2w[1, 3] += theta * np.sin(theta) / 10
+            c2w[:3, :3] = np.array([[np.cos(a), np.sin(a), 0], [-np.sin(a), np.cos(a), 0], [0, 0, 1]])
+            w2c = np.linalg.inv(c2w)
+            theta += float(arc) / r
+            r = b * theta
+            self.transform_grid.append([self._node(w2c[:3, :3], w2c[:3, 3], (i, 0), known_map)])
+
+    def prepare_ring(self, grid_size, known_map=None, horizontal_offset=0):
+        """reference :290-360 (the 'cylinder' shape): every pose is the previous one turned by pi / 80 about the camera's x
+        axis and moved by -step_i (x component replaced by `horizontal_offset`) in ITS OWN frame — a ring that closes after
+        160 poses.  The reference appends every pose to ONE row while naming them (i, 0), so its own loop could not index
+        them (transform_grid[i][0]); here pose i is row i, like the spiral — same poses, steppable."""
+        known_map = known_map or {}
+        start, step_i, _ = _START[self.data]
+        step_i = step_i / self.step_size_denom
+        if self.data != "google_earth":
+            step_i = -step_i                                  # the reference's CLEVR branch of this shape negates it (:309)
+        self.transform_grid, self.anchor_poses = [], {}
+        curr = start @ _GL2CV
+        theta = np.pi / 80
+        rot = np.eye(4)
+        rot[:3, :3] = np.array([[1, 0, 0], [0, np.cos(theta), np.sin(theta)], [0, -np.sin(theta), np.cos(theta)]])
+        for i in range(grid_size[0]):
+            T = np.eye(4)
+            T[:3, 3] = -step_i
+            T[0, 3] = horizontal_offset
+            w2c = T @ rot @ np.linalg.inv(curr)
+            curr = np.linalg.inv(w2c)
+            self.transform_grid.append([self._node(w2c[:3, :3], w2c[:3, 3], (i, 0), known_map)])
+
+    @staticmethod
+    def load_poses(pose_file):
+        """reference :362-368: one pose per line — frame index, then the row-major 4 x 4 camera-to-world matrix"""
+        poses = np.loadtxt(pose_file)
+        frames = poses[:, 0].astype(int)
+        mats = np.reshape(poses[:, 1:], (-1, 4, 4))
+        return {int(k): {"frame_idx": int(k), "pose": v} for k, v in zip(frames, mats)}
+
+    def prepare_trajectory(self, trajectory_length, known_map, pose_path):
+        """reference :370-421: `trajectory_length` consecutive poses of the file, starting at the frame index of the first
+        known frame; returns the visiting order (i, 0)."""
+        self.transform_grid, self.anchor_poses = [], {}
+        poses = self.load_poses(pose_path)
+        if not known_map:
+            raise ValueError("a 'trajectory' run starts from a known frame: none found in " + str(self.grid_transform_path))
+        start_idx = known_map[sorted(known_map.keys())[0]]["orig_frame_idx"]
+        assert start_idx in poses
+        order_idx = sorted(poses.keys())
+        ptr = order_idx.index(start_idx)
+        assert ptr + trajectory_length < len(order_idx)
+        ordered = []
+        for i in range(trajectory_length):
+            w2c = np.linalg.inv(poses[order_idx[ptr + i]]["pose"])
+            self.transform_grid.append([self._node(w2c[:3, :3], w2c[:3, 3], (i, 0), known_map)])
+            ordered.append((i, 0))
+        return ordered
+
+    def get_closest_anchor(self, curr_node):
+        """reference :423-431: the known pose nearest to a node"""
+        best, res = 99999999, None
+        for k in self.anchor_poses:
+            d = np.linalg.norm(self.anchor_poses[k]["position"] - curr_node["position"])
+            if d < best:
+                best, res = d, self.anchor_poses[k]
+        return res
 
     def zig_zag_order(self):
         rows, cols = self.output_dim
@@ -245,10 +397,26 @@ class InfiniteSceneGeneration:
         self.transform_grid[order[0][0]][order[0][1]]["visited"] = True
         return order
 
+    def row_major_order(self):
+        """reference :477-488: boustrophedon over the rows"""
+        rows, cols = self.output_dim
+        order = [(i, j if i % 2 == 0 else cols - j - 1) for i in range(rows) for j in range(cols)]
+        self.transform_grid[order[0][0]][order[0][1]]["visited"] = True
+        return order
+
+    def column_major_order(self):
+        """reference :490-501: boustrophedon over the columns"""
+        rows, cols = self.output_dim
+        order = [(i if j % 2 == 0 else rows - i - 1, j) for j in range(cols) for i in range(rows)]
+        self.transform_grid[order[0][0]][order[0][1]]["visited"] = True
+        return order
+
     def next_pose(self, curr):
         return self._ordered_grid_coords[curr]
 
     def get_src_grid_coords(self, tgt_grid_coord):
+        if getattr(self, "trajectory_shape", "grid") == "trajectory":           # reference :531: the num_src poses just behind the target
+            return [(tgt_grid_coord[0] - i - 1, 0) for i in range(self.num_src)], None
         tgt = self.transform_grid[tgt_grid_coord[0]][tgt_grid_coord[1]]
         radius = 0.3 if self.data != "clevr-infinite" else 1
         found = []
@@ -381,6 +549,8 @@ class InfiniteSceneGeneration:
         them in place.  The frame store (`self.frames`) always holds its own tensors.  A caller that keeps a result
         dictionary across steps passes keep_results=True (six device copies per step) or clones what it keeps."""
         src_coords, _ = self.get_src_grid_coords(tgt_pose_grid_coord)
+        if not src_coords:       # the reference dies in np.stack([]) here (:596); e.g. the GoogleEarth spiral: poses 0.7 apart, radius 0.3
+            raise ValueError(f"no visited pose within the source radius of {tuple(tgt_pose_grid_coord)}: nothing to warp from")
         tgt_meta = self.transform_grid[tgt_pose_grid_coord[0]][tgt_pose_grid_coord[1]]
         src_metas = [self.transform_grid[c[0]][c[1]] for c in src_coords]
         batch = self.prepare_batch_data(tgt_meta, src_metas, self.num_src)

@@ -364,7 +364,12 @@ def _arrive(w, device):
         else:
             w._sgam_arrive = t
     # one launch at a time per counter array (include/sgam_hip.h): launches of ONE stream qualify; a second stream driving the same
-    # weight gets the partial tiles + combine launch instead of sharing the counters
+    # weight gets the partial tiles + combine launch instead of sharing the counters.  A stream CAPTURE is the exception that keeps
+    # the rule: the model's warm-up ran on its side stream, the capture runs on torch's private capture stream right behind it, and
+    # the captured launches are one dependency chain wherever the graph is replayed — the capture inherits the counters (without
+    # this the fix-up was silently inert in every replayed frame: round 5 measured "198 launches" with and without SGAM_XFIXUP=1).
+    if torch.cuda.is_current_stream_capturing():
+        return t
     if getattr(t, "_sgam_stream", None) != int(torch.cuda.current_stream(device).cuda_stream):
         return None
     return t

@@ -552,8 +552,91 @@ def gen_pcd():
     save("prepare_pcd.npz", depth=depth, color=color, K=K, Rt=Rt, points=np.asarray(pcd.points), colors=np.asarray(pcd.colors))
 
 
+def pose_set_inputs():
+    """seeded inputs of the `trajectory` pose-set fixture: a cam0_to_world.txt of 12 rigid poses (frame index + row-major 4x4 per
+    line, the format load_poses reads, inference_pipeline.py:362-368) and the frame indices of two known frames"""
+    rs = np.random.RandomState(5)
+    rows = []
+    for k in range(12):
+        a, b = 0.05 * k, 0.02 * k
+        Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+        Rx = np.array([[1, 0, 0], [0, np.cos(b), -np.sin(b)], [0, np.sin(b), np.cos(b)]])
+        T = np.eye(4)
+        T[:3, :3], T[:3, 3] = Rz @ Rx, rs.uniform(-1, 1, 3) + [0.3 * k, 0, 0]
+        rows.append(np.concatenate([[100 + 3 * k], T.reshape(-1)]))
+    return np.stack(rows), [(103, 0, 0), (106, 1, 0)]
+
+
+def gen_pose_sets():
+    """The reference's OTHER pose sets and visiting orders, run as they stand on a bare instance (their constructor hard-codes
+    trajectory_shape = 'grid', inference_pipeline.py:67 / :82, so they are reachable only by editing it): prepare_spiral (:206-288),
+    prepare_ring (:290-360, the 'cylinder' shape), prepare_trajectory (:370-421) + load_poses, get_known_map (:144-155),
+    row_major_order / column_major_order (:477-501), the trajectory branch of get_src_grid_coords (:531).  Open3D is only used
+    there to DRAW coordinate frames: stubbed to no-ops."""
+    print("pose sets: spiral / cylinder / trajectory, known map, visiting orders")
+    import tempfile
+    import types
+    import sgam.inference_pipeline as ref_ip
+
+    class _Frame:
+        def transform(self, T):
+            return self
+    ref_ip.o3d.geometry = types.SimpleNamespace(TriangleMesh=types.SimpleNamespace(create_coordinate_frame=lambda size=1: _Frame()))
+    ref_ip.o3d.visualization = types.SimpleNamespace(draw_geometries=lambda frames: None)
+    if not hasattr(np, "int"):
+        np.int = int                     # load_poses uses the alias numpy 2 removed
+    out = {}
+    for data in ("google_earth", "clevr-infinite"):
+        tag = "ge" if data == "google_earth" else "clevr"
+        o = object.__new__(InfiniteSceneGeneration)
+        o.data, o.step_size_denom = data, 2
+        o.K = np.array([[248.88887, 0, 128], [0, 248.88887, 128], [0, 0, 1]]) if tag == "ge" else np.array([[355.5555, 0, 128], [0, 355.5555, 128], [0, 0, 1]])
+        for shape, fn, kw in (("spiral", o.prepare_spiral, {}), ("cylinder", o.prepare_ring, {"horizontal_offset": 0.002})):
+            fn((9, 1), {}, "out", **kw)
+            nodes = [n for row in o.transform_grid for n in row]
+            out[f"{tag}_{shape}_R"] = np.stack([n["R"] for n in nodes])
+            out[f"{tag}_{shape}_t"] = np.stack([n["t"] for n in nodes])
+            out[f"{tag}_{shape}_position"] = np.stack([n["position"] for n in nodes])
+            out[f"{tag}_{shape}_rows"] = np.array([len(row) for row in o.transform_grid])
+    # trajectory: poses from a file, known frames from the files of the result folder
+    poses, known = pose_set_inputs()
+    with tempfile.TemporaryDirectory() as d:
+        np.savetxt(os.path.join(d, "cam0_to_world.txt"), poses)
+        for idx, i, j in known:
+            np.save(os.path.join(d, f"dm_{idx:05d}_{i:02d}_{j:02d}.npy"), np.zeros((2, 2), np.float32))
+        o = object.__new__(InfiniteSceneGeneration)
+        o.data, o.step_size_denom, o.K = "google_earth", 2, np.eye(3)
+        o.grid_transform_path = ref_ip.Path(d)
+        km = o.get_known_map()
+        out["known_keys"] = np.array(sorted(km.keys()))
+        out["known_orig_idx"] = np.array([km[k]["orig_frame_idx"] for k in sorted(km.keys())])
+        order = o.prepare_trajectory(7, km, d, pose_path=os.path.join(d, "cam0_to_world.txt"))
+        out["traj_order"] = np.array(order)
+        nodes = [row[0] for row in o.transform_grid]
+        out["traj_R"] = np.stack([n["R"] for n in nodes])
+        out["traj_t"] = np.stack([n["t"] for n in nodes])
+        out["traj_position"] = np.stack([n["position"] for n in nodes])
+        out["traj_visited"] = np.array([n["visited"] for n in nodes])
+        out["traj_anchor_keys"] = np.array(sorted(o.anchor_poses.keys()))
+        o.trajectory_shape, o.num_src, o.curr = "trajectory", 3, 5
+        out["traj_srcs_of_5"] = np.array(o.get_src_grid_coords((5, 0))[0])
+        out["traj_closest_anchor_of_6"] = np.array(o.get_closest_anchor(nodes[6])["grid_coord"])
+    out["poses_txt"] = poses
+    out["known_files"] = np.array(known)
+    # visiting orders on a 3 x 4 grid
+    o = object.__new__(InfiniteSceneGeneration)
+    o.output_dim = (3, 4)
+    o.transform_grid = [[{"visited": False} for _ in range(4)] for _ in range(3)]
+    out["row_major_3x4"] = np.array(o.row_major_order())
+    out["column_major_3x4"] = np.array(o.column_major_order())
+    out["zig_zag_3x4"] = np.array(o.zig_zag_order())
+    save("pose_sets.npz", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
+    if not only or "poses" in only:
+        gen_pose_sets()
     if not only or "pcd" in only:
         gen_pcd()
     rgb0, dm0 = gen_splat() if (not only or "splat" in only or "traj" in only) else (None, None)
