@@ -345,6 +345,29 @@ int sgam_attention_h16_batched(const void *q, const void *k, const void *v, int3
                                int32_t B, float scale, void *out, int32_t ldo, void *workspace, int64_t workspace_bytes,
                                void *stream);
 
+/* (ABI v9) The AttnBlock of the 16-bit mode ahead of proj_out in ONE call of four launches — reference
+ * modules/diffusionmodules/model.py:168-187: `h_ = self.norm(x); q = self.q(h_); k = self.k(h_); v = self.v(h_)`, then the attention
+ * of sgam_attention_h16_batched.  GroupNorm is applied while the projection stages its operand (y = x scale + shift from the
+ * per-channel table, fp32, one rounding to 16 bits — the arithmetic of sgam_groupnorm_from_partials_h16), the stacked q | k | v
+ * projection writes q row-major and K / V^T directly in the fused attention's MFMA-fragment order: the stand-alone normalise pass, the
+ * generic 1 x 1 GEMM and the fragment-split launch disappear.
+ *   x          [B n][ldx] 16-bit block input (ldx % 8 == 0), C == 256, n % 256 == 0 (sgam_attention_h16_batched's shapes)
+ *   gn_partial the chunk statistics x's producer left: [B][nchunk][32][2] fp64 {sum, sumsq}, or (nchunk == 0) its [B][16][32][4]
+ *              int64 accumulator record; gamma, beta [C] of AttnBlock.norm; eps
+ *   w_frag     sgam_pack_qkv_weight_h16 of the stacked [3 C][C] fp32 weight (rows: q.weight, k.weight, v.weight): 3 C C 2 bytes
+ *   bias       [3 C] fp32 (q.bias | k.bias | v.bias), 16-byte aligned
+ *   out        [B n][ldo] 16-bit attention output (the operand of proj_out)
+ *   workspace  sgam_attn_block_h16_workspace_bytes(n, C, B)
+ * sgam_groupnorm_table_from_partials is the finalize half of sgam_groupnorm_from_partials_* on its own: the {scale, shift} table
+ * [B][C][2] fp32 (scale = rstd gamma, shift = beta - mean scale) for a consumer that normalises while staging. */
+int sgam_groupnorm_table_from_partials(const double *partial, int32_t nchunk, const float *gamma, const float *beta,
+                                       float *scale_shift, int32_t B, int32_t HW, int32_t C, int32_t groups, float eps, void *stream);
+int sgam_pack_qkv_weight_h16(const float *w, void *w_frag, int32_t ht, int32_t C, void *stream);
+int64_t sgam_attn_block_h16_workspace_bytes(int32_t n, int32_t C, int32_t B);
+int sgam_attn_block_h16(const void *x, int32_t ldx, const double *gn_partial, int32_t nchunk, const float *gamma, const float *beta,
+                        float eps, const void *w_frag, const float *bias, int32_t ht, int32_t n, int32_t C, int32_t B, float scale,
+                        void *out, int32_t ldo, void *workspace, int64_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * K7/K8 — nearest-codeword quantiser.  Replaces VectorQuantizer2.forward
  * (modules/vqvae/quantize.py:285-307): d = (|z|^2 + |e|^2) - 2 z.e (that expression order, fp32),

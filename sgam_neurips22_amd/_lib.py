@@ -23,7 +23,7 @@ class TsdfGrid(ctypes.Structure):
 
 
 # name -> (restype, argtypes); must list every symbol include/sgam_hip.h declares
-ABI_VERSION = 8      # include/sgam_hip.h: sgam_abi_version() of the library these prototypes were written against
+ABI_VERSION = 9      # include/sgam_hip.h: sgam_abi_version() of the library these prototypes were written against
 
 PROTOTYPES = {
     "sgam_abi_version": (c_i32, []),
@@ -149,6 +149,11 @@ PROTOTYPES = {
                                                  c_i32, c_vp, c_i32, c_vp, c_i64, c_vp]),
     "sgam_attention_h16_batched_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
     "sgam_attention_h16_batched": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_i32, c_vp, c_i64, c_vp]),
+    "sgam_groupnorm_table_from_partials": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp]),
+    "sgam_pack_qkv_weight_h16": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "sgam_attn_block_h16_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
+    "sgam_attn_block_h16": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_i32,
+                                    c_vp, c_i64, c_vp]),
     "sgam_row_sumsq_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
     "sgam_vq_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
     "sgam_vq_nearest_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp,

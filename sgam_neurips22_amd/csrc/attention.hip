@@ -629,6 +629,137 @@ __global__ __launch_bounds__(256) void attn_split_kv_h16_kernel(const unsigned s
     *reinterpret_cast<u32x4 *>(vf + piece) = o;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Front end of the AttnBlock in the 16-bit mode, ONE launch (round 5; reference modules/diffusionmodules/model.py:168-175:
+// h_ = self.norm(x); q = self.q(h_); k = self.k(h_); v = self.v(h_)): GroupNorm applied while the operand panel is staged
+// (y = x scale + shift from the per-channel table, fp32, one rounding to 16 bits — the arithmetic of gn_apply_kernel), the stacked
+// q | k | v projection, and the outputs written where the flash kernel wants them: q row-major, K as its MFMA fragments (a lane
+// holds 16 consecutive channels of one token = two 16-byte fragment pieces, 32 lanes = 512 contiguous bytes), V^T as its
+// fragments through an LDS transpose.  Replaces gn_apply (a read + a write of the activation), the generic 1 x 1 GEMM and
+// attn_split_kv_h16_kernel: three launches and two graph edges of a B = 1 frame per block.
+//
+// The product is computed TRANSPOSED: weights are the MFMA rows, tokens the columns.  MFMA row 8 j + 4 h + i of a 32-channel
+// tile carries channel 16 h + 4 j + i (the packing of sgam_pack_qkv_weight_h16), so accumulator slot e of lane (token, h) is
+// channel 16 h + e.  Tile: 128 channels (four wavefronts, 32 each) x 64 tokens (two column tiles share every weight fragment);
+// K = C = 256 is one panel: a single barrier between staging and the 16 k-steps.
+// ---------------------------------------------------------------------------------------------------------------------
+struct QkvHParams {
+    const unsigned short *x;        // [nt][ldx] 16-bit activation (the block input)
+    const float *table;             // [B][AD][2] {scale, shift} per (image, channel): sgam_groupnorm_table_from_partials
+    const unsigned short *w;        // fragment-ordered stacked weights [3 AD / 32][AD / 16][64 lanes][8 halfs]
+    const float *bias;              // [3 AD]
+    unsigned short *q, *kf, *vf;    // q [nt][AD]; K / V^T fragments (attn_split_kv_h16_kernel's layout)
+    int ldx, n_img;
+};
+
+template <int HT>
+__global__ __launch_bounds__(256, 2) void attn_qkv_gn_h16_kernel(const QkvHParams p) {
+    constexpr int LDK = AD + 8;                                       // panel row pitch in halfs (rows 4 banks apart)
+    constexpr int VLD = 64 + 8;                                       // V transpose: [128 channels][64 tokens + pad]
+    __shared__ __attribute__((aligned(16))) unsigned short sB[64 * LDK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * 64, by = blockIdx.y;                  // 64 tokens; 128 of the 768 output channels
+    const int lr = lane & 31, lh = lane >> 5;
+    const int b = m0 / p.n_img;
+    constexpr int WD = 4, KS = AD / 16;
+    const unsigned short *wt = p.w + (int64_t)(by * 4 + wave) * KS * 512 + lane * 8;      // + k-step * 512 halfs
+    u32x4 wf[WD];
+#pragma unroll
+    for (int t = 0; t < WD; ++t) wf[t] = *reinterpret_cast<const u32x4 *>(wt + t * 512);
+    // ---- stage the 64 x 256 panel: thread = (row, 8 channels), eight rows each; the channel octet is the same in every round
+    {
+        const int c8 = (tid & 31) * 8, r0 = tid >> 5;
+        float sc[8], sf[8];
+        const float *tab = p.table + ((int64_t)b * AD + c8) * 2;
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+            const f32x4 tv = *reinterpret_cast<const f32x4 *>(tab + e4 * 4);
+            sc[2 * e4] = tv[0], sf[2 * e4] = tv[1], sc[2 * e4 + 1] = tv[2], sf[2 * e4 + 1] = tv[3];
+        }
+        u32x4 xr[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) xr[it] = *reinterpret_cast<const u32x4 *>(p.x + (int64_t)(m0 + r0 + it * 8) * p.ldx + c8);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned u = xr[it][e];
+                float f0, f1;
+                if (HT == 0) f0 = __builtin_bit_cast(float, u << 16), f1 = __builtin_bit_cast(float, u & 0xffff0000u);
+                else f0 = (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu)), f1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16));
+                o[e] = HM<HT>::pack2(__builtin_fmaf(f0, sc[2 * e], sf[2 * e]), __builtin_fmaf(f1, sc[2 * e + 1], sf[2 * e + 1]));
+            }
+            *reinterpret_cast<u32x4 *>(&sB[(r0 + it * 8) * LDK + c8]) = o;
+        }
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    __syncthreads();
+    // ---- 16 k-steps: weight fragment (MFMA rows) WD steps ahead in a register ring, token fragments (k = 16 t + 8 lh + 0..7 of
+    // token lr of each column tile) from the panel
+#pragma unroll
+    for (int t = 0; t < KS; ++t) {
+        const u32x4 a = wf[t % WD];
+        wf[t % WD] = *reinterpret_cast<const u32x4 *>(wt + (t + WD < KS ? t + WD : KS - 1) * 512);
+        __builtin_amdgcn_sched_barrier(0);                            // (keeps the request in front of this step's MFMAs: gemm_gn_f32x.hip)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            acc[j] = HM<HT>::mfma(a, *reinterpret_cast<const u32x4 *>(&sB[(j * 32 + lr) * LDK + t * 16 + lh * 8]), acc[j]);
+    }
+    // ---- epilogue: lane (token lr of column tile j, half lh) holds channels cw = 32 wave + 16 lh + 0..15 of this 128-channel slab
+    const int cw = wave * 32 + 16 * lh;
+    float bias[16];
+#pragma unroll
+    for (int e4 = 0; e4 < 4; ++e4) {
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(p.bias + by * 128 + cw + e4 * 4);
+        bias[4 * e4] = bv[0], bias[4 * e4 + 1] = bv[1], bias[4 * e4 + 2] = bv[2], bias[4 * e4 + 3] = bv[3];
+    }
+    u32x4 pk[2][2];                                                   // [column tile][channels 0..7 | 8..15]
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; e += 2)
+            pk[j][e >> 3][(e & 7) >> 1] = HM<HT>::pack2(acc[j][e] + bias[e], acc[j][e + 1] + bias[e + 1]);
+    if (by < 2) {                                                     // q: row-major [token][AD]
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            unsigned short *dst = p.q + (int64_t)(m0 + j * 32 + lr) * AD + by * 128 + cw;
+            *reinterpret_cast<u32x4 *>(dst) = pk[j][0];
+            *reinterpret_cast<u32x4 *>(dst + 8) = pk[j][1];
+        }
+    } else if (by < 4) {                                              // K fragments: piece (k-step lh, half h, key lr) of d-tile (by - 2) 4 + wave
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t kb = (m0 >> 5) + j;
+            unsigned short *dst = p.kf + ((kb * 8 + (by - 2) * 4 + wave) * 128 + (lh * 2) * 32 + lr) * 8;
+            *reinterpret_cast<u32x4 *>(dst) = pk[j][0];
+            *reinterpret_cast<u32x4 *>(dst + 32 * 8) = pk[j][1];
+        }
+    } else {                                                          // V^T fragments: 8 KEYS of one channel per piece -> transpose in LDS
+        __syncthreads();                                              // every wavefront is done reading the panel
+        unsigned short *vt = sB;                                      // [128 channels][VLD]
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                vt[(cw + e) * VLD + j * 32 + lr] = (unsigned short)((pk[j][e >> 3][(e & 7) >> 1] >> (16 * (e & 1))) & 0xffffu);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int pp = tid + 256 * k;                             // (key block of the tile, d-tile, k-step * 2 + half, channel row)
+            const int drow = pp & 31, th = (pp >> 5) & 3, tl = (pp >> 7) & 3, kbl = pp >> 9;
+            const unsigned short *src = vt + (tl * 32 + drow) * VLD + kbl * 32 + 4 * (th & 1) + 16 * (th >> 1);
+            const u32x2 lo = *reinterpret_cast<const u32x2 *>(src), hi = *reinterpret_cast<const u32x2 *>(src + 8);
+            const int64_t kb = (m0 >> 5) + kbl;
+            *reinterpret_cast<u32x4 *>(p.vf + ((kb * 8 + (by - 4) * 4 + tl) * 128 + th * 32 + drow) * 8) = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+    }
+}
+
 struct AttnHParams {
     const unsigned short *q, *kf, *vf;
     float *ws_o, *ws_ml;
@@ -988,4 +1119,102 @@ extern "C" int sgam_attention_h16_batched(const void *q, const void *k, const vo
 extern "C" int sgam_attention_h16(const void *q, const void *k, const void *v, int32_t ht, int32_t ld, int32_t n, int32_t C,
                                   float scale, void *out, int32_t ldo, void *workspace, int64_t workspace_bytes, void *stream) {
     return sgam_attention_h16_batched(q, k, v, ht, ld, n, C, 1, scale, out, ldo, workspace, workspace_bytes, stream);
+}
+
+// ---- fused AttnBlock front end + attention of the 16-bit mode (ABI v9) -------------------------------------------------------
+// stacked q | k | v weights [3 C][C] (fp32, rows q then k then v) -> the fragment order attn_qkv_gn_h16_kernel reads: per 32-row tile and
+// 16-wide k-step one kilobyte, lane (h, rho) = 8 consecutive k of the row that MFMA row rho carries (channel 16 ((rho >> 2) & 1) +
+// 4 (rho >> 3) + (rho & 3) of the tile)
+namespace {
+template <int HT>
+__global__ __launch_bounds__(256) void pack_qkv_weight_h16_kernel(const float *__restrict__ w, unsigned short *__restrict__ o, int rows) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;                  // one 16-byte piece: (tile, k-step, h, rho)
+    const int rho = gid & 31, h = (gid >> 5) & 1, ks = (gid >> 6) % (AD / 16), tile = gid / (64 * (AD / 16));
+    if (tile * 32 >= rows) return;
+    const int ch = 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3);
+    const float *src = w + (int64_t)(tile * 32 + ch) * AD + ks * 16 + h * 8;
+    u32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = HM<HT>::pack2(src[2 * e], src[2 * e + 1]);
+    *reinterpret_cast<u32x4 *>(o + (int64_t)gid * 8) = v;
+}
+}  // namespace
+
+extern "C" int sgam_pack_qkv_weight_h16(const float *w, void *w_frag, int32_t ht, int32_t C, void *stream) {
+    if (!w || !w_frag || C != AD || (ht != 0 && ht != 1)) return SGAM_EINVAL;
+    if (!sgam_aligned16(w_frag)) return SGAM_EALIGN;
+    const int pieces = 3 * AD * AD / 8;
+    hipStream_t s = sgam_stream(stream);
+    if (ht == 0) SGAM_KLAUNCH(pack_qkv_weight_h16_kernel<0>, dim3(pieces / 256), dim3(256), 0, s, w, (unsigned short *)w_frag, 3 * AD);
+    else SGAM_KLAUNCH(pack_qkv_weight_h16_kernel<1>, dim3(pieces / 256), dim3(256), 0, s, w, (unsigned short *)w_frag, 3 * AD);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+extern "C" int sgam_groupnorm_table_from_partials(const double *partial, int32_t nchunk, const float *gamma, const float *beta,
+                                                  float *scale_shift, int32_t B, int32_t HW, int32_t C, int32_t groups, float eps,
+                                                  void *stream);
+
+extern "C" int64_t sgam_attn_block_h16_workspace_bytes(int32_t n, int32_t C, int32_t B) {
+    const int64_t base = sgam_attention_h16_batched_workspace_bytes(n, C, B);
+    if (base < 0) return -1;
+    // + q [B n][C] 16-bit + the {scale, shift} table [B][C][2] fp32
+    return base + (int64_t)B * n * AD * 2 + (int64_t)B * AD * 2 * 4;
+}
+
+// out = softmax(q k^T scale) v with q | k | v = GroupNorm(x) Wqkv^T + b — everything of the AttnBlock ahead of proj_out, 4 launches
+// (table, projection, flash, merge).  x [B n][ldx] 16-bit; gn_partial / nchunk: the chunk statistics x's producer left
+// ([B][nchunk][32][2] fp64, or nchunk = 0: its accumulator record); gamma, beta [C]; w_frag: sgam_pack_qkv_weight_h16; bias [3 C].
+extern "C" int sgam_attn_block_h16(const void *x, int32_t ldx, const double *gn_partial, int32_t nchunk, const float *gamma, const float *beta,
+                                   float eps, const void *w_frag, const float *bias, int32_t ht, int32_t n, int32_t C, int32_t B, float scale,
+                                   void *out, int32_t ldo, void *workspace, int64_t workspace_bytes, void *stream) {
+    if (!x || !gn_partial || !gamma || !beta || !w_frag || !bias || !out || !workspace || (ht != 0 && ht != 1)) return SGAM_EINVAL;
+    const int64_t need = sgam_attn_block_h16_workspace_bytes(n, C, B);
+    if (need < 0) return SGAM_EINVAL;
+    const int nsplit = attn_nsplit(n, B), nt = B * n;
+    if (ldx < C || ldx % 8 != 0 || ldo < C || ldo % 4 != 0 || !(scale > 0.f) || !(eps > 0.f) || (n / KB) % nsplit != 0 || n % 64 != 0)
+        return SGAM_EINVAL;
+    if (workspace_bytes < need) return SGAM_EWORKSPACE;
+    if (!sgam_aligned16(x) || !sgam_aligned16(w_frag) || !sgam_aligned16(bias) || !sgam_aligned16(workspace) || (((uintptr_t)out) & 7u) != 0)
+        return SGAM_EALIGN;
+    hipStream_t s = sgam_stream(stream);
+    unsigned short *kf = (unsigned short *)workspace;
+    unsigned short *vf = kf + (int64_t)nt * AD;
+    float *ws_o = (float *)(vf + (int64_t)nt * AD);
+    float *ws_ml = ws_o + (int64_t)nsplit * nt * AD;
+    unsigned short *qb = (unsigned short *)(ws_ml + (int64_t)nsplit * nt * 2);
+    float *table = (float *)(qb + (int64_t)nt * AD);
+    const int rc = sgam_groupnorm_table_from_partials(gn_partial, nchunk, gamma, beta, table, B, n, C, 32, eps, stream);
+    if (rc != SGAM_OK) return rc;
+    QkvHParams g;
+    g.x = (const unsigned short *)x; g.table = table; g.w = (const unsigned short *)w_frag; g.bias = bias; g.q = qb; g.kf = kf; g.vf = vf;
+    g.ldx = ldx; g.n_img = n;
+    if (sgam_i_prof_on) sgam_i_prof_shape(nt, 3 * AD, AD, 1);
+    if (sgam_i_prof_on) sgam_i_prof_work(2.0 * nt * 3.0 * AD * AD, 2.0 * (4.0 * nt * AD + 3.0 * AD * AD));
+    if (ht == 0) SGAM_KLAUNCH(attn_qkv_gn_h16_kernel<0>, dim3(nt / 64, 6), dim3(256), 0, s, g);
+    else SGAM_KLAUNCH(attn_qkv_gn_h16_kernel<1>, dim3(nt / 64, 6), dim3(256), 0, s, g);
+    SGAM_LAUNCH_CHECK();
+    AttnHParams p;
+    p.q = qb; p.kf = kf; p.vf = vf; p.ws_o = ws_o; p.ws_ml = ws_ml;
+    p.ld = AD; p.n = nt; p.n_img = n; p.nsplit = nsplit; p.blocks_per_split = n / KB / nsplit; p.qscale_log2e = scale * LOG2E;
+    const dim3 grid(nt / 128 * nsplit), cgrid(nt / 32 * 8);
+    if (sgam_i_prof_on) sgam_i_prof_work(4.0 * B * n * (double)n * AD, 4.0 * 2.0 * nt * AD);
+    if (ht == 0) SGAM_KLAUNCH(attn_flash_h16_kernel<0>, grid, dim3(256), 0, s, p);
+    else SGAM_KLAUNCH(attn_flash_h16_kernel<1>, grid, dim3(256), 0, s, p);
+    SGAM_LAUNCH_CHECK();
+#define HCOMBINE2(HT_, NS_) SGAM_KLAUNCH((attn_combine_h16_kernel<HT_, NS_>), cgrid, dim3(256), 0, s, ws_o, ws_ml, (unsigned short *)out, ldo, nt)
+    switch (nsplit * 2 + (ht ? 1 : 0)) {
+        case 16: HCOMBINE2(0, 8); break;
+        case 17: HCOMBINE2(1, 8); break;
+        case 8: HCOMBINE2(0, 4); break;
+        case 9: HCOMBINE2(1, 4); break;
+        case 4: HCOMBINE2(0, 2); break;
+        case 5: HCOMBINE2(1, 2); break;
+        case 2: HCOMBINE2(0, 1); break;
+        case 3: HCOMBINE2(1, 1); break;
+        default: return SGAM_EINVAL;
+    }
+#undef HCOMBINE2
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
 }

@@ -500,6 +500,21 @@ extern "C" int sgam_groupnorm_from_partials_h16(const void *x, const double *par
     return SGAM_OK;
 }
 
+// the per-(image, channel) {scale, shift} table alone, from the producer's chunk records (or its accumulator record, nchunk = 0):
+// the finalize half of sgam_groupnorm_from_partials_*, for consumers that apply y = x scale + shift themselves while they stage x
+// (the fused AttnBlock front end of the 16-bit mode, attention.hip: sgam_attn_block_h16)
+extern "C" int sgam_groupnorm_table_from_partials(const double *partial, int32_t nchunk, const float *gamma, const float *beta,
+                                                  float *scale_shift, int32_t B, int32_t HW, int32_t C, int32_t groups, float eps,
+                                                  void *stream) {
+    if (!partial || nchunk < 0 || (nchunk == 0 && groups != 32) || !gamma || !beta || !scale_shift || !gn_shape_ok(B, HW, C, groups))
+        return SGAM_EINVAL;
+    if (!sgam_aligned16(partial) || !sgam_aligned16(scale_shift)) return SGAM_EALIGN;
+    hipStream_t s = sgam_stream(stream);
+    SGAM_KLAUNCH(gn_finalize_kernel, dim3(groups, B), dim3(256), 0, s, partial, gamma, beta, scale_shift, HW, C, groups, nchunk, eps);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
 extern "C" int sgam_groupnorm_meanrstd_nhwc_h16(const void *x, float *mean_rstd, int32_t ht, int32_t B, int32_t HW, int32_t C,
                                                 int32_t groups, float eps, void *workspace, int64_t workspace_bytes,
                                                 void *stream) {

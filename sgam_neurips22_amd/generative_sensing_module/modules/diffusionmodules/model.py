@@ -264,8 +264,18 @@ def _attn_h16(self, x, wqkv, bqkv, wp, bp):
     """16-bit attention: q/k/v and P in bf16/fp16, scores and softmax in fp32."""
     B, H, W, C = x.shape
     n = H * W
-    h = self.norm.forward_nhwc(x, swish=False)
     scale = int(C) ** (-0.5)
+    if ops.attention_fusable(n, C) and ops.attn_block_h16_fusable(x, n, C, B):
+        # GroupNorm inside the q | k | v projection, K / V^T straight into the attention's fragment order: 4 launches ahead of proj_out
+        # (csrc/attention.hip: attn_qkv_gn_h16_kernel) instead of normalise (2) + GEMM + split + flash + merge
+        wkey = ("frag", x.dtype)
+        wqkvs = self._wqkv
+        if wkey not in wqkvs:
+            wqkvs[wkey] = ops.pack_qkv_weight_h16(wqkvs[torch.float32], x.dtype)
+        o = ops.attn_block_h16(x.reshape(B * n, C), x._gn_partials, self.norm.weight.detach(), self.norm.bias.detach(), self.norm.eps,
+                               wqkvs[wkey], bqkv, C, scale, B=B)
+        return self.proj_out.forward_nhwc(o.view(B, H, W, C), residual=x)
+    h = self.norm.forward_nhwc(x, swish=False)
     if B > 1 and ops.attention_fusable(n, C):
         qkv = ops.gemm_nt(h.reshape(B * n, C), wqkv, bias=bqkv)                    # (B n, 3C): the whole batch in one GEMM
         o = ops.attention_h16(qkv, C, scale, B=B)

@@ -344,6 +344,9 @@ def conv_plan(desc, h16=False, split=False):
 # counters zero.  Created outside stream capture only (the eager warm-up ahead of a capture does it): a torch.zeros inside a
 # capture would become a fill node of every replay.  SGAM_XFIXUP=0: partial tiles + combine launch, as before.
 XFIXUP = os.environ.get("SGAM_XFIXUP", "0") == "1"
+# 16-bit AttnBlock: GroupNorm + q | k | v + fragment split as ONE launch in front of the fused attention (SGAM_ATTN_BLOCK_H16=0: the
+# normalise pass, the generic 1x1 GEMM and the split launch, as before)
+ATTN_BLOCK_H16 = os.environ.get("SGAM_ATTN_BLOCK_H16", "1") != "0"
 ARRIVE_COUNT = 4096
 
 
@@ -854,6 +857,44 @@ def attention_h16(qkv, C, scale, out=None, B=1):
         out = torch.empty((nt, C), device=qkv.device, dtype=qkv.dtype)
     check(lib.sgam_attention_h16_batched(_p(qkv), _p(qkv[:, C:]), _p(qkv[:, 2 * C:]), H16[qkv.dtype], qkv.stride(0), n, C, B,
                                          float(scale), _p(out), out.stride(0), _p(ws), ws_bytes, _stream()), "sgam_attention_h16_batched")
+    return out
+
+
+def pack_qkv_weight_h16(w32, dtype):
+    """stacked q | k | v weight (3C, C) fp32 -> the fragment order of the fused 16-bit AttnBlock front end (attn_block_h16)"""
+    _need_cuda(w32)
+    C = w32.shape[1]
+    assert w32.dtype == torch.float32 and w32.shape[0] == 3 * C and w32.is_contiguous()
+    out = torch.empty((3 * C * C,), device=w32.device, dtype=dtype)
+    check(_lib.load().sgam_pack_qkv_weight_h16(_p(w32), _p(out), H16[dtype], C, _stream()), "sgam_pack_qkv_weight_h16")
+    return out
+
+
+def attn_block_h16_fusable(x, n, C, B):
+    """the block input is 16-bit, carries its producer's chunk statistics and has the fused attention's shape"""
+    pre = getattr(x, "_gn_partials", None)
+    return (ATTN_BLOCK_H16 and x.dtype in H16 and pre is not None and pre[0].dtype == torch.float64 and pre[1] > 0
+            and _lib.load().sgam_attn_block_h16_workspace_bytes(n, C, B) > 0)
+
+
+def attn_block_h16(x2d, pre, gamma, beta, eps, w_frag, bias, C, scale, B=1, out=None):
+    """16-bit AttnBlock ahead of proj_out: GroupNorm (from the producer's chunk statistics `pre` = (partials, chunks)) applied inside
+    the q | k | v projection, K / V^T written in the attention's fragment order, flash + merge: four launches (seven unfused)."""
+    _need_cuda(x2d)
+    nt = x2d.shape[0]
+    assert x2d.dtype in H16 and x2d.shape[1] == C and x2d.stride(1) == 1 and nt % B == 0
+    n = nt // B
+    lib = _lib.load()
+    ws_bytes = lib.sgam_attn_block_h16_workspace_bytes(n, C, B)
+    if ws_bytes < 0:
+        raise SgamHipError(f"sgam_attn_block_h16: unsupported shape n={n} C={C} B={B}")
+    ws = torch.empty((ws_bytes,), device=x2d.device, dtype=torch.uint8)
+    if out is None:
+        out = torch.empty((nt, C), device=x2d.device, dtype=x2d.dtype)
+    partial, chunks = pre
+    check(lib.sgam_attn_block_h16(_p(x2d), x2d.stride(0), _p(partial), int(chunks), _p(gamma), _p(beta), float(eps), _p(w_frag), _p(bias),
+                                  H16[x2d.dtype], n, C, B, float(scale), _p(out), out.stride(0), _p(ws), ws_bytes, _stream()),
+          "sgam_attn_block_h16")
     return out
 
 

@@ -20,7 +20,7 @@ def _declared_symbols():
 def test_library_is_built_and_loads():
     assert os.path.exists(_lib.LIB_PATH), "run `python -m sgam_neurips22_amd.build`"
     lib = _lib.load()
-    assert lib.sgam_abi_version() == _lib.ABI_VERSION == 8
+    assert lib.sgam_abi_version() == _lib.ABI_VERSION == 9
     assert b"gfx950" in lib.sgam_build_info()
 
 

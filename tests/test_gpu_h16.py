@@ -19,6 +19,10 @@ def _nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous()
 
 
+def _maxerr(a, b):
+    return (torch.as_tensor(a).detach().cpu().double() - torch.as_tensor(b).detach().cpu().double()).abs().max().item()
+
+
 def _rel(a, b):
     a, b = a.detach().float().cpu().double(), b.detach().float().cpu().double()
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-9)).item()
@@ -269,3 +273,44 @@ def test_conv_h16_halo_kernel(dt, case):
         refp = F.conv2d(F.group_norm(x.float(), 32, g, bt, eps=1e-6).to(dt).float(), w.to(dt).float(), b, padding=1)
         refp = refp + (0 if res is None else res.float())
         assert _rel(plain_gn.permute(0, 3, 1, 2), refp) <= 4 * EPS[dt], "GroupNorm without swish fused into the staging"
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("B", [1, 2])
+def test_attn_block_front_end_fused_matches_the_separate_launches(dt, B, monkeypatch):
+    """ABI v9: GroupNorm + q | k | v + fragment split as one launch in front of the fused attention (sgam_attn_block_h16) against
+    the normalise pass + generic GEMM + split launch it replaces, and against the fp32 oracle of the block"""
+    from oracle import vqgan as OV
+    from sgam_neurips22_amd.generative_sensing_module.modules.diffusionmodules import model as dm
+    tdt = ops.DTYPES[dt]
+    mod = dm.AttnBlock(256)
+    sd = testing.synthetic_state_dict(mod.state_dict(), seed=7)
+    mod.load_state_dict(sd)
+    mod = mod.to(DEV).eval()
+    # the block input as its producer leaves it: a 16-bit 3x3 convolution's output with its chunk statistics
+    src = ops.cast(ops.nchw_to_nhwc(testing.seeded_tensor("ab.src", (B, 256, 64, 64), 1.0, 0.2).to(DEV)), tdt)
+    w = testing.seeded_tensor("ab.w", (256, 256, 3, 3), scale=(1.0 / (256 * 9)) ** 0.5).to(DEV)
+    pw = ops.pack_conv_weight(w, dtype=tdt)
+    pw._sgam_frag_src = w
+    x = ops.conv2d_nhwc(src, pw, None, cout=256, kh=3, kw=3, pad_t=1, pad_l=1)
+    assert hasattr(x, "_gn_partials") and x._gn_partials[1] > 0
+    with torch.no_grad():
+        monkeypatch.setattr(ops, "ATTN_BLOCK_H16", False)
+        recs0, _ = ops.kernel_timeline(lambda: mod.forward_nhwc(x))
+        sep = mod.forward_nhwc(x).float()
+        monkeypatch.setattr(ops, "ATTN_BLOCK_H16", True)
+        recs1, _ = ops.kernel_timeline(lambda: mod.forward_nhwc(x))
+        fused = mod.forward_nhwc(x).float()
+        again = mod.forward_nhwc(x).float()
+    names1 = [r[0] for r in recs1]
+    assert any("attn_qkv_gn_h16" in k for k in names1), names1
+    assert not any("gn_apply" in k or "split_kv" in k for k in names1), names1
+    assert len(recs1) == len(recs0) - 3, ([r[0] for r in recs0], names1)
+    assert torch.equal(fused, again)
+    ref = OV.attn_block({"a." + k: v for k, v in sd.items()}, "a", x.float().permute(0, 3, 1, 2).cpu()).permute(0, 2, 3, 1)
+    tol = 2 ** -6 if dt == "bf16" else 2 ** -9           # a few roundings of an O(1) activation in the mode's precision
+    scale = ref.abs().max().item()
+    assert _maxerr(fused, ref) <= tol * scale and _maxerr(sep, ref) <= tol * scale
+    # the two forms round the same fp32 values to 16 bits at the same places (the GEMM's summation order differs): a flip of
+    # one 16-bit ulp somewhere, never more
+    assert _maxerr(fused, sep) <= (2 ** -7 if dt == "bf16" else 2 ** -10) * scale
