@@ -360,9 +360,31 @@ int sgam_attention_h16_batched(const void *q, const void *k, const void *v, int3
  *   workspace  sgam_attn_block_h16_workspace_bytes(n, C, B)
  * sgam_groupnorm_table_from_partials is the finalize half of sgam_groupnorm_from_partials_* on its own: the {scale, shift} table
  * [B][C][2] fp32 (scale = rstd gamma, shift = beta - mean scale) for a consumer that normalises while staging. */
+/* (ABI v9) The whole AttnBlock of the split-fp32 path in three launches — reference modules/diffusionmodules/model.py:168-192,
+ * `h_ = self.norm(x); q, k, v = self.q(h_), self.k(h_), self.v(h_); ...; return x + self.proj_out(h_)`: the fused front end (GroupNorm in
+ * the operand staging of the stacked q | k | v projection, q row-major, K / V^T written straight in the attention's hi / lo fragment order —
+ * the arithmetic of sgam_gemm_gn_f32x + the split launch it replaces, equal to fp32 round-off), the one-pass attention, and sgam_attention_proj_f32x_batched's merge +
+ * proj_out + residual (= x).  mean_rstd [B][32][2] (sgam_groupnorm_stats_from_partials_f32); wqkv_planes / wqkv_scale: sgam_split_rows_f32x of
+ * the stacked [3 C][C] weight with the rows of every 32-row tile permuted so that row 8 j + 4 h + i holds channel 16 h + 4 j + i; bqkv [3 C] in
+ * natural order; wp_planes / wp_scale / bp: proj_out as for sgam_attention_proj_f32x_batched; gn_partial / gn_acc as there.  C == 256,
+ * n % 256 == 0, scale a power of two; workspace: sgam_attn_block_f32x_workspace_bytes(n, C, B). */
+int64_t sgam_attn_block_f32x_workspace_bytes(int32_t n, int32_t C, int32_t B);
+int sgam_attn_block_f32x(const float *x, int32_t ldx, const float *mean_rstd, const float *gamma, const float *beta, const void *wqkv_planes,
+                         float wqkv_scale, const float *bqkv, int32_t n, int32_t C, int32_t B, float scale, const void *wp_planes,
+                         float wp_scale, const float *bp, float *out, int32_t ldc, double *gn_partial, int32_t gn_acc, void *workspace,
+                         int64_t workspace_bytes, void *stream);
 int sgam_groupnorm_table_from_partials(const double *partial, int32_t nchunk, const float *gamma, const float *beta,
                                        float *scale_shift, int32_t B, int32_t HW, int32_t C, int32_t groups, float eps, void *stream);
 int sgam_pack_qkv_weight_h16(const float *w, void *w_frag, int32_t ht, int32_t C, void *stream);
+/* sgam_pack_weight_tp_h16: any [rows][C] 1 x 1 weight in that fragment order (rows % 32 == 0); sgam_attn_block_proj_h16: the WHOLE block —
+ * sgam_attn_block_h16 with the merge of the key ranges fused into proj_out + residual (= x), model.py:187-191: out = x + proj_out(h_),
+ * [B n][ldo] 16-bit, ldo % 8 == 0; wp_frag = sgam_pack_weight_tp_h16(proj_out.weight, rows = C); bp [C] or NULL; gn_partial_out (optional)
+ * [B][n / 32][32][2] fp64 chunk statistics of the STORED output for the GroupNorm that follows. */
+int sgam_pack_weight_tp_h16(const float *w, void *w_frag, int32_t ht, int32_t rows, int32_t C, void *stream);
+int sgam_attn_block_proj_h16(const void *x, int32_t ldx, const double *gn_partial, int32_t nchunk, const float *gamma, const float *beta,
+                             float eps, const void *w_frag, const float *bias, int32_t ht, int32_t n, int32_t C, int32_t B, float scale,
+                             const void *wp_frag, const float *bp, double *gn_partial_out, void *out, int32_t ldo, void *workspace,
+                             int64_t workspace_bytes, void *stream);
 int64_t sgam_attn_block_h16_workspace_bytes(int32_t n, int32_t C, int32_t B);
 int sgam_attn_block_h16(const void *x, int32_t ldx, const double *gn_partial, int32_t nchunk, const float *gamma, const float *beta,
                         float eps, const void *w_frag, const float *bias, int32_t ht, int32_t n, int32_t C, int32_t B, float scale,

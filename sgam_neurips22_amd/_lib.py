@@ -149,8 +149,14 @@ PROTOTYPES = {
                                                  c_i32, c_vp, c_i32, c_vp, c_i64, c_vp]),
     "sgam_attention_h16_batched_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
     "sgam_attention_h16_batched": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_i32, c_vp, c_i64, c_vp]),
+    "sgam_attn_block_f32x_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
+    "sgam_attn_block_f32x": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_f32, c_vp, c_vp, c_i32,
+                                     c_vp, c_i32, c_vp, c_i64, c_vp]),
     "sgam_groupnorm_table_from_partials": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp]),
     "sgam_pack_qkv_weight_h16": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "sgam_pack_weight_tp_h16": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "sgam_attn_block_proj_h16": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp,
+                                         c_vp, c_vp, c_i32, c_vp, c_i64, c_vp]),
     "sgam_attn_block_h16_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
     "sgam_attn_block_h16": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_i32,
                                     c_vp, c_i64, c_vp]),

@@ -580,6 +580,157 @@ __global__ __launch_bounds__(256) void attn_combine_proj_f32x_kernel(const CombP
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Front end of the AttnBlock on the split-fp32 path, ONE launch (round 5): GroupNorm applied while the 64 x 256 operand panel is
+// staged + the stacked q | k | v projection — the arithmetic of gemm_gn_f32x_kernel<true, 256>, operation for operation (same
+// normalisation expression, the same three MFMAs per product in the same order, the same un-scale + bias) — computed TRANSPOSED
+// (weights = MFMA rows, tokens = columns, MFMA row 8 j + 4 h + i of a 32-channel tile carrying channel 16 h + 4 j + i) so that a lane
+// holds 16 consecutive channels of one token: q leaves row-major, K as the flash kernel's hi / lo fragment pieces (512 contiguous
+// bytes per 32 lanes), V^T through an fp32 LDS transpose.  attn_split_kv_kernel and its graph edge disappear; results equal (fp32 round-off: measured, not bit-identical — the transposed MFMA chain rounds differently)
+// to the gemm_gn_f32x + split sequence (tests/test_gpu_ops.py).
+// ---------------------------------------------------------------------------------------------------------------------
+struct QkvXParams {
+    const float *x;                 // [nt][ldx] fp32 block input
+    const float *mean_rstd;         // [B][32][2]
+    const float *gamma, *beta;      // [AD]
+    const unsigned short *w;        // split_rows planes of the ROW-PERMUTED stacked weight: [3 AD / 32][AD / 32][256 pieces][8 halfs]
+    const float *bias;              // [3 AD] (natural channel order)
+    float *q;                       // [nt][AD] fp32
+    unsigned short *kf, *vf;        // attn_split_kv_kernel's layout
+    int32_t *range_flag;
+    int ldx, n_img;
+    float inv_w_scale;
+};
+
+__global__ __launch_bounds__(256, 2) void attn_qkv_gn_f32x_kernel(const QkvXParams p) {
+    constexpr int LDK = AD + 8;                                       // panel row pitch in halfs
+    constexpr int VLD = 64 + 4;                                       // V transpose: [128 channels][64 tokens + pad] fp32
+    __shared__ __attribute__((aligned(16))) unsigned short sA[2][64][LDK];              // hi plane, lo plane
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * 64, by = blockIdx.y;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int b = m0 / p.n_img;
+    constexpr int cpg = AD / 32, WD = 4, KS = AD / 16, NIT = 64 * (AD / 4) / 256;
+    const unsigned short *wt = p.w + (int64_t)(by * 4 + wave) * (AD / 32) * 2048;
+    auto wfrag = [&](int kstep, u32x4 &hi, u32x4 &lo) {
+        const unsigned short *q = wt + (int64_t)(kstep >> 1) * 2048 + (((kstep & 1) * 2 + lh) * 32 + lr) * 8;
+        hi = *reinterpret_cast<const u32x4 *>(q);
+        lo = *reinterpret_cast<const u32x4 *>(q + 1024);
+    };
+    u32x4 wh[WD], wl[WD];
+#pragma unroll
+    for (int t = 0; t < WD; ++t) wfrag(t, wh[t], wl[t]);
+    // ---- stage: thread -> (row, 4 consecutive channels), 16 rounds of 4 rows (gemm_gn_f32x_kernel's map and arithmetic)
+    {
+        const int prow = tid / (AD / 4), pc4 = (tid % (AD / 4)) * 4;
+        f32x4 xr[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) xr[it] = *reinterpret_cast<const f32x4 *>(p.x + (int64_t)(m0 + prow + it * 4) * p.ldx + pc4);
+        const int g = pc4 / cpg;
+        const float mean = p.mean_rstd[(b * 32 + g) * 2], rstd = p.mean_rstd[(b * 32 + g) * 2 + 1];
+        const f32x4 ga = *reinterpret_cast<const f32x4 *>(p.gamma + pc4), be = *reinterpret_cast<const f32x4 *>(p.beta + pc4);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int row = prow + it * 4;
+            f32x4 v = xr[it];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (v[e] - mean) * rstd * ga[e] + be[e];
+            unsigned hi[2], lo[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float a0 = v[2 * e], a1 = v[2 * e + 1];
+                const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
+                const _Float16 l0 = (_Float16)(a0 - (float)h0), l1 = (_Float16)(a1 - (float)h1);
+                hi[e] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+                lo[e] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+            }
+            *reinterpret_cast<unsigned long long *>(&sA[0][row][pc4]) = (unsigned long long)hi[0] | ((unsigned long long)hi[1] << 32);
+            *reinterpret_cast<unsigned long long *>(&sA[1][row][pc4]) = (unsigned long long)lo[0] | ((unsigned long long)lo[1] << 32);
+        }
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < KS; ++t) {
+        const u32x4 ah = wh[t % WD], al = wl[t % WD];
+        wfrag(t + WD < KS ? t + WD : KS - 1, wh[t % WD], wl[t % WD]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const u32x4 xh = *reinterpret_cast<const u32x4 *>(&sA[0][j * 32 + lr][t * 16 + lh * 8]);
+            const u32x4 xl = *reinterpret_cast<const u32x4 *>(&sA[1][j * 32 + lr][t * 16 + lh * 8]);
+            acc[j] = mfma16(ah, xh, acc[j]);                          // x_hi . w_hi, x_hi . w_lo, x_lo . w_hi: gemm_gn_f32x's order
+            acc[j] = mfma16(al, xh, acc[j]);
+            acc[j] = mfma16(ah, xl, acc[j]);
+        }
+    }
+    // ---- epilogue: lane (token lr of column tile j, half lh) holds channels cw + 0..15 of this 128-channel slab
+    const int cw = wave * 32 + 16 * lh;
+    float bias[16];
+#pragma unroll
+    for (int e4 = 0; e4 < 4; ++e4) {
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(p.bias + by * 128 + cw + e4 * 4);
+        bias[4 * e4] = bv[0], bias[4 * e4 + 1] = bv[1], bias[4 * e4 + 2] = bv[2], bias[4 * e4 + 3] = bv[3];
+    }
+    float v[2][16], gs = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            v[j][e] = acc[j][e] * p.inv_w_scale + bias[e];
+            gs += v[j][e];
+        }
+    if (p.range_flag && sgam_not_finite(gs)) atomicOr(p.range_flag, 1);          // an operand left fp16's range
+    if (by < 2) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float *dst = p.q + (int64_t)(m0 + j * 32 + lr) * AD + by * 128 + cw;
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4)
+                *reinterpret_cast<f32x4 *>(dst + 4 * e4) = f32x4{v[j][4 * e4], v[j][4 * e4 + 1], v[j][4 * e4 + 2], v[j][4 * e4 + 3]};
+        }
+    } else if (by < 4) {                                              // K pieces (plane, k-step lh, half h, key lr) of d-tile (by - 2) 4 + wave
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t kb = (m0 >> 5) + j;
+            unsigned short *dst = p.kf + ((kb * 8 + (by - 2) * 4 + wave) * 256 + (lh * 2) * 32 + lr) * 8;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                u32x4 hi, lo;
+                split8(&v[j][8 * h], hi, lo);
+                *reinterpret_cast<u32x4 *>(dst + h * 32 * 8) = hi;
+                *reinterpret_cast<u32x4 *>(dst + h * 32 * 8 + 128 * 8) = lo;
+            }
+        }
+    } else {                                                          // V^T pieces hold 8 KEYS of one channel: transpose in LDS (fp32)
+        __syncthreads();
+        float *vt = reinterpret_cast<float *>(&sA[0][0][0]);          // [128][VLD]
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) vt[(cw + e) * VLD + j * 32 + lr] = v[j][e];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int pp = tid + 256 * k;
+            const int drow = pp & 31, th = (pp >> 5) & 3, tl = (pp >> 7) & 3, kbl = pp >> 9;
+            const float *src = vt + (tl * 32 + drow) * VLD + kbl * 32 + 4 * (th & 1) + 16 * (th >> 1);
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(src), c = *reinterpret_cast<const f32x4 *>(src + 8);
+            const float vv[8] = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+            u32x4 hi, lo;
+            split8(vv, hi, lo);
+            const int64_t kb = (m0 >> 5) + kbl;
+            unsigned short *dst = p.vf + ((kb * 8 + (by - 4) * 4 + tl) * 256 + th * 32 + drow) * 8;
+            *reinterpret_cast<u32x4 *>(dst) = hi;
+            *reinterpret_cast<u32x4 *>(dst + 128 * 8) = lo;
+        }
+    }
+}
+
 // =====================================================================================================================
 // 16-bit throughput variant (bf16 `HT` = 0 / fp16 `HT` = 1 activations, the h16.hip mode): the same pass over the keys with
 // ONE MFMA per product and single-plane fragments — half the LDS block (16 KB of K + 16 KB of V^T per 32 keys), a 64-VGPR
@@ -947,6 +1098,164 @@ __global__ __launch_bounds__(256) void attn_combine_h16_kernel(const float *__re
     *reinterpret_cast<u32x2 *>(dst) = pk;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Merge of the key ranges + AttnBlock.proj_out + residual of the 16-bit mode in ONE launch (round 5; the split-fp32 path's
+// attn_combine_proj_f32x_kernel re-balanced for one MFMA per product).  A workgroup owns one 32-query tile: thread = (query row,
+// 32 channels) merges the NS normalised fp16 partial rows exactly as attn_combine_h16_kernel does (same weights, same order of the
+// fused multiply-adds, the same rounding of the merged value to 16 bits), writes the tile into LDS as the B operand of the TRANSPOSED
+// projection (proj_out's weights = MFMA rows, sgam_pack_weight_tp_h16; four wavefronts x 64 output channels), adds bias and the
+// residual, rounds, stores 32 bytes per lane and leaves the GroupNorm statistics of the STORED block output (one chunk per tile).
+// ---------------------------------------------------------------------------------------------------------------------
+struct CombProjHParams {
+    const unsigned short *ws_o;     // normalised fp16 partials [ns][n][AD]
+    const float *ws_ml;             // {max, sum} [ns][n][2]
+    const unsigned short *w;        // proj_out weights, transposed-product fragment order [AD / 32][AD / 16][64 lanes][8 halfs]
+    const float *bias;              // [AD] or NULL
+    const unsigned short *res;      // residual [n][ldr] (the block's input x) or NULL
+    unsigned short *out;            // [n][ldc]
+    double *gn_partial;             // optional [n / 32][32][2]
+    int n, ldr, ldc;
+};
+
+template <int HT, int NS>
+__global__ __launch_bounds__(256) void attn_combine_proj_h16_kernel(const CombProjHParams p) {
+    constexpr int LDK = AD + 8;
+    __shared__ __attribute__((aligned(16))) unsigned short sB[32 * LDK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qt = blockIdx.x, m0 = qt * 32;
+    const int lr = lane & 31, lh = lane >> 5;
+    constexpr int WD = 4, KS = AD / 16;
+    const unsigned short *wt0 = p.w + (int64_t)(wave * 2) * KS * 512 + lane * 8, *wt1 = wt0 + (int64_t)KS * 512;
+    // ---- merge: thread = (row r, channels 32 seg + 0..31): all NS x 4 sixteen-byte loads of the thread in flight at once
+    {
+        const int r = tid >> 3, seg = tid & 7;
+        const int64_t row = (int64_t)m0 + r;
+        u32x4 o[NS][4];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[s][k] = *reinterpret_cast<const u32x4 *>(p.ws_o + ((int64_t)s * p.n + row) * AD + seg * 32 + k * 8);
+        float w[NS], l[NS], M = -INFINITY, L = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const float *ml = p.ws_ml + ((int64_t)s * p.n + row) * 2;
+            w[s] = ml[0];
+            l[s] = ml[1];
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) M = fmaxf(M, w[s]);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            w[s] = __builtin_amdgcn_exp2f(w[s] - M) * l[s];
+            L += w[s];
+        }
+        const float inv = 1.0f / L;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    acc[e] += w[s] * (float)__builtin_bit_cast(_Float16, (unsigned short)((o[s][k][e >> 1] >> (16 * (e & 1))) & 0xffffu));
+            u32x4 pk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk[e] = HM<HT>::pack2(acc[2 * e] * inv, acc[2 * e + 1] * inv);
+            *reinterpret_cast<u32x4 *>(&sB[r * LDK + seg * 32 + k * 8]) = pk;
+        }
+    }
+    u32x4 wf[WD][2];
+#pragma unroll
+    for (int t = 0; t < WD; ++t) {
+        wf[t][0] = *reinterpret_cast<const u32x4 *>(wt0 + t * 512);
+        wf[t][1] = *reinterpret_cast<const u32x4 *>(wt1 + t * 512);
+    }
+    // residual rows of this lane's outputs: token m0 + lr, channels 64 wave + 32 rt + 16 lh + 0..15, requested under the MFMAs
+    u32x4 rres[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            rres[rt][h] = p.res ? *reinterpret_cast<const u32x4 *>(p.res + (int64_t)(m0 + lr) * p.ldr + wave * 64 + rt * 32 + 16 * lh + 8 * h)
+                                : u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+    f32x16 acc[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[rt][e] = 0.f;
+#pragma unroll
+    for (int t = 0; t < KS; ++t) {
+        const u32x4 a0 = wf[t % WD][0], a1 = wf[t % WD][1];
+        const int nx = t + WD < KS ? t + WD : KS - 1;
+        wf[t % WD][0] = *reinterpret_cast<const u32x4 *>(wt0 + nx * 512);
+        wf[t % WD][1] = *reinterpret_cast<const u32x4 *>(wt1 + nx * 512);
+        __builtin_amdgcn_sched_barrier(0);
+        const u32x4 bx = *reinterpret_cast<const u32x4 *>(&sB[lr * LDK + t * 16 + lh * 8]);
+        acc[0] = HM<HT>::mfma(a0, bx, acc[0]);
+        acc[1] = HM<HT>::mfma(a1, bx, acc[1]);
+    }
+    // ---- epilogue
+    double gsum[2][2], gsq[2][2];                                     // [row tile][group of 8 channels inside the lane's 16]
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int c0 = wave * 64 + rt * 32 + 16 * lh;
+        float bias[16];
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+            const f32x4 bv = p.bias ? *reinterpret_cast<const f32x4 *>(p.bias + c0 + e4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            bias[4 * e4] = bv[0], bias[4 * e4 + 1] = bv[1], bias[4 * e4 + 2] = bv[2], bias[4 * e4 + 3] = bv[3];
+        }
+        u32x4 pk[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float s = 0.f, ss = 0.f;
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) {
+                const unsigned ru = rres[rt][h][e2];
+                float r0, r1;
+                if (HT == 0) r0 = __builtin_bit_cast(float, ru << 16), r1 = __builtin_bit_cast(float, ru & 0xffff0000u);
+                else r0 = (float)__builtin_bit_cast(_Float16, (unsigned short)(ru & 0xffffu)), r1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(ru >> 16));
+                const int e = 8 * h + 2 * e2;
+                const unsigned u = HM<HT>::pack2((acc[rt][e] + bias[e]) + r0, (acc[rt][e + 1] + bias[e + 1]) + r1);
+                pk[h][e2] = u;
+                float f0, f1;                                          // the statistics describe the STORED (rounded) tensor
+                if (HT == 0) f0 = __builtin_bit_cast(float, u << 16), f1 = __builtin_bit_cast(float, u & 0xffff0000u);
+                else f0 = (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu)), f1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16));
+                s += f0 + f1;
+                ss += f0 * f0 + f1 * f1;
+            }
+            gsum[rt][h] = (double)s;
+            gsq[rt][h] = (double)ss;
+        }
+        unsigned short *dst = p.out + (int64_t)(m0 + lr) * p.ldc + c0;
+        *reinterpret_cast<u32x4 *>(dst) = pk[0];
+        *reinterpret_cast<u32x4 *>(dst + 8) = pk[1];
+    }
+    if (p.gn_partial) {
+        // a group of the next GroupNorm = 8 channels: this lane's (rt, h); the 32 tokens of the tile sit in the 32 lanes of a half-wave
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                double ds = gsum[rt][h], dss = gsq[rt][h];
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) {
+                    ds += __shfl_xor(ds, o, 64);
+                    dss += __shfl_xor(dss, o, 64);
+                }
+                if (lr == 0) {
+                    const int g = (wave * 64 + rt * 32 + 16 * lh + 8 * h) / 8;
+                    double *o = p.gn_partial + ((int64_t)qt * 32 + g) * 2;
+                    o[0] = ds;
+                    o[1] = dss;
+                }
+            }
+    }
+}
+
 }  // namespace
 
 // key ranges per image: enough workgroups (n_img / 128 query blocks x ranges x images) to fill 256 CUs and as few ranges as
@@ -1140,15 +1449,20 @@ __global__ __launch_bounds__(256) void pack_qkv_weight_h16_kernel(const float *_
 }
 }  // namespace
 
-extern "C" int sgam_pack_qkv_weight_h16(const float *w, void *w_frag, int32_t ht, int32_t C, void *stream) {
-    if (!w || !w_frag || C != AD || (ht != 0 && ht != 1)) return SGAM_EINVAL;
+// [rows][C] fp32 weight of a 1 x 1 convolution -> transposed-product fragment order (rows % 32 == 0, C == 256)
+extern "C" int sgam_pack_weight_tp_h16(const float *w, void *w_frag, int32_t ht, int32_t rows, int32_t C, void *stream) {
+    if (!w || !w_frag || C != AD || rows < 32 || rows % 32 != 0 || (ht != 0 && ht != 1)) return SGAM_EINVAL;
     if (!sgam_aligned16(w_frag)) return SGAM_EALIGN;
-    const int pieces = 3 * AD * AD / 8;
+    const int pieces = rows * AD / 8;
     hipStream_t s = sgam_stream(stream);
-    if (ht == 0) SGAM_KLAUNCH(pack_qkv_weight_h16_kernel<0>, dim3(pieces / 256), dim3(256), 0, s, w, (unsigned short *)w_frag, 3 * AD);
-    else SGAM_KLAUNCH(pack_qkv_weight_h16_kernel<1>, dim3(pieces / 256), dim3(256), 0, s, w, (unsigned short *)w_frag, 3 * AD);
+    if (ht == 0) SGAM_KLAUNCH(pack_qkv_weight_h16_kernel<0>, dim3(pieces / 256), dim3(256), 0, s, w, (unsigned short *)w_frag, rows);
+    else SGAM_KLAUNCH(pack_qkv_weight_h16_kernel<1>, dim3(pieces / 256), dim3(256), 0, s, w, (unsigned short *)w_frag, rows);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
+}
+
+extern "C" int sgam_pack_qkv_weight_h16(const float *w, void *w_frag, int32_t ht, int32_t C, void *stream) {
+    return sgam_pack_weight_tp_h16(w, w_frag, ht, 3 * C, C, stream);
 }
 
 extern "C" int sgam_groupnorm_table_from_partials(const double *partial, int32_t nchunk, const float *gamma, const float *beta,
@@ -1165,10 +1479,13 @@ extern "C" int64_t sgam_attn_block_h16_workspace_bytes(int32_t n, int32_t C, int
 // out = softmax(q k^T scale) v with q | k | v = GroupNorm(x) Wqkv^T + b — everything of the AttnBlock ahead of proj_out, 4 launches
 // (table, projection, flash, merge).  x [B n][ldx] 16-bit; gn_partial / nchunk: the chunk statistics x's producer left
 // ([B][nchunk][32][2] fp64, or nchunk = 0: its accumulator record); gamma, beta [C]; w_frag: sgam_pack_qkv_weight_h16; bias [3 C].
-extern "C" int sgam_attn_block_h16(const void *x, int32_t ldx, const double *gn_partial, int32_t nchunk, const float *gamma, const float *beta,
-                                   float eps, const void *w_frag, const float *bias, int32_t ht, int32_t n, int32_t C, int32_t B, float scale,
-                                   void *out, int32_t ldo, void *workspace, int64_t workspace_bytes, void *stream) {
+static int attn_block_h16_impl(const void *x, int32_t ldx, const double *gn_partial, int32_t nchunk, const float *gamma, const float *beta,
+                               float eps, const void *w_frag, const float *bias, int32_t ht, int32_t n, int32_t C, int32_t B, float scale,
+                               const void *wp_frag, const float *bp, double *gn_partial_out, void *out, int32_t ldo, void *workspace,
+                               int64_t workspace_bytes, void *stream) {
     if (!x || !gn_partial || !gamma || !beta || !w_frag || !bias || !out || !workspace || (ht != 0 && ht != 1)) return SGAM_EINVAL;
+    if (wp_frag && (!sgam_aligned16(wp_frag) || (bp && !sgam_aligned16(bp)) || (gn_partial_out && !sgam_aligned16(gn_partial_out)) || ldo % 8 != 0))
+        return SGAM_EALIGN;
     const int64_t need = sgam_attn_block_h16_workspace_bytes(n, C, B);
     if (need < 0) return SGAM_EINVAL;
     const int nsplit = attn_nsplit(n, B), nt = B * n;
@@ -1202,6 +1519,28 @@ extern "C" int sgam_attn_block_h16(const void *x, int32_t ldx, const double *gn_
     if (ht == 0) SGAM_KLAUNCH(attn_flash_h16_kernel<0>, grid, dim3(256), 0, s, p);
     else SGAM_KLAUNCH(attn_flash_h16_kernel<1>, grid, dim3(256), 0, s, p);
     SGAM_LAUNCH_CHECK();
+    if (wp_frag) {                                                    // merge + proj_out + residual (= x) in one launch
+        CombProjHParams c;
+        c.ws_o = (const unsigned short *)ws_o; c.ws_ml = ws_ml; c.w = (const unsigned short *)wp_frag; c.bias = bp;
+        c.res = (const unsigned short *)x; c.out = (unsigned short *)out; c.gn_partial = gn_partial_out; c.n = nt; c.ldr = ldx; c.ldc = ldo;
+        if (sgam_i_prof_on) sgam_i_prof_shape(nt, AD, AD, 1);
+        if (sgam_i_prof_on) sgam_i_prof_work(2.0 * nt * (double)AD * AD, 2.0 * ((double)nsplit * nt * AD + 2.0 * nt * AD + (double)AD * AD));
+#define HCOMBPROJ(HT_, NS_) SGAM_KLAUNCH((attn_combine_proj_h16_kernel<HT_, NS_>), dim3(nt / 32), dim3(256), 0, s, c)
+        switch (nsplit * 2 + (ht ? 1 : 0)) {
+            case 16: HCOMBPROJ(0, 8); break;
+            case 17: HCOMBPROJ(1, 8); break;
+            case 8: HCOMBPROJ(0, 4); break;
+            case 9: HCOMBPROJ(1, 4); break;
+            case 4: HCOMBPROJ(0, 2); break;
+            case 5: HCOMBPROJ(1, 2); break;
+            case 2: HCOMBPROJ(0, 1); break;
+            case 3: HCOMBPROJ(1, 1); break;
+            default: return SGAM_EINVAL;
+        }
+#undef HCOMBPROJ
+        SGAM_LAUNCH_CHECK();
+        return SGAM_OK;
+    }
 #define HCOMBINE2(HT_, NS_) SGAM_KLAUNCH((attn_combine_h16_kernel<HT_, NS_>), cgrid, dim3(256), 0, s, ws_o, ws_ml, (unsigned short *)out, ldo, nt)
     switch (nsplit * 2 + (ht ? 1 : 0)) {
         case 16: HCOMBINE2(0, 8); break;
@@ -1217,4 +1556,85 @@ extern "C" int sgam_attn_block_h16(const void *x, int32_t ldx, const double *gn_
 #undef HCOMBINE2
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
+}
+
+// ---- the whole AttnBlock of the split-fp32 path in three launches (ABI v9) -------------------------------------------------------
+extern "C" int64_t sgam_attn_block_f32x_workspace_bytes(int32_t n, int32_t C, int32_t B) {
+    const int64_t base = sgam_attention_f32x_batched_workspace_bytes(n, C, B);
+    return base < 0 ? -1 : base + (int64_t)B * n * AD * 4;            // + q [B n][C] fp32
+}
+
+// out = x + proj_out(attention(q, k, v)), q | k | v = GroupNorm(x) Wqkv^T + b: fused front end (attn_qkv_gn_f32x_kernel), flash kernel,
+// merge + proj_out + residual (attn_combine_proj_f32x_kernel).  wqkv_planes: sgam_split_rows_f32x of the stacked [3 C][C] weight whose
+// rows were permuted inside every 32-row tile so that row 8 j + 4 h + i holds channel 16 h + 4 j + i; bqkv in natural order.
+extern "C" int sgam_attn_block_f32x(const float *x, int32_t ldx, const float *mean_rstd, const float *gamma, const float *beta,
+                                    const void *wqkv_planes, float wqkv_scale, const float *bqkv, int32_t n, int32_t C, int32_t B, float scale,
+                                    const void *wp_planes, float wp_scale, const float *bp, float *out, int32_t ldc, double *gn_partial,
+                                    int32_t gn_acc, void *workspace, int64_t workspace_bytes, void *stream) {
+    if (!x || !mean_rstd || !gamma || !beta || !wqkv_planes || !bqkv || !wp_planes || !out || !workspace || !(wqkv_scale > 0.f) || !(wp_scale > 0.f))
+        return SGAM_EINVAL;
+    const int64_t need = sgam_attn_block_f32x_workspace_bytes(n, C, B);
+    if (need < 0 || ldx < C || ldx % 4 != 0 || ldc < C || n % 64 != 0) return SGAM_EINVAL;
+    int ex;
+    if (!(scale > 0.f) || frexpf(scale, &ex) != 0.5f) return SGAM_EINVAL;
+    if (workspace_bytes < need) return SGAM_EWORKSPACE;
+    if (!sgam_aligned16(x) || !sgam_aligned16(gamma) || !sgam_aligned16(beta) || !sgam_aligned16(wqkv_planes) || !sgam_aligned16(bqkv) ||
+        !sgam_aligned16(wp_planes) || !sgam_aligned16(workspace) || (gn_partial && !sgam_aligned16(gn_partial)))
+        return SGAM_EALIGN;
+    const int nsplit = attn_nsplit(n, B), nt = B * n;
+    if ((n / KB) % nsplit != 0) return SGAM_EINVAL;
+    hipStream_t s = sgam_stream(stream);
+    unsigned short *kf = (unsigned short *)workspace;
+    unsigned short *vf = kf + (int64_t)nt * AD * 2;
+    float *ws_o = (float *)(vf + (int64_t)nt * AD * 2);
+    float *ws_ml = ws_o + (int64_t)nsplit * nt * AD;
+    float *qb = ws_ml + (int64_t)nsplit * nt * 2;
+    QkvXParams g;
+    g.x = x; g.mean_rstd = mean_rstd; g.gamma = gamma; g.beta = beta; g.w = (const unsigned short *)wqkv_planes; g.bias = bqkv;
+    g.q = qb; g.kf = kf; g.vf = vf; g.range_flag = sgam_i_range_flag; g.ldx = ldx; g.n_img = n; g.inv_w_scale = 1.0f / wqkv_scale;
+    if (sgam_i_prof_on) sgam_i_prof_shape(nt, 3 * AD, AD, 1);
+    if (sgam_i_prof_on) sgam_i_prof_work(2.0 * nt * 3.0 * AD * AD, 4.0 * (4.0 * nt * AD + 3.0 * AD * AD));
+    SGAM_KLAUNCH(attn_qkv_gn_f32x_kernel, dim3(nt / 64, 6), dim3(256), 0, s, g);
+    SGAM_LAUNCH_CHECK();
+    AttnParams p;
+    p.q = qb; p.kf = kf; p.vf = vf; p.ws_o = ws_o; p.ws_ml = ws_ml;
+    p.ld = AD; p.n = nt; p.n_img = n; p.nsplit = nsplit; p.blocks_per_split = n / KB / nsplit; p.qscale = scale;
+    if (sgam_i_prof_on) sgam_i_prof_work(4.0 * B * n * (double)n * AD, 4.0 * 4.0 * nt * AD);
+    SGAM_KLAUNCH(attn_flash_f32x_kernel, dim3(nt / 128 * nsplit), dim3(256), 0, s, p);
+    SGAM_LAUNCH_CHECK();
+    CombProjParams c;
+    c.ws_o = ws_o; c.ws_ml = ws_ml; c.w = (const unsigned short *)wp_planes; c.bias = bp; c.res = x; c.out = out;
+    c.gn_partial = gn_partial; c.gn_acc = (gn_partial && gn_acc) ? 1 : 0; c.n_img = n;
+    c.range_flag = sgam_i_range_flag; c.n = nt; c.ns = nsplit; c.ldr = ldx; c.ldc = ldc;
+    c.inv_w_scale = 1.0f / wp_scale;
+    if (sgam_i_prof_on) sgam_i_prof_shape(nt, AD, AD, 1);
+    if (sgam_i_prof_on) sgam_i_prof_work(2.0 * nt * (double)AD * AD, 4.0 * ((double)nsplit * nt * AD + 2.0 * nt * AD + (double)AD * AD));
+    switch (nsplit) {
+        case 8: SGAM_KLAUNCH(attn_combine_proj_f32x_kernel<8>, dim3(nt / 32), dim3(256), 0, s, c); break;
+        case 4: SGAM_KLAUNCH(attn_combine_proj_f32x_kernel<4>, dim3(nt / 32), dim3(256), 0, s, c); break;
+        case 2: SGAM_KLAUNCH(attn_combine_proj_f32x_kernel<2>, dim3(nt / 32), dim3(256), 0, s, c); break;
+        case 1: SGAM_KLAUNCH(attn_combine_proj_f32x_kernel<1>, dim3(nt / 32), dim3(256), 0, s, c); break;
+        default: return SGAM_EINVAL;
+    }
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+extern "C" int sgam_attn_block_h16(const void *x, int32_t ldx, const double *gn_partial, int32_t nchunk, const float *gamma, const float *beta,
+                                   float eps, const void *w_frag, const float *bias, int32_t ht, int32_t n, int32_t C, int32_t B, float scale,
+                                   void *out, int32_t ldo, void *workspace, int64_t workspace_bytes, void *stream) {
+    return attn_block_h16_impl(x, ldx, gn_partial, nchunk, gamma, beta, eps, w_frag, bias, ht, n, C, B, scale, nullptr, nullptr, nullptr, out, ldo,
+                               workspace, workspace_bytes, stream);
+}
+
+// the WHOLE 16-bit AttnBlock: sgam_attn_block_h16 with the merge of the key ranges fused into proj_out + residual (= x):
+// out = x + proj_out(attention) [B n][ldo] 16-bit; wp_frag: sgam_pack_weight_tp_h16 of proj_out's [C][C] weight; bp [C] or NULL;
+// gn_partial_out (optional): [B][n / 32][32][2] fp64 chunk statistics of `out` for the GroupNorm that follows
+extern "C" int sgam_attn_block_proj_h16(const void *x, int32_t ldx, const double *gn_partial, int32_t nchunk, const float *gamma,
+                                        const float *beta, float eps, const void *w_frag, const float *bias, int32_t ht, int32_t n, int32_t C,
+                                        int32_t B, float scale, const void *wp_frag, const float *bp, double *gn_partial_out, void *out,
+                                        int32_t ldo, void *workspace, int64_t workspace_bytes, void *stream) {
+    if (!wp_frag) return SGAM_EINVAL;
+    return attn_block_h16_impl(x, ldx, gn_partial, nchunk, gamma, beta, eps, w_frag, bias, ht, n, C, B, scale, wp_frag, bp, gn_partial_out, out,
+                               ldo, workspace, workspace_bytes, stream);
 }

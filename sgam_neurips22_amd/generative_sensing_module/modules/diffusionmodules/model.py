@@ -200,6 +200,21 @@ class AttnBlock(_NHWCModule):
         if x.dtype in ops.H16:
             return self._forward_nhwc_h16(x, wqkv, bqkv, wp, bp)
         fused_qkv = wkey == "f32x" and FUSE_NORM_INTO_QKV and ops.gemm_gn_fits(B * n, 3 * C, C, n)
+        pre = getattr(x, "_gn_partials", None)
+        if (fused_qkv and ops.ATTN_BLOCK_F32X and ops.ATTN_PROJ and ops.attention_fusable(n, C) and isinstance(wp, ops.SplitWeight)
+                and not (pre is not None and pre[1] == 0)):
+            # the whole block in three launches: GroupNorm + q | k | v with K / V^T written straight in the attention's fragment order
+            # (the GEMM + split launch's arithmetic, equal to fp32 round-off), one pass over the keys, merge + proj_out + residual (csrc/attention.hip)
+            if "f32x_perm" not in wqkvs:
+                w32 = wqkvs[torch.float32]
+                wqkvs["f32x_perm"] = ops.split_rows(ops.permute_rows_for_transposed_product(w32), wqkv.scale)
+            mr = ops.groupnorm_meanrstd(x, self.norm.eps)
+            ob = ops.attn_block_f32x(x.reshape(B * n, C), mr, self.norm.weight.detach(), self.norm.bias.detach(), wqkvs["f32x_perm"], bqkv,
+                                     C, int(C) ** (-0.5), wp, bp, B=B)
+            out = ob.view(B, H, W, C)
+            if hasattr(ob, "_gn_partials"):
+                out._gn_partials = ob._gn_partials
+            return out
         if fused_qkv:
             # GroupNorm applied while the q | k | v GEMM stages its operand (csrc/gemm_gn_f32x.hip): no normalise pass
             pre = getattr(x, "_gn_partials", None)
@@ -272,6 +287,17 @@ def _attn_h16(self, x, wqkv, bqkv, wp, bp):
         wqkvs = self._wqkv
         if wkey not in wqkvs:
             wqkvs[wkey] = ops.pack_qkv_weight_h16(wqkvs[torch.float32], x.dtype)
+        if ops.ATTN_BLOCK_H16_PROJ:
+            pkey = ("proj_frag", x.dtype, self.proj_out.weight.data_ptr(), self.proj_out.weight._version)
+            if pkey not in wqkvs:
+                wqkvs[pkey] = (ops.pack_weight_tp_h16(self.proj_out.weight.detach().reshape(C, C).float().contiguous(), x.dtype),
+                               self.proj_out.bias.detach().float().contiguous())
+            ob = ops.attn_block_h16(x.reshape(B * n, C), x._gn_partials, self.norm.weight.detach(), self.norm.bias.detach(), self.norm.eps,
+                                    wqkvs[wkey], bqkv, C, scale, B=B, proj=wqkvs[pkey])
+            out = ob.view(B, H, W, C)
+            if hasattr(ob, "_gn_partials"):
+                out._gn_partials = ob._gn_partials
+            return out
         o = ops.attn_block_h16(x.reshape(B * n, C), x._gn_partials, self.norm.weight.detach(), self.norm.bias.detach(), self.norm.eps,
                                wqkvs[wkey], bqkv, C, scale, B=B)
         return self.proj_out.forward_nhwc(o.view(B, H, W, C), residual=x)

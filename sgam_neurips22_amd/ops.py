@@ -347,6 +347,9 @@ XFIXUP = os.environ.get("SGAM_XFIXUP", "0") == "1"
 # 16-bit AttnBlock: GroupNorm + q | k | v + fragment split as ONE launch in front of the fused attention (SGAM_ATTN_BLOCK_H16=0: the
 # normalise pass, the generic 1x1 GEMM and the split launch, as before)
 ATTN_BLOCK_H16 = os.environ.get("SGAM_ATTN_BLOCK_H16", "1") != "0"
+ATTN_BLOCK_H16_PROJ = os.environ.get("SGAM_ATTN_BLOCK_H16_PROJ", "1") != "0"    # ... and the merge of the key ranges fused into proj_out
+# split-fp32 AttnBlock as three launches (fused front end writes K / V^T in fragment order; SGAM_ATTN_BLOCK_F32X=0: q | k | v GEMM + split)
+ATTN_BLOCK_F32X = os.environ.get("SGAM_ATTN_BLOCK_F32X", "1") != "0"
 ARRIVE_COUNT = 4096
 
 
@@ -842,6 +845,50 @@ def attention_proj(qkv, C, scale, wp, bias, residual, out=None, B=1):
     return out
 
 
+# channel <-> MFMA-row permutation of the transposed products (attention.hip): row 8 j + 4 h + i of a 32-row tile carries channel 16 h + 4 j + i
+_TILE_CHANNEL_OF_ROW = [16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3) for r in range(32)]
+
+
+def permute_rows_for_transposed_product(w2d):
+    """(N, K) weight with the rows of every 32-row tile re-ordered for a kernel that computes the product transposed and wants a
+    lane's sixteen accumulator slots to be sixteen consecutive channels"""
+    N = w2d.shape[0]
+    assert N % 32 == 0
+    idx = (torch.arange(N, device=w2d.device).view(N // 32, 32)[:, torch.tensor(_TILE_CHANNEL_OF_ROW, device=w2d.device)]).reshape(-1)
+    return w2d.index_select(0, idx).contiguous()
+
+
+def attn_block_f32x(x2d, mean_rstd, gamma, beta, wqkv_perm, bqkv, C, scale, wp, bp, B=1, out=None):
+    """The whole AttnBlock of the split-fp32 path (reference diffusionmodules/model.py:168-192) in three launches: fused front end
+    (GroupNorm + q | k | v, K / V^T straight in fragment order), one-pass attention, merge + proj_out + residual x.  wqkv_perm: the
+    SplitWeight of permute_rows_for_transposed_product(stacked weight); statistics of the output travel as `_gn_partials`."""
+    _need_cuda(x2d)
+    nt = x2d.shape[0]
+    assert x2d.dtype == torch.float32 and x2d.shape[1] == C and x2d.stride(1) == 1 and nt % B == 0
+    assert isinstance(wp, SplitWeight) and isinstance(wqkv_perm, SplitWeight)
+    n = nt // B
+    lib = _lib.load()
+    ws_bytes = lib.sgam_attn_block_f32x_workspace_bytes(n, C, B)
+    if ws_bytes < 0:
+        raise SgamHipError(f"sgam_attn_block_f32x: unsupported shape n={n} C={C} B={B}")
+    ws = torch.empty((ws_bytes,), device=x2d.device, dtype=torch.uint8)
+    if out is None:
+        out = torch.empty((nt, C), device=x2d.device, dtype=torch.float32)
+    chunks, partial, acc = n // 32, None, 0
+    if FUSE_GN_STATS:
+        rec = _ARENA.take(B) if _ARENA is not None else None
+        if rec is not None:
+            partial, chunks, acc = rec, 0, 1
+        else:
+            partial = torch.empty((B * chunks * 32 * 2,), device=x2d.device, dtype=torch.float64)
+    check(lib.sgam_attn_block_f32x(_p(x2d), x2d.stride(0), _p(mean_rstd), _p(_f32c(gamma)), _p(_f32c(beta)), _p(wqkv_perm.planes),
+                                   float(wqkv_perm.scale), _p(bqkv), n, C, B, float(scale), _p(wp.planes), float(wp.scale), _p(bp),
+                                   _p(out), out.stride(0), _p(partial), acc, _p(ws), ws_bytes, _stream()), "sgam_attn_block_f32x")
+    if partial is not None:
+        out._gn_partials = (partial, chunks)
+    return out
+
+
 def attention_h16(qkv, C, scale, out=None, B=1):
     """16-bit throughput variant of `attention` (qkv bf16 / fp16, result in the same dtype)."""
     _need_cuda(qkv)
@@ -877,7 +924,17 @@ def attn_block_h16_fusable(x, n, C, B):
             and _lib.load().sgam_attn_block_h16_workspace_bytes(n, C, B) > 0)
 
 
-def attn_block_h16(x2d, pre, gamma, beta, eps, w_frag, bias, C, scale, B=1, out=None):
+def pack_weight_tp_h16(w2d, dtype):
+    """(rows, C) fp32 1x1 weight -> transposed-product fragment order (attn_block_h16's proj_out operand)"""
+    _need_cuda(w2d)
+    rows, C = w2d.shape
+    assert w2d.dtype == torch.float32 and w2d.is_contiguous()
+    out = torch.empty((rows * C,), device=w2d.device, dtype=dtype)
+    check(_lib.load().sgam_pack_weight_tp_h16(_p(w2d), _p(out), H16[dtype], rows, C, _stream()), "sgam_pack_weight_tp_h16")
+    return out
+
+
+def attn_block_h16(x2d, pre, gamma, beta, eps, w_frag, bias, C, scale, B=1, out=None, proj=None):
     """16-bit AttnBlock ahead of proj_out: GroupNorm (from the producer's chunk statistics `pre` = (partials, chunks)) applied inside
     the q | k | v projection, K / V^T written in the attention's fragment order, flash + merge: four launches (seven unfused)."""
     _need_cuda(x2d)
@@ -892,6 +949,17 @@ def attn_block_h16(x2d, pre, gamma, beta, eps, w_frag, bias, C, scale, B=1, out=
     if out is None:
         out = torch.empty((nt, C), device=x2d.device, dtype=x2d.dtype)
     partial, chunks = pre
+    if proj is not None:
+        # proj = (wp_frag, bp): the merge of the key ranges fused into proj_out + residual x — the whole block, with the chunk statistics
+        # of what it stored for the GroupNorm that follows
+        wp_frag, bp = proj
+        po = torch.empty((B * (n // 32) * 32 * 2,), device=x2d.device, dtype=torch.float64) if FUSE_GN_STATS else None
+        check(lib.sgam_attn_block_proj_h16(_p(x2d), x2d.stride(0), _p(partial), int(chunks), _p(gamma), _p(beta), float(eps), _p(w_frag),
+                                           _p(bias), H16[x2d.dtype], n, C, B, float(scale), _p(wp_frag), _p(bp), _p(po), _p(out),
+                                           out.stride(0), _p(ws), ws_bytes, _stream()), "sgam_attn_block_proj_h16")
+        if po is not None:
+            out._gn_partials = (po, n // 32)
+        return out
     check(lib.sgam_attn_block_h16(_p(x2d), x2d.stride(0), _p(partial), int(chunks), _p(gamma), _p(beta), float(eps), _p(w_frag), _p(bias),
                                   H16[x2d.dtype], n, C, B, float(scale), _p(out), out.stride(0), _p(ws), ws_bytes, _stream()),
           "sgam_attn_block_h16")

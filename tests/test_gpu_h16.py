@@ -296,16 +296,25 @@ def test_attn_block_front_end_fused_matches_the_separate_launches(dt, B, monkeyp
     assert hasattr(x, "_gn_partials") and x._gn_partials[1] > 0
     with torch.no_grad():
         monkeypatch.setattr(ops, "ATTN_BLOCK_H16", False)
+        sep = mod.forward_nhwc(x).float()                            # (the first call of either form packs its weights)
         recs0, _ = ops.kernel_timeline(lambda: mod.forward_nhwc(x))
-        sep = mod.forward_nhwc(x).float()
         monkeypatch.setattr(ops, "ATTN_BLOCK_H16", True)
+        fo = mod.forward_nhwc(x)
+        fused = fo.float()
         recs1, _ = ops.kernel_timeline(lambda: mod.forward_nhwc(x))
-        fused = mod.forward_nhwc(x).float()
         again = mod.forward_nhwc(x).float()
     names1 = [r[0] for r in recs1]
-    assert any("attn_qkv_gn_h16" in k for k in names1), names1
-    assert not any("gn_apply" in k or "split_kv" in k for k in names1), names1
-    assert len(recs1) == len(recs0) - 3, ([r[0] for r in recs0], names1)
+    assert any("attn_qkv_gn_h16" in k for k in names1) and any("attn_combine_proj_h16" in k for k in names1), names1
+    assert not any("gn_apply" in k or "split_kv" in k or "conv_gemm" in k for k in names1), names1
+    assert len(recs1) == 4 and len(recs0) == 7, ([r[0] for r in recs0], names1)      # table, projection, flash, merge + proj_out
+    # the chunk statistics the fused block leaves describe the tensor it stored
+    part, chunks = fo._gn_partials
+    assert chunks == 64 * 64 // 32
+    st = part.view(B * chunks, 32, 2)
+    blk = fo.double().view(B * chunks, 32, 32, 8)                    # (tile, token, group, channel in group)
+    # (a lane sums its eight stored values in fp32 before the fp64 fold over the tile's 32 tokens)
+    assert torch.allclose(st[..., 0], blk.sum(dim=(1, 3)), rtol=1e-6, atol=1e-4)
+    assert torch.allclose(st[..., 1], (blk * blk).sum(dim=(1, 3)), rtol=1e-6, atol=1e-4)
     assert torch.equal(fused, again)
     ref = OV.attn_block({"a." + k: v for k, v in sd.items()}, "a", x.float().permute(0, 3, 1, 2).cpu()).permute(0, 2, 3, 1)
     tol = 2 ** -6 if dt == "bf16" else 2 ** -9           # a few roundings of an O(1) activation in the mode's precision

@@ -680,3 +680,39 @@ def test_panel_gemm_1x1_conv_with_residual_and_statistics(case):
     og = ref.reshape(B, 32, -1)
     assert torch.allclose(st[:, :, 0].double(), og.mean(-1), rtol=0, atol=1e-5)
     assert torch.allclose(st[:, :, 1].double(), (og.var(-1, unbiased=False) + 1e-6).rsqrt(), rtol=1e-5, atol=0)
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_attn_block_in_three_launches_matches_the_gemm_and_split_sequence(B, monkeypatch):
+    """ABI v9: the fused front end of the split-fp32 AttnBlock computes the q | k | v projection transposed and writes K / V^T
+    straight in the attention's fragment order — the same normalisation expression, the same three MFMAs per product in the same
+    order; against the gemm_gn_f32x + attn_split_kv sequence (fp32 round-off of a transposed MFMA chain: not bit-identical, measured),
+    against the fp32 oracle of the block, run-to-run identical, one launch fewer"""
+    from oracle import vqgan as OV
+    from sgam_neurips22_amd.generative_sensing_module.modules.diffusionmodules import model as dm
+    ops.set_f32_mode("split")
+    mod = dm.AttnBlock(256)
+    sd = testing.synthetic_state_dict(mod.state_dict(), seed=11)
+    mod.load_state_dict(sd)
+    mod = mod.to(DEV).eval()
+    xc = testing.seeded_tensor("ab3.x", (B, 256, 64, 64), 1.0, 0.3)
+    x = ops.nchw_to_nhwc(xc.to(DEV))
+    with torch.no_grad():
+        monkeypatch.setattr(ops, "ATTN_BLOCK_F32X", False)
+        sep = mod.forward_nhwc(x)                                    # (the first call of either form packs its weights)
+        recs0, _ = ops.kernel_timeline(lambda: mod.forward_nhwc(x))
+        monkeypatch.setattr(ops, "ATTN_BLOCK_F32X", True)
+        fused = mod.forward_nhwc(x)
+        recs1, _ = ops.kernel_timeline(lambda: mod.forward_nhwc(x))
+        again = mod.forward_nhwc(x)
+    names0, names1 = [r[0] for r in recs0], [r[0] for r in recs1]
+    assert any("attn_qkv_gn_f32x" in k for k in names1) and not any("split_kv" in k or "gemm_gn_f32x" in k for k in names1), names1
+    assert len(names1) == len(names0) - 1, (names0, names1)
+    assert torch.equal(fused, again) and torch.equal(fused._gn_partials[0], again._gn_partials[0])
+    d = (fused - sep).abs().max().item()
+    print(f"[attn_block_f32x B={B}] max |fused - separate| = {d:.3e} (max |out| {sep.abs().max().item():.3f})")
+    _close(fused, sep, 2e-6, "three-launch block vs q|k|v GEMM + split launch")
+    ref = OV.attn_block({"a." + k: v for k, v in sd.items()}, "a", xc).permute(0, 2, 3, 1)
+    _close(fused, ref.to(DEV), 2e-5, "three-launch block vs the fp32 oracle")
+    assert fused._gn_partials[1] == sep._gn_partials[1]
+    assert torch.allclose(fused._gn_partials[0], sep._gn_partials[0], rtol=1e-5, atol=1e-3)
