@@ -373,6 +373,18 @@ int sgam_attn_block_f32x(const float *x, int32_t ldx, const float *mean_rstd, co
                          float wqkv_scale, const float *bqkv, int32_t n, int32_t C, int32_t B, float scale, const void *wp_planes,
                          float wp_scale, const float *bp, float *out, int32_t ldc, double *gn_partial, int32_t gn_acc, void *workspace,
                          int64_t workspace_bytes, void *stream);
+/* (ABI v9) The attention of the SMALL AttnBlocks in one launch — the 16 x 16 mid blocks (n = 256 tokens per image, C = 512; n = 128 too):
+ * model.py:176-187, `w_ = bmm(q, k) * c**-0.5; w_ = softmax(w_, dim=2); h_ = bmm(v, w_)` — what otherwise runs as v^T transpose, operand
+ * splits, the q k^T GEMM (+ split-K combine), sgam_softmax_rows_f32 and the P v GEMM: seven launches.  A workgroup holds a query tile's whole
+ * score row (every query attends to the n keys of ITS image; B images stacked along the rows); the soft-max is sgam_softmax_rows_f32's
+ * arithmetic; equal to the chain to fp32 round-off.  q, k, v: [B n][ld] fp32 (ld % 4 == 0), out [B n][ldo]; no workspace. */
+int32_t sgam_attention_small_f32x_fits(int32_t n, int32_t C, int32_t B);
+int sgam_attention_small_f32x(const float *q, const float *k, const float *v, int32_t ld, int32_t n, int32_t C, int32_t B, float scale,
+                              float *out, int32_t ldo, void *stream);
+/* 16-bit twin (`ht` = 0 bf16 / 1 fp16; q, k, v, out 16-bit, ld % 8 == 0): replaces sgam_transpose_h16 + the q k^T GEMM + sgam_softmax_rows_h16
+ * + the P v GEMM; fp32 scores and soft-max (sgam_softmax_rows_h16's arithmetic), probabilities rounded once, fp32 accumulation. */
+int sgam_attention_small_h16(const void *q, const void *k, const void *v, int32_t ht, int32_t ld, int32_t n, int32_t C, int32_t B, float scale,
+                             void *out, int32_t ldo, void *stream);
 int sgam_groupnorm_table_from_partials(const double *partial, int32_t nchunk, const float *gamma, const float *beta,
                                        float *scale_shift, int32_t B, int32_t HW, int32_t C, int32_t groups, float eps, void *stream);
 int sgam_pack_qkv_weight_h16(const float *w, void *w_frag, int32_t ht, int32_t C, void *stream);

@@ -152,6 +152,9 @@ PROTOTYPES = {
     "sgam_attn_block_f32x_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
     "sgam_attn_block_f32x": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_f32, c_vp, c_vp, c_i32,
                                      c_vp, c_i32, c_vp, c_i64, c_vp]),
+    "sgam_attention_small_f32x_fits": (c_i32, [c_i32, c_i32, c_i32]),
+    "sgam_attention_small_f32x": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_i32, c_vp]),
+    "sgam_attention_small_h16": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_i32, c_vp]),
     "sgam_groupnorm_table_from_partials": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp]),
     "sgam_pack_qkv_weight_h16": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
     "sgam_pack_weight_tp_h16": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),

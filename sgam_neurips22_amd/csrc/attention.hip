@@ -731,6 +731,215 @@ __global__ __launch_bounds__(256, 2) void attn_qkv_gn_f32x_kernel(const QkvXPara
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The SMALL AttnBlocks (the two 16 x 16 mid blocks: n = 256 tokens per image, C = 512) in ONE launch instead of seven (round 5).
+// The chain they ran — v^T transpose, split of k, q k^T (split-K 2 + combine), row soft-max, split of v^T, P v — is a sequence of
+// 2 - 10 us launches with a graph edge each for 0.2 GFLOP; nothing in it needs more than one image's 256 keys, so a workgroup can hold a
+// query tile's whole score row.  Workgroup = (32 queries, 128 output channels); its four wavefronts take a quarter of the keys each:
+//   S^T = K Q^T for its keys (keys = MFMA rows, so a lane holds 16 keys of ONE query, as in the flash kernel), operands split into
+//         fp16 hi / lo on the fly — Q once per workgroup into LDS, K straight from L2 a k-step ahead;
+//   soft-max over ALL keys of the image exactly as softmax_rows_kernel spells it (scale, maximum, expf, sum, one reciprocal): the
+//         four wavefronts exchange maxima and sums through LDS;
+//   O^T += V^T P^T for its keys and the workgroup's 128 channels (probabilities lifted by 2^10 before the split, as the chain's
+//         second GEMM does; V^T fragments gathered with the flash kernel's key permutation so that a lane's accumulators ARE its
+//         B operand), then the four partial outputs are added through LDS in a fixed order.
+// The three MFMAs of every product keep the generic kernel's order (hi.hi, q_hi.k_lo / p_hi.v_lo, lo.hi); the summation trees differ
+// from the chain's (no split-K in S, four key ranges in PV): equal to fp32 round-off, not bit for bit.
+// ---------------------------------------------------------------------------------------------------------------------
+struct SmallAttnParams {
+    const float *q, *k, *v;         // [B n][ld] fp32 columns of the q | k | v projection
+    float *out;                     // [B n][ldo]
+    int ld, ldo, n_img;
+    float scale;
+    int32_t *range_flag;
+};
+
+template <int CD, int NKT, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_small_f32x_kernel(const SmallAttnParams p) {
+    constexpr int LDQ = CD + 8;                                       // halfs
+    constexpr int NT = 64 * NW;
+    constexpr int QBYTES = 2 * 32 * LDQ * 2, PBYTES = NW * 4 * 16 * 64 * 4, KBYTES = 2 * (32 * NKT * NW) * (32 + 4) * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[(QBYTES + KBYTES > PBYTES ? QBYTES + KBYTES : PBYTES)];
+    __shared__ float red[2][NW][32];
+    unsigned short *sQ = reinterpret_cast<unsigned short *>(smem);    // [plane][32][LDQ]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int q0 = blockIdx.x * 32, d0 = blockIdx.y * 128;
+    const int kb = (q0 / p.n_img) * p.n_img + wave * (32 * NKT);      // this wavefront's keys of the query tile's image
+    // ---- the query tile, split, into LDS: thread -> (row, float4) pieces
+#pragma unroll
+    for (int it = 0; it < 32 * (CD / 4) / NT; ++it) {
+        const int idx = tid + NT * it, r = idx / (CD / 4), c4 = idx % (CD / 4);
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(p.q + (int64_t)(q0 + r) * p.ld + 4 * c4);
+        unsigned hi[2], lo[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const _Float16 h0 = (_Float16)a[2 * e], h1 = (_Float16)a[2 * e + 1];
+            const _Float16 l0 = (_Float16)(a[2 * e] - (float)h0), l1 = (_Float16)(a[2 * e + 1] - (float)h1);
+            hi[e] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+            lo[e] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+        }
+        *reinterpret_cast<u32x2 *>(sQ + r * LDQ + 4 * c4) = u32x2{hi[0], hi[1]};
+        *reinterpret_cast<u32x2 *>(sQ + (32 + r) * LDQ + 4 * c4) = u32x2{lo[0], lo[1]};
+    }
+    // ---- S^T: keys of tile i = kb + 32 i + lr are MFMA rows; k-step t covers d = 16 t + 8 lh + 0..7; K one k-step ahead
+    f32x16 sacc[NKT];
+#pragma unroll
+    for (int i = 0; i < NKT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sacc[i][e] = 0.f;
+    // K reaches the MFMAs through LDS in chunks of 32 channels, loaded as WHOLE 128-byte lines (eight threads per key row).  (Round 5, the
+    // forms before this one read the fragments straight from L2 — lane = (key row, 8 channels), 64 scattered 16- and 32-byte pieces per
+    // instruction, every line touched by eight instructions: 21 - 24 us per launch whatever the read-ahead (one, four k-steps) and the
+    // wavefront count (four, eight): the CU's address path, not latency, not the split arithmetic.)
+    constexpr int KEYS = 32 * NKT * NW, DCH = 32, NCH = CD / DCH, KLD = DCH + 4, PER = KEYS * (DCH / 4) / NT;
+    static_assert(KEYS * (DCH / 4) % NT == 0, "whole float4 pieces per thread");
+    float *sK = reinterpret_cast<float *>(smem + QBYTES);             // [2][KEYS][KLD]
+    const float *kbase = p.k + (int64_t)((q0 / p.n_img) * p.n_img) * p.ld;
+    f32x4 kr[PER];
+    auto kfetch = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = tid + NT * i;
+            kr[i] = *reinterpret_cast<const f32x4 *>(kbase + (int64_t)(idx / (DCH / 4)) * p.ld + c * DCH + 4 * (idx % (DCH / 4)));
+        }
+    };
+    auto kstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = tid + NT * i;
+            *reinterpret_cast<f32x4 *>(sK + (buf * KEYS + idx / (DCH / 4)) * KLD + 4 * (idx % (DCH / 4))) = kr[i];
+        }
+    };
+    kfetch(0);
+    kstore(0);
+    kfetch(1);
+    __syncthreads();
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+        for (int tt = 0; tt < DCH / 16; ++tt) {
+            const int t = c * (DCH / 16) + tt;
+            const u32x4 qh = *reinterpret_cast<const u32x4 *>(sQ + lr * LDQ + t * 16 + lh * 8);
+            const u32x4 ql = *reinterpret_cast<const u32x4 *>(sQ + (32 + lr) * LDQ + t * 16 + lh * 8);
+#pragma unroll
+            for (int i = 0; i < NKT; ++i) {
+                const float *kq = sK + ((c & 1) * KEYS + wave * 32 * NKT + 32 * i + lr) * KLD + tt * 16 + lh * 8;
+                const f32x4 k0 = *reinterpret_cast<const f32x4 *>(kq), k1 = *reinterpret_cast<const f32x4 *>(kq + 4);
+                const float kv[8] = {k0[0], k0[1], k0[2], k0[3], k1[0], k1[1], k1[2], k1[3]};
+                u32x4 kh, kl;
+                split8(kv, kh, kl);
+                sacc[i] = mfma16(kh, qh, sacc[i]);                    // q_hi . k_hi, q_hi . k_lo, q_lo . k_hi: the generic kernel's order
+                sacc[i] = mfma16(kl, qh, sacc[i]);
+                sacc[i] = mfma16(kh, ql, sacc[i]);
+            }
+        }
+        if (c + 1 < NCH) {
+            kstore((c + 1) & 1);                                      // (the buffer chunk c - 1 was read from: everybody passed the last barrier)
+            if (c + 2 < NCH) kfetch(c + 2);
+        }
+        __syncthreads();
+    }
+    // every V value this wavefront needs (4 d-tiles x NKT key tiles x 2 k-steps x 8 keys: 64 NKT registers) is requested before the
+    // soft-max: its trip to L2 runs under the exponentials and the two barriers
+    float vv[4][NKT][2][8];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        const float *vp = p.v + (int64_t)(kb + 4 * lh) * p.ld + d0 + dt * 32 + lr;
+#pragma unroll
+        for (int i = 0; i < NKT; ++i)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int sl = 0; sl < 8; ++sl) vv[dt][i][t][sl] = vp[(int64_t)(32 * i + 16 * t + 8 * (sl >> 2) + (sl & 3)) * p.ld];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- soft-max over the image's keys (softmax_rows_kernel's arithmetic); lane = query lr, 16 NKT keys, the other half in lane ^ 32
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NKT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            sacc[i][e] *= p.scale;
+            mx = fmaxf(mx, sacc[i][e]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (lh == 0) red[0][wave][lr] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0][0][lr], red[0][1][lr]), fmaxf(red[0][2][lr], red[0][3][lr]));
+    if constexpr (NW == 8) mx = fmaxf(mx, fmaxf(fmaxf(red[0][4][lr], red[0][5][lr]), fmaxf(red[0][6][lr], red[0][7][lr])));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NKT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            sacc[i][e] = expf(sacc[i][e] - mx);
+            sum += sacc[i][e];
+        }
+    sum += __shfl_xor(sum, 32, 64);
+    if (lh == 0) red[1][wave][lr] = sum;
+    __syncthreads();
+    float tot = (red[1][0][lr] + red[1][1][lr]) + (red[1][2][lr] + red[1][3][lr]);
+    if constexpr (NW == 8) tot += (red[1][4][lr] + red[1][5][lr]) + (red[1][6][lr] + red[1][7][lr]);
+    const float inv = 1.0f / tot;
+    if (p.range_flag && sgam_not_finite(inv)) atomicOr(p.range_flag, 1);
+    u32x4 ph[NKT][2], pl[NKT][2];                                     // P^T fragments: k-slot s of (k-step t, half lh) = key(t, lh, s)
+#pragma unroll
+    for (int i = 0; i < NKT; ++i)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float pv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pv[e] = (sacc[i][8 * t + e] * inv) * 1024.0f;
+            split8(pv, ph[i][t], pl[i][t]);
+        }
+    // ---- O^T partial of this wavefront's keys for the workgroup's four 32-channel tiles
+    float *part = reinterpret_cast<float *>(smem);                    // [wave][d-tile][slot e][lane]: the Q panel is no longer read ...
+    __syncthreads();                                                  // ... by anybody
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        f32x16 oacc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[e] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NKT; ++i)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                u32x4 vh, vl;
+                split8(vv[dt][i][t], vh, vl);
+                oacc = mfma16(vh, ph[i][t], oacc);                    // p_hi . v_hi, p_hi . v_lo, p_lo . v_hi
+                oacc = mfma16(vl, ph[i][t], oacc);
+                oacc = mfma16(vh, pl[i][t], oacc);
+            }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) part[((wave * 4 + dt) * 16 + e) * 64 + lane] = oacc[e];
+    }
+    __syncthreads();
+    // the NW partials of every (d-tile, slot) are added in a fixed order: wavefront w takes d-tile w % 4 and, with eight wavefronts, the slot
+    // half w / 4; lane = query lr, channels d0 + 32 dt + 8 j + 4 lh + 0..3
+    {
+        const int dt = wave & 3, j0 = (NW == 8) ? 2 * (wave >> 2) : 0;
+        float *dst = p.out + (int64_t)(q0 + lr) * p.ldo + d0 + 32 * dt + 4 * lh;
+#pragma unroll
+        for (int jj = 0; jj < (NW == 8 ? 2 : 4); ++jj) {
+            const int j = j0 + jj;
+            f32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int e = 4 * j + r;
+                float a[NW];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) a[w] = part[((w * 4 + dt) * 16 + e) * 64 + lane];
+                float t4 = (a[0] + a[1]) + (a[2] + a[3]);
+                if constexpr (NW == 8) t4 += (a[4] + a[5]) + (a[6] + a[7]);
+                o[r] = t4 * (1.0f / 1024.0f);
+            }
+            *reinterpret_cast<f32x4 *>(dst + 8 * j) = o;
+        }
+    }
+}
+
 // =====================================================================================================================
 // 16-bit throughput variant (bf16 `HT` = 0 / fp16 `HT` = 1 activations, the h16.hip mode): the same pass over the keys with
 // ONE MFMA per product and single-plane fragments — half the LDS block (16 KB of K + 16 KB of V^T per 32 keys), a 64-VGPR
@@ -1256,6 +1465,169 @@ __global__ __launch_bounds__(256) void attn_combine_proj_h16_kernel(const CombPr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The small AttnBlocks' attention of the 16-bit mode in one launch (attn_small_f32x_kernel's decomposition, one MFMA per product):
+// replaces transpose_h16 + the q k^T GEMM + softmax_rows_h16 + the P v GEMM.  Scores and soft-max in fp32 (softmax_rows_h16_kernel's
+// arithmetic: scale, maximum, __expf, sum, one reciprocal, probabilities rounded ONCE to 16 bits), fp32 accumulation, output rounded.
+// ---------------------------------------------------------------------------------------------------------------------
+struct SmallAttnHParams {
+    const unsigned short *q, *k, *v;    // [B n][ld] 16-bit columns of the q | k | v projection
+    unsigned short *out;                // [B n][ldo]
+    int ld, ldo, n_img;
+    float scale;
+};
+
+template <int HT, int CD, int NKT, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_small_h16_kernel(const SmallAttnHParams p) {
+    constexpr int LDQ = CD + 8;
+    constexpr int NT = 64 * NW;
+    constexpr int QBYTES = 32 * LDQ * 2, PBYTES = NW * 4 * 16 * 64 * 4, KBYTES = 2 * (32 * NKT * NW) * (64 + 8) * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[(QBYTES + KBYTES > PBYTES ? QBYTES + KBYTES : PBYTES)];
+    __shared__ float red[2][NW][32];
+    unsigned short *sQ = reinterpret_cast<unsigned short *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int q0 = blockIdx.x * 32, d0 = blockIdx.y * 128;
+    const int kb = (q0 / p.n_img) * p.n_img + wave * (32 * NKT);
+#pragma unroll
+    for (int it = 0; it < 32 * (CD / 8) / NT; ++it) {
+        const int idx = tid + NT * it, r = idx / (CD / 8), c8 = idx % (CD / 8);
+        *reinterpret_cast<u32x4 *>(sQ + r * LDQ + 8 * c8) = *reinterpret_cast<const u32x4 *>(p.q + (int64_t)(q0 + r) * p.ld + 8 * c8);
+    }
+    f32x16 sacc[NKT];
+#pragma unroll
+    for (int i = 0; i < NKT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sacc[i][e] = 0.f;
+    // K through LDS in chunks of 64 channels, loaded as whole 128-byte lines (attn_small_f32x_kernel)
+    constexpr int KEYS = 32 * NKT * NW, DCH = 64, NCH = CD / DCH, KLD = DCH + 8, PER = KEYS * (DCH / 8) / NT;
+    static_assert(KEYS * (DCH / 8) % NT == 0, "whole 16-byte pieces per thread");
+    unsigned short *sK = reinterpret_cast<unsigned short *>(smem + QBYTES);       // [2][KEYS][KLD]
+    const unsigned short *kbase = p.k + (int64_t)((q0 / p.n_img) * p.n_img) * p.ld;
+    u32x4 kr[PER];
+    auto kfetch = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = tid + NT * i;
+            kr[i] = *reinterpret_cast<const u32x4 *>(kbase + (int64_t)(idx / (DCH / 8)) * p.ld + c * DCH + 8 * (idx % (DCH / 8)));
+        }
+    };
+    auto kstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = tid + NT * i;
+            *reinterpret_cast<u32x4 *>(sK + (buf * KEYS + idx / (DCH / 8)) * KLD + 8 * (idx % (DCH / 8))) = kr[i];
+        }
+    };
+    kfetch(0);
+    kstore(0);
+    kfetch(1);
+    __syncthreads();
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+        for (int tt = 0; tt < DCH / 16; ++tt) {
+            const int t = c * (DCH / 16) + tt;
+            const u32x4 qf = *reinterpret_cast<const u32x4 *>(sQ + lr * LDQ + t * 16 + lh * 8);
+#pragma unroll
+            for (int i = 0; i < NKT; ++i)
+                sacc[i] = HM<HT>::mfma(*reinterpret_cast<const u32x4 *>(sK + ((c & 1) * KEYS + wave * 32 * NKT + 32 * i + lr) * KLD + tt * 16 + lh * 8),
+                                       qf, sacc[i]);
+        }
+        if (c + 1 < NCH) {
+            kstore((c + 1) & 1);
+            if (c + 2 < NCH) kfetch(c + 2);
+        }
+        __syncthreads();
+    }
+    unsigned short vv[4][NKT][2][8];                                  // every V value of the wavefront, requested ahead of the soft-max
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        const unsigned short *vp = p.v + (int64_t)(kb + 4 * lh) * p.ld + d0 + dt * 32 + lr;
+#pragma unroll
+        for (int i = 0; i < NKT; ++i)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int sl = 0; sl < 8; ++sl) vv[dt][i][t][sl] = vp[(int64_t)(32 * i + 16 * t + 8 * (sl >> 2) + (sl & 3)) * p.ld];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NKT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            sacc[i][e] *= p.scale;
+            mx = fmaxf(mx, sacc[i][e]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (lh == 0) red[0][wave][lr] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0][0][lr], red[0][1][lr]), fmaxf(red[0][2][lr], red[0][3][lr]));
+    if constexpr (NW == 8) mx = fmaxf(mx, fmaxf(fmaxf(red[0][4][lr], red[0][5][lr]), fmaxf(red[0][6][lr], red[0][7][lr])));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NKT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            sacc[i][e] = __expf(sacc[i][e] - mx);
+            sum += sacc[i][e];
+        }
+    sum += __shfl_xor(sum, 32, 64);
+    if (lh == 0) red[1][wave][lr] = sum;
+    __syncthreads();
+    float tot = (red[1][0][lr] + red[1][1][lr]) + (red[1][2][lr] + red[1][3][lr]);
+    if constexpr (NW == 8) tot += (red[1][4][lr] + red[1][5][lr]) + (red[1][6][lr] + red[1][7][lr]);
+    const float inv = 1.0f / tot;
+    u32x4 pf[NKT][2];
+#pragma unroll
+    for (int i = 0; i < NKT; ++i)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) pf[i][t][e >> 1] = HM<HT>::pack2(sacc[i][8 * t + e] * inv, sacc[i][8 * t + e + 1] * inv);
+    float *part = reinterpret_cast<float *>(smem);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        f32x16 oacc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[e] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NKT; ++i)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                u32x4 vf;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vf[e] = (unsigned)vv[dt][i][t][2 * e] | ((unsigned)vv[dt][i][t][2 * e + 1] << 16);
+                oacc = HM<HT>::mfma(vf, pf[i][t], oacc);
+            }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) part[((wave * 4 + dt) * 16 + e) * 64 + lane] = oacc[e];
+    }
+    __syncthreads();
+    {
+        const int dt = wave & 3, j0 = (NW == 8) ? 2 * (wave >> 2) : 0;
+        unsigned short *dst = p.out + (int64_t)(q0 + lr) * p.ldo + d0 + 32 * dt + 4 * lh;
+#pragma unroll
+        for (int jj = 0; jj < (NW == 8 ? 2 : 4); ++jj) {
+            const int j = j0 + jj;
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int e = 4 * j + r;
+                float a[NW];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) a[w] = part[((w * 4 + dt) * 16 + e) * 64 + lane];
+                o[r] = (a[0] + a[1]) + (a[2] + a[3]);
+                if constexpr (NW == 8) o[r] += (a[4] + a[5]) + (a[6] + a[7]);
+            }
+            *reinterpret_cast<u32x2 *>(dst + 8 * j) = u32x2{HM<HT>::pack2(o[0], o[1]), HM<HT>::pack2(o[2], o[3])};
+        }
+    }
+}
+
 }  // namespace
 
 // key ranges per image: enough workgroups (n_img / 128 query blocks x ranges x images) to fill 256 CUs and as few ranges as
@@ -1637,4 +2009,47 @@ extern "C" int sgam_attn_block_proj_h16(const void *x, int32_t ldx, const double
     if (!wp_frag) return SGAM_EINVAL;
     return attn_block_h16_impl(x, ldx, gn_partial, nchunk, gamma, beta, eps, w_frag, bias, ht, n, C, B, scale, wp_frag, bp, gn_partial_out, out,
                                ldo, workspace, workspace_bytes, stream);
+}
+
+// ---- the small AttnBlocks (n = 128 / 256 tokens per image, C = 512) in one launch (ABI v9) ------------------------------------------
+extern "C" int32_t sgam_attention_small_f32x_fits(int32_t n, int32_t C, int32_t B) {
+    return (C == 512 && (n == 128 || n == 256) && B >= 1 && (int64_t)B * n < (1 << 24)) ? 1 : 0;
+}
+
+extern "C" int sgam_attention_small_f32x(const float *q, const float *k, const float *v, int32_t ld, int32_t n, int32_t C, int32_t B,
+                                         float scale, float *out, int32_t ldo, void *stream) {
+    if (!q || !k || !v || !out || sgam_attention_small_f32x_fits(n, C, B) != 1 || ld < C || ld % 4 != 0 || ldo < C || ldo % 4 != 0 ||
+        !(scale > 0.f))
+        return SGAM_EINVAL;
+    if (!sgam_aligned16(q) || !sgam_aligned16(k) || !sgam_aligned16(v) || !sgam_aligned16(out)) return SGAM_EALIGN;
+    SmallAttnParams p;
+    p.q = q; p.k = k; p.v = v; p.out = out; p.ld = ld; p.ldo = ldo; p.n_img = n; p.scale = scale; p.range_flag = sgam_i_range_flag;
+    const dim3 grid(B * n / 32, C / 128);
+    hipStream_t s = sgam_stream(stream);
+    if (sgam_i_prof_on) sgam_i_prof_work(4.0 * B * n * (double)n * C, 4.0 * 4.0 * B * n * C);
+    // n = 256: eight wavefronts of one key tile each (the operand splits are a serial VALU chain: two wavefronts per SIMD halve it)
+    if (n == 256) SGAM_KLAUNCH((attn_small_f32x_kernel<512, 1, 8>), grid, dim3(512), 0, s, p);
+    else SGAM_KLAUNCH((attn_small_f32x_kernel<512, 1, 4>), grid, dim3(256), 0, s, p);
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+extern "C" int sgam_attention_small_h16(const void *q, const void *k, const void *v, int32_t ht, int32_t ld, int32_t n, int32_t C, int32_t B,
+                                        float scale, void *out, int32_t ldo, void *stream) {
+    if (!q || !k || !v || !out || (ht != 0 && ht != 1) || sgam_attention_small_f32x_fits(n, C, B) != 1 || ld < C || ld % 8 != 0 || ldo < C ||
+        ldo % 4 != 0 || !(scale > 0.f))
+        return SGAM_EINVAL;
+    if (!sgam_aligned16(q) || !sgam_aligned16(k) || !sgam_aligned16(v) || (((uintptr_t)out) & 7u) != 0) return SGAM_EALIGN;
+    SmallAttnHParams p;
+    p.q = (const unsigned short *)q; p.k = (const unsigned short *)k; p.v = (const unsigned short *)v; p.out = (unsigned short *)out;
+    p.ld = ld; p.ldo = ldo; p.n_img = n; p.scale = scale;
+    const dim3 grid(B * n / 32, C / 128);
+    hipStream_t s = sgam_stream(stream);
+    if (sgam_i_prof_on) sgam_i_prof_work(4.0 * B * n * (double)n * C, 2.0 * 4.0 * B * n * C);
+#define HSMALL(HT_, NW_) SGAM_KLAUNCH((attn_small_h16_kernel<HT_, 512, 1, NW_>), grid, dim3(64 * NW_), 0, s, p)
+    if (ht == 0) { if (n == 256) HSMALL(0, 8); else HSMALL(0, 4); }
+    else { if (n == 256) HSMALL(1, 8); else HSMALL(1, 4); }
+#undef HSMALL
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
 }

@@ -242,6 +242,10 @@ class AttnBlock(_NHWCModule):
                 return out
             o = ops.attention(qkv_all, C, scale, B=B)
             return self.proj_out.forward_nhwc(o.view(B, H, W, C), residual=x)
+        if fused_qkv and ops.F32_MODE == "split" and ops.attention_small_fits(n, C, B):
+            # the 16 x 16 blocks: scores, soft-max and P v of a query tile in ONE launch (the chain below is seven), any batch
+            o = ops.attention_small(qkv_all, C, scale, B=B)
+            return self.proj_out.forward_nhwc(o.view(B, H, W, C), residual=x)
         if B > 1 and fused_qkv and B * n <= BLOCKDIAG_MAX_ROWS and n % 4 == 0:
             # the small blocks of a batch (16 x 16 maps, C = 512: not the fused kernel's shape) as ONE block-diagonal chain: a
             # (B n) x (B n) score matrix whose soft-max keeps a query inside its image — 8 x the score FLOPs of B separate
@@ -302,6 +306,11 @@ def _attn_h16(self, x, wqkv, bqkv, wp, bp):
                                wqkvs[wkey], bqkv, C, scale, B=B)
         return self.proj_out.forward_nhwc(o.view(B, H, W, C), residual=x)
     h = self.norm.forward_nhwc(x, swish=False)
+    if ops.attention_small_fits(n, C, B):
+        # the 16 x 16 blocks: scores, soft-max and P v of a query tile in ONE launch (transpose + GEMM + soft-max + GEMM otherwise), any batch
+        qkv = ops.gemm_nt(h.reshape(B * n, C), wqkv, bias=bqkv)
+        o = ops.attention_small(qkv, C, scale, B=B)
+        return self.proj_out.forward_nhwc(o.view(B, H, W, C), residual=x)
     if B > 1 and ops.attention_fusable(n, C):
         qkv = ops.gemm_nt(h.reshape(B * n, C), wqkv, bias=bqkv)                    # (B n, 3C): the whole batch in one GEMM
         o = ops.attention_h16(qkv, C, scale, B=B)

@@ -59,11 +59,12 @@ def round_up(v, m):
 #   "mfma"  : fp32-in MFMA (conv_gemm.hip) — bit-for-bit an fp32 fmaf chain; the reference implementation of the
 #             parity path and the one the fused GroupNorm prologue / autotuned plans were built on
 F32_MODE = os.environ.get("SGAM_F32_MODE", "split")
-# the other 1x1 convs / GEMMs on the whole-K-panel kernel of csrc/gemm_gn_f32x.hip where they fit: measured 0.7 % SLOWER in the
-# frame than the generic kernel under its tuned plans (scripts/exp_panel.sh), so opt-in; the fused GroupNorm + q|k|v projection
-# (where the kernel removes a whole pass) is independent of this switch
-PANEL_GEMM = os.environ.get("SGAM_PANEL_GEMM", "0") == "1"
-PANEL_MIN_WGS = int(os.environ.get("SGAM_PANEL_MIN_WGS", "64"))    # ... for shapes of at least this many 64 x 128 tiles
+# the other 1x1 convs / GEMMs on the whole-K-panel kernel of csrc/gemm_gn_f32x.hip where they fit.  Rounds 2 - 4: 0.7 % slower in the
+# frame than the generic kernel under its tuned plans (it lost proj_out by 3.5 us), so opt-in; round 5: proj_out is fused into the
+# attention's merge, what is left are the shapes the panel wins (nin_shortcut, quant / post_quant convs): 373.2 -> 375.0 frames/s
+# (A / B x 3, scripts/r05u.sh), full-model parity unchanged: default.  SGAM_PANEL_GEMM=0: the generic kernel
+PANEL_GEMM = os.environ.get("SGAM_PANEL_GEMM", "1") == "1"
+PANEL_MIN_WGS = int(os.environ.get("SGAM_PANEL_MIN_WGS", "1"))    # ... for shapes of at least this many 64 x 128 tiles
 # split-mode convolutions also emit the GroupNorm statistics of their output from the epilogue (no statistics pass)
 FUSE_GN_STATS = os.environ.get("SGAM_FUSE_GN_STATS", "1") == "1"
 # ... and normalise(+swish) their INPUT while staging it (halo-staged 3x3 kernel): no stand-alone normalise pass
@@ -350,6 +351,8 @@ ATTN_BLOCK_H16 = os.environ.get("SGAM_ATTN_BLOCK_H16", "1") != "0"
 ATTN_BLOCK_H16_PROJ = os.environ.get("SGAM_ATTN_BLOCK_H16_PROJ", "1") != "0"    # ... and the merge of the key ranges fused into proj_out
 # split-fp32 AttnBlock as three launches (fused front end writes K / V^T in fragment order; SGAM_ATTN_BLOCK_F32X=0: q | k | v GEMM + split)
 ATTN_BLOCK_F32X = os.environ.get("SGAM_ATTN_BLOCK_F32X", "1") != "0"
+# the small AttnBlocks' attention (16 x 16 maps) as one launch instead of the seven of the GEMM chain (SGAM_ATTN_SMALL=0: the chain)
+ATTN_SMALL = os.environ.get("SGAM_ATTN_SMALL", "1") != "0"
 ARRIVE_COUNT = 4096
 
 
@@ -886,6 +889,28 @@ def attn_block_f32x(x2d, mean_rstd, gamma, beta, wqkv_perm, bqkv, C, scale, wp, 
                                    _p(out), out.stride(0), _p(partial), acc, _p(ws), ws_bytes, _stream()), "sgam_attn_block_f32x")
     if partial is not None:
         out._gn_partials = (partial, chunks)
+    return out
+
+
+def attention_small_fits(n, C, B=1):
+    return ATTN_SMALL and _lib.load().sgam_attention_small_f32x_fits(int(n), int(C), int(B)) == 1
+
+
+def attention_small(qkv, C, scale, B=1, out=None):
+    """softmax(q k^T scale) v of the small AttnBlocks (n = 256 tokens per image, C = 512) in ONE launch: a workgroup holds a query tile's
+    whole score row (csrc/attention.hip: attn_small_f32x_kernel); B images stacked along the rows attend within themselves."""
+    _need_cuda(qkv)
+    nt = qkv.shape[0]
+    assert qkv.shape[1] == 3 * C and qkv.stride(1) == 1 and nt % B == 0
+    if out is None:
+        out = torch.empty((nt, C), device=qkv.device, dtype=qkv.dtype)
+    if qkv.dtype in H16:
+        check(_lib.load().sgam_attention_small_h16(_p(qkv), _p(qkv[:, C:]), _p(qkv[:, 2 * C:]), H16[qkv.dtype], qkv.stride(0), nt // B, C, B,
+                                                   float(scale), _p(out), out.stride(0), _stream()), "sgam_attention_small_h16")
+        return out
+    assert qkv.dtype == torch.float32
+    check(_lib.load().sgam_attention_small_f32x(_p(qkv), _p(qkv[:, C:]), _p(qkv[:, 2 * C:]), qkv.stride(0), nt // B, C, B, float(scale),
+                                                _p(out), out.stride(0), _stream()), "sgam_attention_small_f32x")
     return out
 
 

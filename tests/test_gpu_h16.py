@@ -323,3 +323,31 @@ def test_attn_block_front_end_fused_matches_the_separate_launches(dt, B, monkeyp
     # the two forms round the same fp32 values to 16 bits at the same places (the GEMM's summation order differs): a flip of
     # one 16-bit ulp somewhere, never more
     assert _maxerr(fused, sep) <= (2 ** -7 if dt == "bf16" else 2 ** -10) * scale
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("B,n", [(1, 256), (3, 256), (2, 128)])
+def test_small_attention_in_one_launch_16bit(dt, B, n):
+    """sgam_attention_small_h16: the 16 x 16 blocks' attention in one launch against fp64 on the same 16-bit inputs and against the
+    transpose / GEMM / soft-max / GEMM chain it replaces; run-to-run identical"""
+    C = 512
+    scale = C ** -0.5
+    tdt = ops.DTYPES[dt]
+    qkv = ops.cast((testing.seeded_tensor(f"attnSh.{B}.{n}", (B * n, 3 * C)) * 1.3).to(DEV), tdt)
+    o = ops.attention_small(qkv, C, scale, B=B)
+    assert o.dtype == tdt
+    recs, _ = ops.kernel_timeline(lambda: ops.attention_small(qkv, C, scale, B=B))
+    assert len(recs) == 1 and "attn_small_h16" in recs[0][0], [r[0] for r in recs]
+    for _ in range(3):
+        assert torch.equal(o, ops.attention_small(qkv, C, scale, B=B))
+    tol = 2 ** -7 if dt == "bf16" else 2 ** -10            # the output's own rounding + the rounded probabilities
+    for b in range(B):
+        blk = qkv[b * n:(b + 1) * n]
+        q, k, v = blk[:, :C].double(), blk[:, C:2 * C].double(), blk[:, 2 * C:].double()
+        ref = torch.softmax(q @ k.t() * scale, dim=1) @ v
+        sc = ref.abs().max().item()
+        assert _maxerr(o[b * n:(b + 1) * n].float(), ref) <= tol * sc
+        vt = ops.transpose_h16(blk[:, 2 * C:])
+        s = ops.gemm_nt(blk[:, :C], blk[:, C:2 * C], out_dtype=torch.float32)
+        chain = ops.gemm_nt(ops.softmax_rows_h16(s, scale, tdt), vt)
+        assert _maxerr(o[b * n:(b + 1) * n].float(), chain.float()) <= tol * sc

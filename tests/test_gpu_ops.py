@@ -716,3 +716,39 @@ def test_attn_block_in_three_launches_matches_the_gemm_and_split_sequence(B, mon
     _close(fused, ref.to(DEV), 2e-5, "three-launch block vs the fp32 oracle")
     assert fused._gn_partials[1] == sep._gn_partials[1]
     assert torch.allclose(fused._gn_partials[0], sep._gn_partials[0], rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("B,n", [(1, 256), (3, 256), (2, 128)])
+def test_small_attention_in_one_launch_matches_the_gemm_chain_and_fp64(B, n):
+    """sgam_attention_small_f32x (ABI v9): scores, soft-max and P v of the 16 x 16 blocks (n tokens per image, C = 512) in one launch,
+    against fp64 per image, against the split-fp32 GEMM chain it replaces (fp32 round-off), run-to-run identical, every query inside
+    its image"""
+    C = 512
+    scale = C ** -0.5
+    ops.set_f32_mode("split")
+    qkv = (testing.seeded_tensor(f"attnS.{B}.{n}", (B * n, 3 * C)) * 1.3).to(DEV)
+    assert ops.attention_small_fits(n, C, B)
+    o = ops.attention_small(qkv, C, scale, B=B)
+    recs, _ = ops.kernel_timeline(lambda: ops.attention_small(qkv, C, scale, B=B))
+    assert len(recs) == 1 and "attn_small_f32x" in recs[0][0], [r[0] for r in recs]
+    for _ in range(4):
+        assert torch.equal(o, ops.attention_small(qkv, C, scale, B=B))
+    for b in range(B):
+        blk = qkv[b * n:(b + 1) * n]
+        q, k, v = blk[:, :C].double(), blk[:, C:2 * C].double(), blk[:, 2 * C:].double()
+        ref = torch.softmax(q @ k.t() * scale, dim=1) @ v
+        _close(o[b * n:(b + 1) * n], ref, 4e-6, f"small attention vs fp64, image {b}")
+        # the chain: v^T, q k^T, row soft-max, P v on the split-fp32 GEMM
+        vt = ops.nhwc_to_nchw(blk[:, 2 * C:].unsqueeze(0).unsqueeze(0), c=C).view(C, n)
+        s = ops.gemm_nt(blk[:, :C], blk[:, C:2 * C])
+        ops.softmax_rows_(s, scale)
+        chain = ops.gemm_nt(s, vt, a_scale=1024.0)
+        _close(o[b * n:(b + 1) * n], chain, 4e-6, f"small attention vs the GEMM chain, image {b}")
+    # a large-magnitude row (soft-max nearly one-hot) and a constant row (uniform weights)
+    qkv2 = qkv.clone()
+    qkv2[5, :C] *= 40.0
+    qkv2[7, :C] = 0.0
+    o2 = ops.attention_small(qkv2, C, scale, B=B)
+    blk = qkv2[:n]
+    ref = torch.softmax(blk[:, :C].double() @ blk[:, C:2 * C].double().t() * scale, dim=1) @ blk[:, 2 * C:].double()
+    _close(o2[:n], ref, 4e-6, "small attention, peaked and uniform rows")
