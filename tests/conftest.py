@@ -11,6 +11,13 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 def pytest_configure(config):
+    # the CPU oracle legs of the GPU tests (32 oracle frames in the free-running trajectory test alone) run on torch's intra-op pool: on
+    # the GPU boxes' 256 hardware threads torch takes 128 and the pool thrashes across both packages — that ONE test: 295 s with the
+    # default pool, 43 s at 32 threads, 36 s at 16 (scripts/r05y.sh; the whole suite 500 - 630 s -> under 300).  SGAM_TEST_THREADS overrides.
+    import torch
+    want = int(os.environ.get("SGAM_TEST_THREADS", "16"))
+    if (os.cpu_count() or 1) > 64 and torch.get_num_threads() > want:
+        torch.set_num_threads(want)
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
     config.addinivalue_line("markers", "experimental: kernels outside the default plans (SGAM_TEST_EXPERIMENTAL=1 to run)")
 

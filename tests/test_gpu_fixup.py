@@ -46,10 +46,11 @@ def test_f32x_fixup_equals_the_combine_launch(B, C, N, H, W, k, plan, use_bias, 
     wp = ops.pack_conv_weight(w.to(DEV), dtype="f32x")
     kw = dict(cout=N, kh=k, kw=k, pad_t=k // 2, pad_l=k // 2)
     key = f"f32x|B{B}|{H}x{W}x{C}|{H}x{W}|N{wp.shape[0]}|k{k}x{k}s1u0"
-    old, old_fix = ops.PLAN_CACHE.get(key), ops.XFIXUP
+    old, old_fix, old_panel = ops.PLAN_CACHE.get(key), ops.XFIXUP, ops.PANEL_GEMM
     ops.PLAN_CACHE[key] = plan
     try:
         ops.XFIXUP = False
+        ops.PANEL_GEMM = False            # (the 1 x 1 cases are about the generic kernel's split-K plans, not the whole-K-panel GEMM)
         ref = ops.conv2d_nhwc(x, wp, bias, residual=res, **kw)
         recs, _ = ops.kernel_timeline(lambda: ops.conv2d_nhwc(x, wp, bias, residual=res, **kw))
         assert any("splitk_reduce" in r[0] for r in recs), [r[0] for r in recs]
@@ -75,7 +76,7 @@ def test_f32x_fixup_equals_the_combine_launch(B, C, N, H, W, k, plan, use_bias, 
             if hasattr(got, "_gn_partials"):
                 assert torch.equal(again._gn_partials[0], got._gn_partials[0])
     finally:
-        ops.XFIXUP = old_fix
+        ops.XFIXUP, ops.PANEL_GEMM = old_fix, old_panel
         if old is None:
             ops.PLAN_CACHE.pop(key, None)
         else:
