@@ -373,6 +373,13 @@ int sgam_attn_block_f32x(const float *x, int32_t ldx, const float *mean_rstd, co
                          float wqkv_scale, const float *bqkv, int32_t n, int32_t C, int32_t B, float scale, const void *wp_planes,
                          float wp_scale, const float *bp, float *out, int32_t ldc, double *gn_partial, int32_t gn_acc, void *workspace,
                          int64_t workspace_bytes, void *stream);
+/* ... with the statistics of x still as its producer's chunk records (gn_partial_in [B][nchunk_in][32][2] fp64 {sum, sumsq}, 1 <= nchunk_in <= 128,
+ * eps): every workgroup of the front end folds them itself — no statistics launch in front of the block.  (sgam_attn_block_h16 does the same
+ * with its `gn_partial` when nchunk <= 128 and the environment says SGAM_ATTN_FOLD=1 — opt-in: measured no faster than the table launch.) */
+int sgam_attn_block_gnp_f32x(const float *x, int32_t ldx, const double *gn_partial_in, int32_t nchunk_in, float eps, const float *gamma,
+                             const float *beta, const void *wqkv_planes, float wqkv_scale, const float *bqkv, int32_t n, int32_t C, int32_t B,
+                             float scale, const void *wp_planes, float wp_scale, const float *bp, float *out, int32_t ldc, double *gn_partial,
+                             int32_t gn_acc, void *workspace, int64_t workspace_bytes, void *stream);
 /* (ABI v9) The attention of the SMALL AttnBlocks in one launch — the 16 x 16 mid blocks (n = 256 tokens per image, C = 512; n = 128 too):
  * model.py:176-187, `w_ = bmm(q, k) * c**-0.5; w_ = softmax(w_, dim=2); h_ = bmm(v, w_)` — what otherwise runs as v^T transpose, operand
  * splits, the q k^T GEMM (+ split-K combine), sgam_softmax_rows_f32 and the P v GEMM: seven launches.  A workgroup holds a query tile's whole

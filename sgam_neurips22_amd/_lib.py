@@ -155,6 +155,8 @@ PROTOTYPES = {
     "sgam_attention_small_f32x_fits": (c_i32, [c_i32, c_i32, c_i32]),
     "sgam_attention_small_f32x": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_i32, c_vp]),
     "sgam_attention_small_h16": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_i32, c_vp]),
+    "sgam_attn_block_gnp_f32x": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_f32, c_vp, c_vp, c_vp, c_f32, c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_f32, c_vp,
+                                         c_vp, c_i32, c_vp, c_i32, c_vp, c_i64, c_vp]),
     "sgam_groupnorm_table_from_partials": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp]),
     "sgam_pack_qkv_weight_h16": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
     "sgam_pack_weight_tp_h16": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),

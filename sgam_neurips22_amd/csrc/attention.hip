@@ -580,6 +580,42 @@ __global__ __launch_bounds__(256) void attn_combine_proj_f32x_kernel(const CombP
     }
 }
 
+// The GroupNorm statistics of the block input, folded by the consuming workgroup itself from its producer's chunk records
+// [B][nchunk][32][2] (fp64 {sum, sumsq}, nchunk <= 128): thread = (group t / 8, part t % 8) adds chunks part, part + 8, ... (all its
+// loads in flight), three xor steps join the eight parts; {mean, rstd} finished like gn_finalize_stats_kernel (fp64, the same
+// expressions — the fold's ORDER differs, i.e. the fp64 sums may differ in their last bit before the rounding to fp32).  Every
+// workgroup of the launch computes the same 64 numbers: 32 - 64 KB of L2 reads each instead of a launch + graph edge in front.
+__device__ __forceinline__ void attn_fold_stats(const double *__restrict__ partial, int nchunk, int b, double inv_n, float eps, int tid,
+                                                float *s_mr /*[64]*/) {
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    const int g = tid >> 3, part = tid & 7;
+    const double *base = partial + ((int64_t)b * nchunk * 32 + g) * 2;
+    f64x2 v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = part + 8 * i;
+        v[i] = c < nchunk ? *reinterpret_cast<const f64x2 *>(base + (int64_t)c * 64) : f64x2{0.0, 0.0};
+    }
+    double s = 0.0, ss = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        s += v[i][0];
+        ss += v[i][1];
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        s += __shfl_xor(s, o, 64);
+        ss += __shfl_xor(ss, o, 64);
+    }
+    if (part == 0) {
+        const double mean = s * inv_n;
+        double var = ss * inv_n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        s_mr[2 * g] = (float)mean;
+        s_mr[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Front end of the AttnBlock on the split-fp32 path, ONE launch (round 5): GroupNorm applied while the 64 x 256 operand panel is
 // staged + the stacked q | k | v projection — the arithmetic of gemm_gn_f32x_kernel<true, 256>, operation for operation (same
@@ -591,7 +627,10 @@ __global__ __launch_bounds__(256) void attn_combine_proj_f32x_kernel(const CombP
 // ---------------------------------------------------------------------------------------------------------------------
 struct QkvXParams {
     const float *x;                 // [nt][ldx] fp32 block input
-    const float *mean_rstd;         // [B][32][2]
+    const float *mean_rstd;         // [B][32][2] — or NULL: folded here from ...
+    const double *gn_partial;       // ... the producer's chunk records [B][nchunk][32][2], nchunk <= 128
+    int nchunk;
+    float gn_eps;
     const float *gamma, *beta;      // [AD]
     const unsigned short *w;        // split_rows planes of the ROW-PERMUTED stacked weight: [3 AD / 32][AD / 32][256 pieces][8 halfs]
     const float *bias;              // [3 AD] (natural channel order)
@@ -606,6 +645,7 @@ __global__ __launch_bounds__(256, 2) void attn_qkv_gn_f32x_kernel(const QkvXPara
     constexpr int LDK = AD + 8;                                       // panel row pitch in halfs
     constexpr int VLD = 64 + 4;                                       // V transpose: [128 channels][64 tokens + pad] fp32
     __shared__ __attribute__((aligned(16))) unsigned short sA[2][64][LDK];              // hi plane, lo plane
+    __shared__ float s_mr[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * 64, by = blockIdx.y;
     const int lr = lane & 31, lh = lane >> 5;
@@ -627,7 +667,14 @@ __global__ __launch_bounds__(256, 2) void attn_qkv_gn_f32x_kernel(const QkvXPara
 #pragma unroll
         for (int it = 0; it < NIT; ++it) xr[it] = *reinterpret_cast<const f32x4 *>(p.x + (int64_t)(m0 + prow + it * 4) * p.ldx + pc4);
         const int g = pc4 / cpg;
-        const float mean = p.mean_rstd[(b * 32 + g) * 2], rstd = p.mean_rstd[(b * 32 + g) * 2 + 1];
+        float mean, rstd;
+        if (p.mean_rstd) {
+            mean = p.mean_rstd[(b * 32 + g) * 2], rstd = p.mean_rstd[(b * 32 + g) * 2 + 1];
+        } else {
+            attn_fold_stats(p.gn_partial, p.nchunk, b, 1.0 / ((double)p.n_img * cpg), p.gn_eps, tid, s_mr);
+            __syncthreads();
+            mean = s_mr[2 * g], rstd = s_mr[2 * g + 1];
+        }
         const f32x4 ga = *reinterpret_cast<const f32x4 *>(p.gamma + pc4), be = *reinterpret_cast<const f32x4 *>(p.beta + pc4);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -1005,7 +1052,11 @@ __global__ __launch_bounds__(256) void attn_split_kv_h16_kernel(const unsigned s
 // ---------------------------------------------------------------------------------------------------------------------
 struct QkvHParams {
     const unsigned short *x;        // [nt][ldx] 16-bit activation (the block input)
-    const float *table;             // [B][AD][2] {scale, shift} per (image, channel): sgam_groupnorm_table_from_partials
+    const float *table;             // [B][AD][2] {scale, shift} per (image, channel): sgam_groupnorm_table_from_partials — or NULL:
+    const double *gn_partial;       // ... folded here from the producer's chunk records [B][nchunk][32][2], nchunk <= 128
+    const float *gamma, *beta;      //     with the affine parameters [AD]
+    int nchunk;
+    float gn_eps;
     const unsigned short *w;        // fragment-ordered stacked weights [3 AD / 32][AD / 16][64 lanes][8 halfs]
     const float *bias;              // [3 AD]
     unsigned short *q, *kf, *vf;    // q [nt][AD]; K / V^T fragments (attn_split_kv_h16_kernel's layout)
@@ -1017,6 +1068,7 @@ __global__ __launch_bounds__(256, 2) void attn_qkv_gn_h16_kernel(const QkvHParam
     constexpr int LDK = AD + 8;                                       // panel row pitch in halfs (rows 4 banks apart)
     constexpr int VLD = 64 + 8;                                       // V transpose: [128 channels][64 tokens + pad]
     __shared__ __attribute__((aligned(16))) unsigned short sB[64 * LDK];
+    __shared__ float s_mr[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * 64, by = blockIdx.y;                  // 64 tokens; 128 of the 768 output channels
     const int lr = lane & 31, lh = lane >> 5;
@@ -1030,15 +1082,27 @@ __global__ __launch_bounds__(256, 2) void attn_qkv_gn_h16_kernel(const QkvHParam
     {
         const int c8 = (tid & 31) * 8, r0 = tid >> 5;
         float sc[8], sf[8];
-        const float *tab = p.table + ((int64_t)b * AD + c8) * 2;
-#pragma unroll
-        for (int e4 = 0; e4 < 4; ++e4) {
-            const f32x4 tv = *reinterpret_cast<const f32x4 *>(tab + e4 * 4);
-            sc[2 * e4] = tv[0], sf[2 * e4] = tv[1], sc[2 * e4 + 1] = tv[2], sf[2 * e4 + 1] = tv[3];
-        }
         u32x4 xr[8];
 #pragma unroll
         for (int it = 0; it < 8; ++it) xr[it] = *reinterpret_cast<const u32x4 *>(p.x + (int64_t)(m0 + r0 + it * 8) * p.ldx + c8);
+        if (p.table) {
+            const float *tab = p.table + ((int64_t)b * AD + c8) * 2;
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+                const f32x4 tv = *reinterpret_cast<const f32x4 *>(tab + e4 * 4);
+                sc[2 * e4] = tv[0], sf[2 * e4] = tv[1], sc[2 * e4 + 1] = tv[2], sf[2 * e4 + 1] = tv[3];
+            }
+        } else {
+            // scale = rstd gamma, shift = beta - mean scale: gn_finalize_kernel's expressions on the {mean, rstd} folded here
+            attn_fold_stats(p.gn_partial, p.nchunk, b, 1.0 / ((double)p.n_img * (AD / 32)), p.gn_eps, tid, s_mr);
+            __syncthreads();
+            const float mean = s_mr[2 * (c8 / 8)], rstd = s_mr[2 * (c8 / 8) + 1];      // (eight channels = one group of C = 256)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                sc[e] = rstd * p.gamma[c8 + e];
+                sf[e] = p.beta[c8 + e] - mean * sc[e];
+            }
+        }
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             u32x4 o;
@@ -1873,10 +1937,18 @@ static int attn_block_h16_impl(const void *x, int32_t ldx, const double *gn_part
     float *ws_ml = ws_o + (int64_t)nsplit * nt * AD;
     unsigned short *qb = (unsigned short *)(ws_ml + (int64_t)nsplit * nt * 2);
     float *table = (float *)(qb + (int64_t)nt * AD);
-    const int rc = sgam_groupnorm_table_from_partials(gn_partial, nchunk, gamma, beta, table, B, n, C, 32, eps, stream);
-    if (rc != SGAM_OK) return rc;
+    // SGAM_ATTN_FOLD=1 (opt-in; read per call, a host-side query): with <= 128 chunk records per image every workgroup of the projection
+    // folds them itself and the table launch goes.  Measured (scripts/r05aa.sh): f32 362.4 -> 361.8, bf16 561.6 -> 559.7 frames/s — the
+    // dependent round trip + fp64 arithmetic in front of every workgroup's staging costs what the 1.6 us launch and its edge cost: off.
+    const char *fold_env = getenv("SGAM_ATTN_FOLD");
+    const bool infold = fold_env && fold_env[0] == '1' && nchunk >= 1 && nchunk <= 128 && sgam_aligned16(gn_partial);
+    if (!infold) {
+        const int rc = sgam_groupnorm_table_from_partials(gn_partial, nchunk, gamma, beta, table, B, n, C, 32, eps, stream);
+        if (rc != SGAM_OK) return rc;
+    }
     QkvHParams g;
-    g.x = (const unsigned short *)x; g.table = table; g.w = (const unsigned short *)w_frag; g.bias = bias; g.q = qb; g.kf = kf; g.vf = vf;
+    g.x = (const unsigned short *)x; g.table = infold ? nullptr : table; g.gn_partial = gn_partial; g.gamma = gamma; g.beta = beta;
+    g.nchunk = nchunk; g.gn_eps = eps; g.w = (const unsigned short *)w_frag; g.bias = bias; g.q = qb; g.kf = kf; g.vf = vf;
     g.ldx = ldx; g.n_img = n;
     if (sgam_i_prof_on) sgam_i_prof_shape(nt, 3 * AD, AD, 1);
     if (sgam_i_prof_on) sgam_i_prof_work(2.0 * nt * 3.0 * AD * AD, 2.0 * (4.0 * nt * AD + 3.0 * AD * AD));
@@ -1939,12 +2011,14 @@ extern "C" int64_t sgam_attn_block_f32x_workspace_bytes(int32_t n, int32_t C, in
 // out = x + proj_out(attention(q, k, v)), q | k | v = GroupNorm(x) Wqkv^T + b: fused front end (attn_qkv_gn_f32x_kernel), flash kernel,
 // merge + proj_out + residual (attn_combine_proj_f32x_kernel).  wqkv_planes: sgam_split_rows_f32x of the stacked [3 C][C] weight whose
 // rows were permuted inside every 32-row tile so that row 8 j + 4 h + i holds channel 16 h + 4 j + i; bqkv in natural order.
-extern "C" int sgam_attn_block_f32x(const float *x, int32_t ldx, const float *mean_rstd, const float *gamma, const float *beta,
-                                    const void *wqkv_planes, float wqkv_scale, const float *bqkv, int32_t n, int32_t C, int32_t B, float scale,
+static int attn_block_f32x_impl(const float *x, int32_t ldx, const float *mean_rstd, const double *gn_partial_in, int32_t nchunk_in, float eps,
+                                const float *gamma, const float *beta, const void *wqkv_planes, float wqkv_scale, const float *bqkv, int32_t n, int32_t C, int32_t B, float scale,
                                     const void *wp_planes, float wp_scale, const float *bp, float *out, int32_t ldc, double *gn_partial,
                                     int32_t gn_acc, void *workspace, int64_t workspace_bytes, void *stream) {
-    if (!x || !mean_rstd || !gamma || !beta || !wqkv_planes || !bqkv || !wp_planes || !out || !workspace || !(wqkv_scale > 0.f) || !(wp_scale > 0.f))
+    if (!x || (!mean_rstd && !gn_partial_in) || !gamma || !beta || !wqkv_planes || !bqkv || !wp_planes || !out || !workspace ||
+        !(wqkv_scale > 0.f) || !(wp_scale > 0.f))
         return SGAM_EINVAL;
+    if (!mean_rstd && (nchunk_in < 1 || nchunk_in > 128 || !(eps > 0.f) || !sgam_aligned16(gn_partial_in))) return SGAM_EINVAL;
     const int64_t need = sgam_attn_block_f32x_workspace_bytes(n, C, B);
     if (need < 0 || ldx < C || ldx % 4 != 0 || ldc < C || n % 64 != 0) return SGAM_EINVAL;
     int ex;
@@ -1962,7 +2036,8 @@ extern "C" int sgam_attn_block_f32x(const float *x, int32_t ldx, const float *me
     float *ws_ml = ws_o + (int64_t)nsplit * nt * AD;
     float *qb = ws_ml + (int64_t)nsplit * nt * 2;
     QkvXParams g;
-    g.x = x; g.mean_rstd = mean_rstd; g.gamma = gamma; g.beta = beta; g.w = (const unsigned short *)wqkv_planes; g.bias = bqkv;
+    g.x = x; g.mean_rstd = mean_rstd; g.gn_partial = gn_partial_in; g.nchunk = nchunk_in; g.gn_eps = eps;
+    g.gamma = gamma; g.beta = beta; g.w = (const unsigned short *)wqkv_planes; g.bias = bqkv;
     g.q = qb; g.kf = kf; g.vf = vf; g.range_flag = sgam_i_range_flag; g.ldx = ldx; g.n_img = n; g.inv_w_scale = 1.0f / wqkv_scale;
     if (sgam_i_prof_on) sgam_i_prof_shape(nt, 3 * AD, AD, 1);
     if (sgam_i_prof_on) sgam_i_prof_work(2.0 * nt * 3.0 * AD * AD, 4.0 * (4.0 * nt * AD + 3.0 * AD * AD));
@@ -2052,4 +2127,24 @@ extern "C" int sgam_attention_small_h16(const void *q, const void *k, const void
 #undef HSMALL
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
+}
+
+extern "C" int sgam_attn_block_f32x(const float *x, int32_t ldx, const float *mean_rstd, const float *gamma, const float *beta,
+                                    const void *wqkv_planes, float wqkv_scale, const float *bqkv, int32_t n, int32_t C, int32_t B, float scale,
+                                    const void *wp_planes, float wp_scale, const float *bp, float *out, int32_t ldc, double *gn_partial,
+                                    int32_t gn_acc, void *workspace, int64_t workspace_bytes, void *stream) {
+    if (!mean_rstd) return SGAM_EINVAL;
+    return attn_block_f32x_impl(x, ldx, mean_rstd, nullptr, 0, 0.f, gamma, beta, wqkv_planes, wqkv_scale, bqkv, n, C, B, scale, wp_planes, wp_scale,
+                                bp, out, ldc, gn_partial, gn_acc, workspace, workspace_bytes, stream);
+}
+
+// sgam_attn_block_f32x with the statistics of x still as its producer's chunk records [B][nchunk_in][32][2] (fp64 {sum, sumsq},
+// 1 <= nchunk_in <= 128): every workgroup of the front end folds them itself — no statistics launch in front of the block
+extern "C" int sgam_attn_block_gnp_f32x(const float *x, int32_t ldx, const double *gn_partial_in, int32_t nchunk_in, float eps, const float *gamma,
+                                        const float *beta, const void *wqkv_planes, float wqkv_scale, const float *bqkv, int32_t n, int32_t C,
+                                        int32_t B, float scale, const void *wp_planes, float wp_scale, const float *bp, float *out, int32_t ldc,
+                                        double *gn_partial, int32_t gn_acc, void *workspace, int64_t workspace_bytes, void *stream) {
+    if (!gn_partial_in) return SGAM_EINVAL;
+    return attn_block_f32x_impl(x, ldx, nullptr, gn_partial_in, nchunk_in, eps, gamma, beta, wqkv_planes, wqkv_scale, bqkv, n, C, B, scale, wp_planes,
+                                wp_scale, bp, out, ldc, gn_partial, gn_acc, workspace, workspace_bytes, stream);
 }

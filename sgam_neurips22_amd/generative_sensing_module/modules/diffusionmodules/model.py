@@ -208,9 +208,10 @@ class AttnBlock(_NHWCModule):
             if "f32x_perm" not in wqkvs:
                 w32 = wqkvs[torch.float32]
                 wqkvs["f32x_perm"] = ops.split_rows(ops.permute_rows_for_transposed_product(w32), wqkv.scale)
-            mr = ops.groupnorm_meanrstd(x, self.norm.eps)
+            infold = (ops.ATTN_FOLD and pre is not None and pre[0].dtype == torch.float64 and 1 <= pre[1] <= 128)
+            mr = None if infold else ops.groupnorm_meanrstd(x, self.norm.eps)      # (<= 128 chunk records: folded inside the front end)
             ob = ops.attn_block_f32x(x.reshape(B * n, C), mr, self.norm.weight.detach(), self.norm.bias.detach(), wqkvs["f32x_perm"], bqkv,
-                                     C, int(C) ** (-0.5), wp, bp, B=B)
+                                     C, int(C) ** (-0.5), wp, bp, B=B, pre=pre, eps=self.norm.eps)
             out = ob.view(B, H, W, C)
             if hasattr(ob, "_gn_partials"):
                 out._gn_partials = ob._gn_partials

@@ -353,6 +353,9 @@ ATTN_BLOCK_H16_PROJ = os.environ.get("SGAM_ATTN_BLOCK_H16_PROJ", "1") != "0"    
 ATTN_BLOCK_F32X = os.environ.get("SGAM_ATTN_BLOCK_F32X", "1") != "0"
 # the small AttnBlocks' attention (16 x 16 maps) as one launch instead of the seven of the GEMM chain (SGAM_ATTN_SMALL=0: the chain)
 ATTN_SMALL = os.environ.get("SGAM_ATTN_SMALL", "1") != "0"
+# opt-in: the fused AttnBlock front ends fold <= 128 chunk statistics of their input themselves instead of a statistics / table launch in
+# front (measured break-even to slightly slower: a dependent round trip in every workgroup's prologue costs what the launch + edge cost)
+ATTN_FOLD = os.environ.get("SGAM_ATTN_FOLD", "0") == "1"
 ARRIVE_COUNT = 4096
 
 
@@ -861,7 +864,7 @@ def permute_rows_for_transposed_product(w2d):
     return w2d.index_select(0, idx).contiguous()
 
 
-def attn_block_f32x(x2d, mean_rstd, gamma, beta, wqkv_perm, bqkv, C, scale, wp, bp, B=1, out=None):
+def attn_block_f32x(x2d, mean_rstd, gamma, beta, wqkv_perm, bqkv, C, scale, wp, bp, B=1, out=None, pre=None, eps=1e-6):
     """The whole AttnBlock of the split-fp32 path (reference diffusionmodules/model.py:168-192) in three launches: fused front end
     (GroupNorm + q | k | v, K / V^T straight in fragment order), one-pass attention, merge + proj_out + residual x.  wqkv_perm: the
     SplitWeight of permute_rows_for_transposed_product(stacked weight); statistics of the output travel as `_gn_partials`."""
@@ -884,9 +887,16 @@ def attn_block_f32x(x2d, mean_rstd, gamma, beta, wqkv_perm, bqkv, C, scale, wp, 
             partial, chunks, acc = rec, 0, 1
         else:
             partial = torch.empty((B * chunks * 32 * 2,), device=x2d.device, dtype=torch.float64)
-    check(lib.sgam_attn_block_f32x(_p(x2d), x2d.stride(0), _p(mean_rstd), _p(_f32c(gamma)), _p(_f32c(beta)), _p(wqkv_perm.planes),
-                                   float(wqkv_perm.scale), _p(bqkv), n, C, B, float(scale), _p(wp.planes), float(wp.scale), _p(bp),
-                                   _p(out), out.stride(0), _p(partial), acc, _p(ws), ws_bytes, _stream()), "sgam_attn_block_f32x")
+    if mean_rstd is None:
+        # pre = (chunk records, chunks <= 128) of x's producer: folded inside the front end (no statistics launch)
+        check(lib.sgam_attn_block_gnp_f32x(_p(x2d), x2d.stride(0), _p(pre[0]), int(pre[1]), float(eps), _p(_f32c(gamma)), _p(_f32c(beta)),
+                                           _p(wqkv_perm.planes), float(wqkv_perm.scale), _p(bqkv), n, C, B, float(scale), _p(wp.planes),
+                                           float(wp.scale), _p(bp), _p(out), out.stride(0), _p(partial), acc, _p(ws), ws_bytes, _stream()),
+              "sgam_attn_block_gnp_f32x")
+    else:
+        check(lib.sgam_attn_block_f32x(_p(x2d), x2d.stride(0), _p(mean_rstd), _p(_f32c(gamma)), _p(_f32c(beta)), _p(wqkv_perm.planes),
+                                       float(wqkv_perm.scale), _p(bqkv), n, C, B, float(scale), _p(wp.planes), float(wp.scale), _p(bp),
+                                       _p(out), out.stride(0), _p(partial), acc, _p(ws), ws_bytes, _stream()), "sgam_attn_block_f32x")
     if partial is not None:
         out._gn_partials = (partial, chunks)
     return out

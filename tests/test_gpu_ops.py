@@ -682,8 +682,8 @@ def test_panel_gemm_1x1_conv_with_residual_and_statistics(case):
     assert torch.allclose(st[:, :, 1].double(), (og.var(-1, unbiased=False) + 1e-6).rsqrt(), rtol=1e-5, atol=0)
 
 
-@pytest.mark.parametrize("B", [1, 2])
-def test_attn_block_in_three_launches_matches_the_gemm_and_split_sequence(B, monkeypatch):
+@pytest.mark.parametrize("B,produced", [(1, False), (2, False), (1, True), (2, True)])
+def test_attn_block_in_three_launches_matches_the_gemm_and_split_sequence(B, produced, monkeypatch):
     """ABI v9: the fused front end of the split-fp32 AttnBlock computes the q | k | v projection transposed and writes K / V^T
     straight in the attention's fragment order — the same normalisation expression, the same three MFMAs per product in the same
     order; against the gemm_gn_f32x + attn_split_kv sequence (fp32 round-off of a transposed MFMA chain: not bit-identical, measured),
@@ -697,6 +697,14 @@ def test_attn_block_in_three_launches_matches_the_gemm_and_split_sequence(B, mon
     mod = mod.to(DEV).eval()
     xc = testing.seeded_tensor("ab3.x", (B, 256, 64, 64), 1.0, 0.3)
     x = ops.nchw_to_nhwc(xc.to(DEV))
+    monkeypatch.setattr(ops, "ATTN_FOLD", produced)          # (opt-in: SGAM_ATTN_FOLD=1)
+    if produced:
+        # the block input as a convolution leaves it, with its chunk statistics: the front end then folds them itself (no statistics
+        # launch: two launches fewer than the GEMM + split sequence, which also runs a fold)
+        w = testing.seeded_tensor("ab3.w", (256, 256, 3, 3), scale=(1.0 / (256 * 9)) ** 0.5).to(DEV)
+        x = ops.conv2d_nhwc(x, ops.pack_conv_weight(w, dtype="f32x"), None, cout=256, kh=3, kw=3, pad_t=1, pad_l=1)
+        assert hasattr(x, "_gn_partials") and 1 <= x._gn_partials[1] <= 128
+        xc = x.permute(0, 3, 1, 2).cpu()
     with torch.no_grad():
         monkeypatch.setattr(ops, "ATTN_BLOCK_F32X", False)
         sep = mod.forward_nhwc(x)                                    # (the first call of either form packs its weights)
@@ -707,7 +715,8 @@ def test_attn_block_in_three_launches_matches_the_gemm_and_split_sequence(B, mon
         again = mod.forward_nhwc(x)
     names0, names1 = [r[0] for r in recs0], [r[0] for r in recs1]
     assert any("attn_qkv_gn_f32x" in k for k in names1) and not any("split_kv" in k or "gemm_gn_f32x" in k for k in names1), names1
-    assert len(names1) == len(names0) - 1, (names0, names1)
+    assert len(names1) == len(names0) - (2 if produced else 1), (names0, names1)
+    assert produced == (not any("gn_finalize" in k for k in names1)), names1
     assert torch.equal(fused, again) and torch.equal(fused._gn_partials[0], again._gn_partials[0])
     d = (fused - sep).abs().max().item()
     print(f"[attn_block_f32x B={B}] max |fused - separate| = {d:.3e} (max |out| {sep.abs().max().item():.3f})")
