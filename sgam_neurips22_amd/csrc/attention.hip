@@ -108,6 +108,8 @@ __global__ __launch_bounds__(256) void attn_split_kv_kernel(const float *__restr
 }
 
 struct AttnParams {
+    const unsigned short *qf;       // optional: Q already scaled, split and in B-fragment order (attn_qkv_gn_f32x_kernel):
+                                    //   [n / 32][16 k-steps][hi | lo][64 lanes][8 halfs]; NULL: q below is read and split here
     const float *q;                 // [n][ld] fp32, AD columns
     const unsigned short *kf, *vf;  // fragment-ordered K and V^T
     float *ws_o;                    // [NSPLIT][n / 32][AD][32]   un-normalised O^T per (split, 32-query tile)
@@ -156,7 +158,16 @@ __global__ __launch_bounds__(256) void attn_flash_f32x_kernel(const AttnParams p
     };
     // ---- query panel -> B fragments (registers): k-step t covers d = 16 t + 8 h + 0..7 of query q0 + lq
     u32x4 qh[16], ql[16];
-    {
+    if (p.qf) {
+        // (round 5) the fused front end left the panel as fragments: 32 coalesced kilobyte loads instead of 32 x 64 scattered 16-byte
+        // pieces (one per (query row, half) — the CU's address path again, §5.5e) and 16 operand splits
+        const unsigned short *qb = p.qf + (int64_t)(q0 >> 5) * (16 * 1024) + lane * 8;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            qh[t] = *reinterpret_cast<const u32x4 *>(qb + t * 1024);
+            ql[t] = *reinterpret_cast<const u32x4 *>(qb + t * 1024 + 512);
+        }
+    } else {
         const float *qp = p.q + (int64_t)(q0 + lq) * p.ld + lh * 8;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
@@ -634,11 +645,11 @@ struct QkvXParams {
     const float *gamma, *beta;      // [AD]
     const unsigned short *w;        // split_rows planes of the ROW-PERMUTED stacked weight: [3 AD / 32][AD / 32][256 pieces][8 halfs]
     const float *bias;              // [3 AD] (natural channel order)
-    float *q;                       // [nt][AD] fp32
+    unsigned short *qf;             // Q scaled by `qscale`, split, in the flash kernel's B-fragment order [nt / 32][16][hi | lo][64][8]
     unsigned short *kf, *vf;        // attn_split_kv_kernel's layout
     int32_t *range_flag;
     int ldx, n_img;
-    float inv_w_scale;
+    float inv_w_scale, qscale;
 };
 
 __global__ __launch_bounds__(256, 2) void attn_qkv_gn_f32x_kernel(const QkvXParams p) {
@@ -732,13 +743,20 @@ __global__ __launch_bounds__(256, 2) void attn_qkv_gn_f32x_kernel(const QkvXPara
             gs += v[j][e];
         }
     if (p.range_flag && sgam_not_finite(gs)) atomicOr(p.range_flag, 1);          // an operand left fp16's range
-    if (by < 2) {
+    if (by < 2) {                                                     // Q: scaled (a power of two: exact), split, as B fragments of k-step (by 128 + cw) / 16
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            float *dst = p.q + (int64_t)(m0 + j * 32 + lr) * AD + by * 128 + cw;
+            unsigned short *dst = p.qf + ((int64_t)((m0 >> 5) + j) * 16 + by * 8 + wave * 2 + lh) * 1024 + lr * 8;
 #pragma unroll
-            for (int e4 = 0; e4 < 4; ++e4)
-                *reinterpret_cast<f32x4 *>(dst + 4 * e4) = f32x4{v[j][4 * e4], v[j][4 * e4 + 1], v[j][4 * e4 + 2], v[j][4 * e4 + 3]};
+            for (int h = 0; h < 2; ++h) {
+                float sv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sv[e] = v[j][8 * h + e] * p.qscale;
+                u32x4 hi, lo;
+                split8(sv, hi, lo);
+                *reinterpret_cast<u32x4 *>(dst + h * 32 * 8) = hi;
+                *reinterpret_cast<u32x4 *>(dst + h * 32 * 8 + 512) = lo;
+            }
         }
     } else if (by < 4) {                                              // K pieces (plane, k-step lh, half h, key lr) of d-tile (by - 2) 4 + wave
 #pragma unroll
@@ -1059,7 +1077,7 @@ struct QkvHParams {
     float gn_eps;
     const unsigned short *w;        // fragment-ordered stacked weights [3 AD / 32][AD / 16][64 lanes][8 halfs]
     const float *bias;              // [3 AD]
-    unsigned short *q, *kf, *vf;    // q [nt][AD]; K / V^T fragments (attn_split_kv_h16_kernel's layout)
+    unsigned short *q, *kf, *vf;    // q as the flash kernel's B fragments [nt / 32][16][64][8]; K / V^T fragments (attn_split_kv_h16_kernel's layout)
     int ldx, n_img;
 };
 
@@ -1148,12 +1166,12 @@ __global__ __launch_bounds__(256, 2) void attn_qkv_gn_h16_kernel(const QkvHParam
 #pragma unroll
         for (int e = 0; e < 16; e += 2)
             pk[j][e >> 3][(e & 7) >> 1] = HM<HT>::pack2(acc[j][e] + bias[e], acc[j][e + 1] + bias[e + 1]);
-    if (by < 2) {                                                     // q: row-major [token][AD]
+    if (by < 2) {                                                     // q: the flash kernel's B fragments, k-step (by 128 + cw) / 16, lane half = channel octet
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            unsigned short *dst = p.q + (int64_t)(m0 + j * 32 + lr) * AD + by * 128 + cw;
+            unsigned short *dst = p.q + ((int64_t)((m0 >> 5) + j) * 16 + by * 8 + wave * 2 + lh) * 512 + lr * 8;
             *reinterpret_cast<u32x4 *>(dst) = pk[j][0];
-            *reinterpret_cast<u32x4 *>(dst + 8) = pk[j][1];
+            *reinterpret_cast<u32x4 *>(dst + 32 * 8) = pk[j][1];
         }
     } else if (by < 4) {                                              // K fragments: piece (k-step lh, half h, key lr) of d-tile (by - 2) 4 + wave
 #pragma unroll
@@ -1185,6 +1203,7 @@ __global__ __launch_bounds__(256, 2) void attn_qkv_gn_h16_kernel(const QkvHParam
 }
 
 struct AttnHParams {
+    int q_frag;                         // q is [n / 32][16 k-steps][64 lanes][8 halfs] (attn_qkv_gn_h16_kernel) instead of rows
     const unsigned short *q, *kf, *vf;
     float *ws_o, *ws_ml;
     int ld, n, blocks_per_split;    // n = tokens of the whole batch, as in AttnParams
@@ -1216,7 +1235,11 @@ __global__ __launch_bounds__(256, 2) void attn_flash_h16_kernel(const AttnHParam
     dma(vg, blk(0), 2);
 
     u32x4 qf[16];                      // query panel: k-step t = d 16 t + 8 h + 0..7 of query q0 + lq
-    {
+    if (p.q_frag) {                    // left as fragments by the fused front end: 16 coalesced kilobyte loads
+        const unsigned short *qp = p.q + (int64_t)(q0 >> 5) * (16 * 512) + lane * 8;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) qf[t] = *reinterpret_cast<const u32x4 *>(qp + t * 512);
+    } else {
         const unsigned short *qp = p.q + (int64_t)(q0 + lq) * p.ld + lh * 8;
 #pragma unroll
         for (int t = 0; t < 16; ++t) qf[t] = *reinterpret_cast<const u32x4 *>(qp + t * 16);
@@ -1735,7 +1758,7 @@ extern "C" int sgam_attention_f32x_batched(const float *q, const float *k, const
     SGAM_KLAUNCH(attn_split_kv_kernel, dim3(nt / KB * 8 * 128 / 256), dim3(256), 0, s, k, v, ld, nt, kf, vf);
     SGAM_LAUNCH_CHECK();
     AttnParams p;
-    p.q = q; p.kf = kf; p.vf = vf; p.ws_o = ws_o; p.ws_ml = ws_ml;
+    p.qf = nullptr; p.q = q; p.kf = kf; p.vf = vf; p.ws_o = ws_o; p.ws_ml = ws_ml;
     p.ld = ld; p.n = nt; p.n_img = n; p.nsplit = nsplit; p.blocks_per_split = n / KB / nsplit; p.qscale = scale;
     if (sgam_i_prof_on) sgam_i_prof_work(4.0 * B * n * (double)n * AD, 4.0 * 4.0 * nt * AD);   // q k^T + P v; q, k, v, o once
     SGAM_KLAUNCH(attn_flash_f32x_kernel, dim3(nt / 128 * nsplit), dim3(256), 0, s, p);
@@ -1785,7 +1808,7 @@ extern "C" int sgam_attention_proj_f32x_batched(const float *q, const float *k, 
     SGAM_KLAUNCH(attn_split_kv_kernel, dim3(nt / KB * 8 * 128 / 256), dim3(256), 0, s, k, v, ld, nt, kf, vf);
     SGAM_LAUNCH_CHECK();
     AttnParams p;
-    p.q = q; p.kf = kf; p.vf = vf; p.ws_o = ws_o; p.ws_ml = ws_ml;
+    p.qf = nullptr; p.q = q; p.kf = kf; p.vf = vf; p.ws_o = ws_o; p.ws_ml = ws_ml;
     p.ld = ld; p.n = nt; p.n_img = n; p.nsplit = nsplit; p.blocks_per_split = n / KB / nsplit; p.qscale = scale;
     if (sgam_i_prof_on) sgam_i_prof_work(4.0 * B * n * (double)n * AD, 4.0 * 4.0 * nt * AD);
     SGAM_KLAUNCH(attn_flash_f32x_kernel, dim3(nt / 128 * nsplit), dim3(256), 0, s, p);
@@ -1837,7 +1860,7 @@ extern "C" int sgam_attention_h16_batched(const void *q, const void *k, const vo
                        (const unsigned short *)v, ld, nt, kf, vf);
     SGAM_LAUNCH_CHECK();
     AttnHParams p;
-    p.q = (const unsigned short *)q; p.kf = kf; p.vf = vf; p.ws_o = ws_o; p.ws_ml = ws_ml;
+    p.q_frag = 0; p.q = (const unsigned short *)q; p.kf = kf; p.vf = vf; p.ws_o = ws_o; p.ws_ml = ws_ml;
     p.ld = ld; p.n = nt; p.n_img = n; p.nsplit = nsplit; p.blocks_per_split = n / KB / nsplit; p.qscale_log2e = scale * LOG2E;
     const dim3 grid(nt / 128 * nsplit), cgrid(nt / 32 * 8);
     if (sgam_i_prof_on) sgam_i_prof_work(4.0 * B * n * (double)n * AD, 4.0 * 2.0 * nt * AD);
@@ -1956,7 +1979,7 @@ static int attn_block_h16_impl(const void *x, int32_t ldx, const double *gn_part
     else SGAM_KLAUNCH(attn_qkv_gn_h16_kernel<1>, dim3(nt / 64, 6), dim3(256), 0, s, g);
     SGAM_LAUNCH_CHECK();
     AttnHParams p;
-    p.q = qb; p.kf = kf; p.vf = vf; p.ws_o = ws_o; p.ws_ml = ws_ml;
+    p.q_frag = 1; p.q = qb; p.kf = kf; p.vf = vf; p.ws_o = ws_o; p.ws_ml = ws_ml;
     p.ld = AD; p.n = nt; p.n_img = n; p.nsplit = nsplit; p.blocks_per_split = n / KB / nsplit; p.qscale_log2e = scale * LOG2E;
     const dim3 grid(nt / 128 * nsplit), cgrid(nt / 32 * 8);
     if (sgam_i_prof_on) sgam_i_prof_work(4.0 * B * n * (double)n * AD, 4.0 * 2.0 * nt * AD);
@@ -2034,17 +2057,18 @@ static int attn_block_f32x_impl(const float *x, int32_t ldx, const float *mean_r
     unsigned short *vf = kf + (int64_t)nt * AD * 2;
     float *ws_o = (float *)(vf + (int64_t)nt * AD * 2);
     float *ws_ml = ws_o + (int64_t)nsplit * nt * AD;
-    float *qb = ws_ml + (int64_t)nsplit * nt * 2;
+    unsigned short *qb = reinterpret_cast<unsigned short *>(ws_ml + (int64_t)nsplit * nt * 2);      // [nt][AD] x (hi + lo): the same bytes as fp32 rows
     QkvXParams g;
     g.x = x; g.mean_rstd = mean_rstd; g.gn_partial = gn_partial_in; g.nchunk = nchunk_in; g.gn_eps = eps;
     g.gamma = gamma; g.beta = beta; g.w = (const unsigned short *)wqkv_planes; g.bias = bqkv;
-    g.q = qb; g.kf = kf; g.vf = vf; g.range_flag = sgam_i_range_flag; g.ldx = ldx; g.n_img = n; g.inv_w_scale = 1.0f / wqkv_scale;
+    g.qf = qb; g.kf = kf; g.vf = vf; g.range_flag = sgam_i_range_flag; g.ldx = ldx; g.n_img = n; g.inv_w_scale = 1.0f / wqkv_scale;
+    g.qscale = scale;
     if (sgam_i_prof_on) sgam_i_prof_shape(nt, 3 * AD, AD, 1);
     if (sgam_i_prof_on) sgam_i_prof_work(2.0 * nt * 3.0 * AD * AD, 4.0 * (4.0 * nt * AD + 3.0 * AD * AD));
     SGAM_KLAUNCH(attn_qkv_gn_f32x_kernel, dim3(nt / 64, 6), dim3(256), 0, s, g);
     SGAM_LAUNCH_CHECK();
     AttnParams p;
-    p.q = qb; p.kf = kf; p.vf = vf; p.ws_o = ws_o; p.ws_ml = ws_ml;
+    p.qf = qb; p.q = nullptr; p.kf = kf; p.vf = vf; p.ws_o = ws_o; p.ws_ml = ws_ml;
     p.ld = AD; p.n = nt; p.n_img = n; p.nsplit = nsplit; p.blocks_per_split = n / KB / nsplit; p.qscale = scale;
     if (sgam_i_prof_on) sgam_i_prof_work(4.0 * B * n * (double)n * AD, 4.0 * 4.0 * nt * AD);
     SGAM_KLAUNCH(attn_flash_f32x_kernel, dim3(nt / 128 * nsplit), dim3(256), 0, s, p);
