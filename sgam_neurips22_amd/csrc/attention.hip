@@ -122,7 +122,7 @@ struct AttnParams {
 constexpr int NSPLIT = 8;          // key ranges = XCDs
 #ifndef SGAM_ATTN_ABLATE
 #define SGAM_ATTN_ABLATE 0         // timing experiments only (results are wrong when != 0), bit mask: 1 no staging in the
-#endif                             // loop, 2 no soft-max arithmetic, 4 no S MFMAs, 8 no PV MFMAs, 16 no loop at all
+#endif                             // loop, 2 no soft-max arithmetic, 4 no S MFMAs, 8 no PV MFMAs, 16 no loop at all, 32 no partial-O stores
 
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
@@ -372,7 +372,8 @@ __global__ __launch_bounds__(256) void attn_flash_f32x_kernel(const AttnParams p
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) wo[(32 * i + 8 * (e >> 2) + 4 * lh + (e & 3)) * 32] = o[i][e];
+        for (int e = 0; e < 16; ++e)
+            if (!(SGAM_ATTN_ABLATE & 32) || o[i][e] == 12345.678f) wo[(32 * i + 8 * (e >> 2) + 4 * lh + (e & 3)) * 32] = o[i][e];
     // the blocks requested past the end of the range (same piece count on every trip keeps the waits countable) must have
     // landed before this workgroup's LDS is handed to the next one
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
