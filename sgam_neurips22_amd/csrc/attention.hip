@@ -1212,24 +1212,31 @@ struct AttnHParams {
     float qscale_log2e;             // C^-1/2 * log2(e): applied to the fp32 scores
 };
 
-template <int HT>
-__global__ __launch_bounds__(256, 2) void attn_flash_h16_kernel(const AttnHParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * HBLK_BYTES];   // K buffers 0, 1 | V^T buffers 0, 1
+// NWV = 4: 128 queries per workgroup, two workgroups per CU by the register budget (one per CU on the B = 1 grid of 256).  NWV = 8 (opt-in
+// experiment, SGAM_ATTN_H8=1): 256 queries share ONE K / V stream — half the LDS-DMA pieces per wavefront and key, two wavefronts per SIMD —
+// on a grid of half as many workgroups.
+template <int HT, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void attn_flash_h16_kernel(const AttnHParams p) {
+    // K buffers 0, 1 | V^T buffers 0, 1; the epilogue's transpose wants one block per wavefront
+    __shared__ __attribute__((aligned(16))) unsigned char smem[(NWV > 4 ? NWV : 4) * HBLK_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sp = blockIdx.x % p.nsplit, qb = blockIdx.x / p.nsplit;
-    const int q0 = qb * 128 + wave * 32;
+    const int q0 = qb * (32 * NWV) + wave * 32;
     const int lq = lane & 31, lh = lane >> 5;
-    const int kb0 = ((qb * 128) / p.n_img) * (p.n_img / KB) + sp * p.blocks_per_split, nb = p.blocks_per_split;
+    const int kb0 = ((qb * (32 * NWV)) / p.n_img) * (p.n_img / KB) + sp * p.blocks_per_split, nb = p.blocks_per_split;
     const unsigned char *kg = reinterpret_cast<const unsigned char *>(p.kf), *vg = reinterpret_cast<const unsigned char *>(p.vf);
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-    // a wavefront moves 4 KB of every 16 KB block: four 1 KB LDS-DMA pieces behind one (address, M0) setup
+    // a wavefront moves 16 KB / NWV of every block: 1 KB LDS-DMA pieces behind one (address, M0) setup
+    constexpr int WB = HBLK_BYTES / NWV;
     auto dma = [&](const unsigned char *g, int kb, int slot) {
-        const unsigned char *src = g + (int64_t)kb * HBLK_BYTES + wave_s * 4096 + lane * 16;
-        unsigned char *dst = smem + slot * HBLK_BYTES + wave_s * 4096;
+        const unsigned char *src = g + (int64_t)kb * HBLK_BYTES + wave_s * WB + lane * 16;
+        unsigned char *dst = smem + slot * HBLK_BYTES + wave_s * WB;
         __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)dst, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)dst, 16, 1024, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)dst, 16, 2048, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)dst, 16, 3072, 0);
+        if constexpr (NWV == 4) {
+            __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)dst, 16, 2048, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)dst, 16, 3072, 0);
+        }
     };
     auto blk = [&](int j) { return kb0 + (j < nb ? j : nb - 1); };
     dma(kg, blk(0), 0);
@@ -1865,8 +1872,13 @@ extern "C" int sgam_attention_h16_batched(const void *q, const void *k, const vo
     p.ld = ld; p.n = nt; p.n_img = n; p.nsplit = nsplit; p.blocks_per_split = n / KB / nsplit; p.qscale_log2e = scale * LOG2E;
     const dim3 grid(nt / 128 * nsplit), cgrid(nt / 32 * 8);
     if (sgam_i_prof_on) sgam_i_prof_work(4.0 * B * n * (double)n * AD, 4.0 * 2.0 * nt * AD);
-    if (ht == 0) SGAM_KLAUNCH(attn_flash_h16_kernel<0>, grid, dim3(256), 0, s, p);
-    else SGAM_KLAUNCH(attn_flash_h16_kernel<1>, grid, dim3(256), 0, s, p);
+    static const int h8 = [] { const char *e = getenv("SGAM_ATTN_H8"); return (e && e[0] == '1') ? 1 : 0; }();
+    if (h8) {                                                          // 256-query workgroups, one K / V stream for eight wavefronts
+        const dim3 grid8(nt / 256 * nsplit);
+        if (ht == 0) SGAM_KLAUNCH((attn_flash_h16_kernel<0, 8>), grid8, dim3(512), 0, s, p);
+        else SGAM_KLAUNCH((attn_flash_h16_kernel<1, 8>), grid8, dim3(512), 0, s, p);
+    } else if (ht == 0) SGAM_KLAUNCH((attn_flash_h16_kernel<0, 4>), grid, dim3(256), 0, s, p);
+    else SGAM_KLAUNCH((attn_flash_h16_kernel<1, 4>), grid, dim3(256), 0, s, p);
     SGAM_LAUNCH_CHECK();
 #define HCOMBINE(HT_, NS_) SGAM_KLAUNCH((attn_combine_h16_kernel<HT_, NS_>), cgrid, dim3(256), 0, s, ws_o, ws_ml, (unsigned short *)out, ldo, nt)
     switch (nsplit * 2 + (ht ? 1 : 0)) {
@@ -1984,8 +1996,13 @@ static int attn_block_h16_impl(const void *x, int32_t ldx, const double *gn_part
     p.ld = AD; p.n = nt; p.n_img = n; p.nsplit = nsplit; p.blocks_per_split = n / KB / nsplit; p.qscale_log2e = scale * LOG2E;
     const dim3 grid(nt / 128 * nsplit), cgrid(nt / 32 * 8);
     if (sgam_i_prof_on) sgam_i_prof_work(4.0 * B * n * (double)n * AD, 4.0 * 2.0 * nt * AD);
-    if (ht == 0) SGAM_KLAUNCH(attn_flash_h16_kernel<0>, grid, dim3(256), 0, s, p);
-    else SGAM_KLAUNCH(attn_flash_h16_kernel<1>, grid, dim3(256), 0, s, p);
+    static const int h8 = [] { const char *e = getenv("SGAM_ATTN_H8"); return (e && e[0] == '1') ? 1 : 0; }();
+    if (h8) {                                                          // 256-query workgroups, one K / V stream for eight wavefronts
+        const dim3 grid8(nt / 256 * nsplit);
+        if (ht == 0) SGAM_KLAUNCH((attn_flash_h16_kernel<0, 8>), grid8, dim3(512), 0, s, p);
+        else SGAM_KLAUNCH((attn_flash_h16_kernel<1, 8>), grid8, dim3(512), 0, s, p);
+    } else if (ht == 0) SGAM_KLAUNCH((attn_flash_h16_kernel<0, 4>), grid, dim3(256), 0, s, p);
+    else SGAM_KLAUNCH((attn_flash_h16_kernel<1, 4>), grid, dim3(256), 0, s, p);
     SGAM_LAUNCH_CHECK();
     if (wp_frag) {                                                    // merge + proj_out + residual (= x) in one launch
         CombProjHParams c;
