@@ -21,3 +21,12 @@ def test_persistent_producer_consumer_kernel_is_bit_identical_to_the_one_role_ke
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "h16_pc_check.py")], capture_output=True, text=True, timeout=900,
                        env={k: v for k, v in os.environ.items() if k != "SGAM_HPC"})
     assert r.returncode == 0 and "BIT-IDENTICAL" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+
+
+def test_flash_h16_with_256_query_workgroups_is_bit_identical():
+    """SGAM_ATTN_H8=1 (attn_flash_h16_kernel<HT, 8>, csrc/attention.hip): eight wavefronts share ONE K / V stream — half the LDS-DMA
+    pieces per wavefront and key — on a grid of half as many workgroups.  Same per-wavefront arithmetic over the same key ranges:
+    scripts/attn_h8_check.py compares SHA-256 digests of the outputs of both forms (bf16 and fp16; B = 1 / 2 at n = 4096, n = 1024)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "attn_h8_check.py")], capture_output=True, text=True, timeout=900,
+                       env={k: v for k, v in os.environ.items() if k != "SGAM_ATTN_H8"})
+    assert r.returncode == 0 and "BIT-IDENTICAL" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
