@@ -85,7 +85,9 @@ def candidates(key):
 changed = {}
 cur = base
 for key in keys:
-    if "|k3x3s1" not in key:                     # the 3x3 / stride 1 convolutions carry the frame; 1x1 / stride-2 shapes keep their plans
+    # the 3x3 / stride 1 convolutions carry the frame; SGAM_PLAN_SEARCH=<substring> searches the shapes whose key contains it instead
+    # (e.g. "k3x3s2": the four Downsample convolutions on the generic kernel)
+    if os.environ.get("SGAM_PLAN_SEARCH", "|k3x3s1") not in key:
         continue
     best_pl, best_ms = None, cur
     for pl in candidates(key):
@@ -110,4 +112,5 @@ ops.PLAN_CACHE.clear(); ops.PLAN_CACHE.update(plans)
 end = frame_ms(3)
 print(f"{mode}: end {end:.4f} ms/frame = {1e3 / end:.1f} frames/s ({len(changed)} plans changed)", flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump({"mode": mode, "start_ms": base, "end_ms": end, "changed": changed}, open(f"gpurun_out/plan_search_{mode}.json", "w"), indent=1)
+tag = os.environ.get("SGAM_PLAN_SEARCH", "").replace("|", "")
+json.dump({"mode": mode, "start_ms": base, "end_ms": end, "changed": changed}, open("gpurun_out/plan_search_" + mode + ("_" + tag if tag else "") + ".json", "w"), indent=1)
