@@ -761,3 +761,55 @@ def test_small_attention_in_one_launch_matches_the_gemm_chain_and_fp64(B, n):
     blk = qkv2[:n]
     ref = torch.softmax(blk[:, :C].double() @ blk[:, C:2 * C].double().t() * scale, dim=1) @ blk[:, 2 * C:].double()
     _close(o2[:n], ref, 4e-6, "small attention, peaked and uniform rows")
+
+
+def test_abi_v9_entries_refuse_what_they_do_not_support():
+    """error behaviour of the round-5 entry points through the raw C ABI: unsupported shapes / a scale that is not a power of two ->
+    SGAM_EINVAL (-1), a short workspace -> SGAM_EWORKSPACE (-3), a misaligned operand -> SGAM_EALIGN (-2); none of them launches"""
+    from sgam_neurips22_amd import _lib
+    lib = _lib.load()
+    C, n = 256, 4096
+    assert lib.sgam_attn_block_f32x_workspace_bytes(n, C, 1) == lib.sgam_attention_f32x_batched_workspace_bytes(n, C, 1) + n * C * 4
+    assert lib.sgam_attn_block_f32x_workspace_bytes(n, 512, 1) == -1 and lib.sgam_attn_block_h16_workspace_bytes(1000, C, 1) == -1
+    assert lib.sgam_attention_small_f32x_fits(256, 512, 3) == 1 and lib.sgam_attention_small_f32x_fits(256, 256, 1) == 0
+    assert lib.sgam_attention_small_f32x_fits(192, 512, 1) == 0
+    x = torch.zeros((n, C), device=DEV)
+    mr = torch.zeros((1, 32, 2), device=DEV)
+    g = torch.ones((C,), device=DEV)
+    w = ops.split_rows(torch.zeros((3 * C, C), device=DEV), 1.0)
+    wp = ops.split_rows(torch.zeros((C, C), device=DEV), 1.0)
+    b3 = torch.zeros((3 * C,), device=DEV)
+    out = torch.empty((n, C), device=DEV)
+    need = lib.sgam_attn_block_f32x_workspace_bytes(n, C, 1)
+    ws = torch.empty((need,), device=DEV, dtype=torch.uint8)
+
+    def call(scale=1 / 16.0, ws_bytes=need, xp=None, nn=n):
+        return lib.sgam_attn_block_f32x(xp if xp is not None else ops._p(x), C, ops._p(mr), ops._p(g), ops._p(g), ops._p(w.planes), 1.0, ops._p(b3), nn, C, 1,
+                                        scale, ops._p(wp.planes), 1.0, None, ops._p(out), C, None, 0, ops._p(ws), ws_bytes, None)
+    assert call() == 0
+    assert call(scale=0.07) == -1                      # folded into q: must be an exact power of two
+    assert call(nn=1000) == -1
+    assert call(ws_bytes=need - 1) == -3
+    assert call(xp=x.data_ptr() + 4) == -2
+    # the small attention: wrong channel count, a row stride that is not a multiple of four
+    q = torch.zeros((256, 3 * 512), device=DEV)
+    o = torch.empty((256, 512), device=DEV)
+    assert lib.sgam_attention_small_f32x(ops._p(q), ops._p(q[:, 512:]), ops._p(q[:, 1024:]), 1536, 256, 512, 1, 0.05, ops._p(o), 512, None) == 0
+    assert lib.sgam_attention_small_f32x(ops._p(q), ops._p(q[:, 512:]), ops._p(q[:, 1024:]), 1536, 256, 256, 1, 0.05, ops._p(o), 512, None) == -1
+    assert lib.sgam_attention_small_f32x(ops._p(q), ops._p(q[:, 512:]), ops._p(q[:, 1024:]), 1534, 256, 512, 1, 0.05, ops._p(o), 512, None) == -1
+    # the 16-bit block: no statistics, a bad type code
+    xh = torch.zeros((n, C), device=DEV, dtype=torch.bfloat16)
+    wf = ops.pack_qkv_weight_h16(torch.zeros((3 * C, C), device=DEV), torch.bfloat16)
+    oh = torch.empty((n, C), device=DEV, dtype=torch.bfloat16)
+    needh = lib.sgam_attn_block_h16_workspace_bytes(n, C, 1)
+    wsh = torch.empty((needh,), device=DEV, dtype=torch.uint8)
+    part = torch.zeros((64 * 32 * 2,), device=DEV, dtype=torch.float64)
+
+    def callh(ht=0, partial=None, ws_bytes=needh):
+        return lib.sgam_attn_block_h16(ops._p(xh), C, partial if partial is not None else ops._p(part), 64, ops._p(g), ops._p(g), 1e-6, ops._p(wf), ops._p(b3),
+                                       ht, n, C, 1, 1 / 16.0, ops._p(oh), C, ops._p(wsh), ws_bytes, None)
+    assert callh() == 0
+    assert callh(ht=2) == -1
+    assert callh(partial=0) == -1
+    assert callh(ws_bytes=needh - 1) == -3
+    torch.cuda.synchronize()
