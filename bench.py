@@ -151,6 +151,7 @@ def timed_loop(step_fn, warmup, steps):
 
 _PMC_FRAME = {}
 _PMC_COMMIT = [None]    # "library @ <commit>" the committed counter files were collected on (profiles/pmc_index.json)
+_PMC_DIGEST = [None]    # the library digest (sgam_build_digest) of that build, when the file carries one (round 6 on)
 
 
 def pmc_frame_entry(mode, timeline_name):
@@ -168,6 +169,7 @@ def pmc_frame_entry(mode, timeline_name):
                 doc = json.load(open(os.path.join(ROOT, "profiles", fn)))
                 _PMC_FRAME[mode] = (fn, doc["kernels"])
                 _PMC_COMMIT[0] = doc.get("collected_at") or _PMC_COMMIT[0]      # the file's own stamp wins over the index's
+                _PMC_DIGEST[0] = doc.get("lib_digest")
     fn, kernels = _PMC_FRAME[mode]
     if timeline_name in kernels:
         return fn, kernels[timeline_name]
@@ -209,7 +211,12 @@ def attach_counters(roofline, mode):
     fn, ent = pmc_frame_entry(mode, roofline["kernel"])
     if ent is not None:
         roofline["traffic"] = ent["hbm_traffic_bytes_per_launch"]
-        roofline["counters_commit"] = _PMC_COMMIT[0]          # the build the committed counters were collected on; compare with `head`
+        commit, digest = lib_stamp()
+        cc = (_PMC_COMMIT[0] or "").replace("library @ ", "").strip()
+        roofline["counters_commit"] = cc or None       # the build the committed counters were collected on; equals `head` when fresh
+        # stale = the counters were collected on another build of the library than the one benched (digest when the file has
+        # one, else the commit stamp)
+        roofline["counters_stale"] = (_PMC_DIGEST[0] != digest) if _PMC_DIGEST[0] else (cc != commit)
         roofline["counters_source"] = (f"traffic + mfma_busy_frac: NOT measured in this run — committed rocprofv3 --pmc passes over the same "
                                        f"eager frame, profiles/{fn}" + (f" ({_PMC_COMMIT[0]})" if _PMC_COMMIT[0] else ""))
         roofline["traffic_note"] = (f"HBM bytes per launch of {roofline['kernel']}, averaged over its {ent['launches_per_frame']} in-frame "
@@ -374,13 +381,13 @@ def warp_roofline(dev, reps=8):
 LINE_BUDGET = 4096      # bytes of the ONE JSON line (the driver's parser choked on the 20 KB line of round 3)
 
 
-def _git_head():
-    try:
-        import subprocess
-        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True,
-                              timeout=5).stdout.strip() or None
-    except Exception:
-        return None
+def lib_stamp():
+    """(commit, digest) compiled into libsgam_hip.so at build time (csrc/build_info.hip, sgam_neurips22_amd/build.py): the last
+    commit that touched the library's sources and a sha256 over sources + flags.  The driver's box has no .git — the stamp
+    travels inside the library."""
+    from sgam_neurips22_amd import _lib
+    lib = _lib.load()
+    return lib.sgam_build_commit().decode(), lib.sgam_build_digest().decode()
 
 
 def compact_line(full):
@@ -398,7 +405,7 @@ def compact_line(full):
     if r is not None:
         line["roofline"] = pick(r, ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us", "calls_per_frame",
                                     "gflop_per_launch", "peak_basis", "frac_vs_fp32_mfma_peak", "frac_vs_h16_dense_peak",
-                                    "mfma_busy_frac", "counters_source", "counters_commit", "share_of_kernel_time", "kernels_per_frame",
+                                    "mfma_busy_frac", "counters_source", "counters_commit", "counters_stale", "share_of_kernel_time", "kernels_per_frame",
                                     "kernel_time_ms_per_frame", "frame"))
     else:
         line["roofline"] = None
@@ -430,7 +437,7 @@ def compact_line(full):
             summ[f"config5_{dtn}_ms_per_batch"] = c5[dtn]["ms_per_batch"]
     put("training_ms_per_update", full.get("training_step"), "ms_per_update")
     line["secondary"] = {k: v for k, v in summ.items() if v is not None}
-    for k in ("f32x_range_flag", "numa_node", "frame_checksums", "head", "extra"):
+    for k in ("f32x_range_flag", "numa_node", "frame_checksums", "head", "lib_digest", "extra"):
         if k in full:
             line[k] = full[k]
     text = json.dumps(line, separators=(",", ":"))
@@ -530,7 +537,7 @@ def main():
 
     range_tripped = ops.f32x_range_tripped() if args.dtype == "f32" and ops.F32_MODE == "split" else False
     checksum = float(sum(int(f["rgb_u8"].sum()) for f in scene.frames.values()) % (1 << 31))
-    g = sdist.gather_metrics(args.steps, dt, checksum, dev)
+    g = sdist.gather_metrics(args.steps, dt, checksum, dev, numa_node=numa)
     t_max = g["max_seconds"]
 
     roofline = None
@@ -762,7 +769,8 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "roofline_warp": warp_leg, "f32_mfma_mode": f32_mfma_leg, "numa_node": numa,
             "f32x_range_flag": int(range_tripped), "rgbd_integration_branch": rgbd_leg, "concurrent_scenes": conc_leg,
             "lockstep_scenes": lock_leg, "throughput_mode": secondary, "config5_512sq_batch4": stress, "training_step": train_leg,
-            "frame_checksums": [r[2] for r in g["per_rank"]], "head": _git_head(),
+            "frame_checksums": [r[2] for r in g["per_rank"]], "head": lib_stamp()[0], "lib_digest": lib_stamp()[1],
+            "per_rank": g.get("per_rank_records"), "rccl": g.get("rccl"),
         }
         written = write_extra(full)
         full["extra"] = written[0] if written else None

@@ -30,8 +30,12 @@ extern "C" {
 
 /* ABI version of this header; bumped on any signature change. */
 int sgam_abi_version(void);
-/* Human-readable build string ("gfx950 ..."). */
+/* Human-readable build string ("gfx950 ... commit <c>; digest <d>"). */
 const char *sgam_build_info(void);
+/* (ABI v10) The build stamp alone: the last commit that touched the library's sources ("+dirty" when the tree differed), and the
+ * first 12 hex digits of a sha256 over every source, header and compile flag (sgam_neurips22_amd/build.py). */
+const char *sgam_build_commit(void);
+const char *sgam_build_digest(void);
 
 /* ------------------------------------------------------------------------------------------
  * Kernel timeline (measurement; no reference counterpart — the reference has no profiling).  While
@@ -580,11 +584,11 @@ int sgam_gemm_gn_acc_f32x(const float *x, int32_t lda, const int64_t *gn_acc, fl
  * consumes the depth.
  *   unit_table [dims.z][dims.y][dims.x] int32, -1 = closed, else brick index | 0x40000000 once the brick holds part of
  *   the truncation band (the ray cast only marches those); unit_stamp same shape, 0-initialised;
- *   counters int32[4] = {bricks allocated, length of this frame's brick list, samples outside the box, pool overflows};
+ *   counters int32[4] = {bricks allocated, length of this step's brick list, samples outside the box, pool overflows};
  *   brick_tsdf [max_bricks][16*16*16] fp32 initialised to 2.0 (= unobserved: observed values are <= 1, so the ray cast
  *   needs no weight loads), brick_weight same shape, 0-initialised; brick_list int32[max_list] scratch.
- *   cam2world / world2cam: row-major 4x4 HOST pointers (16 floats each, copied into the kernel arguments: no upload,
- *   no device allocation per frame); intrinsics by value.  frame_id > 0, distinct per call.
+ *   cam2world / world2cam: row-major 4x4 HOST values (copied into the kernel arguments: no upload, no device allocation
+ *   per frame); intrinsics by value.
  * All state is caller-owned; nothing is synchronised or read back.
  * ------------------------------------------------------------------------------------------ */
 typedef struct sgam_tsdf_grid {
@@ -592,11 +596,24 @@ typedef struct sgam_tsdf_grid {
     int32_t unit_base[3];    /* unit index (floor(world / (16 * voxel_length))) of the box's low corner, x y z */
     int32_t unit_dims[3];    /* units per axis */
 } sgam_tsdf_grid;
-int sgam_tsdf_integrate_f32(const sgam_tsdf_grid *grid, const float *depth, int32_t H, int32_t W, float fx, float fy, float cx,
-                            float cy, const float *cam2world, const float *world2cam, float depth_trunc, int32_t frame_id,
-                            int32_t *unit_table, int32_t *unit_stamp, int32_t *counters, int32_t *brick_list, int32_t max_list,
-                            float *brick_tsdf, float *brick_weight, int32_t max_bricks, const uint8_t *rgb_u8,
-                            float *brick_color, void *stream);
+/* (ABI v10) One source frame of a step: depth [H][W] fp32 and (with brick_color) rgb_u8 [H][W][3] DEVICE pointers; cam2world /
+ * world2cam row-major 4x4 by value.  The array of n_src <= 8 of them is a HOST array, copied into the kernel arguments. */
+typedef struct sgam_tsdf_src {
+    const float *depth;
+    const uint8_t *rgb_u8;
+    float cam2world[16], world2cam[16];
+} sgam_tsdf_src;
+/* Integrates the n_src source frames of ONE step of the scene loop (reference :757-790 calls volume.integrate once per source)
+ * in ONE pass over the union of the units they open: a voxel is loaded once, takes the sources' updates in array order and is
+ * stored once — the same values as n_src single-source calls in that order.  step_id in 1 .. 2^23 - 1, distinct per call
+ * (unit_stamp holds (step_id << 8) | mask of the step's sources that opened the unit). */
+int sgam_tsdf_integrate_srcs_f32(const sgam_tsdf_grid *grid, const sgam_tsdf_src *srcs, int32_t n_src, int32_t H, int32_t W, float fx,
+                                 float fy, float cx, float cy, float depth_trunc, int32_t step_id, int32_t *unit_table,
+                                 int32_t *unit_stamp, int32_t *counters, int32_t *brick_list, int32_t max_list, float *brick_tsdf,
+                                 float *brick_weight, int32_t max_bricks, float *brick_color, const float *ray_mult, void *stream);
+/* ray_mult [H][W] fp32 = sqrt(((u - cx) / fx)^2 + ((v - cy) / fy)^2 + 1), the rule's depth -> camera-distance multiplier of a
+ * pixel: tabulated once per (intrinsics, size) by this call, gathered by the integration beside the depth. */
+int sgam_tsdf_ray_mult_f32(int32_t H, int32_t W, float fx, float fy, float cx, float cy, float *ray_mult, void *stream);
 int sgam_tsdf_raycast_depth_f32(const sgam_tsdf_grid *grid, int32_t H, int32_t W, float fx, float fy, float cx, float cy,
                                 const float *cam2world, float z_near, float z_far, const int32_t *unit_table,
                                 const float *brick_tsdf, float *depth_out, const float *brick_color, float *color_out,

@@ -20,9 +20,10 @@ src_coords, _ = sc.get_src_grid_coords(tgt)
 tm = sc.transform_grid[tgt[0]][tgt[1]]; sm = [sc.transform_grid[c[0]][c[1]] for c in src_coords]
 print("n src", len(sm))
 print("rgbd_integration ms", T(lambda: sc.rgbd_integration(sm, tm)))
-Tm = np.eye(4); Tm[:3,:3], Tm[:3,3] = tm["R"], tm["t"]
+Tm = tm["T"]
 print("  raycast ms", T(lambda: sc.volume.render_depth(sc.K, Tm, 256, 256, 0.05, 4.8)))
-print("  integrate ms", T(lambda: sc.volume.integrate(sc._src_depth(sm[0]["grid_coord"]), sc.K, Tm)))
+print("  integrate x1 ms", T(lambda: sc.volume.integrate(sc.frames[sm[0]["grid_coord"]]["depth"], sc.K, sm[0]["T"])))
+print("  integrate_many ms", T(lambda: sc.volume.integrate_many([sc.frames[s["grid_coord"]]["depth"] for s in sm], sc.K, [s["T"] for s in sm])))
 print("prepare_batch_data ms", T(lambda: sc.prepare_batch_data(tm, sm, sc.num_src)))
 def step():
     b = sc.prepare_batch_data(tm, sm, sc.num_src); b['src_depths'] = b['src_depths'][..., None]

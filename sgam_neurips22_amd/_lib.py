@@ -22,12 +22,19 @@ class TsdfGrid(ctypes.Structure):
     _fields_ = [("voxel_length", c_f32), ("sdf_trunc", c_f32), ("unit_base", c_i32 * 3), ("unit_dims", c_i32 * 3)]
 
 
+class TsdfSrc(ctypes.Structure):
+    """mirror of struct sgam_tsdf_src"""
+    _fields_ = [("depth", c_vp), ("rgb_u8", c_vp), ("cam2world", c_f32 * 16), ("world2cam", c_f32 * 16)]
+
+
 # name -> (restype, argtypes); must list every symbol include/sgam_hip.h declares
-ABI_VERSION = 9      # include/sgam_hip.h: sgam_abi_version() of the library these prototypes were written against
+ABI_VERSION = 10     # include/sgam_hip.h: sgam_abi_version() of the library these prototypes were written against
 
 PROTOTYPES = {
     "sgam_abi_version": (c_i32, []),
     "sgam_build_info": (ctypes.c_char_p, []),
+    "sgam_build_commit": (ctypes.c_char_p, []),
+    "sgam_build_digest": (ctypes.c_char_p, []),
     "sgam_prof_enable": (c_i32, [c_i32]),
     "sgam_prof_mark_empty": (c_i32, [c_vp]),
     "sgam_prof_count": (c_i32, []),
@@ -63,8 +70,9 @@ PROTOTYPES = {
                                           c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "sgam_groupnorm_stats_from_partials_f32": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp]),
     "sgam_groupnorm_meanrstd_nhwc_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_i64, c_vp]),
-    "sgam_tsdf_integrate_f32": (c_i32, [ctypes.POINTER(TsdfGrid), c_vp, c_i32, c_i32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp,
-                                        c_f32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
+    "sgam_tsdf_integrate_srcs_f32": (c_i32, [ctypes.POINTER(TsdfGrid), ctypes.POINTER(TsdfSrc), c_i32, c_i32, c_i32, c_f32, c_f32, c_f32,
+                                             c_f32, c_f32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
+    "sgam_tsdf_ray_mult_f32": (c_i32, [c_i32, c_i32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp]),
     "sgam_tsdf_raycast_depth_f32": (c_i32, [ctypes.POINTER(TsdfGrid), c_i32, c_i32, c_f32, c_f32, c_f32, c_f32, c_vp, c_f32,
                                             c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "sgam_tsdf_extract_points_f32": (c_i32, [ctypes.POINTER(TsdfGrid), c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),

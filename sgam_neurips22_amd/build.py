@@ -49,6 +49,7 @@ SOURCES = {
     "warp.hip": ["-ffp-contract=off"],
     "gemm_gn_f32x.hip": [],
     "train.hip": [],
+    "build_info.hip": [],       # flags = the build stamp, filled in by build()
     "tsdf.hip": ["-ffp-contract=off"] + (["-DSGAM_TSDF_DEBUG_STEPS"] if os.environ.get("SGAM_TSDF_DEBUG_STEPS") else []),
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
@@ -61,6 +62,37 @@ def _hipcc():
         if cand and os.path.exists(cand):
             return cand
     raise RuntimeError("hipcc not found: libsgam_hip.so cannot be built (ROCm toolchain required)")
+
+
+def _git(*args):
+    try:
+        r = subprocess.run(["git", "-C", os.path.join(PKG, "..")] + list(args), capture_output=True, text=True, timeout=10)
+        return r.stdout.strip() if r.returncode == 0 else None
+    except (OSError, subprocess.SubprocessError):
+        return None
+
+
+_STAMP_PATHS = ["sgam_neurips22_amd/csrc", "include", "sgam_neurips22_amd/build.py"]
+
+
+def build_stamp(headers):
+    """(commit, digest) compiled into the library (csrc/build_info.hip).  digest: sha256 over every source, header and flag.
+    commit: the last commit that touched the library's sources, '+dirty' when the tree differs from it — from git where the
+    build runs; without git (the GPU box) the stamp file of the build that produced the same digest is reused."""
+    srcs = sorted(os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f)) and f != "build_info.hip")
+    digest = _digest(srcs + headers, [COMMON] + [SOURCES[os.path.basename(p)] for p in srcs])[:12]
+    stamp_file = os.path.join(LIBDIR, "BUILD_STAMP")
+    commit = _git("log", "-1", "--format=%h", "--abbrev=12", "--", *_STAMP_PATHS)
+    if commit:
+        if _git("status", "--porcelain", "--", *_STAMP_PATHS):
+            commit += "+dirty"
+    else:
+        commit = "nogit"
+        if os.path.exists(stamp_file):
+            old = open(stamp_file).read().split()
+            if len(old) == 2 and old[1] == digest:
+                commit = old[0]
+    return commit, digest, stamp_file
 
 
 def _digest(paths, flags):
@@ -81,6 +113,8 @@ def build(force=False, verbose=False):
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(PKG, "..", "include", "sgam_hip.h"))
     objs, relink = [], force or not os.path.exists(LIB)
+    commit, digest, stamp_file = build_stamp(headers)
+    SOURCES["build_info.hip"] = [f'-DSGAM_BUILD_COMMIT="{commit}"', f'-DSGAM_BUILD_DIGEST="{digest}"']
     for src, extra in SOURCES.items():
         path = os.path.join(CSRC, src)
         if not os.path.exists(path):
@@ -103,6 +137,8 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    with open(stamp_file, "w") as f:
+        f.write(f"{commit} {digest}\n")
     return LIB
 
 

@@ -205,8 +205,7 @@ extern "C" int sgam_prof_get(int32_t i, const char **kernel, const char **where,
     return SGAM_OK;
 }
 
-extern "C" int sgam_abi_version(void) { return 9; }
-extern "C" const char *sgam_build_info(void) { return "libsgam_hip gfx950 (CDNA4): split-fp32 / fp32-in / 16-bit MFMA paths, built " __DATE__; }
+// (sgam_abi_version / sgam_build_info: build_info.hip)
 
 extern "C" int sgam_nchw_to_nhwc_f32(const float *x, float *y, int32_t B, int32_t C, int32_t HW, int32_t ldy,
                                      void *stream) {

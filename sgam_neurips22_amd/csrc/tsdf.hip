@@ -38,6 +38,8 @@ constexpr int BRICK_MASK = 0x3FFFFFFF;
 // (bricks start at 2.0 = unobserved: observed TSDF values are <= 1, so the ray cast tells the two apart in the one load)
 constexpr int RS = 8;                  // depth segments (lanes) per ray in the ray cast
 
+typedef float F2u __attribute__((ext_vector_type(2), aligned(4)));
+
 struct Pose {
     float m[16];                       // row-major 4x4, passed by value in the kernel arguments
 };
@@ -53,13 +55,26 @@ __device__ __forceinline__ int64_t unit_slot(const TsdfGrid &g, int ux, int uy, 
     return ((int64_t)z * g.dims[1] + y) * g.dims[0] + x;
 }
 
-// pass 1: open the units around the back-projected depth samples; units seen for the first time in this frame
-// (stamp != frame_id) are appended once to the frame's brick list.
-__global__ void tsdf_touch_kernel(const float *__restrict__ depth, int H, int W, float fx, float fy, float cx, float cy,
-                                  const Pose c2w_, TsdfGrid g, float depth_trunc, int stride,
-                                  int *__restrict__ table, int *__restrict__ stamp, int frame_id, int *__restrict__ counters,
+// The sources of ONE step of the scene loop (reference :757-790 integrates every source frame of the step, one call each):
+// depth maps, colours and poses travel by value in the kernel arguments (no upload, no device allocation per step).
+constexpr int MAX_SRC = 8;
+struct SrcSet {
+    const float *depth[MAX_SRC];
+    const uint8_t *rgb[MAX_SRC];
+    Pose c2w[MAX_SRC], w2c[MAX_SRC];
+    int n;
+};
+
+// pass 1 (blockIdx.y = source): open the units around the back-projected depth samples.  A unit's stamp word is
+// (step_id << 8) | mask of the sources of this step that opened it; the lane that moves the word to this step's tag appends the
+// unit ONCE to the step's brick list (the union over the sources) and allocates its brick if it never had one.
+__global__ void tsdf_touch_kernel(const SrcSet S, int H, int W, float fx, float fy, float cx, float cy,
+                                  TsdfGrid g, float depth_trunc, int stride,
+                                  int *__restrict__ table, int *__restrict__ stamp, int step_id, int *__restrict__ counters,
                                   int max_bricks, int *__restrict__ list, int max_list) {
-    const float *c2w = c2w_.m;
+    const int k = blockIdx.y;
+    const float *__restrict__ depth = S.depth[k];
+    const float *c2w = S.c2w[k].m;
     const int sw = (W + stride - 1) / stride, sh = (H + stride - 1) / stride;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= sw * sh) return;
@@ -80,6 +95,7 @@ __global__ void tsdf_touch_kernel(const float *__restrict__ depth, int H, int W,
         lo[r] = (int)floorf(__fdiv_rn(__fsub_rn(p[r], g.trunc), g.unit_len));
         hi[r] = (int)floorf(__fdiv_rn(__fadd_rn(p[r], g.trunc), g.unit_len));
     }
+    const int tag = step_id << 8, bit = 1 << k;
     for (int uz = lo[2]; uz <= hi[2]; ++uz)
         for (int uy = lo[1]; uy <= hi[1]; ++uy)
             for (int ux = lo[0]; ux <= hi[0]; ++ux) {
@@ -88,11 +104,24 @@ __global__ void tsdf_touch_kernel(const float *__restrict__ depth, int H, int W,
                     atomicAdd(&counters[2], 1);          // samples outside the scene box (diagnostic)
                     continue;
                 }
-                if (atomicExch(&stamp[s], frame_id) == frame_id) continue;       // already listed for this frame
+                int old = __hip_atomic_load(&stamp[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bool first = false;
+                for (;;) {
+                    const bool same_step = (old & ~0xff) == tag;
+                    const int want = same_step ? (old | bit) : (tag | bit);
+                    if (want == old) break;                                       // this source already marked the unit
+                    const int prev = atomicCAS(&stamp[s], old, want);
+                    if (prev == old) {
+                        first = !same_step;
+                        break;
+                    }
+                    old = prev;
+                }
+                if (!first) continue;                    // listed for this step already
                 int brick = table[s];          // (the NEAR bit, if set, rides along: entries are only ever extended)
                 if (brick < 0) {
-                    // first touch ever: allocate.  The exchange above makes this thread the only one handling slot s
-                    // in this frame, so no CAS loop is needed.
+                    // first touch ever: allocate.  The tag change above makes this lane the only one handling slot s
+                    // in this step, so no CAS loop is needed.
                     brick = atomicAdd(&counters[0], 1);
                     if (brick >= max_bricks) {
                         atomicAdd(&counters[3], 1);      // pool exhausted (diagnostic); unit stays closed
@@ -105,63 +134,128 @@ __global__ void tsdf_touch_kernel(const float *__restrict__ depth, int H, int W,
             }
 }
 
-// pass 2: one workgroup per listed brick (grid-stride over the device-side list), 256 lanes x 16 voxels.
-__global__ __launch_bounds__(256) void tsdf_integrate_kernel(const float *__restrict__ depth, int H, int W, float fx, float fy,
-                                                             float cx, float cy, const Pose w2c_, TsdfGrid g,
-                                                             float depth_trunc, int *__restrict__ table, const int *__restrict__ counters,
+// per-pixel camera-distance multiplier sqrt(((u - cx) / fx)^2 + ((v - cy) / fy)^2 + 1) of the integration rule: a function of the
+// pixel alone, tabulated once per (intrinsics, size) — the integrate kernel gathers it beside the depth instead of spending
+// two divisions and a square root per voxel and source (same expression, same value)
+__global__ void tsdf_ray_mult_kernel(int H, int W, float fx, float fy, float cx, float cy, float *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= H * W) return;
+    const int v = i / W, u = i - v * W;
+    const float rx = __fdiv_rn(__fsub_rn((float)u, cx), fx), ry = __fdiv_rn(__fsub_rn((float)v, cy), fy);
+    out[i] = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry)), 1.0f));
+}
+
+// pass 2: one workgroup per listed brick (grid-stride over the device-side list), 256 lanes x 16 voxels.  A voxel is loaded
+// once, takes the update of every source of the step that opened its unit — in source order, in registers: the same value
+// sequence as one integrate call per source — and is stored once.  NS = sources handled (compile time: poses sit at fixed
+// kernel-argument offsets, the loops unroll); per voxel the projections of ALL sources come first and their depth /
+// multiplier gathers are issued together (clamped addresses, no branch in front of a load), then the updates are applied in
+// order: one memory round trip per voxel instead of one per source behind each other.
+template <int NS, bool COLOR>
+__global__ __launch_bounds__(256) void tsdf_integrate_kernel(const SrcSet S, int H, int W, float fx, float fy,
+                                                             float cx, float cy, TsdfGrid g,
+                                                             float depth_trunc, int *__restrict__ table, const int *__restrict__ stamp,
+                                                             const int *__restrict__ counters,
                                                              const int *__restrict__ list, int max_list,
                                                              float *__restrict__ tsdf, float *__restrict__ weight,
-                                                             const uint8_t *__restrict__ rgb, float *__restrict__ color) {
-    const float *w2c = w2c_.m;
+                                                             float *__restrict__ color, const float *__restrict__ ray_mult) {
     int n = counters[1];
     if (n > max_list) n = max_list;
     const float inv_trunc = __fdiv_rn(1.0f, g.trunc);
     const float safe_w = __fsub_rn((float)W, 0.0001f), safe_h = __fsub_rn((float)H, 0.0001f);
+    const int x = threadIdx.x & 15, y = threadIdx.x >> 4;
     for (int li = blockIdx.x; li < n; li += gridDim.x) {
         const int s = list[li];
         const int brick = table[s] & BRICK_MASK;
+        const int mask = stamp[s] & ((1 << NS) - 1) & ((1 << S.n) - 1);
         const int ux = s % g.dims[0] + g.base[0];
         const int uy = (s / g.dims[0]) % g.dims[1] + g.base[1];
         const int uz = s / (g.dims[0] * g.dims[1]) + g.base[2];
         float *bt = tsdf + (int64_t)brick * UV, *bw = weight + (int64_t)brick * UV;
+        float *bc = COLOR ? color + (int64_t)brick * UV * 3 : nullptr;
+        // voxel centre: unit origin + (i + 0.5) * voxel
+        const float px = __fadd_rn(__fmul_rn((float)ux, g.unit_len), __fmul_rn(__fadd_rn((float)x, 0.5f), g.voxel));
+        const float py = __fadd_rn(__fmul_rn((float)uy, g.unit_len), __fmul_rn(__fadd_rn((float)y, 0.5f), g.voxel));
+        const float oz = __fmul_rn((float)uz, g.unit_len);
+        // the part of the camera transform that does not depend on z: (w2c[r][0] * px + w2c[r][1] * py), per source and row
+        float cxy[NS][3];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) cxy[k][r] = __fadd_rn(__fmul_rn(S.w2c[k].m[r * 4 + 0], px), __fmul_rn(S.w2c[k].m[r * 4 + 1], py));
+        }
         int near = 0;                 // this brick holds an observed voxel inside the truncation band (value < 1)
-        for (int q = threadIdx.x; q < UV; q += 256) {
-            const int x = q & 15, y = (q >> 4) & 15, z = q >> 8;
-            // voxel centre: unit origin + (i + 0.5) * voxel
-            const float px = __fadd_rn(__fmul_rn((float)ux, g.unit_len), __fmul_rn(__fadd_rn((float)x, 0.5f), g.voxel));
-            const float py = __fadd_rn(__fmul_rn((float)uy, g.unit_len), __fmul_rn(__fadd_rn((float)y, 0.5f), g.voxel));
-            const float pz = __fadd_rn(__fmul_rn((float)uz, g.unit_len), __fmul_rn(__fadd_rn((float)z, 0.5f), g.voxel));
-            float c[3];
+        // the column of 16 voxels this lane owns (z = 0..15), its values fetched one step ahead of their use
+        float t_nx = bt[threadIdx.x], w_nx = bw[threadIdx.x];
+        for (int z = 0; z < UR; ++z) {
+            const int q = (z << 8) | threadIdx.x;
+            float t = t_nx, w = w_nx;
+            if (z + 1 < UR) {
+                t_nx = bt[q + 256];
+                w_nx = bw[q + 256];
+            }
+            float c3[3] = {0.f, 0.f, 0.f};
+            if (COLOR) {
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
-                c[r] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(w2c[r * 4 + 0], px), __fmul_rn(w2c[r * 4 + 1], py)),
-                                           __fmul_rn(w2c[r * 4 + 2], pz)),
-                                 w2c[r * 4 + 3]);
-            if (!(c[2] > 0.f)) continue;
-            const float uf = __fadd_rn(__fadd_rn(__fdiv_rn(__fmul_rn(c[0], fx), c[2]), cx), 0.5f);
-            const float vf = __fadd_rn(__fadd_rn(__fdiv_rn(__fmul_rn(c[1], fy), c[2]), cy), 0.5f);
-            if (!(uf >= 0.0001f && uf < safe_w && vf >= 0.0001f && vf < safe_h)) continue;
-            const int u = (int)uf, v = (int)vf;
-            const float d = depth[v * W + u];
-            if (!(d > 0.f) || d > depth_trunc) continue;
-            const float rx = __fdiv_rn(__fsub_rn((float)u, cx), fx), ry = __fdiv_rn(__fsub_rn((float)v, cy), fy);
-            const float mult = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry)), 1.0f));
-            const float sdf = __fmul_rn(__fsub_rn(d, c[2]), mult);
-            if (sdf > -g.trunc) {
-                const float t = fminf(1.0f, __fmul_rn(sdf, inv_trunc));
-                const float w = bw[q];
-                const float nt = __fdiv_rn(__fadd_rn(__fmul_rn(bt[q], w), t), __fadd_rn(w, 1.0f));
-                bt[q] = nt;
-                if (color) {
-                    // TSDFVolumeColorType::RGB8: color <- (color * w + rgb(u, v)) / (w + 1), per channel, 0..255
-                    float *bc = color + ((int64_t)brick * UV + q) * 3;
-                    const uint8_t *px3 = rgb + ((int64_t)v * W + u) * 3;
+                for (int ch = 0; ch < 3; ++ch) c3[ch] = bc[q * 3 + ch];
+            }
+            const float pz = __fadd_rn(oz, __fmul_rn(__fadd_rn((float)z, 0.5f), g.voxel));
+            // stage 1: project into every source, gather depth + multiplier (+ colour)
+            float cz[NS], d[NS], mult[NS];
+            bool in[NS];
+            int pix[NS];
 #pragma unroll
-                    for (int ch = 0; ch < 3; ++ch)
-                        bc[ch] = __fdiv_rn(__fadd_rn(__fmul_rn(bc[ch], w), (float)px3[ch]), __fadd_rn(w, 1.0f));
+            for (int k = 0; k < NS; ++k) {
+                float c[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) c[r] = __fadd_rn(__fadd_rn(cxy[k][r], __fmul_rn(S.w2c[k].m[r * 4 + 2], pz)), S.w2c[k].m[r * 4 + 3]);
+                cz[k] = c[2];
+                const float uf = __fadd_rn(__fadd_rn(__fdiv_rn(__fmul_rn(c[0], fx), c[2]), cx), 0.5f);
+                const float vf = __fadd_rn(__fadd_rn(__fdiv_rn(__fmul_rn(c[1], fy), c[2]), cy), 0.5f);
+                in[k] = ((mask >> k) & 1) && c[2] > 0.f && uf >= 0.0001f && uf < safe_w && vf >= 0.0001f && vf < safe_h;
+                pix[k] = in[k] ? (int)vf * W + (int)uf : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const float *__restrict__ dk = S.depth[k < S.n ? k : 0];
+                d[k] = dk[pix[k]];
+                mult[k] = ray_mult[pix[k]];
+            }
+            uint8_t rgb3[NS][3];
+            if (COLOR) {
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    const uint8_t *rk = S.rgb[k < S.n ? k : 0] + (int64_t)pix[k] * 3;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) rgb3[k][ch] = rk[ch];
                 }
-                bw[q] = __fadd_rn(w, 1.0f);
-                near |= nt < 1.0f;
+            }
+            // stage 2: the updates, in source order
+            bool changed = false;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const float sdf = __fmul_rn(__fsub_rn(d[k], cz[k]), mult[k]);
+                if (in[k] && d[k] > 0.f && !(d[k] > depth_trunc) && sdf > -g.trunc) {
+                    const float tv = fminf(1.0f, __fmul_rn(sdf, inv_trunc));
+                    const float w1 = __fadd_rn(w, 1.0f);
+                    t = __fdiv_rn(__fadd_rn(__fmul_rn(t, w), tv), w1);
+                    if (COLOR) {
+                        // TSDFVolumeColorType::RGB8: color <- (color * w + rgb(u, v)) / (w + 1), per channel, 0..255
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) c3[ch] = __fdiv_rn(__fadd_rn(__fmul_rn(c3[ch], w), (float)rgb3[k][ch]), w1);
+                    }
+                    w = w1;
+                    near |= t < 1.0f;
+                    changed = true;
+                }
+            }
+            if (changed) {
+                bt[q] = t;
+                bw[q] = w;
+                if (COLOR) {
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) bc[q * 3 + ch] = c3[ch];
+                }
             }
         }
         // a weighted mean of values <= 1 that is < 1 once stays < 1: the flag is monotone, a plain store suffices
@@ -181,7 +275,8 @@ __device__ __forceinline__ bool lattice(const TsdfGrid &g, const int *table, con
 }
 
 // TSDF at world point p: trilinear when all eight surrounding lattice points are observed, else the nearest lattice
-// point's value, else false
+// point's value, else false.  (The point-extraction kernel's sampler; the ray cast carries its own copy of this rule with
+// every load of a step in flight at once — SAMPLE_* below.)
 __device__ __forceinline__ bool sample(const TsdfGrid &g, const int *table, const float *tsdf, const float *p, float inv_voxel,
                                        float &val) {
     float f[3];
@@ -195,23 +290,9 @@ __device__ __forceinline__ bool sample(const TsdfGrid &g, const int *table, cons
     }
     float c[8];
     bool all = true;
-    if ((i0[0] & 15) < 15 && (i0[1] & 15) < 15 && (i0[2] & 15) < 15) {
-        // the whole cell lies in one brick: one table lookup, eight (weight, value) pairs
-        const int64_t s = unit_slot(g, i0[0] >> 4, i0[1] >> 4, i0[2] >> 4);
-        const int brick = s >= 0 ? table[s] : -1;
-        if (brick < 0) return false;
-        const int q0 = ((i0[2] & 15) << 8) | ((i0[1] & 15) << 4) | (i0[0] & 15);
-        const float *bt = tsdf + (int64_t)(brick & BRICK_MASK) * UV + q0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            c[k] = bt[(k & 1) + ((k >> 1) & 1) * 16 + (k >> 2) * 256];
-            all = all && c[k] <= 1.0f;
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            all = lattice(g, table, tsdf, i0[0] + (k & 1), i0[1] + ((k >> 1) & 1), i0[2] + (k >> 2), c[k]) && all;
-    }
+    for (int k = 0; k < 8; ++k)
+        all = lattice(g, table, tsdf, i0[0] + (k & 1), i0[1] + ((k >> 1) & 1), i0[2] + (k >> 2), c[k]) && all;
     if (!all) {
         // a cell with an unobserved corner (typically just behind an obliquely seen surface, where the truncation band
         // is thinner than a voxel diagonal): fall back to the nearest lattice point, if that one was observed
@@ -229,22 +310,56 @@ __device__ __forceinline__ bool sample(const TsdfGrid &g, const int *table, cons
     return true;
 }
 
+// ---- the ray cast's form of the same rule, written without data-dependent branches around the loads: a march step is a
+// chain of dependent memory round trips (unit table -> brick values), and a branch per corner turns the eight corners of a
+// cell that straddles a brick face into sixteen round trips IN SERIES — for the whole wavefront, as soon as one lane has such
+// a cell (with 64 lanes: every step).  Here every table entry a step needs is requested at once (index 0 stands in for a
+// unit outside the box), then every value at once: two round trips per step, whatever the lanes' cells look like.
+// unit-table index of unit (ux, uy, uz) -> `idx` (0 when outside the box) and `ok`
+#define TSDF_UNIT_INDEX(ux, uy, uz, idx, ok)                                                                                      \
+    do {                                                                                                                          \
+        const unsigned x_ = (unsigned)((ux) - g.base[0]), y_ = (unsigned)((uy) - g.base[1]), z_ = (unsigned)((uz) - g.base[2]);   \
+        ok = (x_ < (unsigned)g.dims[0]) & (y_ < (unsigned)g.dims[1]) & (z_ < (unsigned)g.dims[2]);                                \
+        idx = (z_ * (unsigned)g.dims[1] + y_) * (unsigned)g.dims[0] + x_;                                                         \
+        idx = ok ? idx : 0u;                                                                                                      \
+    } while (0)
+// value of lattice point (ix, iy, iz) in the brick of table entry e (2 = unobserved when e < 0); the load is unconditional
+#define TSDF_CORNER(e, ix, iy, iz, out)                                                                                           \
+    do {                                                                                                                          \
+        const unsigned q_ = (((unsigned)(iz)&15u) << 8) | (((unsigned)(iy)&15u) << 4) | ((unsigned)(ix)&15u);                     \
+        const float x_ = tsdf[(e) >= 0 ? (size_t)((e)&BRICK_MASK) * UV + q_ : (size_t)0];                                         \
+        out = (e) >= 0 ? x_ : 2.0f;                                                                                               \
+    } while (0)
+
 // depth render: per pixel, march the camera ray; parameter t = view-space z (so the result needs no conversion).
 // Unopened units are crossed in one step each (exit distance of the unit along the ray + a quarter voxel), opened ones with half-voxel steps or, in observed free
 // space, 0.8 x the distance the TSDF value guarantees.
-__global__ void tsdf_raycast_kernel(int H, int W, float fx, float fy, float cx, float cy, const Pose c2w_, TsdfGrid g,
+//
+// Every ray is cut into RS depth segments (each starts with no history and runs two voxels into the next segment so that a
+// crossing on a boundary is seen by the earlier one); the nearest hit wins.  Thread mapping: a WAVEFRONT marches one
+// segment of an 8 x 8 pixel tile, the RS wavefronts of a workgroup the RS segments of that tile.  Neighbouring pixels'
+// rays at one depth are about a voxel apart, so the 64 lanes of a load touch a few 64-byte brick rows instead of 64
+// unrelated bricks (the march is bound by the number of cache lines a wavefront's load touches, not by arithmetic); a
+// segment whose samples are already behind the nearest hit found so far for its pixel (LDS, atomicMin on the float bits)
+// stops — it could only find a farther crossing.
+__global__ __launch_bounds__(64 * RS) void tsdf_raycast_kernel(int H, int W, float fx, float fy, float cx, float cy, const Pose c2w_, TsdfGrid g,
                                     float z_near, float z_far, const int *__restrict__ table, const float *__restrict__ tsdf,
                                     float *__restrict__ out, const float *__restrict__ color, float *__restrict__ color_out) {
-    // The march is a chain of dependent loads (unit table -> brick -> values), i.e. latency-bound, and a 256 x 256 view is
-    // only one wavefront per SIMD: every ray is cut into RS depth segments marched by RS adjacent lanes (each starts with
-    // no history and runs two voxels into the next segment so that a crossing on a boundary is seen by the earlier one);
-    // the nearest hit wins.
+    __shared__ unsigned best_bits[64];
     const float *c2w = c2w_.m;
-    const int gi = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = gi / RS, seg = gi - i * RS;
-    const bool live = i < H * W;
-    const int ii = live ? i : 0;
-    const int v = ii / W, u = ii - v * W;
+    const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int tiles_x = (W + 7) >> 3;
+    // workgroup b runs on XCD b % 8 (observed placement; for speed only): each XCD gets a contiguous run of tiles — a strip of
+    // the image — so that the bricks its rays pierce are fetched into ONE L2 instead of eight
+    const int nb = gridDim.x, per = (nb + 7) >> 3;
+    int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if ((nb & 7) != 0) tile = blockIdx.x;                      // (a tile count that is not a multiple of 8: plain order)
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int v = ty * 8 + (lane >> 3), u = tx * 8 + (lane & 7);
+    const bool live = v < H && u < W;
+    const int i = v * W + u;
+    if (seg == 0) best_bits[lane] = 0x7f7fffffu;              // FLT_MAX
+    __syncthreads();
     // pixel centres at integer coordinates, as in the reference's pinhole set-up (cx, cy in pixel units)
     const float rx = __fdiv_rn(__fsub_rn((float)u, cx), fx), ry = __fdiv_rn(__fsub_rn((float)v, cy), fy);
     float o[3], dir[3];
@@ -264,16 +379,53 @@ __global__ void tsdf_raycast_kernel(int H, int W, float fx, float fy, float cx, 
     int n_coarse = 0, n_fine = 0;
 #endif
     while (live && t < t_end) {
+        // a crossing this lane can still find lies beyond prev_t: pointless once a nearer one is known for the pixel
+        if (__float_as_uint(prev_t) >= __hip_atomic_load(&best_bits[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
         float p[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) p[r] = __fadd_rn(o[r], __fmul_rn(dir[r], t));
         float uf[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) uf[r] = floorf(__fdiv_rn(p[r], g.unit_len));
-        const int64_t s = unit_slot(g, (int)uf[0], (int)uf[1], (int)uf[2]);
+        // ---- stage 1: every unit-table entry of the step
+        unsigned s_here; bool in_box;
+        TSDF_UNIT_INDEX((int)uf[0], (int)uf[1], (int)uf[2], s_here, in_box);
+        const float l0 = __fsub_rn(__fmul_rn(p[0], inv_voxel), 0.5f), l1 = __fsub_rn(__fmul_rn(p[1], inv_voxel), 0.5f),
+                    l2 = __fsub_rn(__fmul_rn(p[2], inv_voxel), 0.5f);             // lattice coordinates
+        const float fl0 = floorf(l0), fl1 = floorf(l1), fl2 = floorf(l2);
+        const int ix = (int)fl0, iy = (int)fl1, iz = (int)fl2;                    // the cell's low corner
+        const float f0 = __fsub_rn(l0, fl0), f1 = __fsub_rn(l1, fl1), f2 = __fsub_rn(l2, fl2);
+        const bool straddles = ((ix & 15) == 15) | ((iy & 15) == 15) | ((iz & 15) == 15);
+        const bool single = __builtin_amdgcn_ballot_w64(straddles) == 0;          // wave-uniform: no lane's cell crosses a brick face
+        const int ux0 = ix >> 4, uy0 = iy >> 4, uz0 = iz >> 4;                    // arithmetic shift = floor division by 16
+        const int ux1 = (ix + 1) >> 4, uy1 = (iy + 1) >> 4, uz1 = (iz + 1) >> 4;
+        unsigned s0, s1, s2, s3, s4, s5, s6, s7;
+        bool k0, k1, k2, k3, k4, k5, k6, k7;
+        TSDF_UNIT_INDEX(ux0, uy0, uz0, s0, k0);
+        int e_here, e0, e1, e2, e3, e4, e5, e6, e7;
+        if (single) {
+            e_here = table[s_here];
+            e0 = table[s0];
+            asm volatile("" : "+v"(e_here), "+v"(e0));       // both requests in flight before either is consumed
+            e0 = k0 ? e0 : -1;
+            e1 = e2 = e3 = e4 = e5 = e6 = e7 = e0;
+        } else {
+            TSDF_UNIT_INDEX(ux1, uy0, uz0, s1, k1);
+            TSDF_UNIT_INDEX(ux0, uy1, uz0, s2, k2);
+            TSDF_UNIT_INDEX(ux1, uy1, uz0, s3, k3);
+            TSDF_UNIT_INDEX(ux0, uy0, uz1, s4, k4);
+            TSDF_UNIT_INDEX(ux1, uy0, uz1, s5, k5);
+            TSDF_UNIT_INDEX(ux0, uy1, uz1, s6, k6);
+            TSDF_UNIT_INDEX(ux1, uy1, uz1, s7, k7);
+            e_here = table[s_here];
+            e0 = table[s0]; e1 = table[s1]; e2 = table[s2]; e3 = table[s3];
+            e4 = table[s4]; e5 = table[s5]; e6 = table[s6]; e7 = table[s7];
+            e0 = k0 ? e0 : -1; e1 = k1 ? e1 : -1; e2 = k2 ? e2 : -1; e3 = k3 ? e3 : -1;
+            e4 = k4 ? e4 : -1; e5 = k5 ? e5 : -1; e6 = k6 ? e6 : -1; e7 = k7 ? e7 : -1;
+        }
         // only bricks that hold part of the truncation band can contain the surface: everything else (unopened units,
         // bricks of observed free space, bricks with nothing observed) is crossed like empty space
-        const int brick_here = s >= 0 ? table[s] : -1;
+        const int brick_here = in_box ? e_here : -1;
         const bool open = brick_here >= 0 && (brick_here & NEAR_BIT) != 0;
         // such a unit is left in ONE step: distance (in t) to the nearest of its faces the ray is heading for
         float coarse = z_far;
@@ -283,11 +435,52 @@ __global__ void tsdf_raycast_kernel(int H, int W, float fx, float fy, float cx, 
             else if (dir[r] < 0.f) coarse = fminf(coarse, __fdiv_rn(__fsub_rn(__fmul_rn(uf[r], g.unit_len), p[r]), dir[r]));
         }
         coarse = __fadd_rn(fmaxf(coarse, 0.f), eps);
+        // ---- stage 2: the eight corner values (when some lane of the wavefront marches a band brick)
         float val = 0.f;
-        const bool ok = open && sample(g, table, tsdf, p, inv_voxel, val);
+        bool ok = false;
+        if (__builtin_amdgcn_ballot_w64(open) != 0) {
+            float v0, v1, v2, v3, v4, v5, v6, v7;
+            if (single) {
+                // the whole cell lies in one brick: four 8-byte loads (x and x + 1 are adjacent floats; 4-byte aligned)
+                const unsigned q0 = (((unsigned)iz & 15u) << 8) | (((unsigned)iy & 15u) << 4) | ((unsigned)ix & 15u);
+                const float *bt = tsdf + (e0 >= 0 ? (size_t)(e0 & BRICK_MASK) * UV + q0 : (size_t)0);
+                const F2u a = *(const F2u *)(bt), b = *(const F2u *)(bt + 16), c = *(const F2u *)(bt + 256), d = *(const F2u *)(bt + 272);
+                const bool have = e0 >= 0;
+                v0 = have ? a.x : 2.0f; v1 = have ? a.y : 2.0f; v2 = have ? b.x : 2.0f; v3 = have ? b.y : 2.0f;
+                v4 = have ? c.x : 2.0f; v5 = have ? c.y : 2.0f; v6 = have ? d.x : 2.0f; v7 = have ? d.y : 2.0f;
+            } else {
+                TSDF_CORNER(e0, ix, iy, iz, v0);
+                TSDF_CORNER(e1, ix + 1, iy, iz, v1);
+                TSDF_CORNER(e2, ix, iy + 1, iz, v2);
+                TSDF_CORNER(e3, ix + 1, iy + 1, iz, v3);
+                TSDF_CORNER(e4, ix, iy, iz + 1, v4);
+                TSDF_CORNER(e5, ix + 1, iy, iz + 1, v5);
+                TSDF_CORNER(e6, ix, iy + 1, iz + 1, v6);
+                TSDF_CORNER(e7, ix + 1, iy + 1, iz + 1, v7);
+            }
+            const bool all = (v0 <= 1.0f) & (v1 <= 1.0f) & (v2 <= 1.0f) & (v3 <= 1.0f) & (v4 <= 1.0f) & (v5 <= 1.0f) & (v6 <= 1.0f) &
+                             (v7 <= 1.0f);
+            // a cell with an unobserved corner (typically just behind an obliquely seen surface, where the truncation band is
+            // thinner than a voxel diagonal): the nearest lattice point — one of the eight corners — if that one was observed
+            const bool nx = f0 >= 0.5f, ny = f1 >= 0.5f, nz = f2 >= 0.5f;
+            const float a0 = nx ? v1 : v0, a1 = nx ? v3 : v2, a2 = nx ? v5 : v4, a3 = nx ? v7 : v6;
+            const float b0 = ny ? a1 : a0, b1 = ny ? a3 : a2;
+            const float nearest = nz ? b1 : b0;
+            // trilinear: x, then y, then z
+            const float c00 = __fadd_rn(v0, __fmul_rn(f0, __fsub_rn(v1, v0)));
+            const float c10 = __fadd_rn(v2, __fmul_rn(f0, __fsub_rn(v3, v2)));
+            const float c01 = __fadd_rn(v4, __fmul_rn(f0, __fsub_rn(v5, v4)));
+            const float c11 = __fadd_rn(v6, __fmul_rn(f0, __fsub_rn(v7, v6)));
+            const float c0 = __fadd_rn(c00, __fmul_rn(f1, __fsub_rn(c10, c00)));
+            const float c1 = __fadd_rn(c01, __fmul_rn(f1, __fsub_rn(c11, c01)));
+            const float tri = __fadd_rn(c0, __fmul_rn(f2, __fsub_rn(c1, c0)));
+            ok = open & (all | (nearest <= 1.0f));
+            val = ok ? (all ? tri : nearest) : 0.f;
+        }
         if (ok && prev_ok && prev_val > 0.f && val <= 0.f) {
             // linear zero crossing between the two samples
             depth = __fadd_rn(prev_t, __fmul_rn(__fsub_rn(t, prev_t), __fdiv_rn(prev_val, __fsub_rn(prev_val, val))));
+            if (depth > 0.f) atomicMin(&best_bits[lane], __float_as_uint(depth));
             break;
         }
         prev_ok = ok;
@@ -302,19 +495,24 @@ __global__ void tsdf_raycast_kernel(int H, int W, float fx, float fy, float cx, 
 #endif
     }
 #ifdef SGAM_TSDF_DEBUG_STEPS
-    depth = (float)(n_coarse * 10000 + n_fine);
-    if (live && seg == 0) out[i] = depth;
+    // instrumented build (scripts/tsdf_steps.py): out = 10000 x coarse steps + fine steps of the pixel, summed over its segments
+    __shared__ unsigned dbg_steps[64];
+    if (seg == 0) dbg_steps[lane] = 0;
+    __syncthreads();
+    atomicAdd(&dbg_steps[lane], (unsigned)(n_coarse * 10000 + n_fine));
+    __syncthreads();
+    if (live && seg == 0) out[i] = (float)dbg_steps[lane];
     return;
 #endif
-    // nearest hit over the RS lanes of this pixel (0 = no hit)
-    float best = depth > 0.f ? depth : 3.0e38f;
-#pragma unroll
-    for (int o = 1; o < RS; o <<= 1) best = fminf(best, __shfl_xor(best, o, 64));
-    if (live && seg == 0) out[i] = best < 3.0e38f ? best : 0.f;
+    __syncthreads();
+    // nearest hit over the RS segments of this pixel (0 = no hit)
+    const float best = __uint_as_float(best_bits[lane]);
+    const bool hit = best < 3.0e38f;
+    if (live && seg == 0) out[i] = hit ? best : 0.f;
     if (color_out && live) {
         // colour of the fused surface at the hit: the nearest voxel's running mean (0 where nothing is hit).  The lane that
         // found the winning crossing writes it (equal depths on two lanes: both write the same voxel's colour).
-        if (seg == 0 && !(best < 3.0e38f)) color_out[i * 3] = color_out[i * 3 + 1] = color_out[i * 3 + 2] = 0.f;
+        if (seg == 0 && !hit) color_out[i * 3] = color_out[i * 3 + 1] = color_out[i * 3 + 2] = 0.f;
         if (depth > 0.f && depth == best) {
             int vi[3];
 #pragma unroll
@@ -427,34 +625,63 @@ TsdfGrid to_dev(const sgam_tsdf_grid *g) {
 
 }  // namespace
 
-extern "C" int sgam_tsdf_integrate_f32(const sgam_tsdf_grid *grid, const float *depth, int32_t H, int32_t W, float fx, float fy,
-                                       float cx, float cy, const float *cam2world, const float *world2cam, float depth_trunc,
-                                       int32_t frame_id,
-                                       int32_t *unit_table, int32_t *unit_stamp, int32_t *counters, int32_t *brick_list,
-                                       int32_t max_list, float *brick_tsdf, float *brick_weight, int32_t max_bricks,
-                                       const uint8_t *rgb_u8, float *brick_color, void *stream) {
-    if ((rgb_u8 == nullptr) != (brick_color == nullptr)) return SGAM_EINVAL;     // colour fusion needs both or neither
-    if (!grid_ok(grid) || !depth || !(fx > 0.f) || !(fy > 0.f) || !cam2world || !world2cam || !unit_table || !unit_stamp || !counters || !brick_list ||
-        !brick_tsdf || !brick_weight || H <= 0 || W <= 0 || max_list <= 0 || max_bricks <= 0 || max_bricks > BRICK_MASK ||
-        frame_id <= 0)
+extern "C" int sgam_tsdf_integrate_srcs_f32(const sgam_tsdf_grid *grid, const sgam_tsdf_src *srcs, int32_t n_src, int32_t H, int32_t W,
+                                            float fx, float fy, float cx, float cy, float depth_trunc, int32_t step_id,
+                                            int32_t *unit_table, int32_t *unit_stamp, int32_t *counters, int32_t *brick_list,
+                                            int32_t max_list, float *brick_tsdf, float *brick_weight, int32_t max_bricks,
+                                            float *brick_color, const float *ray_mult, void *stream) {
+    if (!grid_ok(grid) || !srcs || !ray_mult || n_src <= 0 || n_src > MAX_SRC || !(fx > 0.f) || !(fy > 0.f) || !unit_table || !unit_stamp || !counters ||
+        !brick_list || !brick_tsdf || !brick_weight || H <= 0 || W <= 0 || max_list <= 0 || max_bricks <= 0 || max_bricks > BRICK_MASK ||
+        step_id <= 0 || step_id >= (1 << 23))
         return SGAM_EINVAL;
+    SrcSet S;
+    S.n = n_src;
+    for (int k = 0; k < MAX_SRC; ++k) {
+        const sgam_tsdf_src &src = srcs[k < n_src ? k : 0];
+        if (k < n_src && (!src.depth || (src.rgb_u8 == nullptr) != (brick_color == nullptr))) return SGAM_EINVAL;   // colour: both or neither
+        S.depth[k] = src.depth;
+        S.rgb[k] = src.rgb_u8;
+        for (int i = 0; i < 16; ++i) {
+            S.c2w[k].m[i] = src.cam2world[i];
+            S.w2c[k].m[i] = src.world2cam[i];
+        }
+    }
     const TsdfGrid g = to_dev(grid);
     hipStream_t s = sgam_stream(stream);
-    hipError_t e = hipMemsetAsync(counters + 1, 0, sizeof(int32_t), s);       // this frame's list length
+    hipError_t e = hipMemsetAsync(counters + 1, 0, sizeof(int32_t), s);       // this step's list length
     if (e != hipSuccess) return (int)e;
     const int stride = 4;                                                      // Open3D depth_sampling_stride
     const int ns = ((W + stride - 1) / stride) * ((H + stride - 1) / stride);
-    Pose c2w, w2c;
-    for (int i = 0; i < 16; ++i) {
-        c2w.m[i] = cam2world[i];
-        w2c.m[i] = world2cam[i];
-    }
-    SGAM_KLAUNCH(tsdf_touch_kernel, dim3(sgam_cdiv(ns, 256)), dim3(256), 0, s, depth, H, W, fx, fy, cx, cy,
-                       c2w, g, depth_trunc, stride, unit_table, unit_stamp, frame_id, counters, max_bricks, brick_list,
+    SGAM_KLAUNCH(tsdf_touch_kernel, dim3(sgam_cdiv(ns, 256), n_src), dim3(256), 0, s, S, H, W, fx, fy, cx, cy,
+                       g, depth_trunc, stride, unit_table, unit_stamp, step_id, counters, max_bricks, brick_list,
                        max_list);
     SGAM_LAUNCH_CHECK();
-    SGAM_KLAUNCH(tsdf_integrate_kernel, dim3(2048), dim3(256), 0, s, depth, H, W, fx, fy, cx, cy, w2c, g,
-                       depth_trunc, unit_table, counters, brick_list, max_list, brick_tsdf, brick_weight, rgb_u8, brick_color);
+#define SGAM_TSDF_INTEGRATE(NS, COLOR)                                                                                            \
+    SGAM_KLAUNCH((tsdf_integrate_kernel<NS, COLOR>), dim3(2048), dim3(256), 0, s, S, H, W, fx, fy, cx, cy, g, depth_trunc, unit_table, \
+                 unit_stamp, counters, brick_list, max_list, brick_tsdf, brick_weight, brick_color, ray_mult)
+    // kernels for 1, 2, 3 (GoogleEarth: <= 3 sources), 5 (CLEVR: <= 5) and 8 sources; a step with 4 or 6 .. 7 runs the next larger
+    const int nk = n_src <= 3 ? n_src : (n_src <= 5 ? 5 : 8);
+    if (brick_color) {
+        if (nk == 1) SGAM_TSDF_INTEGRATE(1, true);
+        else if (nk == 2) SGAM_TSDF_INTEGRATE(2, true);
+        else if (nk == 3) SGAM_TSDF_INTEGRATE(3, true);
+        else if (nk == 5) SGAM_TSDF_INTEGRATE(5, true);
+        else SGAM_TSDF_INTEGRATE(8, true);
+    } else {
+        if (nk == 1) SGAM_TSDF_INTEGRATE(1, false);
+        else if (nk == 2) SGAM_TSDF_INTEGRATE(2, false);
+        else if (nk == 3) SGAM_TSDF_INTEGRATE(3, false);
+        else if (nk == 5) SGAM_TSDF_INTEGRATE(5, false);
+        else SGAM_TSDF_INTEGRATE(8, false);
+    }
+#undef SGAM_TSDF_INTEGRATE
+    SGAM_LAUNCH_CHECK();
+    return SGAM_OK;
+}
+
+extern "C" int sgam_tsdf_ray_mult_f32(int32_t H, int32_t W, float fx, float fy, float cx, float cy, float *out, void *stream) {
+    if (H <= 0 || W <= 0 || !(fx > 0.f) || !(fy > 0.f) || !out) return SGAM_EINVAL;
+    SGAM_KLAUNCH(tsdf_ray_mult_kernel, dim3(sgam_cdiv((int64_t)H * W, 256)), dim3(256), 0, sgam_stream(stream), H, W, fx, fy, cx, cy, out);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;
 }
@@ -469,7 +696,7 @@ extern "C" int sgam_tsdf_raycast_depth_f32(const sgam_tsdf_grid *grid, int32_t H
     const TsdfGrid g = to_dev(grid);
     Pose c2w;
     for (int i = 0; i < 16; ++i) c2w.m[i] = cam2world[i];
-    SGAM_KLAUNCH(tsdf_raycast_kernel, dim3(sgam_cdiv((int64_t)H * W * RS, 256)), dim3(256), 0, sgam_stream(stream), H, W, fx, fy,
+    SGAM_KLAUNCH(tsdf_raycast_kernel, dim3(sgam_cdiv(W, 8) * sgam_cdiv(H, 8)), dim3(64 * RS), 0, sgam_stream(stream), H, W, fx, fy,
                        cx, cy, c2w, g, z_near, z_far, unit_table, brick_tsdf, depth_out, brick_color, color_out);
     SGAM_LAUNCH_CHECK();
     return SGAM_OK;

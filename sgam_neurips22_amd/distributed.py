@@ -9,6 +9,8 @@ import os
 # frames/s with the default, 447 with 8 queues; three scenes 392 vs 503).  Must be in the environment before the HIP
 # runtime starts, i.e. before the first CUDA call of the process.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# dmabuf IPC only on this host driver: without it RCCL's peer set-up fails with `hipIpcGetMemHandle: invalid argument`
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -44,6 +46,11 @@ def init(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
+            # RCCL's own version line (NCCL_DEBUG=VERSION), into a per-rank file instead of stdout — rank 0 prints ONE JSON line
+            # there; gather_metrics() reads rank 0's file back into the record, so a failing first multi-GPU run can be
+            # diagnosed from bench_extra.json alone
+            os.environ.setdefault("NCCL_DEBUG", "VERSION")
+            os.environ.setdefault("NCCL_DEBUG_FILE", os.path.join(os.environ.get("TMPDIR", "/tmp"), f"sgam_rccl_{os.getpid()}_r{rank}.log"))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
@@ -99,20 +106,47 @@ def barrier():
         dist.barrier()
 
 
-def gather_metrics(frames, seconds, checksum, device):
-    """All-gather one (frames, seconds, checksum) record per rank.  Returns dict(total_frames, max_seconds,
-    frames_per_s, per_rank=[...]) on every rank.  24 bytes per rank: latency-bound, no bandwidth tuning."""
-    rec = torch.tensor([float(frames), float(seconds), float(checksum)], dtype=torch.float64, device=device)
+def rccl_info():
+    """what this process knows about its RCCL: the library version torch was built against / loaded, the environment that
+    shapes the multi-process path, and (once a communicator exists) RCCL's own NCCL_DEBUG=VERSION line(s)"""
+    info = {"backend": dist.get_backend() if dist.is_available() and dist.is_initialized() else None,
+            "env": {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG", "GPU_MAX_HW_QUEUES", "WORLD_SIZE",
+                                                   "LOCAL_WORLD_SIZE", "MASTER_ADDR")}}
+    try:
+        info["version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as e:                      # CPU-only torch / gloo runs
+        info["version"] = None
+        info["version_error"] = type(e).__name__
+    path = os.environ.get("NCCL_DEBUG_FILE")
+    if path and os.path.exists(path):
+        try:
+            with open(path) as f:
+                info["debug_log"] = [ln.rstrip() for ln in f.readlines()[:8]]
+        except OSError:
+            pass
+    return info
+
+
+def gather_metrics(frames, seconds, checksum, device, numa_node=None):
+    """All-gather one (frames, seconds, checksum, numa node, local rank) record per rank.  Returns dict(total_frames,
+    max_seconds, frames_per_s, per_rank=[(frames, seconds, checksum)], per_rank_records=[{...}], rccl={...}) on every rank.
+    40 bytes per rank: latency-bound, no bandwidth tuning."""
+    rank, local_rank, _ = env_world()
+    rec = torch.tensor([float(frames), float(seconds), float(checksum), -1.0 if numa_node is None else float(numa_node),
+                        float(local_rank)], dtype=torch.float64, device=device)
     if collectives_active():
         out = [torch.zeros_like(rec) for _ in range(dist.get_world_size())]
         dist.all_gather(out, rec)
     else:
         out = [rec]
-    per_rank = [tuple(t.tolist()) for t in out]
+    rows = [t.tolist() for t in out]
+    per_rank = [tuple(r[:3]) for r in rows]
     total = sum(r[0] for r in per_rank)
     tmax = max(r[1] for r in per_rank)
+    records = [{"rank": i, "frames": r[0], "seconds": round(r[1], 6), "checksum": r[2], "numa_node": None if r[3] < 0 else int(r[3]),
+                "local_rank": int(r[4])} for i, r in enumerate(rows)]
     return {"total_frames": total, "max_seconds": tmax, "frames_per_s": total / tmax if tmax > 0 else 0.0,
-            "per_rank": per_rank}
+            "per_rank": per_rank, "per_rank_records": records, "rccl": rccl_info()}
 
 
 class ConcurrentScenes:

@@ -181,6 +181,7 @@ class InfiniteSceneGeneration:
         self._load_known_frames(known_map)
         self.dynamic_model.use_rgbd_integration = use_rgbd_integration
         self.volume = None
+        self._tsdf_log = []      # the source coordinates of every integration step, in order (colour_volume replays them)
         if use_rgbd_integration and tgt_depth_provider is None:
             self.volume = self._make_volume()
         K32 = torch.from_numpy(self.K.astype(np.float32))
@@ -211,35 +212,40 @@ class InfiniteSceneGeneration:
     # view-space z range of valid depths per dataset: the inverse-depth codec's bounds (model.py:210-229)
     _Z_RANGE = {"google_earth": (0.05, 4.8), "clevr-infinite": (1.0, 16.5)}
 
-    def _make_volume(self):
+    def _make_volume(self, color=False):
         from .tsdf import VOLUME_PARAMS, TsdfVolume, frustum_bounds, UNIT
         voxel, trunc = VOLUME_PARAMS[self.data]
-        poses = []
-        for row in self.transform_grid:
-            for node in row:
-                T = np.eye(4)
-                T[:3, :3], T[:3, 3] = node["R"], node["t"]
-                poses.append(T)
+        poses = [node["T"] for row in self.transform_grid for node in row]
         H, W = self.image_resolution
         lo, hi = frustum_bounds(self.K, poses, H, W, self._Z_RANGE[self.data][1], margin=trunc + voxel * UNIT)
-        # RGB8 colour is fused alongside the depth like the reference's volume (:123-131); pool sized from the free memory
-        return TsdfVolume(voxel, trunc, lo, hi, self.device, color=True)
+        # The loop's volume fuses GEOMETRY only: the conditioning path consumes nothing but the rendered depth, and colour
+        # is 60 % of a voxel's bytes.  The reference's RGB8 colour (:123-131) is fused when the run's tail asks for it:
+        # export_point_clouds replays the logged integrations into a colour volume (same kernels, same order).
+        return TsdfVolume(voxel, trunc, lo, hi, self.device, color=color)
 
     def rgbd_integration(self, src_nodes, tgt_node):
         """reference :745-838: integrate every source frame of this step (again — the volume is cumulative, like the
-        reference's self.volume), then render the fused surface's depth at the target pose.  (H,W) device fp32."""
-        for s in src_nodes:
-            T = np.eye(4)
-            T[:3, :3], T[:3, 3] = s["R"], s["t"]
-            # the reference fuses the depth as loaded (:570-574) — for the CLEVR seed that is the ONCE-converted map;
-            # its second ray->z conversion (:582-590) only touches batch['src_depths'], after the fusion
-            fr = self.frames[s["grid_coord"]]
-            self.volume.integrate(fr["depth"], self.K, T, rgb_u8=fr["rgb_u8"])
-        T = np.eye(4)
-        T[:3, :3], T[:3, 3] = tgt_node["R"], tgt_node["t"]
+        reference's self.volume), then render the fused surface's depth at the target pose.  (H,W) device fp32.
+        One pass over the union of the units the sources open (TsdfVolume.integrate_many); poses are the nodes' own 4x4s."""
+        # the reference fuses the depth as loaded (:570-574) — for the CLEVR seed that is the ONCE-converted map;
+        # its second ray->z conversion (:582-590) only touches batch['src_depths'], after the fusion
+        coords = [s["grid_coord"] for s in src_nodes]
+        self.volume.integrate_many([self.frames[c]["depth"] for c in coords], self.K, [s["T"] for s in src_nodes],
+                                   Ts_c2w=[s["T_inv"] for s in src_nodes])
+        self._tsdf_log.append(coords)
         H, W = self.image_resolution
         z0, z1 = self._Z_RANGE[self.data]
-        return self.volume.render_depth(self.K, T, H, W, z0, z1)
+        return self.volume.render_depth(self.K, tgt_node["T"], H, W, z0, z1, T_c2w=tgt_node["T_inv"])
+
+    def colour_volume(self):
+        """The fused volume WITH the reference's RGB8 colour (:123-131, 777-790): the logged integrations of the run replayed
+        in order — every source frame is still in the frame store — through the colour-fusing form of the same kernels."""
+        vol = self._make_volume(color=True)
+        for coords in self._tsdf_log:
+            nodes = [self.transform_grid[c[0]][c[1]] for c in coords]
+            vol.integrate_many([self.frames[c]["depth"] for c in coords], self.K, [n["T"] for n in nodes],
+                               rgbs_u8=[self.frames[c]["rgb_u8"] for c in coords], Ts_c2w=[n["T_inv"] for n in nodes])
+        return vol
 
     # ---------------------------------------------------------------- grid / order / source choice
     def get_known_map(self):
@@ -255,7 +261,11 @@ class InfiniteSceneGeneration:
         return known
 
     def _node(self, R, t, coord, known_map):
-        node = {"R": R, "t": t, "K": self.K, "position": -R.T @ t, "visited": coord in known_map, "grid_coord": coord}
+        T = np.eye(4)
+        T[:3, :3], T[:3, 3] = R, t
+        # "T" = [R | t] world -> camera and its inverse, made once per pose (the step assembles nothing)
+        node = {"R": R, "t": t, "K": self.K, "position": -R.T @ t, "visited": coord in known_map, "grid_coord": coord,
+                "T": T, "T_inv": np.linalg.inv(T)}
         if coord in known_map:
             node["rgb_path"], node["depth_path"] = known_map[coord]["rgb_path"], known_map[coord]["depth_path"]
             self.anchor_poses[coord] = node
@@ -452,13 +462,10 @@ class InfiniteSceneGeneration:
 
     # ---------------------------------------------------------------- batch assembly
     def relative_poses(self, tgt_node, src_nodes):
-        T_tgt = np.eye(4)
-        T_tgt[:3, :3], T_tgt[:3, 3] = tgt_node["R"], tgt_node["t"]
+        T_tgt = tgt_node["T"]
         R_rels, t_rels, T_tgt2srcs = [], [], []
         for s in src_nodes:
-            T_src = np.eye(4)
-            T_src[:3, :3], T_src[:3, 3] = s["R"], s["t"]
-            T_rel = T_tgt @ np.linalg.inv(T_src)
+            T_rel = T_tgt @ np.linalg.inv(s["T"])
             T_tgt2srcs.append(np.linalg.inv(T_rel))
             R_rels.append(T_rel[:3, :3])
             t_rels.append(T_rel[:3, 3])
@@ -603,6 +610,7 @@ class InfiniteSceneGeneration:
             self.transform_grid[c[0]][c[1]]["visited"] = False
         if self.volume is not None:            # the fused volume saw the invalid frames: start it again (every step
             self.volume = self._make_volume()  # re-integrates its own sources, :757-790)
+            self._tsdf_log = []
         return verified_curr
 
     def scene_expansion(self, return_hs=False, range_check_every=8):
@@ -653,7 +661,7 @@ class InfiniteSceneGeneration:
             cols.append(c)
         out = {"merged_pcds.ply": pointcloud.write_ply(os.path.join(out_dir, "merged_pcds.ply"), np.concatenate(pts), np.concatenate(cols))}
         if self.use_rgbd_integration and self.volume is not None:
-            pc = self.volume.extract_point_cloud()
+            pc = self.colour_volume().extract_point_cloud()
             out["rgbd_integrated_mesh.ply"] = pointcloud.write_ply(os.path.join(out_dir, "rgbd_integrated_mesh.ply"), pc["points"],
                                                                    pc.get("colors"), pc["normals"])
         return out

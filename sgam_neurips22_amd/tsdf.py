@@ -64,6 +64,7 @@ class TsdfVolume:
         self.max_list = int(min(n_units, 1 << 22))
         self.brick_list = torch.empty((self.max_list,), dtype=torch.int32, device=device)
         self.frame_id = 0
+        self._ray_mult = {}      # (H, W, fx, fy, cx, cy) -> (H,W) table of the rule's depth -> camera-distance multiplier
 
     @staticmethod
     def _k4(K):
@@ -73,32 +74,57 @@ class TsdfVolume:
     def integrate(self, depth, K, T_w2c, rgb_u8=None):
         """depth (H,W) fp32 device tensor, K 3x3, T_w2c 4x4 world->camera (the reference's extrinsic [R|t]); rgb_u8 (H,W,3)
         uint8 device tensor: the frame's colour, fused when the volume was built with color=True."""
-        ops._need_cuda(depth)
-        rgb = None
-        if self.brick_color is not None:
-            if rgb_u8 is None or rgb_u8.dtype != torch.uint8 or tuple(rgb_u8.shape) != (*depth.shape, 3):
-                raise ops.SgamHipError("TsdfVolume(color=True).integrate needs the frame's (H,W,3) uint8 colour")
-            rgb = rgb_u8.contiguous()
-        H, W = depth.shape
-        T = np.asarray(T_w2c, dtype=np.float64)
-        w2c = np.ascontiguousarray(T, dtype=np.float32)                      # host 4x4s: passed by value to the kernels
-        c2w = np.ascontiguousarray(np.linalg.inv(T), dtype=np.float32)
+        self.integrate_many([depth], K, [T_w2c], None if rgb_u8 is None else [rgb_u8])
+
+    def integrate_many(self, depths, K, Ts_w2c, rgbs_u8=None, Ts_c2w=None):
+        """The source frames of ONE step (reference :757-790: one volume.integrate per source) in one pass over the union of
+        the units they open — the same voxel values as integrate() per source in list order.  Ts_c2w: the inverses, when the
+        caller holds them already (float64 4x4s)."""
+        n = len(depths)
+        if not 0 < n <= 8 or len(Ts_w2c) != n:
+            raise ops.SgamHipError("TsdfVolume.integrate_many: 1 .. 8 source frames, one pose each")
+        H, W = depths[0].shape
+        srcs = (_lib.TsdfSrc * n)()
+        keep = []
+        for k in range(n):
+            d = depths[k]
+            ops._need_cuda(d)
+            if tuple(d.shape) != (H, W) or d.dtype != torch.float32:
+                raise ops.SgamHipError("TsdfVolume.integrate_many: depth maps must be (H,W) fp32 of one size")
+            d = d.contiguous()
+            rgb = None
+            if self.brick_color is not None:
+                rgb = None if rgbs_u8 is None else rgbs_u8[k]
+                if rgb is None or rgb.dtype != torch.uint8 or tuple(rgb.shape) != (H, W, 3):
+                    raise ops.SgamHipError("TsdfVolume(color=True).integrate needs the frame's (H,W,3) uint8 colour")
+                rgb = rgb.contiguous()
+            keep.append((d, rgb))
+            T = np.asarray(Ts_w2c[k], dtype=np.float64)
+            Ti = np.linalg.inv(T) if Ts_c2w is None else np.asarray(Ts_c2w[k], dtype=np.float64)
+            srcs[k].depth, srcs[k].rgb_u8 = ops._p(d), ops._p(rgb)
+            srcs[k].cam2world[:] = Ti.astype(np.float32).ravel().tolist()       # host 4x4s: passed by value to the kernels
+            srcs[k].world2cam[:] = T.astype(np.float32).ravel().tolist()
         self.frame_id += 1
         fx, fy, cx, cy = self._k4(K)
-        d = depth.contiguous()
-        check(_lib.load().sgam_tsdf_integrate_f32(
-            ctypes.byref(self.grid), ops._p(d), H, W, fx, fy, cx, cy, c2w.ctypes.data, w2c.ctypes.data, DEPTH_TRUNC, self.frame_id,
+        key = (H, W, fx, fy, cx, cy)
+        if key not in self._ray_mult:
+            rm = torch.empty((H, W), dtype=torch.float32, device=self.device)
+            check(_lib.load().sgam_tsdf_ray_mult_f32(H, W, fx, fy, cx, cy, ops._p(rm), ops._stream()), "sgam_tsdf_ray_mult_f32")
+            self._ray_mult[key] = rm
+        check(_lib.load().sgam_tsdf_integrate_srcs_f32(
+            ctypes.byref(self.grid), srcs, n, H, W, fx, fy, cx, cy, DEPTH_TRUNC, self.frame_id,
             ops._p(self.unit_table), ops._p(self.unit_stamp), ops._p(self.counters), ops._p(self.brick_list), self.max_list,
-            ops._p(self.brick_tsdf), ops._p(self.brick_weight), self.max_bricks, ops._p(rgb),
-            ops._p(self.brick_color if rgb is not None else None), ops._stream()),
-            "sgam_tsdf_integrate_f32")
+            ops._p(self.brick_tsdf), ops._p(self.brick_weight), self.max_bricks, ops._p(self.brick_color),
+            ops._p(self._ray_mult[key]), ops._stream()), "sgam_tsdf_integrate_srcs_f32")
 
-    def render_depth(self, K, T_w2c, H, W, z_near, z_far, want_color=False):
+    def render_depth(self, K, T_w2c, H, W, z_near, z_far, want_color=False, T_c2w=None, out=None):
         """View-space z of the fused surface at the pose, (H,W) fp32, 0 where nothing is hit; with want_color also the
-        fused colour at the hit, (H,W,3) fp32 in 0..255."""
+        fused colour at the hit, (H,W,3) fp32 in 0..255.  T_c2w: the inverse pose when the caller holds it; out: destination."""
         T = np.asarray(T_w2c, dtype=np.float64)
-        c2w = np.ascontiguousarray(np.linalg.inv(T), dtype=np.float32)
-        out = torch.empty((H, W), dtype=torch.float32, device=self.device)
+        c2w = np.ascontiguousarray(np.linalg.inv(T) if T_c2w is None else T_c2w, dtype=np.float32)
+        if out is None:
+            out = torch.empty((H, W), dtype=torch.float32, device=self.device)
+        assert out.shape == (H, W) and out.dtype == torch.float32 and out.is_contiguous()
         fx, fy, cx, cy = self._k4(K)
         check(_lib.load().sgam_tsdf_raycast_depth_f32(
             ctypes.byref(self.grid), H, W, fx, fy, cx, cy, c2w.ctypes.data, float(z_near), float(z_far), ops._p(self.unit_table),

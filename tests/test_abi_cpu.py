@@ -20,8 +20,12 @@ def _declared_symbols():
 def test_library_is_built_and_loads():
     assert os.path.exists(_lib.LIB_PATH), "run `python -m sgam_neurips22_amd.build`"
     lib = _lib.load()
-    assert lib.sgam_abi_version() == _lib.ABI_VERSION == 9
+    assert lib.sgam_abi_version() == _lib.ABI_VERSION == 10
     assert b"gfx950" in lib.sgam_build_info()
+    # the build stamp (csrc/build_info.hip): commit of the library's sources + digest over sources and flags
+    commit, digest = lib.sgam_build_commit().decode(), lib.sgam_build_digest().decode()
+    assert commit and commit != "unknown" and len(digest) == 12
+    assert commit.encode() in lib.sgam_build_info() and digest.encode() in lib.sgam_build_info()
 
 
 def test_every_declared_symbol_is_exported_and_bound():
@@ -152,8 +156,12 @@ def test_tsdf_argument_validation_without_gpu():
     lib = _lib.load()
     g = _lib.TsdfGrid(0.01, 0.03, (ctypes.c_int32 * 3)(0, 0, 0), (ctypes.c_int32 * 3)(4, 4, 4))
     bad = _lib.TsdfGrid(0.0, 0.03, (ctypes.c_int32 * 3)(0, 0, 0), (ctypes.c_int32 * 3)(4, 4, 4))
-    args = (None, 8, 8, 10.0, 10.0, 4.0, 4.0, None, None, 20.0, 1, None, None, None, None, 16, None, None, 16, None, None, None)
-    assert lib.sgam_tsdf_integrate_f32(ctypes.byref(g), *args) == -1
-    assert lib.sgam_tsdf_integrate_f32(ctypes.byref(bad), *args) == -1
+    srcs = (_lib.TsdfSrc * 2)()
+    args = (8, 8, 10.0, 10.0, 4.0, 4.0, 20.0, 1, None, None, None, None, 16, None, None, 16, None, None, None)
+    assert lib.sgam_tsdf_integrate_srcs_f32(ctypes.byref(g), srcs, 2, *args) == -1          # no state pointers
+    assert lib.sgam_tsdf_integrate_srcs_f32(ctypes.byref(bad), srcs, 2, *args) == -1
+    assert lib.sgam_tsdf_integrate_srcs_f32(ctypes.byref(g), srcs, 9, *args) == -1          # more than 8 sources
+    assert ctypes.sizeof(_lib.TsdfSrc) == 16 + 128
+    assert lib.sgam_tsdf_ray_mult_f32(8, 8, 10.0, 10.0, 4.0, 4.0, None, None) == -1
     assert lib.sgam_tsdf_raycast_depth_f32(ctypes.byref(g), 8, 8, 10.0, 10.0, 4.0, 4.0, None, 0.1, 4.0, None, None, None,
                                            None, None, None) == -1

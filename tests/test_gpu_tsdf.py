@@ -106,9 +106,7 @@ def test_scene_loop_with_rgbd_integration():
     node0, node1 = scene.transform_grid[0][0], scene.transform_grid[1][0]
     d1 = scene.rgbd_integration([node0], node1)
     assert float((d1 > 0).float().mean()) > 0.8
-    T = np.eye(4)
-    T[:3, :3], T[:3, 3] = node0["R"], node0["t"]
-    d0 = scene.volume.render_depth(scene.K, T, 256, 256, 0.05, 4.8)
+    d0 = scene.volume.render_depth(scene.K, node0["T"], 256, 256, 0.05, 4.8)
     seed = scene.frames[(0, 0)]["depth"]
     hit = d0 > 0
     assert float(hit.float().mean()) > 0.9
@@ -122,6 +120,19 @@ def test_scene_loop_with_rgbd_integration():
         assert cover > 0.4, cover
     st = scene.volume.stats()
     assert st[0] > 100 and st[3] == 0, st           # bricks were allocated, the pool did not overflow
+    # the loop fuses geometry only; the colour volume of the run's tail replays the logged integrations: same geometry bit
+    # for bit, and the colours of a volume that had fused them step by step
+    assert scene.volume.brick_color is None and len(scene._tsdf_log) == 4
+    cv = scene.colour_volume()
+    eager = scene._make_volume(color=True)
+    for coords in scene._tsdf_log:
+        for c in coords:
+            eager.integrate(scene.frames[c]["depth"], scene.K, scene.transform_grid[c[0]][c[1]]["T"], rgb_u8=scene.frames[c]["rgb_u8"])
+    ul, uc, ue = _by_unit(scene.volume), _by_unit(cv), _by_unit(eager)
+    assert set(ul) == set(uc) == set(ue)
+    for key in ul:
+        assert all(np.array_equal(x.view(np.uint32), y.view(np.uint32)) for x, y in zip(ul[key][1:3], uc[key][1:3])), key
+        assert all(np.array_equal(x.view(np.uint32), y.view(np.uint32)) for x, y in zip(uc[key][1:], ue[key][1:])), key
 
 
 def _textured(H, W, seed):
@@ -156,6 +167,52 @@ def test_colour_fusion_matches_the_oracle_bit_for_bit():
     with pytest.raises(Exception):
         vol.integrate(torch.from_numpy(plane_depth(K, poses[0], H, W, 2.2)).to(DEV), K, poses[0])     # colour volume needs rgb
     assert vol.check() == n
+
+
+def _by_unit(vol):
+    """{unit key: (tsdf, weight[, colour]) bricks} — brick numbering is allocation order (not part of the result)"""
+    table = vol.unit_table.cpu().numpy().reshape(int(vol.dims[2]), int(vol.dims[1]), int(vol.dims[0]))
+    t, w = vol.brick_tsdf.cpu().numpy(), vol.brick_weight.cpu().numpy()
+    c = vol.brick_color.cpu().numpy() if vol.brick_color is not None else None
+    out = {}
+    for z, y, x in zip(*np.nonzero(table >= 0)):
+        e = int(table[z, y, x])
+        b = e & 0x3FFFFFFF
+        out[(int(x), int(y), int(z))] = (bool(e & 0x40000000), t[b], w[b]) + ((c[b],) if c is not None else ())
+    return out
+
+
+@pytest.mark.parametrize("color", [False, True])
+def test_one_pass_over_the_sources_of_a_step_equals_one_integration_per_source(color):
+    """integrate_many (one launch pair for the step: union of the opened units, each voxel loaded once, the sources' updates
+    applied in order in registers) leaves the volume bit-identical to the reference's loop of one integrate per source
+    (:757-790) — including units only SOME of the sources open, re-integration across steps and the band flags."""
+    H = W = 64
+    K = _K(120.0, 31.5)
+    poses = [_pose(), _pose(tx=0.35, yaw=0.12), _pose(tx=-0.3, ty=0.2, yaw=-0.1), _pose(ty=-0.25), _pose(tx=0.1, ty=0.1, yaw=0.03)]
+    lo, hi = frustum_bounds(K, poses, H, W, 4.8, margin=0.03 + 16 * 0.01)
+    rs = np.random.RandomState(5)
+    frames = []
+    for i, T in enumerate(poses):
+        d = plane_depth(K, T, H, W, 2.2) + (0.05 * rs.standard_normal((H, W))).astype(np.float32)      # rough: many partial units
+        d[rs.uniform(size=(H, W)) < 0.05] = 0.0                                                          # holes
+        frames.append((torch.from_numpy(d).to(DEV), torch.from_numpy(_textured(H, W, i)).to(DEV)))
+    steps = [[0], [1, 0], [2, 1, 0], [3, 2, 1], [4, 3, 2, 1, 0]]
+    a = TsdfVolume(0.01, 0.03, lo, hi, DEV, memory_budget_bytes=2 << 30, color=color)
+    b = TsdfVolume(0.01, 0.03, lo, hi, DEV, memory_budget_bytes=2 << 30, color=color)
+    for srcs in steps:
+        a.integrate_many([frames[i][0] for i in srcs], K, [poses[i] for i in srcs], [frames[i][1] for i in srcs] if color else None)
+        for i in srcs:
+            b.integrate(frames[i][0], K, poses[i], rgb_u8=frames[i][1] if color else None)
+    ua, ub = _by_unit(a), _by_unit(b)
+    assert set(ua) == set(ub) and len(ua) > 100
+    for key in ua:
+        assert ua[key][0] == ub[key][0], key
+        for pa, pb in zip(ua[key][1:], ub[key][1:]):
+            assert np.array_equal(pa.view(np.uint32), pb.view(np.uint32)), key
+    assert a.stats()[0] == b.stats()[0] and a.stats()[2:] == b.stats()[2:]
+    Tn = _pose(tx=0.05, ty=0.02, yaw=0.01)
+    assert torch.equal(a.render_depth(K, Tn, H, W, 0.05, 4.8), b.render_depth(K, Tn, H, W, 0.05, 4.8))
 
 
 @pytest.mark.parametrize("voxel,trunc,zc,radius", [(0.05, 0.5, 9.0, 1.5), (0.01, 0.03, 2.4, 0.5)])
