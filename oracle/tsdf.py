@@ -122,6 +122,9 @@ class TsdfOracle:
             rx, ry = F((F(u) - cx) / fx), F((F(v) - cy) / fy)
             o = [c2w[r, 3] for r in range(3)]
             d = [F(F(F(c2w[r, 0] * rx) + F(c2w[r, 1] * ry)) + c2w[r, 2]) for r in range(3)]
+            inv_unit = F(F(1.0) / self.unit_len)                      # the march multiplies by reciprocals fixed per ray
+            with np.errstate(divide="ignore"):
+                inv_d = [F(F(1.0) / d[r]) for r in range(3)]
             RS = 8
             seg_len = F(F(F(z_far) - F(z_near)) / F(RS))
             best = None
@@ -131,15 +134,15 @@ class TsdfOracle:
                 t, prev_t, prev_val, prev_ok = t_begin, F(0), F(0), False
                 while t < t_end:
                     p = [F(o[r] + F(d[r] * t)) for r in range(3)]
-                    uf = [np.floor(F(p[r] / self.unit_len)) for r in range(3)]
+                    uf = [np.floor(F(p[r] * inv_unit)) for r in range(3)]
                     key = tuple(int(x) for x in uf)
                     is_open = key in self.near
                     coarse = F(z_far)
                     for r in range(3):
                         if d[r] > 0:
-                            coarse = min(coarse, F(F(F(F(uf[r] + F(1)) * self.unit_len) - p[r]) / d[r]))
+                            coarse = min(coarse, F(F(F(F(uf[r] + F(1)) * self.unit_len) - p[r]) * inv_d[r]))
                         elif d[r] < 0:
-                            coarse = min(coarse, F(F(F(F(uf[r]) * self.unit_len) - p[r]) / d[r]))
+                            coarse = min(coarse, F(F(F(F(uf[r]) * self.unit_len) - p[r]) * inv_d[r]))
                     coarse = F(max(coarse, F(0)) + eps)
                     val = self._sample(p, inv_voxel) if is_open else None
                     ok = val is not None

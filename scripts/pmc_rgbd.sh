@@ -15,14 +15,16 @@ run write WRITE_SIZE
 run tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 run tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum
 python3 - <<PY
-import csv, glob, collections, json
+import csv, glob, collections, json, re
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "tsdf" in k or "inverse_warp" in k or "depth_normalise" in k:
-            agg[k.split("(")[0].replace("void (anonymous namespace)::", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
-out = {k: {c: round(sum(v) / len(v), 1) for c, v in cs.items()} | {"launches": max(len(v) for v in cs.values())} for k, cs in agg.items()}
+        m = re.search(r"(tsdf_\w+|inverse_warp_kernel|depth_normalise\w*)", k)
+        if m:
+            agg[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+# (the first launches see a nearly empty volume: averages over the last half of the run)
+out = {k: {c: round(sum(v[len(v) // 2:]) / len(v[len(v) // 2:]), 1) for c, v in cs.items()} | {"launches": max(len(v) for v in cs.values())} for k, cs in agg.items()}
 json.dump(out, open("$R/gpurun_out/pmc_rgbd.json", "w"), indent=1)
 for k, v in out.items():
     print(k, v)

@@ -9,6 +9,18 @@ steps, warmup = int(os.environ.get("STEPS", 31)), int(os.environ.get("WARMUP", 3
 dev = torch.device("cuda", 0)
 model, sd, p = build_model(dev)
 model.enable_hip_graph(os.environ.get("NO_GRAPH", "0") != "1")
+if os.environ.get("SPLAT_TOO", "1") == "1":      # the forward-splat branch on the same box, for the difference
+    s0 = InfiniteSceneGeneration(model, DATASET, seed_index=0, output_dim=(steps + warmup + 4, 1), seed_frame=synthetic_seed_frame(DATASET, 0))
+    for _ in range(warmup):
+        s0.one_step_prediction(s0.next_pose(s0.curr)); s0.curr += 1
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(steps):
+        s0.one_step_prediction(s0.next_pose(s0.curr)); s0.curr += 1
+    torch.cuda.synchronize()
+    dt0 = time.perf_counter() - t
+    print(f"splat loop: {steps / dt0:.1f} frames/s, {1e3 * dt0 / steps:.3f} ms/frame")
+    del s0
 sc = InfiniteSceneGeneration(model, DATASET, seed_index=0, output_dim=(steps + warmup + 4, 1), seed_frame=synthetic_seed_frame(DATASET, 0),
                              use_rgbd_integration=True)
 for _ in range(warmup):

@@ -33,3 +33,10 @@ x, x_dst, em, wd = step()
 print("model ms", T(lambda: sc.dynamic_model(x, topk=1, extrapolation_mask=em, get_pre_quantized_feature=True, get_quantized_feature=True, sample_number=1)))
 print("full step ms", T(lambda: sc.one_step_prediction(tgt, save_res_to_disk=False)))
 print(sc.volume.stats())
+# per-kernel durations of the conditioning path (HIP-event brackets of the library, 6 repetitions)
+reps = 6
+recs, br = ops.kernel_timeline(lambda: [sc.prepare_batch_data(tm, sm, sc.num_src) for _ in range(reps)])
+per = {}
+for name, ms, *_ in recs:
+    per[name.split("<")[0] + ("<" + name.split("<")[1] if "integrate" in name else "")] = per.get(name.split("<")[0] + ("<" + name.split("<")[1] if "integrate" in name else ""), 0.0) + max(ms - br, 0.0)
+print("conditioning kernels, us per step:", {k: round(1e3 * v / reps, 1) for k, v in per.items()}, "bracket us", round(1e3 * br, 2))

@@ -77,10 +77,10 @@ __global__ void tsdf_touch_kernel(const SrcSet S, int H, int W, float fx, float 
     const float *c2w = S.c2w[k].m;
     const int sw = (W + stride - 1) / stride, sh = (H + stride - 1) / stride;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= sw * sh) return;
-    const int v = (i / sw) * stride, u = (i % sw) * stride;
+    const bool in_grid = i < sw * sh;
+    const int v = in_grid ? (i / sw) * stride : 0, u = in_grid ? (i % sw) * stride : 0;
     const float d = depth[v * W + u];
-    if (!(d > 0.f) || d > depth_trunc) return;
+    const bool live = in_grid && d > 0.f && !(d > depth_trunc);      // (no early return: the wavefront's lanes cooperate below)
     // camera point, then world (c2w row-major 4x4)
     const float xc = __fmul_rn(__fdiv_rn(__fsub_rn((float)u, cx), fx), d);
     const float yc = __fmul_rn(__fdiv_rn(__fsub_rn((float)v, cy), fy), d);
@@ -96,42 +96,69 @@ __global__ void tsdf_touch_kernel(const SrcSet S, int H, int W, float fx, float 
         hi[r] = (int)floorf(__fdiv_rn(__fadd_rn(p[r], g.trunc), g.unit_len));
     }
     const int tag = step_id << 8, bit = 1 << k;
-    for (int uz = lo[2]; uz <= hi[2]; ++uz)
-        for (int uy = lo[1]; uy <= hi[1]; ++uy)
-            for (int ux = lo[0]; ux <= hi[0]; ++ux) {
-                const int64_t s = unit_slot(g, ux, uy, uz);
-                if (s < 0) {
-                    atomicAdd(&counters[2], 1);          // samples outside the scene box (diagnostic)
-                    continue;
+    const unsigned long long lanes_below = (1ull << (threadIdx.x & 63)) - 1ull;
+    // The units are visited in lock step by the wavefront (trip counts padded to the wavefront's maximum) so that the three
+    // counters — list length, brick pool, outside-the-box diagnostic — take ONE atomic per wavefront and visit instead of
+    // one per lane: every lane of every workgroup adding to the same word was the whole cost of this kernel.
+    const int nx = live ? hi[0] - lo[0] + 1 : 1, ny = live ? hi[1] - lo[1] + 1 : 1, nz = live ? hi[2] - lo[2] + 1 : 1;
+    const int trips = live ? nx * ny * nz : 0;
+    int max_trips = trips;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) max_trips = max(max_trips, __shfl_xor(max_trips, o, 64));
+    for (int it = 0; it < max_trips; ++it) {
+        const bool act = it < trips;
+        const int ux = lo[0] + it % nx, uy = lo[1] + (it / nx) % ny, uz = lo[2] + it / (nx * ny);
+        const int64_t s = act ? unit_slot(g, ux, uy, uz) : -1;
+        const bool outside = act && s < 0;
+        const unsigned long long m_out = __builtin_amdgcn_ballot_w64(outside);
+        if (m_out && (threadIdx.x & 63) == __builtin_ctzll(m_out)) atomicAdd(&counters[2], __builtin_popcountll(m_out));   // diagnostic
+        bool first = false;
+        if (s >= 0) {
+            int old = __hip_atomic_load(&stamp[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (;;) {
+                const bool same_step = (old & ~0xff) == tag;
+                const int want = same_step ? (old | bit) : (tag | bit);
+                if (want == old) break;                                       // this source already marked the unit
+                const int prev = atomicCAS(&stamp[s], old, want);
+                if (prev == old) {
+                    first = !same_step;
+                    break;
                 }
-                int old = __hip_atomic_load(&stamp[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                bool first = false;
-                for (;;) {
-                    const bool same_step = (old & ~0xff) == tag;
-                    const int want = same_step ? (old | bit) : (tag | bit);
-                    if (want == old) break;                                       // this source already marked the unit
-                    const int prev = atomicCAS(&stamp[s], old, want);
-                    if (prev == old) {
-                        first = !same_step;
-                        break;
-                    }
-                    old = prev;
-                }
-                if (!first) continue;                    // listed for this step already
-                int brick = table[s];          // (the NEAR bit, if set, rides along: entries are only ever extended)
-                if (brick < 0) {
-                    // first touch ever: allocate.  The tag change above makes this lane the only one handling slot s
-                    // in this step, so no CAS loop is needed.
-                    brick = atomicAdd(&counters[0], 1);
-                    if (brick >= max_bricks) {
-                        atomicAdd(&counters[3], 1);      // pool exhausted (diagnostic); unit stays closed
-                        continue;
-                    }
+                old = prev;
+            }
+        }
+        // `first`: this lane moved the word to the step's tag — it alone lists the unit and, if it never had one, allocates
+        // its brick (no CAS loop needed)
+        int brick = first ? table[s] : 0;          // (the NEAR bit, if set, rides along: entries are only ever extended)
+        const bool need = first && brick < 0;
+        const unsigned long long m_need = __builtin_amdgcn_ballot_w64(need);
+        if (m_need) {
+            int base = 0;
+            const int leader = __builtin_ctzll(m_need);
+            if ((threadIdx.x & 63) == leader) base = atomicAdd(&counters[0], __builtin_popcountll(m_need));
+            base = __shfl(base, leader, 64);
+            if (need) {
+                brick = base + __builtin_popcountll(m_need & lanes_below);
+                if (brick >= max_bricks) {
+                    atomicAdd(&counters[3], 1);          // pool exhausted (diagnostic); unit stays closed
+                    first = false;
+                } else {
                     table[s] = brick;
                 }
-                const int li = atomicAdd(&counters[1], 1);
+            }
+        }
+        const unsigned long long m_list = __builtin_amdgcn_ballot_w64(first);
+        if (m_list) {
+            int base = 0;
+            const int leader = __builtin_ctzll(m_list);
+            if ((threadIdx.x & 63) == leader) base = atomicAdd(&counters[1], __builtin_popcountll(m_list));
+            base = __shfl(base, leader, 64);
+            if (first) {
+                const int li = base + __builtin_popcountll(m_list & lanes_below);
                 if (li < max_list) list[li] = (int)s;
             }
+        }
+    }
 }
 
 // per-pixel camera-distance multiplier sqrt(((u - cx) / fx)^2 + ((v - cy) / fy)^2 + 1) of the integration rule: a function of the
@@ -145,12 +172,138 @@ __global__ void tsdf_ray_mult_kernel(int H, int W, float fx, float fy, float cx,
     out[i] = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry)), 1.0f));
 }
 
+// a / d and b / d, correctly rounded (= __fdiv_rn) for operands and quotients in the normal range: the instruction sequence the
+// compiler emits for an IEEE fp32 division — reciprocal estimate, one Newton step on it, quotient, two residual corrections —
+// without its range scaling (v_div_scale / v_div_fixup: identity for normal operands), the reciprocal shared by both quotients.
+// The integration rule divides x fx and y fy by the same z for every voxel and source: 13 VALU instructions instead of 22.
+// Outside the normal range (z <= 0, |quotient| < 2^-126) the results are not used / vanish in the `+ cx + 0.5` that follows.
+__device__ __forceinline__ void div2_same_denominator(float a, float b, float d, float &qa, float &qb) {
+    float r = __builtin_amdgcn_rcpf(d);
+    r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+    qa = __fmul_rn(a, r);
+    qb = __fmul_rn(b, r);
+    qa = __builtin_fmaf(__builtin_fmaf(-d, qa, a), r, qa);
+    qb = __builtin_fmaf(__builtin_fmaf(-d, qb, b), r, qb);
+    qa = __builtin_fmaf(__builtin_fmaf(-d, qa, a), r, qa);
+    qb = __builtin_fmaf(__builtin_fmaf(-d, qb, b), r, qb);
+}
+
 // pass 2: one workgroup per listed brick (grid-stride over the device-side list), 256 lanes x 16 voxels.  A voxel is loaded
 // once, takes the update of every source of the step that opened its unit — in source order, in registers: the same value
-// sequence as one integrate call per source — and is stored once.  NS = sources handled (compile time: poses sit at fixed
-// kernel-argument offsets, the loops unroll); per voxel the projections of ALL sources come first and their depth /
-// multiplier gathers are issued together (clamped addresses, no branch in front of a load), then the updates are applied in
-// order: one memory round trip per voxel instead of one per source behind each other.
+// sequence as one integrate call per source — and is stored once.
+//
+// integrate_brick<NS, MASK, COLOR>: the body for a brick whose opening sources are the set bits of MASK (compile time; MASK = 0
+// stands for "read the run-time mask": the generic form for steps of more than three sources).  Per voxel the projections of
+// ALL of the brick's sources come first and their depth / multiplier gathers are issued together (clamped addresses, no branch
+// in front of a load: a branch makes the compiler wait for the loads issued before it), then the updates are applied in source
+// order: one memory round trip per voxel instead of one per source behind each other, and no arithmetic for a source that
+// did not open the unit (half of the (brick, source) pairs of a step: the sources open different units of the same region).
+template <int NS, int MASK, bool COLOR>
+__device__ __forceinline__ int integrate_brick(const SrcSet &S, int rt_mask, int W, float fx, float fy, float cx, float cy,
+                                               const TsdfGrid &g, float depth_trunc, float inv_trunc, float safe_w, float safe_h,
+                                               float px, float py, float oz, float *__restrict__ bt, float *__restrict__ bw,
+                                               float *__restrict__ bc, const float *__restrict__ ray_mult) {
+    // the part of the camera transform that does not depend on z: (w2c[r][0] * px + w2c[r][1] * py), per source and row
+    float cxy[NS][3];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) cxy[k][r] = __fadd_rn(__fmul_rn(S.w2c[k].m[r * 4 + 0], px), __fmul_rn(S.w2c[k].m[r * 4 + 1], py));
+    }
+    int near = 0;                 // this brick holds an observed voxel inside the truncation band (value < 1)
+    // the column of 16 voxels this lane owns (z = 0..15), fetched ZG voxels at a time, one group ahead of its use: a wavefront
+    // keeps 4 * ZG KB of brick data in flight (with one voxel ahead the kernel ran at the latency x occupancy limit, 2.9 TB/s)
+    constexpr int ZG = 4;
+    float t_nx[ZG], w_nx[ZG];
+#pragma unroll
+    for (int j = 0; j < ZG; ++j) {
+        t_nx[j] = bt[(j << 8) | threadIdx.x];
+        w_nx[j] = bw[(j << 8) | threadIdx.x];
+    }
+    for (int zg = 0; zg < UR; zg += ZG) {
+      float t_cur[ZG], w_cur[ZG];
+#pragma unroll
+      for (int j = 0; j < ZG; ++j) {
+          t_cur[j] = t_nx[j];
+          w_cur[j] = w_nx[j];
+      }
+      if (zg + ZG < UR) {
+#pragma unroll
+          for (int j = 0; j < ZG; ++j) {
+              t_nx[j] = bt[((zg + ZG + j) << 8) | threadIdx.x];
+              w_nx[j] = bw[((zg + ZG + j) << 8) | threadIdx.x];
+          }
+      }
+#pragma unroll
+      for (int j = 0; j < ZG; ++j) {
+        const int z = zg + j;
+        const int q = (z << 8) | threadIdx.x;
+        float t = t_cur[j], w = w_cur[j];
+        float c3[3] = {0.f, 0.f, 0.f};
+        if (COLOR) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) c3[ch] = bc[q * 3 + ch];
+        }
+        const float pz = __fadd_rn(oz, __fmul_rn(__fadd_rn((float)z, 0.5f), g.voxel));
+        // stage 1: project into the sources, gather depth + multiplier (+ colour)
+        float cz[NS], d[NS], mult[NS];
+        bool in[NS];
+        uint8_t rgb3[NS][3];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            if (MASK != 0 && !((MASK >> k) & 1)) continue;            // (compile time)
+            float c[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) c[r] = __fadd_rn(__fadd_rn(cxy[k][r], __fmul_rn(S.w2c[k].m[r * 4 + 2], pz)), S.w2c[k].m[r * 4 + 3]);
+            cz[k] = c[2];
+            float qx, qy;
+            div2_same_denominator(__fmul_rn(c[0], fx), __fmul_rn(c[1], fy), c[2], qx, qy);
+            const float uf = __fadd_rn(__fadd_rn(qx, cx), 0.5f);
+            const float vf = __fadd_rn(__fadd_rn(qy, cy), 0.5f);
+            in[k] = (MASK != 0 || ((rt_mask >> k) & 1)) && c[2] > 0.f && uf >= 0.0001f && uf < safe_w && vf >= 0.0001f && vf < safe_h;
+            const int pix = in[k] ? (int)vf * W + (int)uf : 0;
+            const int ks = MASK != 0 ? k : (k < S.n ? k : 0);
+            d[k] = S.depth[ks][pix];
+            mult[k] = ray_mult[pix];
+            if (COLOR) {
+                const uint8_t *rk = S.rgb[ks] + (int64_t)pix * 3;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) rgb3[k][ch] = rk[ch];
+            }
+        }
+        // stage 2: the updates, in source order
+        bool changed = false;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            if (MASK != 0 && !((MASK >> k) & 1)) continue;            // (compile time)
+            const float sdf = __fmul_rn(__fsub_rn(d[k], cz[k]), mult[k]);
+            if (in[k] && d[k] > 0.f && !(d[k] > depth_trunc) && sdf > -g.trunc) {
+                const float tv = fminf(1.0f, __fmul_rn(sdf, inv_trunc));
+                const float w1 = __fadd_rn(w, 1.0f);
+                t = __fdiv_rn(__fadd_rn(__fmul_rn(t, w), tv), w1);
+                if (COLOR) {
+                    // TSDFVolumeColorType::RGB8: color <- (color * w + rgb(u, v)) / (w + 1), per channel, 0..255
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) c3[ch] = __fdiv_rn(__fadd_rn(__fmul_rn(c3[ch], w), (float)rgb3[k][ch]), w1);
+                }
+                w = w1;
+                near |= t < 1.0f;
+                changed = true;
+            }
+        }
+        if (changed) {
+            bt[q] = t;
+            bw[q] = w;
+            if (COLOR) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) bc[q * 3 + ch] = c3[ch];
+            }
+        }
+      }
+    }
+    return near;
+}
+
 template <int NS, bool COLOR>
 __global__ __launch_bounds__(256) void tsdf_integrate_kernel(const SrcSet S, int H, int W, float fx, float fy,
                                                              float cx, float cy, TsdfGrid g,
@@ -177,87 +330,23 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(const SrcSet S, int
         const float px = __fadd_rn(__fmul_rn((float)ux, g.unit_len), __fmul_rn(__fadd_rn((float)x, 0.5f), g.voxel));
         const float py = __fadd_rn(__fmul_rn((float)uy, g.unit_len), __fmul_rn(__fadd_rn((float)y, 0.5f), g.voxel));
         const float oz = __fmul_rn((float)uz, g.unit_len);
-        // the part of the camera transform that does not depend on z: (w2c[r][0] * px + w2c[r][1] * py), per source and row
-        float cxy[NS][3];
-#pragma unroll
-        for (int k = 0; k < NS; ++k) {
-#pragma unroll
-            for (int r = 0; r < 3; ++r) cxy[k][r] = __fadd_rn(__fmul_rn(S.w2c[k].m[r * 4 + 0], px), __fmul_rn(S.w2c[k].m[r * 4 + 1], py));
+#define SGAM_BRICK(M) integrate_brick<NS, M, COLOR>(S, mask, W, fx, fy, cx, cy, g, depth_trunc, inv_trunc, safe_w, safe_h, px, py, oz, bt, bw, bc, ray_mult)
+        int near;
+        if (NS <= 3) {                 // one specialised body per set of opening sources (the switch is uniform over the workgroup)
+            switch (mask) {
+                case 1: near = SGAM_BRICK(1); break;
+                case 2: near = SGAM_BRICK(NS >= 2 ? 2 : 1); break;
+                case 3: near = SGAM_BRICK(NS >= 2 ? 3 : 1); break;
+                case 4: near = SGAM_BRICK(NS >= 3 ? 4 : 1); break;
+                case 5: near = SGAM_BRICK(NS >= 3 ? 5 : 1); break;
+                case 6: near = SGAM_BRICK(NS >= 3 ? 6 : 1); break;
+                case 7: near = SGAM_BRICK(NS >= 3 ? 7 : 1); break;
+                default: near = 0; break;
+            }
+        } else {
+            near = SGAM_BRICK(0);
         }
-        int near = 0;                 // this brick holds an observed voxel inside the truncation band (value < 1)
-        // the column of 16 voxels this lane owns (z = 0..15), its values fetched one step ahead of their use
-        float t_nx = bt[threadIdx.x], w_nx = bw[threadIdx.x];
-        for (int z = 0; z < UR; ++z) {
-            const int q = (z << 8) | threadIdx.x;
-            float t = t_nx, w = w_nx;
-            if (z + 1 < UR) {
-                t_nx = bt[q + 256];
-                w_nx = bw[q + 256];
-            }
-            float c3[3] = {0.f, 0.f, 0.f};
-            if (COLOR) {
-#pragma unroll
-                for (int ch = 0; ch < 3; ++ch) c3[ch] = bc[q * 3 + ch];
-            }
-            const float pz = __fadd_rn(oz, __fmul_rn(__fadd_rn((float)z, 0.5f), g.voxel));
-            // stage 1: project into every source, gather depth + multiplier (+ colour)
-            float cz[NS], d[NS], mult[NS];
-            bool in[NS];
-            int pix[NS];
-#pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                float c[3];
-#pragma unroll
-                for (int r = 0; r < 3; ++r) c[r] = __fadd_rn(__fadd_rn(cxy[k][r], __fmul_rn(S.w2c[k].m[r * 4 + 2], pz)), S.w2c[k].m[r * 4 + 3]);
-                cz[k] = c[2];
-                const float uf = __fadd_rn(__fadd_rn(__fdiv_rn(__fmul_rn(c[0], fx), c[2]), cx), 0.5f);
-                const float vf = __fadd_rn(__fadd_rn(__fdiv_rn(__fmul_rn(c[1], fy), c[2]), cy), 0.5f);
-                in[k] = ((mask >> k) & 1) && c[2] > 0.f && uf >= 0.0001f && uf < safe_w && vf >= 0.0001f && vf < safe_h;
-                pix[k] = in[k] ? (int)vf * W + (int)uf : 0;
-            }
-#pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                const float *__restrict__ dk = S.depth[k < S.n ? k : 0];
-                d[k] = dk[pix[k]];
-                mult[k] = ray_mult[pix[k]];
-            }
-            uint8_t rgb3[NS][3];
-            if (COLOR) {
-#pragma unroll
-                for (int k = 0; k < NS; ++k) {
-                    const uint8_t *rk = S.rgb[k < S.n ? k : 0] + (int64_t)pix[k] * 3;
-#pragma unroll
-                    for (int ch = 0; ch < 3; ++ch) rgb3[k][ch] = rk[ch];
-                }
-            }
-            // stage 2: the updates, in source order
-            bool changed = false;
-#pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                const float sdf = __fmul_rn(__fsub_rn(d[k], cz[k]), mult[k]);
-                if (in[k] && d[k] > 0.f && !(d[k] > depth_trunc) && sdf > -g.trunc) {
-                    const float tv = fminf(1.0f, __fmul_rn(sdf, inv_trunc));
-                    const float w1 = __fadd_rn(w, 1.0f);
-                    t = __fdiv_rn(__fadd_rn(__fmul_rn(t, w), tv), w1);
-                    if (COLOR) {
-                        // TSDFVolumeColorType::RGB8: color <- (color * w + rgb(u, v)) / (w + 1), per channel, 0..255
-#pragma unroll
-                        for (int ch = 0; ch < 3; ++ch) c3[ch] = __fdiv_rn(__fadd_rn(__fmul_rn(c3[ch], w), (float)rgb3[k][ch]), w1);
-                    }
-                    w = w1;
-                    near |= t < 1.0f;
-                    changed = true;
-                }
-            }
-            if (changed) {
-                bt[q] = t;
-                bw[q] = w;
-                if (COLOR) {
-#pragma unroll
-                    for (int ch = 0; ch < 3; ++ch) bc[q * 3 + ch] = c3[ch];
-                }
-            }
-        }
+#undef SGAM_BRICK
         // a weighted mean of values <= 1 that is < 1 once stays < 1: the flag is monotone, a plain store suffices
         if (__syncthreads_or(near) && threadIdx.x == 0) atomicOr(&table[s], NEAR_BIT);
     }
@@ -369,6 +458,12 @@ __global__ __launch_bounds__(64 * RS) void tsdf_raycast_kernel(int H, int W, flo
         dir[r] = __fadd_rn(__fadd_rn(__fmul_rn(c2w[r * 4 + 0], rx), __fmul_rn(c2w[r * 4 + 1], ry)), c2w[r * 4 + 2]);   // per unit z
     }
     const float inv_voxel = __fdiv_rn(1.0f, g.voxel);
+    // the march's own divisions are by quantities fixed per ray: reciprocals once, products per step (a step costs VALU
+    // issue slots — six IEEE divisions were a third of them)
+    const float inv_unit = __fdiv_rn(1.0f, g.unit_len);
+    float inv_dir[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) inv_dir[r] = __fdiv_rn(1.0f, dir[r]);           // (inf where dir == 0: not used there)
     const float fine = __fmul_rn(0.5f, g.voxel), eps = __fmul_rn(0.25f, g.voxel);
     const float seg_len = __fdiv_rn(__fsub_rn(z_far, z_near), (float)RS);
     const float t_begin = __fadd_rn(z_near, __fmul_rn((float)seg, seg_len));
@@ -386,7 +481,7 @@ __global__ __launch_bounds__(64 * RS) void tsdf_raycast_kernel(int H, int W, flo
         for (int r = 0; r < 3; ++r) p[r] = __fadd_rn(o[r], __fmul_rn(dir[r], t));
         float uf[3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) uf[r] = floorf(__fdiv_rn(p[r], g.unit_len));
+        for (int r = 0; r < 3; ++r) uf[r] = floorf(__fmul_rn(p[r], inv_unit));
         // ---- stage 1: every unit-table entry of the step
         unsigned s_here; bool in_box;
         TSDF_UNIT_INDEX((int)uf[0], (int)uf[1], (int)uf[2], s_here, in_box);
@@ -410,13 +505,17 @@ __global__ __launch_bounds__(64 * RS) void tsdf_raycast_kernel(int H, int W, flo
             e0 = k0 ? e0 : -1;
             e1 = e2 = e3 = e4 = e5 = e6 = e7 = e0;
         } else {
-            TSDF_UNIT_INDEX(ux1, uy0, uz0, s1, k1);
-            TSDF_UNIT_INDEX(ux0, uy1, uz0, s2, k2);
-            TSDF_UNIT_INDEX(ux1, uy1, uz0, s3, k3);
-            TSDF_UNIT_INDEX(ux0, uy0, uz1, s4, k4);
-            TSDF_UNIT_INDEX(ux1, uy0, uz1, s5, k5);
-            TSDF_UNIT_INDEX(ux0, uy1, uz1, s6, k6);
-            TSDF_UNIT_INDEX(ux1, uy1, uz1, s7, k7);
+            // the eight units of the cell's corners: per-axis pieces shared between the corners
+            const unsigned x0 = (unsigned)(ux0 - g.base[0]), x1 = (unsigned)(ux1 - g.base[0]);
+            const unsigned y0 = (unsigned)(uy0 - g.base[1]), y1 = (unsigned)(uy1 - g.base[1]);
+            const unsigned z0 = (unsigned)(uz0 - g.base[2]), z1 = (unsigned)(uz1 - g.base[2]);
+            const unsigned dx = (unsigned)g.dims[0], dy = (unsigned)g.dims[1], dz = (unsigned)g.dims[2];
+            const bool okx0 = x0 < dx, okx1 = x1 < dx, oky0 = y0 < dy, oky1 = y1 < dy, okz0 = z0 < dz, okz1 = z1 < dz;
+            const unsigned r00 = (z0 * dy + y0) * dx, r10 = (z0 * dy + y1) * dx, r01 = (z1 * dy + y0) * dx, r11 = (z1 * dy + y1) * dx;
+            const bool o00 = okz0 & oky0, o10 = okz0 & oky1, o01 = okz1 & oky0, o11 = okz1 & oky1;
+            k1 = o00 & okx1; k2 = o10 & okx0; k3 = o10 & okx1; k4 = o01 & okx0; k5 = o01 & okx1; k6 = o11 & okx0; k7 = o11 & okx1;
+            s1 = k1 ? r00 + x1 : 0u; s2 = k2 ? r10 + x0 : 0u; s3 = k3 ? r10 + x1 : 0u; s4 = k4 ? r01 + x0 : 0u;
+            s5 = k5 ? r01 + x1 : 0u; s6 = k6 ? r11 + x0 : 0u; s7 = k7 ? r11 + x1 : 0u;
             e_here = table[s_here];
             e0 = table[s0]; e1 = table[s1]; e2 = table[s2]; e3 = table[s3];
             e4 = table[s4]; e5 = table[s5]; e6 = table[s6]; e7 = table[s7];
@@ -431,8 +530,8 @@ __global__ __launch_bounds__(64 * RS) void tsdf_raycast_kernel(int H, int W, flo
         float coarse = z_far;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            if (dir[r] > 0.f) coarse = fminf(coarse, __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(uf[r], 1.0f), g.unit_len), p[r]), dir[r]));
-            else if (dir[r] < 0.f) coarse = fminf(coarse, __fdiv_rn(__fsub_rn(__fmul_rn(uf[r], g.unit_len), p[r]), dir[r]));
+            if (dir[r] > 0.f) coarse = fminf(coarse, __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(uf[r], 1.0f), g.unit_len), p[r]), inv_dir[r]));
+            else if (dir[r] < 0.f) coarse = fminf(coarse, __fmul_rn(__fsub_rn(__fmul_rn(uf[r], g.unit_len), p[r]), inv_dir[r]));
         }
         coarse = __fadd_rn(fmaxf(coarse, 0.f), eps);
         // ---- stage 2: the eight corner values (when some lane of the wavefront marches a band brick)
