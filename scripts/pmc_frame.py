@@ -46,7 +46,7 @@ def load(src, group):
     return agg
 
 
-def main(src, out, frames, collected_at=None):
+def main(src, out, frames, collected_at=None, lib_digest=None):
     sq, fe, wr = load(src, "sq"), load(src, "fetch"), load(src, "write")
     rows = {}
     for k, c in sq.items():
@@ -74,6 +74,7 @@ def main(src, out, frames, collected_at=None):
                       "write (WRITE_SIZE)",
            "frames_in_run": frames,
            "collected_at": collected_at,
+           "lib_digest": lib_digest,          # sgam_build_digest() of that build: bench.py flags the counters stale when it differs
            "notes": "per-launch averages over ALL launches of the kernel in the run (in-frame shapes mixed as the frame mixes them); "
                     "hbm_traffic = 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE; mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / "
                     "(1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); profiled passes clock ~3-5 % lower than un-profiled runs",
@@ -86,4 +87,4 @@ def main(src, out, frames, collected_at=None):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4] if len(sys.argv) > 4 else None)
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4] if len(sys.argv) > 4 else None, sys.argv[5] if len(sys.argv) > 5 else None)

@@ -3,7 +3,7 @@
 # counter group (SQ; FETCH_SIZE; WRITE_SIZE — the TCC slots do not hold both), kernel trace only; aggregated per kernel
 # name over that kernel's in-frame launches into gpurun_out/pmc_frame_<mode>.json by scripts/pmc_frame.py.
 #   MODE=f32 (split fp32, default) | fp16 | bf16      STEPS=frames per pass (default 6)
-#   SGAM_COMMIT=<git rev-parse --short HEAD of the tree the box received> -> "collected_at" of the JSON (the box has no .git)
+#   "collected_at" / "lib_digest" of the JSON = the build stamp compiled into the library that ran (sgam_build_commit / sgam_build_digest)
 export TMPDIR=/tmp
 MODE=${MODE:-f32}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmcf_$MODE
@@ -14,5 +14,6 @@ run() { name=$1; shift
 run sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE
 run fetch FETCH_SIZE
 run write WRITE_SIZE
-python3 $GRAFT_REPO_ROOT/scripts/pmc_frame.py $OUT $GRAFT_REPO_ROOT/gpurun_out/pmc_frame_$MODE.json $((${STEPS:-6} + 2)) "library @ ${SGAM_COMMIT:-unknown}"
+STAMP=$(cd $GRAFT_REPO_ROOT && python3 -c "from sgam_neurips22_amd import _lib; l = _lib.load(); print(l.sgam_build_commit().decode(), l.sgam_build_digest().decode())" 2>/dev/null | tail -1)
+python3 $GRAFT_REPO_ROOT/scripts/pmc_frame.py $OUT $GRAFT_REPO_ROOT/gpurun_out/pmc_frame_$MODE.json $((${STEPS:-6} + 2)) "library @ ${STAMP% *}" "${STAMP#* }"
 find $OUT -name "*.csv" -size +8M -delete

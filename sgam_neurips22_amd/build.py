@@ -50,7 +50,9 @@ SOURCES = {
     "gemm_gn_f32x.hip": [],
     "train.hip": [],
     "build_info.hip": [],       # flags = the build stamp, filled in by build()
-    "tsdf.hip": ["-ffp-contract=off"] + (["-DSGAM_TSDF_DEBUG_STEPS"] if os.environ.get("SGAM_TSDF_DEBUG_STEPS") else []),
+    "tsdf.hip": ["-ffp-contract=off", f"-DSGAM_TSDF_ZG={os.environ.get('SGAM_TSDF_ZG', '2')}",
+                 f"-DSGAM_TSDF_LB={os.environ.get('SGAM_TSDF_LB', '8')}"] +
+                (["-DSGAM_TSDF_DEBUG_STEPS"] if os.environ.get("SGAM_TSDF_DEBUG_STEPS") else []),
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 if os.environ.get("SGAM_STATS_R"):          # replicas of a GroupNorm accumulator record (csrc/sgam_common.h; ops.STATS_R must match)

@@ -29,6 +29,13 @@
 // native square root in this toolchain).
 #include "sgam_common.h"
 
+#ifndef SGAM_TSDF_ZG
+#define SGAM_TSDF_ZG 2        // voxels of a column fetched per group, one group ahead (integrate kernel)
+#endif
+#ifndef SGAM_TSDF_LB
+#define SGAM_TSDF_LB 8        // minimum waves per SIMD the integrate kernel is compiled for (register budget)
+#endif
+
 namespace {
 
 constexpr int UR = 16;                 // voxels per unit edge (Open3D volume_unit_resolution)
@@ -76,7 +83,11 @@ __global__ void tsdf_touch_kernel(const SrcSet S, int H, int W, float fx, float 
     const float *__restrict__ depth = S.depth[k];
     const float *c2w = S.c2w[k].m;
     const int sw = (W + stride - 1) / stride, sh = (H + stride - 1) / stride;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // eight lanes per depth sample, one per corner of the sample's box of units: lane c takes, per axis, the low unit (bit
+    // clear) or the units above it (bit set: none when the box is one unit thick there) — almost always at most one unit per
+    // lane, so the chain of atomic round trips below is walked once instead of once per unit of the box
+    const int i8 = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = i8 >> 3, corner = i8 & 7;
     const bool in_grid = i < sw * sh;
     const int v = in_grid ? (i / sw) * stride : 0, u = in_grid ? (i % sw) * stride : 0;
     const float d = depth[v * W + u];
@@ -100,8 +111,14 @@ __global__ void tsdf_touch_kernel(const SrcSet S, int H, int W, float fx, float 
     // The units are visited in lock step by the wavefront (trip counts padded to the wavefront's maximum) so that the three
     // counters — list length, brick pool, outside-the-box diagnostic — take ONE atomic per wavefront and visit instead of
     // one per lane: every lane of every workgroup adding to the same word was the whole cost of this kernel.
-    const int nx = live ? hi[0] - lo[0] + 1 : 1, ny = live ? hi[1] - lo[1] + 1 : 1, nz = live ? hi[2] - lo[2] + 1 : 1;
-    const int trips = live ? nx * ny * nz : 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        if ((corner >> r) & 1) lo[r] = lo[r] + 1;     // the units above the low one (an empty range when hi == the old lo)
+        else hi[r] = lo[r];                           // the low unit alone
+    }
+    const bool some = live && hi[0] >= lo[0] && hi[1] >= lo[1] && hi[2] >= lo[2];
+    const int nx = some ? hi[0] - lo[0] + 1 : 1, ny = some ? hi[1] - lo[1] + 1 : 1, nz = some ? hi[2] - lo[2] + 1 : 1;
+    const int trips = some ? nx * ny * nz : 0;
     int max_trips = trips;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) max_trips = max(max_trips, __shfl_xor(max_trips, o, 64));
@@ -213,7 +230,7 @@ __device__ __forceinline__ int integrate_brick(const SrcSet &S, int rt_mask, int
     int near = 0;                 // this brick holds an observed voxel inside the truncation band (value < 1)
     // the column of 16 voxels this lane owns (z = 0..15), fetched ZG voxels at a time, one group ahead of its use: a wavefront
     // keeps 4 * ZG KB of brick data in flight (with one voxel ahead the kernel ran at the latency x occupancy limit, 2.9 TB/s)
-    constexpr int ZG = 4;
+    constexpr int ZG = SGAM_TSDF_ZG;
     float t_nx[ZG], w_nx[ZG];
 #pragma unroll
     for (int j = 0; j < ZG; ++j) {
@@ -305,7 +322,7 @@ __device__ __forceinline__ int integrate_brick(const SrcSet &S, int rt_mask, int
 }
 
 template <int NS, bool COLOR>
-__global__ __launch_bounds__(256) void tsdf_integrate_kernel(const SrcSet S, int H, int W, float fx, float fy,
+__global__ __launch_bounds__(256, SGAM_TSDF_LB) void tsdf_integrate_kernel(const SrcSet S, int H, int W, float fx, float fy,
                                                              float cx, float cy, TsdfGrid g,
                                                              float depth_trunc, int *__restrict__ table, const int *__restrict__ stamp,
                                                              const int *__restrict__ counters,
@@ -751,7 +768,7 @@ extern "C" int sgam_tsdf_integrate_srcs_f32(const sgam_tsdf_grid *grid, const sg
     if (e != hipSuccess) return (int)e;
     const int stride = 4;                                                      // Open3D depth_sampling_stride
     const int ns = ((W + stride - 1) / stride) * ((H + stride - 1) / stride);
-    SGAM_KLAUNCH(tsdf_touch_kernel, dim3(sgam_cdiv(ns, 256), n_src), dim3(256), 0, s, S, H, W, fx, fy, cx, cy,
+    SGAM_KLAUNCH(tsdf_touch_kernel, dim3(sgam_cdiv((int64_t)ns * 8, 256), n_src), dim3(256), 0, s, S, H, W, fx, fy, cx, cy,
                        g, depth_trunc, stride, unit_table, unit_stamp, step_id, counters, max_bricks, brick_list,
                        max_list);
     SGAM_LAUNCH_CHECK();

@@ -24,7 +24,7 @@ def _roofline(name):
             "share_of_kernel_time": 0.2391, "is_top_kernel_by_time": True, "mfma_busy_frac": 0.4451,
             "counters_source": "traffic + mfma_busy_frac: NOT measured in this run — committed rocprofv3 --pmc passes over the same eager "
                                "frame, profiles/r04_pmc_frame_f32.json (libsgam_hip @ 0123456789ab)",
-            "counters_commit": "library @ 0123456789ab",
+            "counters_commit": "0123456789ab", "counters_stale": False,
             "top5": [_row("conv3x3_f32x_halo2_kernel<64,128,true,false,true>") for _ in range(5)],
             "kernel_time_ms_per_frame": 2.3978, "kernels_per_frame": 212, "bracket_overhead_us": 4.41,
             "frame": {"gflop": 486.4, "ms": 2.923, "tflops": 166.4, "frac": 0.1997}, "method": "x" * 300}
@@ -60,13 +60,19 @@ def full_record():
         "roofline_warp": {"bound": "hbm", "unit": "GB/s", "peak": 8000.0, "achievable": 6300.0, "bytes_model": "w" * 100, "cases": warp_cases,
                           "inverse_warp": warp_cases},
         "f32_mfma_mode": {"value": 150.012, "unit": "frames/s", "ms_per_step": 6.67, "note": "n" * 120}, "numa_node": 0,
-        "f32x_range_flag": 0, "rgbd_integration_branch": {"value": 237.1, "unit": "frames/s", "ms_per_step": 4.2, "tsdf_bricks": 15000, "note": "n" * 300},
+        "f32x_range_flag": 0, "rgbd_integration_branch": {"value": 307.1, "unit": "frames/s", "ms_per_step": 3.26, "note": "n" * 300, **{
+            tag: {"value": 307.1, "unit": "frames/s", "ms_per_step": 3.256, "tsdf_bricks_allocated": 27474, "bricks_touched_per_step": 11586,
+                  "sources": 3, "scene": "s" * 200,
+                  "roofline": {"bound": "hbm", "unit": "GB/s", "peak": 8000.0, "algorithmic_bytes": 383844352, "bytes_model": "b" * 80,
+                               "us": 474.6, "achieved": 808.8, "frac": 0.1011,
+                               "kernels_us": {"tsdf_touch_kernel": 24.1, "tsdf_integrate_kernel": 254.1, "tsdf_raycast_kernel": 190.9,
+                                              "inverse_warp_kernel": 5.4, "depth_normalise_kernel": 2.1}}} for tag in ("noise", "plane")}},
         "concurrent_scenes": {"scenes_on_this_gpu": 4, "value": 447.0, "unit": "frames/s (aggregate)", "ms_per_round": 8.9, "note": "n" * 200},
         "lockstep_scenes": lock, "throughput_mode": tm,
         "config5_512sq_batch4": {"workload": "w" * 80, "note": "n" * 100, "f32": {"ms_per_batch": 34.2, "candidates_per_s": 117.0},
                                  "fp16": {"ms_per_batch": 17.4, "candidates_per_s": 229.9}},
         "training_step": {"ms_per_update": 37.1, "updates_per_s": 26.9, "batch": 1, "rec_loss_first": 0.5, "rec_loss_after_4": 0.49, "note": "n" * 300},
-        "frame_checksums": [123456789.0], "head": "0123456789ab", "extra": "bench_extra.json",
+        "frame_checksums": [123456789.0], "head": "0123456789ab", "lib_digest": "ba6838f22271", "extra": "bench_extra.json",
     }
 
 
@@ -91,6 +97,11 @@ def test_bench_line_is_small_and_round_trips():
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(c)
     assert line["roofline_warp"]["cases"]["large_512_B16_N3"]["achieved"] == 2208.4
     assert line["secondary"]["lockstep_bf16_S8_fps"] == 1341.812 and line["secondary"]["bf16_halo128_frac"] == 0.2659
+    # the reference's default CLI branch beside `value`, with its HBM roofline (both scenes)
+    assert line["value_rgbd_branch"] == 307.1 and line["secondary"]["rgbd_branch_plane_fps"] == 307.1
+    assert line["roofline_rgbd"]["noise"] == 0.1011 and line["roofline_rgbd"]["bound"] == "hbm"
+    # the build stamp travels in the library (no git on the driver's box); stale counters are flagged
+    assert line["head"] == "0123456789ab" and line["lib_digest"] == "ba6838f22271" and r["counters_stale"] is False
 
 
 def test_bench_line_without_secondary_legs():
