@@ -129,31 +129,39 @@ __global__ void tsdf_touch_kernel(const SrcSet S, int H, int W, float fx, float 
         const bool outside = act && s < 0;
         const unsigned long long m_out = __builtin_amdgcn_ballot_w64(outside);
         if (m_out && (threadIdx.x & 63) == __builtin_ctzll(m_out)) atomicAdd(&counters[2], __builtin_popcountll(m_out));   // diagnostic
-        bool first = false;
-        if (s >= 0) {
-            int old = __hip_atomic_load(&stamp[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (;;) {
-                const bool same_step = (old & ~0xff) == tag;
-                const int want = same_step ? (old | bit) : (tag | bit);
-                if (want == old) break;                                       // this source already marked the unit
-                const int prev = atomicCAS(&stamp[s], old, want);
-                if (prev == old) {
-                    first = !same_step;
-                    break;
-                }
-                old = prev;
+        // one lane per DISTINCT unit of the wavefront's visit talks to memory (neighbouring samples open the same unit: up to
+        // 64 same-address atomics otherwise).  Election is register work: peel the lowest undecided lane, claim every lane
+        // that holds the same slot.
+        bool leader = false;
+        {
+            unsigned long long todo = __builtin_amdgcn_ballot_w64(s >= 0);
+            while (todo) {
+                const int l = __builtin_ctzll(todo);
+                const int sl = __shfl((int)s, l, 64);
+                const unsigned long long same = __builtin_amdgcn_ballot_w64(s >= 0 && (int)s == sl);
+                if ((threadIdx.x & 63) == l) leader = true;
+                todo &= ~same;
             }
         }
-        // `first`: this lane moved the word to the step's tag — it alone lists the unit and, if it never had one, allocates
-        // its brick (no CAS loop needed)
-        int brick = first ? table[s] : 0;          // (the NEAR bit, if set, rides along: entries are only ever extended)
+        // the stamp word moves to this step's tag by a returning atomicMax (tags grow with the step: exactly one lane on the
+        // whole device sees the older word — `first`), the source's bit follows by a fire-and-forget atomicOr behind it
+        // (same lane, same address: in order, so the bit lands in a word that already carries the tag); the table entry is
+        // requested beside the atomic, not after it
+        bool first = false;
+        int brick = 0;
+        if (leader) {
+            const int prev = atomicMax(&stamp[s], tag);
+            brick = table[s];                  // (the NEAR bit, if set, rides along: entries are only ever extended)
+            atomicOr(&stamp[s], bit);
+            first = (prev & ~0xff) != tag;
+        }
         const bool need = first && brick < 0;
         const unsigned long long m_need = __builtin_amdgcn_ballot_w64(need);
         if (m_need) {
             int base = 0;
-            const int leader = __builtin_ctzll(m_need);
-            if ((threadIdx.x & 63) == leader) base = atomicAdd(&counters[0], __builtin_popcountll(m_need));
-            base = __shfl(base, leader, 64);
+            const int l0 = __builtin_ctzll(m_need);
+            if ((threadIdx.x & 63) == l0) base = atomicAdd(&counters[0], __builtin_popcountll(m_need));
+            base = __shfl(base, l0, 64);
             if (need) {
                 brick = base + __builtin_popcountll(m_need & lanes_below);
                 if (brick >= max_bricks) {
@@ -167,9 +175,9 @@ __global__ void tsdf_touch_kernel(const SrcSet S, int H, int W, float fx, float 
         const unsigned long long m_list = __builtin_amdgcn_ballot_w64(first);
         if (m_list) {
             int base = 0;
-            const int leader = __builtin_ctzll(m_list);
-            if ((threadIdx.x & 63) == leader) base = atomicAdd(&counters[1], __builtin_popcountll(m_list));
-            base = __shfl(base, leader, 64);
+            const int l1 = __builtin_ctzll(m_list);
+            if ((threadIdx.x & 63) == l1) base = atomicAdd(&counters[1], __builtin_popcountll(m_list));
+            base = __shfl(base, l1, 64);
             if (first) {
                 const int li = base + __builtin_popcountll(m_list & lanes_below);
                 if (li < max_list) list[li] = (int)s;
