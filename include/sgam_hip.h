@@ -82,22 +82,6 @@ typedef struct sgam_conv_desc {
     /* optional plan override (autotuner, sgam_neurips22_amd/tune.py); 0 = built-in heuristic.
      * (plan_bm, plan_bn) in {(128,128), (64,128), (64,64)}; plan_ksplit >= 1. */
     int32_t plan_bm, plan_bn, plan_ksplit;
-    /* optional (split-fp32 family only; the 16-bit kernels ignore it): `arrive_count` int32 arrival counters in device memory, ZERO on entry; a
-     * split-K launch whose tiles fit them sums the partial tiles inside the convolution kernel (the last split of a tile to
-     * arrive does it, in the fixed slab order of the combine kernels) instead of launching a combine, and leaves the
-     * counters zero again.  One launch at a time may use a given counter array (launches on ONE stream qualify).
-     * NULL / 0: partial tiles + combine launch.  sgam_conv2d_f32x_fixup says which it will be;
-     * the *_stats_chunks queries follow it (one statistics chunk per output tile). */
-    int32_t arrive_count;
-    /* 1: the statistics a launch leaves for the next GroupNorm (the `gn_partial` argument of the *_stats / *_gn / *_gnp entry
-     * points) are [B][16][32][4] int64 ACCUMULATORS instead of per-chunk records: {sum hi, sum lo, sumsq hi, sumsq lo} in 2^-40
-     * fixed point (hi in units of 2^-8, lo = 32 fraction bits), added with 64-bit atomics — integer sums do not depend on
-     * the order the workgroups arrive in, so no fold launch is needed between producer and consumer and results stay
-     * run-to-run identical.  ZERO before the launch.  Consumers take them through the *_gnp entry points with
-     * chunks_in = 0 (every GroupNorm-fusing kernel), sgam_groupnorm_stats_from_partials_f32 / *_from_partials_* with nchunk = 0
-     * (32 groups only: the record is laid out per 32 groups). */
-    int32_t stats_acc;
-    int32_t *arrive;
 } sgam_conv_desc;
 
 int64_t sgam_conv2d_workspace_bytes(const sgam_conv_desc *d);
@@ -140,8 +124,6 @@ int sgam_pack_conv_weight(const float *w_oihw, float *w_packed, int32_t Cout, in
  * side does exactly that (VQModel.forward, InfiniteSceneGeneration.scene_expansion).  NULL (default) disables the
  * reporting.  This pointer is the library's only mutable global: one flag per process (= per GPU). */
 int sgam_f32x_set_range_flag(int32_t *device_flag);
-/* 1 when a launch of this descriptor (with its `arrive` counters) combines its split-K partial tiles inside the kernel */
-int32_t sgam_conv2d_f32x_fixup(const sgam_conv_desc *d);
 int64_t sgam_conv2d_f32x_workspace_bytes(const sgam_conv_desc *d);
 int sgam_conv2d_f32x_plan(const sgam_conv_desc *d, int32_t *bm, int32_t *bn, int32_t *ksplit);
 int sgam_conv2d_nhwc_f32x(const sgam_conv_desc *d, const float *x, float a_scale, const void *w_planes,
@@ -338,11 +320,10 @@ int sgam_attention_f32x_batched(const float *q, const float *k, const float *v, 
  * attention output is written and read back, one launch fewer.  w_planes / w_scale: proj_out's [C][C] weight as sgam_split_rows_f32x
  * returns it; bias [C] or NULL; residual [B n][ldr] or NULL; out [B n][ldc]; gn_partial (optional): [B][n / 32][32][2] fp64 {sum, sumsq}
  * of `out` per (32-row tile, group of C / 32 channels) for the GroupNorm that follows (fold with sgam_groupnorm_stats_from_partials_f32,
- * nchunk = n / 32) — or, with gn_acc = 1, the zeroed [B][16][32][4] int64 accumulator record of sgam_conv_desc.stats_acc.  Same shape
- * limits and workspace as sgam_attention_f32x_batched. */
+ * nchunk = n / 32).  Same shape limits and workspace as sgam_attention_f32x_batched. */
 int sgam_attention_proj_f32x_batched(const float *q, const float *k, const float *v, int32_t ld, int32_t n, int32_t C, int32_t B,
                                      float scale, const void *w_planes, float w_scale, const float *bias, const float *residual,
-                                     int32_t ldr, float *out, int32_t ldc, double *gn_partial, int32_t gn_acc, void *workspace,
+                                     int32_t ldr, float *out, int32_t ldc, double *gn_partial, void *workspace,
                                      int64_t workspace_bytes, void *stream);
 int64_t sgam_attention_h16_batched_workspace_bytes(int32_t n, int32_t C, int32_t B);
 int sgam_attention_h16_batched(const void *q, const void *k, const void *v, int32_t ht, int32_t ld, int32_t n, int32_t C,
@@ -356,8 +337,7 @@ int sgam_attention_h16_batched(const void *q, const void *k, const void *v, int3
  * projection writes q row-major and K / V^T directly in the fused attention's MFMA-fragment order: the stand-alone normalise pass, the
  * generic 1 x 1 GEMM and the fragment-split launch disappear.
  *   x          [B n][ldx] 16-bit block input (ldx % 8 == 0), C == 256, n % 256 == 0 (sgam_attention_h16_batched's shapes)
- *   gn_partial the chunk statistics x's producer left: [B][nchunk][32][2] fp64 {sum, sumsq}, or (nchunk == 0) its [B][16][32][4]
- *              int64 accumulator record; gamma, beta [C] of AttnBlock.norm; eps
+ *   gn_partial the chunk statistics x's producer left: [B][nchunk][32][2] fp64 {sum, sumsq}; gamma, beta [C] of AttnBlock.norm; eps
  *   w_frag     sgam_pack_qkv_weight_h16 of the stacked [3 C][C] fp32 weight (rows: q.weight, k.weight, v.weight): 3 C C 2 bytes
  *   bias       [3 C] fp32 (q.bias | k.bias | v.bias), 16-byte aligned
  *   out        [B n][ldo] 16-bit attention output (the operand of proj_out)
@@ -370,20 +350,13 @@ int sgam_attention_h16_batched(const void *q, const void *k, const void *v, int3
  * the arithmetic of sgam_gemm_gn_f32x + the split launch it replaces, equal to fp32 round-off), the one-pass attention, and sgam_attention_proj_f32x_batched's merge +
  * proj_out + residual (= x).  mean_rstd [B][32][2] (sgam_groupnorm_stats_from_partials_f32); wqkv_planes / wqkv_scale: sgam_split_rows_f32x of
  * the stacked [3 C][C] weight with the rows of every 32-row tile permuted so that row 8 j + 4 h + i holds channel 16 h + 4 j + i; bqkv [3 C] in
- * natural order; wp_planes / wp_scale / bp: proj_out as for sgam_attention_proj_f32x_batched; gn_partial / gn_acc as there.  C == 256,
+ * natural order; wp_planes / wp_scale / bp: proj_out as for sgam_attention_proj_f32x_batched; gn_partial as there.  C == 256,
  * n % 256 == 0, scale a power of two; workspace: sgam_attn_block_f32x_workspace_bytes(n, C, B). */
 int64_t sgam_attn_block_f32x_workspace_bytes(int32_t n, int32_t C, int32_t B);
 int sgam_attn_block_f32x(const float *x, int32_t ldx, const float *mean_rstd, const float *gamma, const float *beta, const void *wqkv_planes,
                          float wqkv_scale, const float *bqkv, int32_t n, int32_t C, int32_t B, float scale, const void *wp_planes,
-                         float wp_scale, const float *bp, float *out, int32_t ldc, double *gn_partial, int32_t gn_acc, void *workspace,
+                         float wp_scale, const float *bp, float *out, int32_t ldc, double *gn_partial, void *workspace,
                          int64_t workspace_bytes, void *stream);
-/* ... with the statistics of x still as its producer's chunk records (gn_partial_in [B][nchunk_in][32][2] fp64 {sum, sumsq}, 1 <= nchunk_in <= 128,
- * eps): every workgroup of the front end folds them itself — no statistics launch in front of the block.  (sgam_attn_block_h16 does the same
- * with its `gn_partial` when nchunk <= 128 and the environment says SGAM_ATTN_FOLD=1 — opt-in: measured no faster than the table launch.) */
-int sgam_attn_block_gnp_f32x(const float *x, int32_t ldx, const double *gn_partial_in, int32_t nchunk_in, float eps, const float *gamma,
-                             const float *beta, const void *wqkv_planes, float wqkv_scale, const float *bqkv, int32_t n, int32_t C, int32_t B,
-                             float scale, const void *wp_planes, float wp_scale, const float *bp, float *out, int32_t ldc, double *gn_partial,
-                             int32_t gn_acc, void *workspace, int64_t workspace_bytes, void *stream);
 /* (ABI v9) The attention of the SMALL AttnBlocks in one launch — the 16 x 16 mid blocks (n = 256 tokens per image, C = 512; n = 128 too):
  * model.py:176-187, `w_ = bmm(q, k) * c**-0.5; w_ = softmax(w_, dim=2); h_ = bmm(v, w_)` — what otherwise runs as v^T transpose, operand
  * splits, the q k^T GEMM (+ split-K combine), sgam_softmax_rows_f32 and the P v GEMM: seven launches.  A workgroup holds a query tile's whole
@@ -566,10 +539,6 @@ int sgam_gemm_panel_f32x(const float *x, int32_t lda, const float *mean_rstd, co
 int sgam_gemm_gn_f32x(const float *x, int32_t lda, const float *mean_rstd, const float *gamma, const float *beta, const void *w_planes,
                       float w_scale, const float *bias, float *out, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t HW,
                       void *stream);
-/* ... with the statistics of x as the [B][16][32][4] int64 accumulators its producer left (sgam_conv_desc.stats_acc): no fold launch */
-int sgam_gemm_gn_acc_f32x(const float *x, int32_t lda, const int64_t *gn_acc, float eps, const float *gamma, const float *beta,
-                          const void *w_planes, float w_scale, const float *bias, float *out, int32_t ldc, int32_t M, int32_t N,
-                          int32_t K, int32_t HW, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * f1 — TSDF fusion of the generated RGB-D frames + depth render at the target pose.  Replaces

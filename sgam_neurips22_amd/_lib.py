@@ -14,7 +14,7 @@ class ConvDesc(ctypes.Structure):
     """mirror of struct sgam_conv_desc"""
     _fields_ = [(n, c_i32) for n in (
         "B", "Hi", "Wi", "Cin", "Ho", "Wo", "N", "KH", "KW", "stride", "pad_t", "pad_l", "upsample2x",
-        "lda", "ldb", "ldc", "ldr", "n_valid", "bias_per_row", "plan_bm", "plan_bn", "plan_ksplit", "arrive_count", "stats_acc")] + [("arrive", c_vp)]
+        "lda", "ldb", "ldc", "ldr", "n_valid", "bias_per_row", "plan_bm", "plan_bn", "plan_ksplit")]
 
 
 class TsdfGrid(ctypes.Structure):
@@ -49,7 +49,6 @@ PROTOTYPES = {
                                         c_vp]),
     "sgam_pack_conv_weight": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "sgam_f32x_set_range_flag": (c_i32, [c_vp]),
-    "sgam_conv2d_f32x_fixup": (c_i32, [ctypes.POINTER(ConvDesc)]),
     "sgam_conv2d_f32x_workspace_bytes": (c_i64, [ctypes.POINTER(ConvDesc)]),
     "sgam_conv2d_f32x_plan": (c_i32, [ctypes.POINTER(ConvDesc), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32),
                                       ctypes.POINTER(c_i32)]),
@@ -79,8 +78,6 @@ PROTOTYPES = {
     "sgam_gemm_gn_f32x_fits": (c_i32, [c_i32, c_i32, c_i32, c_i32]),
     "sgam_gemm_panel_f32x": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32,
                                      c_i32, c_vp]),
-    "sgam_gemm_gn_acc_f32x": (c_i32, [c_vp, c_i32, c_vp, c_f32, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32,
-                                      c_vp]),
     "sgam_gemm_gn_f32x": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "sgam_im2col_t_f32": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_i32, c_i64, c_vp]),
     "sgam_col2im_gather_f32": (c_i32, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_i32, c_vp]),
@@ -154,17 +151,15 @@ PROTOTYPES = {
     "sgam_attention_f32x_batched_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
     "sgam_attention_f32x_batched": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_i32, c_vp, c_i64, c_vp]),
     "sgam_attention_proj_f32x_batched": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_f32, c_vp, c_vp, c_i32, c_vp,
-                                                 c_i32, c_vp, c_i32, c_vp, c_i64, c_vp]),
+                                                 c_i32, c_vp, c_vp, c_i64, c_vp]),
     "sgam_attention_h16_batched_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
     "sgam_attention_h16_batched": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_i32, c_vp, c_i64, c_vp]),
     "sgam_attn_block_f32x_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
     "sgam_attn_block_f32x": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_f32, c_vp, c_vp, c_i32,
-                                     c_vp, c_i32, c_vp, c_i64, c_vp]),
+                                     c_vp, c_vp, c_i64, c_vp]),
     "sgam_attention_small_f32x_fits": (c_i32, [c_i32, c_i32, c_i32]),
     "sgam_attention_small_f32x": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_i32, c_vp]),
     "sgam_attention_small_h16": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_i32, c_vp]),
-    "sgam_attn_block_gnp_f32x": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_f32, c_vp, c_vp, c_vp, c_f32, c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_f32, c_vp,
-                                         c_vp, c_i32, c_vp, c_i32, c_vp, c_i64, c_vp]),
     "sgam_groupnorm_table_from_partials": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp]),
     "sgam_pack_qkv_weight_h16": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
     "sgam_pack_weight_tp_h16": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),

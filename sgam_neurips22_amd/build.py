@@ -28,8 +28,7 @@ SOURCES = {
                       f"-DSGAM_XPEEL={os.environ.get('SGAM_XPEEL', '1')}",
                       f"-DSGAM_XLB64={os.environ.get('SGAM_XLB64', '2')}",
                       f"-DSGAM_XNBR64={os.environ.get('SGAM_XNBR64', '6')}",
-                      f"-DSGAM_XRWARM={os.environ.get('SGAM_XRWARM', '0')}",
-                      f"-DSGAM_XFIX_LF={os.environ.get('SGAM_XFIX_LF', '32')}"],
+                      f"-DSGAM_XRWARM={os.environ.get('SGAM_XRWARM', '0')}"],
     "h16_halo.hip": [f"-DSGAM_HABLATE={os.environ.get('SGAM_HABLATE', '0')}",
                      f"-DSGAM_HDIRECT={os.environ.get('SGAM_HDIRECT', '1')}",
                      f"-DSGAM_HWGM={os.environ.get('SGAM_HWGM', '1')}",
@@ -55,8 +54,6 @@ SOURCES = {
                 (["-DSGAM_TSDF_DEBUG_STEPS"] if os.environ.get("SGAM_TSDF_DEBUG_STEPS") else []),
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
-if os.environ.get("SGAM_STATS_R"):          # replicas of a GroupNorm accumulator record (csrc/sgam_common.h; ops.STATS_R must match)
-    COMMON.append(f"-DSGAM_STATS_R={int(os.environ['SGAM_STATS_R'])}")
 
 
 def _hipcc():

@@ -440,8 +440,8 @@ struct CombProjParams {
     const unsigned short *w;        // proj_out weights, fragment-ordered hi / lo planes [AD / 32][AD / 32][256 pieces][8 halfs]
     const float *bias, *res;        // [AD]; residual [n][ldr] (the block's input x) or NULL
     float *out;                     // [n][ldc]
-    double *gn_partial;             // optional [n / 32][32][2]: {sum, sumsq} of the output per (32-row tile, group of 8 channels) ...
-    int gn_acc, n_img;              // ... or (gn_acc) the [B][16][32][4] int64 accumulator record of sgam_common.h; tokens per image
+    double *gn_partial;             // optional [n / 32][32][2]: {sum, sumsq} of the output per (32-row tile, group of 8 channels)
+    int n_img;                      // tokens per image
     int32_t *range_flag;
     int n, ns, ldr, ldc;
     float inv_w_scale;
@@ -580,51 +580,11 @@ __global__ __launch_bounds__(256) void attn_combine_proj_f32x_kernel(const CombP
             ds += __shfl_xor(ds, 32, 64);
             dss += __shfl_xor(dss, 32, 64);
             if (lh == 0 && (lr % CPO) == 0) {
-                if (p.gn_acc) {
-                    sgam_stats_acc_add(reinterpret_cast<long long *>(p.gn_partial), m0 / p.n_img, blockIdx.x, nn / CPO, ds, dss);
-                } else {
-                    double *o = p.gn_partial + ((int64_t)qt * 32 + nn / CPO) * 2;
-                    o[0] = ds;
-                    o[1] = dss;
-                }
+                double *o = p.gn_partial + ((int64_t)qt * 32 + nn / CPO) * 2;
+                o[0] = ds;
+                o[1] = dss;
             }
         }
-    }
-}
-
-// The GroupNorm statistics of the block input, folded by the consuming workgroup itself from its producer's chunk records
-// [B][nchunk][32][2] (fp64 {sum, sumsq}, nchunk <= 128): thread = (group t / 8, part t % 8) adds chunks part, part + 8, ... (all its
-// loads in flight), three xor steps join the eight parts; {mean, rstd} finished like gn_finalize_stats_kernel (fp64, the same
-// expressions — the fold's ORDER differs, i.e. the fp64 sums may differ in their last bit before the rounding to fp32).  Every
-// workgroup of the launch computes the same 64 numbers: 32 - 64 KB of L2 reads each instead of a launch + graph edge in front.
-__device__ __forceinline__ void attn_fold_stats(const double *__restrict__ partial, int nchunk, int b, double inv_n, float eps, int tid,
-                                                float *s_mr /*[64]*/) {
-    typedef double f64x2 __attribute__((ext_vector_type(2)));
-    const int g = tid >> 3, part = tid & 7;
-    const double *base = partial + ((int64_t)b * nchunk * 32 + g) * 2;
-    f64x2 v[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int c = part + 8 * i;
-        v[i] = c < nchunk ? *reinterpret_cast<const f64x2 *>(base + (int64_t)c * 64) : f64x2{0.0, 0.0};
-    }
-    double s = 0.0, ss = 0.0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        s += v[i][0];
-        ss += v[i][1];
-    }
-#pragma unroll
-    for (int o = 1; o < 8; o <<= 1) {
-        s += __shfl_xor(s, o, 64);
-        ss += __shfl_xor(ss, o, 64);
-    }
-    if (part == 0) {
-        const double mean = s * inv_n;
-        double var = ss * inv_n - mean * mean;
-        if (var < 0.0) var = 0.0;
-        s_mr[2 * g] = (float)mean;
-        s_mr[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
     }
 }
 
@@ -639,10 +599,7 @@ __device__ __forceinline__ void attn_fold_stats(const double *__restrict__ parti
 // ---------------------------------------------------------------------------------------------------------------------
 struct QkvXParams {
     const float *x;                 // [nt][ldx] fp32 block input
-    const float *mean_rstd;         // [B][32][2] — or NULL: folded here from ...
-    const double *gn_partial;       // ... the producer's chunk records [B][nchunk][32][2], nchunk <= 128
-    int nchunk;
-    float gn_eps;
+    const float *mean_rstd;         // [B][32][2]
     const float *gamma, *beta;      // [AD]
     const unsigned short *w;        // split_rows planes of the ROW-PERMUTED stacked weight: [3 AD / 32][AD / 32][256 pieces][8 halfs]
     const float *bias;              // [3 AD] (natural channel order)
@@ -657,7 +614,6 @@ __global__ __launch_bounds__(256, 2) void attn_qkv_gn_f32x_kernel(const QkvXPara
     constexpr int LDK = AD + 8;                                       // panel row pitch in halfs
     constexpr int VLD = 64 + 4;                                       // V transpose: [128 channels][64 tokens + pad] fp32
     __shared__ __attribute__((aligned(16))) unsigned short sA[2][64][LDK];              // hi plane, lo plane
-    __shared__ float s_mr[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * 64, by = blockIdx.y;
     const int lr = lane & 31, lh = lane >> 5;
@@ -679,14 +635,7 @@ __global__ __launch_bounds__(256, 2) void attn_qkv_gn_f32x_kernel(const QkvXPara
 #pragma unroll
         for (int it = 0; it < NIT; ++it) xr[it] = *reinterpret_cast<const f32x4 *>(p.x + (int64_t)(m0 + prow + it * 4) * p.ldx + pc4);
         const int g = pc4 / cpg;
-        float mean, rstd;
-        if (p.mean_rstd) {
-            mean = p.mean_rstd[(b * 32 + g) * 2], rstd = p.mean_rstd[(b * 32 + g) * 2 + 1];
-        } else {
-            attn_fold_stats(p.gn_partial, p.nchunk, b, 1.0 / ((double)p.n_img * cpg), p.gn_eps, tid, s_mr);
-            __syncthreads();
-            mean = s_mr[2 * g], rstd = s_mr[2 * g + 1];
-        }
+        const float mean = p.mean_rstd[(b * 32 + g) * 2], rstd = p.mean_rstd[(b * 32 + g) * 2 + 1];
         const f32x4 ga = *reinterpret_cast<const f32x4 *>(p.gamma + pc4), be = *reinterpret_cast<const f32x4 *>(p.beta + pc4);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -1071,11 +1020,7 @@ __global__ __launch_bounds__(256) void attn_split_kv_h16_kernel(const unsigned s
 // ---------------------------------------------------------------------------------------------------------------------
 struct QkvHParams {
     const unsigned short *x;        // [nt][ldx] 16-bit activation (the block input)
-    const float *table;             // [B][AD][2] {scale, shift} per (image, channel): sgam_groupnorm_table_from_partials — or NULL:
-    const double *gn_partial;       // ... folded here from the producer's chunk records [B][nchunk][32][2], nchunk <= 128
-    const float *gamma, *beta;      //     with the affine parameters [AD]
-    int nchunk;
-    float gn_eps;
+    const float *table;             // [B][AD][2] {scale, shift} per (image, channel): sgam_groupnorm_table_from_partials
     const unsigned short *w;        // fragment-ordered stacked weights [3 AD / 32][AD / 16][64 lanes][8 halfs]
     const float *bias;              // [3 AD]
     unsigned short *q, *kf, *vf;    // q as the flash kernel's B fragments [nt / 32][16][64][8]; K / V^T fragments (attn_split_kv_h16_kernel's layout)
@@ -1087,7 +1032,6 @@ __global__ __launch_bounds__(256, 2) void attn_qkv_gn_h16_kernel(const QkvHParam
     constexpr int LDK = AD + 8;                                       // panel row pitch in halfs (rows 4 banks apart)
     constexpr int VLD = 64 + 8;                                       // V transpose: [128 channels][64 tokens + pad]
     __shared__ __attribute__((aligned(16))) unsigned short sB[64 * LDK];
-    __shared__ float s_mr[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * 64, by = blockIdx.y;                  // 64 tokens; 128 of the 768 output channels
     const int lr = lane & 31, lh = lane >> 5;
@@ -1104,22 +1048,12 @@ __global__ __launch_bounds__(256, 2) void attn_qkv_gn_h16_kernel(const QkvHParam
         u32x4 xr[8];
 #pragma unroll
         for (int it = 0; it < 8; ++it) xr[it] = *reinterpret_cast<const u32x4 *>(p.x + (int64_t)(m0 + r0 + it * 8) * p.ldx + c8);
-        if (p.table) {
+        {
             const float *tab = p.table + ((int64_t)b * AD + c8) * 2;
 #pragma unroll
             for (int e4 = 0; e4 < 4; ++e4) {
                 const f32x4 tv = *reinterpret_cast<const f32x4 *>(tab + e4 * 4);
                 sc[2 * e4] = tv[0], sf[2 * e4] = tv[1], sc[2 * e4 + 1] = tv[2], sf[2 * e4 + 1] = tv[3];
-            }
-        } else {
-            // scale = rstd gamma, shift = beta - mean scale: gn_finalize_kernel's expressions on the {mean, rstd} folded here
-            attn_fold_stats(p.gn_partial, p.nchunk, b, 1.0 / ((double)p.n_img * (AD / 32)), p.gn_eps, tid, s_mr);
-            __syncthreads();
-            const float mean = s_mr[2 * (c8 / 8)], rstd = s_mr[2 * (c8 / 8) + 1];      // (eight channels = one group of C = 256)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                sc[e] = rstd * p.gamma[c8 + e];
-                sf[e] = p.beta[c8 + e] - mean * sc[e];
             }
         }
 #pragma unroll
@@ -1212,13 +1146,12 @@ struct AttnHParams {
     float qscale_log2e;             // C^-1/2 * log2(e): applied to the fp32 scores
 };
 
-// NWV = 4: 128 queries per workgroup, two workgroups per CU by the register budget (one per CU on the B = 1 grid of 256).  NWV = 8 (opt-in
-// experiment, SGAM_ATTN_H8=1): 256 queries share ONE K / V stream — half the LDS-DMA pieces per wavefront and key, two wavefronts per SIMD —
-// on a grid of half as many workgroups.
-template <int HT, int NWV = 4>
-__global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void attn_flash_h16_kernel(const AttnHParams p) {
+// 128 queries per workgroup (four wavefronts), two workgroups per CU by the register budget (one per CU on the B = 1 grid of 256)
+template <int HT>
+__global__ __launch_bounds__(256, 2) void attn_flash_h16_kernel(const AttnHParams p) {
+    constexpr int NWV = 4;
     // K buffers 0, 1 | V^T buffers 0, 1; the epilogue's transpose wants one block per wavefront
-    __shared__ __attribute__((aligned(16))) unsigned char smem[(NWV > 4 ? NWV : 4) * HBLK_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * HBLK_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sp = blockIdx.x % p.nsplit, qb = blockIdx.x / p.nsplit;
     const int q0 = qb * (32 * NWV) + wave * 32;
@@ -1233,10 +1166,8 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void attn_flash_h16_ker
         unsigned char *dst = smem + slot * HBLK_BYTES + wave_s * WB;
         __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)dst, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)dst, 16, 1024, 0);
-        if constexpr (NWV == 4) {
-            __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)dst, 16, 2048, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)dst, 16, 3072, 0);
-        }
+        __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)dst, 16, 2048, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)dst, 16, 3072, 0);
     };
     auto blk = [&](int j) { return kb0 + (j < nb ? j : nb - 1); };
     dma(kg, blk(0), 0);
@@ -1791,12 +1722,12 @@ extern "C" int sgam_attention_f32x(const float *q, const float *k, const float *
 // sgam_attention_f32x_batched + AttnBlock.proj_out (+ residual) with the merge of the key ranges fused into the projection
 // (attn_combine_proj_f32x_kernel): out[B n][ldc] = residual + bias + softmax(q k^T scale) v . Wp^T.  w_planes: proj_out's weights as
 // sgam_split_rows_f32x lays them out (fragment-ordered hi / lo planes, [C][C]), w_scale their power-of-two scale.  gn_partial
-// (optional): [B][n / 32][32][2] fp64 {sum, sumsq} of `out` per (32-row tile, group of C / 32 channels) — or, with gn_acc, the zeroed
-// [B][16][32][4] int64 accumulator record of sgam_conv_desc.stats_acc.  Same workspace as sgam_attention_f32x_batched.
+// (optional): [B][n / 32][32][2] fp64 {sum, sumsq} of `out` per (32-row tile, group of C / 32 channels).
+// Same workspace as sgam_attention_f32x_batched.
 extern "C" int sgam_attention_proj_f32x_batched(const float *q, const float *k, const float *v, int32_t ld, int32_t n, int32_t C,
                                                 int32_t B, float scale, const void *w_planes, float w_scale, const float *bias,
                                                 const float *residual, int32_t ldr, float *out, int32_t ldc, double *gn_partial,
-                                                int32_t gn_acc, void *workspace, int64_t workspace_bytes, void *stream) {
+                                                void *workspace, int64_t workspace_bytes, void *stream) {
     if (!q || !k || !v || !out || !workspace || !w_planes || !(w_scale > 0.f)) return SGAM_EINVAL;
     const int64_t need = sgam_attention_f32x_batched_workspace_bytes(n, C, B);
     if (need < 0 || ld < C || ld % 4 != 0 || ldc < C || (residual && ldr < C)) return SGAM_EINVAL;
@@ -1823,7 +1754,7 @@ extern "C" int sgam_attention_proj_f32x_batched(const float *q, const float *k, 
     SGAM_LAUNCH_CHECK();
     CombProjParams c;
     c.ws_o = ws_o; c.ws_ml = ws_ml; c.w = (const unsigned short *)w_planes; c.bias = bias; c.res = residual; c.out = out;
-    c.gn_partial = gn_partial; c.gn_acc = (gn_partial && gn_acc) ? 1 : 0; c.n_img = n;
+    c.gn_partial = gn_partial; c.n_img = n;
     c.range_flag = sgam_i_range_flag; c.n = nt; c.ns = nsplit; c.ldr = ldr; c.ldc = ldc;
     c.inv_w_scale = 1.0f / w_scale;
     if (sgam_i_prof_on) sgam_i_prof_shape(nt, AD, AD, 1);
@@ -1872,13 +1803,8 @@ extern "C" int sgam_attention_h16_batched(const void *q, const void *k, const vo
     p.ld = ld; p.n = nt; p.n_img = n; p.nsplit = nsplit; p.blocks_per_split = n / KB / nsplit; p.qscale_log2e = scale * LOG2E;
     const dim3 grid(nt / 128 * nsplit), cgrid(nt / 32 * 8);
     if (sgam_i_prof_on) sgam_i_prof_work(4.0 * B * n * (double)n * AD, 4.0 * 2.0 * nt * AD);
-    static const int h8 = [] { const char *e = getenv("SGAM_ATTN_H8"); return (e && e[0] == '1') ? 1 : 0; }();
-    if (h8) {                                                          // 256-query workgroups, one K / V stream for eight wavefronts
-        const dim3 grid8(nt / 256 * nsplit);
-        if (ht == 0) SGAM_KLAUNCH((attn_flash_h16_kernel<0, 8>), grid8, dim3(512), 0, s, p);
-        else SGAM_KLAUNCH((attn_flash_h16_kernel<1, 8>), grid8, dim3(512), 0, s, p);
-    } else if (ht == 0) SGAM_KLAUNCH((attn_flash_h16_kernel<0, 4>), grid, dim3(256), 0, s, p);
-    else SGAM_KLAUNCH((attn_flash_h16_kernel<1, 4>), grid, dim3(256), 0, s, p);
+    if (ht == 0) SGAM_KLAUNCH(attn_flash_h16_kernel<0>, grid, dim3(256), 0, s, p);
+    else SGAM_KLAUNCH(attn_flash_h16_kernel<1>, grid, dim3(256), 0, s, p);
     SGAM_LAUNCH_CHECK();
 #define HCOMBINE(HT_, NS_) SGAM_KLAUNCH((attn_combine_h16_kernel<HT_, NS_>), cgrid, dim3(256), 0, s, ws_o, ws_ml, (unsigned short *)out, ldo, nt)
     switch (nsplit * 2 + (ht ? 1 : 0)) {
@@ -1973,18 +1899,14 @@ static int attn_block_h16_impl(const void *x, int32_t ldx, const double *gn_part
     float *ws_ml = ws_o + (int64_t)nsplit * nt * AD;
     unsigned short *qb = (unsigned short *)(ws_ml + (int64_t)nsplit * nt * 2);
     float *table = (float *)(qb + (int64_t)nt * AD);
-    // SGAM_ATTN_FOLD=1 (opt-in; read per call, a host-side query): with <= 128 chunk records per image every workgroup of the projection
-    // folds them itself and the table launch goes.  Measured (scripts/r05aa.sh): f32 362.4 -> 361.8, bf16 561.6 -> 559.7 frames/s — the
-    // dependent round trip + fp64 arithmetic in front of every workgroup's staging costs what the 1.6 us launch and its edge cost: off.
-    const char *fold_env = getenv("SGAM_ATTN_FOLD");
-    const bool infold = fold_env && fold_env[0] == '1' && nchunk >= 1 && nchunk <= 128 && sgam_aligned16(gn_partial);
-    if (!infold) {
+    // (the {scale, shift} table is its own small launch: folding the chunk records inside every workgroup of the projection instead
+    // measured break-even to slower in round 5 — a dependent round trip + fp64 arithmetic in front of every workgroup's staging)
+    {
         const int rc = sgam_groupnorm_table_from_partials(gn_partial, nchunk, gamma, beta, table, B, n, C, 32, eps, stream);
         if (rc != SGAM_OK) return rc;
     }
     QkvHParams g;
-    g.x = (const unsigned short *)x; g.table = infold ? nullptr : table; g.gn_partial = gn_partial; g.gamma = gamma; g.beta = beta;
-    g.nchunk = nchunk; g.gn_eps = eps; g.w = (const unsigned short *)w_frag; g.bias = bias; g.q = qb; g.kf = kf; g.vf = vf;
+    g.x = (const unsigned short *)x; g.table = table; g.w = (const unsigned short *)w_frag; g.bias = bias; g.q = qb; g.kf = kf; g.vf = vf;
     g.ldx = ldx; g.n_img = n;
     if (sgam_i_prof_on) sgam_i_prof_shape(nt, 3 * AD, AD, 1);
     if (sgam_i_prof_on) sgam_i_prof_work(2.0 * nt * 3.0 * AD * AD, 2.0 * (4.0 * nt * AD + 3.0 * AD * AD));
@@ -1996,13 +1918,8 @@ static int attn_block_h16_impl(const void *x, int32_t ldx, const double *gn_part
     p.ld = AD; p.n = nt; p.n_img = n; p.nsplit = nsplit; p.blocks_per_split = n / KB / nsplit; p.qscale_log2e = scale * LOG2E;
     const dim3 grid(nt / 128 * nsplit), cgrid(nt / 32 * 8);
     if (sgam_i_prof_on) sgam_i_prof_work(4.0 * B * n * (double)n * AD, 4.0 * 2.0 * nt * AD);
-    static const int h8 = [] { const char *e = getenv("SGAM_ATTN_H8"); return (e && e[0] == '1') ? 1 : 0; }();
-    if (h8) {                                                          // 256-query workgroups, one K / V stream for eight wavefronts
-        const dim3 grid8(nt / 256 * nsplit);
-        if (ht == 0) SGAM_KLAUNCH((attn_flash_h16_kernel<0, 8>), grid8, dim3(512), 0, s, p);
-        else SGAM_KLAUNCH((attn_flash_h16_kernel<1, 8>), grid8, dim3(512), 0, s, p);
-    } else if (ht == 0) SGAM_KLAUNCH((attn_flash_h16_kernel<0, 4>), grid, dim3(256), 0, s, p);
-    else SGAM_KLAUNCH((attn_flash_h16_kernel<1, 4>), grid, dim3(256), 0, s, p);
+    if (ht == 0) SGAM_KLAUNCH(attn_flash_h16_kernel<0>, grid, dim3(256), 0, s, p);
+    else SGAM_KLAUNCH(attn_flash_h16_kernel<1>, grid, dim3(256), 0, s, p);
     SGAM_LAUNCH_CHECK();
     if (wp_frag) {                                                    // merge + proj_out + residual (= x) in one launch
         CombProjHParams c;
@@ -2052,14 +1969,13 @@ extern "C" int64_t sgam_attn_block_f32x_workspace_bytes(int32_t n, int32_t C, in
 // out = x + proj_out(attention(q, k, v)), q | k | v = GroupNorm(x) Wqkv^T + b: fused front end (attn_qkv_gn_f32x_kernel), flash kernel,
 // merge + proj_out + residual (attn_combine_proj_f32x_kernel).  wqkv_planes: sgam_split_rows_f32x of the stacked [3 C][C] weight whose
 // rows were permuted inside every 32-row tile so that row 8 j + 4 h + i holds channel 16 h + 4 j + i; bqkv in natural order.
-static int attn_block_f32x_impl(const float *x, int32_t ldx, const float *mean_rstd, const double *gn_partial_in, int32_t nchunk_in, float eps,
+static int attn_block_f32x_impl(const float *x, int32_t ldx, const float *mean_rstd,
                                 const float *gamma, const float *beta, const void *wqkv_planes, float wqkv_scale, const float *bqkv, int32_t n, int32_t C, int32_t B, float scale,
                                     const void *wp_planes, float wp_scale, const float *bp, float *out, int32_t ldc, double *gn_partial,
-                                    int32_t gn_acc, void *workspace, int64_t workspace_bytes, void *stream) {
-    if (!x || (!mean_rstd && !gn_partial_in) || !gamma || !beta || !wqkv_planes || !bqkv || !wp_planes || !out || !workspace ||
+                                    void *workspace, int64_t workspace_bytes, void *stream) {
+    if (!x || !mean_rstd || !gamma || !beta || !wqkv_planes || !bqkv || !wp_planes || !out || !workspace ||
         !(wqkv_scale > 0.f) || !(wp_scale > 0.f))
         return SGAM_EINVAL;
-    if (!mean_rstd && (nchunk_in < 1 || nchunk_in > 128 || !(eps > 0.f) || !sgam_aligned16(gn_partial_in))) return SGAM_EINVAL;
     const int64_t need = sgam_attn_block_f32x_workspace_bytes(n, C, B);
     if (need < 0 || ldx < C || ldx % 4 != 0 || ldc < C || n % 64 != 0) return SGAM_EINVAL;
     int ex;
@@ -2077,7 +1993,7 @@ static int attn_block_f32x_impl(const float *x, int32_t ldx, const float *mean_r
     float *ws_ml = ws_o + (int64_t)nsplit * nt * AD;
     unsigned short *qb = reinterpret_cast<unsigned short *>(ws_ml + (int64_t)nsplit * nt * 2);      // [nt][AD] x (hi + lo): the same bytes as fp32 rows
     QkvXParams g;
-    g.x = x; g.mean_rstd = mean_rstd; g.gn_partial = gn_partial_in; g.nchunk = nchunk_in; g.gn_eps = eps;
+    g.x = x; g.mean_rstd = mean_rstd;
     g.gamma = gamma; g.beta = beta; g.w = (const unsigned short *)wqkv_planes; g.bias = bqkv;
     g.qf = qb; g.kf = kf; g.vf = vf; g.range_flag = sgam_i_range_flag; g.ldx = ldx; g.n_img = n; g.inv_w_scale = 1.0f / wqkv_scale;
     g.qscale = scale;
@@ -2093,7 +2009,7 @@ static int attn_block_f32x_impl(const float *x, int32_t ldx, const float *mean_r
     SGAM_LAUNCH_CHECK();
     CombProjParams c;
     c.ws_o = ws_o; c.ws_ml = ws_ml; c.w = (const unsigned short *)wp_planes; c.bias = bp; c.res = x; c.out = out;
-    c.gn_partial = gn_partial; c.gn_acc = (gn_partial && gn_acc) ? 1 : 0; c.n_img = n;
+    c.gn_partial = gn_partial; c.n_img = n;
     c.range_flag = sgam_i_range_flag; c.n = nt; c.ns = nsplit; c.ldr = ldx; c.ldc = ldc;
     c.inv_w_scale = 1.0f / wp_scale;
     if (sgam_i_prof_on) sgam_i_prof_shape(nt, AD, AD, 1);
@@ -2174,19 +2090,7 @@ extern "C" int sgam_attention_small_h16(const void *q, const void *k, const void
 extern "C" int sgam_attn_block_f32x(const float *x, int32_t ldx, const float *mean_rstd, const float *gamma, const float *beta,
                                     const void *wqkv_planes, float wqkv_scale, const float *bqkv, int32_t n, int32_t C, int32_t B, float scale,
                                     const void *wp_planes, float wp_scale, const float *bp, float *out, int32_t ldc, double *gn_partial,
-                                    int32_t gn_acc, void *workspace, int64_t workspace_bytes, void *stream) {
-    if (!mean_rstd) return SGAM_EINVAL;
-    return attn_block_f32x_impl(x, ldx, mean_rstd, nullptr, 0, 0.f, gamma, beta, wqkv_planes, wqkv_scale, bqkv, n, C, B, scale, wp_planes, wp_scale,
-                                bp, out, ldc, gn_partial, gn_acc, workspace, workspace_bytes, stream);
-}
-
-// sgam_attn_block_f32x with the statistics of x still as its producer's chunk records [B][nchunk_in][32][2] (fp64 {sum, sumsq},
-// 1 <= nchunk_in <= 128): every workgroup of the front end folds them itself — no statistics launch in front of the block
-extern "C" int sgam_attn_block_gnp_f32x(const float *x, int32_t ldx, const double *gn_partial_in, int32_t nchunk_in, float eps, const float *gamma,
-                                        const float *beta, const void *wqkv_planes, float wqkv_scale, const float *bqkv, int32_t n, int32_t C,
-                                        int32_t B, float scale, const void *wp_planes, float wp_scale, const float *bp, float *out, int32_t ldc,
-                                        double *gn_partial, int32_t gn_acc, void *workspace, int64_t workspace_bytes, void *stream) {
-    if (!gn_partial_in) return SGAM_EINVAL;
-    return attn_block_f32x_impl(x, ldx, nullptr, gn_partial_in, nchunk_in, eps, gamma, beta, wqkv_planes, wqkv_scale, bqkv, n, C, B, scale, wp_planes,
-                                wp_scale, bp, out, ldc, gn_partial, gn_acc, workspace, workspace_bytes, stream);
+                                    void *workspace, int64_t workspace_bytes, void *stream) {
+    return attn_block_f32x_impl(x, ldx, mean_rstd, gamma, beta, wqkv_planes, wqkv_scale, bqkv, n, C, B, scale, wp_planes, wp_scale,
+                                bp, out, ldc, gn_partial, workspace, workspace_bytes, stream);
 }

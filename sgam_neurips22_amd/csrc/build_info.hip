@@ -3,7 +3,6 @@
 //                      working tree differed from it; taken from git where the build runs (the GPU box has no .git: the
 //                      library travels prebuilt and carries the stamp with it)
 //   SGAM_BUILD_DIGEST  sha256 (first 12 hex digits) over every source, header and compile flag of the library
-//   SGAM_STATS_R       replicas of a GroupNorm accumulator record (sgam_common.h), exported so that the host checks it
 // bench.py prints them as `head` / `lib_digest` and compares them with the stamp of the committed counter files.
 #include "sgam_common.h"
 

@@ -57,15 +57,12 @@ struct XParams {
     // ... or, instead of gn_stats, the producer's partial sums [B][gn_chunks_in][32][2] (fp64 {sum, sumsq} per chunk and group),
     // folded by the consumer itself (GNF kernels: a few chunks, one or two channel slabs per workgroup — no fold launch)
     const double *gn_partial_in;
-    const long long *gn_acc_in;   // ... or as the [B][16][32][4] int64 accumulators of sgam_common.h (any GN kernel: 32 bytes per group)
     double gn_inv_n;     // 1 / (pixels per image x channels per group)
     int gn_chunks_in;
     float gn_eps;
     int red_tc;          // group-major split-K combine: channels per workgroup tile (32, 16 or 8); 0 = row-major combine
-    int *arrive;         // optional: one arrival counter per output tile (zero between launches): the LAST split of a tile sums it (xfixup)
 
     double *gn_partial;  // optional: per-(row-half of the tile, group) {sum, sumsq} of the OUTPUT for the next GroupNorm
-    int gn_acc;          // ... 1: gn_partial is the [B][16][32][4] int64 ACCUMULATOR form (sgam_common.h: atomics instead of chunk records)
     int gn_cpg;          // channels per group of that GroupNorm (N / 32)
     int32_t *range_flag; // optional: set to 1 when an output is not finite (an operand left fp16's range, see sgam_hip.h)
     float inv_w_scale;   // 1 / (a_scale * w_scale), an exact power of two
@@ -190,23 +187,6 @@ __device__ __forceinline__ void gn_scale_shift(const XParams &p, int b, int c, f
     t1 = f32x4{sc[2], sh[2], sc[3], sh[3]};
 }
 
-// ---- split-K without a combine launch.  Every split of an output tile stores its partial tile to the workspace with the
-// device-coherent cache policy (sc1: written through the XCD's L2, which is NOT coherent with the other seven), waits for the
-// stores to be acknowledged and takes a ticket from the tile's arrival counter (a device-scope atomic, executed memory-side).
-// The workgroup that draws the last ticket sums the ksplit partial tiles — device-coherent loads, slabs in the FIXED order
-// z = 0, 1, 2 ... exactly like the combine kernels, so the result does not depend on which split arrives last — un-scales,
-// adds bias and residual, writes the output rows and, when asked, the GroupNorm statistics of what it wrote (one chunk per
-// tile: hw / BM chunks per image, <= 16 on the 16^2 / 32^2 maps, which the consuming convolution folds itself), then puts
-// the counter back to zero for the next launch.  256 threads (k-group 0 of the 64 x 64 tile), float4 per thread, 256 / (BN / 4)
-// rows per pass.  `SGAM_XFIX_FENCE` = 1 replaces the sc1 accesses by the memory model's release / acquire fences
-// (buffer_wbl2 / buffer_inv over the whole L2) — same results, kept for comparison.
-// What the DEFAULT (sc1) form rests on — it is opt-in (SGAM_XFIXUP=1) for that reason among others: the ordering "partial tile
-// visible device-wide before the ticket" comes from gfx950's cache policies (an sc1 store is acknowledged only once it has been
-// written through to memory, `s_waitcnt vmcnt(0)` waits for that acknowledgement, an sc1 load bypasses the non-coherent L2), NOT
-// from the relaxed ticket atomic, which orders nothing in the language's memory model; the fence build is the model-conforming
-// spelling of the same protocol.  The counter array belongs to ONE weight and the header's rule "one launch at a time per
-// counter array" is the caller's to keep: ops.py lends a weight's counters only to launches on the stream that first used
-// them (`_arrive`: any other stream gets partial tiles + the combine launch).
 #ifndef SGAM_XLB64
 #define SGAM_XLB64 2       // workgroups per CU the 64-row halo tile is compiled for.  3 caps it at 168 registers (three wavefronts per SIMD): the
 #endif                     //    peeled GroupNorm form then spills 12 bytes and measured 21.2 against 20.3 us in the frame; 2 lets it take 172
@@ -220,158 +200,6 @@ __device__ __forceinline__ void gn_scale_shift(const XParams &p, int b, int c, f
 #ifndef SGAM_XPEEL
 #define SGAM_XPEEL 1       // halo kernels: the last two slabs of a workgroup peeled (no staging of a slab that does not exist)
 #endif
-#ifndef SGAM_XFIX_FENCE
-#define SGAM_XFIX_FENCE 0
-#endif
-#define SGAM_XFIX_AUX (SGAM_XFIX_FENCE ? 0 : 16)
-#ifndef SGAM_XFIX_LF
-#define SGAM_XFIX_LF 32    // coherent partial-tile loads a thread of the last arriver keeps in flight (0: the four-at-a-time form of round 4)
-#endif
-template <int BM, int BN, class RowMap>
-__device__ __forceinline__ void xfixup(const XParams &p, float *smem_f, int bx, int n0, RowMap rowmap) {
-    constexpr int C4T = BN / 4, RPT = 256 / C4T, PASSES = BM / RPT;
-    const int tid = threadIdx.x;
-    const int tile = (n0 / BN) * p.gx + bx;
-    if (SGAM_XFIX_FENCE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                   // every wavefront's partial rows are out; the staging LDS is free
-    int *tk = reinterpret_cast<int *>(smem_f);
-    if (tid == 0) *tk = __hip_atomic_fetch_add(p.arrive + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const int ticket = *tk;
-    if (ticket != p.ksplit - 1) return;
-    if (SGAM_XFIX_FENCE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __syncthreads();                                   // the ticket has been read: the LDS becomes the statistics'
-    const int64_t zs = (int64_t)p.M * p.N;
-    const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc((void *)p.ws, 0, (int)(unsigned)(zs * p.ksplit * 4), 0x00020000);
-    const unsigned r_bytes = p.res ? (unsigned)(((int64_t)(p.M - 1) * p.ldr + p.n_valid) * 4) : 0u;
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void *)p.res, 0, (int)r_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)p.out, 0, (int)(unsigned)(((int64_t)(p.M - 1) * p.ldc + p.n_valid) * 4), 0x00020000);
-    constexpr unsigned OOB = 0xFFFFFFF0u;
-    const unsigned zb = (unsigned)(zs * 4);
-    const int c4 = tid % C4T, r0 = tid / C4T;
-    const int n4 = n0 + c4 * 4;
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias && !p.bias_per_row && n4 < p.n_valid) bv = *reinterpret_cast<const f32x4 *>(p.bias + n4);
-    float gs = 0.f, gss = 0.f;
-    bool bad = false;
-#define XFIX_LD(wo_, z_) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, (int)(wo_), (int)((unsigned)(z_) * zb), SGAM_XFIX_AUX))
-    // finish one output row segment: un-scale, bias, residual, store, statistics (the order of every operation is the combine kernels')
-    auto finish = [&](int m, bool ok, const f32x4 &s, const f32x4 &rv) {
-        f32x4 v;
-        const float bm = (p.bias && p.bias_per_row && ok) ? p.bias[m] : 0.f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            v[e] = s[e] * p.inv_w_scale;
-            if (p.bias) v[e] += p.bias_per_row ? bm : bv[e];
-            if (p.res) v[e] += rv[e];
-        }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, (int)xsel(ok, (unsigned)(m * p.ldc + n4) * 4u, OOB), 0, SGAM_XNT);
-        if (ok) {
-            const float t4 = (v[0] + v[1]) + (v[2] + v[3]);
-            gs += t4;
-            gss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-            bad |= sgam_not_finite(t4);
-        }
-    };
-    // The last arriver is ONE workgroup reading ksplit x (BM x BN x 4) bytes through device-coherent loads, each a ~1 us round trip
-    // to the fabric: what decides its tail is how many of them a thread keeps in flight.  SGAM_XFIX_LF (32) loads = G rows x KS
-    // slabs are requested before the first is summed (128 registers, free here: the accumulators are dead); the sum of a row still
-    // runs z = 0, 1, 2 ... — bit-identical to the four-at-a-time form below (kept for split counts outside {2, 4, 8, 16}).
-    auto deep = [&](auto ks_c, auto g_c) {
-        constexpr int KS = decltype(ks_c)::value, G = decltype(g_c)::value;
-        static_assert(PASSES % G == 0, "row groups tile the passes");
-#pragma unroll 1
-        for (int pass0 = 0; pass0 < PASSES; pass0 += G) {
-            f32x4 part[G][KS], rv[G];
-            int mm[G];
-            bool okk[G];
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                mm[g] = rowmap((pass0 + g) * RPT + r0);
-                okk[g] = mm[g] < p.M && n4 < p.n_valid;
-                const unsigned wo = xsel(okk[g], (unsigned)(mm[g] * p.N + n4) * 4u, OOB);
-#pragma unroll
-                for (int z = 0; z < KS; ++z) part[g][z] = XFIX_LD(wo, z);
-                rv[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                      rr, (int)xsel(okk[g], (unsigned)(mm[g] * p.ldr + n4) * 4u, OOB), 0, 0));
-            }
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                f32x4 s = part[g][0];
-#pragma unroll
-                for (int z = 1; z < KS; ++z) s += part[g][z];
-                finish(mm[g], okk[g], s, rv[g]);
-            }
-        }
-    };
-    constexpr int LF = SGAM_XFIX_LF;
-#define XFIX_DEEP(KS_) deep(std::integral_constant<int, KS_>{}, std::integral_constant<int, (LF / KS_ < PASSES ? (LF / KS_ < 1 ? 1 : LF / KS_) : PASSES)>{})
-    if (LF >= 8 && p.ksplit == 2) XFIX_DEEP(2);
-    else if (LF >= 8 && p.ksplit == 4) XFIX_DEEP(4);
-    else if (LF >= 8 && p.ksplit == 8) XFIX_DEEP(8);
-    else if (LF >= 16 && p.ksplit == 16) XFIX_DEEP(16);
-    else {
-#pragma unroll 2
-        for (int pass = 0; pass < PASSES; ++pass) {
-            const int m = rowmap(pass * RPT + r0);
-            const bool ok = m < p.M && n4 < p.n_valid;
-            const unsigned wo = xsel(ok, (unsigned)(m * p.N + n4) * 4u, OOB);
-            const f32x4 rv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                           rr, (int)xsel(ok, (unsigned)(m * p.ldr + n4) * 4u, OOB), 0, 0));
-            f32x4 s = XFIX_LD(wo, 0);
-            int z = 1;
-            for (; z + 4 <= p.ksplit; z += 4) {
-                const f32x4 a = XFIX_LD(wo, z), b = XFIX_LD(wo, z + 1), c = XFIX_LD(wo, z + 2), d = XFIX_LD(wo, z + 3);
-                s += a;
-                s += b;
-                s += c;
-                s += d;
-            }
-            for (; z < p.ksplit; ++z) s += XFIX_LD(wo, z);
-            finish(m, ok, s, rv);
-        }
-    }
-#undef XFIX_DEEP
-#undef XFIX_LD
-    if (bad && p.range_flag) atomicOr(p.range_flag, 1);
-    if (tid == 0) __hip_atomic_store(p.arrive + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!p.gn_partial) return;
-    // statistics of the tile (host: n_valid == N, hw % BM == 0, cpg a power of two in [4, 32]): the cpg / 4 neighbouring lanes of
-    // one (row, group) fold by an xor butterfly, the RPT row lanes through LDS in a fixed order and in fp64
-    const int lpg = p.gn_cpg / 4;
-    for (int o = 1; o < lpg; o <<= 1) {
-        gs += __shfl_xor(gs, o, 64);
-        gss += __shfl_xor(gss, o, 64);
-    }
-    const int gt = C4T / lpg, gl = c4 / lpg;           // groups inside the tile's BN columns; this lane's
-    float *sh = smem_f;                                // [RPT][gt][2]
-    if ((c4 % lpg) == 0) {
-        sh[(r0 * gt + gl) * 2] = gs;
-        sh[(r0 * gt + gl) * 2 + 1] = gss;
-    }
-    __syncthreads();
-    if (tid < gt) {
-        double ds = 0.0, dss = 0.0;
-        for (int r = 0; r < RPT; ++r) {
-            ds += (double)sh[(r * gt + tid) * 2];
-            dss += (double)sh[(r * gt + tid) * 2 + 1];
-        }
-        const int hw = p.Ho * p.Wo, chunks_per_b = hw / BM;
-        const int b = (bx * BM) / hw, cb = bx - b * chunks_per_b;
-        if (p.gn_acc) {
-            // replica by TILE, not by workgroup: which split arrives last changes from run to run, and with it blockIdx — the record
-            // would hold the same sums in different replicas (found by test_gpu_fixup under SGAM_XFIXUP=1 + SGAM_STATS_ACC=1)
-            sgam_stats_acc_add(reinterpret_cast<long long *>(p.gn_partial), b, (unsigned)tile, n0 / p.gn_cpg + tid, ds, dss);
-        } else {
-            double *o = p.gn_partial + (((int64_t)b * chunks_per_b + cb) * 32 + n0 / p.gn_cpg + tid) * 2;
-            o[0] = ds;
-            o[1] = dss;
-        }
-    }
-}
-
 // ---- epilogue shared by the tile kernels: each wavefront transposes its (32 TM) x (32 TN) fp32 tile through a private
 // LDS region so that a lane ends up with 4 CONSECUTIVE output channels of one pixel: residual comes in and the result
 // leaves as 16-byte accesses, 16 lanes covering a 256-byte row segment (the MFMA D layout alone gives 4-byte accesses:
@@ -387,7 +215,6 @@ __device__ __forceinline__ void xepilogue(const XParams &p, f32x16 (&acc)[BM / (
     const int wm = WGM == 4 ? wave : (WGM == 2 ? wave >> 1 : 0), wn = WGM == 4 ? 0 : (WGM == 2 ? (wave & 1) : wave);
     float *region = smem_f + wave * (WM * LDR);
     const bool to_ws = p.ws != nullptr;
-    const bool fix = to_ws && p.arrive != nullptr;
     const int n_lim = to_ws ? p.N : p.n_valid;
     const int ldo = to_ws ? p.N : p.ldc;
     float *obase = to_ws ? p.ws + (int64_t)bz * p.M * p.N : p.out;
@@ -436,10 +263,7 @@ __device__ __forceinline__ void xepilogue(const XParams &p, f32x16 (&acc)[BM / (
             v += bm;
         }
         v += rv;
-        if (fix) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro,
-                                                        (int)xsel(ok, (unsigned)(m * ldo + n4) * 4u, OOB), 0, SGAM_XFIX_AUX);
-        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro,
-                                                    (int)xsel(ok, (unsigned)(m * ldo + n4) * 4u, OOB), 0, SGAM_XNT);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, (int)xsel(ok, (unsigned)(m * ldo + n4) * 4u, OOB), 0, SGAM_XNT);
         if (ok) {
             const float t4 = (v[0] + v[1]) + (v[2] + v[3]);
             gs += t4;
@@ -473,21 +297,16 @@ __device__ __forceinline__ void xepilogue(const XParams &p, f32x16 (&acc)[BM / (
                 const int b = (bx * BM) / hw;                    // host guarantees a tile never straddles two images
                 const int chunks_per_b = ((hw + BM - 1) / BM) * 2;
                 const int cb = chunk - b * chunks_per_b;
-                if (p.gn_acc) {
-                    sgam_stats_acc_add(reinterpret_cast<long long *>(p.gn_partial), b, blockIdx.x, g, ds, dss);
-                } else {
-                    double *o = p.gn_partial + (((int64_t)b * chunks_per_b + cb) * groups + g) * 2;
-                    o[0] = ds;
-                    o[1] = dss;
-                    if (WGM == 1) {
-                        o[groups * 2] = 0.0;
-                        o[groups * 2 + 1] = 0.0;
-                    }
+                double *o = p.gn_partial + (((int64_t)b * chunks_per_b + cb) * groups + g) * 2;
+                o[0] = ds;
+                o[1] = dss;
+                if (WGM == 1) {
+                    o[groups * 2] = 0.0;
+                    o[groups * 2 + 1] = 0.0;
                 }
             }
         }
     }
-    if (fix) xfixup<BM, BN>(p, smem_f, bx, n0, rowmap);
 }
 
 template <int BM, int BN, bool UPS, bool ASCALE>
@@ -742,7 +561,7 @@ __global__ __launch_bounds__(256 * wk_of(BM, BN)) void conv_gemm_f32x_kernel(con
                     for (int e = 0; e < 16; ++e) xch[((i * TN + j) * 16 + e) * 64 + lane] = acc[i][j][e];
         }
         __syncthreads();
-        // (the second group's wavefronts END here while the first group still executes __syncthreads() in xepilogue / xfixup: that is
+        // (the second group's wavefronts END here while the first group still executes __syncthreads() in xepilogue: that is
         // defined on this hardware — s_barrier counts the wavefronts of the workgroup that have not terminated — and it is the only
         // place the library relies on it; a port to a part whose barrier counts launched wavefronts must keep them alive instead)
         if (wk == 1) return;
@@ -964,22 +783,10 @@ __global__ __launch_bounds__(256, (BM == 64 && !GNF) ? SGAM_XLB64 : 2) void conv
         const int cpg = p.Cin / 32;
         constexpr int CPT = SGAM_XGN_MAXC / 256;                   // channels per thread, at most
         float mr[CPT][2];
-        if (p.gn_acc_in) {
-            // statistics as the producer's accumulator record, finished by the workgroup (one round trip); the table's first 64
-            // floats carry {mean, rstd} to the threads that own the channels
-            sgam_stats_acc_block_mean_rstd<256>(p.gn_acc_in, b, p.gn_inv_n, p.gn_eps, gn_tab, tid);
 #pragma unroll
-            for (int k = 0; k < CPT; ++k) {
-                const int c = tid + 256 * k;
-                if (c < p.Cin) mr[k][0] = gn_tab[2 * (c / cpg)], mr[k][1] = gn_tab[2 * (c / cpg) + 1];
-            }
-            __syncthreads();
-        } else {
-#pragma unroll
-            for (int k = 0; k < CPT; ++k) {
-                const int c = tid + 256 * k;
-                if (c < p.Cin) mr[k][0] = p.gn_stats[(b * 32 + c / cpg) * 2], mr[k][1] = p.gn_stats[(b * 32 + c / cpg) * 2 + 1];
-            }
+        for (int k = 0; k < CPT; ++k) {
+            const int c = tid + 256 * k;
+            if (c < p.Cin) mr[k][0] = p.gn_stats[(b * 32 + c / cpg) * 2], mr[k][1] = p.gn_stats[(b * 32 + c / cpg) * 2 + 1];
         }
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
@@ -1186,396 +993,6 @@ __global__ __launch_bounds__(256, (BM == 64 && !GNF) ? SGAM_XLB64 : 2) void conv
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------
-// 3x3 / stride 1 / pad 1 convolution for the SMALL maps (16^2, 32^2: M = 256 .. 1024 output pixels, 256 .. 512 channels):
-// K split across the four wavefronts of a workgroup instead of across workgroups.
-// On these maps the halo kernel above needs split-K plans of 8 - 16 to fill the chip: a workgroup then multiplies ONE
-// channel slab between a prologue and an epilogue, a second launch sums the partial slabs, and the layer takes 11 + 3 us
-// (+ a launch gap) for 1.2 GFLOP.  Here a workgroup owns a 4 x 8 patch of output pixels x 32 output channels over the WHOLE
-// K range: the 6 x 10 halo of 128 input channels (four slabs) is staged per step, wavefront w multiplies slab w of the step
-// — same A rows, its own weight fragments straight from L2 (distinct K ranges: no fragment is fetched twice inside a
-// workgroup) — and the four partial tiles are summed through LDS in the fixed order w = 0, 1, 2, 3 before the epilogue
-// (bias, residual, 16-byte stores, GroupNorm statistics of the output).  128 (16^2 x 512) / 256 (32^2 x 256) workgroups of
-// 216 / 108 MFMAs per wavefront, no workspace, no combine launch, and the result does not depend on a split-K plan.
-template <bool GN>
-__global__ __launch_bounds__(256) void conv3x3_f32x_k4_kernel(const XParams p) {
-    constexpr int TH = 4, TW = 8, BM = 32, BN = 32;
-    constexpr int HROWS = TH + 2, HWID = TW + 2, HR = HROWS * HWID;       // 6 x 10 halo pixels
-    constexpr int XBK = 32, XLD = XBK + 8, LP = 448;                       // pixel / line pitch in halfs (as the 8 x 8 patch)
-    constexpr int HPL = HROWS * LP;                                        // halfs per plane of one slab
-    constexpr int SLAB_H = 2 * HPL;                                        // hi plane, lo plane
-    constexpr int STAGE_H = 4 * SLAB_H;                                    // four slabs = 128 channels
-    constexpr int NH = (HR * 32 + 255) / 256;                              // float4 pieces per thread and stage (8)
-    constexpr int LDR = BN + 4;
-    static_assert(4 * BM * LDR * 4 <= 2 * STAGE_H * 2, "the partial tiles must fit the operand LDS");
-    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * STAGE_H];
-    __shared__ float gstat_unused[2];
-    (void)gstat_unused;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    int bx, by, bz;
-    xcd_block(p, bx, by, bz);
-    const int n0 = by * BN;
-    const int tiles_x = p.Wo / TW, tiles_img = tiles_x * (p.Ho / TH);
-    const int b = bx / tiles_img;
-    const int t_img = bx - b * tiles_img;
-    const int ty0 = (t_img / tiles_x) * TH, tx0 = (t_img % tiles_x) * TW;
-
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, (int)p.w_plane_bytes, 0x00020000);
-
-    // staging map: piece = (halo pixel, float4 column of the 128 channels); 256 % 32 == 0, so a thread keeps ONE column
-    const int c4 = tid & 31, my_slab = c4 >> 3, col4 = c4 & 7;
-    unsigned h_off[NH];
-    int h_lds[NH];
-#pragma unroll
-    for (int j = 0; j < NH; ++j) {
-        const int row = (tid >> 5) + 8 * j;                    // halo pixel 0 .. 63 (60 valid)
-        const int hy = row / HWID, hx = row - hy * HWID;
-        const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
-        const bool ok = row < HR && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-        h_off[j] = ok ? (unsigned)(((b * p.Hi + iy) * p.Wi + ix) * p.lda + c4 * 4) * 4u : 0xFFFFFFFFu;
-        h_lds[j] = row < HR ? my_slab * SLAB_H + hy * LP + hx * XLD + col4 * 4 : -1;
-    }
-    const int stages = p.Cin / 128;
-    // The workgroups of one channel tile (8 .. 32 patches) all stream the SAME weights.  Started in step they would request
-    // the same lines at the same time: one miss in flight per line however many workgroups wait for it, i.e. the layer would
-    // run at the latency of a single cold stream (measured: 20 us inside a frame against 9 - 11 us back to back, weights
-    // hot).  Patch i therefore walks the 128-channel steps in the rotated order i, i + 1, ... (mod steps): the patches of a
-    // tile pull different parts of the weight panel concurrently and find the others' parts in L2 afterwards.  The order
-    // is a fixed function of the patch: results stay bit-reproducible.
-    const int phase = t_img % stages;
-    auto rot = [&](int g) { const int r = g + phase; return r >= stages ? r - stages : r; };
-    // ... and the three filter ROWS of a step in the rotated order row_rot, row_rot + 1, ... (mod 3): stages x 3 distinct
-    // walks, so the eight patches of a 16 x 16 map never ask for the same fragment at the same time
-    const int row_rot = (t_img / stages) % 3;
-    const unsigned bf_off = ((unsigned)(n0 >> 5) * ((unsigned)p.ldb / 32u) * 256u + (unsigned)lane) * 16u;
-
-    f32x4 hreg[NH];
-    // GroupNorm scale / shift of this thread's four channels for EVERY step, formed once (the column is fixed per thread):
-    // a load inside the loop would be the newest entry of the in-order VMEM queue right when it is needed, i.e. every step
-    // would wait for all the weight fragments requested ahead (vmcnt(0)) and the deep prefetch below would be void
-    constexpr int MAXST = 8;               // Cin <= 1024
-    f32x4 gts[MAXST][2];
-    if constexpr (GN) {
-#pragma unroll
-        for (int g = 0; g < MAXST; ++g)
-            if (g < stages) gn_scale_shift(p, b, g * 128 + c4 * 4, gts[g][0], gts[g][1]);
-    }
-    f32x4 gt0, gt1;
-    auto hload = [&](int g_seq, bool live) {
-        const int g = live ? rot(g_seq) : 0;
-        const unsigned coff = (unsigned)g * (128u * 4u);
-#pragma unroll
-        for (int j = 0; j < NH; ++j) {
-            const unsigned o = xsel(live && h_off[j] != 0xFFFFFFFFu, h_off[j] + coff, p.x_bytes);
-            hreg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)o, 0, 0));
-        }
-        if constexpr (GN) {
-#pragma unroll
-            for (int k = 0; k < MAXST; ++k)
-                if (k == g) {
-                    gt0 = gts[k][0];
-                    gt1 = gts[k][1];
-                }
-        }
-    };
-    auto hprep_piece = [&](const int j) {
-        u32x2 hi, lo;
-        f32x4 v = hreg[j];
-        if constexpr (GN) {
-            v[0] = v[0] * gt0[0] + gt0[1];
-            v[1] = v[1] * gt0[2] + gt0[3];
-            v[2] = v[2] * gt1[0] + gt1[1];
-            v[3] = v[3] * gt1[2] + gt1[3];
-            if (p.gn_swish) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = sgam_swish(v[e]);
-            }
-            if (h_off[j] == 0xFFFFFFFFu) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        split4(v, hi, lo);
-        hreg[j] = __builtin_bit_cast(f32x4, u32x4{hi[0], hi[1], lo[0], lo[1]});
-    };
-    auto hstore = [&](int hb) {
-        unsigned short *halo = smem + hb * STAGE_H;
-#pragma unroll
-        for (int j = 0; j < NH; ++j) {
-            const u32x4 q = __builtin_bit_cast(u32x4, hreg[j]);
-            if (h_lds[j] >= 0) {
-                *reinterpret_cast<u32x2 *>(halo + h_lds[j]) = u32x2{q[0], q[1]};
-                *reinterpret_cast<u32x2 *>(halo + HPL + h_lds[j]) = u32x2{q[2], q[3]};
-            }
-        }
-    };
-    // weight fragments of THIS wavefront's slab of the stage: channel slab 4 g + wave, two taps ahead, three register sets
-    u32x4 bq[9][2][2];                     // [tap][k-step][hi, lo]
-    auto bload = [&](const int set, int tap_seq, int g_seq, bool live) {
-        const int g = live ? rot(g_seq) : 0;
-        int tap = tap_seq + 3 * row_rot;           // the filter tap this position of the walk multiplies
-        tap = tap >= 9 ? tap - 9 : tap;
-        const unsigned koff = (unsigned)(tap * p.Cin + (4 * g + wave) * XBK) * 128u;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
-                bq[set][kk][pl] = __builtin_amdgcn_raw_buffer_load_b128(
-                    rw, (int)xsel(live, bf_off + koff + (unsigned)((pl * 2 + kk) * 1024), p.w_plane_bytes), 0, 0);
-    };
-
-    // one accumulator per product term: three independent MFMA chains
-    f32x16 acc[3];
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-
-    const int frag_row = lane & 31, frag_k = (lane >> 5) * 8;
-    const int a_base = (frag_row >> 3) * LP + (frag_row & 7) * XLD + frag_k + wave * SLAB_H;
-
-    int hcur = 0;
-    hload(0, true);
-#pragma unroll
-    for (int t = 0; t < 9; ++t) bload(t, t, 0, true);
-#pragma unroll
-    for (int j = 0; j < NH; ++j) hprep_piece(j);
-    hstore(0);
-    hload(1, 1 < stages);
-    __syncthreads();
-
-    u32x4 fa[2][2];                        // [step parity][hi, lo]
-#define K4_DS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
-    for (int g = 0; g < stages; ++g) {
-        const bool has_next = g + 1 < stages;
-        const unsigned a_lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short *)(smem + hcur * STAGE_H) +
-                                2u * (unsigned)a_base;
-        unsigned a_row[3];                     // halo line of filter row (j + row_rot) % 3, j = position in the walk
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int ky = j + row_rot >= 3 ? j + row_rot - 3 : j + row_rot;
-            a_row[j] = a_lds0 + 2u * (unsigned)(ky * LP);
-        }
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int set = tap;
-            if (tap < NH) hprep_piece(tap);                     // next stage's halo: one piece per tap (NH = 8)
-            if (tap == NH) {
-                hstore(hcur ^ 1);                               // idle buffer: nobody reads it during this stage
-                hload(g + 2, g + 2 < stages);
-            }
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int q = tap * 2 + kk;
-                auto rd = [&](const int st, const int tp, const int k2) {
-                    const int kyj = tp / 3, kx = tp - 3 * kyj;
-                    K4_DS_READ(fa[st][0], a_row[kyj], 2 * (kx * XLD + k2 * 16));
-                    K4_DS_READ(fa[st][1], a_row[kyj], 2 * (kx * XLD + k2 * 16 + HPL));
-                };
-                if (q == 0) rd(0, 0, 0);
-                if (q < 17) rd((q + 1) & 1, (q + 1) >> 1, (q + 1) & 1);
-                if (q < 17) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[q & 1][0]), "+v"(fa[q & 1][1]));
-                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[q & 1][0]), "+v"(fa[q & 1][1]));
-                acc[0] = mfma16(fa[q & 1][1], bq[set][kk][0], acc[0]);       // a_lo b_hi
-                acc[1] = mfma16(fa[q & 1][0], bq[set][kk][1], acc[1]);       // a_hi b_lo
-                acc[2] = mfma16(fa[q & 1][0], bq[set][kk][0], acc[2]);       // a_hi b_hi
-            }
-            bload(tap, tap, g + 1, has_next);                   // this tap's registers are free: the next stage's fragments
-        }
-        __syncthreads();
-        hcur ^= 1;
-    }
-    __syncthreads();
-
-    // ---- the four wavefronts' partial tiles meet in LDS; small terms first, then the fixed order w = 0, 1, 2, 3
-    float *xr = reinterpret_cast<float *>(smem);
-    {
-        const int col_l = lane & 31, row_h = 4 * (lane >> 5);
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-            xr[(wave * BM + (e & 3) + 8 * (e >> 2) + row_h) * LDR + col_l] = (acc[0][e] + acc[1][e]) + acc[2][e];
-    }
-    __syncthreads();
-    const int row = tid >> 3, c4o = tid & 7;                   // 32 rows x 8 float4 columns = 256 threads
-    f32x4 v = *reinterpret_cast<const f32x4 *>(xr + (0 * BM + row) * LDR + c4o * 4);
-#pragma unroll
-    for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4 *>(xr + (w * BM + row) * LDR + c4o * 4);
-    const int m = (b * p.Ho + ty0 + (row >> 3)) * p.Wo + tx0 + (row & 7);
-    const int n4 = n0 + c4o * 4;
-    const bool ok = n4 < p.n_valid;                            // n_valid is a multiple of 4
-    v = v * p.inv_w_scale;
-    if (p.bias && ok) v += p.bias_per_row ? f32x4{p.bias[m], p.bias[m], p.bias[m], p.bias[m]} : *reinterpret_cast<const f32x4 *>(p.bias + n4);
-    if (p.res && ok) v += *reinterpret_cast<const f32x4 *>(p.res + (int64_t)m * p.ldr + n4);
-    if (ok) *reinterpret_cast<f32x4 *>(p.out + (int64_t)m * p.ldc + n4) = v;
-    const float t4 = (v[0] + v[1]) + (v[2] + v[3]);
-    if (ok && p.range_flag && sgam_not_finite(t4)) atomicOr(p.range_flag, 1);
-    if (p.gn_partial) {
-        // GroupNorm statistics of the 32 x 32 output tile: chunk = this patch, groups = the tile's 32 / cpg groups
-        __syncthreads();                                       // everybody is done reading the partial tiles
-        float *sl = xr;                                        // [32 rows][8 columns][2]
-        sl[(row * 8 + c4o) * 2] = t4;
-        sl[(row * 8 + c4o) * 2 + 1] = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-        __syncthreads();
-        const int c4_per_group = p.gn_cpg / 4, groups_here = 8 / c4_per_group;
-        if (tid < groups_here) {
-            double ds = 0.0, dss = 0.0;
-            for (int r = 0; r < BM; ++r)
-                for (int k = 0; k < c4_per_group; ++k) {
-                    const int l = r * 8 + tid * c4_per_group + k;
-                    ds += (double)sl[l * 2];
-                    dss += (double)sl[l * 2 + 1];
-                }
-            const int g = n0 / p.gn_cpg + tid, groups = p.N / p.gn_cpg;
-            if (p.gn_acc) {
-                sgam_stats_acc_add(reinterpret_cast<long long *>(p.gn_partial), b, blockIdx.x, g, ds, dss);
-            } else {
-                double *o = p.gn_partial + (((int64_t)b * tiles_img + t_img) * groups + g) * 2;
-                o[0] = ds;
-                o[1] = dss;
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// 3x3 / stride 1 / pad 1 convolution for the WEIGHT-DOMINATED maps (16^2, 32^2: M = 256 .. 1024 pixels against 256 .. 512
-// channels — 9.4 MB of split weights for 0.5 MB of activations at 16^2 x 512): a "weight-stationary" decomposition.
-// The 64 x 128 tile of the halo kernel above under its split-K plan makes every workgroup pull 147 KB of weights (re-read by
-// the four M tiles of the map) plus its halo: ~160 KB per CU at the ~11 B/clk a CU sustains from the fabric = the 10 - 11 us
-// those launches take.  Here a workgroup owns ALL 256 pixels of a 16 x 16 patch (the whole map at 16^2) x 32 output channels
-// x ONE channel slab (9 taps x 32 channels): 36.8 KB of weights that no other workgroup of the patch reads, + the 18 x 18
-// halo of the slab (41 KB of fp32, shared through L2 by the N / 32 workgroups of the slab: xcd_block keeps them on one XCD).
-// Every weight fragment is requested at kernel start — 36 x 1 KB per wavefront in flight while the halo is normalised, split
-// and staged — then 108 MFMAs per wavefront (rows 64 w .. 64 w + 63, two 32 x 32 tiles) read their A fragments from the halo.
-// The partial tile goes to the split-K workspace in the common [z][M][N] layout (a half-wave writes 128 contiguous bytes of
-// a row straight from the accumulator layout): the combine kernels above finish it (bias, residual, statistics).
-// GNM: 0 no GroupNorm, 1 {mean, rstd} given, 2 statistics folded from the producer's chunk partials (GNF).
-template <int GNM>
-__global__ __launch_bounds__(256) void conv3x3_f32x_ws_kernel(const XParams p) {
-    constexpr int TH = 16, TW = 16, HROWS = TH + 2, HWID = TW + 2, HR = HROWS * HWID;     // 18 x 18 halo pixels
-    constexpr int XBK = 32, XLD = XBK + 8, LP = 768, HPL = HROWS * LP;                     // as the 8 x 16 patch of halo2
-    constexpr int NH = (HR * 8 + 255) / 256;                                               // float4 pieces per thread (11)
-    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * HPL];                  // hi plane, lo plane: 55 KB
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int bx, by, bz;
-    xcd_block(p, bx, by, bz);
-    const int n0 = by * 32;
-    const int tiles_x = p.Wo / TW, tiles_img = tiles_x * (p.Ho / TH);
-    const int b = bx / tiles_img, t_img = bx - b * tiles_img;
-    const int ty0 = (t_img / tiles_x) * TH, tx0 = (t_img % tiles_x) * TW;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, (int)p.w_plane_bytes, 0x00020000);
-    const int s0 = (bz * p.iters_per_split) / 9, s1 = min(p.iters_total, (bz + 1) * p.iters_per_split) / 9;   // channel slabs
-
-    unsigned h_off[NH];
-    int h_lds[NH];
-#pragma unroll
-    for (int j = 0; j < NH; ++j) {
-        const int idx = tid + 256 * j, row = idx >> 3, col4 = idx & 7;
-        const int hy = row / HWID, hx = row - hy * HWID;
-        const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
-        const bool ok = row < HR && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-        h_off[j] = ok ? (unsigned)(((b * p.Hi + iy) * p.Wi + ix) * p.lda + col4 * 4) * 4u : 0xFFFFFFFFu;
-        h_lds[j] = row < HR ? hy * LP + hx * XLD + col4 * 4 : -1;
-    }
-    const unsigned bf_off = ((unsigned)(n0 >> 5) * ((unsigned)p.ldb / 32u) * 256u + (unsigned)lane) * 16u;
-    const int frag_row = lane & 31, frag_k = (lane >> 5) * 8;
-    unsigned a_lds[2];
-    const unsigned sm_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short *)smem;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = wave * 64 + i * 32 + frag_row;
-        a_lds[i] = sm_lds + 2u * (unsigned)((r >> 4) * LP + (r & 15) * XLD + frag_k);
-    }
-    f32x16 acc[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-
-    for (int sl = s0; sl < s1; ++sl) {
-        // ---- every weight fragment of (this channel tile, this slab): 9 taps x 2 k-steps x {hi, lo}, all in flight at once
-        u32x4 bq[9][2][2];
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const unsigned koff = (unsigned)(tap * p.Cin + sl * XBK) * 128u;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl)
-                    bq[tap][kk][pl] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)bf_off, (int)(koff + (unsigned)((pl * 2 + kk) * 1024)), 0);
-        }
-        // ---- the slab's halo: load, GroupNorm(+swish), hi / lo split, LDS
-        f32x4 hreg[NH];
-        const unsigned coff = (unsigned)sl * (XBK * 4u);
-#pragma unroll
-        for (int j = 0; j < NH; ++j)
-            hreg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)h_off[j], (int)coff, 0));
-        f32x4 gt0, gt1;
-        if constexpr (GNM != 0) gn_scale_shift<GNM == 2>(p, b, sl * XBK + (tid & 7) * 4, gt0, gt1);
-        if (sl != s0) __syncthreads();                       // the previous slab's fragments have been read
-#pragma unroll
-        for (int j = 0; j < NH; ++j) {
-            f32x4 v = hreg[j];
-            if constexpr (GNM != 0) {
-                v[0] = v[0] * gt0[0] + gt0[1];
-                v[1] = v[1] * gt0[2] + gt0[3];
-                v[2] = v[2] * gt1[0] + gt1[1];
-                v[3] = v[3] * gt1[2] + gt1[3];
-                if (p.gn_swish) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = sgam_swish(v[e]);
-                }
-                if (h_off[j] == 0xFFFFFFFFu) v = f32x4{0.f, 0.f, 0.f, 0.f};      // zero padding is applied AFTER the norm
-            }
-            u32x2 hi, lo;
-            split4(v, hi, lo);
-            if (h_lds[j] >= 0) {
-                *reinterpret_cast<u32x2 *>(smem + h_lds[j]) = hi;
-                *reinterpret_cast<u32x2 *>(smem + HPL + h_lds[j]) = lo;
-            }
-        }
-        __syncthreads();
-        // ---- 18 k-steps: A fragments by explicit ds_read_b128, one step ahead, counted waits (as halo2)
-        u32x4 fa[2][2][2];                      // [step parity][m tile][hi, lo]
-#define WS_READ(set, tap, kk)                                                                                               \
-    do {                                                                                                                    \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                     \
-            XDS_READ(fa[set][i][0], a_lds[i], 2 * (((tap) / 3) * LP + ((tap) % 3) * XLD + (kk) * 16));                      \
-            XDS_READ(fa[set][i][1], a_lds[i], 2 * (((tap) / 3) * LP + ((tap) % 3) * XLD + (kk) * 16 + HPL));                \
-        }                                                                                                                   \
-    } while (0)
-        WS_READ(0, 0, 0);
-#pragma unroll
-        for (int q = 0; q < 18; ++q) {
-            const int tap = q >> 1, kk = q & 1;
-            if (q < 17) {
-                WS_READ((q + 1) & 1, (q + 1) >> 1, (q + 1) & 1);
-                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[q & 1][0][0]), "+v"(fa[q & 1][0][1]), "+v"(fa[q & 1][1][0]), "+v"(fa[q & 1][1][1]));
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[q & 1][0][0]), "+v"(fa[q & 1][0][1]), "+v"(fa[q & 1][1][0]), "+v"(fa[q & 1][1][1]));
-            }
-#pragma unroll
-            for (int term = 0; term < 3; ++term)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    acc[i] = mfma16(fa[q & 1][i][term == 0 ? 1 : 0], bq[tap][kk][term == 1 ? 1 : 0], acc[i]);
-        }
-#undef WS_READ
-    }
-    // ---- partial tile -> workspace [bz][M][N]: lane = column n0 + (lane & 31), rows 8 (e / 4) + 4 (lane >> 5) + e % 4 of a tile
-    float *wo = p.ws + (int64_t)bz * p.M * p.N + n0 + (lane & 31);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int r = wave * 64 + i * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
-            const int m = (b * p.Ho + ty0 + (r >> 4)) * p.Wo + tx0 + (r & 15);
-            wo[(int64_t)m * p.N] = acc[i][e];
-        }
-}
-
 // fixed-order split-K reduction (partials are still weight-scaled) + un-scale + bias + residual; optionally the GroupNorm
 // statistics of what it writes: a workgroup covers 1024 / N whole output rows (N in {128, 256, 512, 1024}), lanes of one
 // (row, group) are neighbours -> shuffle fold, rows -> LDS fold, one {sum, sumsq} pair per (workgroup = chunk, group).
@@ -1641,14 +1058,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_f32x_kernel(const XParams p
             ds += (double)sh[r][threadIdx.x][0];
             dss += (double)sh[r][threadIdx.x][1];
         }
-        if (p.gn_acc) {
-            const int b = (int)(((int64_t)blockIdx.x * rows) / (p.Ho * p.Wo));            // whole workgroups inside one image
-            sgam_stats_acc_add(reinterpret_cast<long long *>(p.gn_partial), b, blockIdx.x, threadIdx.x, ds, dss);
-        } else {
-            double *o = p.gn_partial + ((int64_t)blockIdx.x * 32 + threadIdx.x) * 2;     // chunk = workgroup (image-major)
-            o[0] = ds;
-            o[1] = dss;
-        }
+        double *o = p.gn_partial + ((int64_t)blockIdx.x * 32 + threadIdx.x) * 2;     // chunk = workgroup (image-major)
+        o[0] = ds;
+        o[1] = dss;
     }
 }
 
@@ -1711,14 +1123,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_gm_f32x_kernel(const XParam
             dss += (double)sh[r * gt + threadIdx.x][1];
         }
         // chunk = row tile inside the image (image-major: rt counts over the whole batch, hw % TR == 0)
-        if (p.gn_acc) {
-            const int b = (rt * TR) / (p.Ho * p.Wo);
-            sgam_stats_acc_add(reinterpret_cast<long long *>(p.gn_partial), b, blockIdx.x, ct * gt + threadIdx.x, ds, dss);
-        } else {
-            double *o = p.gn_partial + ((int64_t)rt * 32 + ct * gt + threadIdx.x) * 2;
-            o[0] = ds;
-            o[1] = dss;
-        }
+        double *o = p.gn_partial + ((int64_t)rt * 32 + ct * gt + threadIdx.x) * 2;
+        o[0] = ds;
+        o[1] = dss;
     }
 }
 
@@ -1771,25 +1178,9 @@ struct XPlan {
     int bm, bn, ksplit, iters_total, iters_per_split;
 };
 
-// shapes the halo-staged 3x3 kernels take: 3x3 / stride 1 / pad 1, no upsampling, 8 x 16 (8 x 8) output patches, whole
-// 32-channel slabs
-// shapes the K-in-workgroup kernel takes (plan tile (32, 32)): 3x3 / s1 / p1, no upsampling, 4 x 8 patches, 128-channel steps
-static bool k4_shape(const sgam_conv_desc *d) {
-    return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 && !d->upsample2x &&
-           d->Ho == d->Hi && d->Wo == d->Wi && d->Ho % 4 == 0 && d->Wo % 8 == 0 && d->Cin % 128 == 0 && d->N % 32 == 0 &&
-           d->bias_per_row == 0;
-}
-
-// shapes the weight-stationary kernel takes (plan tile (256, 32)): 3x3 / s1 / p1, no upsampling, 16 x 16 patches, whole slabs
-static bool ws_shape(const sgam_conv_desc *d) {
-    return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 && !d->upsample2x &&
-           d->Ho == d->Hi && d->Wo == d->Wi && d->Ho % 16 == 0 && d->Wo % 16 == 0 && d->Cin % 32 == 0 && d->N % 32 == 0 &&
-           d->bias_per_row == 0;
-}
-
+// shapes the halo-staged 3x3 kernels take: 3x3 / stride 1 / pad 1 (plain or nearest-2x upsampled input), 8 x 16 (8 x 8) output
+// patches, whole 32-channel slabs
 static bool halo_shape(const sgam_conv_desc *d, int bm, int bn) {
-    if (bm == 32 && bn == 32) return k4_shape(d);
-    if (bm == 256 && bn == 32) return ws_shape(d);
     static const int halo_on = [] { const char *e = getenv("SGAM_F32X_HALO"); return (e && e[0] == '0') ? 0 : 1; }();
     static const int h64_on = [] { const char *e = getenv("SGAM_F32X_HALO64"); return (e && e[0] == '0') ? 0 : 1; }();
     const bool tile_ok = (bm == 128 && bn == 128 && d->Wo % 16 == 0) || (bm == 64 && bn == 128 && d->Wo % 8 == 0) ||
@@ -1811,30 +1202,7 @@ XPlan make_xplan(const sgam_conv_desc *d) {
     else if (d->N % 128 == 0 && blocks(128, 128) >= 224) { pl.bm = 128; pl.bn = 128; }
     else if (d->N % 128 == 0 && blocks(64, 128) >= 224) { pl.bm = 64; pl.bn = 128; }
     else { pl.bm = 64; pl.bn = 64; }
-    // small maps with deep K (the 16^2 / 32^2 levels): K inside the workgroup instead of a split-K plan — opt-in
-    // (SGAM_F32X_K4=1 or an explicit (32, 32) plan).  Measured on MI355X: back to back the kernel beats the split-K plan by
-    // 4 - 7 us per layer (no combine launch), but inside a frame, with GroupNorm(+swish) fused into the staging, it loses:
-    // 32 x 32 tiles mean 16 channel tiles per patch, each re-normalising the whole 512-channel halo (4x the staging VALU
-    // work of the 128-wide tiles), and a workgroup streams its 590 KB of cold weights alone.
-    static const int k4_default = [] { const char *e = getenv("SGAM_F32X_K4"); return (e && e[0] == '1') ? 1 : 0; }();
-    if (k4_default && d->plan_bm == 0 && M <= 1024 && d->Cin >= 256 && k4_shape(d)) { pl.bm = 32; pl.bn = 32; }
     if (d->plan_bm > 0 && d->plan_bn > 0) { pl.bm = d->plan_bm; pl.bn = d->plan_bn; }
-    if (pl.bm == 32 && pl.bn == 32) {
-        pl.iters_total = pl.iters_per_split = 9 * (d->Cin / 32);
-        pl.ksplit = 1;
-        return pl;
-    }
-    if (pl.bm == 256 && pl.bn == 32) {
-        // weight-stationary kernel: always a split-K plan (its epilogue writes partial tiles only), whole slabs per range
-        const int slabs = d->Cin / 32;
-        int ks = d->plan_ksplit > 0 ? d->plan_ksplit : slabs;
-        if (ks > slabs) ks = slabs;
-        if (ks < 2) ks = slabs >= 2 ? 2 : 1;
-        pl.iters_total = 9 * slabs;
-        pl.iters_per_split = 9 * ((slabs + ks - 1) / ks);
-        pl.ksplit = (pl.iters_total + pl.iters_per_split - 1) / pl.iters_per_split;
-        return pl;
-    }
     const int xbk = halo_shape(d, pl.bm, pl.bn) ? 32 : xbk_of(pl.bm, pl.bn);     // (the halo kernels walk 32-channel slabs)
     pl.iters_total = d->KH * d->KW * ((d->Cin + xbk - 1) / xbk);
     const int64_t nb = blocks(pl.bm, pl.bn);
@@ -1868,8 +1236,7 @@ int xvalidate(const sgam_conv_desc *d) {
     if (d->plan_bm != 0 || d->plan_bn != 0) {
         const bool ok = (d->plan_bm == 128 && d->plan_bn == 128) || (d->plan_bm == 64 && d->plan_bn == 128) ||
                         (d->plan_bm == 128 && d->plan_bn == 32 && d->N == 32) ||
-                        (d->plan_bm == 64 && d->plan_bn == 64) || (d->plan_bm == 32 && d->plan_bn == 32 && k4_shape(d)) ||
-                        (d->plan_bm == 256 && d->plan_bn == 32 && ws_shape(d) && d->Cin >= 64);
+                        (d->plan_bm == 64 && d->plan_bn == 64);
         if (!ok || (d->plan_bn == 128 && d->N % 128 != 0)) return SGAM_EINVAL;
     }
     if (d->plan_ksplit < 0 || d->plan_ksplit > 64) return SGAM_EINVAL;
@@ -1902,7 +1269,6 @@ struct XExtra {            // optional fusions around the product
     int gn_chunks_in = 0;
     float gn_eps = 1e-6f;
     double *gn_partial = nullptr;     // statistics of the output: per-chunk partial sums (epilogue or split-K combine)
-    const long long *gn_acc_in = nullptr;   // statistics of x as accumulators (sgam_conv2d_gnp_nhwc_f32x with chunks_in == 0)
 };
 
 static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale, const void *w_planes, float w_scale,
@@ -1941,47 +1307,11 @@ static int red_tc_for(const sgam_conv_desc *d) {
     return 0;
 }
 
-// chunks per image of the statistics a launch WITHOUT the in-kernel split-K fix-up delivers
-static int32_t stats_chunks_combine(const sgam_conv_desc *d, const XPlan &pl);
-
-// The in-kernel split-K fix-up (xfixup) serves this descriptor: the caller lent arrival counters (sgam_conv_desc.arrive, one per
-// output tile, zero on entry, left zero), the plan splits K, the kernel is one of the tile kernels with the shared epilogue,
-// the workspace is addressable through one buffer descriptor — and the statistics contract is not weakened: where the combine
-// launch would deliver GroupNorm statistics, the fix-up must be able to (complete rows, whole tiles per image, groups that are
-// a power of two of channels inside one tile)
-static bool fixup_stats_ok(const sgam_conv_desc *d, const XPlan &pl) {
-    const int hw = d->Ho * d->Wo, cpg = d->N / 32;
-    return d->N % 128 == 0 && d->n_valid == d->N && d->N <= 1024 && hw % pl.bm == 0 && (cpg & (cpg - 1)) == 0 && pl.bn % cpg == 0;
-}
-static bool fixup_on(const sgam_conv_desc *d, const XPlan &pl) {
-    static const int on = [] { const char *e = getenv("SGAM_XFIXUP"); return (e && e[0] == '0') ? 0 : 1; }();
-    if (!on || !d->arrive || pl.ksplit < 2 || pl.bm == 32 || pl.bm == 256) return false;
-    const int64_t tiles = (int64_t)sgam_cdiv((int64_t)d->B * d->Ho * d->Wo, pl.bm) * sgam_cdiv(d->N, pl.bn);
-    if (tiles > d->arrive_count) return false;
-    // SGAM_XFIXUP_MAXWG=n: only launches of <= n workgroups (one or two per CU: the register file is theirs, and the last arriver's
-    // tail is not hidden by other tiles anyway) take the fix-up; larger grids keep partial tiles + the combine launch.  0: no limit
-    static const int64_t maxwg = [] { const char *e = getenv("SGAM_XFIXUP_MAXWG"); return e ? (int64_t)atoll(e) : (int64_t)0; }();
-    if (maxwg > 0 && tiles * pl.ksplit > maxwg) return false;
-    if ((int64_t)pl.ksplit * d->B * d->Ho * d->Wo * d->N * 4 >= (1ll << 32) - 64) return false;
-    return fixup_stats_ok(d, pl) || stats_chunks_combine(d, pl) == 0;
-}
-
-extern "C" int32_t sgam_conv2d_f32x_fixup(const sgam_conv_desc *d) {
-    if (xvalidate(d) != SGAM_OK) return 0;
-    return fixup_on(d, make_xplan(d)) ? 1 : 0;
-}
-
 extern "C" int32_t sgam_conv2d_f32x_stats_chunks(const sgam_conv_desc *d) {
     if (xvalidate(d) != SGAM_OK) return -1;
     const XPlan pl = make_xplan(d);
-    if (fixup_on(d, pl)) return fixup_stats_ok(d, pl) ? (d->Ho * d->Wo) / pl.bm : 0;      // one chunk per output tile
-    return stats_chunks_combine(d, pl);
-}
-
-static int32_t stats_chunks_combine(const sgam_conv_desc *d, const XPlan &pl) {
     const int hw = d->Ho * d->Wo;
     if (d->N % 128 != 0 || d->n_valid != d->N) return 0;                           // 32 groups of >= 4 channels, complete rows
-    if (pl.bm == 32) return (d->B > 1 && hw % 32 != 0) ? 0 : hw / 32;               // K-in-workgroup kernel: one chunk per patch
     if (pl.ksplit == 1) {
         // from the conv epilogue: one chunk per (tile, wavefront row)
         if (d->B > 1 && hw % pl.bm != 0) return 0;                                 // a tile must not straddle two images
@@ -2023,14 +1353,9 @@ extern "C" int sgam_conv2d_gn_nhwc_f32x(const sgam_conv_desc *d, const float *x,
 // repeated per slab — stays a few hundred cycles in the prologue), 0: fold them first (sgam_groupnorm_stats_from_partials_f32)
 extern "C" int32_t sgam_conv2d_f32x_gn_foldable(const sgam_conv_desc *d, int32_t chunks_in) {
     static const int on = [] { const char *e = getenv("SGAM_GN_FOLD"); return (e && e[0] == '0') ? 0 : 1; }();
-    if (chunks_in == 0) {                          // accumulator form: every GN kernel that fills the scale / shift table
-        if (sgam_conv2d_f32x_gn_fusable(d) != 1 || d->Cin % 128 != 0) return 0;
-        const XPlan pl0 = make_xplan(d);
-        return (pl0.bm == 32 || pl0.bm == 256) ? 0 : 1;
-    }
     if (!on || chunks_in < 1 || chunks_in > 16 || sgam_conv2d_f32x_gn_fusable(d) != 1 || d->Cin % 128 != 0) return 0;
     const XPlan pl = make_xplan(d);
-    return (((pl.bm == 64 && pl.bn == 128) || (pl.bm == 256 && pl.bn == 32)) && pl.iters_per_split <= 18) ? 1 : 0;
+    return (pl.bm == 64 && pl.bn == 128 && pl.iters_per_split <= 18) ? 1 : 0;
 }
 
 // sgam_conv2d_gn_nhwc_f32x with the statistics of x still as its producer's chunk partials [B][chunks_in][32][2] (fp64 {sum,
@@ -2043,8 +1368,7 @@ extern "C" int sgam_conv2d_gnp_nhwc_f32x(const sgam_conv_desc *d, const float *x
         !sgam_aligned16(gn_beta) || !(eps > 0.f) || sgam_conv2d_f32x_gn_foldable(d, chunks_in) != 1)
         return SGAM_EINVAL;
     XExtra ex;
-    if (chunks_in == 0) ex.gn_acc_in = reinterpret_cast<const long long *>(gn_partial_in);
-    else ex.gn_partial_in = gn_partial_in;
+    ex.gn_partial_in = gn_partial_in;
     ex.gn_chunks_in = chunks_in; ex.gn_eps = eps;
     ex.gn_gamma = gn_gamma; ex.gn_beta = gn_beta; ex.gn_swish = gn_swish ? 1 : 0;
     ex.gn_partial = gn_partial;
@@ -2086,16 +1410,12 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
     p.range_flag = sgam_i_range_flag;
     p.a_scale = a_scale;
     p.gn_partial = ex.gn_partial;
-    p.gn_acc = (ex.gn_partial && d->stats_acc) ? 1 : 0;
-    p.gn_acc_in = ex.gn_acc_in;
     p.gn_cpg = d->N / 32;
     p.gn_stats = ex.gn_stats; p.gn_gamma = ex.gn_gamma; p.gn_beta = ex.gn_beta;
     p.gn_swish = ex.gn_swish;
     p.gn_partial_in = ex.gn_partial_in; p.gn_chunks_in = ex.gn_chunks_in; p.gn_eps = ex.gn_eps;
     p.gn_inv_n = 1.0 / ((double)d->Hi * d->Wi * (d->Cin / 32));
     p.red_tc = 0;
-    const bool fixup = fixup_on(d, pl);
-    p.arrive = fixup ? d->arrive : nullptr;
 
     const int64_t xb = (((int64_t)d->B * d->Hi * d->Wi - 1) * d->lda + d->Cin) * 4;
     const int64_t wb = (int64_t)((d->N + 31) / 32 * 32) * d->ldb * 4;   // fragment order over [N rounded up to 32][ldb]
@@ -2122,26 +1442,17 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
     if (p.ups && a_scale != 1.0f) return SGAM_EINVAL;
     if (d->KH * d->KW > 32) return SGAM_EINVAL;   // tap validity mask is 32 bits
     const bool halo = halo_eligible(d, pl, a_scale);
-    const bool gn_tab_on = ex.gn_stats || ex.gn_acc_in;                      // statistics per (image, group): table-filling GN kernels
+    const bool gn_tab_on = ex.gn_stats != nullptr;                           // statistics per (image, group): table-filling GN kernels
     if ((gn_tab_on || ex.gn_partial_in) && !halo) return SGAM_EINVAL;
     if (gn_tab_on && d->Cin > SGAM_XGN_MAXC) return SGAM_EINVAL;             // the scale / shift table of the fused GroupNorm (LDS)
-    if (ex.gn_partial_in && ((pl.bm != 64 && pl.bm != 256) || p.ups)) return SGAM_EINVAL;   // folding consumers: 64-row halo / ws kernel
+    if (ex.gn_partial_in && (pl.bm != 64 || p.ups)) return SGAM_EINVAL;      // folding consumers: the 64-row halo kernel
     // algorithmic work of this launch: 2 M N K fp32 FLOP; bytes = input + weights + output once
     if (sgam_i_prof_on) sgam_i_prof_shape(p.M, d->n_valid, d->KH * d->KW * d->Cin, pl.ksplit);
     if (sgam_i_prof_on)
         sgam_i_prof_work(2.0 * p.M * d->n_valid * (double)(d->KH * d->KW * d->Cin),
                          4.0 * ((double)d->B * d->Hi * d->Wi * d->Cin + (double)d->n_valid * d->KH * d->KW * d->Cin +
                                 (double)p.M * d->n_valid * (residual ? 2 : 1)));
-    if (halo && pl.bm == 256) {
-        if (a_scale != 1.0f || pl.ksplit < 2) return SGAM_EINVAL;
-        if (p.gn_partial_in) SGAM_KLAUNCH((conv3x3_f32x_ws_kernel<2>), grid, dim3(256), 0, s, p);
-        else if (gn_tab_on) SGAM_KLAUNCH((conv3x3_f32x_ws_kernel<1>), grid, dim3(256), 0, s, p);
-        else SGAM_KLAUNCH((conv3x3_f32x_ws_kernel<0>), grid, dim3(256), 0, s, p);
-    } else if (halo && pl.bm == 32) {
-        if (a_scale != 1.0f) return SGAM_EINVAL;
-        if (gn_tab_on) SGAM_KLAUNCH((conv3x3_f32x_k4_kernel<true>), grid, dim3(256), 0, s, p);
-        else SGAM_KLAUNCH((conv3x3_f32x_k4_kernel<false>), grid, dim3(256), 0, s, p);
-    } else if (halo) {
+    if (halo) {
         if (p.ups) {
             if (pl.bm == 128) SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<128, 128, false, true>), grid, dim3(256), 0, s, p);
             else SGAM_KLAUNCH((conv3x3_f32x_halo2_kernel<64, 128, false, true>), grid, dim3(256), 0, s, p);
@@ -2176,7 +1487,7 @@ static int conv_f32x_impl(const sgam_conv_desc *d, const float *x, float a_scale
     else XLAUNCH(64, 64);
 #undef XLAUNCH
     SGAM_LAUNCH_CHECK();
-    if (pl.ksplit > 1 && !fixup) {
+    if (pl.ksplit > 1) {
         const int64_t q = (int64_t)p.M * (p.N / 4);
         const int tc = p.gn_partial ? red_tc_for(d) : 0;
         if (tc == 32) SGAM_KLAUNCH(splitk_reduce_gm_f32x_kernel<32>, dim3((unsigned)(q / 256)), dim3(256), 0, s, p);

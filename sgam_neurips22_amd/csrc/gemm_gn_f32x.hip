@@ -38,9 +38,6 @@ struct GemmGnParams {
     double *gn_partial;        // [B][M / HW * HW / 64][32][2] or NULL: statistics of the output per 64-row chunk
     int ldr;
     const float *mean_rstd;    // [B][32][2]
-    const long long *acc_in;   // ... or the statistics of x as [B][16][32][4] int64 accumulators (sgam_common.h), finished per workgroup
-    float gn_eps;
-    int gn_acc;                // gn_partial is the accumulator form
     const float *gamma, *beta; // [K]
     int M, N, K, lda, ldc, HW; // HW rows per image (GroupNorm statistics are per image)
     float inv_w_scale;
@@ -67,15 +64,6 @@ __global__ __launch_bounds__(256, 2) void gemm_gn_f32x_kernel(const GemmGnParams
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-    __shared__ float s_mr[64];                                     // {mean, rstd} of the image's 32 groups (accumulator input)
-    if constexpr (GN) {
-        if (p.acc_in) {
-            float *scratch = reinterpret_cast<float *>(&sA[0][0][0]);             // (the operand panel is staged after this)
-            sgam_stats_acc_block_mean_rstd<256>(p.acc_in, b, 1.0 / ((double)p.HW * cpg), p.gn_eps, scratch, tid);
-            if (tid < 64) s_mr[tid] = scratch[tid];
-            __syncthreads();
-        }
-    }
 
     // weight fragments of (row tile n0 / 32, slab s, k-step t): pieces ((plane * 2 + t) * 2 + lh) * 32 + lr
     const unsigned short *wt = p.w + (int64_t)(n0 >> 5) * slabs * 2048;
@@ -116,8 +104,7 @@ __global__ __launch_bounds__(256, 2) void gemm_gn_f32x_kernel(const GemmGnParams
             f32x4 ga = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
             if constexpr (GN) {
                 const int g = c / cpg;
-                if (p.acc_in) mean = s_mr[2 * g], rstd = s_mr[2 * g + 1];
-                else mean = p.mean_rstd[(b * 32 + g) * 2], rstd = p.mean_rstd[(b * 32 + g) * 2 + 1];
+                mean = p.mean_rstd[(b * 32 + g) * 2], rstd = p.mean_rstd[(b * 32 + g) * 2 + 1];
                 ga = *reinterpret_cast<const f32x4 *>(p.gamma + c);
                 be = *reinterpret_cast<const f32x4 *>(p.beta + c);
             }
@@ -195,13 +182,9 @@ __global__ __launch_bounds__(256, 2) void gemm_gn_f32x_kernel(const GemmGnParams
         dss += __shfl_xor(dss, 32, 64);
         if (lh == 0 && (lr % cpo) == 0) {
             const int chunks_per_b = p.HW / GBM, chunk = (m0 - b * p.HW) / GBM;
-            if (p.gn_acc) {
-                sgam_stats_acc_add(reinterpret_cast<long long *>(p.gn_partial), b, blockIdx.x, n / cpo, ds, dss);
-            } else {
-                double *o = p.gn_partial + (((int64_t)b * chunks_per_b + chunk) * 32 + n / cpo) * 2;
-                o[0] = ds;
-                o[1] = dss;
-            }
+            double *o = p.gn_partial + (((int64_t)b * chunks_per_b + chunk) * 32 + n / cpo) * 2;
+            o[0] = ds;
+            o[1] = dss;
         }
     }
 }
@@ -216,11 +199,11 @@ extern "C" int32_t sgam_gemm_gn_f32x_fits(int32_t M, int32_t N, int32_t K, int32
 
 // out = [GroupNorm](x) . W^T (+ bias) (+ residual); mean_rstd / gamma / beta NULL = no normalisation; gn_partial (optional):
 // [B][HW / 64][32][2] fp64 partial statistics of `out` (needs N % 128 == 0 as always, N / 32 a power of two <= 32)
-static int gemm_panel_impl(const float *x, int32_t lda, const float *mean_rstd, const long long *acc_in, float eps, const float *gamma,
+static int gemm_panel_impl(const float *x, int32_t lda, const float *mean_rstd, const float *gamma,
                            const float *beta, const void *w_planes, float w_scale, const float *bias, const float *residual, int32_t ldr,
-                           float *out, int32_t ldc, double *gn_partial, int32_t gn_acc, int32_t M, int32_t N, int32_t K, int32_t HW,
+                           float *out, int32_t ldc, double *gn_partial, int32_t M, int32_t N, int32_t K, int32_t HW,
                            void *stream) {
-    const bool gn = mean_rstd != nullptr || acc_in != nullptr;
+    const bool gn = mean_rstd != nullptr;
     if (!x || !w_planes || !out || sgam_gemm_gn_f32x_fits(M, N, K, HW) != 1 || lda < K || ldc < N || !(w_scale > 0.f) ||
         (gn && (!gamma || !beta)) || (residual && ldr < N))
         return SGAM_EINVAL;
@@ -231,7 +214,6 @@ static int gemm_panel_impl(const float *x, int32_t lda, const float *mean_rstd, 
     GemmGnParams p;
     p.x = x; p.w = (const unsigned short *)w_planes; p.bias = bias; p.res = residual; p.ldr = ldr; p.out = out; p.gn_partial = gn_partial;
     p.mean_rstd = mean_rstd; p.gamma = gamma; p.beta = beta;
-    p.acc_in = acc_in; p.gn_eps = eps; p.gn_acc = (gn_partial && gn_acc) ? 1 : 0;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldc = ldc; p.HW = HW; p.inv_w_scale = 1.0f / w_scale; p.range_flag = sgam_i_range_flag;
     if (sgam_i_prof_on) sgam_i_prof_shape(M, N, K, 1);
     if (sgam_i_prof_on) sgam_i_prof_work(2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
@@ -248,18 +230,7 @@ static int gemm_panel_impl(const float *x, int32_t lda, const float *mean_rstd, 
 extern "C" int sgam_gemm_panel_f32x(const float *x, int32_t lda, const float *mean_rstd, const float *gamma, const float *beta,
                                     const void *w_planes, float w_scale, const float *bias, const float *residual, int32_t ldr, float *out,
                                     int32_t ldc, double *gn_partial, int32_t M, int32_t N, int32_t K, int32_t HW, void *stream) {
-    return gemm_panel_impl(x, lda, mean_rstd, nullptr, 0.f, gamma, beta, w_planes, w_scale, bias, residual, ldr, out, ldc, gn_partial, 0, M, N, K,
-                           HW, stream);
-}
-
-// sgam_gemm_gn_f32x with the statistics of x as the [B][16][32][4] int64 accumulators its producer left (sgam_conv_desc.stats_acc):
-// every workgroup finishes {mean, rstd} of its image's 32 groups itself — no fold launch
-extern "C" int sgam_gemm_gn_acc_f32x(const float *x, int32_t lda, const int64_t *gn_acc, float eps, const float *gamma, const float *beta,
-                                     const void *w_planes, float w_scale, const float *bias, float *out, int32_t ldc, int32_t M, int32_t N,
-                                     int32_t K, int32_t HW, void *stream) {
-    if (!gn_acc || !(eps > 0.f) || !sgam_aligned16(gn_acc)) return SGAM_EINVAL;
-    return gemm_panel_impl(x, lda, nullptr, reinterpret_cast<const long long *>(gn_acc), eps, gamma, beta, w_planes, w_scale, bias, nullptr, 0,
-                           out, ldc, nullptr, 0, M, N, K, HW, stream);
+    return gemm_panel_impl(x, lda, mean_rstd, gamma, beta, w_planes, w_scale, bias, residual, ldr, out, ldc, gn_partial, M, N, K, HW, stream);
 }
 
 extern "C" int sgam_gemm_gn_f32x(const float *x, int32_t lda, const float *mean_rstd, const float *gamma, const float *beta,

@@ -292,8 +292,6 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double *__restri
     const double *base = partial + ((int64_t)b * nchunk * groups + g) * 2;
     double s = 0.0, ss = 0.0;
     gn_fold_chunks(base, groups, nchunk, s, ss);
-    if (nchunk == 0 && threadIdx.x == 0)         // accumulator form (sgam_common.h): one record per (image, group), already complete
-        sgam_stats_acc_get(reinterpret_cast<const long long *>(partial), b, g, s, ss);
     s = sgam_wave_sum_f64(s);
     ss = sgam_wave_sum_f64(ss);
     if ((threadIdx.x & 63) == 0) {
@@ -325,8 +323,6 @@ __global__ __launch_bounds__(256) void gn_finalize_stats_kernel(const double *__
     const double *base = partial + ((int64_t)b * nchunk * groups + g) * 2;
     double s = 0.0, ss = 0.0;
     gn_fold_chunks(base, groups, nchunk, s, ss);
-    if (nchunk == 0 && threadIdx.x == 0)         // accumulator form (sgam_common.h): one record per (image, group), already complete
-        sgam_stats_acc_get(reinterpret_cast<const long long *>(partial), b, g, s, ss);
     s = sgam_wave_sum_f64(s);
     ss = sgam_wave_sum_f64(ss);
     if ((threadIdx.x & 63) == 0) {
@@ -427,7 +423,7 @@ extern "C" int sgam_groupnorm_from_partials_f32(const float *x, const double *pa
                                                 const float *beta, float *y, int32_t B, int32_t HW, int32_t C,
                                                 int32_t groups, float eps, int32_t fuse_swish, void *workspace,
                                                 int64_t workspace_bytes, void *stream) {
-    if (!x || !y || !partial || nchunk < 0 || (nchunk == 0 && groups != 32) || !gamma || !beta || !gn_shape_ok(B, HW, C, groups)) return SGAM_EINVAL;
+    if (!x || !y || !partial || nchunk <= 0 || !gamma || !beta || !gn_shape_ok(B, HW, C, groups)) return SGAM_EINVAL;
     if (!sgam_aligned16(x) || !sgam_aligned16(y) || !sgam_aligned16(workspace) || !sgam_aligned16(partial)) return SGAM_EALIGN;
     if (!workspace || workspace_bytes < (int64_t)B * C * 2 * (int64_t)sizeof(float)) return SGAM_EWORKSPACE;
     hipStream_t s = sgam_stream(stream);
@@ -447,7 +443,7 @@ extern "C" int sgam_groupnorm_from_partials_f32(const float *x, const double *pa
 // a convolution that normalises while staging its input (sgam_conv2d_gn_nhwc_f32x)
 extern "C" int sgam_groupnorm_stats_from_partials_f32(const double *partial, int32_t nchunk, float *mean_rstd, int32_t B,
                                                       int32_t HW, int32_t C, int32_t groups, float eps, void *stream) {
-    if (!partial || nchunk < 0 || (nchunk == 0 && groups != 32) || !mean_rstd || !gn_shape_ok(B, HW, C, groups)) return SGAM_EINVAL;
+    if (!partial || nchunk <= 0 || !mean_rstd || !gn_shape_ok(B, HW, C, groups)) return SGAM_EINVAL;
     if (!sgam_aligned16(partial)) return SGAM_EALIGN;
     SGAM_KLAUNCH(gn_finalize_stats_kernel, dim3(groups, B), dim3(256), 0, sgam_stream(stream), partial, mean_rstd, HW, C,
                        groups, nchunk, eps);
@@ -478,7 +474,7 @@ extern "C" int sgam_groupnorm_from_partials_h16(const void *x, const double *par
                                                 const float *beta, void *y, int32_t ht, int32_t B, int32_t HW, int32_t C,
                                                 int32_t groups, float eps, int32_t fuse_swish, void *workspace,
                                                 int64_t workspace_bytes, void *stream) {
-    if (!x || !y || !partial || nchunk < 0 || (nchunk == 0 && groups != 32) || !gamma || !beta || !gn_shape_ok(B, HW, C, groups) || (ht != 0 && ht != 1))
+    if (!x || !y || !partial || nchunk <= 0 || !gamma || !beta || !gn_shape_ok(B, HW, C, groups) || (ht != 0 && ht != 1))
         return SGAM_EINVAL;
     if (!sgam_aligned16(x) || !sgam_aligned16(y) || !sgam_aligned16(workspace) || !sgam_aligned16(partial)) return SGAM_EALIGN;
     if (!workspace || workspace_bytes < (int64_t)B * C * 2 * (int64_t)sizeof(float)) return SGAM_EWORKSPACE;
@@ -500,13 +496,13 @@ extern "C" int sgam_groupnorm_from_partials_h16(const void *x, const double *par
     return SGAM_OK;
 }
 
-// the per-(image, channel) {scale, shift} table alone, from the producer's chunk records (or its accumulator record, nchunk = 0):
+// the per-(image, channel) {scale, shift} table alone, from the producer's chunk records:
 // the finalize half of sgam_groupnorm_from_partials_*, for consumers that apply y = x scale + shift themselves while they stage x
 // (the fused AttnBlock front end of the 16-bit mode, attention.hip: sgam_attn_block_h16)
 extern "C" int sgam_groupnorm_table_from_partials(const double *partial, int32_t nchunk, const float *gamma, const float *beta,
                                                   float *scale_shift, int32_t B, int32_t HW, int32_t C, int32_t groups, float eps,
                                                   void *stream) {
-    if (!partial || nchunk < 0 || (nchunk == 0 && groups != 32) || !gamma || !beta || !scale_shift || !gn_shape_ok(B, HW, C, groups))
+    if (!partial || nchunk <= 0 || !gamma || !beta || !scale_shift || !gn_shape_ok(B, HW, C, groups))
         return SGAM_EINVAL;
     if (!sgam_aligned16(partial) || !sgam_aligned16(scale_shift)) return SGAM_EALIGN;
     hipStream_t s = sgam_stream(stream);

@@ -47,7 +47,6 @@ struct H16Params {
     int M, ksplit, iters_total, iters_per_split;
     unsigned x_bytes, w_bytes;
     double *gn_partial;   // optional (direct epilogue, whole-K workgroups): per-(BM / 2 rows, group) {sum, sumsq} of the output
-    int gn_acc;           // ... 1: in the [B][16][32][4] int64 accumulator form (sgam_common.h)
     int gn_cpg;           // channels per group of the output (N / 32)
 };
 
@@ -337,14 +336,9 @@ __global__ __launch_bounds__(256) void conv_gemm_h16_kernel(const H16Params p) {
                 const int groups = p.N / p.gn_cpg;
                 const int chunk = blockIdx.x * 2 + wm;          // image-major: chunks of an image are consecutive
                 if (g < groups && (int64_t)chunk * (BM / 2) < p.M) {
-                    if (p.gn_acc) {
-                        const int b = (int)(((int64_t)chunk * (BM / 2)) / (p.Ho * p.Wo));
-                        sgam_stats_acc_add(reinterpret_cast<long long *>(p.gn_partial), b, blockIdx.x, g, ds, dss);
-                    } else {
-                        double *o = p.gn_partial + ((int64_t)chunk * groups + g) * 2;
-                        o[0] = ds;
-                        o[1] = dss;
-                    }
+                    double *o = p.gn_partial + ((int64_t)chunk * groups + g) * 2;
+                    o[0] = ds;
+                    o[1] = dss;
                 }
             }
         }
@@ -618,7 +612,6 @@ int conv_h16_launch(const sgam_conv_desc *d, const void *x, const void *w, const
     if (xb >= (1ll << 32) - 64 || wb >= (1ll << 32) - 64) return SGAM_EINVAL;
     p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
     p.gn_partial = gn_partial; p.gn_cpg = d->N / 32;
-    p.gn_acc = (gn_partial && d->stats_acc) ? 1 : 0;
     if (gn_partial && h16_generic_chunks(d) <= 0) return SGAM_EINVAL;
     const bool dir = h16_direct_ok(d);
     if (pl.ksplit > 1) {

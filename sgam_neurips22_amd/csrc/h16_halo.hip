@@ -121,10 +121,6 @@ struct HHParams {
     const double *gn_partial_in;
     int gn_chunks_in;
     float gn_inv_n, gn_eps;
-    const long long *gn_acc_in;   // ... or as [B][16][32][4] int64 accumulators (sgam_common.h): every table-filling GN kernel takes them
-    int gn_acc;                   // gn_partial is the accumulator form (atomics instead of chunk records)
-    unsigned long long *dbg;      // SGAM_HPC_DBG=1: cycle stamps of workgroup 0 (producer / consumer kernel), else NULL
-    int dbg_flags;                // SGAM_HPC_DBGF: timing experiments of that kernel (results wrong): 1 no MFMAs, 2 no producer priority
 };
 
 __device__ __forceinline__ unsigned hsel(bool c, unsigned a, unsigned b) {
@@ -394,22 +390,10 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
         const int cpg = p.Cin / 32;
         constexpr int CPT = SGAM_HGN_MAXC / 256;                   // channels per thread, at most
         float mr[CPT][2];
-        if (p.gn_acc_in) {
-            // statistics as the producer's accumulator record, finished by the workgroup (one round trip); the table's first 64
-            // floats carry {mean, rstd} to the threads that own the channels
-            sgam_stats_acc_block_mean_rstd<256>(p.gn_acc_in, b, (double)p.gn_inv_n, p.gn_eps, &gn_tab[0][0], tid);
 #pragma unroll
-            for (int k = 0; k < CPT; ++k) {
-                const int c = tid + 256 * k;
-                if (c < p.Cin) mr[k][0] = gn_tab[0][2 * (c / cpg)], mr[k][1] = gn_tab[0][2 * (c / cpg) + 1];
-            }
-            __syncthreads();
-        } else {
-#pragma unroll
-            for (int k = 0; k < CPT; ++k) {
-                const int c = tid + 256 * k;
-                if (c < p.Cin) mr[k][0] = p.gn_stats[(b * 32 + c / cpg) * 2], mr[k][1] = p.gn_stats[(b * 32 + c / cpg) * 2 + 1];
-            }
+        for (int k = 0; k < CPT; ++k) {
+            const int c = tid + 256 * k;
+            if (c < p.Cin) mr[k][0] = p.gn_stats[(b * 32 + c / cpg) * 2], mr[k][1] = p.gn_stats[(b * 32 + c / cpg) * 2 + 1];
         }
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
@@ -769,18 +753,9 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
                 // chunk = (tile, row half): the wavefronts that share a row half own different channels, so each
                 // (chunk = tile * 2 + row half, group) is written by exactly one lane of one wavefront
                 const int chunks_per_b = tiles_img * 2;
-                if (p.gn_acc) {
-                    // (the two row halves of a wavefront go to the same record: joined first, half as many atomics)
-                    if constexpr (RH == 2) {
-                        ds += __shfl_down(ds, groups_here, 64);
-                        dss += __shfl_down(dss, groups_here, 64);
-                    }
-                    if (RH == 1 || r == 0) sgam_stats_acc_add(reinterpret_cast<long long *>(p.gn_partial), b, blockIdx.x, g, ds, dss);
-                } else {
-                    double *o = p.gn_partial + (((int64_t)b * chunks_per_b + t_img * 2 + (RH == 1 ? wm : r)) * groups + g) * 2;
-                    o[0] = ds;
-                    o[1] = dss;
-                }
+                double *o = p.gn_partial + (((int64_t)b * chunks_per_b + t_img * 2 + (RH == 1 ? wm : r)) * groups + g) * 2;
+                o[0] = ds;
+                o[1] = dss;
             }
         }
     }
@@ -856,548 +831,13 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv3x3_h16_halo_kerne
                 // chunk = (tile, row half, column half): two wavefronts share a row half but own different channels, so
                 // each (chunk = tile * 2 + wm, group) is written by exactly one lane of one wavefront
                 const int chunks_per_b = tiles_img * 2;
-                if (p.gn_acc) {
-                    sgam_stats_acc_add(reinterpret_cast<long long *>(p.gn_partial), b, blockIdx.x, g, ds, dss);
-                } else {
-                    double *o = p.gn_partial + (((int64_t)b * chunks_per_b + t_img * 2 + wm) * groups + g) * 2;
-                    o[0] = ds;
-                    o[1] = dss;
-                }
+                double *o = p.gn_partial + (((int64_t)b * chunks_per_b + t_img * 2 + wm) * groups + g) * 2;
+                o[0] = ds;
+                o[1] = dss;
             }
         }
     }
 #endif
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Producer / consumer form of the 128-row tile (round 4; whole-K, no upsampling).
-//
-// What the counters of the kernel above said (rocprofv3 on the 256^2 x 128 -> 128 layer, bf16, GroupNorm + swish fused,
-// profiles/r04_pmc_h16_halo128_b{1,8}.json): a wavefront lives 45 - 47 k cycles per tile for 288 MFMAs = 9.2 k cycles of the
-// matrix pipe; 16 k cycles it spends ISSUING its other 3 100 instructions (2 050 VALU — two thirds of them the GroupNorm /
-// swish / 16-bit packing of the halo —, 515 scalar, 412 LDS, 110 vector-memory), 18 k issue-stalled behind an MFMA, 10 - 12 k
-// parked at s_waitcnt / barriers.  Two such wavefronts per SIMD leave the pipe 0.24 - 0.30 busy, and no placement of scheduling
-// barriers, deeper prefetch or L2 warm-up moved it: the wavefront is in-order, and it does everything.
-// Here the roles are split.  A workgroup is EIGHT wavefronts on one CU:
-//   * wavefronts 0 - 3, the consumers: each owns all 128 rows x 32 channels (the 1 x 4 layout above) and issues nothing but
-//     A-fragment reads (explicit ds_read_b128, two k-steps ahead, three register sets), weight-fragment loads (nine register
-//     sets, one per tap, each refilled for the NEXT slab as soon as its tap is done: 4 600 MFMA-cycles ahead) and MFMAs —
-//     ~13 instructions per four MFMAs;
-//   * wavefronts 4 - 7, the producers: load the next slab's halo (one slab ahead of the one they normalise), apply GroupNorm
-//     (+ swish), round to 16 bits and store it to the other LDS buffer — on the VALU of the same four SIMDs, beside the
-//     consumers' MFMAs instead of in front of them.
-// One s_barrier per slab couples them.  The workgroup is PERSISTENT: 256 workgroups walk tiles blockIdx.x, + gridDim.x, ...
-// as ONE stream of slabs, so the producers are already staging the next tile's first slab while the consumers store the
-// finished tile (the epilogue of tile t overlaps the prologue of tile t + 1), and the consumers' weight ring never drains.
-// Loads stay compiler-visible; the loops are arranged so that whatever crosses a back edge is the ONLY thing outstanding there
-// (the compiler's vmcnt arithmetic turns conservative across a back edge: it drained the whole queue at the top of every slab
-// of the kernel above).
-// Results are bit-identical to the kernel above: same MFMA order per accumulator, same staging arithmetic, same epilogue.
-// ---------------------------------------------------------------------------------------------------------------------
-
-template <int HT, bool GN, bool SW>
-__global__ __launch_bounds__(512, 1) void conv3x3_h16_pc_kernel(const HHParams p) {
-    constexpr int BN = 128, TH = 8, TW = 16, TWS = 4;                    // (a 128-row tile: the 8 x 16 patch)
-    constexpr int HROWS = TH + 2, HWID = TW + 2, HR = HROWS * HWID;       // 10 x 18 halo pixels
-    constexpr int XBK = 32, XLD = XBK + 8, LP = 768, HPL = HROWS * LP;    // halfs per slab buffer
-    constexpr int NH = (HR * 4 + 255) / 256;                               // 16-byte halo pieces per producer thread: 3
-    constexpr int TM = 4;
-    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * HPL];
-    __shared__ __attribute__((aligned(16))) float gn_tab[2][GN ? SGAM_HGN_MAXC : 4];
-    __shared__ float epi[4][32];                                           // consumers' output statistics: [wave][row half][unit][2]
-    __shared__ float estat[4][16][65];                                     // ... and their per-lane partials [wave][statistic][lane] (+1: banks)
-    // the residual tile, fetched by the PRODUCERS during the tile's last two slabs, in the consumers' epilogue order:
-    // [channel quarter][row tile][4-channel unit] rows of 64 lanes x 8 bytes (+ 8 bytes: the producers' column-wise writes spread over the banks)
-    constexpr int RROW = 64 * 2 + 2;                                       // dwords per row
-    __shared__ __attribute__((aligned(8))) unsigned res_lds[4 * 4 * 4 * RROW];
-    __shared__ __attribute__((aligned(16))) float bias_lds[BN];            // ... and the tile's 128 bias values, the same way
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool producer = wave >= 4;
-    // (debug: s_memtime stamps of workgroup 0 — consumer wavefront 0 in slots 0.., producer wavefront 4 in slots 64..)
-#define HPC_STAMP(slot) do { if (p.dbg && blockIdx.x == 0 && lane == 0 && (wave & 3) == 0 && (slot) < 64) p.dbg[(producer ? 64 : 0) + (slot)] = __builtin_readcyclecounter(); } while (0)
-    const int tiles_total = p.gx * p.gy, slabs = p.slabs, G = (int)gridDim.x;
-    const int my_tiles = (tiles_total - (int)blockIdx.x + G - 1) / G;      // (host: gridDim.x <= tiles)
-    const int Q = my_tiles * slabs;                                        // this workgroup's stream of slab steps
-    const int tiles_x = p.Wo / TW, tiles_img = tiles_x * (p.Ho / TH);
-    // tile of the workgroup's it-th turn: virtual block id v = blockIdx.x + it * G through the XCD-aware map of hxcd_block
-    auto decode = [&](int it, int &b, int &ty0, int &tx0, int &n0) {
-        const unsigned L = blockIdx.x + (unsigned)it * (unsigned)G, Tt = (unsigned)tiles_total;
-        unsigned Lp = L;
-        if (p.xcd_swizzle) {
-            const unsigned qq = Tt >> 3, r = Tt & 7u, xcd = L & 7u, idx = L >> 3;
-            Lp = xcd * qq + (xcd < r ? xcd : r) + idx;
-        }
-        const int bx = (int)(Lp % (unsigned)p.gx), by = (int)(Lp / (unsigned)p.gx);
-        n0 = by * BN;
-        b = bx / tiles_img;
-        const int t_img = bx - b * tiles_img;
-        ty0 = (t_img / tiles_x) * TH;
-        tx0 = (t_img % tiles_x) * TW;
-    };
-    // the workgroup's it-th tile starts a different image than its (it - 1)-th: the producers' scale / shift table must be
-    // rewritten before that tile's first slab is staged — both roles evaluate this and meet at an extra barrier (rare)
-    auto image_changes = [&](int it) -> bool {
-        if (!GN || it <= 0 || it >= my_tiles) return false;
-        int b0, b1, a_, c_, d_;
-        decode(it - 1, b0, a_, c_, d_);
-        decode(it, b1, a_, c_, d_);
-        return b0 != b1;
-    };
-    auto fill_table = [&](int b) {                                         // producers only: 256 threads
-        if constexpr (GN) {
-            const int cpg = p.Cin / 32;
-            for (int c = tid - 256; c < p.Cin; c += 256) {
-                const int g = c / cpg;
-                float mean, rstd;
-                if (p.gn_acc_in) sgam_stats_acc_mean_rstd(p.gn_acc_in, b, g, (double)p.gn_inv_n, p.gn_eps, mean, rstd);
-                else mean = p.gn_stats[(b * 32 + g) * 2], rstd = p.gn_stats[(b * 32 + g) * 2 + 1];
-                const float sc = rstd * p.gn_gamma[c];
-                gn_tab[0][c] = sc;
-                gn_tab[1][c] = p.gn_beta[c] - mean * sc;
-            }
-        }
-    };
-
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, (int)p.w_bytes, 0x00020000);
-    if (producer) {
-        // ===================================================================================== producers
-        // One register set: stage step q + 1 (requested during the previous turn — the only loads outstanding, so the wait the
-        // compiler puts in front of the first use is exact even across the loop's back edge), then request step q + 2, then meet
-        // the consumers.  The staging arithmetic is a fraction of a consumer's slab, so the producers arrive early and the loads
-        // fly while they wait at the barrier.
-        const int ptid = tid - 256;
-        int h_lds[NH], h_row[NH];
-#pragma unroll
-        for (int j = 0; j < NH; ++j) {
-            int idx = ptid + 256 * j;
-            if (idx >= HR * 4) idx -= 256;                                 // (a piece staged twice: same bytes to the same place)
-            h_row[j] = idx >> 2;
-            h_lds[j] = (h_row[j] / HWID) * LP + (h_row[j] % HWID) * XLD + (idx & 3) * 8;
-        }
-        const int c8 = (ptid & 3) * 8;
-        u32x4 hreg[2][NH];
-        unsigned h_off[NH], p_off[2][NH];                                  // byte offsets (~0: zero padding): tile being LOADED / of each set
-        int l_it = 0, l_s = 0;                                             // (tile turn, slab) of the next step to LOAD
-        auto issue = [&](const int set) {
-            if (l_s == 0) {
-                int b, ty0, tx0, n0;
-                decode(l_it, b, ty0, tx0, n0);
-#pragma unroll
-                for (int j = 0; j < NH; ++j) {
-                    const int hy = h_row[j] / HWID, hx = h_row[j] - hy * HWID;
-                    const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
-                    const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-                    h_off[j] = ok ? (unsigned)(((b * p.Hi + iy) * p.Wi + ix) * p.lda + c8) * 2u : 0xFFFFFFFFu;
-                }
-            }
-            const unsigned coff = (unsigned)l_s * (XBK * 2u);              // wave-uniform: the load's scalar offset
-#pragma unroll
-            for (int j = 0; j < NH; ++j) {
-                hreg[set][j] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)h_off[j], (int)coff, 0);
-                p_off[set][j] = h_off[j];
-            }
-            if (++l_s == slabs) { l_s = 0; ++l_it; }
-        };
-        int p_s = 0, p_it = 0;                                             // (slab, tile turn) of the next step to PROCESS
-        int dbg_slot = 24;
-        auto process = [&](const int set, const int buf) {
-            if (p_s == 0 && image_changes(p_it)) {
-                int b, a_, c_, d_;
-                decode(p_it, b, a_, c_, d_);
-                fill_table(b);
-                __syncthreads();                                           // (C) with the consumers
-            }
-            float gsc[8], gsh[8];
-            if constexpr (GN) {
-                const int c = p_s * XBK + c8;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const f32x4 a = *reinterpret_cast<const f32x4 *>(&gn_tab[0][c + 4 * h]);
-                    const f32x4 d = *reinterpret_cast<const f32x4 *>(&gn_tab[1][c + 4 * h]);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        gsc[4 * h + e] = a[e];
-                        gsh[4 * h + e] = d[e];
-                    }
-                }
-            }
-            unsigned short *halo = smem + buf * HPL;
-            if (p.dbg) {                                                   // (debug: when did this set's loads land?)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                HPC_STAMP(dbg_slot);
-            }
-            // A single wavefront issues a VALU instruction only every 8 - 11 cycles (scripts/micro/mfma_valu_overlap.hip), so the
-            // staging is counted in INSTRUCTIONS: the two channels of a dword travel as one float2 through packed multiply-adds and
-            // leave through one packed conversion (the element-wise spelling of the one-role kernel compiles to ~8 per element —
-            // separate shifts, ors and selects around the same arithmetic); same operations on the same values: same bits.
-            typedef float f32x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-            for (int j = 0; j < NH; ++j) {
-                u32x4 q = hreg[set][j];
-                if constexpr (GN) {
-#pragma unroll
-                    for (int w2 = 0; w2 < 4; ++w2) {
-                        f32x2 v;
-                        if constexpr (HT == 0) v = f32x2{__builtin_bit_cast(float, q[w2] << 16), __builtin_bit_cast(float, q[w2] & 0xFFFF0000u)};
-                        else v = f32x2{HH<HT>::to_f((unsigned short)(q[w2] & 0xFFFFu)), HH<HT>::to_f((unsigned short)(q[w2] >> 16))};
-                        const f32x2 sc = {gsc[2 * w2], gsc[2 * w2 + 1]}, sh = {gsh[2 * w2], gsh[2 * w2 + 1]};
-                        v = v * sc + sh;
-                        if constexpr (SW) {
-                            const f32x2 t = v * -1.4426950408889634f;
-                            const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-                            const f32x2 d = e + 1.0f;
-                            const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-                            v = v * r;
-                        }
-                        q[w2] = (unsigned)HH<HT>::from_f(v[0]) | ((unsigned)HH<HT>::from_f(v[1]) << 16);
-                    }
-                    if (p_off[set][j] == 0xFFFFFFFFu) q = u32x4{0u, 0u, 0u, 0u};       // zero padding applies to the normalised tensor
-                }
-                *reinterpret_cast<u32x4 *>(halo + h_lds[j]) = q;
-            }
-            if (p.dbg) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                HPC_STAMP(dbg_slot + 1);
-            }
-            if (++p_s == slabs) { p_s = 0; ++p_it; }
-        };
-        // residual of the tile the consumers are finishing: requested while they multiply its second-to-last slab, written to LDS
-        // (their epilogue's order) while they multiply its last: the epilogue finds it behind the barrier instead of waiting two
-        // memory round trips for it (cycle stamps: 8.4 k of the epilogue's 11 k cycles went until its stores were issued)
-        u32x2 rres[16];
-        float rbias = 0.f;
-        int r_s = 0, r_it = 0;                                             // (slab, tile turn) of the step the consumers multiply
-        // The consumers' epilogue leaves the per-lane partial statistics of tile `it` in `estat` and goes straight on to the next
-        // tile; the producer wavefront w + 4 finishes consumer w's chunk records one step later (the consumers are then
-        // multiplying slab 1 of the next tile): the same balanced tree, the same fp64 folds, the same records as the one-role
-        // kernel — 4.8 k cycles that used to sit between two tiles' MFMAs (cycle stamps).
-        auto stats_tree = [&](int it) {
-            int b, ty0, tx0, n0;
-            decode(it, b, ty0, tx0, n0);
-            const int t_img = (ty0 / TH) * tiles_x + tx0 / TW;
-            const int cw = wave - 4, wn0 = n0 + cw * 32;
-            float *sl = epi[cw];                                            // [row half][unit = 4 half + k][2]
-            if (lane < 32) {
-                const int v = lane & 15, h2 = lane >> 4;
-                float t[32];
-#pragma unroll
-                for (int i2 = 0; i2 < 32; ++i2) t[i2] = estat[cw][v][32 * h2 + i2];
-#pragma unroll
-                for (int w2 = 16; w2 >= 1; w2 >>= 1)
-#pragma unroll
-                    for (int i2 = 0; i2 < w2; ++i2) t[i2] = t[i2] + t[i2 + w2];
-                const int r = v >> 3, k = (v >> 1) & 3, which = v & 1;
-                sl[(r * 8 + h2 * 4 + k) * 2 + which] = t[0];
-            }
-            const int c4_per_group = p.gn_cpg / 4;
-            const int groups_here = 8 / c4_per_group;
-            if (lane < groups_here * 2) {
-                const int r = lane / groups_here, gl = lane - r * groups_here;
-                double ds = 0.0, dss = 0.0;
-                for (int k = 0; k < c4_per_group; ++k) {
-                    ds += (double)sl[(r * 8 + gl * c4_per_group + k) * 2];
-                    dss += (double)sl[(r * 8 + gl * c4_per_group + k) * 2 + 1];
-                }
-                const int g = (wn0 / p.gn_cpg) + gl;
-                const int groups = p.N / p.gn_cpg;
-                if (g < groups) {
-                    const int chunks_per_b = tiles_img * 2;
-                    if (p.gn_acc) {
-                        sgam_stats_acc_add(reinterpret_cast<long long *>(p.gn_partial), b, blockIdx.x, g, ds, dss);
-                    } else {
-                        double *o = p.gn_partial + (((int64_t)b * chunks_per_b + t_img * 2 + r) * groups + g) * 2;
-                        o[0] = ds;
-                        o[1] = dss;
-                    }
-                }
-            }
-        };
-        auto residual = [&]() {
-            if (p.gn_partial && r_s == 1 && r_it >= 1) stats_tree(r_it - 1);
-            if (p.bias) {
-                if (r_s == slabs - 2) {
-                    int b, ty0, tx0, n0;
-                    decode(r_it, b, ty0, tx0, n0);
-                    rbias = (ptid < BN && n0 + ptid < p.n_valid) ? p.bias[n0 + ptid] : 0.f;
-                } else if (r_s == slabs - 1 && ptid < BN) {
-                    bias_lds[ptid] = rbias;
-                }
-            } else if (r_s == slabs - 1 && ptid < BN && r_it == 0) {
-                bias_lds[ptid] = 0.f;
-            }
-            if (p.res) {
-                if (r_s == slabs - 2) {
-                    int b, ty0, tx0, n0;
-                    decode(r_it, b, ty0, tx0, n0);
-                    const unsigned r_bytes = (unsigned)(((int64_t)(p.M - 1) * p.ldr + p.n_valid) * 2);
-                    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void *)p.res, 0, (int)r_bytes, 0x00020000);
-                    const int c = ptid & 31;                               // 8-byte chunk of the pixel's 128 channels
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int trow = (ptid >> 5) + 8 * r;
-                        const int m = (b * p.Ho + ty0 + (trow >> TWS)) * p.Wo + tx0 + (trow & (TW - 1));
-                        const int n4 = n0 + 4 * c;
-                        rres[r] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
-                                                                rr, (int)hsel(n4 < p.n_valid, (unsigned)(m * p.ldr + n4) * 2u, 0xFFFFFFF0u), 0, 0));
-                    }
-                } else if (r_s == slabs - 1) {
-                    const int c = ptid & 31;
-                    const int wn_ = c >> 3, hh_ = (c >> 2) & 1, k_ = c & 3;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int trow = (ptid >> 5) + 8 * r;
-                        const int i_ = trow >> 5, lane_ = hh_ * 32 + (trow & 31);
-                        *reinterpret_cast<u32x2 *>(&res_lds[((wn_ * 4 + i_) * 4 + k_) * RROW + lane_ * 2]) = rres[r];
-                    }
-                }
-            }
-            if (++r_s == slabs) { r_s = 0; ++r_it; }
-        };
-        if (!(p.dbg_flags & 2)) __builtin_amdgcn_s_setprio(2);          // the second-dispatched half loses every arbitration otherwise (debug bit 1: off)
-        // Two register sets, every load requested TWO steps before it is staged: step q + 1 is staged (set (q + 1) & 1) while the
-        // consumers multiply step q, then step q + 3 is requested into the set just freed.  What is outstanding when a set is
-        // waited for is the other set, requested a whole step earlier: a conservative wait of the compiler (across the back edge)
-        // costs nothing.  (With one set — request after staging — the producers waited a full memory latency per step and the
-        // consumers waited for them: cycle stamps, 3.9 k cycles per step against 2.8 k of MFMA work.)
-        int b0, ty0_, tx0_, n0_;
-        decode(0, b0, ty0_, tx0_, n0_);
-        HPC_STAMP(0);
-        issue(0);
-        if (Q > 1) issue(1);
-        fill_table(b0);
-        __syncthreads();                                                   // (A) table visible to all producers
-        HPC_STAMP(1);
-        process(0, 0);
-        if (Q > 2) issue(0);
-        HPC_STAMP(2);
-        __syncthreads();                                                   // (B) step 0 staged
-        HPC_STAMP(3);
-        for (int q = 0; q < Q; q += 2) {
-            // consumers multiply step q (buffer 0): stage step q + 1 from set 1 into buffer 1, request step q + 3 into set 1
-            dbg_slot = 24 + 4 * q;
-            if (q + 1 < Q) process(1, 1);
-            if (q + 3 < Q) issue(1);
-            HPC_STAMP(26 + 4 * q);
-            residual();
-            HPC_STAMP(4 + 2 * q);                                          // staging done
-            __syncthreads();
-            HPC_STAMP(5 + 2 * q);                                          // past the barrier
-            if (q + 1 >= Q) break;
-            // consumers multiply step q + 1 (buffer 1): stage step q + 2 from set 0 into buffer 0, request step q + 4 into set 0
-            dbg_slot = 28 + 4 * q;
-            if (q + 2 < Q) process(0, 0);
-            if (q + 4 < Q) issue(0);
-            HPC_STAMP(30 + 4 * q);
-            residual();
-            HPC_STAMP(6 + 2 * q);
-            __syncthreads();
-            HPC_STAMP(7 + 2 * q);
-        }
-        if (p.gn_partial) {
-            __syncthreads();                                               // (Z) the consumers' last epilogue has left its partials
-            stats_tree(my_tiles - 1);
-        }
-        return;
-    }
-
-    // ========================================================================================= consumers
-    const int wn = wave;                                                   // channel quarter of the 128-channel tile
-    const int frag_row = lane & 31, frag_k = (lane >> 5) * 8;
-    unsigned a_rel[TM];                                                    // byte offset of (row of m tile i, tap (0,0), k-step 0) in a slab buffer
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int r = i * 32 + frag_row;
-        a_rel[i] = 2u * (unsigned)((r >> TWS) * LP + (r & (TW - 1)) * XLD + frag_k);
-    }
-    const unsigned smem_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short *)smem;
-    // weight ring: one register set per tap, refilled for the next step right after its tap.  Plain buffer loads: the compiler
-    // counts the waits (exactly inside the four-slab body below; conservatively only where the ring crosses its back edge, i.e.
-    // behind an epilogue when a tile is four slabs — by then everything has landed).  (A first version issued them as inline asm
-    // with hand-counted waits: under register pressure the compiler copies such a "defined" value elsewhere and re-uses the
-    // register before the data lands — the late write then hit live addresses: memory faults.)
-    u32x4 bq[9][2];
-    int w_it = 0, w_s = 0;                                                 // (tile turn, slab) the NEXT weight loads belong to
-    unsigned w_voff = 0;                                                   // fragment offset of that step's channel tile + lane
-    auto w_retile = [&]() {
-        int b, ty0, tx0, n0;
-        decode(w_it, b, ty0, tx0, n0);
-        const int nt = (n0 + wn * 32) >> 5;
-        w_voff = ((unsigned)nt * ((unsigned)p.ldb / 32u) * 128u + (unsigned)lane) * 16u;
-    };
-    // (the fragments of (w_it, w_s, tap) into set `tap`; !live: an out-of-range offset — zeros come back, no memory traffic, and
-    // the slab body stays free of branches, which is what keeps the compiler's wait counts exact)
-    auto bload = [&](const int tap, const bool live) {
-        const unsigned koff = (unsigned)(tap * p.Cin + w_s * XBK) * 64u;   // 2048 bytes per (row tile, slab); scalar offset
-        const unsigned vo = live ? w_voff : 0xFFFFFFF0u;
-        bq[tap][0] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)vo, (int)koff, 0);
-        bq[tap][1] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)vo, (int)(koff + 1024u), 0);
-    };
-    auto w_advance = [&]() {
-        if (++w_s == slabs) { w_s = 0; ++w_it; if (w_it < my_tiles) w_retile(); }
-    };
-    f32x16 acc[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-    u32x4 fa[3][TM];
-#define HPC_DS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
-    unsigned a_lds[TM];
-    auto afrag = [&](const int set, const int tap, const int kk) {
-        const int ky = tap / 3, kx = tap - 3 * ky;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) HPC_DS_READ(fa[set][i], a_lds[i], 2 * (ky * LP + kx * XLD + kk * 16));
-    };
-    // one slab step out of LDS buffer `buf`: 9 taps x 2 k-steps x 4 MFMAs
-    auto consume = [&](const int buf, const bool refill) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) a_lds[i] = smem_lds + (unsigned)(buf * HPL * 2) + a_rel[i];
-        afrag(0, 0, 0);
-        afrag(1, 0, 1);
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int k18 = tap * 2 + kk;
-                if (k18 + 2 < 18) afrag((k18 + 2) % 3, (k18 + 2) >> 1, (k18 + 2) & 1);
-                const int s3 = k18 % 3;
-                if (k18 + 2 < 18) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(fa[s3][0]), "+v"(fa[s3][1]), "+v"(fa[s3][2]), "+v"(fa[s3][3]));
-                else if (k18 + 1 < 18) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[s3][0]), "+v"(fa[s3][1]), "+v"(fa[s3][2]), "+v"(fa[s3][3]));
-                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[s3][0]), "+v"(fa[s3][1]), "+v"(fa[s3][2]), "+v"(fa[s3][3]));
-                if (!(p.dbg_flags & 1)) {                 // (debug bit 0: the consumers skip their MFMAs)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) acc[i] = HH<HT>::mfma(bq[tap][kk], fa[s3][i], acc[i]);
-                }
-            }
-            bload(tap, refill);                                            // same tap, next step
-        }
-        if (refill) w_advance();
-    };
-
-    // ---- epilogue of one tile (the direct epilogue of conv3x3_h16_halo_kernel: lane = one pixel x 16 consecutive channels)
-    auto epilogue = [&](int it) {
-        int b, ty0, tx0, n0;
-        decode(it, b, ty0, tx0, n0);
-        const int n_lim = p.n_valid;
-        const unsigned osz = p.out_f32 ? 4u : 2u;
-        const unsigned o_bytes = (unsigned)(((int64_t)(p.M - 1) * p.ldc + n_lim) * osz);
-        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)o_bytes, 0x00020000);
-        constexpr unsigned OOB = 0xFFFFFFF0u;
-        const int wn0 = n0 + wn * 32;
-        const int pl = lane & 31, hh = lane >> 5;
-        int mrow[TM];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int trow = i * 32 + pl;
-            mrow[i] = (b * p.Ho + ty0 + (trow >> TWS)) * p.Wo + tx0 + (trow & (TW - 1));
-        }
-        float us[2][4], uss[2][4];
-        const int nb = wn0 + hh * 16;
-        f32x4 bv[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            bv[k] = *reinterpret_cast<const f32x4 *>(&bias_lds[wn * 32 + hh * 16 + 4 * k]);      // (zeros beyond n_valid, like the OOB load)
-            us[0][k] = us[1][k] = uss[0][k] = uss[1][k] = 0.f;
-        }
-        // two row halves (= the two statistics chunks of the tile); the residual comes out of LDS (the producers put it there)
-#pragma unroll
-        for (int ih = 0; ih < 2; ++ih) {
-            u32x2 rq[2][4];
-#pragma unroll
-            for (int i2 = 0; i2 < 2; ++i2)
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    rq[i2][k] = p.res ? *reinterpret_cast<const u32x2 *>(&res_lds[((wn * 4 + 2 * ih + i2) * 4 + k) * RROW + lane * 2]) : u32x2{0u, 0u};
-#pragma unroll
-            for (int i2 = 0; i2 < 2; ++i2) {
-                const int i = 2 * ih + i2;
-                u32x4 o16[2];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int n4 = nb + 4 * k;
-                    const bool ok = n4 < n_lim;
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[i][4 * k + e] + bv[k][e];
-                    v[0] += HH<HT>::to_f((unsigned short)(rq[i2][k][0] & 0xFFFFu));
-                    v[1] += HH<HT>::to_f((unsigned short)(rq[i2][k][0] >> 16));
-                    v[2] += HH<HT>::to_f((unsigned short)(rq[i2][k][1] & 0xFFFFu));
-                    v[3] += HH<HT>::to_f((unsigned short)(rq[i2][k][1] >> 16));
-                    if (p.out_f32) {
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro,
-                                                               (int)hsel(ok, (unsigned)(mrow[i] * p.ldc + n4) * 4u, OOB), 0, 0);
-                    } else {
-                        const unsigned short h0 = HH<HT>::from_f(v[0]), h1 = HH<HT>::from_f(v[1]), h2 = HH<HT>::from_f(v[2]),
-                                             h3 = HH<HT>::from_f(v[3]);
-                        o16[k >> 1][(k & 1) * 2] = (unsigned)h0 | ((unsigned)h1 << 16);
-                        o16[k >> 1][(k & 1) * 2 + 1] = (unsigned)h2 | ((unsigned)h3 << 16);
-                        v = f32x4{HH<HT>::to_f(h0), HH<HT>::to_f(h1), HH<HT>::to_f(h2), HH<HT>::to_f(h3)};     // statistics of the STORED tensor
-                    }
-                    if (ok) hstat_add(us[ih][k], uss[ih][k], v);
-                }
-                if (!p.out_f32) {
-                    if (nb + 16 <= n_lim) {
-#pragma unroll
-                        for (int q2 = 0; q2 < 2; ++q2)
-                            __builtin_amdgcn_raw_buffer_store_b128(o16[q2], ro, (int)((unsigned)(mrow[i] * p.ldc + nb + 8 * q2) * 2u), 0, 0);
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const u32x2 o8 = {o16[k >> 1][(k & 1) * 2], o16[k >> 1][(k & 1) * 2 + 1]};
-                            __builtin_amdgcn_raw_buffer_store_b64(o8, ro, (int)hsel(nb + 4 * k < n_lim, (unsigned)(mrow[i] * p.ldc + nb + 4 * k) * 2u, OOB), 0, 0);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;              // the next tile starts from zero
-            }
-        }
-        HPC_STAMP(50 + 3 * it);                                            // stores issued
-        if (p.gn_partial) {
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    estat[wave][(r * 4 + k) * 2][lane] = us[r][k];
-                    estat[wave][(r * 4 + k) * 2 + 1][lane] = uss[r][k];
-                }
-            // (the tree over the lanes and the fp64 folds: the producers' stats_tree, one step later)
-        }
-    };
-
-    // prologue: the whole weight ring of step 0 requested; barriers (A), (B) with the producers
-    HPC_STAMP(0);
-    w_retile();
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) bload(tap, true);
-    w_advance();
-    __syncthreads();                                                       // (A)
-    HPC_STAMP(1);
-    __syncthreads();                                                       // (B) step 0 staged
-    HPC_STAMP(3);
-    int c_s = 0, c_it = 0;                                                 // (slab, tile turn) of the step being multiplied
-    // barrier (C): the producers stage step q + 1 while this role multiplies step q; when that step opens a new image they
-    // rewrite their table first and everybody meets
-    auto meet_retable = [&](bool next_exists) {
-        if (next_exists && c_s + 1 == slabs && image_changes(c_it + 1)) __syncthreads();
-    };
-    for (int q = 0; q < Q; q += 4) {                 // (host: slabs % 4 == 0 — a tile ends on a multiple of four steps)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            meet_retable(q + u + 1 < Q);
-            consume(u & 1, q + u + 1 < Q);
-            HPC_STAMP(4 + 2 * (q + u));                                    // slab multiplied
-            __syncthreads();
-            HPC_STAMP(5 + 2 * (q + u));                                    // past the barrier
-            ++c_s;
-        }
-        if (c_s == slabs) { c_s = 0; epilogue(c_it++); HPC_STAMP(40 + c_it); }
-    }
-    if (p.gn_partial) __syncthreads();                                     // (Z)
-#undef HPC_DS_READ
-#undef HPC_STAMP
 }
 
 // split-K combine: out = round16(sum_z ws[z] + bias + residual), ranges added in the order z = 0, 1, 2, ...; thread = 4
@@ -1467,13 +907,9 @@ __global__ __launch_bounds__(256) void h16_splitk_reduce_kernel(const HHParams p
             ds += (double)sh[r][threadIdx.x][0];
             dss += (double)sh[r][threadIdx.x][1];
         }
-        if (p.gn_acc) {
-            sgam_stats_acc_add(reinterpret_cast<long long *>(p.gn_partial), (int)(((int64_t)blockIdx.x * rows) / (p.Ho * p.Wo)), blockIdx.x, threadIdx.x, ds, dss);
-        } else {
-            double *o = p.gn_partial + ((int64_t)blockIdx.x * 32 + threadIdx.x) * 2;     // chunk = workgroup (image-major)
-            o[0] = ds;
-            o[1] = dss;
-        }
+        double *o = p.gn_partial + ((int64_t)blockIdx.x * 32 + threadIdx.x) * 2;     // chunk = workgroup (image-major)
+        o[0] = ds;
+        o[1] = dss;
     }
 }
 
@@ -1541,13 +977,9 @@ __global__ __launch_bounds__(256) void h16_splitk_reduce_gm_kernel(const HHParam
             dss += (double)sh[r * gt + threadIdx.x][1];
         }
         // chunk = row tile inside the image (image-major: rt counts over the whole batch, hw % TR == 0)
-        if (p.gn_acc) {
-            sgam_stats_acc_add(reinterpret_cast<long long *>(p.gn_partial), (rt * TR) / (p.Ho * p.Wo), blockIdx.x, ct * gt + threadIdx.x, ds, dss);
-        } else {
-            double *o = p.gn_partial + ((int64_t)rt * 32 + ct * gt + threadIdx.x) * 2;
-            o[0] = ds;
-            o[1] = dss;
-        }
+        double *o = p.gn_partial + ((int64_t)rt * 32 + ct * gt + threadIdx.x) * 2;
+        o[0] = ds;
+        o[1] = dss;
     }
 }
 
@@ -1676,8 +1108,6 @@ extern "C" int sgam_pack_conv_weight_h16_frag(const float *w_oihw, void *w_frag,
 // slab), groups of >= 8 channels (a thread's eight staged channels are one group), at most 16 chunks
 extern "C" int32_t sgam_conv2d_h16_gn_foldable(const sgam_conv_desc *d, int32_t chunks_in) {
     static const int on = [] { const char *e = getenv("SGAM_GN_FOLD"); return (e && e[0] == '0') ? 0 : 1; }();
-    if (d && chunks_in == 0)               // accumulator form (sgam_conv_desc.stats_acc of the producer): every GN-fusing launch of the halo kernel
-        return (!d->upsample2x && d->Cin % 128 == 0 && d->Cin <= SGAM_HGN_MAXC && hh_plan(d).bm != 0) ? 1 : 0;
     if (!on || !d || chunks_in < 1 || chunks_in > 16 || d->upsample2x || d->Cin % 256 != 0) return 0;
     const HHPlan pl = hh_plan(d);
     return (pl.bm == 64 && pl.slabs_per_split <= 2) ? 1 : 0;
@@ -1690,17 +1120,11 @@ static int hh_conv_impl(const sgam_conv_desc *d, int32_t ht, const void *x, cons
     const HHPlan pl = hh_plan(d);
     const int bm = pl.bm;
     if (!bm || !x || !w_frag || !out || (ht != 0 && ht != 1)) return SGAM_EINVAL;
-    const long long *gn_acc_in = nullptr;           // chunks_in == 0: the statistics of x are accumulators, not chunk records
-    if (gn_partial_in && chunks_in == 0) {
-        if (gn_mean_rstd || !(gn_eps > 0.f) || !sgam_aligned16(gn_partial_in) || sgam_conv2d_h16_gn_foldable(d, 0) != 1) return SGAM_EINVAL;
-        gn_acc_in = reinterpret_cast<const long long *>(gn_partial_in);
-        gn_partial_in = nullptr;
-    }
     if (!sgam_aligned16(x) || !sgam_aligned16(w_frag) || (((uintptr_t)out) & 7u) || (residual && (((uintptr_t)residual) & 7u)))
         return SGAM_EALIGN;
     if (gn_partial_in && (gn_mean_rstd || sgam_conv2d_h16_gn_foldable(d, chunks_in) != 1 || !sgam_aligned16(gn_partial_in)))
         return SGAM_EINVAL;
-    const bool gn = gn_mean_rstd != nullptr || gn_partial_in != nullptr || gn_acc_in != nullptr;
+    const bool gn = gn_mean_rstd != nullptr || gn_partial_in != nullptr;
     if (gn && (!gn_gamma || !gn_beta || !sgam_aligned16(gn_gamma) || !sgam_aligned16(gn_beta) || d->upsample2x || d->Cin % 128 ||
                d->Cin > SGAM_HGN_MAXC))
         return SGAM_EINVAL;
@@ -1723,12 +1147,8 @@ static int hh_conv_impl(const sgam_conv_desc *d, int32_t ht, const void *x, cons
     p.gn_stats = gn_mean_rstd; p.gn_gamma = gn_gamma; p.gn_beta = gn_beta; p.gn_swish = gn_swish ? 1 : 0;
     p.gn_partial = gn_partial; p.gn_cpg = d->N / 32;
     p.gn_partial_in = gn_partial_in; p.gn_chunks_in = chunks_in; p.gn_eps = gn_eps;
-    p.gn_acc_in = gn_acc_in; p.gn_acc = (gn_partial && d->stats_acc) ? 1 : 0;
     p.gn_inv_n = 1.0f / ((float)d->Hi * (float)d->Wi * (float)(d->Cin / 32));
     p.gx = p.M / bm; p.gy = d->N / 128;
-    p.dbg = nullptr;
-    static const int dbgf = [] { const char *e = getenv("SGAM_HPC_DBGF"); return e ? atoi(e) : 0; }();
-    p.dbg_flags = dbgf;
     static const int swz = [] { const char *e = getenv("SGAM_XCD_SWIZZLE"); return (e && e[0] == '0') ? 0 : 1; }();
     p.xcd_swizzle = swz;
     const dim3 grid((unsigned)((int64_t)p.gx * p.gy), (unsigned)pl.ksplit);
@@ -1756,47 +1176,6 @@ static int hh_conv_impl(const sgam_conv_desc *d, int32_t ht, const void *x, cons
         else if (gn) SGAM_KLAUNCH((conv3x3_h16_halo_kernel<BM_, 128, HT_, true, false, false, false, 6>), grid, dim3(256), 0, s, p);        \
         else SGAM_KLAUNCH((conv3x3_h16_halo_kernel<BM_, 128, HT_, false, false, true, false, 6>), grid, dim3(256), 0, s, p);                \
     } while (0)
-    // the 128-row tile, whole K, no upsampling: the persistent producer / consumer kernel — OPT-IN (SGAM_HPC=1).  Bit-identical to the
-    // one-role kernel (scripts/h16_pc_check.py) and its consumers run at 0.8 of the matrix pipe, but the launch as a whole measured
-    // 28.8 against 26.2 us at B = 1 and 108 against 100 us per launch at B = 8: not the default.
-    static const int hpc_on = [] { const char *e = getenv("SGAM_HPC"); return (e && e[0] == '1') ? 1 : 0; }();
-    static const int n_cu = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        return n;
-    }();
-    if (hpc_on && bm == 128 && !p.ups && pl.ksplit == 1 && !gn_partial_in && d->Cin <= SGAM_HGN_MAXC && p.slabs % 4 == 0) {
-        const int64_t tiles_total = (int64_t)p.gx * p.gy;
-        const dim3 pg((unsigned)(tiles_total < n_cu ? tiles_total : n_cu));
-#define HPC_LAUNCH(HT_)                                                                                                   \
-    do {                                                                                                                  \
-        if (gn && p.gn_swish) SGAM_KLAUNCH((conv3x3_h16_pc_kernel<HT_, true, true>), pg, dim3(512), 0, s, p);             \
-        else if (gn) SGAM_KLAUNCH((conv3x3_h16_pc_kernel<HT_, true, false>), pg, dim3(512), 0, s, p);                     \
-        else SGAM_KLAUNCH((conv3x3_h16_pc_kernel<HT_, false, false>), pg, dim3(512), 0, s, p);                            \
-    } while (0)
-        static const int dbg_on = [] { const char *e = getenv("SGAM_HPC_DBG"); return (e && e[0] == '1') ? 1 : 0; }();
-        static unsigned long long *dbg_buf = nullptr;
-        if (dbg_on) {
-            if (!dbg_buf && hipMalloc((void **)&dbg_buf, 128 * 8) != hipSuccess) dbg_buf = nullptr;
-            if (dbg_buf) (void)hipMemsetAsync(dbg_buf, 0, 128 * 8, s);
-            p.dbg = dbg_buf;
-        }
-        if (ht == 0) HPC_LAUNCH(0); else HPC_LAUNCH(1);
-#undef HPC_LAUNCH
-        SGAM_LAUNCH_CHECK();
-        if (dbg_on && dbg_buf) {               // debug only: synchronises and prints workgroup 0's stamps relative to its first
-            unsigned long long h[128];
-            if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h, dbg_buf, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
-                const unsigned long long t0 = h[0] < h[64] ? h[0] : h[64];
-                fprintf(stderr, "HPC_DBG consumer:");
-                for (int i = 0; i < 64; ++i) if (h[i]) fprintf(stderr, " %d:%llu", i, h[i] - t0);
-                fprintf(stderr, "\nHPC_DBG producer:");
-                for (int i = 64; i < 128; ++i) if (h[i]) fprintf(stderr, " %d:%llu", i - 64, h[i] - t0);
-                fprintf(stderr, "\n");
-            }
-        }
-        return SGAM_OK;
-    }
     if (gn_partial_in) {
 #if SGAM_HNBRF == 6
         if (ht == 0 && p.gn_swish) SGAM_KLAUNCH((conv3x3_h16_halo_kernel<64, 128, 0, true, false, true, true, 6>), grid, dim3(256), 0, s, p);

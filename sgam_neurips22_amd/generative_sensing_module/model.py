@@ -144,30 +144,19 @@ class VQModel(nn.Module):
         return out
 
     # ---- NHWC core ----
-    def _stats_arena(self, t):
-        """the accumulator records of one pass over the encoder or the decoder at t's batch size (ops.StatsArena; one per
-        (device, batch size), created by the eager warm-up that precedes a graph capture)"""
-        arenas = self.__dict__.setdefault("_arenas", {})
-        key = (str(t.device), int(t.shape[0]))
-        if key not in arenas:
-            arenas[key] = ops.StatsArena(t.device, int(t.shape[0]))
-        return arenas[key]
-
     def _encode_nhwc(self, x, extrapolation_mask):
         """x (B,4,H,W) NCHW + mask -> pre-quant latent (B,h,w,D) NHWC fp32."""
         dt = self.compute_dtype
-        with ops.stats_arena(self._stats_arena(x)):
-            if self.use_extrapolation_mask:
-                h = ops.encode_head(x, extrapolation_mask, self.conv_in.weight, self.conv_in.bias, ld=32, dtype=dt)
-            else:
-                h = ops.cast(ops.nchw_to_nhwc(x, c_pad=32), dt)
-            return self.quant_conv.forward_nhwc(self.encoder.forward_nhwc(h), out_dtype=torch.float32)
+        if self.use_extrapolation_mask:
+            h = ops.encode_head(x, extrapolation_mask, self.conv_in.weight, self.conv_in.bias, ld=32, dtype=dt)
+        else:
+            h = ops.cast(ops.nchw_to_nhwc(x, c_pad=32), dt)
+        return self.quant_conv.forward_nhwc(self.encoder.forward_nhwc(h), out_dtype=torch.float32)
 
     def _decode_nhwc(self, quant_nhwc):
         """fp32 quantised latent (B,h,w,D) -> fp32 RGB-D (B,H,W,4)."""
-        with ops.stats_arena(self._stats_arena(quant_nhwc)):
-            q = ops.cast(quant_nhwc, self.compute_dtype)
-            return self.decoder.forward_nhwc(self.post_quant_conv.forward_nhwc(q))
+        q = ops.cast(quant_nhwc, self.compute_dtype)
+        return self.decoder.forward_nhwc(self.post_quant_conv.forward_nhwc(q))
 
     # ---- reference API ----
     def encode(self, x, topk=None, encoding_indices=None, extrapolation_mask=None, use_old=False, sample_number=1):

@@ -200,31 +200,23 @@ class AttnBlock(_NHWCModule):
         if x.dtype in ops.H16:
             return self._forward_nhwc_h16(x, wqkv, bqkv, wp, bp)
         fused_qkv = wkey == "f32x" and FUSE_NORM_INTO_QKV and ops.gemm_gn_fits(B * n, 3 * C, C, n)
-        pre = getattr(x, "_gn_partials", None)
-        if (fused_qkv and ops.ATTN_BLOCK_F32X and ops.ATTN_PROJ and ops.attention_fusable(n, C) and isinstance(wp, ops.SplitWeight)
-                and not (pre is not None and pre[1] == 0)):
+        if fused_qkv and ops.ATTN_BLOCK_F32X and ops.ATTN_PROJ and ops.attention_fusable(n, C) and isinstance(wp, ops.SplitWeight):
             # the whole block in three launches: GroupNorm + q | k | v with K / V^T written straight in the attention's fragment order
             # (the GEMM + split launch's arithmetic, equal to fp32 round-off), one pass over the keys, merge + proj_out + residual (csrc/attention.hip)
             if "f32x_perm" not in wqkvs:
                 w32 = wqkvs[torch.float32]
                 wqkvs["f32x_perm"] = ops.split_rows(ops.permute_rows_for_transposed_product(w32), wqkv.scale)
-            infold = (ops.ATTN_FOLD and pre is not None and pre[0].dtype == torch.float64 and 1 <= pre[1] <= 128)
-            mr = None if infold else ops.groupnorm_meanrstd(x, self.norm.eps)      # (<= 128 chunk records: folded inside the front end)
+            mr = ops.groupnorm_meanrstd(x, self.norm.eps)
             ob = ops.attn_block_f32x(x.reshape(B * n, C), mr, self.norm.weight.detach(), self.norm.bias.detach(), wqkvs["f32x_perm"], bqkv,
-                                     C, int(C) ** (-0.5), wp, bp, B=B, pre=pre, eps=self.norm.eps)
+                                     C, int(C) ** (-0.5), wp, bp, B=B)
             out = ob.view(B, H, W, C)
             if hasattr(ob, "_gn_partials"):
                 out._gn_partials = ob._gn_partials
             return out
         if fused_qkv:
             # GroupNorm applied while the q | k | v GEMM stages its operand (csrc/gemm_gn_f32x.hip): no normalise pass
-            pre = getattr(x, "_gn_partials", None)
-            if pre is not None and pre[1] == 0:      # statistics of x as its producer's accumulators: finished inside the GEMM
-                qkv_all = ops.gemm_gn_f32x(x.reshape(B * n, C), None, self.norm.weight.detach(), self.norm.bias.detach(), wqkv, bqkv, n,
-                                           acc=pre[0], eps=self.norm.eps)
-            else:
-                mr = ops.groupnorm_meanrstd(x, self.norm.eps)
-                qkv_all = ops.gemm_gn_f32x(x.reshape(B * n, C), mr, self.norm.weight.detach(), self.norm.bias.detach(), wqkv, bqkv, n)
+            mr = ops.groupnorm_meanrstd(x, self.norm.eps)
+            qkv_all = ops.gemm_gn_f32x(x.reshape(B * n, C), mr, self.norm.weight.detach(), self.norm.bias.detach(), wqkv, bqkv, n)
             table, h = None, None
         elif FUSE_GROUPNORM_INTO_CONV:
             table, h = self.norm.stats_nhwc(x), x                         # (B, C, 2), no swish for attention

@@ -127,12 +127,11 @@ class SplitWeight:
     """fp32 matrix (N, K) pre-split into fp16 hi / lo halves of scale * w in MFMA-fragment order
     [Np/32][Kp/32][256 pieces][8 halfs] (N, K rounded up to 32; piece = ((plane*2 + k-step)*2 + k-half)*32 + row): the
     B operand of one v_mfma_f32_32x32x16_f16 is one contiguous kilobyte (conv_f32x.hip)."""
-    __slots__ = ("planes", "scale", "shape", "arrive")
+    __slots__ = ("planes", "scale", "shape")
 
     def __init__(self, planes, scale, n=None, k=None, transient=False):
         np_, kp = planes.shape[0] * 32, planes.shape[1] * 32
         self.planes, self.scale, self.shape = planes, scale, (np_ if n is None else n, kp if k is None else k)
-        self.arrive = False if transient else None      # split-K arrival counters of the layer that owns this weight (_arrive)
 
     def stride(self, dim):
         return self.planes.shape[1] * 32 if dim == 0 else 1       # logical row length (ldb), in K elements
@@ -340,11 +339,6 @@ def conv_plan(desc, h16=False, split=False):
     return bm.value, bn.value, ks.value
 
 
-# split-K arrival counters (sgam_conv_desc.arrive): one small zeroed int32 array per LAYER, kept on its weight — launches of one
-# layer are ordered on one stream, two model instances (ConcurrentScenes) own separate weights, and the kernels leave the
-# counters zero.  Created outside stream capture only (the eager warm-up ahead of a capture does it): a torch.zeros inside a
-# capture would become a fill node of every replay.  SGAM_XFIXUP=0: partial tiles + combine launch, as before.
-XFIXUP = os.environ.get("SGAM_XFIXUP", "0") == "1"
 # 16-bit AttnBlock: GroupNorm + q | k | v + fragment split as ONE launch in front of the fused attention (SGAM_ATTN_BLOCK_H16=0: the
 # normalise pass, the generic 1x1 GEMM and the split launch, as before)
 ATTN_BLOCK_H16 = os.environ.get("SGAM_ATTN_BLOCK_H16", "1") != "0"
@@ -353,105 +347,13 @@ ATTN_BLOCK_H16_PROJ = os.environ.get("SGAM_ATTN_BLOCK_H16_PROJ", "1") != "0"    
 ATTN_BLOCK_F32X = os.environ.get("SGAM_ATTN_BLOCK_F32X", "1") != "0"
 # the small AttnBlocks' attention (16 x 16 maps) as one launch instead of the seven of the GEMM chain (SGAM_ATTN_SMALL=0: the chain)
 ATTN_SMALL = os.environ.get("SGAM_ATTN_SMALL", "1") != "0"
-# opt-in: the fused AttnBlock front ends fold <= 128 chunk statistics of their input themselves instead of a statistics / table launch in
-# front (measured break-even to slightly slower: a dependent round trip in every workgroup's prologue costs what the launch + edge cost)
-ATTN_FOLD = os.environ.get("SGAM_ATTN_FOLD", "0") == "1"
-ARRIVE_COUNT = 4096
-
-
-def _arrive(w, device):
-    if not XFIXUP:
-        return None
-    split = isinstance(w, SplitWeight)
-    t = w.arrive if split else getattr(w, "_sgam_arrive", None)
-    if t is False:
-        return None
-    if t is None or t.device != device:
-        if torch.cuda.is_current_stream_capturing():
-            return None
-        t = torch.zeros((ARRIVE_COUNT,), device=device, dtype=torch.int32)
-        t._sgam_stream = int(torch.cuda.current_stream(device).cuda_stream)
-        if split:
-            w.arrive = t
-        else:
-            w._sgam_arrive = t
-    # one launch at a time per counter array (include/sgam_hip.h): launches of ONE stream qualify; a second stream driving the same
-    # weight gets the partial tiles + combine launch instead of sharing the counters.  A stream CAPTURE is the exception that keeps
-    # the rule: the model's warm-up ran on its side stream, the capture runs on torch's private capture stream right behind it, and
-    # the captured launches are one dependency chain wherever the graph is replayed — the capture inherits the counters (without
-    # this the fix-up was silently inert in every replayed frame: round 5 measured "198 launches" with and without SGAM_XFIXUP=1).
-    if torch.cuda.is_current_stream_capturing():
-        return t
-    if getattr(t, "_sgam_stream", None) != int(torch.cuda.current_stream(device).cuda_stream):
-        return None
-    return t
-
-
-# GroupNorm statistics as accumulators (sgam_conv_desc.stats_acc, csrc/sgam_common.h): a pass of a model lends every producing launch
-# a zeroed [B][16 replicas][32][4] int64 record from ONE arena that is cleared once at the start of the pass; the launch adds its partial sums
-# with integer atomics and the consumer reads the finished sums — the fold launch between every producer / consumer pair
-# (33 - 39 per frame) is gone.  Tensors carry the record as `_gn_partials = (record, 0)`: chunk count 0 = accumulator form.
-# Outside a pass (no arena active) launches leave chunk records as before.  SGAM_STATS_ACC=0 switches the arenas off.
-STATS_ACC = os.environ.get("SGAM_STATS_ACC", "0") == "1"
-_ARENA = None
-
-
-STATS_R = int(os.environ.get("SGAM_STATS_R", "16"))   # replicas of a record (SGAM_STATS_R of csrc/sgam_common.h: a variant build's value travels in the environment)
-STATS_RECORD = STATS_R * 32 * 4                   # int64 words per image
-
-
-class StatsArena:
-    SLOTS = 96                                    # producing launches per pass (a half of the 256^2 VQGAN forward has < 60)
-
-    def __init__(self, device, B):
-        self.buf = torch.zeros((self.SLOTS * B * STATS_RECORD,), device=device, dtype=torch.int64)
-        self.off = 0
-
-    def begin(self):
-        if os.environ.get("SGAM_STATS_ZERO") == "mul":
-            self.buf.mul_(0)
-        else:
-            self.buf.zero_()                      # one fill launch per pass (a memset node of a captured graph)
-        self.off = 0
-
-    def take(self, B):
-        n = B * STATS_RECORD
-        if self.off + n > self.buf.numel():
-            return None
-        t = self.buf[self.off:self.off + n]
-        self.off += n
-        return t
-
-
-class stats_arena:
-    """with ops.stats_arena(arena): ...   — convolutions inside leave / take GroupNorm statistics as accumulators of `arena`"""
-
-    def __init__(self, arena):
-        self.arena = arena if STATS_ACC else None
-
-    def __enter__(self):
-        global _ARENA
-        self.old, _ARENA = _ARENA, self.arena
-        if self.arena is not None:
-            self.arena.begin()
-        return self.arena
-
-    def __exit__(self, *exc):
-        global _ARENA
-        _ARENA = self.old
-        return False
 
 
 def _stats_out(desc, x, chunks):
-    """(record tensor, chunk count) for the statistics of a launch that can deliver `chunks` > 0 chunk records per image: an
-    accumulator of the active arena (chunk count 0, desc.stats_acc set) or a fresh [B][chunks][32][2] fp64 buffer"""
+    """(record tensor, chunk count) for the GroupNorm statistics of a launch that delivers `chunks` > 0 chunk records per image:
+    a fresh [B][chunks][32][2] fp64 buffer"""
     if chunks <= 0:
         return None, 0
-    if _ARENA is not None:
-        acc = _ARENA.take(desc.B)
-        if acc is not None:
-            desc.stats_acc = 1
-            return acc, 0
     return torch.empty((desc.B * chunks * 32 * 2,), device=x.device, dtype=torch.float64), chunks
 
 
@@ -461,10 +363,6 @@ def _run_conv(desc, x, w, bias, residual, out, gn=None, a_scale=1.0, norm=None):
     lib = _lib.load()
     split = isinstance(w, SplitWeight)
     _apply_plan(desc, "f32x" if split else x.dtype)
-    if split:                                     # (split-fp32 family only: the 16-bit kernels have no in-kernel fix-up)
-        arr = _arrive(w, x.device)
-        if arr is not None:
-            desc.arrive, desc.arrive_count = arr.data_ptr(), arr.numel()
     if norm is not None:
         gamma, beta, swish, groups, eps = norm
         fusable = (split and FUSE_GN_APPLY and x.dtype == torch.float32 and x.dim() == 4 and groups == 32 and eps == 1e-6
@@ -658,20 +556,14 @@ def gemm_gn_fits(M, N, K, HW):
     return F32_MODE == "split" and _lib.load().sgam_gemm_gn_f32x_fits(M, N, K, HW) == 1
 
 
-def gemm_gn_f32x(x2d, mean_rstd, gamma, beta, w, bias, hw, acc=None, eps=1e-6):
+def gemm_gn_f32x(x2d, mean_rstd, gamma, beta, w, bias, hw):
     """out[M][N] = GroupNorm(x)[M][K] @ W^T + bias with the normalisation fused into the operand staging (AttnBlock's q | k | v
     projection on the split-fp32 path; csrc/gemm_gn_f32x.hip).  x2d (M, K) fp32 rows of NHWC pixels, `hw` rows per image,
-    mean_rstd (B, 32, 2) — or `acc`, the statistics of x as the accumulators its producer left — w a SplitWeight of the stacked
-    (N, K) weights."""
+    mean_rstd (B, 32, 2), w a SplitWeight of the stacked (N, K) weights."""
     _need_cuda(x2d)
     M, K = x2d.shape
     N = w.shape[0]
     out = torch.empty((M, N), device=x2d.device, dtype=torch.float32)
-    if acc is not None:
-        check(_lib.load().sgam_gemm_gn_acc_f32x(_p(x2d), x2d.stride(0), _p(acc), float(eps), _p(_f32c(gamma)), _p(_f32c(beta)),
-                                                _p(w.planes), float(w.scale), _p(bias), _p(out), N, M, N, K, hw, _stream()),
-              "sgam_gemm_gn_acc_f32x")
-        return out
     check(_lib.load().sgam_gemm_gn_f32x(_p(x2d), x2d.stride(0), _p(mean_rstd), _p(_f32c(gamma)), _p(_f32c(beta)), _p(w.planes),
                                         float(w.scale), _p(bias), _p(out), N, M, N, K, hw, _stream()), "sgam_gemm_gn_f32x")
     return out
@@ -835,17 +727,12 @@ def attention_proj(qkv, C, scale, wp, bias, residual, out=None, B=1):
     if out is None:
         out = torch.empty((nt, C), device=qkv.device, dtype=torch.float32)
     assert out.stride(1) == 1 and (residual is None or (residual.stride(1) == 1 and residual.dtype == torch.float32))
-    chunks, partial, acc = n // 32, None, 0
-    if FUSE_GN_STATS:
-        rec = _ARENA.take(B) if _ARENA is not None else None              # accumulator form while a statistics arena is active
-        if rec is not None:
-            partial, chunks, acc = rec, 0, 1
-        else:
-            partial = torch.empty((B * chunks * 32 * 2,), device=qkv.device, dtype=torch.float64)
+    chunks = n // 32
+    partial = torch.empty((B * chunks * 32 * 2,), device=qkv.device, dtype=torch.float64) if FUSE_GN_STATS else None
     check(lib.sgam_attention_proj_f32x_batched(_p(qkv), _p(qkv[:, C:]), _p(qkv[:, 2 * C:]), qkv.stride(0), n, C, B, float(scale),
                                                _p(wp.planes), float(wp.scale), _p(bias), _p(residual),
                                                residual.stride(0) if residual is not None else 0, _p(out), out.stride(0), _p(partial),
-                                               acc, _p(ws), ws_bytes, _stream()), "sgam_attention_proj_f32x_batched")
+                                               _p(ws), ws_bytes, _stream()), "sgam_attention_proj_f32x_batched")
     if partial is not None:
         out._gn_partials = (partial, chunks)
     return out
@@ -864,7 +751,7 @@ def permute_rows_for_transposed_product(w2d):
     return w2d.index_select(0, idx).contiguous()
 
 
-def attn_block_f32x(x2d, mean_rstd, gamma, beta, wqkv_perm, bqkv, C, scale, wp, bp, B=1, out=None, pre=None, eps=1e-6):
+def attn_block_f32x(x2d, mean_rstd, gamma, beta, wqkv_perm, bqkv, C, scale, wp, bp, B=1, out=None):
     """The whole AttnBlock of the split-fp32 path (reference diffusionmodules/model.py:168-192) in three launches: fused front end
     (GroupNorm + q | k | v, K / V^T straight in fragment order), one-pass attention, merge + proj_out + residual x.  wqkv_perm: the
     SplitWeight of permute_rows_for_transposed_product(stacked weight); statistics of the output travel as `_gn_partials`."""
@@ -880,23 +767,11 @@ def attn_block_f32x(x2d, mean_rstd, gamma, beta, wqkv_perm, bqkv, C, scale, wp, 
     ws = torch.empty((ws_bytes,), device=x2d.device, dtype=torch.uint8)
     if out is None:
         out = torch.empty((nt, C), device=x2d.device, dtype=torch.float32)
-    chunks, partial, acc = n // 32, None, 0
-    if FUSE_GN_STATS:
-        rec = _ARENA.take(B) if _ARENA is not None else None
-        if rec is not None:
-            partial, chunks, acc = rec, 0, 1
-        else:
-            partial = torch.empty((B * chunks * 32 * 2,), device=x2d.device, dtype=torch.float64)
-    if mean_rstd is None:
-        # pre = (chunk records, chunks <= 128) of x's producer: folded inside the front end (no statistics launch)
-        check(lib.sgam_attn_block_gnp_f32x(_p(x2d), x2d.stride(0), _p(pre[0]), int(pre[1]), float(eps), _p(_f32c(gamma)), _p(_f32c(beta)),
-                                           _p(wqkv_perm.planes), float(wqkv_perm.scale), _p(bqkv), n, C, B, float(scale), _p(wp.planes),
-                                           float(wp.scale), _p(bp), _p(out), out.stride(0), _p(partial), acc, _p(ws), ws_bytes, _stream()),
-              "sgam_attn_block_gnp_f32x")
-    else:
-        check(lib.sgam_attn_block_f32x(_p(x2d), x2d.stride(0), _p(mean_rstd), _p(_f32c(gamma)), _p(_f32c(beta)), _p(wqkv_perm.planes),
-                                       float(wqkv_perm.scale), _p(bqkv), n, C, B, float(scale), _p(wp.planes), float(wp.scale), _p(bp),
-                                       _p(out), out.stride(0), _p(partial), acc, _p(ws), ws_bytes, _stream()), "sgam_attn_block_f32x")
+    chunks = n // 32
+    partial = torch.empty((B * chunks * 32 * 2,), device=x2d.device, dtype=torch.float64) if FUSE_GN_STATS else None
+    check(lib.sgam_attn_block_f32x(_p(x2d), x2d.stride(0), _p(mean_rstd), _p(_f32c(gamma)), _p(_f32c(beta)), _p(wqkv_perm.planes),
+                                   float(wqkv_perm.scale), _p(bqkv), n, C, B, float(scale), _p(wp.planes), float(wp.scale), _p(bp),
+                                   _p(out), out.stride(0), _p(partial), _p(ws), ws_bytes, _stream()), "sgam_attn_block_f32x")
     if partial is not None:
         out._gn_partials = (partial, chunks)
     return out

@@ -48,8 +48,7 @@ def test_conv_desc_layout_matches_header():
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     fields = [f.strip().lstrip("*") for decl in re.findall(r"int32_t ([^;]+);", body) for f in decl.split(",")]
     assert fields == [n for n, _ in _lib.ConvDesc._fields_]
-    # the trailing pointer (`int32_t *arrive`) sits on its natural 8-byte boundary in both views of the struct
-    assert _lib.ConvDesc.arrive.offset == 96 and ctypes.sizeof(_lib.ConvDesc) == 104
+    assert ctypes.sizeof(_lib.ConvDesc) == 4 * len(_lib.ConvDesc._fields_) == 88
 
 
 def test_argument_validation_without_gpu():
