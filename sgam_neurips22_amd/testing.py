@@ -68,6 +68,12 @@ def rect_hole_input(B, H, W, seed=3, hole_frac=0.3):
     return x, mask
 
 
+def config1_input(res=256):
+    """BASELINE config 1: x = seeded U(-1, 1) (1, 4, res, res), extrapolation mask all false"""
+    g = torch.Generator().manual_seed(1)
+    return torch.rand((1, 4, res, res), generator=g) * 2 - 1, torch.zeros((1, 1, res, res), dtype=torch.bool)
+
+
 def seeded_tensor(tag, shape, scale=1.0, shift=0.0):
     """Deterministic N(shift, scale^2) fp32 tensor keyed by a string tag (inputs of the per-op fixtures)."""
     g = torch.Generator().manual_seed(zlib.crc32(tag.encode()) % (2 ** 31))

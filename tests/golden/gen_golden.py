@@ -8,7 +8,8 @@ Fixtures
   splat_*.npz      render_projection_from_srcs_fast (warp.py:193-286), torch.use_deterministic_algorithms(True)
   invwarp_*.npz    InfiniteSceneGeneration.inverse_warping (inference_pipeline.py:662-743)
   vqgan_ops.npz    ResnetBlock / AttnBlock / Downsample / Upsample / GroupNorm+swish / VectorQuantizer2
-  vqgan_full_*.npz VQModel.forward on seeded synthetic weights + margin-guarded codebook
+  vqgan_full_*.npz VQModel.forward on seeded synthetic weights + margin-guarded codebook (clevr256_argmin = BASELINE config 1
+                   verbatim: CLEVR, U(-1, 1) input, mask all false, topk=None, get_codebook_count=True)
   trajectory_ge.npz 3 steps of InfiniteSceneGeneration.one_step_prediction (GoogleEarth seed0)
   vqgan_topk4_s2.npz        VQModel.forward(topk=4, sample_number=2): get_multiple_codewords' sampling branch (CPU RNG)
   config5_ge512_b4.npz      BASELINE config 5: 512x512, four warp candidates (two real template sources) -> get_x -> forward
@@ -98,14 +99,14 @@ def gen_ops():
     save("vqgan_ops.npz", **out)
 
 
-def gen_full(dataset, res, tag, topk=None):
+def gen_full(dataset, res, tag, topk=None, plain_input=False):
     print(f"full model {dataset} {res}x{res} topk={topk}")
     p = R.load_params(dataset)
     torch.manual_seed(0)
     model = VQModel(**p).eval()
     sd = testing.synthetic_state_dict(model.state_dict(), seed=0)
     model.load_state_dict(sd)
-    x, mask = testing.rect_hole_input(1, res, res, seed=3)
+    x, mask = testing.config1_input(res) if plain_input else testing.rect_hole_input(1, res, res, seed=3)
     with torch.no_grad():
         pre = model.encode(x, extrapolation_mask=mask)[3]
     z = pre.permute(0, 2, 3, 1).reshape(-1, pre.shape[1])
@@ -136,7 +137,7 @@ def gen_full(dataset, res, tag, topk=None):
     save(f"vqgan_full_{tag}.npz", dataset=dataset, res=res, zmean=zmean, zstd=zstd, cb_seed=cb_seed, **extra,
          weight_abs_sums=wsum, dec_sub=dec[..., ::step, ::step], dec_step=step, dec_sum=float(dec.double().sum()),
          dec_abs_sum=float(dec.double().abs().sum()), indices=idx, pre_quant=pre, quant=quant,
-         topk=-1 if topk is None else topk)
+         topk=-1 if topk is None else topk, plain_input=int(plain_input))
 
 
 def gen_trajectory(rgb0, dm0):
@@ -648,6 +649,9 @@ if __name__ == "__main__":
         gen_full("google_earth", 64, "ge64")
         gen_full("google_earth", 256, "ge256")
         gen_full("clevr-infinite", 256, "clevr256_topk1", topk=1)
+    if not only or "config1" in only:
+        # BASELINE config 1 verbatim: CLEVR (16 384 codes), forward(x, extrapolation_mask, get_codebook_count=True), arg-min path
+        gen_full("clevr-infinite", 256, "clevr256_argmin", plain_input=True)
     if not only or "traj" in only:
         gen_trajectory(rgb0, dm0)
     if not only or "topk4" in only:

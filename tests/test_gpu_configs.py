@@ -437,6 +437,32 @@ def test_clevr_rgbd_branch_uses_once_converted_seed_depth():
     assert torch.equal(res["x"][:, :3], want)
 
 
+@pytest.mark.parametrize("dataset,grid", [("google_earth", (100, 1)), ("clevr-infinite", (20, 20))])
+def test_scene_constructed_with_the_reference_scripts_exact_arguments(dataset, grid):
+    """`main_scene_generation.py:46-53` verbatim: model `.to('cuda:0').eval()`, the three seeds, then
+    `InfiniteSceneGeneration(model, data, seed_index=args.seed_index, use_rgbd_integration=args.use_rgbd_integration,
+    offscreen_rendering=args.offscreen_rendering)` with argparse's defaults — seed_index the STRING "0", both flags True — i.e.
+    the default CLI path: the TSDF branch, the reference's default grid (100 x 1 / 20 x 20), num_src 3 / 5.  Two steps of its
+    `scene_expansion` loop body run (templates/ is absent on this box: synthetic seed frame, announced by a warning)."""
+    import random
+    import warnings
+    model = VQModel(**default_params(dataset)).to("cuda:0").eval()
+    random.seed(10)
+    np.random.seed(29)
+    torch.random.manual_seed(3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        framework = InfiniteSceneGeneration(model, dataset, seed_index="0", use_rgbd_integration=True, offscreen_rendering=True)
+    assert framework.output_dim == grid and framework.num_src == (3 if dataset == "google_earth" else 5)
+    assert framework.use_rgbd_integration and model.use_rgbd_integration and framework.volume is not None
+    assert len(framework._ordered_grid_coords) == grid[0] * grid[1] and framework.curr == 1
+    for _ in range(2):                                         # the body of scene_expansion (:436-440)
+        res = framework.one_step_prediction(framework.next_pose(framework.curr))
+        framework.curr += 1
+        assert res["rgbd"].shape == (4, 256, 256) and torch.isfinite(res["rgbd"]).all()
+    assert len(framework.frames) == 3 and framework.volume.check() > 0
+
+
 # ------------------------------------------------------------------------------------------------ split-fp32 range guard
 def test_split_fp32_range_guard_fires_and_recovers():
     """the split-fp32 path needs |x| < 65520 on operands that are not GroupNorm-ed first (the

@@ -155,6 +155,35 @@ def test_clevr_topk1_step_config2(golden):
     assert _maxerr(decs[0][0][..., ::2, ::2], g["dec_sub"]) <= TOL
 
 
+@pytest.mark.parametrize("mode", ["split", "mfma"])
+def test_clevr_argmin_forward_config1(golden, mode):
+    """BASELINE config 1 verbatim on the GPU: CLEVR-Infinite (16 384 codes), one 256 x 256 RGB-D frame, U(-1, 1) input, extrapolation
+    mask all false, `forward(x, extrapolation_mask=mask, get_codebook_count=True)` — encode -> arg-min quantise -> decode, no sampler —
+    against the reference's own outputs (tests/golden/gen_golden.py config1): all 256 indices bit-exact, latent / quantised / decoded
+    within 1e-4, the commitment loss; and against the oracle on the full decoded tensor."""
+    g = golden("vqgan_full_clevr256_argmin.npz")
+    assert int(g["topk"]) == -1 and int(g["plain_input"]) == 1
+    ops.set_f32_mode(mode)
+    try:
+        m, sd, p = _model("clevr-infinite", g)
+        assert p["n_embed"] == 16384
+        x, mask = testing.config1_input(256)
+        with torch.no_grad():
+            out = m(x.to(DEV), extrapolation_mask=mask.to(DEV), get_codebook_count=True)
+            dec, diff, idx = out
+            _, _, _, pre, quant = m(x.to(DEV), extrapolation_mask=mask.to(DEV), get_codebook_count=True, get_pre_quantized_feature=True,
+                                    get_quantized_feature=True)
+        assert len(out) == 3 and dec.shape == (1, 4, 256, 256) and idx.shape == (1, 16, 16) and idx.dtype == torch.int64
+        assert torch.equal(idx.cpu(), torch.from_numpy(g["indices"])), "codebook indices must be bit-exact"
+        assert _maxerr(pre, g["pre_quant"]) <= TOL and _maxerr(quant, g["quant"]) <= TOL
+        assert _maxerr(dec[..., ::2, ::2], g["dec_sub"]) <= TOL
+        assert abs(float(diff) - float(g["emb_loss"])) <= 1e-6 * max(1.0, abs(float(g["emb_loss"])))
+        o = OV.forward(sd, p["ddconfig"], x, mask)
+        assert _maxerr(dec, o["dec"]) <= TOL
+    finally:
+        ops.set_f32_mode("split")
+
+
 def test_encode_decode_api_shapes():
     m = VQModel(**default_params("google_earth")).to(DEV).eval()
     x, mask = testing.rect_hole_input(2, 64, 64)

@@ -55,7 +55,7 @@ def _ref_like_sd(dataset):
 
 
 @pytest.mark.parametrize("name,dataset", [("ge64", "google_earth"), ("ge256", "google_earth"),
-                                          ("clevr256_topk1", "clevr-infinite")])
+                                          ("clevr256_topk1", "clevr-infinite"), ("clevr256_argmin", "clevr-infinite")])
 def test_vqgan_oracle_matches_reference(golden, name, dataset):
     g = golden(f"vqgan_full_{name}.npz")
     p = default_params(dataset)
@@ -65,7 +65,9 @@ def test_vqgan_oracle_matches_reference(golden, name, dataset):
     sd["quantize.embedding.weight"] = testing.codebook_from_stats(float(g["zmean"]), float(g["zstd"]), p["n_embed"], 256,
                                                                   int(g["cb_seed"]))
     res = int(g["res"])
-    x, mask = testing.rect_hole_input(1, res, res, seed=3)
+    # (clevr256_argmin = BASELINE config 1 verbatim: U(-1, 1) input, mask all false, arg-min path)
+    plain = "plain_input" in g.files and int(g["plain_input"])
+    x, mask = testing.config1_input(res) if plain else testing.rect_hole_input(1, res, res, seed=3)
     topk = int(g["topk"])
     torch.manual_seed(3)
     o = OV.forward(sd, p["ddconfig"], x, mask, topk=None if topk < 0 else topk)
