@@ -553,7 +553,8 @@ int sgam_gemm_gn_f32x(const float *x, int32_t lda, const float *mean_rstd, const
  * consumes the depth.
  *   unit_table [dims.z][dims.y][dims.x] int32, -1 = closed, else brick index | 0x40000000 once the brick holds part of
  *   the truncation band (the ray cast only marches those); unit_stamp same shape, 0-initialised;
- *   counters int32[4] = {bricks allocated, length of this step's brick list, samples outside the box, pool overflows};
+ *   counters int32[4 * 32], zero-initialised: counter k at index 32 k (one 128-byte line each: same-line atomics are serialised)
+ *   = {bricks allocated, length of this step's brick list, samples outside the box, pool overflows};
  *   brick_tsdf [max_bricks][16*16*16] fp32 initialised to 2.0 (= unobserved: observed values are <= 1, so the ray cast
  *   needs no weight loads), brick_weight same shape, 0-initialised; brick_list int32[max_list] scratch.
  *   cam2world / world2cam: row-major 4x4 HOST values (copied into the kernel arguments: no upload, no device allocation

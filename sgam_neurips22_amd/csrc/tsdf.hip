@@ -43,6 +43,7 @@ constexpr int UV = UR * UR * UR;       // voxels per brick
 constexpr int NEAR_BIT = 0x40000000;   // unit table entry = brick index | NEAR_BIT once the brick holds part of the band
 constexpr int BRICK_MASK = 0x3FFFFFFF;
 // (bricks start at 2.0 = unobserved: observed TSDF values are <= 1, so the ray cast tells the two apart in the one load)
+constexpr int CS = 32;                 // the four counters sit CS int32 apart: one 128-byte line each (same-line atomics are serialised)
 constexpr int RS = 8;                  // depth segments (lanes) per ray in the ray cast
 
 typedef float F2u __attribute__((ext_vector_type(2), aligned(4)));
@@ -122,13 +123,13 @@ __global__ void tsdf_touch_kernel(const SrcSet S, int H, int W, float fx, float 
     int max_trips = trips;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) max_trips = max(max_trips, __shfl_xor(max_trips, o, 64));
+    int n_outside = 0;
     for (int it = 0; it < max_trips; ++it) {
         const bool act = it < trips;
         const int ux = lo[0] + it % nx, uy = lo[1] + (it / nx) % ny, uz = lo[2] + it / (nx * ny);
         const int64_t s = act ? unit_slot(g, ux, uy, uz) : -1;
         const bool outside = act && s < 0;
-        const unsigned long long m_out = __builtin_amdgcn_ballot_w64(outside);
-        if (m_out && (threadIdx.x & 63) == __builtin_ctzll(m_out)) atomicAdd(&counters[2], __builtin_popcountll(m_out));   // diagnostic
+        n_outside += __builtin_popcountll(__builtin_amdgcn_ballot_w64(outside));       // (wave-uniform; one atomic per wavefront at the end)
         // one lane per DISTINCT unit of the wavefront's visit talks to memory (neighbouring samples open the same unit: up to
         // 64 same-address atomics otherwise).  Election is register work: peel the lowest undecided lane, claim every lane
         // that holds the same slot.
@@ -160,12 +161,12 @@ __global__ void tsdf_touch_kernel(const SrcSet S, int H, int W, float fx, float 
         if (m_need) {
             int base = 0;
             const int l0 = __builtin_ctzll(m_need);
-            if ((threadIdx.x & 63) == l0) base = atomicAdd(&counters[0], __builtin_popcountll(m_need));
+            if ((threadIdx.x & 63) == l0) base = atomicAdd(&counters[0 * CS], __builtin_popcountll(m_need));
             base = __shfl(base, l0, 64);
             if (need) {
                 brick = base + __builtin_popcountll(m_need & lanes_below);
                 if (brick >= max_bricks) {
-                    atomicAdd(&counters[3], 1);          // pool exhausted (diagnostic); unit stays closed
+                    atomicAdd(&counters[3 * CS], 1);          // pool exhausted (diagnostic); unit stays closed
                     first = false;
                 } else {
                     table[s] = brick;
@@ -176,7 +177,7 @@ __global__ void tsdf_touch_kernel(const SrcSet S, int H, int W, float fx, float 
         if (m_list) {
             int base = 0;
             const int l1 = __builtin_ctzll(m_list);
-            if ((threadIdx.x & 63) == l1) base = atomicAdd(&counters[1], __builtin_popcountll(m_list));
+            if ((threadIdx.x & 63) == l1) base = atomicAdd(&counters[1 * CS], __builtin_popcountll(m_list));
             base = __shfl(base, l1, 64);
             if (first) {
                 const int li = base + __builtin_popcountll(m_list & lanes_below);
@@ -184,6 +185,7 @@ __global__ void tsdf_touch_kernel(const SrcSet S, int H, int W, float fx, float 
             }
         }
     }
+    if (n_outside && (threadIdx.x & 63) == 0) atomicAdd(&counters[2 * CS], n_outside);      // samples outside the scene box (diagnostic)
 }
 
 // per-pixel camera-distance multiplier sqrt(((u - cx) / fx)^2 + ((v - cy) / fy)^2 + 1) of the integration rule: a function of the
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(256, SGAM_TSDF_LB) void tsdf_integrate_kernel(const
                                                              const int *__restrict__ list, int max_list,
                                                              float *__restrict__ tsdf, float *__restrict__ weight,
                                                              float *__restrict__ color, const float *__restrict__ ray_mult) {
-    int n = counters[1];
+    int n = counters[1 * CS];
     if (n > max_list) n = max_list;
     const float inv_trunc = __fdiv_rn(1.0f, g.trunc);
     const float safe_w = __fsub_rn((float)W, 0.0001f), safe_h = __fsub_rn((float)H, 0.0001f);
@@ -772,7 +774,7 @@ extern "C" int sgam_tsdf_integrate_srcs_f32(const sgam_tsdf_grid *grid, const sg
     }
     const TsdfGrid g = to_dev(grid);
     hipStream_t s = sgam_stream(stream);
-    hipError_t e = hipMemsetAsync(counters + 1, 0, sizeof(int32_t), s);       // this step's list length
+    hipError_t e = hipMemsetAsync(counters + 1 * CS, 0, sizeof(int32_t), s);       // this step's list length
     if (e != hipSuccess) return (int)e;
     const int stride = 4;                                                      // Open3D depth_sampling_stride
     const int ns = ((W + stride - 1) / stride) * ((H + stride - 1) / stride);

@@ -130,9 +130,10 @@ class InfiniteSceneGeneration:
         constructor sets trajectory_shape = 'grid' (:67, :82) and fills `grid_res/<data>_seed<k>` with the seed frame, so its
         'spiral' / 'cylinder' / 'trajectory' pose sets (:206-421) and the known-frame map (:144-155) are reachable only by
         editing it.  Here they are arguments: the shape selects the pose set, and a `grid_transform_path` folder holding
-        `dm_<frame>_<ii>_<jj>.npy` + `im_<frame>_<ii>_<jj>.png` pairs (the layout export_to_disk writes — i.e. a previous run:
-        RESUME) marks those poses visited and loads them into the frame store as sources; 'trajectory' also reads
-        `cam0_to_world.txt` there."""
+        `dm_<frame>_<ii>_<jj>.npy` + `im_<frame>_<ii>_<jj>.png` pairs (the layout export_to_disk writes) marks those poses
+        visited and loads them into the frame store as KNOWN frames: a 'trajectory' run (which also reads `cam0_to_world.txt`
+        there) warps from them; the grid / spiral / cylinder loops regenerate every pose from index 1, like the reference's —
+        known frames there only seed `anchor_poses`, nothing is resumed."""
         if data not in _START:
             raise NotImplementedError(data)
         if trajectory_shape not in ("grid", "spiral", "cylinder", "trajectory"):
@@ -256,7 +257,8 @@ class InfiniteSceneGeneration:
             return known
         for f in Path(self.grid_transform_path).glob("dm*"):
             idx, gi, gj = (int(v) for v in f.name[3:-4].split("_")[:3])
-            known[(gi, gj)] = {"rgb_path": str(f).replace("dm", "im").replace("npy", "png"), "depth_path": str(f),
+            # (the sibling file by NAME: the reference's str.replace("dm", "im") rewrites those letters anywhere in the path)
+            known[(gi, gj)] = {"rgb_path": str(f.with_name("im" + f.name[2:-3] + "png")), "depth_path": str(f),
                                "orig_frame_idx": idx}
         return known
 
@@ -272,7 +274,7 @@ class InfiniteSceneGeneration:
         return node
 
     def _load_known_frames(self, known_map):
-        """RESUME: the known frames of the folder become sources exactly as the reference reads them back in
+        """the known frames of the folder enter the frame store exactly as the reference reads them back in
         prepare_batch_data (:534-537, 570-574): PIL LANCZOS resize of the PNG, nearest resize of the depth map, RGB through
         the uint8 codec.  The seed pose keeps the seed frame handed to the constructor."""
         if not known_map:
@@ -426,7 +428,14 @@ class InfiniteSceneGeneration:
 
     def get_src_grid_coords(self, tgt_grid_coord):
         if getattr(self, "trajectory_shape", "grid") == "trajectory":           # reference :531: the num_src poses just behind the target
-            return [(tgt_grid_coord[0] - i - 1, 0) for i in range(self.num_src)], None
+            # (the reference indexes tgt - i - 1 unchecked: close to the start that wraps to the END of the trajectory; here the
+            # sources are the poses that exist behind the target and hold a frame)
+            srcs = [(tgt_grid_coord[0] - i - 1, 0) for i in range(self.num_src) if tgt_grid_coord[0] - i - 1 >= 0]
+            srcs = [c for c in srcs if c in self.frames]
+            if not srcs:
+                raise ValueError(f"trajectory pose {tuple(tgt_grid_coord)} has no known frame behind it: a 'trajectory' run needs "
+                                 "the frame of the pose before its first target in grid_transform_path")
+            return srcs, None
         tgt = self.transform_grid[tgt_grid_coord[0]][tgt_grid_coord[1]]
         radius = 0.3 if self.data != "clevr-infinite" else 1
         found = []

@@ -748,10 +748,12 @@ def attn_block_h16(x2d, pre, gamma, beta, eps, w_frag, bias, C, scale, B=1, out=
     if out is None:
         out = torch.empty((nt, C), device=x2d.device, dtype=x2d.dtype)
     partial, chunks = pre
+    gamma, beta, bias = _f32c(gamma), _f32c(beta), _f32c(bias)      # (the kernel reads fp32: a .half() / .bfloat16() model is converted here)
     if proj is not None:
         # proj = (wp_frag, bp): the merge of the key ranges fused into proj_out + residual x — the whole block, with the chunk statistics
         # of what it stored for the GroupNorm that follows
         wp_frag, bp = proj
+        bp = _f32c(bp)
         po = torch.empty((B * (n // 32) * 32 * 2,), device=x2d.device, dtype=torch.float64) if FUSE_GN_STATS else None
         check(lib.sgam_attn_block_proj_h16(_p(x2d), x2d.stride(0), _p(partial), int(chunks), _p(gamma), _p(beta), float(eps), _p(w_frag),
                                            _p(bias), H16[x2d.dtype], n, C, B, float(scale), _p(wp_frag), _p(bp), _p(po), _p(out),

@@ -57,7 +57,7 @@ class TsdfVolume:
                              (ctypes.c_int32 * 3)(*map(int, dims)))
         self.unit_table = torch.full((n_units,), -1, dtype=torch.int32, device=device)
         self.unit_stamp = torch.zeros((n_units,), dtype=torch.int32, device=device)
-        self.counters = torch.zeros((4,), dtype=torch.int32, device=device)
+        self.counters = torch.zeros((4 * 32,), dtype=torch.int32, device=device)        # counter k at index 32 k (a cache line each)
         self.brick_tsdf = torch.full((self.max_bricks, UNIT ** 3), 2.0, dtype=torch.float32, device=device)   # 2 = unobserved
         self.brick_weight = torch.zeros((self.max_bricks, UNIT ** 3), dtype=torch.float32, device=device)
         self.brick_color = torch.zeros((self.max_bricks, UNIT ** 3, 3), dtype=torch.float32, device=device) if color else None
@@ -161,7 +161,7 @@ class TsdfVolume:
 
     def stats(self):
         """(bricks allocated, last frame's brick count, samples outside the box, pool overflows) — host sync."""
-        return tuple(int(v) for v in self.counters.cpu())
+        return tuple(int(v) for v in self.counters[::32].cpu())
 
     def check(self):
         """Raise when the fusion silently lost geometry: units that could not be opened because the brick pool was

@@ -115,3 +115,40 @@ def test_trainer_collectives_on_device_tensors_world1():
     out = _last_json(r)
     assert out["synced"] > 100 and out["bucket_bytes"] > 0
     assert out["l0"] == out["l0"] and out["l1"] == out["l1"]          # finite losses, two updates
+
+
+_SELF_LAUNCH_PROBE = r"""
+import json, os, torch
+from sgam_neurips22_amd import distributed as sdist
+import torch.distributed as dist
+rank, local_rank, world = sdist.init()
+dev = torch.device("cuda", local_rank)
+g = sdist.gather_metrics(7, 0.5, 11.0, dev, numa_node=sdist.pin_to_gpu_numa_node(local_rank))
+sdist.barrier()
+dist.destroy_process_group()
+print(json.dumps({"ipc": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), "world": world, "backend": g["rccl"]["backend"],
+                  "rccl": g["rccl"], "rec": g["per_rank_records"]}), flush=True)
+"""
+
+
+def test_self_launch_exports_the_ipc_mode_and_the_record_carries_the_diagnostics(tmp_path):
+    """`python bench.py --gpus N` without a launcher goes through distributed.self_launch: the child ranks must see
+    HSA_ENABLE_IPC_MODE_LEGACY=0 even when the parent's environment does not have it (dmabuf IPC only on this host driver: RCCL's peer
+    set-up fails otherwise), and the gathered record carries what a failing first multi-GPU run is diagnosed from — per-rank frames,
+    seconds, checksum, NUMA node, local rank, RCCL's version and its own NCCL_DEBUG=VERSION line(s).  World 1 through the same
+    launcher command line an N-GPU run uses."""
+    script = tmp_path / "probe.py"
+    script.write_text(_SELF_LAUNCH_PROBE)
+    env = {k: v for k, v in os.environ.items() if k not in ("HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG", "NCCL_DEBUG_FILE")}
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    env["TMPDIR"] = str(tmp_path)
+    code = ("import sys; from sgam_neurips22_amd import distributed as s; "
+            f"sys.exit(s.self_launch({str(script)!r}, [], 1))")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=560, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _last_json(r)
+    assert out["ipc"] == "0" and out["world"] == 1 and out["backend"] == "nccl"
+    assert out["rccl"]["version"] and out["rccl"]["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and out["rccl"]["env"]["NCCL_DEBUG"] == "VERSION"
+    rec = out["rec"]
+    assert len(rec) == 1 and rec[0]["rank"] == 0 and rec[0]["frames"] == 7.0 and rec[0]["checksum"] == 11.0 and rec[0]["local_rank"] == 0
+    assert "numa_node" in rec[0]
