@@ -96,8 +96,8 @@ def build_stamp(headers):
 
 def _digest(paths, flags):
     h = hashlib.sha256()
-    for p in sorted(paths):
-        h.update(p.encode())
+    for p in sorted(paths, key=os.path.basename):
+        h.update(os.path.basename(p).encode())          # (names, not locations: the GPU box unpacks the tree under another root)
         with open(p, "rb") as f:
             h.update(f.read())
     h.update(repr(flags).encode())

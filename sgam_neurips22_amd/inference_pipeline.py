@@ -429,13 +429,8 @@ class InfiniteSceneGeneration:
     def get_src_grid_coords(self, tgt_grid_coord):
         if getattr(self, "trajectory_shape", "grid") == "trajectory":           # reference :531: the num_src poses just behind the target
             # (the reference indexes tgt - i - 1 unchecked: close to the start that wraps to the END of the trajectory; here the
-            # sources are the poses that exist behind the target and hold a frame)
-            srcs = [(tgt_grid_coord[0] - i - 1, 0) for i in range(self.num_src) if tgt_grid_coord[0] - i - 1 >= 0]
-            srcs = [c for c in srcs if c in self.frames]
-            if not srcs:
-                raise ValueError(f"trajectory pose {tuple(tgt_grid_coord)} has no known frame behind it: a 'trajectory' run needs "
-                                 "the frame of the pose before its first target in grid_transform_path")
-            return srcs, None
+            # sources are the poses that exist behind the target — one_step_prediction checks that they hold a frame)
+            return [(tgt_grid_coord[0] - i - 1, 0) for i in range(self.num_src) if tgt_grid_coord[0] - i - 1 >= 0], None
         tgt = self.transform_grid[tgt_grid_coord[0]][tgt_grid_coord[1]]
         radius = 0.3 if self.data != "clevr-infinite" else 1
         found = []
@@ -567,6 +562,9 @@ class InfiniteSceneGeneration:
         src_coords, _ = self.get_src_grid_coords(tgt_pose_grid_coord)
         if not src_coords:       # the reference dies in np.stack([]) here (:596); e.g. the GoogleEarth spiral: poses 0.7 apart, radius 0.3
             raise ValueError(f"no visited pose within the source radius of {tuple(tgt_pose_grid_coord)}: nothing to warp from")
+        missing = [c for c in src_coords if c not in self.frames]
+        if missing:          # (a 'trajectory' run started without the frame of the pose behind its first target)
+            raise ValueError(f"source pose(s) {missing} of target {tuple(tgt_pose_grid_coord)} hold no frame: nothing to warp from")
         tgt_meta = self.transform_grid[tgt_pose_grid_coord[0]][tgt_pose_grid_coord[1]]
         src_metas = [self.transform_grid[c[0]][c[1]] for c in src_coords]
         batch = self.prepare_batch_data(tgt_meta, src_metas, self.num_src)
