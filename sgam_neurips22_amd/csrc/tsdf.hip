@@ -319,7 +319,7 @@ __device__ __forceinline__ int integrate_brick(const SrcSet &S, int rt_mask, int
             }
         }
         if (changed) {
-            bt[q] = t;
+            if (t != t_cur[j]) bt[q] = t;      // (free space seen as free space again: (1 w + 1) / (w + 1) = 1 — only the weight moves)
             bw[q] = w;
             if (COLOR) {
 #pragma unroll
