@@ -1,4 +1,4 @@
-import sys, time; sys.path.insert(0, "/root/repo")
+import os, sys, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from sgam_neurips22_amd import testing, ops
 from sgam_neurips22_amd.config import default_params
@@ -8,7 +8,13 @@ p = default_params("google_earth"); m = VQModel(**p)
 sd = testing.synthetic_state_dict(m.state_dict(), seed=0)
 sd["quantize.embedding.weight"] = testing.codebook_from_stats(0.0, 0.5, p["n_embed"], 256, 1)
 m.load_state_dict(sd); m = m.cuda().eval(); m.enable_hip_graph(True)
-sc = InfiniteSceneGeneration(m, "google_earth", output_dim=(40, 1), seed_frame=synthetic_seed_frame("google_earth", 0, 256), use_rgbd_integration=True)
+if os.environ.get("PLANE") == "1":          # consistent geometry (bench.PlaneDepthScene) instead of the generated noise depths
+    from bench import PlaneDepthScene as Scene
+else:
+    Scene = InfiniteSceneGeneration
+sc = Scene(m, "google_earth", output_dim=(40, 1), seed_frame=synthetic_seed_frame("google_earth", 0, 256), use_rgbd_integration=True)
+if os.environ.get("PLANE") == "1":
+    sc.prepare_planes()
 for _ in range(5):
     sc.one_step_prediction(sc.next_pose(sc.curr)); sc.curr += 1
 def T(f, n=10):

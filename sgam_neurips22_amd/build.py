@@ -50,7 +50,8 @@ SOURCES = {
     "train.hip": [],
     "build_info.hip": [],       # flags = the build stamp, filled in by build()
     "tsdf.hip": ["-ffp-contract=off", f"-DSGAM_TSDF_ZG={os.environ.get('SGAM_TSDF_ZG', '2')}",
-                 f"-DSGAM_TSDF_LB={os.environ.get('SGAM_TSDF_LB', '8')}"] +
+                 f"-DSGAM_TSDF_LB={os.environ.get('SGAM_TSDF_LB', '8')}",
+                 f"-DSGAM_TSDF_TOUCH_ABLATE={os.environ.get('SGAM_TSDF_TOUCH_ABLATE', '0')}"] +
                 (["-DSGAM_TSDF_DEBUG_STEPS"] if os.environ.get("SGAM_TSDF_DEBUG_STEPS") else []),
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]

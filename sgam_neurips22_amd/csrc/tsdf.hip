@@ -32,6 +32,9 @@
 #ifndef SGAM_TSDF_ZG
 #define SGAM_TSDF_ZG 2        // voxels of a column fetched per group, one group ahead (integrate kernel)
 #endif
+#ifndef SGAM_TSDF_TOUCH_ABLATE
+#define SGAM_TSDF_TOUCH_ABLATE 0
+#endif
 #ifndef SGAM_TSDF_LB
 #define SGAM_TSDF_LB 8        // minimum waves per SIMD the integrate kernel is compiled for (register budget)
 #endif
@@ -76,7 +79,7 @@ struct SrcSet {
 // pass 1 (blockIdx.y = source): open the units around the back-projected depth samples.  A unit's stamp word is
 // (step_id << 8) | mask of the sources of this step that opened it; the lane that moves the word to this step's tag appends the
 // unit ONCE to the step's brick list (the union over the sources) and allocates its brick if it never had one.
-__global__ void tsdf_touch_kernel(const SrcSet S, int H, int W, float fx, float fy, float cx, float cy,
+__global__ __launch_bounds__(256) void tsdf_touch_kernel(const SrcSet S, int H, int W, float fx, float fy, float cx, float cy,
                                   TsdfGrid g, float depth_trunc, int stride,
                                   int *__restrict__ table, int *__restrict__ stamp, int step_id, int *__restrict__ counters,
                                   int max_bricks, int *__restrict__ list, int max_list) {
@@ -107,6 +110,10 @@ __global__ void tsdf_touch_kernel(const SrcSet S, int H, int W, float fx, float 
         lo[r] = (int)floorf(__fdiv_rn(__fsub_rn(p[r], g.trunc), g.unit_len));
         hi[r] = (int)floorf(__fdiv_rn(__fadd_rn(p[r], g.trunc), g.unit_len));
     }
+#if SGAM_TSDF_TOUCH_ABLATE == 1
+    if (lo[0] == 12345678) counters[3 * CS] = hi[0];      // timing experiment: everything below removed
+    return;
+#endif
     const int tag = step_id << 8, bit = 1 << k;
     const unsigned long long lanes_below = (1ull << (threadIdx.x & 63)) - 1ull;
     // The units are visited in lock step by the wavefront (trip counts padded to the wavefront's maximum) so that the three
@@ -123,8 +130,17 @@ __global__ void tsdf_touch_kernel(const SrcSet S, int H, int W, float fx, float 
     int max_trips = trips;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) max_trips = max(max_trips, __shfl_xor(max_trips, o, 64));
+    // ... and by the WORKGROUP: its four wavefronts' requests for list slots / bricks are joined through LDS and thread 0 takes
+    // them from the two counters with one atomic each (the list counter is ONE word: per-wavefront requests — 7 000 of them on
+    // the noise scene — were 15 of the kernel's 20 us)
+    __shared__ int s_trips[4], s_cnt[2][2][4], s_base[2][2];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) s_trips[wave] = max_trips;
+    __syncthreads();
+    max_trips = max(max(s_trips[0], s_trips[1]), max(s_trips[2], s_trips[3]));
     int n_outside = 0;
     for (int it = 0; it < max_trips; ++it) {
+        const int pb = it & 1;                            // LDS slots alternate: a fast wavefront's next visit does not overwrite this one's
         const bool act = it < trips;
         const int ux = lo[0] + it % nx, uy = lo[1] + (it / nx) % ny, uz = lo[2] + it / (nx * ny);
         const int64_t s = act ? unit_slot(g, ux, uy, uz) : -1;
@@ -156,33 +172,43 @@ __global__ void tsdf_touch_kernel(const SrcSet S, int H, int W, float fx, float 
             atomicOr(&stamp[s], bit);
             first = (prev & ~0xff) != tag;
         }
+#if SGAM_TSDF_TOUCH_ABLATE == 2
+        first = false;                                     // timing experiment: stamps only, no list / allocation
+#endif
         const bool need = first && brick < 0;
-        const unsigned long long m_need = __builtin_amdgcn_ballot_w64(need);
-        if (m_need) {
-            int base = 0;
-            const int l0 = __builtin_ctzll(m_need);
-            if ((threadIdx.x & 63) == l0) base = atomicAdd(&counters[0 * CS], __builtin_popcountll(m_need));
-            base = __shfl(base, l0, 64);
-            if (need) {
-                brick = base + __builtin_popcountll(m_need & lanes_below);
-                if (brick >= max_bricks) {
-                    atomicAdd(&counters[3 * CS], 1);          // pool exhausted (diagnostic); unit stays closed
-                    first = false;
-                } else {
-                    table[s] = brick;
-                }
+        const unsigned long long m_need = __builtin_amdgcn_ballot_w64(need), m_first = __builtin_amdgcn_ballot_w64(first);
+        if (lane == 0) {
+            s_cnt[pb][0][wave] = __builtin_popcountll(m_need);
+            s_cnt[pb][1][wave] = __builtin_popcountll(m_first);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int n_need = (s_cnt[pb][0][0] + s_cnt[pb][0][1]) + (s_cnt[pb][0][2] + s_cnt[pb][0][3]);
+            const int n_first = (s_cnt[pb][1][0] + s_cnt[pb][1][1]) + (s_cnt[pb][1][2] + s_cnt[pb][1][3]);
+            const int b0 = n_need ? atomicAdd(&counters[0 * CS], n_need) : 0;
+            const int b1 = n_first ? atomicAdd(&counters[1 * CS], n_first) : 0;
+            s_base[pb][0] = b0;
+            s_base[pb][1] = b1;
+        }
+        __syncthreads();
+        int off_need = s_base[pb][0], off_list = s_base[pb][1];
+        for (int w = 0; w < wave; ++w) {
+            off_need += s_cnt[pb][0][w];
+            off_list += s_cnt[pb][1][w];
+        }
+        bool listed = first;
+        if (need) {
+            brick = off_need + __builtin_popcountll(m_need & lanes_below);
+            if (brick >= max_bricks) {
+                atomicAdd(&counters[3 * CS], 1);          // pool exhausted (diagnostic); unit stays closed, and out of the list
+                listed = false;
+            } else {
+                table[s] = brick;
             }
         }
-        const unsigned long long m_list = __builtin_amdgcn_ballot_w64(first);
-        if (m_list) {
-            int base = 0;
-            const int l1 = __builtin_ctzll(m_list);
-            if ((threadIdx.x & 63) == l1) base = atomicAdd(&counters[1 * CS], __builtin_popcountll(m_list));
-            base = __shfl(base, l1, 64);
-            if (first) {
-                const int li = base + __builtin_popcountll(m_list & lanes_below);
-                if (li < max_list) list[li] = (int)s;
-            }
+        if (first) {                                      // (a slot is reserved for every first toucher; a unit that got no brick leaves
+            const int li = off_list + __builtin_popcountll(m_first & lanes_below);      //  its slot pointing at a closed unit: skipped below)
+            if (li < max_list) list[li] = listed ? (int)s : -1;
         }
     }
     if (n_outside && (threadIdx.x & 63) == 0) atomicAdd(&counters[2 * CS], n_outside);      // samples outside the scene box (diagnostic)
@@ -346,6 +372,7 @@ __global__ __launch_bounds__(256, SGAM_TSDF_LB) void tsdf_integrate_kernel(const
     const int x = threadIdx.x & 15, y = threadIdx.x >> 4;
     for (int li = blockIdx.x; li < n; li += gridDim.x) {
         const int s = list[li];
+        if (s < 0) continue;                              // (a unit the exhausted brick pool could not open)
         const int brick = table[s] & BRICK_MASK;
         const int mask = stamp[s] & ((1 << NS) - 1) & ((1 << S.n) - 1);
         const int ux = s % g.dims[0] + g.base[0];
