@@ -231,12 +231,15 @@ class VQModel(nn.Module):
             zqs, idx = self.quantize.sample_nhwc(pre, topk, sample_number, extrapolation_mask)
             zs = [zqs[:, i].contiguous() for i in range(sample_number)]   # dense NHWC per sample (batch stride!)
             decs = [ops.nhwc_to_nchw(self._decode_nhwc(z))[None] for z in zs]
-            quants = torch.stack([ops.nhwc_to_nchw(z) for z in zs], 1) if want_q else None
+            # (B,S,D,h,w) as the channels-first VIEW of the NHWC samples: same shape and values as the reference's stacked
+            # tensor, no transpose / stack launches in the frame (the scene loop only files it in the step's result)
+            quants = zqs.permute(0, 1, 4, 2, 3) if want_q else None
         res = [decs, diff]
         if get_codebook_count:
             res.append(idx)
         if get_pre_quantized_feature:
-            res.append(ops.nhwc_to_nchw(pre))
+            # inference (the scene loop): the channels-first view of the NHWC latent; a training caller gets its own tensor
+            res.append(pre.permute(0, 3, 1, 2) if not torch.is_grad_enabled() else ops.nhwc_to_nchw(pre))
         if get_quantized_feature:
             res.append(quants)
         return res

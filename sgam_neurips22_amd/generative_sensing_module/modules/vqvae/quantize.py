@@ -103,6 +103,11 @@ class VectorQuantizer2(nn.Module):
             # softmax over one candidate is 1.0 and multinomial can only return slot 0: every token gets its
             # arg-min whatever the mask says, so nothing has to leave the GPU (the reference's 256 CPU draws
             # per frame change no output; set consume_host_rng=True to also advance the CPU RNG like it does).
+            if sample_number == 1:
+                # one sample per token: the arg-min launch writes the chosen codebook row itself (no straight-through
+                # arithmetic: get_multiple_codewords returns the embedding, :381) — no gather launch
+                idx1, zq, _ = ops.vq_nearest(z_nhwc.reshape(B * T, D), cb, cb_sq, straight_through=False, want_zq=True)
+                return zq.view(B, 1, h, w, D), idx1.view(B, 1, h, w)
             idx1, _, _ = ops.vq_nearest(z_nhwc.reshape(B * T, D), cb, cb_sq, want_zq=False)
             sampled = idx1.view(B, T, 1).expand(-1, -1, sample_number)
         else:
